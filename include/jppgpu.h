@@ -1,0 +1,177 @@
+/*
+ * jppgpu -- C ABI of the MI355X-native Juman++ analysis hot path.
+ *
+ * This is the drop-in boundary: what the reference's host code (C++14) binds
+ * instead of running Analyzer::analyze on the CPU.  Plain C types only; the
+ * caller owns inputs, the library owns results until jppgpu_result_release.
+ *
+ * Reference interfaces replaced (paths relative to the ku-nlp/jumanpp tree):
+ *   Analyzer::initialize(CoreHolder*, AnalyzerConfig, ScoringConfig, ScorerDef*)
+ *       src/core/analysis/analyzer.cc:16-43, analyzer_impl.cc:27-89   -> jppgpu_ctx_create
+ *   Analyzer::analyze(StringPiece, ScorePlugin*)
+ *       src/core/analysis/analyzer.h:51, analyzer.cc:45-53             -> jppgpu_analyze_batch*
+ *   Lattice / LatticeBoundary / ConnectionBeamElement read by formatters
+ *       src/core/analysis/lattice_types.h, lattice_config.h:37-79      -> jppgpu_result views
+ *   ExtraNodesContext::node(EntryPtr) (UNK nodes)
+ *       src/core/analysis/extra_nodes.h:79-87                           -> jppgpu_node.unk_*
+ *   Status kinds returned by analyze()
+ *       analysis_input.cc:12-33, characters.cc:267-269, analyzer_impl.cc:133-135 -> status codes
+ */
+#ifndef JPPGPU_H
+#define JPPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes of API calls (mirror of jumanpp::StatusCode, src/util/status.hpp) */
+enum {
+  JPPGPU_OK = 0,
+  JPPGPU_INVALID_PARAMETER = 1,
+  JPPGPU_INVALID_STATE = 2,
+  JPPGPU_NOT_IMPLEMENTED = 3,
+  JPPGPU_NO_DEVICE = 4,
+  JPPGPU_OUT_OF_MEMORY = 5
+};
+
+/* per-sentence status (jppgpu_result.status[i]) */
+enum {
+  JPPGPU_SENT_OK = 0,
+  JPPGPU_SENT_TOO_LONG = 1,   /* input > max_input_bytes: InvalidParameter in the reference */
+  JPPGPU_SENT_BAD_UTF8 = 2,   /* InvalidParameter */
+  JPPGPU_SENT_NO_LATTICE = 3, /* InvalidState "could not build lattice" */
+  JPPGPU_SENT_CAPACITY = 4    /* a device-side staging capacity was exceeded (see DESIGN.md limits) */
+};
+
+typedef struct jppgpu_ctx jppgpu_ctx;
+typedef struct jppgpu_result jppgpu_result;
+
+/* One UNK maker (spec::UnkProcessorDescriptor, src/core/spec/spec_types.h) */
+typedef struct {
+  int32_t type;           /* spec::UnkMakerType: 1 single, 2 chunking, 3 onomatopoeia, 4 numeric, 5 normalize */
+  int32_t char_class;     /* chars::CharacterClass mask */
+  int32_t pattern_ptr;    /* EntryPtr raw of the template dictionary entry */
+  int32_t priority;       /* 0: stage 1, 1: stage 2 (lowPriority) */
+  int32_t placeholder;    /* target placeholder or -1 */
+  uint32_t replace_mask;  /* bit f: entry feature f receives the surface hash (outputTo) */
+} jppgpu_unk_maker;
+
+/* Model blobs, borrowed for the duration of jppgpu_ctx_create (copied to HBM).
+ * They are exactly the blocks of the reference's .jppmdl parts
+ * (src/core/dic/dic_builder.cc:99-107, src/core/analysis/perceptron.cc:64-123). */
+typedef struct {
+  const void* trie;            /* dictionary part data[1]: darts-clone units (u32[]) */
+  size_t trie_bytes;
+  const void* entry_ptrs;      /* data[2]: varint entry-pointer lists */
+  size_t entry_ptrs_bytes;
+  const void* entry_data;      /* data[3]: varint entry rows */
+  size_t entry_data_bytes;
+  const float* weights;        /* perceptron part data[1]: float[2^weight_exponent] */
+  uint32_t weight_exponent;
+  int32_t num_features;        /* spec.features.numDicFeatures */
+  int32_t num_placeholders;    /* spec.features.numPlaceholders */
+  const jppgpu_unk_maker* unk_makers; /* spec.unkCreators, in spec order */
+  int32_t num_unk_makers;
+  const void* feature_spec;    /* flattened FeaturesSpec descriptors; must equal the built-in jumandic tables */
+  size_t feature_spec_bytes;
+} jppgpu_model;
+
+/* AnalyzerConfig + ScoringConfig subset (src/core/analysis/analyzer.h:15-27,
+ * defaults of the CLI: src/jumandic/shared/jumanpp_args.h:50-54) */
+typedef struct {
+  int32_t beam;             /* 5 */
+  int32_t global_beam;      /* 6 */
+  int32_t right_check;      /* 1 */
+  int32_t right_beam;       /* 5 */
+  int32_t max_input_bytes;  /* 4096 */
+  int32_t device;           /* HIP device ordinal */
+} jppgpu_config;
+
+typedef struct {
+  int32_t entry_ptr;   /* EntryPtr raw: >=0 dictionary, BOS/EOS specials, otherwise ~(unk ordinal) */
+  uint16_t start;      /* codepoint span */
+  uint16_t end;
+} jppgpu_node;
+
+typedef struct {
+  int32_t template_ptr; /* UNK: template EntryPtr raw; 0 for dictionary nodes */
+  int32_t content_hash; /* UNK: surface hash (negative) */
+  uint16_t placeholder[2];
+  uint16_t maker;
+  uint16_t pad;
+} jppgpu_unk;
+
+typedef struct {
+  uint16_t left;        /* index into the ends list of the node's boundary */
+  uint16_t beam;        /* slot in the previous node's beam */
+  float total;
+  uint32_t prev_node;   /* sentence-local node id of the previous node, 0xffffffff for BOS */
+  uint32_t pad;
+} jppgpu_beam_slot;     /* fake slot: left == beam == 0xffff */
+
+/* Host-side view of one analysed batch.  Index spaces:
+ *   node k of sentence i lives at node_base[i] + k   (0,1 = BOS, last = EOS)
+ *   boundary b of sentence i lives at bnd_base[i] + b
+ * Arrays marked (debug) are only filled when the batch was fetched with full=1. */
+typedef struct {
+  uint32_t n_sentences;
+  const int32_t* status;         /* [n] */
+  const uint32_t* n_codepoints;  /* [n] */
+  const uint32_t* n_nodes;       /* [n] */
+  const uint64_t* node_base;     /* [n] */
+  const uint64_t* bnd_base;      /* [n] */
+  uint64_t total_nodes;
+  uint64_t total_boundaries;
+  int32_t beam, global_beam;
+  /* top-1 path: node ids from EOS back to the first morpheme, path_len[i] entries at node_base[i] */
+  const uint32_t* path_len;
+  const uint32_t* path_nodes;
+  const jppgpu_node* nodes;          /* [total_nodes] */
+  const jppgpu_unk* unk;             /* [total_nodes] */
+  /* lattice detail (full=1) */
+  const uint32_t* bnd_first;         /* [total_boundaries] first node starting at boundary */
+  const uint32_t* bnd_count;         /* R_b */
+  const uint32_t* end_first;         /* offset into end_nodes (relative to node_base) */
+  const uint32_t* end_count;         /* L_b */
+  const uint32_t* end_nodes;         /* [total_nodes] */
+  const int32_t* entry_rows;         /* [total_nodes][num_features] */
+  const uint64_t* patterns;          /* [total_nodes][14] */
+  const float* t0_scores;            /* [total_nodes] */
+  const jppgpu_beam_slot* beams;     /* [total_nodes][beam] */
+  const float* cells;                /* [total_nodes][global_beam] */
+  const uint8_t* kept;               /* [total_nodes] */
+  const uint32_t* gbeam_count;       /* [total_boundaries] */
+  const uint32_t* gbeam;             /* [total_boundaries][global_beam][2]: (left | beam<<16), score bits */
+} jppgpu_result_view;
+
+int jppgpu_ctx_create(const jppgpu_model* model, const jppgpu_config* config, jppgpu_ctx** out);
+void jppgpu_ctx_destroy(jppgpu_ctx* ctx);
+const char* jppgpu_last_error(void);
+
+/* Analyse n sentences given as one UTF-8 buffer + n+1 byte offsets (host memory). */
+int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                         jppgpu_result** out);
+/* Same, but text/offsets are already resident in device memory (HBM) and the
+ * work is enqueued on `stream` (a hipStream_t, may be NULL).  total_bytes =
+ * offsets[n].  Results stay on the device until fetched. */
+int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
+                                uint32_t total_bytes, void* stream, jppgpu_result** out);
+/* Copy results to the host.  full=0: status, node table, UNK table, top-1 paths.
+ * full=1: additionally the whole lattice (patterns, T0, beams, cells, global beams). */
+int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_view* view);
+/* Per-batch statistics without copying the lattice: total nodes, sum of path lengths. */
+int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path);
+void jppgpu_result_release(jppgpu_result* res);
+
+/* device timing of the last batch's kernels in milliseconds (HIP events on the launch stream):
+ * [0] decode [1] seeds [2] layout [3] t0 [4] sweep [5] path, [6] whole pipeline */
+int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* JPPGPU_H */

@@ -1,0 +1,106 @@
+// Runtime layer: the product build is HIP/gfx950 only.  The JPP_EMU branch
+// exists solely so that tests/emu can run the same kernel sources on a CPU
+// fiber emulator (tests/emu/hip_emu.h); it is never part of libjppgpu.so.
+#ifndef JPP_RT_H
+#define JPP_RT_H
+
+#include <cstddef>
+#include <cstdint>
+
+#if defined(JPP_EMU)
+#include "hip_emu.h"
+typedef void* jpp_stream_t;
+#define JPP_LAUNCH(kernel, grid, block, stream, ...) \
+  hip_emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t jpp_stream_t;
+#define JPP_LAUNCH(kernel, grid, block, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+namespace jpp {
+
+// ---- wavefront (64 lanes) helpers -------------------------------------------
+__device__ __forceinline__ int lane_id() {
+#if defined(JPP_EMU)
+  return hip_emu::lane();
+#else
+  return (int)(threadIdx.x & 63);
+#endif
+}
+
+__device__ __forceinline__ u64 wave_ballot(bool p) {
+#if defined(JPP_EMU)
+  return hip_emu::ballot(p);
+#else
+  return __ballot(p);
+#endif
+}
+
+__device__ __forceinline__ u32 wave_shfl_u32(u32 v, int src) {
+#if defined(JPP_EMU)
+  return (u32)hip_emu::shfl_u64(v, src);
+#else
+  return (u32)__shfl((int)v, src, 64);
+#endif
+}
+
+__device__ __forceinline__ float wave_shfl_f32(float v, int src) {
+  u32 x;
+  __builtin_memcpy(&x, &v, 4);
+  x = wave_shfl_u32(x, src);
+  float r;
+  __builtin_memcpy(&r, &x, 4);
+  return r;
+}
+
+__device__ __forceinline__ u64 wave_shfl_u64(u64 v, int src) {
+#if defined(JPP_EMU)
+  return hip_emu::shfl_u64(v, src);
+#else
+  u32 lo = (u32)__shfl((int)(u32)v, src, 64);
+  u32 hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
+  return ((u64)hi << 32) | lo;
+#endif
+}
+
+// max over the whole wave (all 64 lanes must call)
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    u64 o = wave_shfl_u64(v, lane_id() ^ off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v += wave_shfl_u32(v, lane_id() ^ off);
+  }
+  return v;
+}
+
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    u32 o = wave_shfl_u32(v, lane_id() ^ off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int popc64(u64 v) { return __builtin_popcountll(v); }
+
+}  // namespace jpp
+
+#endif  // JPP_RT_H

@@ -1,0 +1,156 @@
+// Step-for-step restatement of libstdc++'s std::nth_element (GCC 11
+// bits/stl_algo.h __introselect / __unguarded_partition_pivot /
+// __move_median_to_first / __insertion_sort / __heap_select, and
+// bits/stl_heap.h __adjust_heap / __push_heap) on an index array.
+//
+// Why: the reference picks the right nodes that receive full global-beam
+// scoring with std::nth_element over float prescores
+// (ScoreProcessor::makeT0cutoffBeam, src/core/analysis/score_processor.cc:471-495).
+// With tied scores (aliased dictionary entries, zero weights) the chosen set
+// depends on the exact sequence of comparisons and swaps, so bit-identical
+// lattices need the same algorithm, not just "a" selection.  It runs on one
+// lane over LDS-resident arrays (R <= 256 elements).
+#ifndef JPP_SELECT_H
+#define JPP_SELECT_H
+
+#include "jpp_rt.h"
+
+namespace jpp {
+
+struct ScoreGreater {
+  const float* sc;
+  __device__ __forceinline__ bool operator()(u16 a, u16 b) const { return sc[a] > sc[b]; }
+};
+
+template <typename T>
+__device__ __forceinline__ void sel_swap(T* a, T* b) {
+  T t = *a;
+  *a = *b;
+  *b = t;
+}
+
+template <typename T, typename C>
+__device__ inline void sel_insertion_sort(T* first, T* last, C comp) {
+  if (first == last) return;
+  for (T* i = first + 1; i != last; ++i) {
+    if (comp(*i, *first)) {
+      T val = *i;
+      for (T* p = i; p != first; --p) *p = *(p - 1);
+      *first = val;
+    } else {
+      T val = *i;
+      T* lastp = i;
+      T* next = i - 1;
+      while (comp(val, *next)) {
+        *lastp = *next;
+        lastp = next;
+        --next;
+      }
+      *lastp = val;
+    }
+  }
+}
+
+template <typename T, typename C>
+__device__ inline void sel_move_median_to_first(T* result, T* a, T* b, T* c, C comp) {
+  if (comp(*a, *b)) {
+    if (comp(*b, *c)) sel_swap(result, b);
+    else if (comp(*a, *c)) sel_swap(result, c);
+    else sel_swap(result, a);
+  } else if (comp(*a, *c)) {
+    sel_swap(result, a);
+  } else if (comp(*b, *c)) {
+    sel_swap(result, c);
+  } else {
+    sel_swap(result, b);
+  }
+}
+
+template <typename T, typename C>
+__device__ inline T* sel_unguarded_partition(T* first, T* last, T* pivot, C comp) {
+  for (;;) {
+    while (comp(*first, *pivot)) ++first;
+    --last;
+    while (comp(*pivot, *last)) --last;
+    if (!(first < last)) return first;
+    sel_swap(first, last);
+    ++first;
+  }
+}
+
+template <typename T, typename C>
+__device__ inline void sel_push_heap(T* first, long hole, long top, T value, C comp) {
+  long parent = (hole - 1) / 2;
+  while (hole > top && comp(first[parent], value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+
+template <typename T, typename C>
+__device__ inline void sel_adjust_heap(T* first, long hole, long len, T value, C comp) {
+  const long top = hole;
+  long second = hole;
+  while (second < (len - 1) / 2) {
+    second = 2 * (second + 1);
+    if (comp(first[second], first[second - 1])) second--;
+    first[hole] = first[second];
+    hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) {
+    second = 2 * (second + 1);
+    first[hole] = first[second - 1];
+    hole = second - 1;
+  }
+  sel_push_heap(first, hole, top, value, comp);
+}
+
+template <typename T, typename C>
+__device__ inline void sel_heap_select(T* first, T* middle, T* last, C comp) {
+  long len = middle - first;
+  if (len >= 2) {
+    long parent = (len - 2) / 2;
+    for (;;) {
+      T value = first[parent];
+      sel_adjust_heap(first, parent, len, value, comp);
+      if (parent == 0) break;
+      parent--;
+    }
+  }
+  for (T* i = middle; i < last; ++i) {
+    if (comp(*i, *first)) {
+      T value = *i;
+      *i = *first;
+      sel_adjust_heap(first, 0, len, value, comp);
+    }
+  }
+}
+
+template <typename C>
+__device__ inline void nth_element_u16(u16* first, u16* nth, u16* last, C comp) {
+  if (first == last || nth == last) return;
+  long n = last - first;
+  long lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  long depth = lg * 2;
+  while (last - first > 3) {
+    if (depth == 0) {
+      sel_heap_select(first, nth + 1, last, comp);
+      sel_swap(first, nth);
+      return;
+    }
+    --depth;
+    u16* mid = first + (last - first) / 2;
+    sel_move_median_to_first(first, first + 1, mid, last - 1, comp);
+    u16* cut = sel_unguarded_partition(first + 1, last, first, comp);
+    if (cut <= nth) first = cut;
+    else last = cut;
+  }
+  sel_insertion_sort(first, last, comp);
+}
+
+}  // namespace jpp
+
+#endif  // JPP_SELECT_H

@@ -1,0 +1,167 @@
+// HBM-resident data layout of one analysis batch (see DESIGN.md "Data layout").
+#ifndef JPP_TYPES_H
+#define JPP_TYPES_H
+
+#include "jpp_rt.h"
+
+namespace jpp {
+
+constexpr int kMaxUnkMakers = 16;
+constexpr int kMaxDicFeatures = 16;
+constexpr int kPat = 14;          // stored patterns per node (jumandic spec)
+constexpr int kMaxGbeam = 16;     // exact stable-rank beam forming holds for <= 16 (std::sort == insertion sort)
+constexpr int kMaxBeam = 16;
+constexpr int kMaxRight = 256;    // right nodes per boundary staged in LDS by the sweep kernel
+constexpr int kMaxNormStates = 48;
+constexpr int kMaxNormResults = 48;
+
+// entry pointers (reference src/core/core_types.h:44-58)
+constexpr i32 kEptrBOS = (i32)0x80000000;
+constexpr i32 kEptrEOS = (i32)0x80000002;
+
+// per-sentence status codes (mirror of the reference Status kinds that
+// Analyzer::analyze can return, src/core/analysis/analysis_input.cc:12-33,
+// src/util/characters.cc:267-269, src/core/analysis/analyzer_impl.cc:133-135)
+enum SentStatus : i32 {
+  ST_OK = 0,
+  ST_TOO_LONG = 1,        // > maxInputBytes (InvalidParameter)
+  ST_BAD_UTF8 = 2,        // InvalidParameter
+  ST_NO_LATTICE = 3,      // InvalidState "could not build lattice"
+  ST_CAPACITY = 4,        // an internal device-side capacity was exceeded (not a reference status)
+};
+
+// UNK maker kinds: spec::UnkMakerType (reference src/core/spec/spec_types.h)
+enum UnkType : i32 { UNK_SINGLE = 1, UNK_CHUNKING = 2, UNK_ONOMATOPOEIA = 3, UNK_NUMERIC = 4, UNK_NORMALIZE = 5 };
+
+struct UnkMaker {
+  i32 type;
+  i32 char_class;
+  i32 pattern_ptr;      // EntryPtr raw of the template entry
+  i32 priority;         // 0 = stage 1, 1 = stage 2 (only if the lattice is disconnected)
+  i32 placeholder;      // target placeholder index or -1
+  u32 replace_mask;     // bit f set: entry feature f is replaced by the surface hash
+  u32 pattern_mask;     // features compared by dicPatternMatches (numeric maker)
+  i32 tmpl[kMaxDicFeatures];  // decoded template entry row
+};
+
+struct DevModel {
+  const u32* trie;
+  const u8* entry_ptrs;
+  const u8* entry_data;
+  const float* weights;
+  u32 trie_units;
+  u32 entry_ptrs_bytes;
+  u32 entry_data_bytes;
+  u32 wmask;
+  i32 num_features;
+  i32 n_unk;
+  i32 n_stage1;          // makers[0..n_stage1) are stage 1 in spec order, the rest stage 2
+  i32 norm_maker;        // index of the Normalize maker or -1
+  UnkMaker makers[kMaxUnkMakers];
+};
+
+struct Config {
+  i32 beam;
+  i32 gbeam;
+  i32 rcheck;
+  i32 rbeam;
+  i32 max_input_bytes;
+};
+
+// One lattice node (reference NodeInfo, src/core/core_types.h:71-90)
+struct NodeInfo {
+  i32 eptr;     // dictionary EntryPtr raw value; for UNK nodes ~(per-sentence unk index)
+  u16 start;
+  u16 end;
+};
+
+// UNK side data (reference UnkNodeHeader + placeholders, src/core/analysis/extra_nodes.h:25-47)
+struct NodeAux {
+  i32 tmpl;     // template EntryPtr raw (normalized nodes: the dictionary entry)
+  i32 hash;     // content hash (negative) or 0 for dictionary nodes
+  u16 ph0;      // placeholder 0 (jumandic: nonstdSurf = charlattice Modifiers bits)
+  u16 ph1;      // placeholder 1 (jumandic: notPrefix 0/1)
+  u16 maker;    // index into DevModel::makers
+  u16 pad;
+};
+
+// One beam slot: the index form of ConnectionBeamElement
+// (src/core/analysis/lattice_config.h:37-79).  `prev_node` (sentence-local
+// node id of the left node) replaces the host pointer `previous`.
+struct BeamSlot {
+  u16 left;       // index into ends[boundary]
+  u16 beam;       // slot index inside the left node's beam
+  float total;
+  u32 prev_node;
+  u32 pad;
+};
+constexpr u16 kFake16 = 0xffff;
+
+struct GbeamEntry {
+  u16 left;
+  u16 beam;
+  float score;
+};
+
+// charlattice extra nodes per input position (reference CharLattice::Parse,
+// src/core/analysis/charlattice.cc:197-264)
+struct ClNodes {
+  u32 cp[3];
+  u16 type[3];
+  u16 n;
+};
+
+// All device arrays of one batch.  Index spaces:
+//   g   = byte_off[s] + s + i      codepoint i of sentence s   (arrays sized total_bytes + n)
+//   bb  = byte_off[s] + 4*s + b    boundary b of sentence s    (arrays sized total_bytes + 4*n)
+//   gn  = node_base[s] + k         node k of sentence s        (arrays sized total_nodes)
+// sentence-local node ids: 0 = BOS (boundary 0), 1 = BOS (boundary 1),
+// 2.. = lattice nodes ordered by (start, seed order), last = EOS.
+struct Batch {
+  // input
+  const u8* text;
+  const u32* byte_off;     // [n+1]
+  u32 n_sent;
+  u32 total_bytes;
+  // decode
+  u32* cp_code;
+  i32* cp_class;
+  u16* cp_boff;            // byte offset of codepoint i inside the sentence; entry [ncp] = byte length
+  ClNodes* cl_nodes;
+  u32* sent_ncp;
+  i32* sent_status;
+  u32* sent_flags;         // bit0: charlattice applicable, bit1: stage-2 makers active
+  // seeds
+  u16* pos_cnt1;           // dictionary + stage-1 maker nodes (w/o normalize) starting at position g
+  u16* pos_cntN;           // normalize-maker nodes starting at position g
+  u16* pos_cnt2;           // stage-2 maker nodes starting at position g
+  u8* reach;               // [g] connectivity scratch
+  u32* sent_nodes;         // nodes of sentence incl. 2 BOS + EOS (after stage decision)
+  u32* sent_nodes2;        // node count with stage 2 (scratch for the relocation scan)
+  u64* node_base;          // [n+1] exclusive scan of sent_nodes
+  u64* node_base2;         // [n+1] relocation offsets of stage-2 sentences
+  // lattice
+  u32* bnd_first;          // [bb] first local node id starting at boundary
+  u32* bnd_cnt;            // [bb] R_b
+  u32* end_first;          // [bb] offset into end_nodes (relative to node_base[s])
+  u32* end_cnt;            // [bb] L_b
+  u32* end_nodes;          // [gn] local node ids
+  NodeInfo* node_info;     // [gn]
+  NodeAux* node_aux;       // [gn]
+  i32* node_entry;         // [gn][8]
+  u64* node_pat;           // [gn][14]
+  float* node_t0;          // [gn]
+  BeamSlot* node_beam;     // [gn][beam]
+  float* node_cells;       // [gn][gbeam]
+  u8* node_kept;           // [gn]
+  GbeamEntry* bnd_gbeam;   // [bb][gbeam]
+  u32* bnd_ngb;            // [bb]
+  // result
+  u32* path_len;           // [n]
+  u32* path_nodes;         // [gn] top-1 path (local node ids, EOS side first), at node_base[s]
+  u64 total_nodes;
+};
+
+}  // namespace jpp
+
+#endif  // JPP_TYPES_H

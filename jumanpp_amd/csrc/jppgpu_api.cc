@@ -1,0 +1,586 @@
+// C-ABI implementation (include/jppgpu.h): model upload, batch pipeline,
+// result views.  Compiled with hipcc for gfx950 into libjppgpu.so.  There is
+// no CPU path: without a HIP device jppgpu_ctx_create fails with
+// JPPGPU_NO_DEVICE.  (tests/emu builds this same file with -DJPP_EMU against a
+// fiber emulator to exercise the kernel sources in CI; that library is test
+// infrastructure and is never loaded by the product.)
+#include "../../include/jppgpu.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jpp_rt.h"
+#include "jpp_types.h"
+#include "k_decode.h"
+#include "k_lattice.h"
+#include "k_seeds.h"
+#include "k_sweep.h"
+#include "k_t0.h"
+
+using namespace jpp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+// ---- thin device-memory layer ------------------------------------------------
+#if defined(JPP_EMU)
+bool rt_ok(int) { return true; }
+void* rt_malloc(size_t n) { return calloc(1, n ? n : 1); }
+void rt_free(void* p) { free(p); }
+void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t) { memcpy(d, h, n); }
+void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
+void rt_sync(jpp_stream_t) {}
+struct Timer {
+  void init() {}
+  void destroy() {}
+  void mark(int, jpp_stream_t) {}
+  void collect(float* ms) {
+    for (int i = 0; i < 8; ++i) ms[i] = 0;
+  }
+};
+#else
+void* rt_malloc(size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n ? n : 1) != hipSuccess) return nullptr;
+  return p;
+}
+void rt_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t s) {
+  (void)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s);
+}
+void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
+  (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
+}
+void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
+struct Timer {
+  hipEvent_t ev[8];
+  bool have = false;
+  void init() {
+    for (auto& e : ev) (void)hipEventCreate(&e);
+    have = true;
+  }
+  void destroy() {
+    if (have)
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    have = false;
+  }
+  void mark(int i, jpp_stream_t s) { (void)hipEventRecord(ev[i], s); }
+  void collect(float* ms) {
+    // ev[0]..ev[6] bracket the six phases
+    for (int i = 0; i < 6; ++i) {
+      ms[i] = 0;
+      (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    }
+    ms[6] = 0;
+    (void)hipEventElapsedTime(&ms[6], ev[0], ev[6]);
+    ms[7] = 0;
+  }
+};
+#endif
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool ensure(size_t bytes) {
+    if (bytes <= cap) return true;
+    rt_free(p);
+    size_t want = bytes + bytes / 4 + 256;
+    p = rt_malloc(want);
+    cap = p ? want : 0;
+    return p != nullptr;
+  }
+  void release() {
+    rt_free(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return static_cast<T*>(p);
+  }
+};
+
+u64 host_varint(const u8* p, size_t& pos) {
+  u64 r = 0;
+  int shift = 0;
+  for (;;) {
+    u32 b = p[pos++];
+    r |= (u64)(b & 0x7f) << shift;
+    if (b < 0x80 || shift >= 63) break;
+    shift += 7;
+  }
+  return r;
+}
+
+}  // namespace
+
+struct jppgpu_result {
+  jppgpu_ctx* ctx = nullptr;
+  Batch B{};
+  u64 generation = 0;
+  bool fetched_basic = false, fetched_full = false;
+  // host copies
+  std::vector<i32> status;
+  std::vector<u32> ncp, nnodes, path_len, path_nodes;
+  std::vector<u64> node_base, bnd_base;
+  std::vector<jppgpu_node> nodes;
+  std::vector<jppgpu_unk> unk;
+  std::vector<u32> bnd_first, bnd_cnt, end_first, end_cnt, end_nodes, ngb, gbeam;
+  std::vector<i32> entry_rows;
+  std::vector<u64> patterns;
+  std::vector<float> t0, cells;
+  std::vector<jppgpu_beam_slot> beams;
+  std::vector<u8> kept;
+  std::vector<u32> byte_off;
+};
+
+struct jppgpu_ctx {
+  Config cfg{};
+  int device = 0;
+  DevModel hmodel{};
+  DevModel* dmodel = nullptr;
+  DevBuf trie, eptrs, edata, weights;
+  // workspace
+  DevBuf text, offs;
+  DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
+  DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
+  DevBuf path_len;
+  DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
+  DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
+      path_nodes;
+  jppgpu_result result;
+  u64 generation = 0;
+  Timer timer;
+  float last_ms[8] = {0};
+  jpp_stream_t last_stream = nullptr;
+  bool timing_pending = false;
+};
+
+static_assert(sizeof(jppgpu_node) == sizeof(NodeInfo), "node layout");
+static_assert(sizeof(jppgpu_unk) == sizeof(NodeAux), "unk layout");
+static_assert(sizeof(jppgpu_beam_slot) == sizeof(BeamSlot), "beam layout");
+
+extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
+
+extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, jppgpu_ctx** out) {
+  if (!m || !c || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  *out = nullptr;
+#if !defined(JPP_EMU)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    return fail(JPPGPU_NO_DEVICE, "jppgpu: no HIP device available (the analysis path has no CPU fallback)");
+  }
+  if (c->device < 0 || c->device >= ndev) return fail(JPPGPU_INVALID_PARAMETER, "bad device ordinal");
+  if (hipSetDevice(c->device) != hipSuccess) return fail(JPPGPU_NO_DEVICE, "hipSetDevice failed");
+#endif
+  // --- configuration checks (AnalyzerImpl::initScorers, analyzer_impl.cc:43-89) ---
+  if (c->beam <= 0) return fail(JPPGPU_INVALID_PARAMETER, "AnalyzerImpl: beam size can not be zero for scoring");
+  if (c->global_beam <= 0)
+    return fail(JPPGPU_NOT_IMPLEMENTED,
+                "jppgpu: the full-beam path (--global-beam 0, computeScoresFull) is not implemented yet");
+  if (c->right_check > 0 && c->right_beam <= 0)
+    return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
+  if (c->right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
+  if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
+    return fail(JPPGPU_NOT_IMPLEMENTED,
+                "jppgpu: beam/global beam > 16 needs the libstdc++ introsort tie order; not implemented yet");
+  if (c->global_beam > c->beam * 4 / 3)
+    return fail(JPPGPU_NOT_IMPLEMENTED,
+                "jppgpu: global beam > beam*4/3 takes the reference's quickselect branch of makeT0Beam; not "
+                "implemented yet");
+  if (m->num_features != spec::kNumDicFeatures || m->num_placeholders != spec::kNumPlaceholders)
+    return fail(JPPGPU_INVALID_PARAMETER, "model does not have the jumandic entry layout");
+  // the reference only accepts static feature code whose spec hash matches
+  // (features_api.cc:38-47); we compare the flattened descriptors themselves.
+  if (m->feature_spec_bytes != spec::kSpecBlobSize ||
+      memcmp(m->feature_spec, spec::kSpecBlob, spec::kSpecBlobSize) != 0)
+    return fail(JPPGPU_INVALID_PARAMETER,
+                "model feature spec differs from the built-in jumandic feature tables "
+                "(regenerate jumandic_spec.inc with tools/gen_spec_tables.py)");
+  if (m->weight_exponent >= 32 || !m->weights) return fail(JPPGPU_INVALID_PARAMETER, "bad perceptron weights");
+  if (m->num_unk_makers > kMaxUnkMakers - 1) return fail(JPPGPU_NOT_IMPLEMENTED, "too many UNK makers");
+  if (m->trie_bytes % 4 != 0 || m->trie_bytes == 0) return fail(JPPGPU_INVALID_PARAMETER, "bad trie blob");
+
+  auto* ctx = new jppgpu_ctx();
+  ctx->device = c->device;
+  ctx->cfg = Config{c->beam, c->global_beam, c->right_check, c->right_beam,
+                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096};
+  if (ctx->cfg.max_input_bytes > 65535) ctx->cfg.max_input_bytes = 65535;
+  DevModel& H = ctx->hmodel;
+  size_t wbytes = (size_t{1} << m->weight_exponent) * sizeof(float);
+  bool ok = ctx->trie.ensure(m->trie_bytes) && ctx->eptrs.ensure(m->entry_ptrs_bytes + 16) &&
+            ctx->edata.ensure(m->entry_data_bytes + 16) && ctx->weights.ensure(wbytes);
+  if (!ok) {
+    jppgpu_ctx_destroy(ctx);
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (model)");
+  }
+  rt_h2d(ctx->trie.p, m->trie, m->trie_bytes, nullptr);
+  rt_h2d(ctx->eptrs.p, m->entry_ptrs, m->entry_ptrs_bytes, nullptr);
+  rt_h2d(ctx->edata.p, m->entry_data, m->entry_data_bytes, nullptr);
+  rt_h2d(ctx->weights.p, m->weights, wbytes, nullptr);
+  H.trie = ctx->trie.as<u32>();
+  H.entry_ptrs = ctx->eptrs.as<u8>();
+  H.entry_data = ctx->edata.as<u8>();
+  H.weights = ctx->weights.as<float>();
+  H.trie_units = (u32)(m->trie_bytes / 4);
+  H.entry_ptrs_bytes = (u32)m->entry_ptrs_bytes;
+  H.entry_data_bytes = (u32)m->entry_data_bytes;
+  H.wmask = (u32)((size_t{1} << m->weight_exponent) - 1);
+  H.num_features = m->num_features;
+  // makers: [stage-1 except normalize][stage-2][normalize]
+  std::vector<UnkMaker> st1, st2, norm;
+  bool seenNorm = false;
+  for (int i = 0; i < m->num_unk_makers; ++i) {
+    const jppgpu_unk_maker& u = m->unk_makers[i];
+    UnkMaker k{};
+    k.type = u.type;
+    k.char_class = u.char_class;
+    k.pattern_ptr = u.pattern_ptr;
+    k.priority = u.priority;
+    k.placeholder = u.placeholder;
+    k.replace_mask = u.replace_mask;
+    k.pattern_mask = ~u.replace_mask & ((1u << m->num_features) - 1);
+    if (u.pattern_ptr < 0 || (size_t)(u.pattern_ptr >> 1) >= m->entry_data_bytes) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_INVALID_PARAMETER, "UNK template pointer outside entry data");
+    }
+    size_t pos = (size_t)(u.pattern_ptr >> 1);
+    for (int f = 0; f < m->num_features; ++f)
+      k.tmpl[f] = (i32)host_varint(static_cast<const u8*>(m->entry_data), pos);
+    if (u.type < UNK_SINGLE || u.type > UNK_NORMALIZE || u.priority < 0 || u.priority > 1) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_NOT_IMPLEMENTED, "unsupported UNK maker type/priority");
+    }
+    if (u.type == UNK_NORMALIZE) {
+      if (u.priority != 0 || seenNorm) {
+        jppgpu_ctx_destroy(ctx);
+        return fail(JPPGPU_NOT_IMPLEMENTED, "normalize maker must be a single stage-1 maker");
+      }
+      seenNorm = true;
+      norm.push_back(k);
+    } else if (u.priority == 0) {
+      if (seenNorm) {
+        jppgpu_ctx_destroy(ctx);
+        return fail(JPPGPU_NOT_IMPLEMENTED, "normalize maker must be the last stage-1 maker");
+      }
+      st1.push_back(k);
+    } else {
+      st2.push_back(k);
+    }
+  }
+  int idx = 0;
+  for (auto& k : st1) H.makers[idx++] = k;
+  H.n_stage1 = idx;
+  for (auto& k : st2) H.makers[idx++] = k;
+  H.n_unk = idx;
+  H.norm_maker = -1;
+  if (!norm.empty()) {
+    H.norm_maker = idx;
+    H.makers[idx++] = norm[0];
+  }
+  ctx->dmodel = static_cast<DevModel*>(rt_malloc(sizeof(DevModel)));
+  if (!ctx->dmodel) {
+    jppgpu_ctx_destroy(ctx);
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (model header)");
+  }
+  rt_h2d(ctx->dmodel, &H, sizeof(DevModel), nullptr);
+  rt_sync(nullptr);
+  ctx->timer.init();
+  *out = ctx;
+  return JPPGPU_OK;
+}
+
+extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
+  if (!ctx) return;
+  DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
+                    &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
+                    &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_cnt2,   &ctx->reach,     &ctx->sent_ncp,
+                    &ctx->sent_status, &ctx->sent_flags, &ctx->sent_nodes, &ctx->sent_nodes2, &ctx->node_base,
+                    &ctx->node_base2, &ctx->path_len,  &ctx->bnd_first,  &ctx->bnd_cnt,   &ctx->end_first,
+                    &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
+                    &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
+                    &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes};
+  for (auto* b : bufs) b->release();
+  rt_free(ctx->dmodel);
+  ctx->timer.destroy();
+  delete ctx;
+}
+
+extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
+                                           uint32_t total_bytes, void* stream_, jppgpu_result** out) {
+  if (!ctx || !out || (!d_utf8 && total_bytes) || !d_offsets) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jpp_stream_t st = static_cast<jpp_stream_t>(stream_);
+  *out = nullptr;
+  const size_t cpN = (size_t)total_bytes + n + 8;
+  const size_t bbN = (size_t)total_bytes + 4 * (size_t)n + 8;
+  const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
+  bool ok = ctx->cp_code.ensure(cpN * 4) && ctx->cp_class.ensure(cpN * 4) && ctx->cp_boff.ensure(cpN * 2) &&
+            ctx->cl_nodes.ensure(cpN * sizeof(ClNodes)) && ctx->pos_cnt1.ensure(cpN * 2) &&
+            ctx->pos_cntN.ensure(cpN * 2) && ctx->pos_cnt2.ensure(cpN * 2) && ctx->reach.ensure(cpN) &&
+            ctx->sent_ncp.ensure((n + 1) * 4) && ctx->sent_status.ensure((n + 1) * 4) &&
+            ctx->sent_flags.ensure((n + 1) * 4) && ctx->sent_nodes.ensure((n + 1) * 4) &&
+            ctx->sent_nodes2.ensure((n + 1) * 4) && ctx->node_base.ensure((n + 2) * 8) &&
+            ctx->node_base2.ensure((n + 2) * 8) && ctx->path_len.ensure((n + 1) * 4) &&
+            ctx->bnd_first.ensure(bbN * 4) && ctx->bnd_cnt.ensure(bbN * 4) && ctx->end_first.ensure(bbN * 4) &&
+            ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) &&
+            ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry));
+  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
+
+  ctx->generation++;
+  jppgpu_result& R = ctx->result;
+  R = jppgpu_result();
+  R.ctx = ctx;
+  R.generation = ctx->generation;
+  Batch& B = R.B;
+  B.text = static_cast<const u8*>(d_utf8);
+  B.byte_off = static_cast<const u32*>(d_offsets);
+  B.n_sent = n;
+  B.total_bytes = total_bytes;
+  B.cp_code = ctx->cp_code.as<u32>();
+  B.cp_class = ctx->cp_class.as<i32>();
+  B.cp_boff = ctx->cp_boff.as<u16>();
+  B.cl_nodes = ctx->cl_nodes.as<ClNodes>();
+  B.pos_cnt1 = ctx->pos_cnt1.as<u16>();
+  B.pos_cntN = ctx->pos_cntN.as<u16>();
+  B.pos_cnt2 = ctx->pos_cnt2.as<u16>();
+  B.reach = ctx->reach.as<u8>();
+  B.sent_ncp = ctx->sent_ncp.as<u32>();
+  B.sent_status = ctx->sent_status.as<i32>();
+  B.sent_flags = ctx->sent_flags.as<u32>();
+  B.sent_nodes = ctx->sent_nodes.as<u32>();
+  B.sent_nodes2 = ctx->sent_nodes2.as<u32>();
+  B.node_base = ctx->node_base.as<u64>();
+  B.node_base2 = ctx->node_base2.as<u64>();
+  B.path_len = ctx->path_len.as<u32>();
+  B.bnd_first = ctx->bnd_first.as<u32>();
+  B.bnd_cnt = ctx->bnd_cnt.as<u32>();
+  B.end_first = ctx->end_first.as<u32>();
+  B.end_cnt = ctx->end_cnt.as<u32>();
+  B.bnd_ngb = ctx->bnd_ngb.as<u32>();
+  B.bnd_gbeam = ctx->bnd_gbeam.as<GbeamEntry>();
+  if (n == 0) {
+    B.total_nodes = 0;
+    *out = &R;
+    return JPPGPU_OK;
+  }
+
+  const u32 sblocks = (n + 255) / 256;
+  Timer& T = ctx->timer;
+  T.mark(0, st);
+  JPP_LAUNCH(k_decode, sblocks, 256, st, B, ctx->cfg);
+  T.mark(1, st);
+  JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_norm<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_layout<1>, sblocks, 256, st, B);
+  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
+  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
+  u64 totals[2] = {0, 0};
+  rt_d2h(&totals[0], B.node_base + n, 8, st);
+  rt_d2h(&totals[1], B.node_base2 + n, 8, st);
+  rt_sync(st);
+  const u64 total1 = totals[0];
+  const u64 seedCap = total1 + totals[1] + 8;
+  if (!(ctx->node_info.ensure(seedCap * sizeof(NodeInfo)) && ctx->node_aux.ensure(seedCap * sizeof(NodeAux))))
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (node table)");
+  B.node_info = ctx->node_info.as<NodeInfo>();
+  B.node_aux = ctx->node_aux.as<NodeAux>();
+  JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_norm<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_connect<1>, sblocks, 256, st, B);
+  // stage 2 for disconnected sentences: relocate them behind the stage-1 region
+  JPP_LAUNCH(k_layout<2>, sblocks, 256, st, B);
+  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
+  JPP_LAUNCH(k_relocate, sblocks, 256, st, B);
+  JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_connect<2>, sblocks, 256, st, B);
+  u64 totalNodes = 0;
+  rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
+  rt_sync(st);
+  B.total_nodes = totalNodes;
+  const u64 cap = totalNodes + 8;
+  ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * spec::kNumDicFeatures * 4) &&
+       ctx->node_pat.ensure(cap * kPat * 8) && ctx->node_t0.ensure(cap * 4) &&
+       ctx->node_beam.ensure(cap * beam * sizeof(BeamSlot)) && ctx->node_cells.ensure(cap * G * 4) &&
+       ctx->node_kept.ensure(cap) && ctx->path_nodes.ensure(cap * 4);
+  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice)");
+  B.end_nodes = ctx->end_nodes.as<u32>();
+  B.node_entry = ctx->node_entry.as<i32>();
+  B.node_pat = ctx->node_pat.as<u64>();
+  B.node_t0 = ctx->node_t0.as<float>();
+  B.node_beam = ctx->node_beam.as<BeamSlot>();
+  B.node_cells = ctx->node_cells.as<float>();
+  B.node_kept = ctx->node_kept.as<u8>();
+  B.path_nodes = ctx->path_nodes.as<u32>();
+  T.mark(2, st);
+  JPP_LAUNCH(k_ends, sblocks, 256, st, B, ctx->cfg);
+  T.mark(3, st);
+  JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  T.mark(4, st);
+  JPP_LAUNCH(k_sweep, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  T.mark(5, st);
+  JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
+  T.mark(6, st);
+  ctx->last_stream = st;
+  ctx->timing_pending = true;
+#if !defined(JPP_EMU)
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(JPPGPU_INVALID_STATE, std::string("kernel launch failed: ") + hipGetErrorString(e));
+#endif
+  *out = &R;
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                    jppgpu_result** out) {
+  if (!ctx || !offsets || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  u32 total = offsets[n];
+  if (!(ctx->text.ensure((size_t)total + 64) && ctx->offs.ensure(((size_t)n + 1) * 4)))
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (input)");
+  if (total) rt_h2d(ctx->text.p, utf8, total, nullptr);
+  rt_h2d(ctx->offs.p, offsets, ((size_t)n + 1) * 4, nullptr);
+  rt_sync(nullptr);
+  return jppgpu_analyze_batch_device(ctx, ctx->text.p, ctx->offs.p, n, total, nullptr, out);
+}
+
+extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
+  if (!ctx || !ms) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (ctx->timing_pending) {
+    rt_sync(ctx->last_stream);
+    ctx->timer.collect(ctx->last_ms);
+    ctx->timing_pending = false;
+  }
+  for (int i = 0; i < n && i < 8; ++i) ms[i] = ctx->last_ms[i];
+  return JPPGPU_OK;
+}
+
+namespace {
+template <typename T>
+void pull(std::vector<T>& v, const void* d, size_t count, jpp_stream_t st) {
+  v.resize(count);
+  if (count) rt_d2h(v.data(), d, count * sizeof(T), st);
+}
+}  // namespace
+
+extern "C" int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path) {
+  if (!res || !res->ctx) return fail(JPPGPU_INVALID_PARAMETER, "null result");
+  if (res->generation != res->ctx->generation) return fail(JPPGPU_INVALID_STATE, "result was invalidated");
+  jpp_stream_t st = res->ctx->last_stream;
+  std::vector<u32> pl;
+  pull(pl, res->B.path_len, res->B.n_sent, st);
+  rt_sync(st);
+  u64 sum = 0;
+  for (auto x : pl) sum += x;
+  if (total_nodes) *total_nodes = res->B.total_nodes;
+  if (total_path) *total_path = sum;
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_view* v) {
+  if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jppgpu_ctx* ctx = res->ctx;
+  if (res->generation != ctx->generation)
+    return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+  jpp_stream_t st = ctx->last_stream;
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  const u64 N = B.total_nodes;
+  const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
+  if (!res->fetched_basic) {
+    pull(res->status, B.sent_status, n, st);
+    pull(res->ncp, B.sent_ncp, n, st);
+    pull(res->nnodes, B.sent_nodes, n, st);
+    pull(res->node_base, B.node_base, n, st);
+    pull(res->path_len, B.path_len, n, st);
+    pull(res->byte_off, B.byte_off, (size_t)n + 1, st);
+    if (n) {
+      // nodes live in [0, seed region end); copy the whole region that holds any sentence
+      pull(res->nodes, B.node_info, N, st);
+      pull(res->unk, B.node_aux, N, st);
+      pull(res->path_nodes, B.path_nodes, N, st);
+    }
+    rt_sync(st);
+    res->bnd_base.resize(n);
+    for (u32 s = 0; s < n; ++s) res->bnd_base[s] = (u64)res->byte_off[s] + 4ull * s;
+    for (u32 s = 0; s < n; ++s) {
+      if (res->status[s] != ST_OK) {
+        res->nnodes[s] = 0;
+        res->path_len[s] = 0;
+      }
+    }
+    res->fetched_basic = true;
+  }
+  const u64 NB = n ? (u64)B.total_bytes + 4ull * n : 0;
+  if (full && !res->fetched_full && n) {
+    pull(res->bnd_first, B.bnd_first, NB, st);
+    pull(res->bnd_cnt, B.bnd_cnt, NB, st);
+    pull(res->end_first, B.end_first, NB, st);
+    pull(res->end_cnt, B.end_cnt, NB, st);
+    pull(res->ngb, B.bnd_ngb, NB, st);
+    pull(res->gbeam, B.bnd_gbeam, NB * G * 2, st);
+    pull(res->end_nodes, B.end_nodes, N, st);
+    pull(res->entry_rows, B.node_entry, N * spec::kNumDicFeatures, st);
+    pull(res->patterns, B.node_pat, N * kPat, st);
+    pull(res->t0, B.node_t0, N, st);
+    pull(res->beams, B.node_beam, N * beam, st);
+    pull(res->cells, B.node_cells, N * G, st);
+    pull(res->kept, B.node_kept, N, st);
+    rt_sync(st);
+    res->fetched_full = true;
+  }
+  memset(v, 0, sizeof(*v));
+  v->n_sentences = n;
+  v->status = res->status.data();
+  v->n_codepoints = res->ncp.data();
+  v->n_nodes = res->nnodes.data();
+  v->node_base = res->node_base.data();
+  v->bnd_base = res->bnd_base.data();
+  v->total_nodes = N;
+  v->total_boundaries = NB;
+  v->beam = beam;
+  v->global_beam = G;
+  v->path_len = res->path_len.data();
+  v->path_nodes = res->path_nodes.data();
+  v->nodes = res->nodes.data();
+  v->unk = res->unk.data();
+  if (res->fetched_full) {
+    v->bnd_first = res->bnd_first.data();
+    v->bnd_count = res->bnd_cnt.data();
+    v->end_first = res->end_first.data();
+    v->end_count = res->end_cnt.data();
+    v->end_nodes = res->end_nodes.data();
+    v->entry_rows = res->entry_rows.data();
+    v->patterns = res->patterns.data();
+    v->t0_scores = res->t0.data();
+    v->beams = res->beams.data();
+    v->cells = res->cells.data();
+    v->kept = res->kept.data();
+    v->gbeam_count = res->ngb.data();
+    v->gbeam = res->gbeam.data();
+  }
+  return JPPGPU_OK;
+}
+
+extern "C" void jppgpu_result_release(jppgpu_result* res) {
+  if (!res) return;
+  // results are views on the context's workspace (same lifetime rule as the
+  // reference: valid until the next analyze on that Analyzer); drop host copies.
+  jppgpu_ctx* ctx = res->ctx;
+  u64 gen = res->generation;
+  Batch B = res->B;
+  *res = jppgpu_result();
+  res->ctx = ctx;
+  res->generation = gen;
+  res->B = B;
+}

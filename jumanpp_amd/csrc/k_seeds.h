@@ -1,0 +1,527 @@
+// Kernel 2: lattice node seeds.  One 64-lane workgroup per sentence, one lane
+// per start codepoint: dictionary double-array walk + entry-pointer list
+// expansion, then the rule-based UNK makers for that start, in the order that
+// the reference's stable sort by start produces:
+//   dictionary seeds (end asc, list order), then every stage-1 maker in spec order.
+// Stage-2 (lowPriority) makers are counted/emitted separately; they only join
+// the lattice of sentences whose stage-1 lattice is disconnected.
+//
+// Reference behaviour reproduced:
+//   DictionaryNodeCreator::spawnNodes  src/core/analysis/dictionary_node_creator.cc:11-38
+//   IndexedEntries::readOnePtr         src/core/dic/dic_entries.h:171-179 (+ field_reader.h:78-85,176-187)
+//   SingleUnkMaker / ChunkingUnkMaker  src/core/analysis/unk_nodes_creator.cc:19-103
+//   UnkNodesContext::makePtr           src/core/analysis/unk_nodes_creator.cc:105-142
+//   UnkNodesContext::dicPatternMatches src/core/analysis/unk_nodes_creator.cc:144-168
+//   NumericUnkMaker                    src/core/analysis/numeric_creator.cc:57-274
+//   OnomatopoeiaUnkMaker               src/core/analysis/onomatopoeia_creator.cc:16-104
+//   NormalizedNodeMaker + CharLattceTraversal
+//                                      src/core/analysis/normalized_node_creator.cc:15-48,
+//                                      src/core/analysis/charlattice.cc:266-415
+#ifndef JPP_K_SEEDS_H
+#define JPP_K_SEEDS_H
+
+#include "jpp_device.h"
+#include "k_decode.h"
+
+namespace jpp {
+
+struct SentView {
+  const u8* txt;     // sentence bytes
+  const u32* cp;     // codepoints
+  const i32* cls;    // classes
+  const u16* boff;   // byte offsets (n+1 entries)
+  u32 n;
+};
+
+struct SeedSink {
+  bool emit;
+  NodeInfo* ni;
+  NodeAux* na;
+  u32 n;
+  __device__ __forceinline__ void dic(i32 eptr, u32 s, u32 e) {
+    if (emit) {
+      ni[n] = NodeInfo{eptr, (u16)s, (u16)e};
+      na[n] = NodeAux{0, 0, 0, 0, 0, 0};
+    }
+    ++n;
+  }
+  __device__ __forceinline__ void unk(i32 tmpl, i32 hash, i32 ph0, i32 ph1, u32 maker, u32 s, u32 e) {
+    if (emit) {
+      ni[n] = NodeInfo{-1, (u16)s, (u16)e};  // final ~index is assigned by k_ends
+      na[n] = NodeAux{tmpl, hash, (u16)ph0, (u16)ph1, (u16)maker, 0};
+    }
+    ++n;
+  }
+};
+
+__device__ __forceinline__ int step_cp(const DevModel& M, const SentView& S, TrieCursor& c, u32 j) {
+  return trie_step(M.trie, c, S.txt + S.boff[j], (int)(S.boff[j + 1] - S.boff[j]));
+}
+
+__device__ __forceinline__ i32 surface_hash(const SentView& S, u32 s, u32 e) {
+  return unk_string_hash(S.txt + S.boff[s], (u32)(S.boff[e] - S.boff[s]));
+}
+
+// makePtr(surface, conf, notPrefix)
+__device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, const SentView& S,
+                                         SeedSink& out, u32 s, u32 e, bool notPrefix) {
+  if (!out.emit) {
+    ++out.n;
+    return;
+  }
+  i32 ph[2] = {0, 0};
+  if (mk.placeholder >= 0 && mk.placeholder < 2) ph[mk.placeholder] = notPrefix ? 1 : 0;
+  out.unk(mk.pattern_ptr, surface_hash(S, s, e), ph[0], ph[1], (u32)(&mk - M.makers), s, e);
+}
+
+// expand the entry-pointer list at trie value `v`
+template <typename F>
+__device__ __forceinline__ void for_each_entry(const DevModel& M, i32 v, F&& f) {
+  u32 pos = (u32)v;
+  i32 cnt = (i32)read_varint(M.entry_ptrs, pos);
+  i32 ptr = 0;
+  for (i32 k = 0; k < cnt; ++k) {
+    ptr += (i32)read_varint(M.entry_ptrs, pos);
+    f(ptr);
+  }
+}
+
+__device__ __forceinline__ void dic_seeds(const DevModel& M, const SentView& S, u32 i, SeedSink& out) {
+  TrieCursor c{0, 0};
+  for (u32 j = i; j < S.n; ++j) {
+    int st = step_cp(M, S, c, j);
+    if (st == TRIE_OK) {
+      u32 e = j + 1;
+      for_each_entry(M, c.value, [&](i32 ptr) { out.dic(ptr, i, e); });
+    } else if (st == TRIE_NONODE) {
+      break;
+    }
+  }
+}
+
+__device__ __forceinline__ void single_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+                                             u32 i, SeedSink& out) {
+  if ((S.cls[i] & mk.char_class) == 0) return;
+  TrieCursor c{0, 0};
+  int st = step_cp(M, S, c, i);
+  if (st == TRIE_OK) return;
+  emit_unk(M, mk, S, out, i, i + 1, st == TRIE_NONODE);
+}
+
+__device__ __forceinline__ void chunking_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+                                               u32 i, SeedSink& out) {
+  if ((S.cls[i] & mk.char_class) == 0) return;
+  TrieCursor c{0, 0};
+  for (u32 j = i; j < S.n; ++j) {
+    if ((S.cls[j] & mk.char_class) == 0) break;
+    int st = step_cp(M, S, c, j);
+    if (st == TRIE_NONODE) {
+      for (; j < S.n; ++j) {
+        if ((S.cls[j] & mk.char_class) == 0) break;
+        emit_unk(M, mk, S, out, i, j + 1, true);
+      }
+      return;
+    } else if (st == TRIE_NOLEAF) {
+      emit_unk(M, mk, S, out, i, j + 1, false);
+    }
+  }
+}
+
+// ---- numeric ---------------------------------------------------------------
+__device__ __forceinline__ bool cls_has(const SentView& S, u32 k, i32 mask) { return (S.cls[k] & mask) != 0; }
+
+__device__ __forceinline__ u32 num_check_suffix(const SentView& S, u32 start, u32 pos) {
+  // suffixPatterns キロ メガ ギガ テラ ミリ
+  const u32 pats[5][2] = {{U'キ', U'ロ'}, {U'メ', U'ガ'}, {U'ギ', U'ガ'}, {U'テ', U'ラ'}, {U'ミ', U'リ'}};
+  pos &= 0xffff;
+  u32 rest = S.n - (start + pos);
+  if (pos > 0) {
+    for (int p = 0; p < 5; ++p) {
+      bool isException = cls_has(S, start + pos - 1, CC_FAMILY_EXCEPTION);
+      if (isException && rest >= 2) {
+        if (S.cp[start + pos] == pats[p][0] && S.cp[start + pos + 1] == pats[p][1]) return 2;
+      }
+    }
+  }
+  return 0;
+}
+
+__device__ __forceinline__ u32 num_check_prefix(const SentView& S, u32 start, u32 pos) {
+  const u32 pats[3] = {U'数', U'何', U'幾'};
+  for (int p = 0; p < 3; ++p) {
+    u32 suffixLength = num_check_suffix(S, start, pos + 1) & 0xffff;
+    if (start + pos + 1 < S.n && (cls_has(S, start + pos + 1, CC_FIGURE_DIGIT) || suffixLength > 0)) {
+      if (S.cp[start + pos] == pats[p]) return 1 + suffixLength;
+    }
+  }
+  return 0;
+}
+
+__device__ __forceinline__ u32 num_check_interfix(const SentView& S, u32 start, u32 pos, i32 cc) {
+  u32 rest = S.n - (start + pos);
+  if (pos > 0) {
+    // ぶんの
+    if (cls_has(S, start + pos - 1, cc) && rest > 3 && cls_has(S, start + pos + 3, cc)) {
+      if (S.cp[start + pos] == U'ぶ' && S.cp[start + pos + 1] == U'ん' && S.cp[start + pos + 2] == U'の') return 3;
+    }
+    // 分の
+    if (cls_has(S, start + pos - 1, cc) && rest > 2 && cls_has(S, start + pos + 2, cc)) {
+      if (S.cp[start + pos] == U'分' && S.cp[start + pos + 1] == U'の') return 2;
+    }
+  }
+  return 0;
+}
+
+__device__ __forceinline__ u32 num_check_comma(const SentView& S, u32 start, u32 pos) {
+  u32 posComma = (start + pos) & 0xffff;
+  if (pos == 0) return 0;
+  if (!cls_has(S, posComma, CC_COMMA)) return 0;
+  u32 k = 0;
+  for (k = 0; k <= 4 && posComma + 1 + k < S.n; ++k) {
+    if (!cls_has(S, posComma + 1 + k, CC_FIGURE)) break;
+  }
+  return k == 3 ? 1 : 0;
+}
+
+__device__ __forceinline__ u32 num_check_period(const SentView& S, u32 start, u32 pos, i32 cc) {
+  u32 pp = start + pos;
+  if (pos == 0) return 0;
+  if (!cls_has(S, pp, CC_FAMILY_NUM_PERIOD)) return 0;
+  if (!cls_has(S, pp - 1, cc)) return 0;
+  if (pp + 1 < S.n && cls_has(S, pp + 1, cc)) return 1;
+  return 0;
+}
+
+__device__ __forceinline__ u32 num_find_longest(const SentView& S, u32 start, i32 cc) {
+  u32 pos = 0;
+  for (pos = 0; pos <= 64 && start + pos < S.n; pos = (pos + 1) & 0xffff) {
+    if (!cls_has(S, start + pos, cc)) {
+      u32 len = num_check_prefix(S, start, pos);
+      if (len == 0) len = num_check_interfix(S, start, pos, cc);
+      if (len == 0) len = num_check_suffix(S, start, pos);
+      if (len == 0) len = num_check_comma(S, start, pos);
+      if (len == 0) len = num_check_period(S, start, pos, cc);
+      if (len > 0) {
+        pos = (pos + len - 1) & 0xffff;
+      } else {
+        return pos;
+      }
+    }
+  }
+  return pos;
+}
+
+// decode the first `nf` ints of the entry row at EntryPtr `eptr`
+__device__ __forceinline__ void read_entry_row(const DevModel& M, i32 eptr, i32* row, int nf) {
+  u32 pos = (u32)(eptr >> 1);
+  for (int k = 0; k < nf; ++k) row[k] = (i32)read_varint(M.entry_data, pos);
+}
+
+__device__ __forceinline__ bool dic_pattern_matches(const DevModel& M, const UnkMaker& mk, i32 value) {
+  bool match = false;
+  for_each_entry(M, value, [&](i32 ptr) {
+    if (match) return;
+    i32 row[kMaxDicFeatures];
+    read_entry_row(M, ptr, row, M.num_features);
+    bool same = true;
+    for (int f = 0; f < M.num_features; ++f) {
+      if ((mk.pattern_mask >> f) & 1) {
+        if (row[f] != mk.tmpl[f]) same = false;
+      }
+    }
+    if (same) match = true;
+  });
+  return match;
+}
+
+__device__ __forceinline__ void numeric_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+                                              u32 i, SeedSink& out) {
+  u32 length = num_find_longest(S, i, mk.char_class);
+  if (length == 0) return;
+  TrieCursor c{0, 0};
+  int st = TRIE_NONODE;
+  bool nonode = false;
+  for (u32 k = i; k < i + length; ++k) {
+    st = step_cp(M, S, c, k);
+    if (st == TRIE_NONODE) nonode = true;
+  }
+  if (nonode) st = TRIE_NONODE;
+  u32 e = i + length;
+  if (st == TRIE_NONODE) {
+    emit_unk(M, mk, S, out, i, e, true);
+  } else if (st == TRIE_NOLEAF) {
+    emit_unk(M, mk, S, out, i, e, false);
+  } else {
+    if (!dic_pattern_matches(M, mk, c.value)) emit_unk(M, mk, S, out, i, e, false);
+  }
+}
+
+// ---- onomatopoeia ----------------------------------------------------------
+__device__ __forceinline__ u32 onoma_find(const SentView& S, u32 start, i32 cc) {
+  if (start + 4 >= S.n) return 0;
+  if ((S.cls[start] & cc) == 0) return 0;
+  i32 c1 = S.cls[start];
+  if ((S.cls[start + 1] & c1) == 0) return 0;
+  u32 pattern = 0;
+  for (u32 half = 2; half * 2 <= 8 && start + half * 2 - 1 < S.n; ++half) {
+    if ((S.cls[start + half] & c1) == 0) return pattern;
+    if (S.cp[start] != S.cp[start + half]) continue;
+    bool ok = true;
+    for (u32 p = 1; p < half; ++p) {
+      if (S.cp[start + p] != S.cp[start + half + p]) {
+        ok = false;
+        break;
+      }
+    }
+    if (ok) pattern |= (1u << half) & 0x1c;
+  }
+  return pattern;
+}
+
+__device__ __forceinline__ void onoma_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+                                            u32 i, SeedSink& out) {
+  u32 pattern = onoma_find(S, i, mk.char_class);
+  if (pattern == 0) return;
+  TrieCursor c{0, 0};
+  u32 next = i;
+  int st = TRIE_NONODE;
+  for (u32 half = 2; half * 2 <= 8; ++half) {
+    if (pattern & ((1u << half) & 0x1c)) {
+      for (; next < i + half * 2; ++next) st = step_cp(M, S, c, next);
+      if (st == TRIE_NONODE) emit_unk(M, mk, S, out, i, i + half * 2, true);
+      else if (st == TRIE_NOLEAF) emit_unk(M, mk, S, out, i, i + half * 2, false);
+    }
+  }
+}
+
+__device__ __forceinline__ void run_maker(const DevModel& M, const UnkMaker& mk, const SentView& S, u32 i,
+                                          SeedSink& out) {
+  switch (mk.type) {
+    case UNK_SINGLE: single_maker(M, mk, S, i, out); break;
+    case UNK_CHUNKING: chunking_maker(M, mk, S, i, out); break;
+    case UNK_NUMERIC: numeric_maker(M, mk, S, i, out); break;
+    case UNK_ONOMATOPOEIA: onoma_maker(M, mk, S, i, out); break;
+    default: break;  // UNK_NORMALIZE is handled by k_norm
+  }
+}
+
+// ---- normalize (charlattice traversal from one start) ----------------------
+struct NormState {
+  u32 node_pos;
+  i32 value;
+  u16 end;
+  u16 flags;
+  u8 key_pos;
+  u8 last;
+};
+struct NormResult {
+  i32 ptr;
+  u16 flags;
+  u16 end;
+};
+
+__device__ __forceinline__ int utf8_encode3(u32 cp, u8* b) {
+  // every replacement codepoint of CharDb is a 3-byte kana
+  b[0] = (u8)(0xE0 | (cp >> 12));
+  b[1] = (u8)(0x80 | ((cp >> 6) & 0x3f));
+  b[2] = (u8)(0x80 | (cp & 0x3f));
+  return 3;
+}
+
+// returns number of results or -1 on capacity overflow; results are sorted and uniqued
+__device__ inline int norm_lookup(const DevModel& M, const SentView& S, const ClNodes* cl, u32 start,
+                                  NormResult* res) {
+  NormState a[kMaxNormStates], b[kMaxNormStates];
+  NormState* s1 = a;
+  NormState* s2 = b;
+  int n1 = 0, n2 = 0, nres = 0;
+  bool overflow = false;
+  TrieCursor c{0, 0x7fffffff};
+  int st = step_cp(M, S, c, start);
+  if (st == TRIE_NONODE) return 0;
+  s1[n1++] = NormState{c.node_pos, c.value, (u16)(start + 1), (u16)CL_ORIGINAL,
+                       (u8)(S.boff[start + 1] - S.boff[start]), (u8)st};
+  u32 step = start + 1;
+  while (step < S.n && n1 > 0) {
+    n2 = 0;
+    const ClNodes& xn = cl[step];
+    for (int k = 0; k < n1; ++k) {
+      const NormState ps = s1[k];
+      for (int w = -1; w < (int)xn.n; ++w) {
+        u16 newFlag = w < 0 ? (u16)CL_ORIGINAL : xn.type[w];
+        bool doStep = w < 0 ? true : (xn.type[w] & CL_DELETE) == 0;
+        NormState ns = ps;
+        u32 e = (u32)ps.end + 1;
+        ns.end = (u16)(e < S.n ? e : S.n);
+        ns.flags = ps.flags | newFlag;
+        int status;
+        if (doStep) {
+          TrieCursor tc{ps.node_pos, ps.value};
+          if (w < 0) {
+            status = step_cp(M, S, tc, step);
+            ns.key_pos = (u8)(S.boff[step + 1] - S.boff[step]);
+          } else {
+            u8 bytes[4];
+            int nb = utf8_encode3(xn.cp[w], bytes);
+            status = trie_step(M.trie, tc, bytes, nb);
+            ns.key_pos = (u8)nb;
+          }
+          // a failed step leaves key_pos at the failing byte in the reference, but such
+          // states are discarded, so only successful steps matter
+          ns.node_pos = tc.node_pos;
+          ns.value = tc.value;
+        } else {
+          status = ps.last;
+        }
+        if (status == TRIE_NONODE) continue;
+        ns.last = (u8)status;
+        if (status == TRIE_OK && ns.flags != CL_ORIGINAL) {
+          u16 flags = ns.flags;
+          if (newFlag & CL_DELETE) flags |= CL_DELETE_LAST;
+          for_each_entry(M, ns.value, [&](i32 ptr) {
+            if (nres < kMaxNormResults) res[nres++] = NormResult{ptr, flags, ns.end};
+            else overflow = true;
+          });
+        }
+        if (n2 < kMaxNormStates) s2[n2++] = ns;
+        else overflow = true;
+      }
+    }
+    ++step;
+    // consecutive-duplicate removal (charlattice.cc:266-296 + :336-345)
+    int m = 0;
+    for (int k = 0; k < n2; ++k) {
+      if (m > 0) {
+        const NormState& p = s2[m - 1];
+        const NormState& q = s2[k];
+        if (p.end == q.end && p.flags == q.flags && p.node_pos == q.node_pos && p.key_pos == q.key_pos &&
+            p.value == q.value)
+          continue;
+      }
+      s2[m++] = s2[k];
+    }
+    NormState* t = s1;
+    s1 = s2;
+    s2 = t;
+    n1 = m;
+  }
+  if (overflow) return -1;
+  if (nres == 0) return 0;
+  // util::sort == std::sort: an insertion sort (stable) for <= 16 elements.  More than 16
+  // candidates from one start would need libstdc++'s introsort order; report as capacity.
+  if (nres > 16) return -1;
+  for (int x = 1; x < nres; ++x) {
+    NormResult v = res[x];
+    int y = x - 1;
+    while (y >= 0 && (v.end == res[y].end ? v.ptr < res[y].ptr : v.end < res[y].end)) {
+      res[y + 1] = res[y];
+      --y;
+    }
+    res[y + 1] = v;
+  }
+  int m = 0;
+  for (int x = 0; x < nres; ++x) {
+    if (m > 0 && res[m - 1].ptr == res[x].ptr && res[m - 1].end == res[x].end) continue;
+    res[m++] = res[x];
+  }
+  return m;
+}
+
+// makePtr(surface, conf, eptr, feature): entry row of `eptr` with the replace
+// fields overwritten by the hash of the *input* surface, placeholder = flags
+__device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk, const SentView& S,
+                                          SeedSink& out, u32 s, const NormResult& r) {
+  if (!out.emit) {
+    ++out.n;
+    return;
+  }
+  i32 ph[2] = {0, 0};
+  if (mk.placeholder >= 0 && mk.placeholder < 2) ph[mk.placeholder] = (i32)r.flags;
+  out.unk(r.ptr, surface_hash(S, s, r.end), ph[0], ph[1], (u32)M.norm_maker, s, r.end);
+}
+
+// MODE 0: count (writes pos_cntA / pos_cnt2); MODE 1: emit stage 1; MODE 2: emit stage 1+2
+// for sentences with the stage-2 flag (into their relocated region).
+template <int MODE>
+__global__ void k_seeds(Batch B, const DevModel* Mp) {
+  const DevModel& M = *Mp;
+  u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
+  u32 off = B.byte_off[s];
+  u32 g0 = off + s;
+  u32 bb0 = off + 4 * s;
+  SentView S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, B.sent_ncp[s]};
+  u64 nbase = MODE == 0 ? 0 : B.node_base[s];
+  for (u32 i = threadIdx.x; i < S.n; i += blockDim.x) {
+    SeedSink out;
+    out.emit = MODE != 0;
+    out.n = 0;
+    if (MODE != 0) {
+      u32 first = B.bnd_first[bb0 + i + 2];
+      out.ni = B.node_info + nbase + first;
+      out.na = B.node_aux + nbase + first;
+    } else {
+      out.ni = nullptr;
+      out.na = nullptr;
+    }
+    dic_seeds(M, S, i, out);
+    for (int m = 0; m < M.n_stage1; ++m) run_maker(M, M.makers[m], S, i, out);
+    if (MODE == 0) {
+      B.pos_cnt1[g0 + i] = (u16)(out.n > 0xffff ? 0xffff : out.n);
+      u32 n1 = out.n;
+      for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, out);
+      B.pos_cnt2[g0 + i] = (u16)(out.n - n1);
+    } else if (MODE == 2) {
+      // stage-2 nodes follow the stage-1 nodes (incl. normalize) of this start
+      u32 skip = B.pos_cntN[g0 + i];
+      out.n += skip;
+      for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, out);
+    }
+  }
+}
+
+// normalize maker: same modes.  Its nodes are the last stage-1 nodes of a start.
+template <int MODE>
+__global__ void k_norm(Batch B, const DevModel* Mp) {
+  const DevModel& M = *Mp;
+  u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  u32 off = B.byte_off[s];
+  u32 g0 = off + s;
+  u32 bb0 = off + 4 * s;
+  u32 n = B.sent_ncp[s];
+  bool applicable = M.norm_maker >= 0 && (B.sent_flags[s] & 1);
+  if (MODE == 0 && !applicable) {
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) B.pos_cntN[g0 + i] = 0;
+    return;
+  }
+  if (!applicable) return;
+  if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
+  SentView S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, n};
+  const UnkMaker& mk = M.makers[M.norm_maker];
+  u64 nbase = MODE == 0 ? 0 : B.node_base[s];
+  for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+    NormResult res[kMaxNormResults];
+    int nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
+    if (nr < 0) {
+      atomicMax(&B.sent_status[s], (i32)ST_CAPACITY);
+      nr = 0;
+    }
+    if (MODE == 0) {
+      B.pos_cntN[g0 + i] = (u16)nr;
+    } else {
+      SeedSink out;
+      out.emit = true;
+      u32 first = B.bnd_first[bb0 + i + 2] + B.pos_cnt1[g0 + i];
+      out.ni = B.node_info + nbase + first;
+      out.na = B.node_aux + nbase + first;
+      out.n = 0;
+      for (int k = 0; k < nr; ++k) norm_emit(M, mk, S, out, i, res[k]);
+    }
+  }
+}
+
+}  // namespace jpp
+
+#endif  // JPP_K_SEEDS_H

@@ -1,0 +1,409 @@
+// Kernel 5: the boundary sweep -- global-beam Viterbi with bigram/trigram
+// perceptron scoring.  One wavefront (64-lane workgroup) per sentence walks
+// the boundaries in order (the recurrence is sequential over boundaries); all
+// per-boundary work is spread over the 64 lanes:
+//   * global beam  : wave-wide arg-max over the unique u64 keys, G rounds
+//   * prescores    : 8 lanes per (gbeam head, right node), round-robin partial sums
+//   * tail scoring : 4 lanes per (kept right node, unique T1), 1 lane per (node, tail entry)
+//   * beams        : stable rank of each candidate among <= G totals
+// The per-boundary working set (gbeam, T1/T2 patterns, prescores, totals) is
+// staged in ~10 KB of LDS; node patterns / beams / weights stay in HBM.
+//
+// Every float sum below reproduces the association order of the reference
+// (SURVEY section 7 "Float summation order"); the comments name the code.
+//
+// Reference behaviour reproduced:
+//   AnalyzerImpl::computeScoresGbeam        src/core/analysis/analyzer_impl.cc:250-297
+//   ScoreProcessor::makeGlobalBeam          src/core/analysis/score_processor.cc:246-282
+//   processBeamCandidates / BeamCandidate   score_processor.cc:193-206, score_processor.h:81-115
+//   ScoreProcessor::computeGbeamScores      score_processor.cc:284-361
+//   dedupT1 / gatherT1 / gatherT2           score_processor.cc:363-409
+//   computeT0Prescores                      score_processor.cc:497-511
+//   generated applyBiStep2 / applyTriStep3  (8 / 4 round-robin accumulators; last row
+//                                            computeUnrolled4RawPerceptron, perceptron.h:46-72)
+//   makeT0cutoffBeam (std::nth_element)     score_processor.cc:471-495
+//   applyBiTriFullKernel                    src/core/impl/feature_impl_ngram_partial_kernels.h:19-111
+//   copyT0Scores / makeT0Beam               score_processor.cc:411-469
+#ifndef JPP_K_SWEEP_H
+#define JPP_K_SWEEP_H
+
+#include "jpp_device.h"
+#include "jpp_select.h"
+#include "k_t0.h"
+
+namespace jpp {
+
+struct NgramTables {
+  u64 bi_pre[spec::kNumBi];
+  int bi_t0[spec::kNumBi];
+  int bi_t1[spec::kNumBi];
+  u64 tri_pre[spec::kNumTri];
+  int tri_t0[spec::kNumTri];
+  int tri_t1[spec::kNumTri];
+  int tri_t2[spec::kNumTri];
+  constexpr NgramTables() : bi_pre{}, bi_t0{}, bi_t1{}, tri_pre{}, tri_t0{}, tri_t1{}, tri_t2{} {
+    for (int k = 0; k < spec::kNumBi; ++k) {
+      bi_pre[k] = bi_prefix(spec::kBi[k].index);
+      bi_t0[k] = spec::kBi[k].t0;
+      bi_t1[k] = spec::kBi[k].t1;
+    }
+    for (int k = 0; k < spec::kNumTri; ++k) {
+      tri_pre[k] = tri_prefix(spec::kTri[k].index);
+      tri_t0[k] = spec::kTri[k].t0;
+      tri_t1[k] = spec::kTri[k].t1;
+      tri_t2[k] = spec::kTri[k].t2;
+    }
+  }
+};
+constexpr NgramTables kNg{};
+
+constexpr int kChunk = 16;      // kept right nodes processed per pass
+constexpr int kPresCap = 512;   // rcheck * R prescores staged in LDS
+
+__device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == kFake16 && s.beam == kFake16; }
+
+__global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
+  const DevModel& M = *Mp;
+  const u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  const int lane = (int)threadIdx.x;
+  const u32 off = B.byte_off[s];
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_ncp[s];
+  const u64 nb = B.node_base[s];
+  const int beam = cfg.beam;
+  const int G = cfg.gbeam;
+  const float* __restrict__ W = M.weights;
+  const u32 wmask = M.wmask;
+  const u32* en = B.end_nodes + nb;
+  BeamSlot* beams = B.node_beam + nb * beam;
+  const u64* pats = B.node_pat + nb * kPat;
+  const float* t0s = B.node_t0 + nb;
+
+  __shared__ u64 gb_key[kMaxGbeam];
+  __shared__ u16 gb_left[kMaxGbeam];
+  __shared__ u16 gb_slot[kMaxGbeam];
+  __shared__ float gb_score[kMaxGbeam];
+  __shared__ u32 gb_lnode[kMaxGbeam];
+  __shared__ u32 gb_pnode[kMaxGbeam];
+  __shared__ u32 gb_t1[kMaxGbeam];
+  __shared__ u32 t1node[kMaxGbeam];
+  __shared__ u32 sh_U;
+  __shared__ u64 t1pat[kMaxGbeam][kPat];
+  __shared__ u64 t2pat[kMaxGbeam][kPat];
+  __shared__ float pres[kPresCap];
+  __shared__ float csum[kMaxRight];
+  __shared__ u16 order[kMaxRight];
+  __shared__ float biS[kChunk][kMaxGbeam];
+  __shared__ float tot[kChunk][kMaxGbeam];
+
+  for (u32 b = 2; b <= n + 2; ++b) {
+    const u32 R = B.bnd_cnt[bb0 + b];
+    if (R == 0) continue;
+    const u32 rfirst = B.bnd_first[bb0 + b];
+    const u32 L = B.end_cnt[bb0 + b];
+    const u32 efirst = B.end_first[bb0 + b];
+    if (R > (u32)kMaxRight) {
+      if (lane == 0) B.sent_status[s] = ST_CAPACITY;
+      return;
+    }
+
+    // ---- 1. global beam: top-G of all live (left, slot) by the packed key ----
+    int ngb = 0;
+    {
+      u64 last = ~u64{0};
+      const u32 ncand = L * (u32)beam;
+      for (int r = 0; r < G; ++r) {
+        u64 best = 0;
+        for (u32 q = lane; q < ncand; q += 64) {
+          u32 l = q / (u32)beam, k = q - l * (u32)beam;
+          BeamSlot sl = beams[(u64)en[efirst + l] * beam + k];
+          if (!slot_fake(sl)) {
+            u64 key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
+            if (key < last && key > best) best = key;
+          }
+        }
+        u64 win = wave_max_u64(best);
+        if (win == 0) break;
+        if (lane == 0) gb_key[r] = win;
+        last = win;
+        ++ngb;
+      }
+    }
+    __syncthreads();
+    if (lane < ngb) {
+      u64 key = gb_key[lane];
+      u32 l = (u32)(key >> 16) & 0xffff, k = (u32)key & 0xffff;
+      u32 lnode = en[efirst + l];
+      BeamSlot sl = beams[(u64)lnode * beam + k];
+      gb_left[lane] = (u16)l;
+      gb_slot[lane] = (u16)k;
+      gb_score[lane] = sortable_f32((u32)(key >> 32));
+      gb_lnode[lane] = lnode;
+      gb_pnode[lane] = sl.prev_node;
+      B.bnd_gbeam[(u64)(bb0 + b) * G + lane] = GbeamEntry{(u16)l, (u16)k, gb_score[lane]};
+    }
+    if (lane == 0) B.bnd_ngb[bb0 + b] = (u32)ngb;
+    __syncthreads();
+
+    if (ngb == 0) {
+      // unreachable boundary: every right node gets an all-fake beam (makeT0Beam with an empty gbeam)
+      for (u32 q = lane; q < R * (u32)beam; q += 64) {
+        beams[(u64)rfirst * beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+      }
+      for (u32 q = lane; q < R; q += 64) B.node_kept[nb + rfirst + q] = 0;
+      __syncthreads();
+      continue;
+    }
+
+    // ---- 2. T1 dedup in first-seen order, gather T1 / T2 pattern rows ----
+    if (lane == 0) {
+      u32 U = 0;
+      for (int i = 0; i < ngb; ++i) {
+        int found = -1;
+        for (int j = 0; j < i; ++j) {
+          if (gb_left[j] == gb_left[i]) {
+            found = j;
+            break;
+          }
+        }
+        if (found >= 0) {
+          gb_t1[i] = gb_t1[found];
+        } else {
+          gb_t1[i] = U;
+          t1node[U] = gb_lnode[i];
+          ++U;
+        }
+      }
+      sh_U = U;
+    }
+    __syncthreads();
+    const int U = (int)sh_U;
+    for (int q = lane; q < (U + ngb) * kPat; q += 64) {
+      int row = q / kPat, p = q - row * kPat;
+      if (row < U) t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
+      else t2pat[row - U][p] = pats[(u64)gb_pnode[row - U] * kPat + p];
+    }
+    __syncthreads();
+
+    // ---- 3. prescores for the first c gbeam entries over all right nodes ----
+    int c = cfg.rcheck;
+    if (c > (int)R) c = (int)R;
+    if (c > ngb) c = ngb;
+    if ((u32)c * R > (u32)kPresCap) {
+      if (lane == 0) B.sent_status[s] = ST_CAPACITY;
+      return;
+    }
+    {
+      const int grp = lane >> 3, j = lane & 7;
+      const u32 units = (u32)c * R;
+      for (u32 base = 0; base < units; base += 8) {
+        u32 u = base + grp;
+        bool act = u < units;
+        u32 i = act ? u / R : 0, t = act ? u - i * R : 0;
+        bool lastRow = (t == R - 1);
+        int Wd = lastRow ? 4 : 8;
+        const u64* p0 = pats + (u64)(rfirst + t) * kPat;
+        const u64* t1r = t1pat[gb_t1[i]];
+        const u64* t2r = t2pat[i];
+        float f = 0.f;
+        if (act && j < Wd) {
+          for (int k = j; k < spec::kNumBi; k += Wd) {
+            u32 idx = (u32)hmix(hmix(kNg.bi_pre[k], p0[kNg.bi_t0[k]]), t1r[kNg.bi_t1[k]]) & wmask;
+            f += W[idx];
+          }
+        }
+        float g = 0.f;
+        if (act && j < spec::kNumTri) {
+          u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[j], p0[kNg.tri_t0[j]]), t1r[kNg.tri_t1[j]]),
+                              t2r[kNg.tri_t2[j]]) & wmask;
+          g += W[idx];
+        }
+        // f_0 + f_1 + ... (left to right) ; g_0 + g_1 + g_2 + g_3
+        float bsum = wave_shfl_f32(f, (grp << 3));
+        float tsum = wave_shfl_f32(g, (grp << 3));
+#pragma unroll
+        for (int jj = 1; jj < 8; ++jj) {
+          float v = wave_shfl_f32(f, (grp << 3) + jj);
+          float w = wave_shfl_f32(g, (grp << 3) + jj);
+          if (jj < Wd) bsum += v;
+          if (jj < spec::kNumTri) tsum += w;
+        }
+        if (act && j == 0) {
+          float sc = t0s[rfirst + t];
+          sc += bsum;
+          sc += tsum;
+          pres[i * R + t] = sc;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 4. right-node cutoff (std::nth_element semantics) ----
+    const u32 K = (cfg.rcheck > 0) ? ((u32)cfg.rbeam < R ? (u32)cfg.rbeam : R) : R;
+    for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
+    if (cfg.rcheck > 0 && R > (u32)cfg.rbeam) {
+      for (u32 t = lane; t < R; t += 64) {
+        float sc = 0.f;
+        for (int i = 0; i < c; ++i) sc += pres[i * R + t];
+        csum[t] = sc;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        ScoreGreater cmp{csum};
+        nth_element_u16(order, order + cfg.rbeam, order + R, cmp);
+      }
+    }
+    __syncthreads();
+
+    // ---- 5. score + beams, kChunk right nodes at a time in cutoff order ----
+    const int ntail = ngb - c;
+    for (u32 op0 = 0; op0 < R; op0 += kChunk) {
+      const int nx = (int)((R - op0) < (u32)kChunk ? (R - op0) : (u32)kChunk);
+      // 5a. bigram sums per (kept node, unique T1 row) -- applyBiTriFullKernel rows
+      if (ntail > 0) {
+        const int units = nx * U;
+        for (int base = 0; base < units; base += 16) {
+          int u = base + (lane >> 2);
+          int j = lane & 3;
+          bool act = u < units;
+          int x = act ? u / U : 0, tu = act ? u - x * U : 0;
+          bool kept = (op0 + x) < K;
+          act = act && kept;
+          u32 t = order[op0 + x];
+          const u64* p0 = pats + (u64)(rfirst + t) * kPat;
+          const u64* t1r = t1pat[tu];
+          bool lastRow = (tu == U - 1);
+          int Wd = lastRow ? 4 : 2;
+          float f = 0.f;
+          if (act && j < Wd) {
+            for (int k = j; k < spec::kNumBi; k += Wd) {
+              u32 idx = (u32)hmix(hmix(kNg.bi_pre[k], p0[kNg.bi_t0[k]]), t1r[kNg.bi_t1[k]]) & wmask;
+              f += W[idx];
+            }
+          }
+          int gl = lane & ~3;
+          float r1 = wave_shfl_f32(f, gl), r2 = wave_shfl_f32(f, gl + 1);
+          float r3 = wave_shfl_f32(f, gl + 2), r4 = wave_shfl_f32(f, gl + 3);
+          if (act && j == 0) {
+            float sum = r1 + r2;
+            if (lastRow) {
+              sum += r3;
+              sum += r4;
+            }
+            biS[x][tu] = sum;
+          }
+        }
+      }
+      __syncthreads();
+      // 5b. cells and totals per (node, gbeam entry)
+      for (int q = lane; q < nx * ngb; q += 64) {
+        int x = q / ngb, i = q - x * ngb;
+        bool kept = (op0 + x) < K;
+        u32 t = order[op0 + x];
+        float cell, total;
+        bool defined = true;
+        if (i < c) {
+          // copyT0Scores(head, result, 0): v += 0; cell = v; v += gb.score()
+          float v = pres[i * R + t];
+          v += 0.f;
+          cell = v;
+          v += gb_score[i];
+          total = v;
+        } else if (kept) {
+          const u64* p0 = pats + (u64)(rfirst + t) * kPat;
+          const u64* t1r = t1pat[gb_t1[i]];
+          const u64* t2r = t2pat[i];
+          float w[spec::kNumTri];
+#pragma unroll
+          for (int f = 0; f < spec::kNumTri; ++f) {
+            u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[f], p0[kNg.tri_t0[f]]), t1r[kNg.tri_t1[f]]),
+                                t2r[kNg.tri_t2[f]]) & wmask;
+            w[f] = W[idx];
+          }
+          static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
+          float S = biS[x][gb_t1[i]];
+          float res;
+          if (i < ngb - 1) {
+            float r1 = 0.f, r2 = 0.f;
+            r1 += w[0];
+            r2 += w[1];
+            r1 += w[2];
+            r2 += w[3];
+            res = S + r1 + r2;
+          } else {
+            float q1 = 0.f, q2 = 0.f, q3 = 0.f, q4 = 0.f;
+            q1 += w[0];
+            q2 += w[1];
+            q3 += w[2];
+            q4 += w[3];
+            res = S + (q1 + q2 + q3 + q4);
+          }
+          // copyT0Scores(tail, resultTail, t0Score)
+          float v = res;
+          v += t0s[rfirst + t];
+          cell = v;
+          v += gb_score[i];
+          total = v;
+        } else {
+          defined = false;
+          cell = 0.f;
+          total = 0.f;
+        }
+        tot[x][i] = total;
+        if (defined) B.node_cells[(nb + rfirst + t) * G + i] = cell;
+      }
+      __syncthreads();
+      // 5c. beams: stable descending rank among the node's candidates (makeT0Beam; for <= 16
+      //     candidates std::sort is an insertion sort, i.e. stable)
+      for (int q = lane; q < nx * kMaxGbeam; q += 64) {
+        int x = q / kMaxGbeam, i = q - x * kMaxGbeam;
+        bool kept = (op0 + x) < K;
+        u32 t = order[op0 + x];
+        int cnt = kept ? ngb : c;
+        BeamSlot* row = beams + (u64)(rfirst + t) * beam;
+        if (i < cnt) {
+          float me = tot[x][i];
+          int rank = 0;
+          for (int jx = 0; jx < cnt; ++jx) {
+            float o = tot[x][jx];
+            if (o > me || (o == me && jx < i)) ++rank;
+          }
+          if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], 0};
+        } else if (i < beam) {
+          row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+        }
+        if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// top-1 path: follow the EOS beam's best slot back to BOS (AnalysisPath::fillIn,
+// src/core/analysis/analysis_result.cc:25-76).  One lane per sentence.
+__global__ void k_path(Batch B, Config cfg) {
+  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.n_sent) return;
+  B.path_len[s] = 0;
+  if (B.sent_status[s] != ST_OK) return;
+  u32 N = B.sent_nodes[s];
+  u64 nb = B.node_base[s];
+  const BeamSlot* beams = B.node_beam + nb * cfg.beam;
+  u32* out = B.path_nodes + nb;
+  u32 node = N - 1;
+  u32 slot = 0;
+  u32 len = 0;
+  while (node >= 2 && len < N) {
+    BeamSlot sl = beams[(u64)node * cfg.beam + slot];
+    if (slot_fake(sl)) break;
+    out[len++] = node;
+    node = sl.prev_node;
+    slot = sl.beam;
+  }
+  B.path_len[s] = len;
+}
+
+}  // namespace jpp
+
+#endif  // JPP_K_SWEEP_H

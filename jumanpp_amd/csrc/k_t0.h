@@ -1,0 +1,177 @@
+// Kernel 4 ("T0"): per lattice node -- entry row, 20 primitive features, 38
+// pattern hashes (14 stored), 32 unigram weight gathers summed in the exact
+// association of the reference's generated static code.
+// One workgroup (64 lanes) per sentence, one lane per node.  The spec tables
+// are constexpr, so every loop below unrolls into straight-line integer code;
+// the only memory traffic per node is the varint entry row (8-24 B), 32
+// scattered 4-byte weight gathers and the 112+32+4 byte result row.
+//
+// Reference behaviour reproduced:
+//   generated PatternFeatureStaticApply_JumandicStatic::patternsAndUnigramsApply
+//     (emitted by src/core/codegen/pattern_feature_codegen.cc; called from
+//      ScoreProcessor::computeT0All, src/core/analysis/score_processor.cc:123-134)
+//   PrimitiveFeatureContext::fillEntryBuffer / providedFeature
+//     src/core/impl/feature_impl_types.h:104-148
+//   primitive features  src/core/impl/feature_impl_prim.h:62-236
+//   compute features    src/core/impl/feature_impl_compute.cc:12-26,59-63
+//   pattern hash        src/core/impl/feature_impl_pattern.h:28-41
+//   UnigramFeature::maskedValueFor  src/core/impl/feature_impl_ngram_partial.h:29-32
+//   computeUnrolled4RawPerceptron   src/core/analysis/perceptron.h:46-72 (last row)
+#ifndef JPP_K_T0_H
+#define JPP_K_T0_H
+
+#include "jpp_device.h"
+#include "jumandic_spec.inc"
+
+namespace jpp {
+
+__host__ __device__ constexpr u64 pattern_prefix(int idx, int nargs) {
+  return hmix(hmix(hmix(kHashSeed0, (u64)(u32)idx), (u64)nargs), kPatternSeed);
+}
+__host__ __device__ constexpr u64 uni_prefix(int index) {
+  return hmix(hmix(hmix(kHashSeed0, 3), (u64)(u32)index), kUnigramSeed);
+}
+__host__ __device__ constexpr u64 bi_prefix(int index) {
+  return hmix(hmix(hmix(kHashSeed0, 4), (u64)(u32)index), kBigramSeed);
+}
+__host__ __device__ constexpr u64 tri_prefix(int index) {
+  return hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)index), kTrigramSeed);
+}
+
+__global__ void k_t0(Batch B, const DevModel* Mp) {
+  const DevModel& M = *Mp;
+  u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  u32 off = B.byte_off[s];
+  u32 g0 = off + s;
+  u32 bb0 = off + 4 * s;
+  u32 n = B.sent_ncp[s];
+  u32 N = B.sent_nodes[s];
+  u64 nb = B.node_base[s];
+  const u32* cps = B.cp_code + g0;
+  const i32* cls = B.cp_class + g0;
+
+  for (u32 k = 2 + threadIdx.x; k < N; k += blockDim.x) {
+    NodeInfo ni = B.node_info[nb + k];
+    NodeAux na = B.node_aux[nb + k];
+    u32 b = (k == N - 1) ? n + 2 : (u32)ni.start + 2;
+    u32 first = B.bnd_first[bb0 + b];
+    u32 R = B.bnd_cnt[bb0 + b];
+    bool isLast = (k - first) == R - 1;
+
+    // ---- entry row ----
+    i32 entry[spec::kNumDicFeatures];
+    bool isUnk = false;
+    if (ni.eptr == kEptrEOS) {
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = kEptrEOS;
+    } else if (ni.eptr >= 0) {
+      read_entry_row(M, ni.eptr, entry, spec::kNumDicFeatures);
+    } else {
+      isUnk = true;
+      const UnkMaker& mk = M.makers[na.maker];
+      if (mk.type == UNK_NORMALIZE) {
+        read_entry_row(M, na.tmpl, entry, spec::kNumDicFeatures);
+      } else {
+#pragma unroll
+        for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = mk.tmpl[f];
+      }
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) {
+        if ((mk.replace_mask >> f) & 1) entry[f] = na.hash;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < spec::kNumDicFeatures; ++f) B.node_entry[(nb + k) * spec::kNumDicFeatures + f] = entry[f];
+
+    // ---- primitive features ----
+    u64 prim[spec::kNumPrims];
+#pragma unroll
+    for (int p = 0; p < spec::kNumPrims; ++p) {
+      const int kind = spec::kPrims[p].kind;
+      const int a = spec::kPrims[p].a;
+      const int bsh = spec::kPrims[p].b;
+      u64 v = 0;
+      if (kind == spec::Copy) {
+        v = (u32)entry[a];
+      } else if (kind == spec::SingleBit) {
+        v = ((u32)entry[a] >> bsh) & 1u;
+      } else if (kind == spec::Provided) {
+        v = isUnk ? (u64)(u32)(a == 0 ? na.ph0 : na.ph1) : 0;
+      } else if (kind == spec::SurfaceCodepointSize) {
+        v = (u64)((i32)ni.end - (i32)ni.start);
+      } else if (kind == spec::Codepoint) {
+        v = ~u64{0};
+        if (a > 0) {
+          u32 pos = (u32)ni.end + (u32)(a - 1);
+          if (pos < n) v = cps[pos];
+        } else {
+          i32 pos = (i32)ni.start + a;
+          if (pos >= 0 && (u32)pos < n) v = cps[pos];
+        }
+      } else if (kind == spec::CodepointType) {
+        v = 0;
+        if (a == 0) {
+          for (u32 q = ni.start; q < ni.end; ++q) v |= (u32)cls[q];
+        } else if (a > 0) {
+          u32 pos = (u32)ni.end + (u32)(a - 1);
+          if (pos < n) v = (u32)cls[pos];
+        } else {
+          i32 pos = (i32)ni.start + a;
+          if (pos >= 0 && (u32)pos < n) v = (u32)cls[pos];
+        }
+      }
+      prim[p] = v;
+    }
+
+    // ---- pattern hashes ----
+    u64 pat[spec::kNumPatterns];
+#pragma unroll
+    for (int p = 0; p < spec::kNumPatterns; ++p) {
+      u64 h = pattern_prefix(p, spec::kPatterns[p].nargs);
+#pragma unroll
+      for (int q = 0; q < spec::kPatterns[p].nargs; ++q) {
+        const int c = spec::kPatterns[p].args[q];
+        if (spec::kComputes[c].cond < 0) {
+          h = hmix(h, prim[spec::kComputes[c].t[0]]);
+        } else {
+          u64 ht = h, hf = h;
+#pragma unroll
+          for (int z = 0; z < spec::kComputes[c].nt; ++z) ht = hmix(ht, prim[spec::kComputes[c].t[z]]);
+#pragma unroll
+          for (int z = 0; z < spec::kComputes[c].nf; ++z) hf = hmix(hf, prim[spec::kComputes[c].f[z]]);
+          h = prim[spec::kComputes[c].cond] != 0 ? ht : hf;
+        }
+      }
+      pat[p] = h;
+    }
+#pragma unroll
+    for (int p = 0; p < spec::kNumStoredPatterns; ++p) B.node_pat[(nb + k) * kPat + p] = pat[p];
+
+    // ---- unigram perceptron ----
+    static_assert(spec::kNumUni >= 4, "unigram count");
+    float w[spec::kNumUni];
+#pragma unroll
+    for (int u = 0; u < spec::kNumUni; ++u) {
+      u32 idx = (u32)hmix(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0]) & M.wmask;
+      w[u] = M.weights[idx];
+    }
+    float part[4];
+    if (isLast) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[j] = 0.f;
+#pragma unroll
+      for (int u = 0; u < spec::kNumUni; ++u) part[u & 3] += w[u];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[j] = w[j];
+#pragma unroll
+      for (int u = 4; u < spec::kNumUni; ++u) part[u & 3] += w[u];
+    }
+    B.node_t0[nb + k] = part[0] + part[1] + part[2] + part[3];
+  }
+}
+
+}  // namespace jpp
+
+#endif  // JPP_K_T0_H

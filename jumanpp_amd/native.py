@@ -1,0 +1,256 @@
+"""ctypes binding of the C ABI in include/jppgpu.h.
+
+The product library is jumanpp_amd/libjppgpu.so (hipcc, gfx950).  There is no
+CPU implementation behind this module: creating a context without a HIP device
+raises.  (tests/ may point `lib_path` at the emulator build of the same kernel
+sources; that is test infrastructure.)
+"""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, 'libjppgpu.so')
+
+
+class UnkMaker(C.Structure):
+    _fields_ = [('type', C.c_int32), ('char_class', C.c_int32), ('pattern_ptr', C.c_int32),
+                ('priority', C.c_int32), ('placeholder', C.c_int32), ('replace_mask', C.c_uint32)]
+
+
+class Model(C.Structure):
+    _fields_ = [('trie', C.c_void_p), ('trie_bytes', C.c_size_t),
+                ('entry_ptrs', C.c_void_p), ('entry_ptrs_bytes', C.c_size_t),
+                ('entry_data', C.c_void_p), ('entry_data_bytes', C.c_size_t),
+                ('weights', C.c_void_p), ('weight_exponent', C.c_uint32),
+                ('num_features', C.c_int32), ('num_placeholders', C.c_int32),
+                ('unk_makers', C.POINTER(UnkMaker)), ('num_unk_makers', C.c_int32),
+                ('feature_spec', C.c_void_p), ('feature_spec_bytes', C.c_size_t)]
+
+
+class Config(C.Structure):
+    _fields_ = [('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
+                ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32)]
+
+
+class ResultView(C.Structure):
+    _fields_ = [('n_sentences', C.c_uint32),
+                ('status', C.c_void_p), ('n_codepoints', C.c_void_p), ('n_nodes', C.c_void_p),
+                ('node_base', C.c_void_p), ('bnd_base', C.c_void_p),
+                ('total_nodes', C.c_uint64), ('total_boundaries', C.c_uint64),
+                ('beam', C.c_int32), ('global_beam', C.c_int32),
+                ('path_len', C.c_void_p), ('path_nodes', C.c_void_p),
+                ('nodes', C.c_void_p), ('unk', C.c_void_p),
+                ('bnd_first', C.c_void_p), ('bnd_count', C.c_void_p),
+                ('end_first', C.c_void_p), ('end_count', C.c_void_p), ('end_nodes', C.c_void_p),
+                ('entry_rows', C.c_void_p), ('patterns', C.c_void_p), ('t0_scores', C.c_void_p),
+                ('beams', C.c_void_p), ('cells', C.c_void_p), ('kept', C.c_void_p),
+                ('gbeam_count', C.c_void_p), ('gbeam', C.c_void_p)]
+
+
+NODE_DT = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
+UNK_DT = np.dtype([('tmpl', '<i4'), ('hash', '<i4'), ('ph0', '<u2'), ('ph1', '<u2'), ('maker', '<u2'), ('pad', '<u2')])
+BEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('total', '<f4'), ('prev_node', '<u4'), ('pad', '<u4')])
+GBEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('score', '<f4')])
+
+_libs = {}
+
+
+def load_library(path=None):
+    path = path or os.environ.get('JPPGPU_LIB') or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError('jppgpu: native library %s is missing -- build it with '
+                           '`python -c "import __graft_entry__ as g; g.build()"`' % path)
+    lib = C.CDLL(path)
+    lib.jppgpu_last_error.restype = C.c_char_p
+    lib.jppgpu_ctx_create.argtypes = [C.POINTER(Model), C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.jppgpu_ctx_destroy.argtypes = [C.c_void_p]
+    lib.jppgpu_analyze_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.jppgpu_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.jppgpu_result_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(ResultView)]
+    lib.jppgpu_result_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.jppgpu_result_release.argtypes = [C.c_void_p]
+    lib.jppgpu_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    _libs[path] = lib
+    return lib
+
+
+class JppGpuError(RuntimeError):
+    pass
+
+
+def read_image(path):
+    """sections of a `ref_dump export` image: list of (tag, aux, bytes)"""
+    data = open(path, 'rb').read()
+    if data[:8] != b'JPPGPUI1':
+        raise JppGpuError('bad model image magic')
+    pos = 8
+    out = []
+    while True:
+        pos = (pos + 7) & ~7
+        tag, aux, size = struct.unpack_from('<IIQ', data, pos)
+        pos += 16
+        if tag == 0:
+            break
+        out.append((tag, aux, data[pos:pos + size]))
+        pos += size
+    return out
+
+
+class Result:
+    """numpy views over one fetched batch (copies owned by the native result)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.handle = handle
+        self.view = None
+
+    def _arr(self, ptr, dtype, count):
+        if not ptr or count == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=count)
+
+    def fetch(self, full=False):
+        v = ResultView()
+        rc = self.ctx.lib.jppgpu_result_fetch(self.handle, 1 if full else 0, C.byref(v))
+        if rc != 0:
+            raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
+        self.view = v
+        n, N, NB = v.n_sentences, v.total_nodes, v.total_boundaries
+        self.n = n
+        self.beam, self.gbeam = v.beam, v.global_beam
+        self.status = self._arr(v.status, '<i4', n)
+        self.ncp = self._arr(v.n_codepoints, '<u4', n)
+        self.nnodes = self._arr(v.n_nodes, '<u4', n)
+        self.node_base = self._arr(v.node_base, '<u8', n)
+        self.bnd_base = self._arr(v.bnd_base, '<u8', n)
+        self.path_len = self._arr(v.path_len, '<u4', n)
+        self.path_nodes = self._arr(v.path_nodes, '<u4', N)
+        self.nodes = self._arr(v.nodes, NODE_DT, N)
+        self.unk = self._arr(v.unk, UNK_DT, N)
+        if full:
+            self.bnd_first = self._arr(v.bnd_first, '<u4', NB)
+            self.bnd_count = self._arr(v.bnd_count, '<u4', NB)
+            self.end_first = self._arr(v.end_first, '<u4', NB)
+            self.end_count = self._arr(v.end_count, '<u4', NB)
+            self.end_nodes = self._arr(v.end_nodes, '<u4', N)
+            self.entry_rows = self._arr(v.entry_rows, '<i4', N * 8).reshape(-1, 8)
+            self.patterns = self._arr(v.patterns, '<u8', N * 14).reshape(-1, 14)
+            self.t0 = self._arr(v.t0_scores, '<f4', N)
+            self.beams = self._arr(v.beams, BEAM_DT, N * v.beam).reshape(-1, v.beam)
+            self.cells = self._arr(v.cells, '<f4', N * v.global_beam).reshape(-1, v.global_beam)
+            self.kept = self._arr(v.kept, 'u1', N)
+            self.gbeam_count = self._arr(v.gbeam_count, '<u4', NB)
+            self.gbeam_entries = self._arr(v.gbeam, GBEAM_DT, NB * v.global_beam).reshape(-1, v.global_beam)
+        return self
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        rc = self.ctx.lib.jppgpu_result_stats(self.handle, C.byref(a), C.byref(b))
+        if rc != 0:
+            raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
+        return a.value, b.value
+
+    def release(self):
+        self.ctx.lib.jppgpu_result_release(self.handle)
+
+
+class Context:
+    """jppgpu_ctx: model resident in HBM + analysis configuration."""
+
+    def __init__(self, image_path, beam=5, global_beam=6, right_check=1, right_beam=5,
+                 max_input_bytes=4096, device=0, lib_path=None):
+        self.lib = load_library(lib_path)
+        secs = read_image(image_path)
+        by = {}
+        for tag, aux, payload in secs:
+            by.setdefault(tag, []).append((aux, payload))
+        info = struct.unpack_from('<8i', by[1][0][1], 0)
+        self.num_features, self.num_data, self.num_placeholders = info[0], info[1], info[2]
+        self._keep = []
+
+        def buf(b):
+            a = np.frombuffer(b, dtype=np.uint8).copy()
+            self._keep.append(a)
+            return a.ctypes.data, a.size
+
+        m = Model()
+        m.trie, m.trie_bytes = buf(by[2][0][1])
+        m.entry_ptrs, m.entry_ptrs_bytes = buf(by[3][0][1])
+        m.entry_data, m.entry_data_bytes = buf(by[4][0][1])
+        if 5 not in by:
+            raise JppGpuError('model image has no perceptron weights (untrained model)')
+        m.weight_exponent = by[5][0][0]
+        m.weights, _ = buf(by[5][0][1])
+        m.num_features = self.num_features
+        m.num_placeholders = self.num_placeholders
+        ub = by[6][0][1]
+        pos = 0
+        (n_unk,) = struct.unpack_from('<i', ub, pos)
+        pos += 4
+        makers = (UnkMaker * n_unk)()
+        for i in range(n_unk):
+            t, cc, pp, pr, ph, nrep = struct.unpack_from('<6i', ub, pos)
+            pos += 24
+            mask = 0
+            for _ in range(nrep):
+                (f,) = struct.unpack_from('<i', ub, pos)
+                pos += 4
+                mask |= 1 << f
+            makers[i] = UnkMaker(t, cc, pp, pr, ph, mask)
+        self._keep.append(makers)
+        m.unk_makers = makers
+        m.num_unk_makers = n_unk
+        m.feature_spec, m.feature_spec_bytes = buf(by[7][0][1])
+        cfg = Config(beam, global_beam, right_check, right_beam, max_input_bytes, device)
+        h = C.c_void_p()
+        rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise JppGpuError('jppgpu_ctx_create failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+        self.handle = h
+        self.cfg = cfg
+
+    def analyze(self, sentences):
+        """sentences: list of bytes/str.  Host buffers in, Result (device resident) out."""
+        enc = [s.encode('utf-8') if isinstance(s, str) else bytes(s) for s in sentences]
+        offs = np.zeros(len(enc) + 1, dtype=np.uint32)
+        if enc:
+            offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64).astype(np.uint32)
+        text = b''.join(enc)
+        r = C.c_void_p()
+        rc = self.lib.jppgpu_analyze_batch(self.handle, text, offs.ctypes.data, len(enc), C.byref(r))
+        if rc != 0:
+            raise JppGpuError('jppgpu_analyze_batch failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+        return Result(self, r)
+
+    def analyze_device(self, d_text_ptr, d_offsets_ptr, n, total_bytes, stream=None):
+        r = C.c_void_p()
+        rc = self.lib.jppgpu_analyze_batch_device(self.handle, d_text_ptr, d_offsets_ptr, n, total_bytes,
+                                                  stream, C.byref(r))
+        if rc != 0:
+            raise JppGpuError('jppgpu_analyze_batch_device failed (%d): %s'
+                              % (rc, self.lib.jppgpu_last_error().decode()))
+        return Result(self, r)
+
+    def timings(self):
+        ms = (C.c_float * 8)()
+        self.lib.jppgpu_last_timings(self.handle, ms, 8)
+        names = ['decode', 'seeds', 'layout', 't0', 'sweep', 'path', 'total']
+        return dict(zip(names, list(ms)[:7]))
+
+    def close(self):
+        if self.handle:
+            self.lib.jppgpu_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,214 @@
+// TEST INFRASTRUCTURE ONLY.  Functional CPU emulation of the tiny subset of
+// HIP that jumanpp_amd's kernels use, so that the *actual kernel sources* can
+// be run against the oracle without a GPU (pytest -m "not gpu").  It is never
+// compiled into the product library (libjppgpu.so); the product fails loudly
+// when no HIP device is present.
+//
+// Model: a launch runs its blocks one after another; the threads of a block
+// are ucontext fibers on one OS thread.  __syncthreads() and the wave-level
+// exchange primitives are rendezvous points; a pass over all fibers without
+// progress is reported as a deadlock (this catches divergent barriers).
+#ifndef JPP_TESTS_HIP_EMU_H
+#define JPP_TESTS_HIP_EMU_H
+
+#include <ucontext.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+namespace hip_emu {
+
+constexpr int kWave = 64;
+
+struct Fiber {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier
+};
+
+struct State {
+  dim3 grid, block;
+  dim3 bidx, tidx;
+  int cur = 0;
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  std::function<void()> body;
+  // per-wave exchange slots for shuffles / ballots
+  std::vector<uint64_t> xchg;
+};
+
+inline State& st() {
+  static State s;
+  return s;
+}
+
+inline void yield_to_sched() {
+  State& s = st();
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+inline void block_barrier() {
+  State& s = st();
+  s.fibers[s.cur].wait = 1;
+  yield_to_sched();
+}
+
+inline void wave_barrier() {
+  State& s = st();
+  s.fibers[s.cur].wait = 2;
+  yield_to_sched();
+}
+
+inline void fiber_main() {
+  State& s = st();
+  s.body();
+  s.fibers[s.cur].done = true;
+  yield_to_sched();
+}
+
+inline void run_block(unsigned nthreads) {
+  State& s = st();
+  constexpr size_t kStack = 256 * 1024;
+  if (s.fibers.size() < nthreads) s.fibers.resize(nthreads);
+  s.xchg.assign(nthreads, 0);
+  for (unsigned t = 0; t < nthreads; ++t) {
+    Fiber& f = s.fibers[t];
+    if (!f.stack) f.stack = static_cast<char*>(malloc(kStack));
+    f.done = false;
+    f.wait = 0;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_main, 0);
+  }
+  for (;;) {
+    bool progress = false;
+    bool alldone = true;
+    for (unsigned t = 0; t < nthreads; ++t) {
+      Fiber& f = s.fibers[t];
+      if (f.done) continue;
+      alldone = false;
+      if (f.wait != 0) continue;
+      s.cur = (int)t;
+      s.tidx = dim3(t % s.block.x, 0, 0);
+      swapcontext(&s.sched, &f.ctx);
+      progress = true;
+    }
+    if (alldone) break;
+    // release wave barriers
+    for (unsigned w0 = 0; w0 < nthreads; w0 += kWave) {
+      unsigned w1 = w0 + kWave < nthreads ? w0 + kWave : nthreads;
+      bool any = false, all = true;
+      for (unsigned t = w0; t < w1; ++t) {
+        if (s.fibers[t].done) continue;
+        if (s.fibers[t].wait == 2) any = true; else all = false;
+      }
+      if (any && all) {
+        for (unsigned t = w0; t < w1; ++t) if (!s.fibers[t].done) s.fibers[t].wait = 0;
+        progress = true;
+      }
+    }
+    // release the block barrier
+    {
+      bool any = false, all = true;
+      for (unsigned t = 0; t < nthreads; ++t) {
+        if (s.fibers[t].done) continue;
+        if (s.fibers[t].wait == 1) any = true; else all = false;
+      }
+      if (any && all) {
+        for (unsigned t = 0; t < nthreads; ++t) if (!s.fibers[t].done) s.fibers[t].wait = 0;
+        progress = true;
+      }
+    }
+    if (!progress) {
+      fprintf(stderr, "hip_emu: deadlock (divergent barrier?) in block %u\n", s.bidx.x);
+      abort();
+    }
+  }
+}
+
+template <typename F>
+void launch(dim3 grid, dim3 block, F&& f) {
+  State& s = st();
+  s.grid = grid;
+  s.block = block;
+  s.body = f;
+  for (unsigned b = 0; b < grid.x; ++b) {
+    s.bidx = dim3(b, 0, 0);
+    run_block(block.x);
+  }
+}
+
+}  // namespace hip_emu
+
+#define threadIdx (hip_emu::st().tidx)
+#define blockIdx (hip_emu::st().bidx)
+#define blockDim (hip_emu::st().block)
+#define gridDim (hip_emu::st().grid)
+
+inline void __syncthreads() { hip_emu::block_barrier(); }
+
+// ---- wave primitives used through jpp_rt.h wrappers -------------------------
+namespace hip_emu {
+inline int lane() { return st().cur % kWave; }
+inline uint64_t shfl_u64(uint64_t v, int src) {
+  State& s = st();
+  int base = s.cur - s.cur % kWave;
+  s.xchg[s.cur] = v;
+  wave_barrier();
+  uint64_t r = s.xchg[base + (src & (kWave - 1))];
+  wave_barrier();
+  return r;
+}
+inline uint64_t ballot(bool p) {
+  State& s = st();
+  int base = s.cur - s.cur % kWave;
+  s.xchg[s.cur] = p ? 1 : 0;
+  wave_barrier();
+  uint64_t r = 0;
+  for (int i = 0; i < kWave && base + i < (int)s.block.x; ++i) {
+    if (!s.fibers[base + i].done && s.xchg[base + i]) r |= (uint64_t{1} << i);
+  }
+  wave_barrier();
+  return r;
+}
+}  // namespace hip_emu
+
+template <typename T>
+inline T atomicAdd(T* p, T v) {
+  T o = *p;
+  *p = o + v;
+  return o;
+}
+template <typename T>
+inline T atomicMax(T* p, T v) {
+  T o = *p;
+  if (v > o) *p = v;
+  return o;
+}
+inline unsigned atomicOr(unsigned* p, unsigned v) {
+  unsigned o = *p;
+  *p = o | v;
+  return o;
+}
+
+#endif  // JPP_TESTS_HIP_EMU_H

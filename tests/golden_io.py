@@ -1,0 +1,186 @@
+"""Parser for the golden vectors written by `oracle/_ref/ref_dump dump`
+(format documented in oracle/ref_dump.cc) and the lattice comparison used by
+both the emulator (CPU) and the GPU parity tests."""
+import struct
+
+import numpy as np
+
+EOS = -2147483646
+BOS = -2147483648
+
+
+class GoldSentence:
+    pass
+
+
+def read_gold(path):
+    data = open(path, 'rb').read()
+    assert data[:8] == b'JPPGOLD1'
+    pos = 8
+    hdr = struct.unpack_from('<9I', data, pos)
+    pos += 36
+    meta = dict(beam=hdr[0], gbeam=hdr[1], rcheck=hdr[2], rbeam=hdr[3], nscorers=hdr[4], npat=hdr[5],
+                entry=hdr[6], nph=hdr[7], nsent=hdr[8])
+    beam, npat, esz, nsc = meta['beam'], meta['npat'], meta['entry'], meta['nscorers']
+    sents = []
+    for _ in range(meta['nsent']):
+        g = GoldSentence()
+        g.status, g.ncp = struct.unpack_from('<II', data, pos)
+        pos += 8
+        if g.status != 0:
+            sents.append(g)
+            continue
+        (nb,) = struct.unpack_from('<I', data, pos)
+        pos += 4
+        g.bnds = []
+        for b in range(nb):
+            R, L = struct.unpack_from('<II', data, pos)
+            pos += 8
+            ends = np.frombuffer(data, dtype='<u2', count=2 * L, offset=pos).reshape(-1, 2).copy()
+            pos += 4 * L
+            (ngb,) = struct.unpack_from('<I', data, pos)
+            pos += 4
+            gb = np.frombuffer(data, dtype=np.dtype([('left', '<u2'), ('beam', '<u2'), ('score', '<f4')]),
+                               count=ngb, offset=pos).copy()
+            pos += 8 * ngb
+            node_dt = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2'), ('unk', '<i4', (4,)),
+                                ('entry', '<i4', (esz,)), ('pat', '<u8', (npat,)), ('t0', '<f4'),
+                                ('kept', '<u4'),
+                                ('beam', np.dtype([('cp', '<u2', (4,)), ('prev', '<u2', (4,)), ('total', '<f4'),
+                                                   ('valid', '<u4')]), (beam,)),
+                                ('cells', '<f4', (ngb * nsc,))])
+            nodes = np.frombuffer(data, dtype=node_dt, count=R, offset=pos).copy()
+            pos += node_dt.itemsize * R
+            g.bnds.append(dict(R=R, L=L, ends=ends, gbeam=gb, nodes=nodes))
+        (npath,) = struct.unpack_from('<I', data, pos)
+        pos += 4
+        g.path = np.frombuffer(data, dtype='<u2', count=2 * npath, offset=pos).reshape(-1, 2).copy()
+        pos += 4 * npath
+        (tlen,) = struct.unpack_from('<I', data, pos)
+        pos += 4
+        g.text = data[pos:pos + tlen].decode('utf-8')
+        pos += tlen
+        pos = (pos + 7) & ~7
+        sents.append(g)
+    assert pos == len(data), (pos, len(data))
+    return meta, sents
+
+
+def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
+    """Compare sentence `s` of a fully fetched jumanpp_amd Result with golden `g`.
+    Returns a list of mismatch strings (empty == parity)."""
+    errs = []
+
+    def bad(msg):
+        errs.append('sent %d: %s' % (s, msg))
+        return errs
+
+    if g.status != 0:
+        if res.status[s] == 0:
+            bad('reference failed but device status is OK')
+        return errs
+    if res.status[s] != 0:
+        return bad('device status %d, reference OK' % res.status[s])
+    if res.ncp[s] != g.ncp:
+        return bad('codepoints %d vs %d' % (res.ncp[s], g.ncp))
+    nb = len(g.bnds)
+    nbase = int(res.node_base[s])
+    bbase = int(res.bnd_base[s])
+    beam = meta['beam']
+    N = int(res.nnodes[s])
+    total_ref = sum(b['R'] for b in g.bnds)
+    if total_ref != N:
+        bad('node count %d vs reference %d' % (N, total_ref))
+    for b in range(nb):
+        gb = g.bnds[b]
+        R = int(res.bnd_count[bbase + b])
+        first = int(res.bnd_first[bbase + b])
+        if R != gb['R']:
+            bad('boundary %d: R %d vs %d' % (b, R, gb['R']))
+            continue
+        # ends
+        if b >= 1:
+            L = int(res.end_count[bbase + b])
+            if L != gb['L']:
+                bad('boundary %d: L %d vs %d' % (b, L, gb['L']))
+            else:
+                ef = int(res.end_first[bbase + b])
+                for l in range(L):
+                    node = int(res.end_nodes[nbase + ef + l])
+                    rb, rp = int(gb['ends'][l][0]), int(gb['ends'][l][1])
+                    exp = int(res.bnd_first[bbase + rb]) + rp
+                    if node != exp:
+                        bad('boundary %d: end %d is node %d, reference node %d' % (b, l, node, exp))
+        scored = b >= 2 and R > 0
+        if scored:
+            ngb = int(res.gbeam_count[bbase + b])
+            if ngb != len(gb['gbeam']):
+                bad('boundary %d: gbeam size %d vs %d' % (b, ngb, len(gb['gbeam'])))
+            else:
+                for i in range(ngb):
+                    e = res.gbeam_entries[bbase + b][i]
+                    r = gb['gbeam'][i]
+                    if e['left'] != r['left'] or e['beam'] != r['beam']:
+                        bad('boundary %d: gbeam[%d] (%d,%d) vs (%d,%d)' % (b, i, e['left'], e['beam'], r['left'], r['beam']))
+        for r in range(R):
+            k = nbase + first + r
+            gn = gb['nodes'][r]
+            nd = res.nodes[k]
+            if nd['start'] != gn['start'] or nd['end'] != gn['end']:
+                bad('b%d n%d: span (%d,%d) vs (%d,%d)' % (b, r, nd['start'], nd['end'], gn['start'], gn['end']))
+                continue
+            ge = int(gn['eptr'])
+            if ge >= 0 or ge in (BOS, EOS):
+                if int(nd['eptr']) != ge:
+                    bad('b%d n%d: eptr %d vs %d' % (b, r, nd['eptr'], ge))
+            else:
+                u = res.unk[k]
+                if int(nd['eptr']) >= 0:
+                    bad('b%d n%d: dictionary node where reference has UNK' % (b, r))
+                if (int(u['tmpl']), int(u['hash']), int(u['ph0']), int(u['ph1'])) != tuple(int(x) for x in gn['unk']):
+                    bad('b%d n%d: unk (%d,%d,%d,%d) vs %s' % (b, r, u['tmpl'], u['hash'], u['ph0'], u['ph1'], gn['unk']))
+            if not scored:
+                continue
+            if not np.array_equal(res.entry_rows[k], gn['entry']):
+                bad('b%d n%d: entry row %s vs %s' % (b, r, res.entry_rows[k], gn['entry']))
+            if not np.array_equal(res.patterns[k], gn['pat']):
+                bad('b%d n%d: patterns differ' % (b, r))
+            if check_scores:
+                a, e = np.float32(res.t0[k]), np.float32(gn['t0'])
+                if (tol == 0.0 and a.view('<u4') != e.view('<u4')) or (tol > 0 and abs(float(a) - float(e)) > tol):
+                    bad('b%d n%d: T0 %r vs %r' % (b, r, float(a), float(e)))
+            if int(res.kept[k]) != int(gn['kept']) and len(gb['gbeam']) > 0:
+                bad('b%d n%d: kept %d vs %d' % (b, r, res.kept[k], gn['kept']))
+            for q in range(beam):
+                sl = res.beams[k][q]
+                gs = gn['beam'][q]
+                fake = sl['left'] == 0xffff and sl['beam'] == 0xffff
+                if gs['valid'] == 0:
+                    if not fake:
+                        bad('b%d n%d slot %d: live where reference is fake' % (b, r, q))
+                    continue
+                if fake:
+                    bad('b%d n%d slot %d: fake where reference is live' % (b, r, q))
+                    continue
+                if sl['left'] != gs['cp'][1] or sl['beam'] != gs['cp'][3]:
+                    bad('b%d n%d slot %d: (left,beam)=(%d,%d) vs (%d,%d)' % (b, r, q, sl['left'], sl['beam'], gs['cp'][1], gs['cp'][3]))
+                pb, pr = int(gs['prev'][0]), int(gs['prev'][1])
+                exp_prev = int(res.bnd_first[bbase + pb]) + pr
+                if int(sl['prev_node']) != exp_prev:
+                    bad('b%d n%d slot %d: prev node %d vs %d' % (b, r, q, sl['prev_node'], exp_prev))
+                if check_scores and meta['nscorers'] == 1:
+                    a, e = np.float32(sl['total']), np.float32(gs['total'])
+                    if (tol == 0.0 and a.view('<u4') != e.view('<u4')) or (tol > 0 and abs(float(a) - float(e)) > tol):
+                        bad('b%d n%d slot %d: total %r vs %r' % (b, r, q, float(a), float(e)))
+    # top-1 path
+    plen = int(res.path_len[s])
+    if plen != len(g.path):
+        bad('path length %d vs %d' % (plen, len(g.path)))
+    else:
+        for i in range(plen):
+            node = int(res.path_nodes[nbase + i])
+            pb, pr = int(g.path[i][0]), int(g.path[i][1])
+            exp = int(res.bnd_first[bbase + pb]) + pr
+            if node != exp:
+                bad('path[%d]: node %d vs %d' % (i, node, exp))
+    return errs
