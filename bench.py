@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py -- sentences/sec of the Juman++ analysis hot path on MI355X.
+
+One "step" = one pass of the whole hot path (decode -> seeds -> lattice -> T0
+-> global-beam sweep -> top-1 path) over one batch of 65,536 synthetic
+40-codepoint sentences that is already resident in HBM.  Workload =
+BASELINE.json configs[1]: perceptron scorer only, beam 5 (global beam 6,
+right-check 1, right-beam 5 = the CLI defaults), 1M sentences batched 64k.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the
+definition of the roofline and cpu_baseline objects.
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+REF = os.path.join(ROOT, 'oracle', '_ref')
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_workload(args, cache_dir):
+    """synthetic dictionary + random perceptron + corpus, built with the
+    reference's own offline tools (oracle/_ref) -- untimed setup."""
+    os.makedirs(cache_dir, exist_ok=True)
+    key = 'd%d_w%d_s%d' % (args.dict_entries, args.weights_exp, args.seed)
+    mdic = os.path.join(cache_dir, key + '.mdic')
+    model = os.path.join(cache_dir, key + '.model')
+    img = os.path.join(cache_dir, key + '.img')
+    if not os.path.exists(img):
+        with open(mdic, 'w', encoding='utf-8') as f:
+            subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_dict.py'), str(args.dict_entries),
+                                   '--seed', str(args.seed)], stdout=f)
+        seed_model = os.path.join(cache_dir, key + '.seed')
+        subprocess.check_call([os.path.join(REF, 'jpp_jumandic_bootstrap'), mdic, seed_model],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(REF, 'ref_dump'), 'mkmodel', seed_model, model, str(args.weights_exp),
+                               str(args.seed), '0.1'])
+        subprocess.check_call([os.path.join(REF, 'ref_dump'), 'export', model, img], stderr=subprocess.DEVNULL)
+    return mdic, model, img
+
+
+def make_corpus(args, mdic, cache_dir, n_lines, seed):
+    path = os.path.join(cache_dir, 'corpus_%d_%d_%d.txt' % (n_lines, args.sent_len, seed))
+    if not os.path.exists(path):
+        with open(path, 'w', encoding='utf-8') as f:
+            subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines),
+                                   '--seed', str(seed), '--len', str(args.sent_len), '--oov', '0.05'], stdout=f)
+    return path
+
+
+def load_batches(path, batch, np):
+    data = open(path, 'rb').read()
+    lines = data.split(b'\n')
+    if lines and lines[-1] == b'':
+        lines.pop()
+    out = []
+    for i in range(0, len(lines), batch):
+        chunk = lines[i:i + batch]
+        if len(chunk) < batch:
+            break
+        offs = np.zeros(len(chunk) + 1, dtype=np.uint32)
+        offs[1:] = np.cumsum([len(c) for c in chunk])
+        out.append((b''.join(chunk), offs))
+    return out
+
+
+def algorithmic_bytes(res, cfg_beam, cfg_gbeam, rcheck, rbeam, np):
+    """Algorithmic HBM bytes of one batch, per kernel, from the fetched lattice
+    (DESIGN.md "Algorithmic bytes").  4 B per weight gather, no sector rounding."""
+    ok = res.status == 0
+    N = int(res.nnodes[ok].sum())
+    # T0 kernel: node info+aux (24) + entry row read (~12 varint bytes) + 32 gathers + writes (entry 32, pat 112, t0 4)
+    t0_bytes = N * (24 + 12 + 32 * 4 + 32 + 112 + 4)
+    total = 0
+    R = res.bnd_count.astype(np.int64)
+    L = res.end_count.astype(np.int64)
+    ngb = res.gbeam_count.astype(np.int64)
+    scored = np.zeros(len(R), dtype=bool)
+    for s in np.nonzero(ok)[0]:
+        b0 = int(res.bnd_base[s])
+        scored[b0 + 2: b0 + int(res.ncp[s]) + 3] = True
+    scored &= R > 0
+    Rs, Ls, Gs = R[scored], L[scored], ngb[scored]
+    gl = res.gbeam_entries['left'][scored]
+    U = np.zeros(len(Rs), dtype=np.int64)
+    for j in range(cfg_gbeam):
+        col = gl[:, j]
+        new = Gs > j
+        for k in range(j):
+            new &= ~((gl[:, k] == col) & (Gs > k))
+        U += new
+    c = np.minimum(np.minimum(rcheck, Rs), Gs)
+    K = np.minimum(rbeam, Rs) if rcheck > 0 else Rs
+    slot = 16
+    sweep = (Ls * cfg_beam * slot                      # left beams read for the global beam
+             + (U + Gs) * 112                           # T1 / T2 pattern rows
+             + Rs * (112 + 4)                           # right-node patterns + T0
+             + 4 * (c * Rs * 41 + K * (U * 37 + np.maximum(Gs - c, 0) * 4))  # bi/tri weight gathers
+             + Rs * cfg_beam * slot                     # beams written
+             + (K * Gs + (Rs - K) * c) * 4)             # score cells written
+    return dict(t0=int(t0_bytes), sweep=int(sweep.sum()), nodes=N)
+
+
+def cpu_baseline(args, model, mdic, cache_dir):
+    corpus = make_corpus(args, mdic, cache_dir, args.cpu_sample, args.seed + 1000)
+    t = time.time()
+    with open(corpus, 'rb') as f:
+        out = subprocess.check_output([os.path.join(REF, 'ref_dump'), 'time', model], stdin=f)
+    r = json.loads(out.decode())
+    return {
+        'value': round(r['sent_per_s_analyze'], 1),
+        'unit': 'sentences/s',
+        'cores': 1,
+        'kind': 'reference',
+        'sample': '%d sentences of the same synthetic workload through the reference Analyzer::analyze '
+                  '(oracle/_ref, g++ -O2 -march=haswell, 1 thread, best of 3; %.1f s wall)'
+                  % (r['sentences'], time.time() - t),
+        'with_juman_format': round(r['sent_per_s_total'], 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=65536)
+    ap.add_argument('--sent-len', type=int, default=40)
+    ap.add_argument('--dict-entries', type=int, default=300000)
+    ap.add_argument('--weights-exp', type=int, default=22)
+    ap.add_argument('--seed', type=int, default=20260925)
+    ap.add_argument('--cpu-sample', type=int, default=20000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cache', default=os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache'))
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as ge
+    ge.build_native()
+    import jumanpp_amd as J
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')
+    cache = args.cache + ('_r%d' % rank if world > 1 else '')
+
+    mdic, model, img = make_workload(args, cache)
+    n_batches = min(16, args.steps + args.warmup)
+    # sentences shard embarrassingly: every rank analyses its own distinct lines (weak scaling)
+    corpus = make_corpus(args, mdic, cache, args.batch * n_batches, args.seed + 1 + rank)
+    batches = load_batches(corpus, args.batch, np)
+    log('[rank %d] workload ready: %d batches of %d sentences' % (rank, len(batches), args.batch))
+
+    ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank)
+    dev = torch.device('cuda', local_rank)
+    d_batches = []
+    for text, offs in batches:
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+        o = torch.from_numpy(offs.astype(np.int32).view(np.int32)).to(dev)
+        d_batches.append((t, o, len(offs) - 1, len(text)))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        t, o, n, nbytes = d_batches[i % len(d_batches)]
+        r = ctx.analyze_device(t.data_ptr(), o.data_ptr(), n, nbytes, stream)
+        return r
+
+    for i in range(args.warmup):
+        step(i).release()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = {}
+    total_path = 0
+    for i in range(args.steps):
+        r = step(args.warmup + i)
+        _, npath = r.stats()  # forces completion of the batch; 4 bytes/sentence D2H
+        total_path += npath
+        for k, v in ctx.timings().items():
+            kernel_ms[k] = kernel_ms.get(k, 0.0) + v
+        r.release()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    sentences = args.batch * args.steps * world
+    value = sentences / elapsed
+
+    out = None
+    if rank == 0:
+        # algorithmic bytes of one representative batch (untimed)
+        r = step(0).fetch(full=True)
+        ab = algorithmic_bytes(r, 5, 6, 1, 5, np)
+        bad = int((r.status != 0).sum())
+        r.release()
+        avg = {k: v / args.steps for k, v in kernel_ms.items()}
+        dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'
+        achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        out = {
+            'metric': 'sentences/sec whole-node, beam=5 jumandic perceptron (RNN off); achieved HBM GB/s',
+            'value': round(value, 1),
+            'unit': 'sentences/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'u64 hashing + f32 adds',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'BASELINE configs[1]: 1xMI355X per rank, linear perceptron scorer only (RNN off), '
+                            'beam=5 gbeam=6 rcheck=1 rbeam=5, synthetic %d-codepoint UTF-8 sentences batched %d, '
+                            '%d-entry synthetic jumandic-layout dictionary, 2^%d random weights'
+                            % (args.sent_len, args.batch, args.dict_entries, args.weights_exp),
+                'sentences_per_step_per_gpu': args.batch,
+                'nodes_per_sentence': round(ab['nodes'] / args.batch, 1),
+                'failed_sentences_in_batch': bad,
+                'parallelism': 'sentence-sharded x%d, no data-path collective' % world,
+            },
+            'kernel_ms_per_step': {k: round(v, 3) for k, v in avg.items()},
+            'roofline': {
+                'bound': 'hbm',
+                'kernel': 'k_' + dom,
+                'achieved': round(achieved, 2),
+                'peak': 8000.0,
+                'unit': 'GB/s',
+                'frac': round(achieved / 8000.0, 5),
+                'traffic': None,
+                'algorithmic_bytes_per_launch': ab[dom],
+                'avg_launch_ms': round(avg[dom], 3),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
+        print(json.dumps(out, ensure_ascii=False), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

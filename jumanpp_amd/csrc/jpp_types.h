@@ -11,7 +11,7 @@ constexpr int kMaxDicFeatures = 16;
 constexpr int kPat = 14;          // stored patterns per node (jumandic spec)
 constexpr int kMaxGbeam = 16;     // exact stable-rank beam forming holds for <= 16 (std::sort == insertion sort)
 constexpr int kMaxBeam = 16;
-constexpr int kMaxRight = 256;    // right nodes per boundary staged in LDS by the sweep kernel
+constexpr int kMaxRight = 512;    // right nodes per boundary staged in LDS by the sweep kernel
 constexpr int kMaxNormStates = 48;
 constexpr int kMaxNormResults = 48;
 

@@ -159,7 +159,6 @@ struct jppgpu_ctx {
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
   DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
       path_nodes;
-  jppgpu_result result;
   u64 generation = 0;
   Timer timer;
   float last_ms[8] = {0};
@@ -338,8 +337,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
   ctx->generation++;
-  jppgpu_result& R = ctx->result;
-  R = jppgpu_result();
+  jppgpu_result* Rp = new jppgpu_result();
+  jppgpu_result& R = *Rp;
   R.ctx = ctx;
   R.generation = ctx->generation;
   Batch& B = R.B;
@@ -371,7 +370,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.bnd_gbeam = ctx->bnd_gbeam.as<GbeamEntry>();
   if (n == 0) {
     B.total_nodes = 0;
-    *out = &R;
+    *out = Rp;
     return JPPGPU_OK;
   }
 
@@ -438,7 +437,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(JPPGPU_INVALID_STATE, std::string("kernel launch failed: ") + hipGetErrorString(e));
 #endif
-  *out = &R;
+  *out = Rp;
   return JPPGPU_OK;
 }
 
@@ -573,14 +572,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
 }
 
 extern "C" void jppgpu_result_release(jppgpu_result* res) {
-  if (!res) return;
-  // results are views on the context's workspace (same lifetime rule as the
-  // reference: valid until the next analyze on that Analyzer); drop host copies.
-  jppgpu_ctx* ctx = res->ctx;
-  u64 gen = res->generation;
-  Batch B = res->B;
-  *res = jppgpu_result();
-  res->ctx = ctx;
-  res->generation = gen;
-  res->B = B;
+  // results are views on the context workspace (same lifetime rule as the reference:
+  // valid until the next analyze on that Analyzer); this drops the handle and host copies.
+  delete res;
 }

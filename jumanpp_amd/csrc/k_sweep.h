@@ -58,7 +58,7 @@ struct NgramTables {
 constexpr NgramTables kNg{};
 
 constexpr int kChunk = 16;      // kept right nodes processed per pass
-constexpr int kPresCap = 512;   // rcheck * R prescores staged in LDS
+constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
 __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == kFake16 && s.beam == kFake16; }
 
@@ -97,6 +97,13 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
   __shared__ float biS[kChunk][kMaxGbeam];
   __shared__ float tot[kChunk][kMaxGbeam];
 
+  if (n == 0) {
+    // empty input: the reference returns before scoring anything
+    // (computeScoresGbeam: bndCount <= 3, analyzer_impl.cc:255-258)
+    for (int q = lane; q < beam; q += 64) beams[(u64)2 * beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+    if (lane == 0) B.bnd_ngb[bb0 + 2] = 0;
+    return;
+  }
   for (u32 b = 2; b <= n + 2; ++b) {
     const u32 R = B.bnd_cnt[bb0 + b];
     if (R == 0) continue;

@@ -158,7 +158,15 @@ class Result:
         return a.value, b.value
 
     def release(self):
-        self.ctx.lib.jppgpu_result_release(self.handle)
+        if self.handle:
+            self.ctx.lib.jppgpu_result_release(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class Context:

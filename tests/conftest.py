@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(scope='session')
+def emu_lib():
+    """TEST ONLY: kernel sources built against the CPU fiber emulator."""
+    import __graft_entry__ as ge
+    return ge.build_emu()
+
+
+@pytest.fixture(scope='session')
+def gpu_lib():
+    import __graft_entry__ as ge
+    return ge.build_native()
+
+
+@pytest.fixture(scope='session')
+def ref_tools():
+    """oracle/_ref binaries (real reference); None if they were not built."""
+    d = os.path.join(ROOT, 'oracle', '_ref')
+    need = ['ref_dump', 'jpp_jumandic_bootstrap', 'jumanpp_v2']
+    if all(os.path.exists(os.path.join(d, n)) for n in need):
+        return d
+    return None

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Regenerates the committed golden fixtures from the REAL reference (oracle/_ref,
+# built by oracle/Makefile from /root/reference).  Run in the build container:
+#   bash tests/golden/make_golden.sh
+# Inputs are fully synthetic and seeded (tools/gen_dict.py, tools/gen_corpus.py).
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+REF="$ROOT/oracle/_ref"
+TMP="$(mktemp -d)"
+python3 "$ROOT/tools/gen_dict.py" 2500 --seed 11 > "$TMP/mini.mdic"
+"$REF/jpp_jumandic_bootstrap" "$TMP/mini.mdic" "$TMP/mini.seed" > /dev/null 2>&1
+"$REF/ref_dump" mkmodel "$TMP/mini.seed" "$TMP/mini.model" 14 20260925 0.1
+"$REF/ref_dump" export "$TMP/mini.model" "$HERE/mini.img"
+{
+  python3 "$ROOT/tools/gen_corpus.py" "$TMP/mini.mdic" 20 --seed 21 --oov 0.15 --len 40
+  python3 "$ROOT/tools/gen_corpus.py" "$TMP/mini.mdic" 2 --seed 22 --oov 0.2 --len 90
+  # edge cases: empty line, single char, ASCII only, digits with separators, prolong/small kana, onomatopoeia
+  printf '\n'
+  printf 'あ\n'
+  printf 'hello, world (test) [x]\n'
+  printf '１２，３４５．６７キロ数十何百分の一ぶんの３\n'
+  printf 'すごーーい〜かぁっこいいねぇっッ！ケーキとヶ月\n'
+  printf 'どきどきドキドキわんわんわんわんぱたぱたた\n'
+} > "$HERE/mini.txt"
+"$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini.gold" < "$HERE/mini.txt"
+"$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini_b3.gold" 3 4 2 3 < "$HERE/mini.txt"
+"$REF/jumanpp_v2" --model="$TMP/mini.model" "$HERE/mini.txt" > "$HERE/mini.juman.txt"
+rm -rf "$TMP"
+ls -la "$HERE"

@@ -111,7 +111,7 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
                     exp = int(res.bnd_first[bbase + rb]) + rp
                     if node != exp:
                         bad('boundary %d: end %d is node %d, reference node %d' % (b, l, node, exp))
-        scored = b >= 2 and R > 0
+        scored = b >= 2 and R > 0 and nb > 3
         if scored:
             ngb = int(res.gbeam_count[bbase + b])
             if ngb != len(gb['gbeam']):

@@ -1,0 +1,124 @@
+"""CPU-side tests (pytest -m "not gpu"): the kernel sources, executed by the
+fiber emulator, against golden vectors produced by the real reference; the
+libstdc++ nth_element restatement against std::nth_element; C-ABI exports."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_io as G
+import jumanpp_amd as J
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_golden(lib, golden_dir, gold_name, **cfg):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=lib, **cfg)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    meta, gold = G.read_gold(os.path.join(golden_dir, gold_name))
+    assert meta['nsent'] == len(lines)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+    return res
+
+
+def test_emulated_kernels_match_reference_default_config(emu_lib, golden_dir):
+    res = _run_golden(emu_lib, golden_dir, 'mini.gold')
+    assert int(res.nnodes.sum()) > 2000
+
+
+def test_emulated_kernels_match_reference_other_beam_config(emu_lib, golden_dir):
+    # beam 3, global beam 4, right-check 2, right-beam 3
+    _run_golden(emu_lib, golden_dir, 'mini_b3.gold', beam=3, global_beam=4, right_check=2, right_beam=3)
+
+
+def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
+    # reference: invalid UTF-8 -> InvalidParameter (characters.cc:267-269);
+    # > 4096 bytes -> InvalidParameter (analysis_input.cc:13-17)
+    sents = [b'\xe3\x81', b'ok', b'\xff\xfe', ('あ' * 1400).encode('utf-8'), b'']
+    res = ctx.analyze(sents).fetch(full=True)
+    assert list(res.status) == [2, 0, 2, 1, 0]
+    assert res.path_len[1] > 0 and res.path_len[4] == 0
+
+
+def test_config_validation_mirrors_reference(emu_lib, golden_dir):
+    img = os.path.join(golden_dir, 'mini.img')
+    with pytest.raises(J.JppGpuError, match='beam size can not be zero'):
+        J.Context(img, lib_path=emu_lib, beam=0)
+    with pytest.raises(J.JppGpuError, match='right global beam size'):
+        J.Context(img, lib_path=emu_lib, right_check=1, right_beam=0)
+    with pytest.raises(J.JppGpuError, match='not implemented'):
+        J.Context(img, lib_path=emu_lib, global_beam=0)
+
+
+def test_result_invalidated_by_next_batch(emu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
+    r1 = ctx.analyze(['あいう'])
+    ctx.analyze(['かきく'])
+    with pytest.raises(J.JppGpuError, match='invalidated'):
+        r1.fetch()
+
+
+def test_nth_element_restatement_matches_libstdcxx(tmp_path):
+    src = tmp_path / 'sel.cc'
+    src.write_text(r'''
+#include <algorithm>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "jpp_select.h"
+int main() {
+  std::mt19937 rng(12345);
+  long bad = 0, cases = 0;
+  for (int n = 1; n <= 200; ++n) {
+    for (int rep = 0; rep < 60; ++rep) {
+      int levels = 1 + rng() % 6;  // few distinct scores => many ties
+      std::vector<float> sc(n);
+      for (auto& x : sc) x = (float)(rng() % levels) * 0.25f - (rep % 3 == 0 ? 0.f : (float)(rng() % 1000) * (rep % 2 ? 0.f : 1e-3f));
+      for (int k = 0; k <= n; ++k) {
+        if (rep % 7 && k != (int)(rng() % (n + 1))) continue;
+        std::vector<u16> a(n), b(n);
+        for (int i = 0; i < n; ++i) a[i] = b[i] = (u16)i;
+        auto cmp = [&](u16 x, u16 y) { return sc[x] > sc[y]; };
+        std::nth_element(a.begin(), a.begin() + k, a.end(), cmp);
+        jpp::ScoreGreater g{sc.data()};
+        jpp::nth_element_u16(b.data(), b.data() + k, b.data() + n, g);
+        ++cases;
+        if (a != b) ++bad;
+      }
+    }
+  }
+  printf("%ld %ld\n", cases, bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / 'sel'
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-DJPP_EMU', '-I', os.path.join(ROOT, 'tests', 'emu'),
+                           '-I', os.path.join(ROOT, 'jumanpp_amd', 'csrc'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) > 5000 and int(out[1]) == 0
+
+
+def test_c_abi_exports_every_declared_symbol(gpu_lib):
+    hdr = open(os.path.join(ROOT, 'include', 'jppgpu.h')).read()
+    names = set(re.findall(r'\b(jppgpu_[a-z_]+)\s*\(', hdr))
+    assert {'jppgpu_ctx_create', 'jppgpu_analyze_batch', 'jppgpu_analyze_batch_device', 'jppgpu_result_fetch',
+            'jppgpu_result_release', 'jppgpu_ctx_destroy', 'jppgpu_last_error'} <= names
+    lib = ctypes.CDLL(gpu_lib)  # loads without a GPU; only symbol presence is checked here
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_product_library_fails_loudly_without_gpu(gpu_lib, golden_dir):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(J.JppGpuError, match='no HIP device'):
+        J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=gpu_lib)

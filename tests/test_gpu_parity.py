@@ -1,0 +1,117 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI,
+against (a) the committed golden vectors of the real reference and (b) fresh
+golden vectors produced on this box by oracle/_ref (the real reference binary
+travels with the snapshot) for a larger seeded synthetic workload."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import golden_io as G
+import jumanpp_amd as J
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compare_all(res, gold, meta, n):
+    errs = []
+    for s in range(n):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    return errs
+
+
+def test_gpu_matches_reference_goldens(gpu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=gpu_lib)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    meta, gold = G.read_gold(os.path.join(golden_dir, 'mini.gold'))
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, errs[:10]
+
+
+def test_gpu_matches_reference_other_beam_config(gpu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=gpu_lib, beam=3, global_beam=4,
+                    right_check=2, right_beam=3)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    meta, gold = G.read_gold(os.path.join(golden_dir, 'mini_b3.gold'))
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, errs[:10]
+
+
+def test_gpu_status_codes(gpu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=gpu_lib)
+    sents = [b'\xe3\x81', b'ok', b'\xff\xfe', ('あ' * 1400).encode('utf-8'), b'']
+    res = ctx.analyze(sents).fetch(full=True)
+    assert list(res.status) == [2, 0, 2, 1, 0]
+
+
+def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40):
+    mdic = os.path.join(tmp, 'w.mdic')
+    with open(mdic, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)],
+                              stdout=f)
+    subprocess.check_call([os.path.join(ref_tools, 'jpp_jumandic_bootstrap'), mdic, os.path.join(tmp, 'w.seed')],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'mkmodel', os.path.join(tmp, 'w.seed'),
+                           os.path.join(tmp, 'w.model'), str(exp), str(seed), '0.1'])
+    subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'export', os.path.join(tmp, 'w.model'),
+                           os.path.join(tmp, 'w.img')], stderr=subprocess.DEVNULL)
+    txt = os.path.join(tmp, 'w.txt')
+    with open(txt, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines), '--seed',
+                               str(seed + 1), '--oov', '0.08', '--len', str(length)], stdout=f)
+    with open(txt, 'rb') as f:
+        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', os.path.join(tmp, 'w.model'),
+                               os.path.join(tmp, 'w.gold')], stdin=f, stderr=subprocess.DEVNULL)
+    lines = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
+    return os.path.join(tmp, 'w.img'), lines, os.path.join(tmp, 'w.gold')
+
+
+def test_gpu_matches_live_reference_on_fresh_workload(gpu_lib, ref_tools, tmp_path):
+    """2000 fresh 40-codepoint sentences, 30k-entry dictionary, 2^20 random weights:
+    every node, pattern, T0 score, global beam, beam slot and top-1 path must be
+    bit-identical to the reference running on this box's CPU."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 30000, 2000, 20, 77)
+    ctx = J.Context(img, lib_path=gpu_lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
+
+
+def test_gpu_long_sentences(gpu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 8000, 100, 18, 91, length=220)
+    ctx = J.Context(img, lib_path=gpu_lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
+
+
+def test_gpu_batch_split_invariance(gpu_lib, golden_dir):
+    """size-independent property: analysing a batch in one call or sentence by
+    sentence gives identical top-1 paths and totals."""
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=gpu_lib)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')] * 40
+    res = ctx.analyze(lines).fetch(full=True)
+    whole = []
+    for s in range(len(lines)):
+        nb = int(res.node_base[s])
+        pl = int(res.path_len[s])
+        nodes = res.nodes[nb + res.path_nodes[nb:nb + pl]]
+        tot = res.beams[nb + int(res.nnodes[s]) - 1][0]['total'] if res.nnodes[s] else 0.0
+        whole.append((tuple((int(x['start']), int(x['end']), int(x['eptr'])) for x in nodes if x['eptr'] >= 0 or True), float(tot)))
+    for s in range(0, 28):
+        assert whole[s] == whole[s + 28 * 7]
+    res1 = ctx.analyze(lines[3:4]).fetch(full=True)
+    pl = int(res1.path_len[0])
+    nodes = res1.nodes[res1.path_nodes[:pl]]
+    one = tuple((int(x['start']), int(x['end']), int(x['eptr'])) for x in nodes)
+    assert one == whole[3][0]
