@@ -151,6 +151,73 @@ __device__ inline void nth_element_u16(u16* first, u16* nth, u16* last, C comp) 
   sel_insertion_sort(first, last, comp);
 }
 
+// std::sort (GCC 11 bits/stl_algo.h: __introsort_loop with threshold 16, then
+// __final_insertion_sort).  For n <= 16 this is a plain (stable) insertion sort.
+template <typename T, typename C>
+__device__ inline void std_sort(T* first, T* last, C comp) {
+  if (first == last) return;
+  long n = last - first;
+  long lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  // explicit stack instead of the recursion on the right half (the two halves are disjoint,
+  // so the processing order does not change the result)
+  T* stF[24];
+  T* stL[24];
+  long stD[24];
+  int sp = 0;
+  stF[sp] = first;
+  stL[sp] = last;
+  stD[sp] = lg * 2;
+  ++sp;
+  while (sp > 0) {
+    --sp;
+    T* f = stF[sp];
+    T* l = stL[sp];
+    long depth = stD[sp];
+    while (l - f > 16) {
+      if (depth == 0) {
+        // __partial_sort(f, l, l): make_heap + sort_heap
+        sel_heap_select(f, l, l, comp);
+        T* e = l;
+        while (e - f > 1) {
+          --e;
+          T value = *e;
+          *e = *f;
+          sel_adjust_heap(f, 0, (long)(e - f), value, comp);
+        }
+        break;
+      }
+      --depth;
+      T* mid = f + (l - f) / 2;
+      sel_move_median_to_first(f, f + 1, mid, l - 1, comp);
+      T* cut = sel_unguarded_partition(f + 1, l, f, comp);
+      if (sp < 24) {
+        stF[sp] = cut;
+        stL[sp] = l;
+        stD[sp] = depth;
+        ++sp;
+      }
+      l = cut;
+    }
+  }
+  if (last - first > 16) {
+    sel_insertion_sort(first, first + 16, comp);
+    for (T* i = first + 16; i != last; ++i) {
+      T val = *i;
+      T* lastp = i;
+      T* next = i - 1;
+      while (comp(val, *next)) {
+        *lastp = *next;
+        lastp = next;
+        --next;
+      }
+      *lastp = val;
+    }
+  } else {
+    sel_insertion_sort(first, last, comp);
+  }
+}
+
 }  // namespace jpp
 
 #endif  // JPP_SELECT_H

@@ -12,8 +12,8 @@ constexpr int kPat = 14;          // stored patterns per node (jumandic spec)
 constexpr int kMaxGbeam = 16;     // exact stable-rank beam forming holds for <= 16 (std::sort == insertion sort)
 constexpr int kMaxBeam = 16;
 constexpr int kMaxRight = 512;    // right nodes per boundary staged in LDS by the sweep kernel
-constexpr int kMaxNormStates = 48;
-constexpr int kMaxNormResults = 48;
+constexpr int kMaxNormStates = 64;
+constexpr int kMaxNormResults = 160;
 
 // entry pointers (reference src/core/core_types.h:44-58)
 constexpr i32 kEptrBOS = (i32)0x80000000;

@@ -21,6 +21,7 @@
 #define JPP_K_SEEDS_H
 
 #include "jpp_device.h"
+#include "jpp_select.h"
 #include "k_decode.h"
 
 namespace jpp {
@@ -407,18 +408,10 @@ __device__ inline int norm_lookup(const DevModel& M, const SentView& S, const Cl
   }
   if (overflow) return -1;
   if (nres == 0) return 0;
-  // util::sort == std::sort: an insertion sort (stable) for <= 16 elements.  More than 16
-  // candidates from one start would need libstdc++'s introsort order; report as capacity.
-  if (nres > 16) return -1;
-  for (int x = 1; x < nres; ++x) {
-    NormResult v = res[x];
-    int y = x - 1;
-    while (y >= 0 && (v.end == res[y].end ? v.ptr < res[y].ptr : v.end < res[y].end)) {
-      res[y + 1] = res[y];
-      --y;
-    }
-    res[y + 1] = v;
-  }
+  // util::sort == std::sort (charlattice.cc:347-353): exact libstdc++ order incl. ties
+  std_sort(res, res + nres, [](const NormResult& c1, const NormResult& c2) {
+    return c1.end == c2.end ? c1.ptr < c2.ptr : c1.end < c2.end;
+  });
   int m = 0;
   for (int x = 0; x < nres; ++x) {
     if (m > 0 && res[m - 1].ptr == res[x].ptr && res[m - 1].end == res[x].end) continue;

@@ -95,6 +95,21 @@ int main() {
       }
     }
   }
+  // std::sort restatement on structs with a partial key (ties keep libstdc++'s order)
+  struct It { int key; int tag; bool operator==(const It& o) const { return key == o.key && tag == o.tag; } };
+  for (int n = 1; n <= 300; ++n) {
+    for (int rep = 0; rep < 40; ++rep) {
+      int levels = 1 + rng() % (rep % 2 ? 5 : 50);
+      std::vector<It> a(n), b;
+      for (int i = 0; i < n; ++i) a[i] = It{(int)(rng() % levels), i};
+      b = a;
+      auto cmp = [](const It& x, const It& y) { return x.key < y.key; };
+      std::sort(a.begin(), a.end(), cmp);
+      jpp::std_sort(b.data(), b.data() + n, cmp);
+      ++cases;
+      if (!(a == b)) ++bad;
+    }
+  }
   printf("%ld %ld\n", cases, bad);
   return bad != 0;
 }

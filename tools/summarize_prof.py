@@ -1,37 +1,32 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 outputs (kernel stats CSV + PMC counter CSVs) into a
-small text summary that is committed under profiles/."""
-import csv
+"""Condense rocprofv3 rocpd databases (kernel trace + PMC passes) into a small
+text summary that is committed under profiles/.
+usage: summarize_prof.py <dir with prof_trace/ prof_fetch/ prof_write/>"""
 import glob
 import os
+import sqlite3
 import sys
 
 
-def find(root, pattern):
-    return sorted(glob.glob(os.path.join(root, '**', pattern), recursive=True))
+def dbs(root, sub):
+    return sorted(glob.glob(os.path.join(root, sub, '**', '*.db'), recursive=True))
 
 
 def main():
     out = sys.argv[1]
-    for f in find(os.path.join(out, 'prof_trace'), '*kernel_stats.csv'):
-        print('== kernel stats:', os.path.relpath(f, out))
-        rows = list(csv.DictReader(open(f)))
-        for r in rows[:20]:
-            print('  %-60s calls=%s total_ns=%s avg_ns=%s pct=%s' % (
-                r.get('Name', '')[:60], r.get('Calls'), r.get('TotalDurationNs'), r.get('AverageNs'),
-                r.get('Percentage')))
-    for name in ('prof_fetch', 'prof_write'):
-        for f in find(os.path.join(out, name), '*counter_collection.csv'):
-            print('== counters:', os.path.relpath(f, out))
-            agg = {}
-            for r in csv.DictReader(open(f)):
-                k = (r.get('Kernel_Name', '')[:50], r.get('Counter_Name'))
-                v = float(r.get('Counter_Value', 0) or 0)
-                a = agg.setdefault(k, [0, 0.0])
-                a[0] += 1
-                a[1] += v
-            for (kn, cn), (cnt, tot) in sorted(agg.items(), key=lambda x: -x[1][1])[:16]:
-                print('  %-50s %-12s dispatches=%d sum=%.0f avg=%.1f' % (kn, cn, cnt, tot, tot / cnt))
+    for db in dbs(out, 'prof_trace'):
+        con = sqlite3.connect(db)
+        print('== rocprofv3 --kernel-trace --stats (%s): name, calls, total_us, avg_us, pct' % os.path.relpath(db, out))
+        for name, calls, total, avg, pct in con.execute('select name,total_calls,total_duration,average,percentage from top_kernels'):
+            print('  %-78s %5d %12.1f %10.1f %6.2f' % (name[:78], calls, total, avg, pct))
+    for sub in ('prof_fetch', 'prof_write'):
+        for db in dbs(out, sub):
+            con = sqlite3.connect(db)
+            print('== rocprofv3 --pmc (%s): kernel, counter, dispatches, avg value (KB), avg duration us' % os.path.relpath(db, out))
+            q = ('select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection '
+                 'group by kernel_name, counter_name order by sum(value) desc')
+            for kn, cn, n, v, d in con.execute(q):
+                print('  %-70s %-11s %4d %14.1f %10.1f' % (kn[:70], cn, n, v, d / 1e3))
 
 
 if __name__ == '__main__':
