@@ -32,7 +32,7 @@ def make_workload(args, cache_dir):
     """synthetic dictionary + random perceptron + corpus, built with the
     reference's own offline tools (oracle/_ref) -- untimed setup."""
     os.makedirs(cache_dir, exist_ok=True)
-    key = 'd%d_w%d_s%d' % (args.dict_entries, args.weights_exp, args.seed)
+    key = 'd%d_w%d_s%d%s' % (args.dict_entries, args.weights_exp, args.seed, '_rnn%d' % args.rnn_hidden if args.rnn else '')
     mdic = os.path.join(cache_dir, key + '.mdic')
     model = os.path.join(cache_dir, key + '.model')
     img = os.path.join(cache_dir, key + '.img')
@@ -45,6 +45,19 @@ def make_workload(args, cache_dir):
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         subprocess.check_call([os.path.join(REF, 'ref_dump'), 'mkmodel', seed_model, model, str(args.weights_exp),
                                str(args.seed), '0.1'])
+        if args.rnn:
+            # BASELINE configs[2]: + synthetic faster-rnnlm NCE model embedded by the reference's trainer binary
+            rnn = os.path.join(cache_dir, key + '.rnnlm')
+            subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_rnn.py'), mdic, rnn, '--vocab',
+                                   str(args.rnn_vocab), '--hidden', str(args.rnn_hidden), '--maxent-size',
+                                   str(1 << 22), '--seed', str(args.seed)], stdout=subprocess.DEVNULL)
+            pmodel = model + '.perceptron'
+            os.rename(model, pmodel)
+            subprocess.check_call([os.path.join(REF, 'jumanpp_v2_train'), '--model-input=' + pmodel,
+                                   '--model-output=' + model, '--rnn-model=' + rnn, '--rnn-fields=surface,pos',
+                                   '--rnn-nce-bias=5.62844432562', '--rnn-unk-constant=-3.4748115191',
+                                   '--rnn-unk-length=-2.92994951022', '--feature-weight-perceptron=1',
+                                   '--feature-weight-rnn=0.0176'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         subprocess.check_call([os.path.join(REF, 'ref_dump'), 'export', model, img], stderr=subprocess.DEVNULL)
     return mdic, model, img
 
@@ -141,6 +154,9 @@ def main():
     ap.add_argument('--seed', type=int, default=20260925)
     ap.add_argument('--cpu-sample', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rnn', action='store_true', help='BASELINE configs[2]: perceptron + RNNLM re-ranker')
+    ap.add_argument('--rnn-hidden', type=int, default=128)
+    ap.add_argument('--rnn-vocab', type=int, default=30000)
     ap.add_argument('--cache', default=os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache'))
     args = ap.parse_args()
 
@@ -222,7 +238,7 @@ def main():
         dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'
         achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         out = {
-            'metric': 'sentences/sec whole-node, beam=5 jumandic perceptron (RNN off); achieved HBM GB/s',
+            'metric': 'sentences/sec whole-node, beam=5 jumandic %s; achieved HBM GB/s' % ('+RNNLM' if args.rnn else 'perceptron (RNN off)'),
             'value': round(value, 1),
             'unit': 'sentences/s',
             'n_gpus': world,
@@ -235,7 +251,7 @@ def main():
             'dtype': 'u64 hashing + f32 adds',
             'data': 'synthetic',
             'config': {
-                'workload': 'BASELINE configs[1]: 1xMI355X per rank, linear perceptron scorer only (RNN off), '
+                'workload': ('BASELINE configs[2]: 1xMI355X per rank, perceptron + RNNLM (E=%d), ' % args.rnn_hidden if args.rnn else 'BASELINE configs[1]: 1xMI355X per rank, linear perceptron scorer only (RNN off), ')
                             'beam=5 gbeam=6 rcheck=1 rbeam=5, synthetic %d-codepoint UTF-8 sentences batched %d, '
                             '%d-entry synthetic jumandic-layout dictionary, 2^%d random weights'
                             % (args.sent_len, args.batch, args.dict_entries, args.weights_exp),

@@ -77,6 +77,27 @@ typedef struct {
   int32_t num_unk_makers;
   const void* feature_spec;    /* flattened FeaturesSpec descriptors; must equal the built-in jumandic tables */
   size_t feature_spec_bytes;
+  /* optional RNN re-ranker = blocks of the model's Rnn part
+   * (src/core/analysis/rnn_scorer_gbeam.cc:375-398): data[1..6] + decoded header */
+  int32_t has_rnn;
+  const void* rnn_known_index;   /* data[1] double array: word repr -> id (dictionary nodes) */
+  size_t rnn_known_index_bytes;
+  const void* rnn_unk_index;     /* data[2] double array (UNK nodes) */
+  size_t rnn_unk_index_bytes;
+  const float* rnn_matrix;       /* data[3] W[E x E] column-major: out[i] = sum_k W[i*E+k] ctx[k] */
+  const float* rnn_embeddings;   /* data[4] [V x E] */
+  const float* rnn_nce_embeddings; /* data[5] [V x E] */
+  const float* rnn_maxent;       /* data[6] [maxent_size] */
+  uint32_t rnn_layer_size;       /* E */
+  uint32_t rnn_maxent_order;
+  uint64_t rnn_maxent_size;
+  uint64_t rnn_vocab_size;
+  float rnn_nce_constant;        /* effective MikolovRnn::rnnNceConstant */
+  int32_t rnn_unk_id;
+  float rnn_unk_constant;        /* RnnInferenceConfig::unkConstantTerm */
+  float rnn_unk_length;          /* RnnInferenceConfig::unkLengthPenalty */
+  uint32_t rnn_num_fields;       /* RnnIdResolver::fields_ (entry feature indices) */
+  uint32_t rnn_fields[8];
 } jppgpu_model;
 
 /* AnalyzerConfig + ScoringConfig subset (src/core/analysis/analyzer.h:15-27,
@@ -88,6 +109,9 @@ typedef struct {
   int32_t right_beam;       /* 5 */
   int32_t max_input_bytes;  /* 4096 */
   int32_t device;           /* HIP device ordinal */
+  int32_t use_rnn;          /* 1: run the RNN scorer (ScorerDef::others), needs model.has_rnn */
+  float weight_perceptron;  /* ScorerDef::scoreWeights[0] (used only with use_rnn) */
+  float weight_rnn;         /* ScorerDef::scoreWeights[1] */
 } jppgpu_config;
 
 typedef struct {
@@ -126,6 +150,8 @@ typedef struct {
   uint64_t total_nodes;
   uint64_t total_boundaries;
   int32_t beam, global_beam;
+  int32_t num_scorers;
+  int32_t reserved0;
   /* top-1 path: node ids from EOS back to the first morpheme, path_len[i] entries at node_base[i] */
   const uint32_t* path_len;
   const uint32_t* path_nodes;
@@ -141,7 +167,7 @@ typedef struct {
   const uint64_t* patterns;          /* [total_nodes][14] */
   const float* t0_scores;            /* [total_nodes] */
   const jppgpu_beam_slot* beams;     /* [total_nodes][beam] */
-  const float* cells;                /* [total_nodes][global_beam] */
+  const float* cells;                /* [total_nodes][global_beam][num_scorers] */
   const uint8_t* kept;               /* [total_nodes] */
   const uint32_t* gbeam_count;       /* [total_boundaries] */
   const uint32_t* gbeam;             /* [total_boundaries][global_beam][2]: (left | beam<<16), score bits */

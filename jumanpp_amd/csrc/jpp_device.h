@@ -5,6 +5,8 @@
 #ifndef JPP_DEVICE_H
 #define JPP_DEVICE_H
 
+#include <cmath>
+
 #include "jpp_rt.h"
 #include "jpp_types.h"
 

@@ -14,6 +14,8 @@ constexpr int kMaxBeam = 16;
 constexpr int kMaxRight = 512;    // right nodes per boundary staged in LDS by the sweep kernel
 constexpr int kMaxNormStates = 64;
 constexpr int kMaxNormResults = 160;
+constexpr int kMaxRnnE = 256;      // RNN hidden size staged per lane (E/64 <= 4)
+constexpr int kRnnCtxCap = 2048;   // global_beam * E floats of LDS per context buffer
 
 // entry pointers (reference src/core/core_types.h:44-58)
 constexpr i32 kEptrBOS = (i32)0x80000000;
@@ -58,6 +60,23 @@ struct DevModel {
   i32 n_stage1;          // makers[0..n_stage1) are stage 1 in spec order, the rest stage 2
   i32 norm_maker;        // index of the Normalize maker or -1
   UnkMaker makers[kMaxUnkMakers];
+  // RNN re-ranker (reference RNN model part, rnn_scorer_gbeam.cc:375-398,426-470)
+  i32 has_rnn;
+  const u32* rnn_known;      // word -> id double array for dictionary nodes
+  const u32* rnn_unk;        // word -> id double array for UNK nodes
+  const float* rnn_wt;       // W transposed: wt[k * E + i] = W[i * E + k]
+  const float* rnn_emb;      // [V][E]
+  const float* rnn_nce;      // [V][E]
+  const float* rnn_maxent;   // [M]
+  u32 rnn_E;
+  u32 rnn_order;             // maxent order
+  u64 rnn_hash_max;          // maxentSize - vocabSize
+  float rnn_nce_const;
+  i32 rnn_unk_id;
+  float rnn_unk_const;
+  float rnn_unk_len;
+  u32 rnn_nfields;
+  u32 rnn_fields[8];
 };
 
 struct Config {
@@ -66,6 +85,9 @@ struct Config {
   i32 rcheck;
   i32 rbeam;
   i32 max_input_bytes;
+  i32 nscorers;          // 1: perceptron, 2: perceptron + RNN
+  float w_perceptron;    // ScorerDef::scoreWeights
+  float w_rnn;
 };
 
 // One lattice node (reference NodeInfo, src/core/core_types.h:71-90)
@@ -152,7 +174,16 @@ struct Batch {
   u64* node_pat;           // [gn][14]
   float* node_t0;          // [gn]
   BeamSlot* node_beam;     // [gn][beam]
-  float* node_cells;       // [gn][gbeam]
+  float* node_cells;       // [gn][gbeam][nscorers]
+  u32* rnn_conn;           // [bb][gbeam] connection of EOS path p at boundary b: node | slot<<28, or ~0
+  i32* rnn_id;             // [bb][gbeam] RNN vocabulary id of that node
+  u32* rnn_assign;         // [bb][gbeam] rnn node (index within boundary) a connection is scored with
+  u32* rnn_prev;           // [bb][gbeam] rnn node -> prev rnn node handle (b * G + idx)
+  u64* rnn_hash;           // [bb][gbeam] prefix hash of the rnn node
+  i32* rnn_nid;            // [bb][gbeam] word id of the rnn node
+  u32* rnn_nlen;           // [bb][gbeam] codepoint length of the rnn node
+  u32* rnn_cnt;            // [bb] rnn nodes per boundary
+  float* rnn_ctx;          // [bb][gbeam][E] hidden state after each rnn node
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]
   u32* bnd_ngb;            // [bb]

@@ -16,6 +16,7 @@
 #include "jpp_types.h"
 #include "k_decode.h"
 #include "k_lattice.h"
+#include "k_rnn.h"
 #include "k_seeds.h"
 #include "k_sweep.h"
 #include "k_t0.h"
@@ -151,6 +152,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
@@ -214,7 +216,8 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   auto* ctx = new jppgpu_ctx();
   ctx->device = c->device;
   ctx->cfg = Config{c->beam, c->global_beam, c->right_check, c->right_beam,
-                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096};
+                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096, c->use_rnn ? 2 : 1,
+                    c->use_rnn ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
   if (ctx->cfg.max_input_bytes > 65535) ctx->cfg.max_input_bytes = 65535;
   DevModel& H = ctx->hmodel;
   size_t wbytes = (size_t{1} << m->weight_exponent) * sizeof(float);
@@ -288,6 +291,53 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     H.norm_maker = idx;
     H.makers[idx++] = norm[0];
   }
+  H.has_rnn = 0;
+  if (c->use_rnn) {
+    // AnalyzerImpl::initScorers: scorer count must match the weights; RNN needs the global beam
+    if (!m->has_rnn) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_INVALID_PARAMETER, "use_rnn set but the model has no RNN part");
+    }
+    const u64 E = m->rnn_layer_size, V = m->rnn_vocab_size;
+    if (E == 0 || E > (u64)kMaxRnnE || E * (u64)c->global_beam > (u64)kRnnCtxCap || m->rnn_maxent_order > 4 ||
+        m->rnn_num_fields > 8 || m->rnn_maxent_size <= V) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_NOT_IMPLEMENTED, "RNN shape outside the supported range (E<=256, G*E<=2048, order<=4)");
+    }
+    std::vector<float> wt(E * E);
+    for (u64 i = 0; i < E; ++i)
+      for (u64 k = 0; k < E; ++k) wt[k * E + i] = m->rnn_matrix[i * E + k];
+    bool ok2 = ctx->rnn_known.ensure(m->rnn_known_index_bytes) && ctx->rnn_unk.ensure(m->rnn_unk_index_bytes) &&
+               ctx->rnn_wt.ensure(E * E * 4) && ctx->rnn_emb.ensure(V * E * 4) && ctx->rnn_nce.ensure(V * E * 4) &&
+               ctx->rnn_maxent.ensure(m->rnn_maxent_size * 4);
+    if (!ok2) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (rnn)");
+    }
+    rt_h2d(ctx->rnn_known.p, m->rnn_known_index, m->rnn_known_index_bytes, nullptr);
+    rt_h2d(ctx->rnn_unk.p, m->rnn_unk_index, m->rnn_unk_index_bytes, nullptr);
+    rt_h2d(ctx->rnn_wt.p, wt.data(), E * E * 4, nullptr);
+    rt_h2d(ctx->rnn_emb.p, m->rnn_embeddings, V * E * 4, nullptr);
+    rt_h2d(ctx->rnn_nce.p, m->rnn_nce_embeddings, V * E * 4, nullptr);
+    rt_h2d(ctx->rnn_maxent.p, m->rnn_maxent, m->rnn_maxent_size * 4, nullptr);
+    rt_sync(nullptr);
+    H.has_rnn = 1;
+    H.rnn_known = ctx->rnn_known.as<u32>();
+    H.rnn_unk = ctx->rnn_unk.as<u32>();
+    H.rnn_wt = ctx->rnn_wt.as<float>();
+    H.rnn_emb = ctx->rnn_emb.as<float>();
+    H.rnn_nce = ctx->rnn_nce.as<float>();
+    H.rnn_maxent = ctx->rnn_maxent.as<float>();
+    H.rnn_E = (u32)E;
+    H.rnn_order = m->rnn_maxent_order;
+    H.rnn_hash_max = m->rnn_maxent_size - V;
+    H.rnn_nce_const = m->rnn_nce_constant;
+    H.rnn_unk_id = m->rnn_unk_id;
+    H.rnn_unk_const = m->rnn_unk_constant;
+    H.rnn_unk_len = m->rnn_unk_length;
+    H.rnn_nfields = m->rnn_num_fields;
+    for (u32 f = 0; f < m->rnn_num_fields; ++f) H.rnn_fields[f] = m->rnn_fields[f];
+  }
   ctx->dmodel = static_cast<DevModel*>(rt_malloc(sizeof(DevModel)));
   if (!ctx->dmodel) {
     jppgpu_ctx_destroy(ctx);
@@ -309,7 +359,10 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_base2, &ctx->path_len,  &ctx->bnd_first,  &ctx->bnd_cnt,   &ctx->end_first,
                     &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
                     &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
-                    &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes};
+                    &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
+                    &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
+                    &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   ctx->timer.destroy();
@@ -333,7 +386,12 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
             ctx->node_base2.ensure((n + 2) * 8) && ctx->path_len.ensure((n + 1) * 4) &&
             ctx->bnd_first.ensure(bbN * 4) && ctx->bnd_cnt.ensure(bbN * 4) && ctx->end_first.ensure(bbN * 4) &&
             ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) &&
-            ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry));
+            ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry)) &&
+            (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) &&
+              ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
+              ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
+              ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) &&
+              ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_E * 4)));
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
   ctx->generation++;
@@ -368,6 +426,15 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.end_cnt = ctx->end_cnt.as<u32>();
   B.bnd_ngb = ctx->bnd_ngb.as<u32>();
   B.bnd_gbeam = ctx->bnd_gbeam.as<GbeamEntry>();
+  B.rnn_conn = ctx->rnn_conn.as<u32>();
+  B.rnn_id = ctx->rnn_id.as<i32>();
+  B.rnn_assign = ctx->rnn_assign.as<u32>();
+  B.rnn_prev = ctx->rnn_prev.as<u32>();
+  B.rnn_hash = ctx->rnn_hash.as<u64>();
+  B.rnn_nid = ctx->rnn_nid.as<i32>();
+  B.rnn_nlen = ctx->rnn_nlen.as<u32>();
+  B.rnn_cnt = ctx->rnn_cnt.as<u32>();
+  B.rnn_ctx = ctx->rnn_ctx.as<float>();
   if (n == 0) {
     B.total_nodes = 0;
     *out = Rp;
@@ -411,7 +478,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const u64 cap = totalNodes + 8;
   ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * spec::kNumDicFeatures * 4) &&
        ctx->node_pat.ensure(cap * kPat * 8) && ctx->node_t0.ensure(cap * 4) &&
-       ctx->node_beam.ensure(cap * beam * sizeof(BeamSlot)) && ctx->node_cells.ensure(cap * G * 4) &&
+       ctx->node_beam.ensure(cap * beam * sizeof(BeamSlot)) && ctx->node_cells.ensure(cap * G * 4 * ctx->cfg.nscorers) &&
        ctx->node_kept.ensure(cap) && ctx->path_nodes.ensure(cap * 4);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice)");
   B.end_nodes = ctx->end_nodes.as<u32>();
@@ -428,6 +495,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
   T.mark(4, st);
   JPP_LAUNCH(k_sweep, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_rnn, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   T.mark(5, st);
   JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
   T.mark(6, st);
@@ -533,7 +601,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
     pull(res->patterns, B.node_pat, N * kPat, st);
     pull(res->t0, B.node_t0, N, st);
     pull(res->beams, B.node_beam, N * beam, st);
-    pull(res->cells, B.node_cells, N * G, st);
+    pull(res->cells, B.node_cells, N * G * ctx->cfg.nscorers, st);
     pull(res->kept, B.node_kept, N, st);
     rt_sync(st);
     res->fetched_full = true;
@@ -549,6 +617,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   v->total_boundaries = NB;
   v->beam = beam;
   v->global_beam = G;
+  v->num_scorers = ctx->cfg.nscorers;
   v->path_len = res->path_len.data();
   v->path_nodes = res->path_nodes.data();
   v->nodes = res->nodes.data();

@@ -1,0 +1,372 @@
+// Kernel 6: RNNLM re-ranking of the paths that survive at EOS (Mikolov
+// faster-rnnlm NCE model), then adjustBeamScores + remakeEosBeam.
+// One wavefront per sentence.  The <= G surviving paths advance in lock-step
+// over the boundaries, so every W element fetched (coalesced from the
+// transposed copy) is used for all active paths; the hidden vector is spread
+// over the lanes (E/64 outputs per lane), contexts live in LDS.
+//
+// The reference merges equal path prefixes (RnnIdContainer::addPrevChain,
+// rnn_id_resolver.cc:207-245) purely to save CPU work: a merged node has, by
+// construction (prefix hash over (rnnId, length)), the same context vector and
+// therefore the same score.  Here every path is evaluated on its own prefix,
+// which yields the same values without the hash maps.
+//
+// Reference behaviour reproduced:
+//   RnnIdResolver::resolveIdsAtGbeam / RnnIdContainer::resolveId / reprOf
+//                                   src/core/analysis/rnn_id_resolver.cc:157-196,291-323
+//   GbeamRnnState::computeContext / scoreBoundary / copyScoresToLattice
+//                                   src/core/analysis/rnn_scorer_gbeam.cc:142-267
+//     (incl. the quirk that every maxent context slot holds prev->id, :171-188,
+//      and embedding id -1 -> 0, :130-133,214-217)
+//   MikolovRnnImplParallel          src/rnn/mikolov_rnn_impl.h:196-256
+//   MikolovIndexCalculator / ScoreCalculator  mikolov_rnn_impl.h:21-131, PRIMES mikolov_rnn.h:18-25
+//   ScoreProcessor::adjustBeamScores / remakeEosBeam  score_processor.cc:521-576
+// Float tolerance: exp() and the lane-tree dot product differ from the CPU in
+// the last ulps (as Eigen itself would from a scalar loop): 1e-4, see DESIGN.md.
+#ifndef JPP_K_RNN_H
+#define JPP_K_RNN_H
+
+#include "jpp_device.h"
+#include "k_sweep.h"
+
+namespace jpp {
+
+__device__ __forceinline__ u64 rnn_prime(u32 i) {
+  const u64 P[36] = {108641969, 116049371, 125925907, 133333309, 145678979, 175308587, 197530793, 234567803,
+                     251851741, 264197411, 330864029, 399999781, 407407183, 459258997, 479012069, 545678687,
+                     560493491, 607407037, 629629243, 656789717, 716048933, 718518067, 725925469, 733332871,
+                     753085943, 755555077, 782715551, 790122953, 812345159, 814814293, 893826581, 923456189,
+                     940740127, 953085797, 985184539, 990122807};
+  return P[i];
+}
+
+// one byte at a time through a double array; returns false once a label mismatches
+__device__ __forceinline__ bool rnn_trie_byte(const u32* units, u32& id, u32& unit, u32 b) {
+  id ^= da_offset(unit) ^ b;
+  unit = units[id];
+  return da_label(unit) == b;
+}
+
+// RnnIdContainer::resolveId: word id of lattice node `k` (not EOS)
+__device__ inline i32 rnn_resolve_id(const DevModel& M, const Batch& B, u32 s, u64 nb, u32 k) {
+  NodeInfo ni = B.node_info[nb + k];
+  const i32* entry = B.node_entry + (nb + k) * spec::kNumDicFeatures;
+  const u32* units = ni.eptr >= 0 ? M.rnn_known : M.rnn_unk;
+  u32 id = 0;
+  u32 unit = units[0];
+  bool ok = true;
+  u32 off = B.byte_off[s];
+  const u16* boff = B.cp_boff + off + s;
+  for (u32 f = 0; f < M.rnn_nfields && ok; ++f) {
+    i32 v = entry[M.rnn_fields[f]];
+    if (v >= 0) {
+      u32 x = (u32)v;  // RnnReprBuilder::addInt: varint of the u32 value
+      for (;;) {
+        u32 b = x & 0x7f;
+        x >>= 7;
+        if (x) b |= 0x80;
+        ok = rnn_trie_byte(units, id, unit, b);
+        if (!ok || !x) break;
+      }
+    } else {
+      // addString(surface): raw bytes, then varint(1)
+      const u8* p = B.text + off + boff[ni.start];
+      u32 len = (u32)boff[ni.end] - boff[ni.start];
+      for (u32 q = 0; q < len && ok; ++q) ok = rnn_trie_byte(units, id, unit, p[q]);
+      if (ok) ok = rnn_trie_byte(units, id, unit, 1);
+    }
+  }
+  if (!ok) return M.rnn_unk_id;
+  if (((unit >> 8) & 1) == 0) return M.rnn_unk_id;
+  u32 leaf = units[id ^ da_offset(unit)];
+  return (i32)(leaf & ((1u << 31) - 1));
+}
+
+constexpr u32 kNoConn = 0xffffffffu;
+
+// FastHash1::mix (src/util/fast_hash.h:39-64)
+__device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
+  u64 v = (state ^ data) * kHashMult;
+  return v ^ (v >> 32);
+}
+
+__global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config cfg) {
+  const DevModel& M = *Mp;
+  const u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  const int lane = (int)threadIdx.x;
+  const u32 off = B.byte_off[s];
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_ncp[s];
+  if (n == 0) return;
+  const u32 N = B.sent_nodes[s];
+  const u64 nb = B.node_base[s];
+  const int beam = cfg.beam;
+  const int G = cfg.gbeam;
+  const int S = cfg.nscorers;
+  const u32 bE = n + 2;
+  const int ngb = (int)B.bnd_ngb[bb0 + bE];
+  if (ngb == 0) return;
+  const u32 E = M.rnn_E;
+  const int J = (int)((E + 63) / 64);
+  BeamSlot* beams = B.node_beam + nb * beam;
+  const u32* en = B.end_nodes + nb;
+  // per (boundary, path) and per (boundary, rnn node) scratch of this sentence
+  u32* conn = B.rnn_conn + (u64)bb0 * G;      // lattice connection of path p at boundary b
+  i32* wid = B.rnn_id + (u64)bb0 * G;         // word id of that connection's lattice node
+  u32* assign = B.rnn_assign + (u64)bb0 * G;  // rnn node index (within boundary) the connection is scored with
+  u32* rn_prev = B.rnn_prev + (u64)bb0 * G;   // rnn node -> handle (pb * G + pidx) of its prev node
+  u64* rn_hash = B.rnn_hash + (u64)bb0 * G;
+  i32* rn_id = B.rnn_nid + (u64)bb0 * G;
+  u32* rn_len = B.rnn_nlen + (u64)bb0 * G;
+  u32* rn_cnt = B.rnn_cnt + bb0;              // rnn nodes per boundary
+  float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * E;
+
+  __shared__ float pctx[kRnnCtxCap];  // contexts of the prev nodes of the current boundary's nodes
+  __shared__ float nscore[kMaxGbeam];
+  __shared__ float full[kMaxGbeam];
+  __shared__ float prev_total[kMaxGbeam];
+
+  // ---- A. connection of every EOS path at every boundary ----
+  for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) conn[q] = kNoConn;
+  for (u32 q = lane; q <= bE; q += 64) rn_cnt[q] = 0;
+  __syncthreads();
+  const u32 efirstE = B.end_first[bb0 + bE];
+  if (lane < ngb) {
+    GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
+    conn[(u64)bE * G + lane] = (N - 1) | ((u32)lane << 28);  // fake EOS connection, "slot" = path index
+    u32 nd = en[efirstE + ge.left];
+    u32 k = ge.beam;
+    u32 guard = 0;
+    while (nd >= 2 && guard++ <= n) {
+      u32 b = (u32)B.node_info[nb + nd].start + 2;
+      conn[(u64)b * G + lane] = nd | (k << 28);
+      BeamSlot sl = beams[(u64)nd * beam + k];
+      nd = sl.prev_node;
+      k = sl.beam;
+    }
+  }
+  __syncthreads();
+  // ---- B. word ids of the connections ----
+  for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) {
+    u32 c = conn[q];
+    if (c == kNoConn) continue;
+    u32 nd = c & 0x0fffffffu;
+    wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
+  }
+  __syncthreads();
+  // ---- B2. RNN lattice: RnnIdContainer::addPath / addPrevChain, path by path ----
+  if (lane == 0) {
+    // BOS node (boundary 1): RnnIdContainer::addBos
+    rn_cnt[1] = 1;
+    rn_hash[(u64)1 * G] = 0xdeadbeef0000ULL;
+    rn_id[(u64)1 * G] = 0;
+    rn_len[(u64)1 * G] = 0;
+    rn_prev[(u64)1 * G] = kNoConn;
+    for (int p = 0; p < ngb; ++p) {
+      u32 cur = 1u * G;  // handle of the BOS node
+      for (u32 b = 2; b <= bE; ++b) {
+        u32 c = conn[(u64)b * G + p];
+        if (c == kNoConn) continue;
+        // ptrCache hit: an earlier path went through the same connection
+        int shared = -1;
+        for (int pp = 0; pp < p; ++pp) {
+          if (conn[(u64)b * G + pp] == c) {
+            shared = pp;
+            break;
+          }
+        }
+        if (shared >= 0) {
+          u32 a = assign[(u64)b * G + shared];
+          assign[(u64)b * G + p] = a;
+          cur = b * G + a;
+          continue;
+        }
+        u32 nd = c & 0x0fffffffu;
+        i32 id = wid[(u64)b * G + p];
+        u32 len = (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
+        u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
+        u32 cnt = rn_cnt[b];
+        // crdCache_.find(coord): newest published node with the same (boundary, length, id)
+        int it = -1;
+        for (int x = (int)cnt - 1; x >= 0; --x) {
+          if (rn_id[(u64)b * G + x] == id && rn_len[(u64)b * G + x] == len) {
+            it = x;
+            break;
+          }
+        }
+        bool merged = false;
+        if (it >= 0) {
+          // walk nextInBnd (all older nodes of the boundary) comparing the prefix hash;
+          // on a match the connection is attached to it->second, not to the matching node
+          for (int x = it; x >= 0; --x) {
+            if (rn_hash[(u64)b * G + x] == h) {
+              merged = true;
+              break;
+            }
+          }
+        }
+        if (merged) {
+          assign[(u64)b * G + p] = (u32)it;
+          cur = b * G + (u32)it;
+        } else {
+          rn_cnt[b] = cnt + 1;
+          rn_hash[(u64)b * G + cnt] = h;
+          rn_id[(u64)b * G + cnt] = id;
+          rn_len[(u64)b * G + cnt] = len;
+          rn_prev[(u64)b * G + cnt] = cur;
+          assign[(u64)b * G + p] = cnt;
+          cur = b * G + cnt;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- C. contexts and scores, boundary by boundary ----
+  // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
+  for (u32 e = lane; e < E; e += 64) {
+    float x = 0.f + M.rnn_emb[e];
+    rn_ctx[(u64)1 * G * E + e] = 1.0f / (1.0f + expf(-x));
+  }
+  __syncthreads();
+  for (u32 b = 2; b <= bE; ++b) {
+    const int cnt = (int)rn_cnt[b];
+    if (cnt == 0) continue;
+    // stage the prev contexts
+    for (u32 q = lane; q < (u32)cnt * E; q += 64) {
+      u32 x = q / E, e = q - x * E;
+      pctx[q] = rn_ctx[(u64)rn_prev[(u64)b * G + x] * E + e];
+    }
+    __syncthreads();
+    // score of every rnn node of this boundary
+    for (int x = 0; x < cnt; ++x) {
+      i32 id = rn_id[(u64)b * G + x];
+      u32 eid = id == -1 ? 0u : (u32)id;
+      float part = 0.f;
+      for (u32 e = lane; e < E; e += 64) part += M.rnn_nce[(u64)eid * E + e] * pctx[(u32)x * E + e];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) part += wave_shfl_f32(part, lane ^ o);
+      if (lane == 0) {
+        float score = part;
+        // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
+        float me = 0.f;
+        u32 order = M.rnn_order;
+        i32 pid = rn_id[rn_prev[(u64)b * G + x]];
+        for (u32 i = 0; i < order; ++i) {
+          u64 xx = rnn_prime(0) * rnn_prime(1);
+          for (u32 j = 1; j <= i; ++j) {
+            u64 pi = ((u64)i * rnn_prime(j) + j) % 36;
+            xx += rnn_prime((u32)pi) * ((u64)(i64)pid + 1);
+          }
+          u64 h = xx % M.rnn_hash_max;
+          u64 idx = (h + (u64)(i64)id) % M.rnn_hash_max;
+          float w = M.rnn_maxent[idx];
+          me = (i == 0) ? w : me + w;
+        }
+        if (order > 0) score += me;
+        else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+        score -= M.rnn_nce_const;
+        if (id == M.rnn_unk_id) score = M.rnn_unk_const + M.rnn_unk_len * (float)rn_len[(u64)b * G + x];
+        nscore[x] = score;
+      }
+    }
+    __syncthreads();
+    if (lane < ngb) {
+      u32 c = conn[(u64)b * G + lane];
+      if (c != kNoConn) {
+        u32 nd = c & 0x0fffffffu, k = c >> 28;
+        u32 gi = (nd == N - 1) ? k : beams[(u64)nd * beam + k].pad;
+        B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
+      }
+    }
+    // new contexts (GbeamRnnState::computeContext; not needed for EOS)
+    if (b < bE) {
+      float acc[kMaxGbeam][kMaxRnnE / 64];
+#pragma unroll
+      for (int p = 0; p < kMaxGbeam; ++p)
+#pragma unroll
+        for (int j = 0; j < kMaxRnnE / 64; ++j) acc[p][j] = 0.f;
+      for (u32 k = 0; k < E; ++k) {
+        float w[kMaxRnnE / 64];
+#pragma unroll
+        for (int j = 0; j < kMaxRnnE / 64; ++j) {
+          u32 i = (u32)lane + 64u * j;
+          w[j] = (j < J && i < E) ? M.rnn_wt[(u64)k * E + i] : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < kMaxGbeam; ++p) {
+          if (p < cnt) {
+            float c = pctx[(u32)p * E + k];
+#pragma unroll
+            for (int j = 0; j < kMaxRnnE / 64; ++j) {
+              float prod = w[j] * c;
+              acc[p][j] += prod;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kMaxGbeam; ++p) {
+        if (p < cnt) {
+          i32 id = rn_id[(u64)b * G + p];
+          u32 eid = id == -1 ? 0u : (u32)id;
+#pragma unroll
+          for (int j = 0; j < kMaxRnnE / 64; ++j) {
+            u32 i = (u32)lane + 64u * j;
+            if (j < J && i < E) {
+              float x = acc[p][j] + M.rnn_emb[(u64)eid * E + i];
+              rn_ctx[((u64)b * G + p) * E + i] = 1.0f / (1.0f + expf(-x));
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- D. adjustBeamScores along the EOS paths ----
+  if (lane < ngb) {
+    float prevT = 0.f;  // BOS element total
+    for (u32 b = 2; b < bE; ++b) {
+      u32 c = conn[(u64)b * G + lane];
+      if (c == kNoConn) continue;
+      u32 nd = c & 0x0fffffffu, k = c >> 28;
+      BeamSlot* sl = &beams[(u64)nd * beam + k];
+      const float* cell = B.node_cells + ((nb + nd) * G + sl->pad) * S;
+      float local = 0.f;
+      local += cell[0] * cfg.w_perceptron;
+      local += cell[1] * cfg.w_rnn;
+      local += prevT;
+      sl->total = local;
+      prevT = local;
+    }
+    // ---- E. remakeEosBeam ----
+    const float* cell = B.node_cells + ((nb + N - 1) * G + lane) * S;
+    float local = 0.f;
+    local += cell[0] * cfg.w_perceptron;
+    local += cell[1] * cfg.w_rnn;
+    full[lane] = local + prevT;
+    prev_total[lane] = prevT;
+  }
+  __syncthreads();
+  if (lane < kMaxGbeam) {
+    BeamSlot* row = beams + (u64)(N - 1) * beam;
+    if (lane < ngb) {
+      float me = full[lane];
+      int rank = 0;
+      for (int j = 0; j < ngb; ++j) {
+        float o = full[j];
+        if (o > me || (o == me && j < lane)) ++rank;
+      }
+      GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
+      if (rank < beam) row[rank] = BeamSlot{ge.left, ge.beam, me, en[efirstE + ge.left], (u32)lane};
+      B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
+    } else if (lane < beam) {
+      row[lane] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+    }
+  }
+}
+
+}  // namespace jpp
+
+#endif  // JPP_K_RNN_H

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
           total = 0.f;
         }
         tot[x][i] = total;
-        if (defined) B.node_cells[(nb + rfirst + t) * G + i] = cell;
+        if (defined) B.node_cells[((nb + rfirst + t) * G + i) * cfg.nscorers] = cell;
       }
       __syncthreads();
       // 5c. beams: stable descending rank among the node's candidates (makeT0Beam; for <= 16
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
             float o = tot[x][jx];
             if (o > me || (o == me && jx < i)) ++rank;
           }
-          if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], 0};
+          if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
         } else if (i < beam) {
           row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
         }

@@ -22,6 +22,7 @@
 
 #include "jpp_device.h"
 #include "jumandic_spec.inc"
+#include "k_seeds.h"
 
 namespace jpp {
 

@@ -27,12 +27,23 @@ class Model(C.Structure):
                 ('weights', C.c_void_p), ('weight_exponent', C.c_uint32),
                 ('num_features', C.c_int32), ('num_placeholders', C.c_int32),
                 ('unk_makers', C.POINTER(UnkMaker)), ('num_unk_makers', C.c_int32),
-                ('feature_spec', C.c_void_p), ('feature_spec_bytes', C.c_size_t)]
+                ('feature_spec', C.c_void_p), ('feature_spec_bytes', C.c_size_t),
+                ('has_rnn', C.c_int32),
+                ('rnn_known_index', C.c_void_p), ('rnn_known_index_bytes', C.c_size_t),
+                ('rnn_unk_index', C.c_void_p), ('rnn_unk_index_bytes', C.c_size_t),
+                ('rnn_matrix', C.c_void_p), ('rnn_embeddings', C.c_void_p), ('rnn_nce_embeddings', C.c_void_p),
+                ('rnn_maxent', C.c_void_p),
+                ('rnn_layer_size', C.c_uint32), ('rnn_maxent_order', C.c_uint32),
+                ('rnn_maxent_size', C.c_uint64), ('rnn_vocab_size', C.c_uint64),
+                ('rnn_nce_constant', C.c_float), ('rnn_unk_id', C.c_int32),
+                ('rnn_unk_constant', C.c_float), ('rnn_unk_length', C.c_float),
+                ('rnn_num_fields', C.c_uint32), ('rnn_fields', C.c_uint32 * 8)]
 
 
 class Config(C.Structure):
     _fields_ = [('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
-                ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32)]
+                ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32),
+                ('use_rnn', C.c_int32), ('weight_perceptron', C.c_float), ('weight_rnn', C.c_float)]
 
 
 class ResultView(C.Structure):
@@ -40,7 +51,7 @@ class ResultView(C.Structure):
                 ('status', C.c_void_p), ('n_codepoints', C.c_void_p), ('n_nodes', C.c_void_p),
                 ('node_base', C.c_void_p), ('bnd_base', C.c_void_p),
                 ('total_nodes', C.c_uint64), ('total_boundaries', C.c_uint64),
-                ('beam', C.c_int32), ('global_beam', C.c_int32),
+                ('beam', C.c_int32), ('global_beam', C.c_int32), ('num_scorers', C.c_int32), ('reserved0', C.c_int32),
                 ('path_len', C.c_void_p), ('path_nodes', C.c_void_p),
                 ('nodes', C.c_void_p), ('unk', C.c_void_p),
                 ('bnd_first', C.c_void_p), ('bnd_count', C.c_void_p),
@@ -144,7 +155,7 @@ class Result:
             self.patterns = self._arr(v.patterns, '<u8', N * 14).reshape(-1, 14)
             self.t0 = self._arr(v.t0_scores, '<f4', N)
             self.beams = self._arr(v.beams, BEAM_DT, N * v.beam).reshape(-1, v.beam)
-            self.cells = self._arr(v.cells, '<f4', N * v.global_beam).reshape(-1, v.global_beam)
+            self.cells = self._arr(v.cells, '<f4', N * v.global_beam * v.num_scorers).reshape(-1, v.global_beam, v.num_scorers)
             self.kept = self._arr(v.kept, 'u1', N)
             self.gbeam_count = self._arr(v.gbeam_count, '<u4', NB)
             self.gbeam_entries = self._arr(v.gbeam, GBEAM_DT, NB * v.global_beam).reshape(-1, v.global_beam)
@@ -173,7 +184,11 @@ class Context:
     """jppgpu_ctx: model resident in HBM + analysis configuration."""
 
     def __init__(self, image_path, beam=5, global_beam=6, right_check=1, right_beam=5,
-                 max_input_bytes=4096, device=0, lib_path=None):
+                 max_input_bytes=4096, device=0, lib_path=None, use_rnn=None,
+                 weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None):
+        """use_rnn=None: run the RNN scorer iff the model image has an RNN part (what
+        JumanppEnv::loadModel does); the score weights default to the model's saved
+        RnnInferenceConfig (env.cc:86-100)."""
         self.lib = load_library(lib_path)
         secs = read_image(image_path)
         by = {}
@@ -216,7 +231,34 @@ class Context:
         m.unk_makers = makers
         m.num_unk_makers = n_unk
         m.feature_spec, m.feature_spec_bytes = buf(by[7][0][1])
-        cfg = Config(beam, global_beam, right_check, right_beam, max_input_bytes, device)
+        self.has_rnn = 11 in by and any(a == 100 for a, _ in by[11])
+        wp, wr = 1.0, 0.0
+        if self.has_rnn:
+            blk = dict(by[11])
+            hdr = blk[100]
+            E, order, msize, vsize, nce, unk_id, unk_c, unk_l, wp, wr, nf = struct.unpack_from('<IIQQfiffffI', hdr, 0)
+            fields = struct.unpack_from('<%dI' % nf, hdr, 52)
+            m.has_rnn = 1
+            m.rnn_known_index, m.rnn_known_index_bytes = buf(blk[1])
+            m.rnn_unk_index, m.rnn_unk_index_bytes = buf(blk[2])
+            m.rnn_matrix, _ = buf(blk[3])
+            m.rnn_embeddings, _ = buf(blk[4])
+            m.rnn_nce_embeddings, _ = buf(blk[5])
+            m.rnn_maxent, _ = buf(blk[6])
+            m.rnn_layer_size, m.rnn_maxent_order, m.rnn_maxent_size, m.rnn_vocab_size = E, order, msize, vsize
+            m.rnn_nce_constant = nce if rnn_nce_bias is None else rnn_nce_bias
+            m.rnn_unk_id, m.rnn_unk_constant, m.rnn_unk_length = unk_id, unk_c, unk_l
+            m.rnn_num_fields = nf
+            for i, f in enumerate(fields):
+                m.rnn_fields[i] = f
+        if use_rnn is None:
+            use_rnn = self.has_rnn
+        if weight_perceptron is not None:
+            wp = weight_perceptron
+        if weight_rnn is not None:
+            wr = weight_rnn
+        cfg = Config(beam, global_beam, right_check, right_beam, max_input_bytes, device,
+                     1 if use_rnn else 0, wp, wr)
         h = C.c_void_p()
         rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))
         if rc != 0:

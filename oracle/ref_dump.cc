@@ -30,6 +30,10 @@
 
 #include "core/analysis/analyzer_impl.h"
 #include "core/analysis/perceptron.h"
+#include "core/analysis/rnn_scorer.h"
+#include "core/analysis/rnn_scorer_gbeam.h"
+#include "rnn/mikolov_rnn.h"
+#include "util/cfg.h"
 #include "core/analysis/score_processor.h"
 #include "core/analysis/unk_nodes_creator.h"
 #include "core/core.h"
@@ -81,6 +85,36 @@ struct Writer {
     }
   }
 };
+
+// RNN part header: same field order as the (file-local) RnnModelHeader of
+// src/core/analysis/rnn_scorer_gbeam.cc:353-373, declared here because that
+// type is not visible outside its translation unit.
+struct OracleRnnHeader {
+  core::analysis::rnn::RnnInferenceConfig config;
+  i32 unkIdx = 0;
+  std::vector<u32> fields;
+  jumanpp::rnn::mikolov::MikolovRnnModelHeader rnnHeader{};
+};
+
+template <typename Arch>
+void Serialize(Arch& a, OracleRnnHeader& o) {
+  a& o.config.nceBias;
+  a& o.config.unkConstantTerm;
+  a& o.config.unkLengthPenalty;
+  a& o.config.perceptronWeight;
+  a& o.config.rnnWeight;
+  a& o.config.eosSymbol;
+  a& o.config.unkSymbol;
+  a& o.config.rnnFields;
+  a& o.config.fieldSeparator;
+  a& o.unkIdx;
+  a& o.fields;
+  a& o.rnnHeader.layerSize;
+  a& o.rnnHeader.maxentOrder;
+  a& o.rnnHeader.maxentSize;
+  a& o.rnnHeader.vocabSize;
+  a& o.rnnHeader.nceLnz;
+}
 
 // ---------------------------------------------------------------- export ---
 // section tags, must match jumanpp_amd/csrc/model_image.h
@@ -229,6 +263,31 @@ int doExport(const char* modelFile, const char* out) {
     for (size_t i = 0; i < rp->data.size(); ++i) {
       section(w, SEC_RNN, (u32)i, rp->data[i].data(), rp->data[i].size());
     }
+    // decoded parameters (aux = 100).  The effective NCE constant follows
+    // RnnScorerGbeamFactory::load (rnn_scorer_gbeam.cc:426-470): nceLnz, replaced by
+    // rnnWeight when that is defined (:465-467) -- no CLI override is applied here.
+    OracleRnnHeader h;
+    util::serialization::Loader l{rp->data[0]};
+    if (!l.load(&h)) {
+      std::cerr << "bad rnn header\n";
+      return 1;
+    }
+    float nce = h.rnnHeader.nceLnz;
+    if (h.config.rnnWeight.defined()) nce = h.config.rnnWeight;
+    Writer s;
+    s.put<u32>(h.rnnHeader.layerSize);
+    s.put<u32>(h.rnnHeader.maxentOrder);
+    s.put<u64>(h.rnnHeader.maxentSize);
+    s.put<u64>(h.rnnHeader.vocabSize);
+    s.put<float>(nce);
+    s.put<i32>(h.unkIdx);
+    s.put<float>(h.config.unkConstantTerm);
+    s.put<float>(h.config.unkLengthPenalty);
+    s.put<float>(h.config.perceptronWeight);
+    s.put<float>(h.config.rnnWeight);
+    s.put<u32>((u32)h.fields.size());
+    for (auto f : h.fields) s.put<u32>(f);
+    section(w, SEC_RNN, 100, s.buf.data(), s.buf.size());
   }
   w.align8();
   w.put<u32>(0);

@@ -26,5 +26,12 @@ python3 "$ROOT/tools/gen_dict.py" 2500 --seed 11 > "$TMP/mini.mdic"
 "$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini.gold" < "$HERE/mini.txt"
 "$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini_b3.gold" 3 4 2 3 < "$HERE/mini.txt"
 "$REF/jumanpp_v2" --model="$TMP/mini.model" "$HERE/mini.txt" > "$HERE/mini.juman.txt"
+# perceptron + synthetic RNNLM (faster-rnnlm NCE format), embedded by the reference's own trainer binary
+python3 "$ROOT/tools/gen_rnn.py" "$TMP/mini.mdic" "$TMP/mini_rnn" --vocab 600 --hidden 32 --maxent-size 16384 --seed 31
+"$REF/jumanpp_v2_train" --model-input="$TMP/mini.model" --model-output="$TMP/mini_rnn.model" \
+    --rnn-model="$TMP/mini_rnn" --rnn-fields=surface,pos --rnn-nce-bias=5.6 --rnn-unk-constant=-3.47 \
+    --rnn-unk-length=-2.93 --feature-weight-perceptron=1 --feature-weight-rnn=0.0176 > /dev/null 2>&1
+"$REF/ref_dump" export "$TMP/mini_rnn.model" "$HERE/mini_rnn.img"
+"$REF/ref_dump" dump "$TMP/mini_rnn.model" "$HERE/mini_rnn.gold" < "$HERE/mini.txt" 2> /dev/null
 rm -rf "$TMP"
 ls -la "$HERE"

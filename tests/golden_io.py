@@ -84,6 +84,20 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
     if res.ncp[s] != g.ncp:
         return bad('codepoints %d vs %d' % (res.ncp[s], g.ncp))
     nb = len(g.bnds)
+    # with the RNN scorer only the elements on the surviving EOS paths carry defined totals
+    # (adjustBeamScores touches every global-beam element, but RNN cells exist only on those paths)
+    on_path = set()
+    if meta['nscorers'] == 2 and nb > 3:
+        eos = g.bnds[nb - 1]['nodes'][0]
+        stack = [(nb - 1, 0, q) for q in range(meta['beam']) if eos['beam'][q]['valid']]
+        while stack:
+            key = stack.pop()
+            if key in on_path or key[0] < 2:
+                continue
+            on_path.add(key)
+            sl = g.bnds[key[0]]['nodes'][key[1]]['beam'][key[2]]
+            stack.append((int(sl['prev'][0]), int(sl['prev'][1]), int(sl['prev'][2])))
+    rtol = 1e-4
     nbase = int(res.node_base[s])
     bbase = int(res.bnd_base[s])
     beam = meta['beam']
@@ -151,6 +165,26 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
                     bad('b%d n%d: T0 %r vs %r' % (b, r, float(a), float(e)))
             if int(res.kept[k]) != int(gn['kept']) and len(gb['gbeam']) > 0:
                 bad('b%d n%d: kept %d vs %d' % (b, r, res.kept[k], gn['kept']))
+            eos_rnn = meta['nscorers'] == 2 and b == nb - 1
+            if eos_rnn:
+                # RNN totals carry a 1e-4 tolerance, so candidates whose totals differ by less may swap
+                # ranks; require the same candidate set, matching totals, and a non-increasing order.
+                dev = [(int(x['left']), int(x['beam']), float(x['total'])) for x in res.beams[k]
+                       if not (x['left'] == 0xffff and x['beam'] == 0xffff)]
+                ref = [(int(x['cp'][1]), int(x['cp'][3]), float(x['total'])) for x in gn['beam'] if x['valid']]
+                if len(dev) != len(ref):
+                    bad('EOS beam size %d vs %d' % (len(dev), len(ref)))
+                if any(dev[i][2] < dev[i + 1][2] for i in range(len(dev) - 1)):
+                    bad('EOS beam not sorted: %s' % (dev,))
+                cutoff = min([x[2] for x in ref]) if ref else 0.0
+                for (l, bm, t) in ref:
+                    m = [d for d in dev if d[0] == l and d[1] == bm]
+                    if m:
+                        if abs(m[0][2] - t) > rtol * max(1.0, abs(t)):
+                            bad('EOS beam (%d,%d): total %r vs %r' % (l, bm, m[0][2], t))
+                    elif abs(t - cutoff) > rtol * max(1.0, abs(t)):
+                        bad('EOS beam candidate (%d,%d) total %r missing on device' % (l, bm, t))
+                continue
             for q in range(beam):
                 sl = res.beams[k][q]
                 gs = gn['beam'][q]
@@ -172,7 +206,27 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
                     a, e = np.float32(sl['total']), np.float32(gs['total'])
                     if (tol == 0.0 and a.view('<u4') != e.view('<u4')) or (tol > 0 and abs(float(a) - float(e)) > tol):
                         bad('b%d n%d slot %d: total %r vs %r' % (b, r, q, float(a), float(e)))
+                if check_scores and meta['nscorers'] == 2 and (b, r, q) in on_path:
+                    a, e = float(sl['total']), float(gs['total'])
+                    if abs(a - e) > rtol * max(1.0, abs(e)):
+                        bad('b%d n%d slot %d: rnn-adjusted total %r vs %r' % (b, r, q, a, e))
+                    # score cells of this connection: [perceptron, rnn]
+                    gi = None
+                    for i, ge in enumerate(gb['gbeam']):
+                        if ge['left'] == gs['cp'][1] and ge['beam'] == gs['cp'][3]:
+                            gi = i
+                    if gi is not None and b < nb - 1:
+                        c_ref = gn['cells'][gi * 2:gi * 2 + 2]
+                        c_dev = res.cells[k][gi]
+                        if np.float32(c_ref[0]).view('<u4') != np.float32(c_dev[0]).view('<u4'):
+                            bad('b%d n%d slot %d: perceptron cell %r vs %r' % (b, r, q, float(c_dev[0]), float(c_ref[0])))
+                        if abs(float(c_ref[1]) - float(c_dev[1])) > rtol * max(1.0, abs(float(c_ref[1]))):
+                            bad('b%d n%d slot %d: rnn cell %r vs %r' % (b, r, q, float(c_dev[1]), float(c_ref[1])))
     # top-1 path
+    if meta['nscorers'] == 2 and nb > 3:
+        eb = [float(x['total']) for x in g.bnds[nb - 1]['nodes'][0]['beam'] if x['valid']]
+        if len(eb) > 1 and abs(eb[0] - eb[1]) <= rtol * max(1.0, abs(eb[0])):
+            return errs  # best two paths tie within the RNN tolerance: the top-1 choice is not defined
     plen = int(res.path_len[s])
     if plen != len(g.path):
         bad('path length %d vs %d' % (plen, len(g.path)))

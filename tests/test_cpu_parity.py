@@ -15,8 +15,8 @@ import jumanpp_amd as J
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_golden(lib, golden_dir, gold_name, **cfg):
-    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=lib, **cfg)
+def _run_golden(lib, golden_dir, gold_name, image='mini.img', **cfg):
+    ctx = J.Context(os.path.join(golden_dir, image), lib_path=lib, **cfg)
     lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
     meta, gold = G.read_gold(os.path.join(golden_dir, gold_name))
     assert meta['nsent'] == len(lines)
@@ -36,6 +36,13 @@ def test_emulated_kernels_match_reference_default_config(emu_lib, golden_dir):
 def test_emulated_kernels_match_reference_other_beam_config(emu_lib, golden_dir):
     # beam 3, global beam 4, right-check 2, right-beam 3
     _run_golden(emu_lib, golden_dir, 'mini_b3.gold', beam=3, global_beam=4, right_check=2, right_beam=3)
+
+
+def test_emulated_kernels_match_reference_with_rnn(emu_lib, golden_dir):
+    # perceptron + RNNLM re-ranking: lattice/perceptron cells bit-exact, RNN cells and
+    # re-ranked totals within 1e-4 (tests/golden_io.py)
+    res = _run_golden(emu_lib, golden_dir, 'mini_rnn.gold', image='mini_rnn.img')
+    assert res.cells.shape[2] == 2
 
 
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):

@@ -41,6 +41,16 @@ def test_gpu_matches_reference_other_beam_config(gpu_lib, golden_dir):
     assert not errs, errs[:10]
 
 
+def test_gpu_matches_reference_with_rnn(gpu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=gpu_lib)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    meta, gold = G.read_gold(os.path.join(golden_dir, 'mini_rnn.gold'))
+    assert meta['nscorers'] == 2
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, errs[:10]
+
+
 def test_gpu_status_codes(gpu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=gpu_lib)
     sents = [b'\xe3\x81', b'ok', b'\xff\xfe', ('あ' * 1400).encode('utf-8'), b'']
@@ -48,7 +58,7 @@ def test_gpu_status_codes(gpu_lib, golden_dir):
     assert list(res.status) == [2, 0, 2, 1, 0]
 
 
-def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40):
+def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None):
     mdic = os.path.join(tmp, 'w.mdic')
     with open(mdic, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)],
@@ -57,6 +67,17 @@ def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40):
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'mkmodel', os.path.join(tmp, 'w.seed'),
                            os.path.join(tmp, 'w.model'), str(exp), str(seed), '0.1'])
+    if rnn is not None:
+        hidden, vocab = rnn
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_rnn.py'), mdic, os.path.join(tmp, 'rnn'),
+                               '--vocab', str(vocab), '--hidden', str(hidden), '--maxent-size', str(1 << 18),
+                               '--seed', str(seed)], stdout=subprocess.DEVNULL)
+        os.rename(os.path.join(tmp, 'w.model'), os.path.join(tmp, 'p.model'))
+        subprocess.check_call([os.path.join(ref_tools, 'jumanpp_v2_train'), '--model-input=' + os.path.join(tmp, 'p.model'),
+                               '--model-output=' + os.path.join(tmp, 'w.model'), '--rnn-model=' + os.path.join(tmp, 'rnn'),
+                               '--rnn-fields=surface,pos', '--rnn-nce-bias=5.6', '--rnn-unk-constant=-3.47',
+                               '--rnn-unk-length=-2.93', '--feature-weight-perceptron=1', '--feature-weight-rnn=0.0176'],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'export', os.path.join(tmp, 'w.model'),
                            os.path.join(tmp, 'w.img')], stderr=subprocess.DEVNULL)
     txt = os.path.join(tmp, 'w.txt')
@@ -79,6 +100,19 @@ def test_gpu_matches_live_reference_on_fresh_workload(gpu_lib, ref_tools, tmp_pa
     img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 30000, 2000, 20, 77)
     ctx = J.Context(img, lib_path=gpu_lib)
     meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
+
+
+def test_gpu_matches_live_reference_with_rnn(gpu_lib, ref_tools, tmp_path):
+    """config[2] shape: perceptron + RNNLM (E=128), 1000 fresh sentences vs the live reference."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 30000, 1000, 20, 55, rnn=(128, 8000))
+    ctx = J.Context(img, lib_path=gpu_lib)
+    meta, gold = G.read_gold(gold_path)
+    assert meta['nscorers'] == 2
     res = ctx.analyze(lines).fetch(full=True)
     errs = _compare_all(res, gold, meta, len(lines))
     assert not errs, (len(errs), errs[:10])
