@@ -251,10 +251,12 @@ def main():
             'dtype': 'u64 hashing + f32 adds',
             'data': 'synthetic',
             'config': {
-                'workload': ('BASELINE configs[2]: 1xMI355X per rank, perceptron + RNNLM (E=%d), ' % args.rnn_hidden if args.rnn else 'BASELINE configs[1]: 1xMI355X per rank, linear perceptron scorer only (RNN off), ')
-                            'beam=5 gbeam=6 rcheck=1 rbeam=5, synthetic %d-codepoint UTF-8 sentences batched %d, '
-                            '%d-entry synthetic jumandic-layout dictionary, 2^%d random weights'
-                            % (args.sent_len, args.batch, args.dict_entries, args.weights_exp),
+                'workload': (('BASELINE configs[2]: 1xMI355X per rank, perceptron + RNNLM (E=%d), ' % args.rnn_hidden)
+                             if args.rnn else
+                             'BASELINE configs[1]: 1xMI355X per rank, linear perceptron scorer only (RNN off), ')
+                            + ('beam=5 gbeam=6 rcheck=1 rbeam=5, synthetic %d-codepoint UTF-8 sentences batched %d, '
+                               '%d-entry synthetic jumandic-layout dictionary, 2^%d random weights'
+                               % (args.sent_len, args.batch, args.dict_entries, args.weights_exp)),
                 'sentences_per_step_per_gpu': args.batch,
                 'nodes_per_sentence': round(ab['nodes'] / args.batch, 1),
                 'failed_sentences_in_batch': bad,

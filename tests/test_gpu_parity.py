@@ -146,6 +146,7 @@ def test_gpu_batch_split_invariance(gpu_lib, golden_dir):
         assert whole[s] == whole[s + 28 * 7]
     res1 = ctx.analyze(lines[3:4]).fetch(full=True)
     pl = int(res1.path_len[0])
-    nodes = res1.nodes[res1.path_nodes[:pl]]
+    nb1 = int(res1.node_base[0])
+    nodes = res1.nodes[nb1 + res1.path_nodes[nb1:nb1 + pl]]
     one = tuple((int(x['start']), int(x['end']), int(x['eptr'])) for x in nodes)
     assert one == whole[3][0]
