@@ -193,6 +193,11 @@ def main():
         o = torch.from_numpy(offs.astype(np.int32).view(np.int32)).to(dev)
         d_batches.append((t, o, len(offs) - 1, len(text)))
     stream = torch.cuda.current_stream().cuda_stream
+    # packed top-1 output (8 B / morpheme) -- what a CLI would format, and what is gathered across GPUs
+    cap_items = args.batch * (args.sent_len + 1)
+    d_offs = torch.zeros(args.batch + 1, dtype=torch.int32, device=dev)
+    d_items = torch.zeros((cap_items, 2), dtype=torch.int32, device=dev)
+    from jumanpp_amd.dist import gather_packed
 
     def step(i):
         t, o, n, nbytes = d_batches[i % len(d_batches)]
@@ -210,8 +215,13 @@ def main():
     total_path = 0
     for i in range(args.steps):
         r = step(args.warmup + i)
-        _, npath = r.stats()  # forces completion of the batch; 4 bytes/sentence D2H
-        total_path += npath
+        r.pack(d_offs.data_ptr(), d_items.data_ptr(), cap_items)
+        if dist is not None:
+            got = gather_packed(d_offs, d_items, dst=0)   # RCCL: sizes all-gather + payload gather to rank 0
+            if rank == 0:
+                total_path += sum(int(g[0][-1]) for g in got)
+        else:
+            total_path += int(d_offs[-1].item())          # forces completion of the batch
         for k, v in ctx.timings().items():
             kernel_ms[k] = kernel_ms.get(k, 0.0) + v
         r.release()
@@ -235,7 +245,7 @@ def main():
         bad = int((r.status != 0).sum())
         r.release()
         avg = {k: v / args.steps for k, v in kernel_ms.items()}
-        dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'
+        dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'  # k_rnn has its own line in kernel_ms_per_step
         achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         out = {
             'metric': 'sentences/sec whole-node, beam=5 jumandic %s; achieved HBM GB/s' % ('+RNNLM' if args.rnn else 'perceptron (RNN off)'),
@@ -260,6 +270,7 @@ def main():
                 'sentences_per_step_per_gpu': args.batch,
                 'nodes_per_sentence': round(ab['nodes'] / args.batch, 1),
                 'failed_sentences_in_batch': bad,
+                'morphemes_per_sentence': round(total_path / max(1, sentences), 2),
                 'parallelism': 'sentence-sharded x%d, no data-path collective' % world,
             },
             'kernel_ms_per_step': {k: round(v, 3) for k, v in avg.items()},

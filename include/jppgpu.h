@@ -190,10 +190,14 @@ int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void*
 int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_view* view);
 /* Per-batch statistics without copying the lattice: total nodes, sum of path lengths. */
 int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path);
+/* Packed top-1 output written to caller-provided DEVICE buffers (e.g. to be gathered
+ * across GPUs with RCCL): d_offsets[n+1] (exclusive scan of morphemes per sentence) and
+ * d_items[cap_items] of jppgpu_node in text order.  Enqueued on the batch's stream. */
+int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_items, uint64_t cap_items);
 void jppgpu_result_release(jppgpu_result* res);
 
 /* device timing of the last batch's kernels in milliseconds (HIP events on the launch stream):
- * [0] decode [1] seeds [2] layout [3] t0 [4] sweep [5] path, [6] whole pipeline */
+ * [0] decode [1] seeds [2] layout [3] t0 [4] sweep [5] rnn [6] path, [7] whole pipeline */
 int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n);
 
 #ifdef __cplusplus

@@ -65,7 +65,7 @@ void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
 }
 void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
 struct Timer {
-  hipEvent_t ev[8];
+  hipEvent_t ev[9];
   bool have = false;
   void init() {
     for (auto& e : ev) (void)hipEventCreate(&e);
@@ -78,14 +78,13 @@ struct Timer {
   }
   void mark(int i, jpp_stream_t s) { (void)hipEventRecord(ev[i], s); }
   void collect(float* ms) {
-    // ev[0]..ev[6] bracket the six phases
-    for (int i = 0; i < 6; ++i) {
+    // ev[0]..ev[7] bracket the seven phases
+    for (int i = 0; i < 7; ++i) {
       ms[i] = 0;
       (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
     }
-    ms[6] = 0;
-    (void)hipEventElapsedTime(&ms[6], ev[0], ev[6]);
     ms[7] = 0;
+    (void)hipEventElapsedTime(&ms[7], ev[0], ev[7]);
   }
 };
 #endif
@@ -152,7 +151,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
@@ -362,7 +361,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx};
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   ctx->timer.destroy();
@@ -495,10 +494,11 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
   T.mark(4, st);
   JPP_LAUNCH(k_sweep, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_rnn, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   T.mark(5, st);
-  JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
+  if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_rnn, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   T.mark(6, st);
+  JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
+  T.mark(7, st);
   ctx->last_stream = st;
   ctx->timing_pending = true;
 #if !defined(JPP_EMU)
@@ -551,6 +551,23 @@ extern "C" int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, ui
   for (auto x : pl) sum += x;
   if (total_nodes) *total_nodes = res->B.total_nodes;
   if (total_path) *total_path = sum;
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_items, uint64_t cap_items) {
+  if (!res || !res->ctx || !d_offsets || (!d_items && cap_items)) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jppgpu_ctx* ctx = res->ctx;
+  if (res->generation != ctx->generation) return fail(JPPGPU_INVALID_STATE, "result was invalidated");
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  if (!(ctx->pack_cnt.ensure(((size_t)n + 1) * 4) && ctx->pack_off.ensure(((size_t)n + 2) * 8)))
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (pack)");
+  jpp_stream_t st = ctx->last_stream;
+  const u32 sblocks = (n + 1 + 255) / 256;
+  if (n) JPP_LAUNCH(k_pack_count, sblocks, 256, st, B, ctx->pack_cnt.as<u32>());
+  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
+  JPP_LAUNCH(k_pack_write, sblocks, 256, st, B, (const u64*)ctx->pack_off.as<u64>(), static_cast<u32*>(d_offsets),
+             static_cast<NodeInfo*>(d_items), (u64)cap_items);
   return JPPGPU_OK;
 }
 

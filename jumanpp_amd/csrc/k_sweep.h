@@ -411,6 +411,31 @@ __global__ void k_path(Batch B, Config cfg) {
   B.path_len[s] = len;
 }
 
+// Packed top-1 results for the host / for the cross-GPU gather: per sentence the
+// morphemes of the best path in text order (EOS dropped), 8 bytes each.
+__global__ void k_pack_count(Batch B, u32* counts) {
+  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.n_sent) return;
+  u32 pl = B.sent_status[s] == ST_OK ? B.path_len[s] : 0;
+  counts[s] = pl > 0 ? pl - 1 : 0;
+}
+
+__global__ void k_pack_write(Batch B, const u64* offs, u32* out_off, NodeInfo* items, u64 cap) {
+  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > B.n_sent) return;
+  u64 o = offs[s];
+  out_off[s] = (u32)o;
+  if (s == B.n_sent) return;
+  u32 pl = B.sent_status[s] == ST_OK ? B.path_len[s] : 0;
+  if (pl <= 1) return;
+  u64 nb = B.node_base[s];
+  for (u32 k = 0; k + 1 < pl; ++k) {
+    // path_nodes is EOS first; emit first morpheme first
+    u32 node = B.path_nodes[nb + (pl - 1 - k)];
+    if (o + k < cap) items[o + k] = B.node_info[nb + node];
+  }
+}
+
 }  // namespace jpp
 
 #endif  // JPP_K_SWEEP_H

@@ -1,0 +1,44 @@
+"""Result gather for sentence-sharded multi-GPU runs.
+
+Sentences are independent, so the data path has no collective.  The only
+exchange is the gather of packed top-1 results to rank 0: an all-gather of the
+per-rank sizes, then one gather of the padded payloads (RCCL over xGMI when the
+tensors live on the GPUs and the backend is "nccl"; gloo on CPU in tests).
+Sentence order is preserved because shards are contiguous blocks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def gather_packed(offsets, items, dst=0):
+    """offsets: int32 [n+1] exclusive scan, items: int32 [m, 2] (8-byte morpheme records).
+    Returns on `dst` a list of (offsets, items) per rank in rank order, None elsewhere."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    dev = offsets.device
+    n = offsets.numel() - 1
+    m = int(offsets[-1].item())
+    sizes = torch.tensor([n, m], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    max_n = max(int(x[0]) for x in all_sizes)
+    max_m = max(int(x[1]) for x in all_sizes)
+    payload = torch.zeros(max_n + 1 + 2 * max_m, dtype=torch.int32, device=dev)
+    payload[:n + 1] = offsets
+    payload[max_n + 1:max_n + 1 + 2 * m] = items[:m].reshape(-1)
+    bufs = [torch.zeros_like(payload) for _ in range(world)] if rank == dst else None
+    dist.gather(payload, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = []
+    for r in range(world):
+        rn, rm = int(all_sizes[r][0]), int(all_sizes[r][1])
+        out.append((bufs[r][:rn + 1].clone(), bufs[r][max_n + 1:max_n + 1 + 2 * rm].reshape(-1, 2).clone()))
+    return out
+
+
+def shard_range(n, rank, world):
+    """contiguous block partition by sentence index"""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)

@@ -86,6 +86,7 @@ def load_library(path=None):
     lib.jppgpu_result_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(ResultView)]
     lib.jppgpu_result_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.jppgpu_result_release.argtypes = [C.c_void_p]
+    lib.jppgpu_result_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     lib.jppgpu_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     _libs[path] = lib
     return lib
@@ -167,6 +168,12 @@ class Result:
         if rc != 0:
             raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
         return a.value, b.value
+
+    def pack(self, offsets_ptr, items_ptr, cap_items):
+        """packed top-1 morphemes into caller-owned device buffers (see jppgpu_result_pack)"""
+        rc = self.ctx.lib.jppgpu_result_pack(self.handle, offsets_ptr, items_ptr, cap_items)
+        if rc != 0:
+            raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
 
     def release(self):
         if self.handle:
@@ -291,8 +298,8 @@ class Context:
     def timings(self):
         ms = (C.c_float * 8)()
         self.lib.jppgpu_last_timings(self.handle, ms, 8)
-        names = ['decode', 'seeds', 'layout', 't0', 'sweep', 'path', 'total']
-        return dict(zip(names, list(ms)[:7]))
+        names = ['decode', 'seeds', 'layout', 't0', 'sweep', 'rnn', 'path', 'total']
+        return dict(zip(names, list(ms)[:8]))
 
     def close(self):
         if self.handle:
