@@ -9,13 +9,14 @@ namespace jpp {
 constexpr int kMaxUnkMakers = 16;
 constexpr int kMaxDicFeatures = 16;
 constexpr int kPat = 14;          // stored patterns per node (jumandic spec)
-constexpr int kMaxGbeam = 16;     // exact stable-rank beam forming holds for <= 16 (std::sort == insertion sort)
-constexpr int kMaxBeam = 16;
+constexpr int kMaxGbeam = 32;     // global beam capacity (k_sweep<8> for the CLI defaults, k_sweep<32> beyond)
+constexpr int kMaxBeam = 32;
 constexpr int kMaxRight = 512;    // right nodes per boundary staged in LDS by the sweep kernel
 constexpr int kMaxNormStates = 64;
 constexpr int kMaxNormResults = 160;
 constexpr int kMaxRnnE = 256;      // RNN hidden size staged per lane (E/64 <= 4)
-constexpr int kRnnCtxCap = 2048;   // global_beam * E floats of LDS per context buffer
+constexpr int kRnnChunk = 8;       // rnn nodes of one boundary processed per pass
+constexpr int kRnnCtxCap = kRnnChunk * kMaxRnnE;  // floats of LDS for the staged prev contexts
 
 // entry pointers (reference src/core/core_types.h:44-58)
 constexpr i32 kEptrBOS = (i32)0x80000000;

@@ -194,7 +194,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   if (c->right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
   if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED,
-                "jppgpu: beam/global beam > 16 needs the libstdc++ introsort tie order; not implemented yet");
+                "jppgpu: beam / global beam > 32 is not supported");
   if (c->global_beam > c->beam * 4 / 3)
     return fail(JPPGPU_NOT_IMPLEMENTED,
                 "jppgpu: global beam > beam*4/3 takes the reference's quickselect branch of makeT0Beam; not "
@@ -298,10 +298,10 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
       return fail(JPPGPU_INVALID_PARAMETER, "use_rnn set but the model has no RNN part");
     }
     const u64 E = m->rnn_layer_size, V = m->rnn_vocab_size;
-    if (E == 0 || E > (u64)kMaxRnnE || E * (u64)c->global_beam > (u64)kRnnCtxCap || m->rnn_maxent_order > 4 ||
+    if (E == 0 || E > (u64)kMaxRnnE || m->rnn_maxent_order > 4 ||
         m->rnn_num_fields > 8 || m->rnn_maxent_size <= V) {
       jppgpu_ctx_destroy(ctx);
-      return fail(JPPGPU_NOT_IMPLEMENTED, "RNN shape outside the supported range (E<=256, G*E<=2048, order<=4)");
+      return fail(JPPGPU_NOT_IMPLEMENTED, "RNN shape outside the supported range (E<=256, maxent order<=4)");
     }
     std::vector<float> wt(E * E);
     for (u64 i = 0; i < E; ++i)
@@ -493,7 +493,11 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(3, st);
   JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
   T.mark(4, st);
-  JPP_LAUNCH(k_sweep, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8) {
+    JPP_LAUNCH(k_sweep<8>, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else {
+    JPP_LAUNCH(k_sweep<32>, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  }
   T.mark(5, st);
   if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_rnn, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   T.mark(6, st);

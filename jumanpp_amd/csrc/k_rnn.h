@@ -134,13 +134,13 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
   const u32 efirstE = B.end_first[bb0 + bE];
   if (lane < ngb) {
     GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
-    conn[(u64)bE * G + lane] = (N - 1) | ((u32)lane << 28);  // fake EOS connection, "slot" = path index
+    conn[(u64)bE * G + lane] = (N - 1) | ((u32)lane << 26);  // fake EOS connection, "slot" = path index
     u32 nd = en[efirstE + ge.left];
     u32 k = ge.beam;
     u32 guard = 0;
     while (nd >= 2 && guard++ <= n) {
       u32 b = (u32)B.node_info[nb + nd].start + 2;
-      conn[(u64)b * G + lane] = nd | (k << 28);
+      conn[(u64)b * G + lane] = nd | (k << 26);
       BeamSlot sl = beams[(u64)nd * beam + k];
       nd = sl.prev_node;
       k = sl.beam;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
   for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) {
     u32 c = conn[q];
     if (c == kNoConn) continue;
-    u32 nd = c & 0x0fffffffu;
+    u32 nd = c & 0x03ffffffu;
     wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
   }
   __syncthreads();
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
           cur = b * G + a;
           continue;
         }
-        u32 nd = c & 0x0fffffffu;
+        u32 nd = c & 0x03ffffffu;
         i32 id = wid[(u64)b * G + p];
         u32 len = (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
         u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
@@ -232,93 +232,96 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
   for (u32 b = 2; b <= bE; ++b) {
     const int cnt = (int)rn_cnt[b];
     if (cnt == 0) continue;
-    // stage the prev contexts
-    for (u32 q = lane; q < (u32)cnt * E; q += 64) {
-      u32 x = q / E, e = q - x * E;
-      pctx[q] = rn_ctx[(u64)rn_prev[(u64)b * G + x] * E + e];
-    }
-    __syncthreads();
-    // score of every rnn node of this boundary
-    for (int x = 0; x < cnt; ++x) {
-      i32 id = rn_id[(u64)b * G + x];
-      u32 eid = id == -1 ? 0u : (u32)id;
-      float part = 0.f;
-      for (u32 e = lane; e < E; e += 64) part += M.rnn_nce[(u64)eid * E + e] * pctx[(u32)x * E + e];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) part += wave_shfl_f32(part, lane ^ o);
-      if (lane == 0) {
-        float score = part;
-        // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
-        float me = 0.f;
-        u32 order = M.rnn_order;
-        i32 pid = rn_id[rn_prev[(u64)b * G + x]];
-        for (u32 i = 0; i < order; ++i) {
-          u64 xx = rnn_prime(0) * rnn_prime(1);
-          for (u32 j = 1; j <= i; ++j) {
-            u64 pi = ((u64)i * rnn_prime(j) + j) % 36;
-            xx += rnn_prime((u32)pi) * ((u64)(i64)pid + 1);
-          }
-          u64 h = xx % M.rnn_hash_max;
-          u64 idx = (h + (u64)(i64)id) % M.rnn_hash_max;
-          float w = M.rnn_maxent[idx];
-          me = (i == 0) ? w : me + w;
-        }
-        if (order > 0) score += me;
-        else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
-        score -= M.rnn_nce_const;
-        if (id == M.rnn_unk_id) score = M.rnn_unk_const + M.rnn_unk_len * (float)rn_len[(u64)b * G + x];
-        nscore[x] = score;
+    for (int c0 = 0; c0 < cnt; c0 += kRnnChunk) {
+      const int cn = (cnt - c0) < kRnnChunk ? (cnt - c0) : kRnnChunk;
+      // stage the prev contexts of this chunk of rnn nodes
+      for (u32 q = lane; q < (u32)cn * E; q += 64) {
+        u32 x = q / E, e = q - x * E;
+        pctx[q] = rn_ctx[(u64)rn_prev[(u64)b * G + c0 + x] * E + e];
       }
-    }
-    __syncthreads();
-    if (lane < ngb) {
-      u32 c = conn[(u64)b * G + lane];
-      if (c != kNoConn) {
-        u32 nd = c & 0x0fffffffu, k = c >> 28;
-        u32 gi = (nd == N - 1) ? k : beams[(u64)nd * beam + k].pad;
-        B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
-      }
-    }
-    // new contexts (GbeamRnnState::computeContext; not needed for EOS)
-    if (b < bE) {
-      float acc[kMaxGbeam][kMaxRnnE / 64];
+      __syncthreads();
+      // score of every rnn node of the chunk
+      for (int x = 0; x < cn; ++x) {
+        i32 id = rn_id[(u64)b * G + c0 + x];
+        u32 eid = id == -1 ? 0u : (u32)id;
+        float part = 0.f;
+        for (u32 e = lane; e < E; e += 64) part += M.rnn_nce[(u64)eid * E + e] * pctx[(u32)x * E + e];
 #pragma unroll
-      for (int p = 0; p < kMaxGbeam; ++p)
-#pragma unroll
-        for (int j = 0; j < kMaxRnnE / 64; ++j) acc[p][j] = 0.f;
-      for (u32 k = 0; k < E; ++k) {
-        float w[kMaxRnnE / 64];
-#pragma unroll
-        for (int j = 0; j < kMaxRnnE / 64; ++j) {
-          u32 i = (u32)lane + 64u * j;
-          w[j] = (j < J && i < E) ? M.rnn_wt[(u64)k * E + i] : 0.f;
-        }
-#pragma unroll
-        for (int p = 0; p < kMaxGbeam; ++p) {
-          if (p < cnt) {
-            float c = pctx[(u32)p * E + k];
-#pragma unroll
-            for (int j = 0; j < kMaxRnnE / 64; ++j) {
-              float prod = w[j] * c;
-              acc[p][j] += prod;
+        for (int o = 32; o > 0; o >>= 1) part += wave_shfl_f32(part, lane ^ o);
+        if (lane == 0) {
+          float score = part;
+          // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
+          float me = 0.f;
+          u32 order = M.rnn_order;
+          i32 pid = rn_id[rn_prev[(u64)b * G + c0 + x]];
+          for (u32 i = 0; i < order; ++i) {
+            u64 xx = rnn_prime(0) * rnn_prime(1);
+            for (u32 j = 1; j <= i; ++j) {
+              u64 pi = ((u64)i * rnn_prime(j) + j) % 36;
+              xx += rnn_prime((u32)pi) * ((u64)(i64)pid + 1);
             }
+            u64 h = xx % M.rnn_hash_max;
+            u64 idx = (h + (u64)(i64)id) % M.rnn_hash_max;
+            float w = M.rnn_maxent[idx];
+            me = (i == 0) ? w : me + w;
           }
+          if (order > 0) score += me;
+          else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+          score -= M.rnn_nce_const;
+          if (id == M.rnn_unk_id) score = M.rnn_unk_const + M.rnn_unk_len * (float)rn_len[(u64)b * G + c0 + x];
+          nscore[c0 + x] = score;
         }
       }
+      // new contexts (GbeamRnnState::computeContext; not needed for EOS)
+      if (b < bE) {
+        float acc[kRnnChunk][kMaxRnnE / 64];
 #pragma unroll
-      for (int p = 0; p < kMaxGbeam; ++p) {
-        if (p < cnt) {
-          i32 id = rn_id[(u64)b * G + p];
-          u32 eid = id == -1 ? 0u : (u32)id;
+        for (int p = 0; p < kRnnChunk; ++p)
+#pragma unroll
+          for (int j = 0; j < kMaxRnnE / 64; ++j) acc[p][j] = 0.f;
+        for (u32 k = 0; k < E; ++k) {
+          float w[kMaxRnnE / 64];
 #pragma unroll
           for (int j = 0; j < kMaxRnnE / 64; ++j) {
             u32 i = (u32)lane + 64u * j;
-            if (j < J && i < E) {
-              float x = acc[p][j] + M.rnn_emb[(u64)eid * E + i];
-              rn_ctx[((u64)b * G + p) * E + i] = 1.0f / (1.0f + expf(-x));
+            w[j] = (j < J && i < E) ? M.rnn_wt[(u64)k * E + i] : 0.f;
+          }
+#pragma unroll
+          for (int p = 0; p < kRnnChunk; ++p) {
+            if (p < cn) {
+              float c = pctx[(u32)p * E + k];
+#pragma unroll
+              for (int j = 0; j < kMaxRnnE / 64; ++j) {
+                float prod = w[j] * c;
+                acc[p][j] += prod;
+              }
             }
           }
         }
+#pragma unroll
+        for (int p = 0; p < kRnnChunk; ++p) {
+          if (p < cn) {
+            i32 id = rn_id[(u64)b * G + c0 + p];
+            u32 eid = id == -1 ? 0u : (u32)id;
+#pragma unroll
+            for (int j = 0; j < kMaxRnnE / 64; ++j) {
+              u32 i = (u32)lane + 64u * j;
+              if (j < J && i < E) {
+                float x = acc[p][j] + M.rnn_emb[(u64)eid * E + i];
+                rn_ctx[((u64)b * G + c0 + p) * E + i] = 1.0f / (1.0f + expf(-x));
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (lane < ngb) {
+      u32 c = conn[(u64)b * G + lane];
+      if (c != kNoConn) {
+        u32 nd = c & 0x03ffffffu, k = c >> 26;
+        u32 gi = (nd == N - 1) ? k : beams[(u64)nd * beam + k].pad;
+        B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
       }
     }
     __syncthreads();
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
     for (u32 b = 2; b < bE; ++b) {
       u32 c = conn[(u64)b * G + lane];
       if (c == kNoConn) continue;
-      u32 nd = c & 0x0fffffffu, k = c >> 28;
+      u32 nd = c & 0x03ffffffu, k = c >> 26;
       BeamSlot* sl = &beams[(u64)nd * beam + k];
       const float* cell = B.node_cells + ((nb + nd) * G + sl->pad) * S;
       float local = 0.f;

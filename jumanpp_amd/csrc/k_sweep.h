@@ -62,6 +62,8 @@ constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
 __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == kFake16 && s.beam == kFake16; }
 
+// GM = compile-time capacity of the global beam / per-node beam (8 for the CLI defaults, 32 for wide beams)
+template <int GM>
 __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
@@ -80,22 +82,22 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
   const u64* pats = B.node_pat + nb * kPat;
   const float* t0s = B.node_t0 + nb;
 
-  __shared__ u64 gb_key[kMaxGbeam];
-  __shared__ u16 gb_left[kMaxGbeam];
-  __shared__ u16 gb_slot[kMaxGbeam];
-  __shared__ float gb_score[kMaxGbeam];
-  __shared__ u32 gb_lnode[kMaxGbeam];
-  __shared__ u32 gb_pnode[kMaxGbeam];
-  __shared__ u32 gb_t1[kMaxGbeam];
-  __shared__ u32 t1node[kMaxGbeam];
+  __shared__ u64 gb_key[GM];
+  __shared__ u16 gb_left[GM];
+  __shared__ u16 gb_slot[GM];
+  __shared__ float gb_score[GM];
+  __shared__ u32 gb_lnode[GM];
+  __shared__ u32 gb_pnode[GM];
+  __shared__ u32 gb_t1[GM];
+  __shared__ u32 t1node[GM];
   __shared__ u32 sh_U;
-  __shared__ u64 t1pat[kMaxGbeam][kPat];
-  __shared__ u64 t2pat[kMaxGbeam][kPat];
+  __shared__ u64 t1pat[GM][kPat];
+  __shared__ u64 t2pat[GM][kPat];
   __shared__ float pres[kPresCap];
   __shared__ float csum[kMaxRight];
   __shared__ u16 order[kMaxRight];
-  __shared__ float biS[kChunk][kMaxGbeam];
-  __shared__ float tot[kChunk][kMaxGbeam];
+  __shared__ float biS[kChunk][GM];
+  __shared__ float tot[kChunk][GM];
 
   if (n == 0) {
     // empty input: the reference returns before scoring anything
@@ -363,12 +365,28 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
       __syncthreads();
       // 5c. beams: stable descending rank among the node's candidates (makeT0Beam; for <= 16
       //     candidates std::sort is an insertion sort, i.e. stable)
-      for (int q = lane; q < nx * kMaxGbeam; q += 64) {
-        int x = q / kMaxGbeam, i = q - x * kMaxGbeam;
+      for (int q = lane; q < nx * GM; q += 64) {
+        int x = q / GM, i = q - x * GM;
         bool kept = (op0 + x) < K;
         u32 t = order[op0 + x];
         int cnt = kept ? ngb : c;
         BeamSlot* row = beams + (u64)(rfirst + t) * beam;
+        if (GM > 16 && cnt > 16) {
+          // more than 16 candidates: libstdc++'s std::sort is an introsort (not stable); one lane per
+          // right node replays it on the index array exactly as makeT0Beam does
+          if (i == 0) {
+            u8 idx[GM];
+            for (int z = 0; z < cnt; ++z) idx[z] = (u8)z;
+            const float* tr = tot[x];
+            std_sort(idx, idx + cnt, [tr](u8 a, u8 bb) { return tr[a] > tr[bb]; });
+            for (int z = 0; z < beam; ++z) {
+              if (z < cnt) row[z] = BeamSlot{gb_left[idx[z]], gb_slot[idx[z]], tr[idx[z]], gb_lnode[idx[z]], (u32)idx[z]};
+              else row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+            }
+            B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
+          }
+          continue;
+        }
         if (i < cnt) {
           float me = tot[x][i];
           int rank = 0;

@@ -45,6 +45,22 @@ def test_emulated_kernels_match_reference_with_rnn(emu_lib, golden_dir):
     assert res.cells.shape[2] == 2
 
 
+def test_emulated_wide_beam_matches_live_reference(emu_lib, golden_dir, ref_tools, tmp_path):
+    """beam 20 / global beam 24: more than 16 candidates per node -> libstdc++ introsort order."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    img, lines, gold_path = tg._fresh_workload(ref_tools, str(tmp_path), 2500, 10, 14, 5, length=40,
+                                               beams=[20, 24, 1, 20])
+    ctx = J.Context(img, lib_path=emu_lib, beam=20, global_beam=24, right_check=1, right_beam=20)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     # reference: invalid UTF-8 -> InvalidParameter (characters.cc:267-269);

@@ -58,7 +58,7 @@ def test_gpu_status_codes(gpu_lib, golden_dir):
     assert list(res.status) == [2, 0, 2, 1, 0]
 
 
-def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None):
+def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None, beams=None):
     mdic = os.path.join(tmp, 'w.mdic')
     with open(mdic, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)],
@@ -86,7 +86,8 @@ def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rn
                                str(seed + 1), '--oov', '0.08', '--len', str(length)], stdout=f)
     with open(txt, 'rb') as f:
         subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', os.path.join(tmp, 'w.model'),
-                               os.path.join(tmp, 'w.gold')], stdin=f, stderr=subprocess.DEVNULL)
+                               os.path.join(tmp, 'w.gold')] + [str(x) for x in (beams or [])],
+                              stdin=f, stderr=subprocess.DEVNULL)
     lines = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
     return os.path.join(tmp, 'w.img'), lines, os.path.join(tmp, 'w.gold')
 
@@ -124,6 +125,21 @@ def test_gpu_long_sentences(gpu_lib, ref_tools, tmp_path):
     img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 8000, 100, 18, 91, length=220)
     ctx = J.Context(img, lib_path=gpu_lib)
     meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
+
+
+def test_gpu_config5_wide_beam_long_sentences_rnn(gpu_lib, ref_tools, tmp_path):
+    """BASELINE configs[4] shape: beam=32, global beam 32, >= 200-codepoint sentences, RNN on.
+    More than 16 beam candidates means libstdc++'s introsort tie order must be replayed exactly."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 20000, 120, 18, 123, length=210,
+                                            rnn=(128, 5000), beams=[32, 32, 1, 32])
+    ctx = J.Context(img, lib_path=gpu_lib, beam=32, global_beam=32, right_check=1, right_beam=32)
+    meta, gold = G.read_gold(gold_path)
+    assert meta['beam'] == 32 and meta['nscorers'] == 2
     res = ctx.analyze(lines).fetch(full=True)
     errs = _compare_all(res, gold, meta, len(lines))
     assert not errs, (len(errs), errs[:10])
