@@ -19,6 +19,7 @@
 #include "k_rnn.h"
 #include "k_seeds.h"
 #include "k_sweep.h"
+#include "k_sweep_full.h"
 #include "k_t0.h"
 
 using namespace jpp;
@@ -186,16 +187,15 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
 #endif
   // --- configuration checks (AnalyzerImpl::initScorers, analyzer_impl.cc:43-89) ---
   if (c->beam <= 0) return fail(JPPGPU_INVALID_PARAMETER, "AnalyzerImpl: beam size can not be zero for scoring");
-  if (c->global_beam <= 0)
-    return fail(JPPGPU_NOT_IMPLEMENTED,
-                "jppgpu: the full-beam path (--global-beam 0, computeScoresFull) is not implemented yet");
-  if (c->right_check > 0 && c->right_beam <= 0)
+  if (c->global_beam <= 0 && c->use_rnn)
+    return fail(JPPGPU_INVALID_STATE, "additional scorers are supported only with global beam enabled");
+  if (c->global_beam > 0 && c->right_check > 0 && c->right_beam <= 0)
     return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
   if (c->right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
   if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED,
                 "jppgpu: beam / global beam > 32 is not supported");
-  if (c->global_beam > c->beam * 4 / 3)
+  if (c->global_beam > 0 && c->global_beam > c->beam * 4 / 3)
     return fail(JPPGPU_NOT_IMPLEMENTED,
                 "jppgpu: global beam > beam*4/3 takes the reference's quickselect branch of makeT0Beam; not "
                 "implemented yet");
@@ -214,7 +214,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
 
   auto* ctx = new jppgpu_ctx();
   ctx->device = c->device;
-  ctx->cfg = Config{c->beam, c->global_beam, c->right_check, c->right_beam,
+  ctx->cfg = Config{c->beam, c->global_beam > 0 ? c->global_beam : 0, c->right_check, c->right_beam,
                     c->max_input_bytes > 0 ? c->max_input_bytes : 4096, c->use_rnn ? 2 : 1,
                     c->use_rnn ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
   if (ctx->cfg.max_input_bytes > 65535) ctx->cfg.max_input_bytes = 65535;
@@ -493,7 +493,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(3, st);
   JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
   T.mark(4, st);
-  if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8) {
+  if (ctx->cfg.gbeam == 0) {
+    JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8) {
     JPP_LAUNCH(k_sweep<8>, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else {
     JPP_LAUNCH(k_sweep<32>, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);

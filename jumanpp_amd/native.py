@@ -156,10 +156,10 @@ class Result:
             self.patterns = self._arr(v.patterns, '<u8', N * 14).reshape(-1, 14)
             self.t0 = self._arr(v.t0_scores, '<f4', N)
             self.beams = self._arr(v.beams, BEAM_DT, N * v.beam).reshape(-1, v.beam)
-            self.cells = self._arr(v.cells, '<f4', N * v.global_beam * v.num_scorers).reshape(-1, v.global_beam, v.num_scorers)
+            self.cells = self._arr(v.cells, '<f4', N * v.global_beam * v.num_scorers).reshape(N if v.global_beam else 0, v.global_beam, v.num_scorers)
             self.kept = self._arr(v.kept, 'u1', N)
             self.gbeam_count = self._arr(v.gbeam_count, '<u4', NB)
-            self.gbeam_entries = self._arr(v.gbeam, GBEAM_DT, NB * v.global_beam).reshape(-1, v.global_beam)
+            self.gbeam_entries = self._arr(v.gbeam, GBEAM_DT, NB * v.global_beam).reshape(NB if v.global_beam else 0, v.global_beam)
         return self
 
     def stats(self):

@@ -443,8 +443,33 @@ int doDump(const char* modelFile, const char* out, char** extra, int nextra) {
     std::vector<std::vector<float>> t0(nb);
     std::vector<std::vector<u8>> kept(nb);
     std::vector<std::vector<BeamCandidate>> gbeams(nb);
-    // same stage order as analyzer_impl.cc:258-283
-    if (nb > 3) {
+    // same stage order as analyzer_impl.cc:258-283 (global beam) / :206-245 (full beam)
+    if (nb > 3 && e.gbeam <= 0) {
+      for (u32 b = 2; b < nb; ++b) {
+        auto bnd = lat->boundary(b);
+        auto R = bnd->localNodeCount();
+        auto left = bnd->ends()->nodePtrs();
+        EntryBeam::initializeBlock(bnd->starts()->beamData().data());
+        proc.startBoundary(R);
+        if (R > 0) {
+          proc.computeT0All(b, sconf->feature, &pfc);
+          auto t0buf = proc.scores_.bufferT0();
+          t0[b].assign(t0buf.begin(), t0buf.begin() + R);
+        }
+        kept[b].assign(R, 1);
+        for (i32 t1idx = 0; t1idx < (i32)left.size(); ++t1idx) {
+          auto& t1node = left[t1idx];
+          proc.applyT1(t1node.boundary, t1node.position, sconf->feature);
+          proc.resolveBeamAt(t1node.boundary, t1node.position);
+          i32 activeBeam = proc.activeBeamSize();
+          for (i32 beamIdx = 0; beamIdx < activeBeam; ++beamIdx) {
+            proc.applyT2(beamIdx, sconf->feature);
+            proc.copyFeatureScores(t1idx, beamIdx, bnd->scores());
+          }
+        }
+        proc.makeBeams(b, bnd, sconf);
+      }
+    } else if (nb > 3) {
       for (u32 b = 2; b < nb; ++b) {
         auto bnd = lat->boundary(b);
         auto R = bnd->localNodeCount();

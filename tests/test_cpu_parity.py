@@ -61,6 +61,23 @@ def test_emulated_wide_beam_matches_live_reference(emu_lib, golden_dir, ref_tool
     assert not errs, errs[:10]
 
 
+def test_emulated_full_beam_matches_live_reference(emu_lib, golden_dir, ref_tools, tmp_path):
+    """--global-beam 0: AnalyzerImpl::computeScoresFull (k_sweep_full)."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    img, lines, gold_path = tg._fresh_workload(ref_tools, str(tmp_path), 2500, 12, 14, 6, length=40,
+                                               beams=[5, 0, 0, 0])
+    ctx = J.Context(img, lib_path=emu_lib, beam=5, global_beam=0, right_check=0, right_beam=0)
+    meta, gold = G.read_gold(gold_path)
+    assert meta['gbeam'] == 0
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     # reference: invalid UTF-8 -> InvalidParameter (characters.cc:267-269);
@@ -78,7 +95,9 @@ def test_config_validation_mirrors_reference(emu_lib, golden_dir):
     with pytest.raises(J.JppGpuError, match='right global beam size'):
         J.Context(img, lib_path=emu_lib, right_check=1, right_beam=0)
     with pytest.raises(J.JppGpuError, match='not implemented'):
-        J.Context(img, lib_path=emu_lib, global_beam=0)
+        J.Context(img, lib_path=emu_lib, beam=5, global_beam=8)   # quickselect branch of makeT0Beam
+    with pytest.raises(J.JppGpuError, match='only with global beam'):
+        J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=emu_lib, global_beam=0)
 
 
 def test_result_invalidated_by_next_batch(emu_lib, golden_dir):

@@ -145,6 +145,17 @@ def test_gpu_config5_wide_beam_long_sentences_rnn(gpu_lib, ref_tools, tmp_path):
     assert not errs, (len(errs), errs[:10])
 
 
+def test_gpu_full_beam(gpu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 20000, 300, 18, 321, beams=[5, 0, 0, 0])
+    ctx = J.Context(img, lib_path=gpu_lib, beam=5, global_beam=0, right_check=0, right_beam=0)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
+
+
 def test_gpu_batch_split_invariance(gpu_lib, golden_dir):
     """size-independent property: analysing a batch in one call or sentence by
     sentence gives identical top-1 paths and totals."""
