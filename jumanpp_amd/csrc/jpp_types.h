@@ -191,6 +191,7 @@ struct Batch {
   // result
   u32* path_len;           // [n]
   u32* path_nodes;         // [gn] top-1 path (local node ids, EOS side first), at node_base[s]
+  u32* gstats;             // [4] batch statistics: [0] max right nodes at one boundary
   u64 total_nodes;
 };
 

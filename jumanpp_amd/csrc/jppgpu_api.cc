@@ -152,7 +152,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
@@ -361,7 +361,8 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off};
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,
+                    &ctx->gstats};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   ctx->timer.destroy();
@@ -391,6 +392,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) &&
               ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_E * 4)));
+  ok = ok && ctx->gstats.ensure(64);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
   ctx->generation++;
@@ -425,6 +427,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.end_cnt = ctx->end_cnt.as<u32>();
   B.bnd_ngb = ctx->bnd_ngb.as<u32>();
   B.bnd_gbeam = ctx->bnd_gbeam.as<GbeamEntry>();
+  B.gstats = ctx->gstats.as<u32>();
   B.rnn_conn = ctx->rnn_conn.as<u32>();
   B.rnn_id = ctx->rnn_id.as<i32>();
   B.rnn_assign = ctx->rnn_assign.as<u32>();
@@ -471,8 +474,11 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_connect<2>, sblocks, 256, st, B);
   u64 totalNodes = 0;
+  u32 gstats[4] = {0, 0, 0, 0};
   rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
+  rt_d2h(gstats, B.gstats, sizeof(gstats), st);
   rt_sync(st);
+  const u32 maxR = gstats[0];
   B.total_nodes = totalNodes;
   const u64 cap = totalNodes + 8;
   ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * spec::kNumDicFeatures * 4) &&
@@ -495,10 +501,12 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(4, st);
   if (ctx->cfg.gbeam == 0) {
     JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && maxR <= 64 && ctx->cfg.rcheck <= 2) {
+    JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8) {
-    JPP_LAUNCH(k_sweep<8>, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    JPP_LAUNCH((k_sweep<8, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else {
-    JPP_LAUNCH(k_sweep<32>, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    JPP_LAUNCH((k_sweep<32, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   }
   T.mark(5, st);
   if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_rnn, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);

@@ -34,6 +34,7 @@ __global__ void k_layout(Batch B) {
   B.bnd_cnt[bb0 + 1] = 1;
   u32 next = 2;
   u32 sum2 = 0;
+  u32 maxR = 0;
   bool overflow = false;
   for (u32 i = 0; i < n; ++i) {
     u32 c = (u32)B.pos_cnt1[g0 + i] + B.pos_cntN[g0 + i];
@@ -43,7 +44,9 @@ __global__ void k_layout(Batch B) {
     B.bnd_first[bb0 + i + 2] = next;
     B.bnd_cnt[bb0 + i + 2] = c;
     next += c;
+    if (c > maxR) maxR = c;
   }
+  if (maxR > 0) atomicMax(&B.gstats[0], maxR);
   // EOS boundary
   B.bnd_first[bb0 + n + 2] = next;
   B.bnd_cnt[bb0 + n + 2] = 1;

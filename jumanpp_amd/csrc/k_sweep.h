@@ -57,14 +57,18 @@ struct NgramTables {
 };
 constexpr NgramTables kNg{};
 
+#ifndef JPP_SWEEP_WAVES
+#define JPP_SWEEP_WAVES 8
+#endif
 constexpr int kChunk = 16;      // kept right nodes processed per pass
 constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
 __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == kFake16 && s.beam == kFake16; }
 
 // GM = compile-time capacity of the global beam / per-node beam (8 for the CLI defaults, 32 for wide beams)
-template <int GM>
-__global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
+// RM = capacity of right nodes per boundary staged in LDS (the host picks the variant from the batch maximum)
+template <int GM, int RM>
+__global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
@@ -93,9 +97,9 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
   __shared__ u32 sh_U;
   __shared__ u64 t1pat[GM][kPat];
   __shared__ u64 t2pat[GM][kPat];
-  __shared__ float pres[kPresCap];
-  __shared__ float csum[kMaxRight];
-  __shared__ u16 order[kMaxRight];
+  __shared__ float pres[2 * RM];
+  __shared__ float csum[RM];
+  __shared__ u16 order[RM];
   __shared__ float biS[kChunk][GM];
   __shared__ float tot[kChunk][GM];
 
@@ -112,7 +116,7 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
     const u32 rfirst = B.bnd_first[bb0 + b];
     const u32 L = B.end_cnt[bb0 + b];
     const u32 efirst = B.end_first[bb0 + b];
-    if (R > (u32)kMaxRight) {
+    if (R > (u32)RM) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }
@@ -122,21 +126,48 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
     {
       u64 last = ~u64{0};
       const u32 ncand = L * (u32)beam;
-      for (int r = 0; r < G; ++r) {
-        u64 best = 0;
-        for (u32 q = lane; q < ncand; q += 64) {
-          u32 l = q / (u32)beam, k = q - l * (u32)beam;
-          BeamSlot sl = beams[(u64)en[efirst + l] * beam + k];
-          if (!slot_fake(sl)) {
-            u64 key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
-            if (key < last && key > best) best = key;
+      if (ncand <= 64u * 4) {
+        // common case: every lane keeps its <= 4 candidate keys in registers, one pass over HBM
+        u64 mykey[4];
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+          u32 q = (u32)lane + 64u * jx;
+          u64 key = 0;
+          if (q < ncand) {
+            u32 l = q / (u32)beam, k = q - l * (u32)beam;
+            BeamSlot sl = beams[(u64)en[efirst + l] * beam + k];
+            if (!slot_fake(sl)) key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
           }
+          mykey[jx] = key;
         }
-        u64 win = wave_max_u64(best);
-        if (win == 0) break;
-        if (lane == 0) gb_key[r] = win;
-        last = win;
-        ++ngb;
+        for (int r = 0; r < G; ++r) {
+          u64 best = 0;
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx)
+            if (mykey[jx] < last && mykey[jx] > best) best = mykey[jx];
+          u64 win = wave_max_u64(best);
+          if (win == 0) break;
+          if (lane == 0) gb_key[r] = win;
+          last = win;
+          ++ngb;
+        }
+      } else {
+        for (int r = 0; r < G; ++r) {
+          u64 best = 0;
+          for (u32 q = lane; q < ncand; q += 64) {
+            u32 l = q / (u32)beam, k = q - l * (u32)beam;
+            BeamSlot sl = beams[(u64)en[efirst + l] * beam + k];
+            if (!slot_fake(sl)) {
+              u64 key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
+              if (key < last && key > best) best = key;
+            }
+          }
+          u64 win = wave_max_u64(best);
+          if (win == 0) break;
+          if (lane == 0) gb_key[r] = win;
+          last = win;
+          ++ngb;
+        }
       }
     }
     __syncthreads();
@@ -199,7 +230,7 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
     int c = cfg.rcheck;
     if (c > (int)R) c = (int)R;
     if (c > ngb) c = ngb;
-    if ((u32)c * R > (u32)kPresCap) {
+    if ((u32)c * R > (u32)(2 * RM)) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }
@@ -258,9 +289,28 @@ __global__ void __launch_bounds__(64) k_sweep(Batch B, const DevModel* Mp, Confi
         csum[t] = sc;
       }
       __syncthreads();
-      if (lane == 0) {
-        ScoreGreater cmp{csum};
-        nth_element_u16(order, order + cfg.rbeam, order + R, cmp);
+      // Fast path: only the SET of the first rbeam entries matters downstream (kept nodes are scored
+      // independently).  If no tie straddles the cut, that set is the unique top-rbeam by score and a
+      // parallel stable rank gives it; otherwise replay std::nth_element step by step on one lane.
+      for (u32 t = lane; t < R; t += 64) {
+        float me = csum[t];
+        u32 rank = 0;
+        for (u32 u = 0; u < R; ++u) {
+          float o = csum[u];
+          rank += (o > me || (o == me && u < t)) ? 1u : 0u;
+        }
+        order[rank] = (u16)t;
+      }
+      __syncthreads();
+      const bool tieAtCut = csum[order[cfg.rbeam - 1]] == csum[order[cfg.rbeam]];
+      __syncthreads();
+      if (tieAtCut) {
+        for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
+        __syncthreads();
+        if (lane == 0) {
+          ScoreGreater cmp{csum};
+          nth_element_u16(order, order + cfg.rbeam, order + R, cmp);
+        }
       }
     }
     __syncthreads();
