@@ -58,14 +58,102 @@ struct NgramTables {
 constexpr NgramTables kNg{};
 
 #ifndef JPP_SWEEP_WAVES
-#define JPP_SWEEP_WAVES 8
+#define JPP_SWEEP_WAVES 4
 #endif
-constexpr int kChunk = 16;      // kept right nodes processed per pass
+constexpr int kChunk = 8;       // right nodes processed per pass (= 8-lane groups per wave)
 constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
 __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == kFake16 && s.beam == kFake16; }
 
 // GM = compile-time capacity of the global beam / per-node beam (8 for the CLI defaults, 32 for wide beams)
+
+// ---- 8-lane group helpers -------------------------------------------------------
+// The bigram features of one (right node, T1 row) pair are spread over an 8-lane group:
+// lane j of the group owns features k = j + 8m (m < 5), its table entries live in
+// registers (loaded once per kernel), so all weight gathers of a group are issued
+// together.  The reference's summation orders are then rebuilt with shuffles.
+constexpr int kBiPerLane = (spec::kNumBi + 7) / 8;
+
+#ifndef JPP_BI_TABLE_LDS
+#define JPP_BI_TABLE_LDS 1
+#endif
+#if JPP_BI_TABLE_LDS
+// tables in LDS (filled once per kernel): keeps ~20 VGPRs free for occupancy
+struct LaneBi {
+  const u64* pre;   // [kNumBi] hash prefixes
+  const u8* t01;    // [kNumBi] (t0 << 4) | t1
+};
+#define JPP_LBI_PRE(t, m, j) ((t).pre[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0])
+#define JPP_LBI_T0(t, m, j) ((t).t01[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0] >> 4)
+#define JPP_LBI_T1(t, m, j) ((t).t01[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0] & 15)
+#else
+struct LaneBi {
+  u64 pre_[kBiPerLane];
+  int t0_[kBiPerLane];
+  int t1_[kBiPerLane];
+};
+#define JPP_LBI_PRE(t, m, j) ((t).pre_[m])
+#define JPP_LBI_T0(t, m, j) ((t).t0_[m])
+#define JPP_LBI_T1(t, m, j) ((t).t1_[m])
+#endif
+
+// weights of this lane's bigram features for (p0 = right patterns, t1 = left patterns), both in LDS
+__device__ __forceinline__ void bi_gather(const LaneBi& t, int j, const u64* p0, const u64* t1r,
+                                          const float* __restrict__ W, u32 wmask, bool act, float* w) {
+  u32 idx[kBiPerLane];
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m)
+    idx[m] = (u32)hmix(hmix(JPP_LBI_PRE(t, m, j), p0[JPP_LBI_T0(t, m, j)]), t1r[JPP_LBI_T1(t, m, j)]) & wmask;
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? W[idx[m]] : 0.f;
+}
+
+// generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7
+__device__ __forceinline__ float bi_sum8(const float* w, int lane, int j) {
+  float f = 0.f;
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m)
+    if (j + 8 * m < spec::kNumBi) f += w[m];
+  const int gb = lane & ~7;
+  float total = wave_shfl_f32(f, gb);
+#pragma unroll
+  for (int jj = 1; jj < 8; ++jj) total += wave_shfl_f32(f, gb + jj);
+  return total;
+}
+
+// computeUnrolled4RawPerceptron: r_q = 0 + w_q + w_{q+4} + ... (q < 4), then ((r0 + r1) + r2) + r3.
+// Feature q + 4n sits in lane q (n even) or lane q + 4 (n odd) of the group.
+__device__ __forceinline__ float bi_sum4(const float* w, int lane, int j) {
+  const int gb = lane & ~7;
+  float r = 0.f;
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m) {
+    float other = wave_shfl_f32(w[m], gb + ((j + 4) & 7));
+    if (j + 8 * m < spec::kNumBi) r += w[m];
+    if (j + 4 + 8 * m < spec::kNumBi) r += other;
+  }
+  float total = wave_shfl_f32(r, gb);
+#pragma unroll
+  for (int q = 1; q < 4; ++q) total += wave_shfl_f32(r, gb + q);
+  return total;
+}
+
+// applyBiTriFullKernel: r1 = 0 + w_0 + w_2 + ..., r2 = 0 + w_1 + w_3 + ..., result r1 + r2
+__device__ __forceinline__ float bi_sum2(const float* w, int lane, int j) {
+  const int gb = lane & ~7;
+  const int par = j & 1;
+  float r = 0.f;
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = wave_shfl_f32(w[m], gb + 2 * q + par);
+      if (2 * q + par + 8 * m < spec::kNumBi) r += v;
+    }
+  }
+  return wave_shfl_f32(r, gb) + wave_shfl_f32(r, gb + 1);
+}
+
 // RM = capacity of right nodes per boundary staged in LDS (the host picks the variant from the batch maximum)
 template <int GM, int RM>
 __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
@@ -102,6 +190,32 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ u16 order[RM];
   __shared__ float biS[kChunk][GM];
   __shared__ float tot[kChunk][GM];
+  __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass
+  __shared__ float t0R[kChunk];
+
+  const int grp = lane >> 3, gj = lane & 7;
+  LaneBi lbi;
+#if JPP_BI_TABLE_LDS
+  __shared__ u64 s_bipre[spec::kNumBi];
+  __shared__ u8 s_bit01[spec::kNumBi];
+  static_assert(kPat <= 16, "pattern indices are packed in 4 bits");
+  if (lane < spec::kNumBi) {
+    s_bipre[lane] = kNg.bi_pre[lane];
+    s_bit01[lane] = (u8)((kNg.bi_t0[lane] << 4) | kNg.bi_t1[lane]);
+  }
+  lbi.pre = s_bipre;
+  lbi.t01 = s_bit01;
+  __syncthreads();
+#else
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m) {
+    int k = gj + 8 * m;
+    int kk = k < spec::kNumBi ? k : 0;
+    lbi.pre_[m] = kNg.bi_pre[kk];
+    lbi.t0_[m] = kNg.bi_t0[kk];
+    lbi.t1_[m] = kNg.bi_t1[kk];
+  }
+#endif
 
   if (n == 0) {
     // empty input: the reference returns before scoring anything
@@ -234,50 +348,41 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }
-    {
-      const int grp = lane >> 3, j = lane & 7;
-      const u32 units = (u32)c * R;
-      for (u32 base = 0; base < units; base += 8) {
-        u32 u = base + grp;
-        bool act = u < units;
-        u32 i = act ? u / R : 0, t = act ? u - i * R : 0;
-        bool lastRow = (t == R - 1);
-        int Wd = lastRow ? 4 : 8;
-        const u64* p0 = pats + (u64)(rfirst + t) * kPat;
+    for (u32 tc = 0; tc < R && c > 0; tc += kChunk) {
+      const u32 nx = (R - tc) < (u32)kChunk ? (R - tc) : (u32)kChunk;
+      for (u32 q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + tc) * kPat + q];
+      if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
+      __syncthreads();
+      for (int i = 0; i < c; ++i) {
+        const bool act = (u32)grp < nx;
+        const u32 t = tc + (u32)grp;
+        const u64* p0 = pR[act ? grp : 0];
         const u64* t1r = t1pat[gb_t1[i]];
         const u64* t2r = t2pat[i];
-        float f = 0.f;
-        if (act && j < Wd) {
-          for (int k = j; k < spec::kNumBi; k += Wd) {
-            u32 idx = (u32)hmix(hmix(kNg.bi_pre[k], p0[kNg.bi_t0[k]]), t1r[kNg.bi_t1[k]]) & wmask;
-            f += W[idx];
-          }
-        }
+        float w[kBiPerLane];
+        bi_gather(lbi, gj, p0, t1r, W, wmask, act, w);
         float g = 0.f;
-        if (act && j < spec::kNumTri) {
-          u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[j], p0[kNg.tri_t0[j]]), t1r[kNg.tri_t1[j]]),
-                              t2r[kNg.tri_t2[j]]) & wmask;
+        if (act && gj < spec::kNumTri) {
+          u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[gj], p0[kNg.tri_t0[gj]]), t1r[kNg.tri_t1[gj]]),
+                              t2r[kNg.tri_t2[gj]]) & wmask;
           g += W[idx];
         }
-        // f_0 + f_1 + ... (left to right) ; g_0 + g_1 + g_2 + g_3
-        float bsum = wave_shfl_f32(f, (grp << 3));
-        float tsum = wave_shfl_f32(g, (grp << 3));
+        // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
+        const float b8 = bi_sum8(w, lane, gj);
+        const float b4 = bi_sum4(w, lane, gj);
+        const int gbase = lane & ~7;
+        float tsum = wave_shfl_f32(g, gbase);
 #pragma unroll
-        for (int jj = 1; jj < 8; ++jj) {
-          float v = wave_shfl_f32(f, (grp << 3) + jj);
-          float w = wave_shfl_f32(g, (grp << 3) + jj);
-          if (jj < Wd) bsum += v;
-          if (jj < spec::kNumTri) tsum += w;
-        }
-        if (act && j == 0) {
-          float sc = t0s[rfirst + t];
-          sc += bsum;
+        for (int jj = 1; jj < spec::kNumTri; ++jj) tsum += wave_shfl_f32(g, gbase + jj);
+        if (act && gj == 0) {
+          float sc = t0R[grp];
+          sc += (t == R - 1) ? b4 : b8;
           sc += tsum;
-          pres[i * R + t] = sc;
+          pres[(u32)i * R + t] = sc;
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
 
     // ---- 4. right-node cutoff (std::nth_element semantics) ----
     const u32 K = (cfg.rcheck > 0) ? ((u32)cfg.rbeam < R ? (u32)cfg.rbeam : R) : R;
@@ -319,39 +424,23 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     const int ntail = ngb - c;
     for (u32 op0 = 0; op0 < R; op0 += kChunk) {
       const int nx = (int)((R - op0) < (u32)kChunk ? (R - op0) : (u32)kChunk);
+      // stage the patterns / T0 of this pass's right nodes (cutoff order)
+      for (int q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + order[op0 + q / kPat]) * kPat + q % kPat];
+      if (lane < nx) t0R[lane] = t0s[rfirst + order[op0 + lane]];
+      __syncthreads();
       // 5a. bigram sums per (kept node, unique T1 row) -- applyBiTriFullKernel rows
       if (ntail > 0) {
         const int units = nx * U;
-        for (int base = 0; base < units; base += 16) {
-          int u = base + (lane >> 2);
-          int j = lane & 3;
+        for (int base = 0; base < units; base += 8) {
+          int u = base + grp;
           bool act = u < units;
           int x = act ? u / U : 0, tu = act ? u - x * U : 0;
-          bool kept = (op0 + x) < K;
-          act = act && kept;
-          u32 t = order[op0 + x];
-          const u64* p0 = pats + (u64)(rfirst + t) * kPat;
-          const u64* t1r = t1pat[tu];
-          bool lastRow = (tu == U - 1);
-          int Wd = lastRow ? 4 : 2;
-          float f = 0.f;
-          if (act && j < Wd) {
-            for (int k = j; k < spec::kNumBi; k += Wd) {
-              u32 idx = (u32)hmix(hmix(kNg.bi_pre[k], p0[kNg.bi_t0[k]]), t1r[kNg.bi_t1[k]]) & wmask;
-              f += W[idx];
-            }
-          }
-          int gl = lane & ~3;
-          float r1 = wave_shfl_f32(f, gl), r2 = wave_shfl_f32(f, gl + 1);
-          float r3 = wave_shfl_f32(f, gl + 2), r4 = wave_shfl_f32(f, gl + 3);
-          if (act && j == 0) {
-            float sum = r1 + r2;
-            if (lastRow) {
-              sum += r3;
-              sum += r4;
-            }
-            biS[x][tu] = sum;
-          }
+          act = act && (op0 + x) < K;
+          float w[kBiPerLane];
+          bi_gather(lbi, gj, pR[x], t1pat[tu], W, wmask, act, w);
+          const float s2 = bi_sum2(w, lane, gj);
+          const float s4 = bi_sum4(w, lane, gj);
+          if (act && gj == 0) biS[x][tu] = (tu == U - 1) ? s4 : s2;
         }
       }
       __syncthreads();
@@ -370,7 +459,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           v += gb_score[i];
           total = v;
         } else if (kept) {
-          const u64* p0 = pats + (u64)(rfirst + t) * kPat;
+          const u64* p0 = pR[x];
           const u64* t1r = t1pat[gb_t1[i]];
           const u64* t2r = t2pat[i];
           float w[spec::kNumTri];
@@ -400,7 +489,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           }
           // copyT0Scores(tail, resultTail, t0Score)
           float v = res;
-          v += t0s[rfirst + t];
+          v += t0R[x];
           cell = v;
           v += gb_score[i];
           total = v;
