@@ -37,6 +37,19 @@ __device__ __forceinline__ int lane_id() {
 #endif
 }
 
+// Synchronise the lanes of ONE wavefront around LDS traffic (multi-wave workgroups whose
+// waves work on independent sentences cannot use the workgroup barrier inside ragged loops).
+// LDS operations of a wave complete in order; the fences make the compiler emit the waits.
+__device__ __forceinline__ void wave_sync() {
+#if defined(JPP_EMU)
+  hip_emu::wave_barrier();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 __device__ __forceinline__ u64 wave_ballot(bool p) {
 #if defined(JPP_EMU)
   return hip_emu::ballot(p);

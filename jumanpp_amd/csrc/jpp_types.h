@@ -17,6 +17,7 @@ constexpr int kMaxNormResults = 160;
 constexpr int kMaxRnnE = 256;      // RNN hidden size staged per lane (E/64 <= 4)
 constexpr int kRnnChunk = 8;       // rnn nodes of one boundary processed per pass
 constexpr int kRnnCtxCap = kRnnChunk * kMaxRnnE;  // floats of LDS for the staged prev contexts
+static_assert(kRnnChunk == 8, "k_rnn scores one rnn node per 8-lane group");
 
 // entry pointers (reference src/core/core_types.h:44-58)
 constexpr i32 kEptrBOS = (i32)0x80000000;

@@ -509,7 +509,14 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     JPP_LAUNCH((k_sweep<32, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   }
   T.mark(5, st);
-  if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_rnn, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  if (ctx->cfg.nscorers == 2) {
+    const u32 rblocks = (n + kRnnWaves - 1) / kRnnWaves;
+    if (ctx->hmodel.rnn_E <= (u32)kRnnLdsE) {
+      JPP_LAUNCH(k_rnn<true>, rblocks, 64 * kRnnWaves, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    } else {
+      JPP_LAUNCH(k_rnn<false>, rblocks, 64 * kRnnWaves, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    }
+  }
   T.mark(6, st);
   JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
   T.mark(7, st);

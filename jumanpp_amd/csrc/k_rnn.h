@@ -90,11 +90,26 @@ __device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
   return v ^ (v >> 32);
 }
 
-__global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config cfg) {
+constexpr int kRnnWaves = 8;        // sentences (wavefronts) per workgroup
+constexpr int kRnnLdsE = 128;       // W is staged in LDS (E*E*4 = 64 KB) when E <= this
+
+// WLDS: the transposed recurrent matrix lives in LDS and is shared by the 8 wavefronts of the
+// workgroup (each wavefront still owns one sentence); otherwise W is streamed from L2.
+template <bool WLDS>
+__global__ void __launch_bounds__(64 * kRnnWaves) k_rnn(Batch B, const DevModel* Mp, Config cfg) {
   const DevModel& M = *Mp;
-  const u32 s = blockIdx.x;
+  const int wv = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  __shared__ float s_W[WLDS ? kRnnLdsE * kRnnLdsE : 1];
+  if (WLDS) {
+    const u32 EE = M.rnn_E * M.rnn_E;
+    for (u32 q = threadIdx.x; q < EE; q += blockDim.x) s_W[q] = M.rnn_wt[q];
+    __syncthreads();
+  }
+  const float* __restrict__ Wt = WLDS ? s_W : M.rnn_wt;
+  const u32 s = blockIdx.x * kRnnWaves + wv;
+  if (s >= B.n_sent) return;
   if (B.sent_status[s] != ST_OK) return;
-  const int lane = (int)threadIdx.x;
   const u32 off = B.byte_off[s];
   const u32 bb0 = off + 4 * s;
   const u32 n = B.sent_ncp[s];
@@ -112,25 +127,52 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
   BeamSlot* beams = B.node_beam + nb * beam;
   const u32* en = B.end_nodes + nb;
   // per (boundary, path) and per (boundary, rnn node) scratch of this sentence
-  u32* conn = B.rnn_conn + (u64)bb0 * G;      // lattice connection of path p at boundary b
-  i32* wid = B.rnn_id + (u64)bb0 * G;         // word id of that connection's lattice node
-  u32* assign = B.rnn_assign + (u64)bb0 * G;  // rnn node index (within boundary) the connection is scored with
-  u32* rn_prev = B.rnn_prev + (u64)bb0 * G;   // rnn node -> handle (pb * G + pidx) of its prev node
-  u64* rn_hash = B.rnn_hash + (u64)bb0 * G;
-  i32* rn_id = B.rnn_nid + (u64)bb0 * G;
-  u32* rn_len = B.rnn_nlen + (u64)bb0 * G;
-  u32* rn_cnt = B.rnn_cnt + bb0;              // rnn nodes per boundary
+  // per (boundary, path) and per (boundary, rnn node) bookkeeping: LDS for ordinary sentences,
+  // the HBM scratch arrays for very long ones
+  constexpr u32 kCap = 288, kCapB = 48;
+  __shared__ u32 l_conn_all[kRnnWaves][kCap];
+  u32* l_conn = l_conn_all[wv];
+  __shared__ i32 l_wid_all[kRnnWaves][kCap];
+  i32* l_wid = l_wid_all[wv];
+  __shared__ u32 l_assign_all[kRnnWaves][kCap];
+  u32* l_assign = l_assign_all[wv];
+  __shared__ u32 l_prev_all[kRnnWaves][kCap];
+  u32* l_prev = l_prev_all[wv];
+  __shared__ u64 l_hash_all[kRnnWaves][kCap];
+  u64* l_hash = l_hash_all[wv];
+  __shared__ i32 l_id_all[kRnnWaves][kCap];
+  i32* l_id = l_id_all[wv];
+  __shared__ u32 l_len_all[kRnnWaves][kCap];
+  u32* l_len = l_len_all[wv];
+  __shared__ u32 l_cnt_all[kRnnWaves][kCapB];
+  u32* l_cnt = l_cnt_all[wv];
+  const bool inLds = (bE + 1) * (u32)G <= kCap && (bE + 1) <= kCapB;
+  u32* conn = inLds ? l_conn : B.rnn_conn + (u64)bb0 * G;      // lattice connection of path p at boundary b
+  i32* wid = inLds ? l_wid : B.rnn_id + (u64)bb0 * G;          // word id of that connection's lattice node
+  u32* assign = inLds ? l_assign : B.rnn_assign + (u64)bb0 * G;  // rnn node (index within boundary) scoring the connection
+  u32* rn_prev = inLds ? l_prev : B.rnn_prev + (u64)bb0 * G;   // rnn node -> handle (pb * G + pidx) of its prev node
+  u64* rn_hash = inLds ? l_hash : B.rnn_hash + (u64)bb0 * G;
+  i32* rn_id = inLds ? l_id : B.rnn_nid + (u64)bb0 * G;
+  u32* rn_len = inLds ? l_len : B.rnn_nlen + (u64)bb0 * G;
+  u32* rn_cnt = inLds ? l_cnt : B.rnn_cnt + bb0;               // rnn nodes per boundary
   float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * E;
 
-  __shared__ float pctx[kRnnCtxCap];  // contexts of the prev nodes of the current boundary's nodes
-  __shared__ float nscore[kMaxGbeam];
-  __shared__ float full[kMaxGbeam];
-  __shared__ float prev_total[kMaxGbeam];
+  // contexts of the prev nodes of the current chunk of rnn nodes (chunk = kCtxFloats / E nodes, <= 8)
+  constexpr u32 kCtxFloats = WLDS ? 4 * kRnnLdsE : kRnnCtxCap;
+  __shared__ float pctx_all[kRnnWaves][kCtxFloats];
+  __shared__ float nscore_all[kRnnWaves][kMaxGbeam];
+  __shared__ float full_all[kRnnWaves][kMaxGbeam];
+  __shared__ float prev_total_all[kRnnWaves][kMaxGbeam];
+  float* pctx = pctx_all[wv];
+  float* nscore = nscore_all[wv];
+  float* full = full_all[wv];
+  float* prev_total = prev_total_all[wv];
+  const int chunkMax = (int)(kCtxFloats / E) < kRnnChunk ? (int)(kCtxFloats / E) : kRnnChunk;
 
   // ---- A. connection of every EOS path at every boundary ----
   for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) conn[q] = kNoConn;
   for (u32 q = lane; q <= bE; q += 64) rn_cnt[q] = 0;
-  __syncthreads();
+  wave_sync();
   const u32 efirstE = B.end_first[bb0 + bE];
   if (lane < ngb) {
     GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
@@ -146,7 +188,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
       k = sl.beam;
     }
   }
-  __syncthreads();
+  wave_sync();
   // ---- B. word ids of the connections ----
   for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) {
     u32 c = conn[q];
@@ -154,7 +196,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
     u32 nd = c & 0x03ffffffu;
     wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
   }
-  __syncthreads();
+  wave_sync();
   // ---- B2. RNN lattice: RnnIdContainer::addPath / addPrevChain, path by path ----
   if (lane == 0) {
     // BOS node (boundary 1): RnnIdContainer::addBos
@@ -221,34 +263,38 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   // ---- C. contexts and scores, boundary by boundary ----
   // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
   for (u32 e = lane; e < E; e += 64) {
     float x = 0.f + M.rnn_emb[e];
     rn_ctx[(u64)1 * G * E + e] = 1.0f / (1.0f + expf(-x));
   }
-  __syncthreads();
+  wave_sync();
   for (u32 b = 2; b <= bE; ++b) {
     const int cnt = (int)rn_cnt[b];
     if (cnt == 0) continue;
-    for (int c0 = 0; c0 < cnt; c0 += kRnnChunk) {
-      const int cn = (cnt - c0) < kRnnChunk ? (cnt - c0) : kRnnChunk;
+    for (int c0 = 0; c0 < cnt; c0 += chunkMax) {
+      const int cn = (cnt - c0) < chunkMax ? (cnt - c0) : chunkMax;
       // stage the prev contexts of this chunk of rnn nodes
       for (u32 q = lane; q < (u32)cn * E; q += 64) {
         u32 x = q / E, e = q - x * E;
         pctx[q] = rn_ctx[(u64)rn_prev[(u64)b * G + c0 + x] * E + e];
       }
-      __syncthreads();
-      // score of every rnn node of the chunk
-      for (int x = 0; x < cn; ++x) {
-        i32 id = rn_id[(u64)b * G + c0 + x];
+      wave_sync();
+      // score of every rnn node of the chunk: one 8-lane group per node
+      {
+        const int x = lane >> 3, gj = lane & 7;
+        const bool act = x < cn;
+        i32 id = act ? rn_id[(u64)b * G + c0 + x] : 0;
         u32 eid = id == -1 ? 0u : (u32)id;
         float part = 0.f;
-        for (u32 e = lane; e < E; e += 64) part += M.rnn_nce[(u64)eid * E + e] * pctx[(u32)x * E + e];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += wave_shfl_f32(part, lane ^ o);
-        if (lane == 0) {
+        if (act)
+          for (u32 e = gj; e < E; e += 8) part += M.rnn_nce[(u64)eid * E + e] * pctx[(u32)x * E + e];
+        part += wave_shfl_f32(part, lane ^ 4);
+        part += wave_shfl_f32(part, lane ^ 2);
+        part += wave_shfl_f32(part, lane ^ 1);
+        if (act && gj == 0) {
           float score = part;
           // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
           float me = 0.f;
@@ -279,12 +325,13 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
         for (int p = 0; p < kRnnChunk; ++p)
 #pragma unroll
           for (int j = 0; j < kMaxRnnE / 64; ++j) acc[p][j] = 0.f;
+#pragma unroll 4
         for (u32 k = 0; k < E; ++k) {
           float w[kMaxRnnE / 64];
 #pragma unroll
           for (int j = 0; j < kMaxRnnE / 64; ++j) {
             u32 i = (u32)lane + 64u * j;
-            w[j] = (j < J && i < E) ? M.rnn_wt[(u64)k * E + i] : 0.f;
+            w[j] = (j < J && i < E) ? Wt[(u64)k * E + i] : 0.f;
           }
 #pragma unroll
           for (int p = 0; p < kRnnChunk; ++p) {
@@ -314,7 +361,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
           }
         }
       }
-      __syncthreads();
+      wave_sync();
     }
     if (lane < ngb) {
       u32 c = conn[(u64)b * G + lane];
@@ -324,7 +371,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
         B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
       }
     }
-    __syncthreads();
+    wave_sync();
   }
 
   // ---- D. adjustBeamScores along the EOS paths ----
@@ -351,7 +398,7 @@ __global__ void __launch_bounds__(64) k_rnn(Batch B, const DevModel* Mp, Config 
     full[lane] = local + prevT;
     prev_total[lane] = prevT;
   }
-  __syncthreads();
+  wave_sync();
   if (lane < kMaxGbeam) {
     BeamSlot* row = beams + (u64)(N - 1) * beam;
     if (lane < ngb) {
