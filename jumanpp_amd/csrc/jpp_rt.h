@@ -75,6 +75,36 @@ __device__ __forceinline__ float wave_shfl_f32(float v, int src) {
   return r;
 }
 
+// broadcast lane `src` (wave-uniform) of v to every lane: v_readlane_b32
+__device__ __forceinline__ float wave_bcast_f32(float v, int src) {
+#if defined(JPP_EMU)
+  return wave_shfl_f32(v, src);
+#else
+  int x;
+  __builtin_memcpy(&x, &v, 4);
+  x = __builtin_amdgcn_readlane(x, src);
+  float r;
+  __builtin_memcpy(&r, &x, 4);
+  return r;
+#endif
+}
+
+__device__ __forceinline__ u64 mulhi_u64(u64 a, u64 b) {
+#if defined(JPP_EMU)
+  return (u64)(((unsigned __int128)a * b) >> 64);
+#else
+  return __umul64hi(a, b);
+#endif
+}
+
+// x % m with magic = floor((2^64 - 1) / m): the estimate of the quotient is short by at most 2
+__device__ __forceinline__ u64 fastmod_u64(u64 x, u64 m, u64 magic) {
+  u64 q = mulhi_u64(x, magic);
+  u64 r = x - q * m;
+  while (r >= m) r -= m;
+  return r;
+}
+
 __device__ __forceinline__ u64 wave_shfl_u64(u64 v, int src) {
 #if defined(JPP_EMU)
   return hip_emu::shfl_u64(v, src);

@@ -15,9 +15,6 @@ constexpr int kMaxRight = 512;    // right nodes per boundary staged in LDS by t
 constexpr int kMaxNormStates = 64;
 constexpr int kMaxNormResults = 160;
 constexpr int kMaxRnnE = 256;      // RNN hidden size staged per lane (E/64 <= 4)
-constexpr int kRnnChunk = 8;       // rnn nodes of one boundary processed per pass
-constexpr int kRnnCtxCap = kRnnChunk * kMaxRnnE;  // floats of LDS for the staged prev contexts
-static_assert(kRnnChunk == 8, "k_rnn scores one rnn node per 8-lane group");
 
 // entry pointers (reference src/core/core_types.h:44-58)
 constexpr i32 kEptrBOS = (i32)0x80000000;
@@ -66,13 +63,15 @@ struct DevModel {
   i32 has_rnn;
   const u32* rnn_known;      // word -> id double array for dictionary nodes
   const u32* rnn_unk;        // word -> id double array for UNK nodes
-  const float* rnn_wt;       // W transposed: wt[k * E + i] = W[i * E + k]
+  const float* rnn_wt;       // W transposed and zero-padded: wt[k * EP + i] = W[i * E + k]
   const float* rnn_emb;      // [V][E]
   const float* rnn_nce;      // [V][E]
   const float* rnn_maxent;   // [M]
   u32 rnn_E;
+  u32 rnn_EP;                // E rounded up to 64, 128 or 256 (row stride of rnn_wt and rnn_ctx)
   u32 rnn_order;             // maxent order
   u64 rnn_hash_max;          // maxentSize - vocabSize
+  u64 rnn_hash_magic;        // floor((2^64 - 1) / rnn_hash_max) for fastmod_u64
   float rnn_nce_const;
   i32 rnn_unk_id;
   float rnn_unk_const;
@@ -185,7 +184,7 @@ struct Batch {
   i32* rnn_nid;            // [bb][gbeam] word id of the rnn node
   u32* rnn_nlen;           // [bb][gbeam] codepoint length of the rnn node
   u32* rnn_cnt;            // [bb] rnn nodes per boundary
-  float* rnn_ctx;          // [bb][gbeam][E] hidden state after each rnn node
+  float* rnn_ctx;          // [bb][gbeam][EP] hidden state after each rnn node
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]
   u32* bnd_ngb;            // [bb]

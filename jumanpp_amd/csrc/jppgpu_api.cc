@@ -303,11 +303,12 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
       jppgpu_ctx_destroy(ctx);
       return fail(JPPGPU_NOT_IMPLEMENTED, "RNN shape outside the supported range (E<=256, maxent order<=4)");
     }
-    std::vector<float> wt(E * E);
+    const u64 EP = E <= 64 ? 64 : E <= 128 ? 128 : 256;
+    std::vector<float> wt(EP * EP, 0.f);
     for (u64 i = 0; i < E; ++i)
-      for (u64 k = 0; k < E; ++k) wt[k * E + i] = m->rnn_matrix[i * E + k];
+      for (u64 k = 0; k < E; ++k) wt[k * EP + i] = m->rnn_matrix[i * E + k];
     bool ok2 = ctx->rnn_known.ensure(m->rnn_known_index_bytes) && ctx->rnn_unk.ensure(m->rnn_unk_index_bytes) &&
-               ctx->rnn_wt.ensure(E * E * 4) && ctx->rnn_emb.ensure(V * E * 4) && ctx->rnn_nce.ensure(V * E * 4) &&
+               ctx->rnn_wt.ensure(EP * EP * 4) && ctx->rnn_emb.ensure(V * E * 4) && ctx->rnn_nce.ensure(V * E * 4) &&
                ctx->rnn_maxent.ensure(m->rnn_maxent_size * 4);
     if (!ok2) {
       jppgpu_ctx_destroy(ctx);
@@ -315,7 +316,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     }
     rt_h2d(ctx->rnn_known.p, m->rnn_known_index, m->rnn_known_index_bytes, nullptr);
     rt_h2d(ctx->rnn_unk.p, m->rnn_unk_index, m->rnn_unk_index_bytes, nullptr);
-    rt_h2d(ctx->rnn_wt.p, wt.data(), E * E * 4, nullptr);
+    rt_h2d(ctx->rnn_wt.p, wt.data(), EP * EP * 4, nullptr);
     rt_h2d(ctx->rnn_emb.p, m->rnn_embeddings, V * E * 4, nullptr);
     rt_h2d(ctx->rnn_nce.p, m->rnn_nce_embeddings, V * E * 4, nullptr);
     rt_h2d(ctx->rnn_maxent.p, m->rnn_maxent, m->rnn_maxent_size * 4, nullptr);
@@ -328,8 +329,10 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     H.rnn_nce = ctx->rnn_nce.as<float>();
     H.rnn_maxent = ctx->rnn_maxent.as<float>();
     H.rnn_E = (u32)E;
+    H.rnn_EP = (u32)EP;
     H.rnn_order = m->rnn_maxent_order;
     H.rnn_hash_max = m->rnn_maxent_size - V;
+    H.rnn_hash_magic = ~0ull / H.rnn_hash_max;
     H.rnn_nce_const = m->rnn_nce_constant;
     H.rnn_unk_id = m->rnn_unk_id;
     H.rnn_unk_const = m->rnn_unk_constant;
@@ -391,7 +394,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) &&
-              ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_E * 4)));
+              ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_EP * 4)));
   ok = ok && ctx->gstats.ensure(64);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
@@ -510,11 +513,14 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   T.mark(5, st);
   if (ctx->cfg.nscorers == 2) {
-    const u32 rblocks = (n + kRnnWaves - 1) / kRnnWaves;
-    if (ctx->hmodel.rnn_E <= (u32)kRnnLdsE) {
-      JPP_LAUNCH(k_rnn<true>, rblocks, 64 * kRnnWaves, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
+               (const DevModel*)ctx->dmodel, ctx->cfg);
+    if (ctx->hmodel.rnn_EP == 64) {
+      JPP_LAUNCH((k_rnn_score<1, true>), (n + 15) / 16, 1024, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    } else if (ctx->hmodel.rnn_EP == 128) {
+      JPP_LAUNCH((k_rnn_score<2, true>), (n + 15) / 16, 1024, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
     } else {
-      JPP_LAUNCH(k_rnn<false>, rblocks, 64 * kRnnWaves, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+      JPP_LAUNCH((k_rnn_score<4, false>), (n + 3) / 4, 256, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
     }
   }
   T.mark(6, st);

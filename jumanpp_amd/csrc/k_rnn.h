@@ -1,15 +1,19 @@
-// Kernel 6: RNNLM re-ranking of the paths that survive at EOS (Mikolov
+// Kernels 6a/6b: RNNLM re-ranking of the paths that survive at EOS (Mikolov
 // faster-rnnlm NCE model), then adjustBeamScores + remakeEosBeam.
-// One wavefront per sentence.  The <= G surviving paths advance in lock-step
-// over the boundaries, so every W element fetched (coalesced from the
-// transposed copy) is used for all active paths; the hidden vector is spread
-// over the lanes (E/64 outputs per lane), contexts live in LDS.
 //
-// The reference merges equal path prefixes (RnnIdContainer::addPrevChain,
-// rnn_id_resolver.cc:207-245) purely to save CPU work: a merged node has, by
-// construction (prefix hash over (rnnId, length)), the same context vector and
-// therefore the same score.  Here every path is evaluated on its own prefix,
-// which yields the same values without the hash maps.
+// k_rnn_prep (one wavefront per sentence): walks the <= G EOS paths back through the
+// beam pointers, resolves the RNN vocabulary id of every node on them and replays
+// RnnIdContainer::addPath/addPrevChain exactly (including its attach-to-it->second
+// quirk) to obtain the RNN lattice: which rnn node scores which connection, and each
+// rnn node's predecessor.  The replay is a skewed pipeline: lane p handles path p and
+// reaches boundary b at step b + p, i.e. after every earlier path has finished that
+// boundary, which is the only ordering the sequential algorithm depends on.
+//
+// k_rnn_score (one wavefront per sentence, 16 sentences per workgroup sharing the
+// zero-padded transposed recurrent matrix in LDS): boundary by boundary, up to 4 rnn
+// nodes at a time.  The hidden vector is spread over the lanes (J = EP/64 outputs per
+// lane, EP = E rounded up to 64/128/256) and stays in registers; the matvec broadcasts
+// context element k with v_readlane and reads row k of W^T as one J-wide LDS read.
 //
 // Reference behaviour reproduced:
 //   RnnIdResolver::resolveIdsAtGbeam / RnnIdContainer::resolveId / reprOf
@@ -82,6 +86,8 @@ __device__ inline i32 rnn_resolve_id(const DevModel& M, const Batch& B, u32 s, u
   return (i32)(leaf & ((1u << 31) - 1));
 }
 
+constexpr int kRnnPrepWaves = 4;    // sentences (wavefronts) per k_rnn_prep workgroup
+constexpr int kRnnCN = 4;           // rnn nodes of one boundary evaluated per pass
 constexpr u32 kNoConn = 0xffffffffu;
 
 // FastHash1::mix (src/util/fast_hash.h:39-64)
@@ -90,24 +96,11 @@ __device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
   return v ^ (v >> 32);
 }
 
-constexpr int kRnnWaves = 8;        // sentences (wavefronts) per workgroup
-constexpr int kRnnLdsE = 128;       // W is staged in LDS (E*E*4 = 64 KB) when E <= this
-
-// WLDS: the transposed recurrent matrix lives in LDS and is shared by the 8 wavefronts of the
-// workgroup (each wavefront still owns one sentence); otherwise W is streamed from L2.
-template <bool WLDS>
-__global__ void __launch_bounds__(64 * kRnnWaves) k_rnn(Batch B, const DevModel* Mp, Config cfg) {
+__global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const DevModel* Mp, Config cfg) {
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
-  __shared__ float s_W[WLDS ? kRnnLdsE * kRnnLdsE : 1];
-  if (WLDS) {
-    const u32 EE = M.rnn_E * M.rnn_E;
-    for (u32 q = threadIdx.x; q < EE; q += blockDim.x) s_W[q] = M.rnn_wt[q];
-    __syncthreads();
-  }
-  const float* __restrict__ Wt = WLDS ? s_W : M.rnn_wt;
-  const u32 s = blockIdx.x * kRnnWaves + wv;
+  const u32 s = blockIdx.x * kRnnPrepWaves + wv;
   if (s >= B.n_sent) return;
   if (B.sent_status[s] != ST_OK) return;
   const u32 off = B.byte_off[s];
@@ -118,59 +111,41 @@ __global__ void __launch_bounds__(64 * kRnnWaves) k_rnn(Batch B, const DevModel*
   const u64 nb = B.node_base[s];
   const int beam = cfg.beam;
   const int G = cfg.gbeam;
-  const int S = cfg.nscorers;
   const u32 bE = n + 2;
   const int ngb = (int)B.bnd_ngb[bb0 + bE];
   if (ngb == 0) return;
-  const u32 E = M.rnn_E;
-  const int J = (int)((E + 63) / 64);
-  BeamSlot* beams = B.node_beam + nb * beam;
+  const BeamSlot* beams = B.node_beam + nb * beam;
   const u32* en = B.end_nodes + nb;
-  // per (boundary, path) and per (boundary, rnn node) scratch of this sentence
-  // per (boundary, path) and per (boundary, rnn node) bookkeeping: LDS for ordinary sentences,
-  // the HBM scratch arrays for very long ones
+  // per (boundary, path) and per (boundary, rnn node) bookkeeping: built in LDS for ordinary
+  // sentences and copied out at the end, built in place in the HBM arrays for very long ones
   constexpr u32 kCap = 288, kCapB = 48;
-  __shared__ u32 l_conn_all[kRnnWaves][kCap];
-  u32* l_conn = l_conn_all[wv];
-  __shared__ i32 l_wid_all[kRnnWaves][kCap];
-  i32* l_wid = l_wid_all[wv];
-  __shared__ u32 l_assign_all[kRnnWaves][kCap];
-  u32* l_assign = l_assign_all[wv];
-  __shared__ u32 l_prev_all[kRnnWaves][kCap];
-  u32* l_prev = l_prev_all[wv];
-  __shared__ u64 l_hash_all[kRnnWaves][kCap];
-  u64* l_hash = l_hash_all[wv];
-  __shared__ i32 l_id_all[kRnnWaves][kCap];
-  i32* l_id = l_id_all[wv];
-  __shared__ u32 l_len_all[kRnnWaves][kCap];
-  u32* l_len = l_len_all[wv];
-  __shared__ u32 l_cnt_all[kRnnWaves][kCapB];
-  u32* l_cnt = l_cnt_all[wv];
-  const bool inLds = (bE + 1) * (u32)G <= kCap && (bE + 1) <= kCapB;
-  u32* conn = inLds ? l_conn : B.rnn_conn + (u64)bb0 * G;      // lattice connection of path p at boundary b
-  i32* wid = inLds ? l_wid : B.rnn_id + (u64)bb0 * G;          // word id of that connection's lattice node
-  u32* assign = inLds ? l_assign : B.rnn_assign + (u64)bb0 * G;  // rnn node (index within boundary) scoring the connection
-  u32* rn_prev = inLds ? l_prev : B.rnn_prev + (u64)bb0 * G;   // rnn node -> handle (pb * G + pidx) of its prev node
-  u64* rn_hash = inLds ? l_hash : B.rnn_hash + (u64)bb0 * G;
-  i32* rn_id = inLds ? l_id : B.rnn_nid + (u64)bb0 * G;
-  u32* rn_len = inLds ? l_len : B.rnn_nlen + (u64)bb0 * G;
-  u32* rn_cnt = inLds ? l_cnt : B.rnn_cnt + bb0;               // rnn nodes per boundary
-  float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * E;
-
-  // contexts of the prev nodes of the current chunk of rnn nodes (chunk = kCtxFloats / E nodes, <= 8)
-  constexpr u32 kCtxFloats = WLDS ? 4 * kRnnLdsE : kRnnCtxCap;
-  __shared__ float pctx_all[kRnnWaves][kCtxFloats];
-  __shared__ float nscore_all[kRnnWaves][kMaxGbeam];
-  __shared__ float full_all[kRnnWaves][kMaxGbeam];
-  __shared__ float prev_total_all[kRnnWaves][kMaxGbeam];
-  float* pctx = pctx_all[wv];
-  float* nscore = nscore_all[wv];
-  float* full = full_all[wv];
-  float* prev_total = prev_total_all[wv];
-  const int chunkMax = (int)(kCtxFloats / E) < kRnnChunk ? (int)(kCtxFloats / E) : kRnnChunk;
+  __shared__ u32 l_conn_all[kRnnPrepWaves][kCap];
+  __shared__ i32 l_wid_all[kRnnPrepWaves][kCap];
+  __shared__ u32 l_assign_all[kRnnPrepWaves][kCap];
+  __shared__ u32 l_prev_all[kRnnPrepWaves][kCap];
+  __shared__ u64 l_hash_all[kRnnPrepWaves][kCap];
+  __shared__ i32 l_id_all[kRnnPrepWaves][kCap];
+  __shared__ u32 l_len_all[kRnnPrepWaves][kCap];
+  __shared__ u32 l_cnt_all[kRnnPrepWaves][kCapB];
+  const u32 nq = (bE + 1) * (u32)G;
+  const bool inLds = nq <= kCap && (bE + 1) <= kCapB;
+  u32* g_conn = B.rnn_conn + (u64)bb0 * G;
+  u32* g_assign = B.rnn_assign + (u64)bb0 * G;
+  u32* g_prev = B.rnn_prev + (u64)bb0 * G;
+  i32* g_id = B.rnn_nid + (u64)bb0 * G;
+  u32* g_len = B.rnn_nlen + (u64)bb0 * G;
+  u32* g_cnt = B.rnn_cnt + bb0;
+  u32* conn = inLds ? l_conn_all[wv] : g_conn;                  // lattice connection of path p at boundary b
+  i32* wid = inLds ? l_wid_all[wv] : B.rnn_id + (u64)bb0 * G;   // word id of that connection's lattice node
+  u32* assign = inLds ? l_assign_all[wv] : g_assign;            // rnn node (index within boundary) scoring it
+  u32* rn_prev = inLds ? l_prev_all[wv] : g_prev;               // rnn node -> handle (pb * G + pidx) of its prev
+  u64* rn_hash = inLds ? l_hash_all[wv] : B.rnn_hash + (u64)bb0 * G;
+  i32* rn_id = inLds ? l_id_all[wv] : g_id;
+  u32* rn_len = inLds ? l_len_all[wv] : g_len;
+  u32* rn_cnt = inLds ? l_cnt_all[wv] : g_cnt;                  // rnn nodes per boundary
 
   // ---- A. connection of every EOS path at every boundary ----
-  for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) conn[q] = kNoConn;
+  for (u32 q = lane; q < nq; q += 64) conn[q] = kNoConn;
   for (u32 q = lane; q <= bE; q += 64) rn_cnt[q] = 0;
   wave_sync();
   const u32 efirstE = B.end_first[bb0 + bE];
@@ -190,179 +165,293 @@ __global__ void __launch_bounds__(64 * kRnnWaves) k_rnn(Batch B, const DevModel*
   }
   wave_sync();
   // ---- B. word ids of the connections ----
-  for (u32 q = lane; q < (bE + 1) * (u32)G; q += 64) {
+  for (u32 q = lane; q < nq; q += 64) {
     u32 c = conn[q];
     if (c == kNoConn) continue;
     u32 nd = c & 0x03ffffffu;
     wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
   }
-  wave_sync();
-  // ---- B2. RNN lattice: RnnIdContainer::addPath / addPrevChain, path by path ----
+  // BOS node (boundary 1): RnnIdContainer::addBos
   if (lane == 0) {
-    // BOS node (boundary 1): RnnIdContainer::addBos
     rn_cnt[1] = 1;
     rn_hash[(u64)1 * G] = 0xdeadbeef0000ULL;
     rn_id[(u64)1 * G] = 0;
     rn_len[(u64)1 * G] = 0;
     rn_prev[(u64)1 * G] = kNoConn;
-    for (int p = 0; p < ngb; ++p) {
-      u32 cur = 1u * G;  // handle of the BOS node
-      for (u32 b = 2; b <= bE; ++b) {
-        u32 c = conn[(u64)b * G + p];
-        if (c == kNoConn) continue;
-        // ptrCache hit: an earlier path went through the same connection
-        int shared = -1;
-        for (int pp = 0; pp < p; ++pp) {
-          if (conn[(u64)b * G + pp] == c) {
-            shared = pp;
-            break;
-          }
-        }
-        if (shared >= 0) {
-          u32 a = assign[(u64)b * G + shared];
-          assign[(u64)b * G + p] = a;
-          cur = b * G + a;
-          continue;
-        }
-        u32 nd = c & 0x03ffffffu;
-        i32 id = wid[(u64)b * G + p];
-        u32 len = (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
-        u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
-        u32 cnt = rn_cnt[b];
-        // crdCache_.find(coord): newest published node with the same (boundary, length, id)
-        int it = -1;
-        for (int x = (int)cnt - 1; x >= 0; --x) {
-          if (rn_id[(u64)b * G + x] == id && rn_len[(u64)b * G + x] == len) {
-            it = x;
-            break;
-          }
-        }
-        bool merged = false;
-        if (it >= 0) {
-          // walk nextInBnd (all older nodes of the boundary) comparing the prefix hash;
-          // on a match the connection is attached to it->second, not to the matching node
-          for (int x = it; x >= 0; --x) {
-            if (rn_hash[(u64)b * G + x] == h) {
-              merged = true;
+  }
+  wave_sync();
+  // ---- B2. RNN lattice: RnnIdContainer::addPath / addPrevChain ----
+  // Path p (= lane p) is at boundary t - p in step t: all earlier paths have already published
+  // their rnn nodes of that boundary, later ones have not touched it yet.
+  {
+    const int p = lane;
+    u32 cur = 1u * G;  // handle of the BOS node
+    for (u32 t = 2; t < bE + 1 + (u32)ngb; ++t) {
+      const u32 b = t - (u32)p;
+      if (p < ngb && t >= (u32)p + 2 && b <= bE) {
+        const u32 c = conn[(u64)b * G + p];
+        if (c != kNoConn) {
+          // ptrCache hit: an earlier path went through the same connection
+          int shared = -1;
+          for (int pp = 0; pp < p; ++pp) {
+            if (conn[(u64)b * G + pp] == c) {
+              shared = pp;
               break;
             }
           }
+          if (shared >= 0) {
+            u32 a = assign[(u64)b * G + shared];
+            assign[(u64)b * G + p] = a;
+            cur = b * G + a;
+          } else {
+            u32 nd = c & 0x03ffffffu;
+            i32 id = wid[(u64)b * G + p];
+            u32 len = (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
+            u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
+            u32 cnt = rn_cnt[b];
+            // crdCache_.find(coord): newest published node with the same (boundary, length, id)
+            int it = -1;
+            for (int x = (int)cnt - 1; x >= 0; --x) {
+              if (rn_id[(u64)b * G + x] == id && rn_len[(u64)b * G + x] == len) {
+                it = x;
+                break;
+              }
+            }
+            bool merged = false;
+            if (it >= 0) {
+              // walk nextInBnd (all older nodes of the boundary) comparing the prefix hash;
+              // on a match the connection is attached to it->second, not to the matching node
+              for (int x = it; x >= 0; --x) {
+                if (rn_hash[(u64)b * G + x] == h) {
+                  merged = true;
+                  break;
+                }
+              }
+            }
+            if (merged) {
+              assign[(u64)b * G + p] = (u32)it;
+              cur = b * G + (u32)it;
+            } else {
+              rn_cnt[b] = cnt + 1;
+              rn_hash[(u64)b * G + cnt] = h;
+              rn_id[(u64)b * G + cnt] = id;
+              rn_len[(u64)b * G + cnt] = len;
+              rn_prev[(u64)b * G + cnt] = cur;
+              assign[(u64)b * G + p] = cnt;
+              cur = b * G + cnt;
+            }
+          }
         }
-        if (merged) {
-          assign[(u64)b * G + p] = (u32)it;
-          cur = b * G + (u32)it;
-        } else {
-          rn_cnt[b] = cnt + 1;
-          rn_hash[(u64)b * G + cnt] = h;
-          rn_id[(u64)b * G + cnt] = id;
-          rn_len[(u64)b * G + cnt] = len;
-          rn_prev[(u64)b * G + cnt] = cur;
-          assign[(u64)b * G + p] = cnt;
-          cur = b * G + cnt;
-        }
+      }
+      wave_sync();
+    }
+  }
+  if (inLds) {
+    for (u32 q = lane; q < nq; q += 64) {
+      g_conn[q] = conn[q];
+      g_assign[q] = assign[q];
+      g_prev[q] = rn_prev[q];
+      g_id[q] = rn_id[q];
+      g_len[q] = rn_len[q];
+    }
+    for (u32 q = lane; q <= bE; q += 64) g_cnt[q] = rn_cnt[q];
+  }
+}
+
+// out[p][:] += W^T[k][:] * ctx[p][k] for every k; lane owns outputs lane*J .. lane*J+J-1
+template <int J, int CN>
+__device__ __forceinline__ void rnn_matvec(const float* __restrict__ Wt, const float (&ctx)[kRnnCN][J],
+                                           float (&acc)[kRnnCN][J], int lane) {
+  constexpr int EP = 64 * J;
+#pragma unroll 8
+  for (int kk = 0; kk < 64; ++kk) {
+#pragma unroll
+    for (int j2 = 0; j2 < J; ++j2) {
+      const float* row = Wt + (kk * J + j2) * EP + lane * J;
+      float w[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) w[j] = row[j];
+#pragma unroll
+      for (int p = 0; p < CN; ++p) {
+        float c = wave_bcast_f32(ctx[p][j2], kk);
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[p][j] = __builtin_fmaf(w[j], c, acc[p][j]);
       }
     }
   }
-  wave_sync();
+}
+
+// WLDS: the padded transposed recurrent matrix lives in LDS and is shared by the 16 wavefronts
+// of the workgroup; otherwise (E > 128) W is streamed from L2.
+template <int J, bool WLDS>
+__global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, const DevModel* Mp, Config cfg) {
+  constexpr int kWaves = WLDS ? 16 : 4;
+  constexpr int EP = 64 * J;
+  const DevModel& M = *Mp;
+  const int wv = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  __shared__ float s_W[WLDS ? EP * EP : 1];
+  if (WLDS) {
+    for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[q] = M.rnn_wt[q];
+    __syncthreads();
+  }
+  const float* __restrict__ Wt = WLDS ? s_W : M.rnn_wt;
+  const u32 s = blockIdx.x * kWaves + wv;
+  if (s >= B.n_sent) return;
+  if (B.sent_status[s] != ST_OK) return;
+  const u32 off = B.byte_off[s];
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_ncp[s];
+  if (n == 0) return;
+  const u32 N = B.sent_nodes[s];
+  const u64 nb = B.node_base[s];
+  const int beam = cfg.beam;
+  const int G = cfg.gbeam;
+  const int S = cfg.nscorers;
+  const u32 bE = n + 2;
+  const int ngb = (int)B.bnd_ngb[bb0 + bE];
+  if (ngb == 0) return;
+  const u32 E = M.rnn_E;
+  BeamSlot* beams = B.node_beam + nb * beam;
+  const u32* en = B.end_nodes + nb;
+  const u32* conn = B.rnn_conn + (u64)bb0 * G;
+  const u32* assign = B.rnn_assign + (u64)bb0 * G;
+  const u32* g_len = B.rnn_nlen + (u64)bb0 * G;
+  float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * EP;
+
+  // the per-node fields the boundary loop depends on are staged in LDS when they fit
+  constexpr u32 kCap = 320, kCapB = 56;
+  __shared__ u32 l_prev_all[kWaves][kCap];
+  __shared__ i32 l_id_all[kWaves][kCap];
+  __shared__ u32 l_cnt_all[kWaves][kCapB];
+  __shared__ float nscore_all[kWaves][kMaxGbeam];
+  __shared__ float full_all[kWaves][kMaxGbeam];
+  __shared__ float prev_total_all[kWaves][kMaxGbeam];
+  float* nscore = nscore_all[wv];
+  float* full = full_all[wv];
+  float* prev_total = prev_total_all[wv];
+  const u32 nq = (bE + 1) * (u32)G;
+  const bool inLds = nq <= kCap && (bE + 1) <= kCapB;
+  const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
+  const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
+  const u32* rn_cnt = B.rnn_cnt + bb0;
+  if (inLds) {
+    for (u32 q = lane; q < nq; q += 64) {
+      l_prev_all[wv][q] = rn_prev[q];
+      l_id_all[wv][q] = rn_id[q];
+    }
+    for (u32 q = lane; q <= bE; q += 64) l_cnt_all[wv][q] = rn_cnt[q];
+    rn_prev = l_prev_all[wv];
+    rn_id = l_id_all[wv];
+    rn_cnt = l_cnt_all[wv];
+  }
   // ---- C. contexts and scores, boundary by boundary ----
   // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
-  for (u32 e = lane; e < E; e += 64) {
-    float x = 0.f + M.rnn_emb[e];
-    rn_ctx[(u64)1 * G * E + e] = 1.0f / (1.0f + expf(-x));
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    u32 i = (u32)lane * J + j;
+    float v = 0.f;
+    if (i < E) {
+      float x = 0.f + M.rnn_emb[i];
+      v = 1.0f / (1.0f + expf(-x));
+    }
+    rn_ctx[(u64)1 * G * EP + i] = v;
   }
   wave_sync();
   for (u32 b = 2; b <= bE; ++b) {
     const int cnt = (int)rn_cnt[b];
     if (cnt == 0) continue;
-    for (int c0 = 0; c0 < cnt; c0 += chunkMax) {
-      const int cn = (cnt - c0) < chunkMax ? (cnt - c0) : chunkMax;
-      // stage the prev contexts of this chunk of rnn nodes
-      for (u32 q = lane; q < (u32)cn * E; q += 64) {
-        u32 x = q / E, e = q - x * E;
-        pctx[q] = rn_ctx[(u64)rn_prev[(u64)b * G + c0 + x] * E + e];
-      }
-      wave_sync();
-      // score of every rnn node of the chunk: one 8-lane group per node
-      {
-        const int x = lane >> 3, gj = lane & 7;
-        const bool act = x < cn;
-        i32 id = act ? rn_id[(u64)b * G + c0 + x] : 0;
-        u32 eid = id == -1 ? 0u : (u32)id;
-        float part = 0.f;
-        if (act)
-          for (u32 e = gj; e < E; e += 8) part += M.rnn_nce[(u64)eid * E + e] * pctx[(u32)x * E + e];
-        part += wave_shfl_f32(part, lane ^ 4);
-        part += wave_shfl_f32(part, lane ^ 2);
-        part += wave_shfl_f32(part, lane ^ 1);
-        if (act && gj == 0) {
-          float score = part;
-          // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
-          float me = 0.f;
-          u32 order = M.rnn_order;
-          i32 pid = rn_id[rn_prev[(u64)b * G + c0 + x]];
-          for (u32 i = 0; i < order; ++i) {
-            u64 xx = rnn_prime(0) * rnn_prime(1);
-            for (u32 j = 1; j <= i; ++j) {
-              u64 pi = ((u64)i * rnn_prime(j) + j) % 36;
-              xx += rnn_prime((u32)pi) * ((u64)(i64)pid + 1);
-            }
-            u64 h = xx % M.rnn_hash_max;
-            u64 idx = (h + (u64)(i64)id) % M.rnn_hash_max;
-            float w = M.rnn_maxent[idx];
-            me = (i == 0) ? w : me + w;
-          }
-          if (order > 0) score += me;
-          else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
-          score -= M.rnn_nce_const;
-          if (id == M.rnn_unk_id) score = M.rnn_unk_const + M.rnn_unk_len * (float)rn_len[(u64)b * G + c0 + x];
-          nscore[c0 + x] = score;
+    for (int c0 = 0; c0 < cnt; c0 += kRnnCN) {
+      const int cn = (cnt - c0) < kRnnCN ? (cnt - c0) : kRnnCN;
+      float ctx[kRnnCN][J];
+      float embv[kRnnCN][J];
+      float dot[kRnnCN];
+#pragma unroll
+      for (int p = 0; p < kRnnCN; ++p) {
+        dot[p] = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          ctx[p][j] = 0.f;
+          embv[p][j] = 0.f;
         }
+        if (p < cn) {
+          const u32 hnd = rn_prev[(u64)b * G + c0 + p];
+          const i32 id = rn_id[(u64)b * G + c0 + p];
+          const u32 eid = id == -1 ? 0u : (u32)id;
+          const float* cp = rn_ctx + (u64)hnd * EP + (u32)lane * J;
+#pragma unroll
+          for (int j = 0; j < J; ++j) ctx[p][j] = cp[j];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            u32 i = (u32)lane * J + j;
+            if (i < E) {
+              dot[p] += M.rnn_nce[(u64)eid * E + i] * ctx[p][j];
+              if (b < bE) embv[p][j] = M.rnn_emb[(u64)eid * E + i];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < kRnnCN; ++p) {
+        if (p < cn) {
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) dot[p] += wave_shfl_f32(dot[p], lane ^ o);
+        }
+      }
+      // score of rnn node c0 + x on lane x
+      if (lane < cn) {
+        const int x = lane;
+        float score = x == 0 ? dot[0] : x == 1 ? dot[1] : x == 2 ? dot[2] : dot[3];
+        const i32 id = rn_id[(u64)b * G + c0 + x];
+        // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
+        float me = 0.f;
+        const u32 order = M.rnn_order;
+        const i32 pid = rn_id[rn_prev[(u64)b * G + c0 + x]];
+        for (u32 i = 0; i < order; ++i) {
+          u64 xx = rnn_prime(0) * rnn_prime(1);
+          for (u32 j = 1; j <= i; ++j) {
+            u64 pi = ((u64)i * rnn_prime(j) + j) % 36;
+            xx += rnn_prime((u32)pi) * ((u64)(i64)pid + 1);
+          }
+          u64 h = fastmod_u64(xx, M.rnn_hash_max, M.rnn_hash_magic);
+          u64 idx = fastmod_u64(h + (u64)(i64)id, M.rnn_hash_max, M.rnn_hash_magic);
+          float w = M.rnn_maxent[idx];
+          me = (i == 0) ? w : me + w;
+        }
+        if (order > 0) score += me;
+        else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+        score -= M.rnn_nce_const;
+        if (id == M.rnn_unk_id) score = M.rnn_unk_const + M.rnn_unk_len * (float)g_len[(u64)b * G + c0 + x];
+        nscore[c0 + x] = score;
       }
       // new contexts (GbeamRnnState::computeContext; not needed for EOS)
       if (b < bE) {
-        float acc[kRnnChunk][kMaxRnnE / 64];
+        float acc[kRnnCN][J];
 #pragma unroll
-        for (int p = 0; p < kRnnChunk; ++p)
+        for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
-          for (int j = 0; j < kMaxRnnE / 64; ++j) acc[p][j] = 0.f;
-#pragma unroll 4
-        for (u32 k = 0; k < E; ++k) {
-          float w[kMaxRnnE / 64];
-#pragma unroll
-          for (int j = 0; j < kMaxRnnE / 64; ++j) {
-            u32 i = (u32)lane + 64u * j;
-            w[j] = (j < J && i < E) ? Wt[(u64)k * E + i] : 0.f;
-          }
-#pragma unroll
-          for (int p = 0; p < kRnnChunk; ++p) {
-            if (p < cn) {
-              float c = pctx[(u32)p * E + k];
-#pragma unroll
-              for (int j = 0; j < kMaxRnnE / 64; ++j) {
-                float prod = w[j] * c;
-                acc[p][j] += prod;
-              }
-            }
-          }
+          for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
+        switch (cn) {
+          case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
+          case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
+          case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
+          default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
         }
 #pragma unroll
-        for (int p = 0; p < kRnnChunk; ++p) {
+        for (int p = 0; p < kRnnCN; ++p) {
           if (p < cn) {
-            i32 id = rn_id[(u64)b * G + c0 + p];
-            u32 eid = id == -1 ? 0u : (u32)id;
+            float* op = rn_ctx + ((u64)b * G + c0 + p) * EP + (u32)lane * J;
 #pragma unroll
-            for (int j = 0; j < kMaxRnnE / 64; ++j) {
-              u32 i = (u32)lane + 64u * j;
-              if (j < J && i < E) {
-                float x = acc[p][j] + M.rnn_emb[(u64)eid * E + i];
-                rn_ctx[((u64)b * G + c0 + p) * E + i] = 1.0f / (1.0f + expf(-x));
-              }
+            for (int j = 0; j < J; ++j) {
+              u32 i = (u32)lane * J + j;
+              float x = acc[p][j] + embv[p][j];
+              op[j] = i < E ? 1.0f / (1.0f + expf(-x)) : 0.f;
             }
           }
         }
       }
-      wave_sync();
     }
+    wave_sync();
     if (lane < ngb) {
       u32 c = conn[(u64)b * G + lane];
       if (c != kNoConn) {
@@ -375,6 +464,7 @@ __global__ void __launch_bounds__(64 * kRnnWaves) k_rnn(Batch B, const DevModel*
   }
 
   // ---- D. adjustBeamScores along the EOS paths ----
+  const u32 efirstE = B.end_first[bb0 + bE];
   if (lane < ngb) {
     float prevT = 0.f;  // BOS element total
     for (u32 b = 2; b < bE; ++b) {

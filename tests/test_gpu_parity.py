@@ -106,11 +106,14 @@ def test_gpu_matches_live_reference_on_fresh_workload(gpu_lib, ref_tools, tmp_pa
     assert not errs, (len(errs), errs[:10])
 
 
-def test_gpu_matches_live_reference_with_rnn(gpu_lib, ref_tools, tmp_path):
-    """config[2] shape: perceptron + RNNLM (E=128), 1000 fresh sentences vs the live reference."""
+@pytest.mark.parametrize('hidden,vocab,n_lines', [(128, 8000, 1000), (100, 3000, 300), (48, 3000, 300),
+                                                 (200, 3000, 300)])
+def test_gpu_matches_live_reference_with_rnn(gpu_lib, ref_tools, tmp_path, hidden, vocab, n_lines):
+    """config[2] shape: perceptron + RNNLM, fresh sentences vs the live reference.  E=128 is the
+    benchmark shape; 100 and 48 exercise the zero-padded LDS layouts, 200 the streamed-W kernel."""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
-    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 30000, 1000, 20, 55, rnn=(128, 8000))
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 30000, n_lines, 20, 55, rnn=(hidden, vocab))
     ctx = J.Context(img, lib_path=gpu_lib)
     meta, gold = G.read_gold(gold_path)
     assert meta['nscorers'] == 2
