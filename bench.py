@@ -154,7 +154,11 @@ def main():
     ap.add_argument('--seed', type=int, default=20260925)
     ap.add_argument('--cpu-sample', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--rnn', action='store_true', help='BASELINE configs[2]: perceptron + RNNLM re-ranker')
+    ap.add_argument('--rnn', dest='rnn', action='store_true', default=True,
+                    help='BASELINE configs[2] (default; the metric is quoted on jumandic+RNNLM): perceptron + RNNLM re-ranker')
+    ap.add_argument('--no-rnn', dest='rnn', action='store_false', help='BASELINE configs[1]: perceptron only')
+    ap.add_argument('--traffic-profile', default=os.path.join(ROOT, 'profiles', 'traffic.json'),
+                    help='per-kernel HBM bytes per launch from the committed rocprofv3 --pmc passes of this command')
     ap.add_argument('--rnn-hidden', type=int, default=128)
     ap.add_argument('--rnn-vocab', type=int, default=30000)
     ap.add_argument('--cache', default=os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache'))
@@ -247,6 +251,43 @@ def main():
         avg = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'  # k_rnn has its own line in kernel_ms_per_step
         achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
+        # HBM traffic of the dominant kernel: measured offline by tools/gpu_profile.sh (separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), committed under profiles/
+        traffic, traffic_note = None, None
+        try:
+            tp = json.load(open(args.traffic_profile))
+            if (tp.get('batch') == args.batch and tp.get('rnn') == bool(args.rnn) and tp.get('sent_len') == args.sent_len
+                    and tp.get('dict_entries') == args.dict_entries and world == 1):
+                ent = tp['kernels'].get('k_' + dom)
+                if ent:
+                    traffic = ent['hbm_bytes_per_launch']
+                    traffic_note = tp.get('note')
+        except (OSError, ValueError, KeyError):
+            pass
+        # configs[1] (perceptron only) on the same model and batches, outside the timed region
+        perceptron_only = None
+        if args.rnn and world == 1:
+            ctx2 = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank, use_rnn=False)
+            def step2(i):
+                t, o, n, nbytes = d_batches[i % len(d_batches)]
+                return ctx2.analyze_device(t.data_ptr(), o.data_ptr(), n, nbytes, stream)
+            step2(0).release()
+            torch.cuda.synchronize()
+            k2 = min(args.steps, 8)
+            t1 = time.perf_counter()
+            km2 = {}
+            for i in range(k2):
+                r2 = step2(1 + i)
+                r2.pack(d_offs.data_ptr(), d_items.data_ptr(), cap_items)
+                int(d_offs[-1].item())
+                for k, v in ctx2.timings().items():
+                    km2[k] = km2.get(k, 0.0) + v
+                r2.release()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            perceptron_only = {'workload': 'BASELINE configs[1]: same model and batches, RNN off', 'value': round(args.batch * k2 / e2, 1),
+                               'unit': 'sentences/s', 'steps': k2, 'ms_per_step': round(e2 / k2 * 1e3, 3),
+                               'kernel_ms_per_step': {k: round(v / k2, 3) for k, v in km2.items()}}
         out = {
             'metric': 'sentences/sec whole-node, beam=5 jumandic %s; achieved HBM GB/s' % ('+RNNLM' if args.rnn else 'perceptron (RNN off)'),
             'value': round(value, 1),
@@ -281,11 +322,14 @@ def main():
                 'peak': 8000.0,
                 'unit': 'GB/s',
                 'frac': round(achieved / 8000.0, 5),
-                'traffic': None,
+                'traffic': traffic,
+                'traffic_source': traffic_note,
                 'algorithmic_bytes_per_launch': ab[dom],
                 'avg_launch_ms': round(avg[dom], 3),
             },
         }
+        if perceptron_only is not None:
+            out['perceptron_only'] = perceptron_only
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
         print(json.dumps(out, ensure_ascii=False), flush=True)

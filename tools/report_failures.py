@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=65536)
     a = ap.parse_args()
-    args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, sent_len=40, batch=a.batch)
+    args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, sent_len=40, batch=a.batch, rnn=True, rnn_hidden=128, rnn_vocab=30000)
     cache = os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache')
     mdic, model, img = bench.make_workload(args, cache)
     corpus = bench.make_corpus(args, mdic, cache, args.batch * 2, args.seed + 1)
