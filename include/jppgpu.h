@@ -124,7 +124,7 @@ typedef struct {
   int32_t template_ptr; /* UNK: template EntryPtr raw; 0 for dictionary nodes */
   int32_t content_hash; /* UNK: surface hash (negative) */
   uint16_t placeholder[2];
-  uint16_t maker;
+  uint16_t maker;          /* UNK: index into jppgpu_model::unk_makers (spec order) */
   uint16_t pad;
 } jppgpu_unk;
 

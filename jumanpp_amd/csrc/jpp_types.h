@@ -42,6 +42,7 @@ struct UnkMaker {
   i32 placeholder;      // target placeholder index or -1
   u32 replace_mask;     // bit f set: entry feature f is replaced by the surface hash
   u32 pattern_mask;     // features compared by dicPatternMatches (numeric maker)
+  i32 spec_index;       // position in spec.unkCreators (= jppgpu_model::unk_makers), reported in jppgpu_unk::maker
   i32 tmpl[kMaxDicFeatures];  // decoded template entry row
 };
 
@@ -59,6 +60,7 @@ struct DevModel {
   i32 n_stage1;          // makers[0..n_stage1) are stage 1 in spec order, the rest stage 2
   i32 norm_maker;        // index of the Normalize maker or -1
   UnkMaker makers[kMaxUnkMakers];
+  i32 maker_of_spec[kMaxUnkMakers];  // spec order (NodeAux::maker) -> index into makers[]
   // RNN re-ranker (reference RNN model part, rnn_scorer_gbeam.cc:375-398,426-470)
   i32 has_rnn;
   const u32* rnn_known;      // word -> id double array for dictionary nodes

@@ -252,6 +252,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     k.placeholder = u.placeholder;
     k.replace_mask = u.replace_mask;
     k.pattern_mask = ~u.replace_mask & ((1u << m->num_features) - 1);
+    k.spec_index = i;
     if (u.pattern_ptr < 0 || (size_t)(u.pattern_ptr >> 1) >= m->entry_data_bytes) {
       jppgpu_ctx_destroy(ctx);
       return fail(JPPGPU_INVALID_PARAMETER, "UNK template pointer outside entry data");
@@ -290,6 +291,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     H.norm_maker = idx;
     H.makers[idx++] = norm[0];
   }
+  for (int q = 0; q < idx; ++q) H.maker_of_spec[H.makers[q].spec_index] = q;
   H.has_rnn = 0;
   if (c->use_rnn) {
     // AnalyzerImpl::initScorers: scorer count must match the weights; RNN needs the global beam

@@ -72,7 +72,7 @@ __device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, 
   }
   i32 ph[2] = {0, 0};
   if (mk.placeholder >= 0 && mk.placeholder < 2) ph[mk.placeholder] = notPrefix ? 1 : 0;
-  out.unk(mk.pattern_ptr, surface_hash(S, s, e), ph[0], ph[1], (u32)(&mk - M.makers), s, e);
+  out.unk(mk.pattern_ptr, surface_hash(S, s, e), ph[0], ph[1], (u32)mk.spec_index, s, e);
 }
 
 // expand the entry-pointer list at trie value `v`
@@ -430,7 +430,7 @@ __device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk,
   }
   i32 ph[2] = {0, 0};
   if (mk.placeholder >= 0 && mk.placeholder < 2) ph[mk.placeholder] = (i32)r.flags;
-  out.unk(r.ptr, surface_hash(S, s, r.end), ph[0], ph[1], (u32)M.norm_maker, s, r.end);
+  out.unk(r.ptr, surface_hash(S, s, r.end), ph[0], ph[1], (u32)M.makers[M.norm_maker].spec_index, s, r.end);
 }
 
 // MODE 0: count (writes pos_cntA / pos_cnt2); MODE 1: emit stage 1; MODE 2: emit stage 1+2

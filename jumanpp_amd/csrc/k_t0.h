@@ -70,7 +70,7 @@ __global__ void k_t0(Batch B, const DevModel* Mp) {
       read_entry_row(M, ni.eptr, entry, spec::kNumDicFeatures);
     } else {
       isUnk = true;
-      const UnkMaker& mk = M.makers[na.maker];
+      const UnkMaker& mk = M.makers[M.maker_of_spec[na.maker]];
       if (mk.type == UNK_NORMALIZE) {
         read_entry_row(M, na.tmpl, entry, spec::kNumDicFeatures);
       } else {

@@ -1,0 +1,114 @@
+// GpuAnalyzer: the C++14 host-side mirror of core::analysis::Analyzer
+// (src/core/analysis/analyzer.h:37-57) above the C ABI of libjppgpu.so.
+//
+//   reference                                   here
+//   Analyzer::initialize(core, cfg, sconf, def)  GpuAnalyzer::initialize(model, cfg, sconf, def)
+//   Analyzer::analyze(StringPiece)               GpuAnalyzer::analyze(StringPiece)        (batch of one)
+//                                                GpuAnalyzer::analyzeBatch(inputs)        (the fast path)
+//   Analyzer::output() / impl()->lattice()       GpuAnalyzer::sentence(i) -> SentenceResult
+//
+// Same argument meaning (AnalyzerConfig / ScoringConfig / ScorerDef), same
+// validation and the same error kinds: input longer than maxInputBytes and
+// invalid UTF-8 are InvalidParameter, an unconnectable lattice is InvalidState
+// (src/core/analysis/analyzer_impl.cc:19-25,131-136, util/characters.cc:267-269).
+// Results stay valid until the next analyze/analyzeBatch on the same object,
+// like the reference's pool-allocated lattice (analyzer_impl.h:48-55).
+// There is no CPU path: initialize fails with NoDevice without an MI355X.
+#ifndef JUMANPP_AMD_HOST_GPU_ANALYZER_H
+#define JUMANPP_AMD_HOST_GPU_ANALYZER_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "jpp_status.h"
+#include "jppgpu.h"
+#include "model_image.h"
+
+namespace jumanpp_amd {
+
+// core::analysis::AnalyzerConfig (analyzer.h:14-25); the auto-beam members are accepted only as 0
+struct AnalyzerConfig {
+  size_t pageSize = 4 * 1024 * 1024;  // unused: device workspaces are sized per batch
+  size_t maxInputBytes = 4 * 1024;
+  int32_t globalBeamSize = 0;
+  int32_t otherScorersTopN = 0;
+  int32_t rightGbeamCheck = 0;
+  int32_t rightGbeamSize = 0;
+  bool storeAllPatterns = false;
+  int32_t autoBeamStep = 0;
+  int32_t autoBeamBase = 0;
+  int32_t autoBeamMax = 0;
+};
+
+// core::ScoringConfig (src/core/core_types.h)
+struct ScoringConfig {
+  int32_t beamSize = 1;
+  int32_t numScorers = 1;
+};
+
+// core::analysis::ScorerDef (score_api.h:66-72).  The feature scorer is the model's perceptron;
+// `others` can only hold the model's RNN (useRnn), weighted by scoreWeights like the reference.
+struct ScorerDef {
+  bool useRnn = false;
+  std::vector<float> scoreWeights;
+};
+
+struct SentenceResult {
+  StringPiece input;
+  uint32_t numCodepoints = 0;
+  uint32_t numNodes = 0;
+  const jppgpu_node* nodes = nullptr;  // [numNodes], 0/1 = BOS, last = EOS
+  const jppgpu_unk* unk = nullptr;     // [numNodes]
+  const uint32_t* pathNodes = nullptr; // top-1 path, EOS first
+  uint32_t pathLen = 0;
+  const uint32_t* cpByteOffsets = nullptr;  // [numCodepoints + 1]
+  // byte span of a node's surface in `input`
+  StringPiece surface(const jppgpu_node& n) const {
+    return StringPiece(input.data() + cpByteOffsets[n.start], cpByteOffsets[n.end] - cpByteOffsets[n.start]);
+  }
+};
+
+class GpuAnalyzer {
+  const ModelImage* model_ = nullptr;
+  jppgpu_ctx* ctx_ = nullptr;
+  jppgpu_result* result_ = nullptr;
+  jppgpu_result_view view_{};
+  AnalyzerConfig cfg_;
+  ScoringConfig sconf_;
+  std::vector<StringPiece> inputs_;
+  std::string text_;
+  std::vector<uint32_t> offsets_;
+  std::vector<uint32_t> cpOffsets_;      // concatenated per-sentence codepoint -> byte offset tables
+  std::vector<uint64_t> cpOffsetsBase_;
+  std::string singleInput_;
+
+  void releaseResult();
+
+ public:
+  GpuAnalyzer() = default;
+  GpuAnalyzer(const GpuAnalyzer&) = delete;
+  GpuAnalyzer& operator=(const GpuAnalyzer&) = delete;
+  ~GpuAnalyzer();
+
+  Status initialize(const ModelImage* model, const AnalyzerConfig& cfg, const ScoringConfig& sconf,
+                    const ScorerDef* scorer, int device = 0);
+  // one sentence; the Status is the sentence's own status
+  Status analyze(StringPiece input);
+  // n sentences, one launch sequence; a failing sentence does not fail the batch (see sentenceStatus)
+  Status analyzeBatch(const std::vector<StringPiece>& inputs, bool fullLattice = false);
+
+  size_t numSentences() const { return inputs_.size(); }
+  Status sentenceStatus(size_t i) const;
+  SentenceResult sentence(size_t i) const;
+  const jppgpu_result_view& view() const { return view_; }
+  const ModelImage& model() const { return *model_; }
+  const AnalyzerConfig& cfg() const { return cfg_; }
+  const ScoringConfig& scoringConfig() const { return sconf_; }
+  // [0]decode [1]seeds [2]layout [3]t0 [4]sweep [5]rnn [6]path [7]total, ms of the last batch
+  void lastTimings(float ms[8]) const;
+};
+
+}  // namespace jumanpp_amd
+
+#endif  // JUMANPP_AMD_HOST_GPU_ANALYZER_H

@@ -1,0 +1,156 @@
+#include "juman_format.h"
+
+namespace jumanpp_amd {
+
+Status JumandicFields::initialize(const OutputManager& om) {
+  JPPA_RETURN_IF_ERROR(om.stringField("surface", &surface));
+  JPPA_RETURN_IF_ERROR(om.stringField("pos", &pos));
+  JPPA_RETURN_IF_ERROR(om.stringField("subpos", &subpos));
+  JPPA_RETURN_IF_ERROR(om.stringField("conjtype", &conjType));
+  JPPA_RETURN_IF_ERROR(om.stringField("conjform", &conjForm));
+  JPPA_RETURN_IF_ERROR(om.stringField("baseform", &baseform));
+  JPPA_RETURN_IF_ERROR(om.stringField("reading", &reading));
+  JPPA_RETURN_IF_ERROR(om.stringField("canonic", &canonicForm));
+  JPPA_RETURN_IF_ERROR(om.kvListField("features", &features));
+  return Status::Ok();
+}
+
+namespace {
+
+// charlattice::Modifiers (src/core/analysis/charlattice.h:22-34)
+enum : int32_t {
+  M_REPLACE_SMALLKANA = 0x2, M_REPLACE = 0x4, M_DELETE = 0x8, M_REPLACE_PROLONG = 0x10, M_DELETE_LAST = 0x20,
+  M_DELETE_PROLONG = 0x40, M_DELETE_HASTSUON = 0x80, M_DELETE_SMALLKANA = 0x100, M_REPLACE_EROW_WITH_E = 0x200,
+};
+
+inline void put(std::string& p, StringPiece s) { p.append(s.data(), s.size()); }
+
+// escapeForJumanOutput (juman_format.cc:42-54)
+inline StringPiece escapeForJumanOutput(StringPiece in) {
+  if (in.size() == 1) {
+    switch (in[0]) {
+      case '\t': return StringPiece("\\t");
+      case ' ': return StringPiece("\\\xe2\x90\xa3");  // backslash + U+2423
+    }
+  }
+  return in;
+}
+
+inline StringPiece ifEmpty(StringPiece s, StringPiece dflt) { return s.empty() ? dflt : s; }
+
+// formatNormalizedFeature (juman_format.cc:57-92); ExistFlag = any common bit (charlattice.h:55-57)
+void formatNormalizedFeature(std::string& p, int32_t v) {
+  put(p, "非標準表記:");
+  auto has = [v](int32_t f) { return (v & f) != 0; };
+  if (has(M_REPLACE)) p += 'R';
+  if (has(M_REPLACE_SMALLKANA)) p += 's';
+  if (has(M_REPLACE_PROLONG)) p += 'p';
+  if (has(M_REPLACE_EROW_WITH_E)) p += 'e';
+  if (has(M_DELETE)) p += 'D';
+  if (has(M_DELETE_PROLONG)) p += 'P';
+  if (has(M_DELETE_SMALLKANA)) p += 'S';
+  if (has(M_DELETE_HASTSUON)) p += 'H';
+  if (has(M_DELETE_LAST)) p += 'L';
+}
+
+}  // namespace
+
+Status JumanFormat::initialize(const ModelImage* model) {
+  model_ = model;
+  if (!model->hasIdMap()) {
+    return Status::InvalidState("model image has no JUMAN id tables (re-export it with the current ref_dump)");
+  }
+  OutputManager om(model);
+  return flds_.initialize(om);
+}
+
+bool JumanFormat::formatOne(const OutputManager& om, const SentenceResult& s, uint32_t node, bool first) {
+  if (!om.locate(s, node, &walker_)) return false;
+  std::string& printer = printer_;
+  while (walker_.next()) {
+    if (!first) put(printer, "@ ");
+    const int32_t* fb = walker_.features();
+    int32_t ids[4];
+    // conjForm and conjType are reversed in the entry row (juman_format.cc:104-106)
+    model_->dicToJuman(fb[1], fb[2], fb[4], fb[3], ids);
+    put(printer, escapeForJumanOutput(flds_.surface[walker_]));
+    printer += ' ';
+    put(printer, escapeForJumanOutput(flds_.reading[walker_]));
+    printer += ' ';
+    put(printer, escapeForJumanOutput(flds_.baseform[walker_]));
+    printer += ' ';
+    put(printer, ifEmpty(flds_.pos[walker_], "*"));
+    printer += ' ';
+    printer += std::to_string(ids[0]);
+    printer += ' ';
+    put(printer, ifEmpty(flds_.subpos[walker_], "*"));
+    printer += ' ';
+    printer += std::to_string(ids[1]);
+    printer += ' ';
+    put(printer, ifEmpty(flds_.conjType[walker_], "*"));
+    printer += ' ';
+    printer += std::to_string(ids[2]);
+    printer += ' ';
+    put(printer, ifEmpty(flds_.conjForm[walker_], "*"));
+    printer += ' ';
+    printer += std::to_string(ids[3]);
+    printer += ' ';
+    KVListIterator res = flds_.features[walker_];
+    StringPiece canonic = flds_.canonicForm[walker_];
+    const bool special = walker_.isSpecial();
+    const bool hasFeatures = special || res.hasNext() || !canonic.empty();
+    if (!hasFeatures) {
+      put(printer, "NIL");
+    } else {
+      bool output = false;
+      printer += '"';
+      if (!canonic.empty()) {
+        put(printer, "代表表記:");
+        put(printer, canonic);
+        if (res.hasNext()) printer += ' ';
+        output = true;
+      }
+      while (res.next()) {
+        output = true;
+        put(printer, res.key());
+        if (res.hasValue()) {
+          printer += ':';
+          put(printer, res.value());
+        }
+        if (res.hasNext()) printer += ' ';
+      }
+      if (special) {
+        int32_t ufld = walker_.placeholder(NormalizedPlaceholderIdx);
+        if (ufld != 0) {
+          if (output) printer += ' ';
+          formatNormalizedFeature(printer, ufld);
+        }
+      }
+      printer += '"';
+    }
+    printer += '\n';
+    first = false;
+  }
+  return true;
+}
+
+Status JumanFormat::format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment) {
+  printer_.clear();
+  JPPA_RETURN_IF_ERROR(analysis.sentenceStatus(sentence));
+  SentenceResult s = analysis.sentence(sentence);
+  OutputManager om(model_);
+  if (!comment.empty()) {
+    put(printer_, "# ");
+    put(printer_, comment);
+    printer_ += '\n';
+  }
+  // AnalysisPath::fillIn + nextBoundary/nextNode (analysis_result.cc:25-72): the top-1 path in text
+  // order, one node per chunk; pathNodes is EOS first
+  for (uint32_t k = s.pathLen; k-- > 1;) {
+    if (!formatOne(om, s, s.pathNodes[k], true)) return Status::InvalidState("failed to load a node");
+  }
+  put(printer_, "EOS\n");
+  return Status::Ok();
+}
+
+}  // namespace jumanpp_amd

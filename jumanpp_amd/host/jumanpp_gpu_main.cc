@@ -1,0 +1,199 @@
+// jumanpp_gpu: the reference CLI's read-analyze-format loop
+// (src/jumandic/main/jumanpp.cc:100-182, PlainStreamReader
+// src/core/input/stream_reader.cc:12-38) with the per-line Analyzer::analyze
+// replaced by batched GpuAnalyzer::analyzeBatch.  Output is byte-identical to
+// `jumanpp_v2 --model=... ` in the JUMAN format.
+//
+// usage: jumanpp_gpu --model=MODEL.img [--beam=5] [--global-beam=6] [--right-check=1]
+//                    [--right-beam=5] [--no-rnn] [--batch=65536] [--device=0] [-o OUT] [INPUT...]
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gpu_analyzer.h"
+#include "juman_format.h"
+
+using namespace jumanpp_amd;
+
+namespace {
+
+struct Conf {
+  std::string model;
+  int beam = 5, globalBeam = 6, rightCheck = 1, rightBeam = 5;  // jumanpp_args.h:50-54
+  bool noRnn = false;
+  size_t batch = 65536;
+  int device = 0;
+  std::string output;
+  std::vector<std::string> inputs;
+  bool timing = false;
+};
+
+bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
+  size_t n = std::strlen(name);
+  const char* a = argv[i];
+  if (std::strncmp(a, name, n) != 0) return false;
+  if (a[n] == '=') {
+    *out = a + n + 1;
+    return true;
+  }
+  if (a[n] == 0 && i + 1 < argc) {
+    *out = argv[++i];
+    return true;
+  }
+  return false;
+}
+
+struct Example {
+  std::string comment;
+  std::string input;
+  Status readStatus;
+};
+
+}  // namespace
+
+int main(int argc, const char** argv) {
+  Conf conf;
+  for (int i = 1; i < argc; ++i) {
+    std::string v;
+    if (argValue(argc, argv, i, "--model", &v)) conf.model = v;
+    else if (argValue(argc, argv, i, "--beam", &v)) conf.beam = std::atoi(v.c_str());
+    else if (argValue(argc, argv, i, "--global-beam", &v)) conf.globalBeam = std::atoi(v.c_str());
+    else if (argValue(argc, argv, i, "--right-check", &v)) conf.rightCheck = std::atoi(v.c_str());
+    else if (argValue(argc, argv, i, "--right-beam", &v)) conf.rightBeam = std::atoi(v.c_str());
+    else if (argValue(argc, argv, i, "--batch", &v)) conf.batch = (size_t)std::atoll(v.c_str());
+    else if (argValue(argc, argv, i, "--device", &v)) conf.device = std::atoi(v.c_str());
+    else if (argValue(argc, argv, i, "--output", &v) || argValue(argc, argv, i, "-o", &v)) conf.output = v;
+    else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
+    else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
+    else if (argv[i][0] == '-' && argv[i][1] != 0) {
+      std::cerr << "unknown option " << argv[i] << "\n";
+      return 1;
+    } else conf.inputs.push_back(argv[i]);
+  }
+  if (conf.model.empty()) {
+    std::cerr << "Model file was not specified\n";
+    return 1;
+  }
+  ModelImage model;
+  Status s = model.loadModel(conf.model);
+  if (!s) {
+    std::cerr << "failed to load model from disk: " << s << "\n";
+    return 1;
+  }
+  // JumanppEnv::makeAnalyzer: the RNN scorer is used whenever the model carries one (env.cc:86-121)
+  AnalyzerConfig acfg;
+  acfg.globalBeamSize = conf.globalBeam;
+  acfg.rightGbeamCheck = conf.rightCheck;
+  acfg.rightGbeamSize = conf.rightBeam;
+  ScoringConfig sconf;
+  sconf.beamSize = conf.beam;
+  ScorerDef def;
+  def.useRnn = model.hasRnn() && !conf.noRnn;
+  if (def.useRnn) {
+    sconf.numScorers = 2;
+    def.scoreWeights = {model.savedScoreWeights().perceptron, model.savedScoreWeights().rnn};
+  } else {
+    sconf.numScorers = 1;
+    def.scoreWeights = {1.0f};
+  }
+  GpuAnalyzer analyzer;
+  s = analyzer.initialize(&model, acfg, sconf, &def, conf.device);
+  if (!s) {
+    std::cerr << "failed to initialize the analyzer: " << s << "\n";
+    return 1;
+  }
+  JumanFormat format;
+  s = format.initialize(&model);
+  if (!s) {
+    std::cerr << "Failed to initialize I/O: " << s << "\n";
+    return 1;
+  }
+
+  std::unique_ptr<std::ofstream> ofile;
+  std::ostream* out = &std::cout;
+  if (!conf.output.empty() && conf.output != "-") {
+    ofile.reset(new std::ofstream(conf.output, std::ios::binary));
+    out = ofile.get();
+  }
+  std::ios::sync_with_stdio(false);
+
+  size_t fileIdx = 0;
+  std::unique_ptr<std::ifstream> ifile;
+  std::istream* in = &std::cin;
+  auto openNext = [&]() -> bool {
+    if (fileIdx >= conf.inputs.size()) return false;
+    ifile.reset(new std::ifstream(conf.inputs[fileIdx++], std::ios::binary));
+    in = ifile.get();
+    return true;
+  };
+  if (!conf.inputs.empty()) openNext();
+  // InputOutput::hasNext (jumanpp.cc:82-97)
+  auto hasNext = [&]() -> bool {
+    for (;;) {
+      if (in->good() && in->peek() != std::char_traits<char>::eof()) return true;
+      if (conf.inputs.empty() || !openNext()) return false;
+    }
+  };
+
+  const size_t maxInput = 65535, maxComment = 1024;  // rdr->setMaxSizes(65535, 1024), jumanpp.cc:72
+  std::vector<Example> batch;
+  std::vector<StringPiece> pieces;
+  int result = 0;
+  double gpuMs = 0;
+  size_t sentences = 0;
+  auto flush = [&]() {
+    pieces.clear();
+    for (auto& e : batch) pieces.push_back(e.readStatus.isOk() ? StringPiece(e.input) : StringPiece(""));
+    Status bs = analyzer.analyzeBatch(pieces);
+    if (conf.timing) {
+      float ms[8];
+      analyzer.lastTimings(ms);
+      gpuMs += ms[7];
+    }
+    for (size_t i = 0; i < batch.size(); ++i) {
+      if (!batch[i].readStatus.isOk()) {
+        std::cerr << "failed to read an example: " << batch[i].readStatus;
+        result = 1;
+        continue;
+      }
+      result = 0;
+      Status st = bs.isOk() ? analyzer.sentenceStatus(i) : bs;
+      if (!st) {
+        std::cerr << st;
+        *out << JumanFormat::emptyResult();
+        continue;
+      }
+      StringPiece comment = batch[i].comment.size() < 2 ? StringPiece("") : StringPiece(batch[i].comment.data() + 2, batch[i].comment.size() - 2);
+      st = format.format(analyzer, i, comment);
+      if (!st) std::cerr << st;
+      else *out << format.result();
+    }
+    sentences += batch.size();
+    batch.clear();
+  };
+  while (hasNext()) {
+    // PlainStreamReader::readExample
+    Example e;
+    for (;;) {
+      e.input.clear();
+      std::getline(*in, e.input);
+      if (e.input.size() > 2 && e.input[0] == '#' && e.input[1] == ' ') std::swap(e.comment, e.input);
+      else break;
+    }
+    if (e.comment.size() > maxComment) {
+      e.readStatus = Status::InvalidParameter() << "Comment size was: " << e.comment.size() << " which is more than max: " << maxComment;
+    } else if (e.input.size() > maxInput) {
+      e.readStatus = Status::InvalidParameter() << "Input size was: " << e.input.size() << " which is more than max: " << maxInput;
+    }
+    batch.push_back(std::move(e));
+    if (batch.size() >= conf.batch) flush();
+  }
+  if (!batch.empty()) flush();
+  out->flush();
+  if (conf.timing) std::cerr << "sentences=" << sentences << " gpu_ms=" << gpuMs << "\n";
+  return result;
+}

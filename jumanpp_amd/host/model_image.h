@@ -1,0 +1,86 @@
+// Flat model image (JPPGPUI1) -> jppgpu_model + the dictionary field storages
+// the output formats read.  Plays the role of JumanppEnv::loadModel /
+// CoreHolder for the host layer (src/core/env.cc:28-121, src/core/core.cc:11-40):
+// one immutable, shared object that must outlive every GpuAnalyzer.
+//
+// The image is written by `oracle/_ref/ref_dump export` from a .jppmdl; its
+// sections are the model's own blobs, verbatim (see jumanpp_amd/native.py for the
+// Python twin of this reader).
+#ifndef JUMANPP_AMD_HOST_MODEL_IMAGE_H
+#define JUMANPP_AMD_HOST_MODEL_IMAGE_H
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "jpp_status.h"
+#include "jppgpu.h"
+
+namespace jumanpp_amd {
+
+// spec::FieldType (src/core/spec/spec_types.h:18)
+enum class FieldType : int32_t { String = 0, Int = 1, StringList = 2, StringKVList = 3, Error = 4 };
+
+// dic::DictionaryField (src/core/dic/dictionary.h:19-30)
+struct DictionaryField {
+  int32_t idxInEntry = 0;      // >= 0: feature column, < 0: ~data column
+  int32_t specIndex = 0;
+  FieldType columnType = FieldType::Error;
+  int32_t stringStorage = -1;
+  int32_t intStorage = -1;
+  uint32_t alignPower = 0;
+  bool isTrieKey = false;
+  std::string name;
+  std::string emptyValue;
+};
+
+struct RnnScoreWeights {
+  float perceptron = 1.0f;
+  float rnn = 0.0f;
+};
+
+class ModelImage {
+  std::vector<char> data_;
+  jppgpu_model model_{};
+  std::vector<jppgpu_unk_maker> makers_;
+  std::vector<DictionaryField> fields_;
+  std::vector<StringPiece> stringStorages_;
+  std::vector<StringPiece> intStorages_;
+  int32_t numFeatures_ = 0, numData_ = 0, numPlaceholders_ = 0;
+  bool hasRnn_ = false;
+  RnnScoreWeights rnnWeights_;
+  std::unordered_map<uint64_t, uint64_t> posMap_, conjMap_;
+  bool hasIdMap_ = false;
+
+ public:
+  ModelImage() = default;
+  ModelImage(const ModelImage&) = delete;
+  ModelImage& operator=(const ModelImage&) = delete;
+
+  Status loadModel(StringPiece filename);
+
+  const jppgpu_model& cmodel() const { return model_; }
+  bool hasRnn() const { return hasRnn_; }
+  // ScorerDef::scoreWeights saved with the model (RnnInferenceConfig, src/core/env.cc:86-100)
+  RnnScoreWeights savedScoreWeights() const { return rnnWeights_; }
+  int32_t numFeatures() const { return numFeatures_; }
+  int32_t numData() const { return numData_; }
+  int32_t numPlaceholders() const { return numPlaceholders_; }
+  const jppgpu_unk_maker& unkMaker(size_t i) const { return makers_[i]; }
+  size_t numUnkMakers() const { return makers_.size(); }
+
+  // DictionaryHolder::fieldByName (src/core/dic/dictionary.h)
+  const DictionaryField* fieldByName(StringPiece name) const;
+  StringPiece stringStorage(int32_t idx) const { return stringStorages_[idx]; }
+  StringPiece intStorage(int32_t idx) const { return intStorages_[idx]; }
+  StringPiece entryData() const { return StringPiece((const char*)model_.entry_data, model_.entry_data_bytes); }
+
+  // JumandicIdResolver::dicToJuman (src/jumandic/shared/jumandic_id_resolver.cc:80-86), resolved at export time
+  bool hasIdMap() const { return hasIdMap_; }
+  void dicToJuman(int32_t pos, int32_t subpos, int32_t conjType, int32_t conjForm, int32_t out[4]) const;
+};
+
+}  // namespace jumanpp_amd
+
+#endif  // JUMANPP_AMD_HOST_MODEL_IMAGE_H

@@ -130,6 +130,7 @@ enum : u32 {
   SEC_STRINGS = 9,   // one per string storage
   SEC_INTS = 10,     // one per int storage
   SEC_RNN = 11,
+  SEC_IDMAP = 12,    // aux 0: (pos, subpos) -> JUMAN ids, aux 1: (conjtype, conjform) -> JUMAN ids
 };
 
 void section(Writer& w, u32 tag, u32 aux, const void* data, u64 size) {
@@ -257,6 +258,44 @@ int doExport(const char* modelFile, const char* out) {
   for (size_t i = 0; i < bd.intStorages.size(); ++i) {
     section(w, SEC_INTS, (u32)i, bd.intStorages[i].data(),
             bd.intStorages[i].size());
+  }
+  {  // JUMAN grammar ids used by the Juman output format: the resolved maps of
+     // JumandicIdResolver (src/jumandic/shared/jumandic_id_resolver.cc:32-88), enumerated over
+     // every string pointer the four fields can take
+    jumandic::JumandicIdResolver res;
+    auto st = res.initialize(holder);
+    if (st.isOk()) {
+      auto positions = [&](const char* name) {
+        std::vector<i32> r{0};
+        auto fld = holder.fieldByName(StringPiece{name, std::strlen(name)});
+        dic::impl::StringStorageTraversal trav(fld->strings);
+        StringPiece sp;
+        while (trav.next(&sp)) r.push_back(trav.position());
+        return r;
+      };
+      auto pos = positions("pos"), sub = positions("subpos"), ct = positions("conjtype"), cf = positions("conjform");
+      Writer a, b;
+      i32 na = 0, nb2 = 0;
+      for (auto p : pos)
+        for (auto q : sub) {
+          auto r = res.dicToJuman(jumandic::JumandicPosId{p, q, 0, 0});
+          if (r.pos != 0 || r.subpos != 0) {
+            a.put<i32>(p); a.put<i32>(q); a.put<i32>(r.pos); a.put<i32>(r.subpos);
+            ++na;
+          }
+        }
+      for (auto p : ct)
+        for (auto q : cf) {
+          auto r = res.dicToJuman(jumandic::JumandicPosId{0, 0, p, q});
+          if (r.conjType != 0 || r.conjForm != 0) {
+            b.put<i32>(p); b.put<i32>(q); b.put<i32>(r.conjType); b.put<i32>(r.conjForm);
+            ++nb2;
+          }
+        }
+      section(w, SEC_IDMAP, 0, a.buf.data(), a.buf.size());
+      section(w, SEC_IDMAP, 1, b.buf.data(), b.buf.size());
+      (void)na; (void)nb2;
+    }
   }
   if (auto rp = info.firstPartOf(model::ModelPartKind::Rnn)) {
     // RNN part blocks verbatim (src/core/analysis/rnn_scorer_gbeam.cc:375-398,426-470)

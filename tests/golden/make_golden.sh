@@ -33,5 +33,6 @@ python3 "$ROOT/tools/gen_rnn.py" "$TMP/mini.mdic" "$TMP/mini_rnn" --vocab 600 --
     --rnn-unk-length=-2.93 --feature-weight-perceptron=1 --feature-weight-rnn=0.0176 > /dev/null 2>&1
 "$REF/ref_dump" export "$TMP/mini_rnn.model" "$HERE/mini_rnn.img"
 "$REF/ref_dump" dump "$TMP/mini_rnn.model" "$HERE/mini_rnn.gold" < "$HERE/mini.txt" 2> /dev/null
+"$REF/jumanpp_v2" --model="$TMP/mini_rnn.model" "$HERE/mini.txt" > "$HERE/mini_rnn.juman.txt"
 rm -rf "$TMP"
 ls -la "$HERE"

@@ -1,0 +1,147 @@
+"""C++14 host layer (jumanpp_amd/host: GpuAnalyzer + JumanFormat + jumanpp_gpu CLI) against
+the reference CLI `jumanpp_v2`: the JUMAN-format output must be byte-identical
+(src/jumandic/shared/juman_format.cc, src/jumandic/main/jumanpp.cc).
+
+CPU tests link the host layer against the emulator build of the kernels (test
+infrastructure); the `gpu` tests run the shipped binary on the MI355X."""
+import os
+import subprocess
+
+import pytest
+
+import golden_io as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='session')
+def cli_emu(emu_lib):
+    import __graft_entry__ as ge
+    return ge.build_host_emu()
+
+
+@pytest.fixture(scope='session')
+def cli_gpu(gpu_lib):
+    import __graft_entry__ as ge
+    return ge.build_host()
+
+
+def _run(cli, args, stdin=None):
+    p = subprocess.run([cli] + args, input=stdin, capture_output=True)
+    return p.returncode, p.stdout, p.stderr
+
+
+def _sentences(out):
+    """split JUMAN output into per-sentence blocks (each ends with EOS)"""
+    blocks, cur = [], []
+    for line in out.split(b'\n'):
+        cur.append(line)
+        if line == b'EOS':
+            blocks.append(cur)
+            cur = []
+    return blocks
+
+
+def _assert_juman_equal_up_to_ties(ours, ref, gold):
+    """With the RNN scorer, float noise (1e-4 contract) may flip the order of EOS-beam paths whose
+    reference totals tie; such a sentence may differ, any other one must be byte-identical."""
+    bo, br = _sentences(ours), _sentences(ref)
+    assert len(bo) == len(br)
+    flips = 0
+    for s, (a, b) in enumerate(zip(bo, br)):
+        if a == b:
+            continue
+        g = gold[s]
+        eos = g.bnds[len(g.bnds) - 1]['nodes'][0]['beam']
+        tot = [float(x['total']) for x in eos if x['valid']]
+        assert len(tot) > 1 and abs(tot[0] - tot[1]) <= 1e-4 * max(1.0, abs(tot[0])), (s, a, b)
+        flips += 1
+    return flips
+
+
+def test_juman_format_byte_identical_to_reference_cli(cli_emu, golden_dir):
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.img'), os.path.join(golden_dir, 'mini.txt')])
+    assert rc == 0, err
+    ref = open(os.path.join(golden_dir, 'mini.juman.txt'), 'rb').read()
+    assert out == ref
+
+
+def test_juman_format_with_rnn(cli_emu, golden_dir):
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini_rnn.img'), os.path.join(golden_dir, 'mini.txt')])
+    assert rc == 0, err
+    ref = open(os.path.join(golden_dir, 'mini_rnn.juman.txt'), 'rb').read()
+    meta, gold = G.read_gold(os.path.join(golden_dir, 'mini_rnn.gold'))
+    flips = _assert_juman_equal_up_to_ties(out, ref, gold)
+    assert flips <= 3
+    # the perceptron-only run of the same model must not use the RNN and equals the plain model's output
+    rc, out2, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini_rnn.img'), '--no-rnn',
+                                   os.path.join(golden_dir, 'mini.txt')])
+    assert rc == 0 and out2 == open(os.path.join(golden_dir, 'mini.juman.txt'), 'rb').read()
+
+
+def test_cli_comments_errors_and_batching_like_reference(cli_emu, golden_dir, ref_tools, tmp_path):
+    """comment lines, an over-long line, invalid UTF-8, empty lines, stdin input, tiny batches:
+    stdout must equal the reference CLI's on the same bytes (the model comes from the goldens' recipe)."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 12, 14, 11, length=30)
+    text = []
+    for i, l in enumerate(lines):
+        if i % 3 == 0:
+            text.append('# S-ID:%d comment text' % i)
+        text.append(l)
+    data = ('\n'.join(text) + '\n').encode('utf-8')
+    data += b'# only a comment before a bad line\n\xe3\x81\n' + ('あ' * 1400).encode('utf-8') + b'\n\n' \
+        + 'x\ty z　全角\n'.encode('utf-8') + '# trailing comment\n最後の行に改行なし'.encode('utf-8')
+    ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + os.path.join(tmp, 'w.model')],
+                         input=data, capture_output=True)
+    for batch in ('1', '5', '65536'):
+        rc, out, err = _run(cli_emu, ['--model=' + img, '--batch=' + batch], stdin=data)
+        assert out == ref.stdout, (batch, err[-300:])
+        assert rc == ref.returncode
+
+
+def test_gpu_analyzer_initialize_validates_like_the_reference(cli_emu, golden_dir):
+    # unknown model file / missing model option: the CLI's own messages
+    rc, out, err = _run(cli_emu, [])
+    assert rc == 1 and b'Model file was not specified' in err
+    rc, out, err = _run(cli_emu, ['--model=/nonexistent.img'])
+    assert rc == 1 and b'failed to load model from disk' in err
+    # global beam larger than the beam allows (AnalyzerImpl::initScorers) is rejected at initialize
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.img'), '--beam=40'], stdin=b'')
+    assert rc == 1 and b'failed to initialize the analyzer' in err
+
+
+@pytest.mark.gpu
+def test_gpu_cli_byte_identical_on_fresh_workload(cli_gpu, ref_tools, tmp_path):
+    """2000 fresh sentences through the shipped jumanpp_gpu on the MI355X vs jumanpp_v2 on the host CPU."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 30000, 2000, 20, 321)
+    ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + os.path.join(tmp, 'w.model'),
+                          os.path.join(tmp, 'w.txt')], capture_output=True)
+    rc, out, err = _run(cli_gpu, ['--model=' + img, os.path.join(tmp, 'w.txt')])
+    assert rc == 0, err[-500:]
+    assert out == ref.stdout
+    rc, out, err = _run(cli_gpu, ['--model=' + img, '--batch=300', os.path.join(tmp, 'w.txt')])
+    assert out == ref.stdout
+
+
+@pytest.mark.gpu
+def test_gpu_cli_with_rnn_on_fresh_workload(cli_gpu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 30000, 600, 20, 77, rnn=(128, 8000))
+    ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + os.path.join(tmp, 'w.model'),
+                          os.path.join(tmp, 'w.txt')], capture_output=True)
+    rc, out, err = _run(cli_gpu, ['--model=' + img, os.path.join(tmp, 'w.txt')])
+    assert rc == 0, err[-500:]
+    meta, gold = G.read_gold(gold_path)
+    flips = _assert_juman_equal_up_to_ties(out, ref.stdout, gold)
+    assert flips <= 0.05 * len(lines)
