@@ -38,6 +38,8 @@ inline StringPiece escapeForJumanOutput(StringPiece in) {
 
 inline StringPiece ifEmpty(StringPiece s, StringPiece dflt) { return s.empty() ? dflt : s; }
 
+}  // namespace
+
 // formatNormalizedFeature (juman_format.cc:57-92); ExistFlag = any common bit (charlattice.h:55-57)
 void formatNormalizedFeature(std::string& p, int32_t v) {
   put(p, "非標準表記:");
@@ -52,8 +54,6 @@ void formatNormalizedFeature(std::string& p, int32_t v) {
   if (has(M_DELETE_HASTSUON)) p += 'H';
   if (has(M_DELETE_LAST)) p += 'L';
 }
-
-}  // namespace
 
 Status JumanFormat::initialize(const ModelImage* model) {
   model_ = model;

@@ -16,6 +16,7 @@
 
 #include "gpu_analyzer.h"
 #include "juman_format.h"
+#include "lattice_format.h"
 
 using namespace jumanpp_amd;
 
@@ -30,6 +31,7 @@ struct Conf {
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
+  int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
 };
 
 bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
@@ -42,6 +44,10 @@ bool argValue(int argc, const char** argv, int& i, const char* name, std::string
   }
   if (a[n] == 0 && i + 1 < argc) {
     *out = argv[++i];
+    return true;
+  }
+  if (n == 2 && a[n] != 0) {  // -s5
+    *out = a + n;
     return true;
   }
   return false;
@@ -67,6 +73,8 @@ int main(int argc, const char** argv) {
     else if (argValue(argc, argv, i, "--batch", &v)) conf.batch = (size_t)std::atoll(v.c_str());
     else if (argValue(argc, argv, i, "--device", &v)) conf.device = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--output", &v) || argValue(argc, argv, i, "-o", &v)) conf.output = v;
+    else if (argValue(argc, argv, i, "--lattice", &v) || argValue(argc, argv, i, "--specifics", &v) ||
+             argValue(argc, argv, i, "-s", &v) || argValue(argc, argv, i, "-L", &v)) conf.lattice = std::atoi(v.c_str());
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -106,8 +114,12 @@ int main(int argc, const char** argv) {
     std::cerr << "failed to initialize the analyzer: " << s << "\n";
     return 1;
   }
+  // JumanppExec::initOutput (jumandic_env.cc:55-150): Juman by default, Lattice for -s N
   JumanFormat format;
-  s = format.initialize(&model);
+  int latticeN = conf.lattice == -1 ? conf.beam : conf.lattice;
+  LatticeFormat latticeFormat(latticeN);
+  const bool useLattice = conf.lattice != 0;
+  s = useLattice ? latticeFormat.initialize(&model, def.scoreWeights) : format.initialize(&model);
   if (!s) {
     std::cerr << "Failed to initialize I/O: " << s << "\n";
     return 1;
@@ -148,7 +160,7 @@ int main(int argc, const char** argv) {
   auto flush = [&]() {
     pieces.clear();
     for (auto& e : batch) pieces.push_back(e.readStatus.isOk() ? StringPiece(e.input) : StringPiece(""));
-    Status bs = analyzer.analyzeBatch(pieces);
+    Status bs = analyzer.analyzeBatch(pieces, useLattice);
     if (conf.timing) {
       float ms[8];
       analyzer.lastTimings(ms);
@@ -168,9 +180,9 @@ int main(int argc, const char** argv) {
         continue;
       }
       StringPiece comment = batch[i].comment.size() < 2 ? StringPiece("") : StringPiece(batch[i].comment.data() + 2, batch[i].comment.size() - 2);
-      st = format.format(analyzer, i, comment);
+      st = useLattice ? latticeFormat.format(analyzer, i, comment) : format.format(analyzer, i, comment);
       if (!st) std::cerr << st;
-      else *out << format.result();
+      else *out << (useLattice ? latticeFormat.result() : format.result());
     }
     sentences += batch.size();
     batch.clear();

@@ -1,0 +1,43 @@
+// Lattice output format (`-s N` / `--lattice N`): the N best paths as a graph of
+// morphemes, byte-for-byte what jumandic::output::LatticeFormat prints
+// (src/jumandic/shared/lattice_format.{h,cc}).  Needs the full lattice view
+// (beams + score cells), i.e. GpuAnalyzer::analyzeBatch(inputs, /*fullLattice=*/true).
+#ifndef JUMANPP_AMD_HOST_LATTICE_FORMAT_H
+#define JUMANPP_AMD_HOST_LATTICE_FORMAT_H
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "juman_format.h"
+
+namespace jumanpp_amd {
+
+class LatticeFormat {
+  // LatticeNodeInfo (lattice_format.h:17-25) keyed by sentence-local node id, which is already
+  // ordered by (boundary, position) like publishResult's sort
+  struct NodeInfo {
+    std::vector<uint16_t> ranks;
+    std::vector<uint32_t> prev;    // distinct previous lattice nodes
+    std::vector<uint32_t> slots;   // distinct beam slots of this node = the ConnectionPtr set
+    int32_t id = 0;
+  };
+  const ModelImage* model_ = nullptr;
+  JumandicFields flds_;
+  std::string printer_;
+  NodeWalker walker_;
+  std::map<uint32_t, NodeInfo> info_;
+  int32_t topN_ = 1;
+  std::vector<float> weights_;
+
+ public:
+  explicit LatticeFormat(int32_t topN) : topN_(topN) {}
+  // scoreWeights = ScorerDef::scoreWeights of the analyzer (lattice_format.cc:127)
+  Status initialize(const ModelImage* model, const std::vector<float>& scoreWeights);
+  Status format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment);
+  StringPiece result() const { return StringPiece(printer_); }
+};
+
+}  // namespace jumanpp_amd
+
+#endif  // JUMANPP_AMD_HOST_LATTICE_FORMAT_H

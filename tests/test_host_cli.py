@@ -145,3 +145,100 @@ def test_gpu_cli_with_rnn_on_fresh_workload(cli_gpu, ref_tools, tmp_path):
     meta, gold = G.read_gold(gold_path)
     flips = _assert_juman_equal_up_to_ties(out, ref.stdout, gold)
     assert flips <= 0.05 * len(lines)
+
+
+# ---- lattice format (-s N): src/jumandic/shared/lattice_format.cc ----
+
+def _ref_cli(ref_tools, model, args, path):
+    return subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + model] + args + [path],
+                          capture_output=True).stdout
+
+
+def _lattice_lines_equal_up_to_float_noise(ours, ref, gold, beam_n):
+    """RNN runs: the structure must be identical; printed scores may differ in the last printed digit
+    (1e-4 contract), and a sentence whose N best reference totals contain a near tie may rank differently."""
+    import re
+    bo, br = _sentences(ours), _sentences(ref)
+    assert len(bo) == len(br)
+    num = re.compile('(スコア:|rank\\d+:)(-?[0-9.e+-]+)'.encode('utf-8'))
+    skipped = 0
+    for s, (a, b) in enumerate(zip(bo, br)):
+        if a == b:
+            continue
+        g = gold[s]
+        eos = g.bnds[len(g.bnds) - 1]['nodes'][0]['beam']
+        tot = [float(x['total']) for x in eos if x['valid']][:beam_n + 1]
+        near_tie = any(abs(tot[i] - tot[i + 1]) <= 1e-4 * max(1.0, abs(tot[i])) for i in range(len(tot) - 1))
+        if near_tie:
+            skipped += 1
+            continue
+        assert len(a) == len(b), s
+        for la, lb in zip(a, b):
+            if la == lb:
+                continue
+            assert num.sub(b'\\1#', la) == num.sub(b'\\1#', lb), (s, la, lb)
+            for (_, x), (_, y) in zip(num.findall(la), num.findall(lb)):
+                assert abs(float(x) - float(y)) <= 2e-4 * max(1.0, abs(float(y))), (s, la, lb)
+    return skipped
+
+
+def test_lattice_format_byte_identical_to_reference_cli(cli_emu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 16, 14, 23, length=36)
+    with open(os.path.join(tmp, 'w.txt'), 'ab') as f:
+        f.write('\n# a comment replaces the MA-SCORE line\nすごーーい〜かぁっこいいねぇっッ！\nx\ty\n'.encode('utf-8'))
+    for n in ('1', '5'):
+        ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['-s', n], os.path.join(tmp, 'w.txt'))
+        rc, out, err = _run(cli_emu, ['--model=' + img, '-s', n, os.path.join(tmp, 'w.txt')])
+        assert rc == 0, err[-300:]
+        assert out == ref, n
+
+
+def test_lattice_format_with_rnn(cli_emu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, 12, 14, 29, length=30, rnn=(32, 600))
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['-s', '3'], os.path.join(tmp, 'w.txt'))
+    rc, out, err = _run(cli_emu, ['--model=' + img, '-s', '3', os.path.join(tmp, 'w.txt')])
+    assert rc == 0, err[-300:]
+    meta, gold = G.read_gold(gold_path)
+    skipped = _lattice_lines_equal_up_to_float_noise(out, ref, gold, 3)
+    assert skipped <= len(lines) // 2
+
+
+@pytest.mark.gpu
+def test_gpu_config5_lattice_output_beam32_long_sentences(cli_gpu, ref_tools, tmp_path):
+    """BASELINE configs[4] shape without the RNN: beam 32, >= 200 codepoints, `-s 32`: byte-identical."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 8000, 60, 18, 131, length=210)
+    flags = ['--beam=32', '--global-beam=32', '--right-check=1', '--right-beam=32', '-s', '32']
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt'))
+    rc, out, err = _run(cli_gpu, ['--model=' + img] + flags + [os.path.join(tmp, 'w.txt')])
+    assert rc == 0, err[-300:]
+    assert out == ref
+
+
+@pytest.mark.gpu
+def test_gpu_config5_lattice_output_with_rnn(cli_gpu, ref_tools, tmp_path):
+    """BASELINE configs[4]: beam 32, long sentences, RNNLM on, lattice-format output."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 8000, 40, 18, 137, length=210, rnn=(128, 5000),
+                                               beams=[32, 32, 1, 32])
+    flags = ['--beam=32', '--global-beam=32', '--right-check=1', '--right-beam=32', '-s', '8']
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt'))
+    rc, out, err = _run(cli_gpu, ['--model=' + img] + flags + [os.path.join(tmp, 'w.txt')])
+    assert rc == 0, err[-300:]
+    meta, gold = G.read_gold(gold_path)
+    skipped = _lattice_lines_equal_up_to_float_noise(out, ref, gold, 8)
+    assert skipped <= len(lines) // 2
