@@ -50,6 +50,38 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// Asynchronous global -> LDS copy (gfx950 `global_load_lds_dword` / `_dwordx4`): every lane for which
+// `act` holds copies BYTES (4 or 16) from its own global address to lds_base + lane * BYTES without
+// passing through VGPRs.  lds_base must be wave-uniform.  The data is visible after lds_async_wait()
+// (a workgroup barrier of a single-wavefront workgroup does not imply the vmcnt wait).
+template <int BYTES>
+__device__ __forceinline__ void lds_async_load(void* lds_base, const void* gptr, bool act) {
+  static_assert(BYTES == 4 || BYTES == 16, "global_load_lds moves a dword or four dwords per lane");
+#if defined(JPP_EMU)
+  if (act) __builtin_memcpy(static_cast<char*>(lds_base) + (size_t)lane_id() * BYTES, gptr, BYTES);
+#else
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (act) {
+    auto g = (const void __attribute__((address_space(1)))*)gptr;
+    auto l = (void __attribute__((address_space(3)))*)lds_base;
+    if constexpr (BYTES == 16) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+  }
+#else
+  (void)lds_base; (void)gptr; (void)act;
+#endif
+#endif
+}
+
+// wait until every lds_async_load of this wavefront has landed in LDS
+__device__ __forceinline__ void lds_async_wait() {
+#if !defined(JPP_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  asm volatile("" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ u64 wave_ballot(bool p) {
 #if defined(JPP_EMU)
   return hip_emu::ballot(p);

@@ -34,6 +34,14 @@ enum SentStatus : i32 {
 // UNK maker kinds: spec::UnkMakerType (reference src/core/spec/spec_types.h)
 enum UnkType : i32 { UNK_SINGLE = 1, UNK_CHUNKING = 2, UNK_ONOMATOPOEIA = 3, UNK_NUMERIC = 4, UNK_NORMALIZE = 5 };
 
+// the four per-boundary layout words k_sweep needs, in one 16-byte record
+struct alignas(16) BndMeta {
+  u32 first;   // first node starting at the boundary
+  u32 cnt;     // R_b
+  u32 efirst;  // offset of the ends list
+  u32 ecnt;    // L_b
+};
+
 struct UnkMaker {
   i32 type;
   i32 char_class;
@@ -189,6 +197,7 @@ struct Batch {
   float* rnn_ctx;          // [bb][gbeam][EP] hidden state after each rnn node
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]
+  BndMeta* bnd_meta;       // [bb] {bnd_first, bnd_cnt, end_first, end_cnt} packed for k_sweep (written by k_ends)
   u32* bnd_ngb;            // [bb]
   // result
   u32* path_len;           // [n]

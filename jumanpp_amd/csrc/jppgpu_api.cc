@@ -77,7 +77,15 @@ struct Timer {
       for (auto& e : ev) (void)hipEventDestroy(e);
     have = false;
   }
-  void mark(int i, jpp_stream_t s) { (void)hipEventRecord(ev[i], s); }
+  void mark(int i, jpp_stream_t s) {
+    // JPPGPU_DEBUG_SYNC=1: synchronise after every phase and say which one finished (fault triage)
+    static const bool dbg = std::getenv("JPPGPU_DEBUG_SYNC") != nullptr;
+    if (dbg) {
+      hipError_t e = hipStreamSynchronize(s);
+      std::fprintf(stderr, "[jppgpu] phase mark %d reached: %s\n", i, hipGetErrorString(e));
+    }
+    (void)hipEventRecord(ev[i], s);
+  }
   void collect(float* ms) {
     // ev[0]..ev[7] bracket the seven phases
     for (int i = 0; i < 7; ++i) {
@@ -157,7 +165,7 @@ struct jppgpu_ctx {
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
-  DevBuf path_len;
+  DevBuf path_len, bnd_meta;
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
   DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
       path_nodes;
@@ -367,7 +375,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,
-                    &ctx->gstats};
+                    &ctx->gstats,     &ctx->bnd_meta};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   ctx->timer.destroy();
@@ -390,7 +398,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
             ctx->sent_nodes2.ensure((n + 1) * 4) && ctx->node_base.ensure((n + 2) * 8) &&
             ctx->node_base2.ensure((n + 2) * 8) && ctx->path_len.ensure((n + 1) * 4) &&
             ctx->bnd_first.ensure(bbN * 4) && ctx->bnd_cnt.ensure(bbN * 4) && ctx->end_first.ensure(bbN * 4) &&
-            ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) &&
+            ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) && ctx->bnd_meta.ensure(bbN * sizeof(BndMeta)) &&
             ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry)) &&
             (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) &&
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
@@ -429,6 +437,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.bnd_first = ctx->bnd_first.as<u32>();
   B.bnd_cnt = ctx->bnd_cnt.as<u32>();
   B.end_first = ctx->end_first.as<u32>();
+  B.bnd_meta = ctx->bnd_meta.as<BndMeta>();
   B.end_cnt = ctx->end_cnt.as<u32>();
   B.bnd_ngb = ctx->bnd_ngb.as<u32>();
   B.bnd_gbeam = ctx->bnd_gbeam.as<GbeamEntry>();
@@ -449,13 +458,14 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
 
   const u32 sblocks = (n + 255) / 256;
+  const u32 wblocks = (n + kLatWaves - 1) / kLatWaves;
   Timer& T = ctx->timer;
   T.mark(0, st);
   JPP_LAUNCH(k_decode, sblocks, 256, st, B, ctx->cfg);
   T.mark(1, st);
   JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_norm<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  JPP_LAUNCH(k_layout<1>, sblocks, 256, st, B);
+  JPP_LAUNCH(k_layout<1>, wblocks, 64 * kLatWaves, st, B);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
   u64 totals[2] = {0, 0};
@@ -470,14 +480,14 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.node_aux = ctx->node_aux.as<NodeAux>();
   JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_norm<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  JPP_LAUNCH(k_connect<1>, sblocks, 256, st, B);
+  JPP_LAUNCH(k_connect<1>, wblocks, 64 * kLatWaves, st, B);
   // stage 2 for disconnected sentences: relocate them behind the stage-1 region
-  JPP_LAUNCH(k_layout<2>, sblocks, 256, st, B);
+  JPP_LAUNCH(k_layout<2>, wblocks, 64 * kLatWaves, st, B);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
   JPP_LAUNCH(k_relocate, sblocks, 256, st, B);
   JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  JPP_LAUNCH(k_connect<2>, sblocks, 256, st, B);
+  JPP_LAUNCH(k_connect<2>, wblocks, 64 * kLatWaves, st, B);
   u64 totalNodes = 0;
   u32 gstats[4] = {0, 0, 0, 0};
   rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
@@ -500,7 +510,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.node_kept = ctx->node_kept.as<u8>();
   B.path_nodes = ctx->path_nodes.as<u32>();
   T.mark(2, st);
-  JPP_LAUNCH(k_ends, sblocks, 256, st, B, ctx->cfg);
+  JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg);
   T.mark(3, st);
   JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
   T.mark(4, st);
@@ -549,6 +559,24 @@ extern "C" int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uin
   rt_sync(nullptr);
   return jppgpu_analyze_batch_device(ctx, ctx->text.p, ctx->offs.p, n, total, nullptr, out);
 }
+
+#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
+extern "C" int jppgpu_debug_sweep_dbg(unsigned long long* out16) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(jpp::g_sweep_dbg), 16 * sizeof(unsigned long long));
+  return 0;
+}
+#endif
+#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
+// developer build only: cycles per k_sweep phase accumulated since the last call (then reset)
+extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(jpp::g_sweep_prof), 16 * sizeof(unsigned long long));
+  unsigned long long z[16] = {};
+  hipMemcpyToSymbol(HIP_SYMBOL(jpp::g_sweep_prof), z, sizeof(z));
+  return 0;
+}
+#endif
 
 extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
   if (!ctx || !ms) return fail(JPPGPU_INVALID_PARAMETER, "null argument");

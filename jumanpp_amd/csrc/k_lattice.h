@@ -1,6 +1,5 @@
-// Kernels 3: lattice layout.  All are one lane per sentence: they are short
-// sequential passes over ~C positions / ~N nodes, and 64k sentences keep the
-// chip busy.
+// Kernels 3: lattice layout: short passes over ~C positions / ~N nodes, one wavefront per sentence
+// (lane per position / per boundary, prefix sums by wave scan).
 //
 // Reference behaviour reproduced:
 //   LatticeBuilder::prepare            src/core/analysis/lattice_builder.cc:16-39
@@ -14,39 +13,68 @@
 
 namespace jpp {
 
+constexpr int kLatWaves = 4;  // sentences (wavefronts) per workgroup of the wave-per-sentence kernels below
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ u32 wave_scan_incl_u32(u32 v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 o = wave_shfl_u32(v, lane >= d ? lane - d : lane);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
 // STAGE 1: layout with dic + stage-1 makers.  STAGE 2: (flagged sentences only) all makers.
+// One wavefront per sentence, one lane per start position.
 template <int STAGE>
-__global__ void k_layout(Batch B) {
-  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64 * kLatWaves) k_layout(Batch B) {
+  const int lane = (int)(threadIdx.x & 63);
+  const u32 s = blockIdx.x * kLatWaves + (threadIdx.x >> 6);
   if (s >= B.n_sent) return;
   if (STAGE == 2 && (B.sent_status[s] != ST_OK || (B.sent_flags[s] & 2) == 0)) {
-    B.sent_nodes2[s] = 0;
+    if (lane == 0) B.sent_nodes2[s] = 0;
     return;
   }
-  u32 off = B.byte_off[s];
-  u32 g0 = off + s;
-  u32 bb0 = off + 4 * s;
-  u32 n = B.sent_status[s] == ST_OK ? B.sent_ncp[s] : 0;
+  const u32 off = B.byte_off[s];
+  const u32 g0 = off + s;
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_status[s] == ST_OK ? B.sent_ncp[s] : 0;
   // local node ids: 0,1 = BOS; boundary b = i + 2 starts at position i
-  B.bnd_first[bb0 + 0] = 0;
-  B.bnd_cnt[bb0 + 0] = 1;
-  B.bnd_first[bb0 + 1] = 1;
-  B.bnd_cnt[bb0 + 1] = 1;
+  if (lane < 2) {
+    B.bnd_first[bb0 + lane] = (u32)lane;
+    B.bnd_cnt[bb0 + lane] = 1;
+  }
   u32 next = 2;
   u32 sum2 = 0;
   u32 maxR = 0;
   bool overflow = false;
-  for (u32 i = 0; i < n; ++i) {
-    u32 c = (u32)B.pos_cnt1[g0 + i] + B.pos_cntN[g0 + i];
-    if (B.pos_cnt1[g0 + i] == 0xffff) overflow = true;
-    sum2 += B.pos_cnt2[g0 + i];
-    if (STAGE == 2) c += B.pos_cnt2[g0 + i];
-    B.bnd_first[bb0 + i + 2] = next;
-    B.bnd_cnt[bb0 + i + 2] = c;
-    next += c;
-    if (c > maxR) maxR = c;
+  for (u32 i0 = 0; i0 < n; i0 += 64) {
+    const u32 i = i0 + (u32)lane;
+    u32 c = 0, c2 = 0;
+    bool ovf = false;
+    if (i < n) {
+      u32 c1 = B.pos_cnt1[g0 + i];
+      c = c1 + B.pos_cntN[g0 + i];
+      ovf = c1 == 0xffff;
+      c2 = B.pos_cnt2[g0 + i];
+      if (STAGE == 2) c += c2;
+    }
+    const u32 incl = wave_scan_incl_u32(c, lane);
+    if (i < n) {
+      B.bnd_first[bb0 + i + 2] = next + incl - c;
+      B.bnd_cnt[bb0 + i + 2] = c;
+    }
+    next += wave_shfl_u32(incl, 63);
+    sum2 += wave_sum_u32(c2);
+    const u32 m = wave_max_u32(c);
+    if (m > maxR) maxR = m;
+    overflow = overflow || wave_ballot(ovf) != 0;
   }
-  if (maxR > 0) atomicMax(&B.gstats[0], maxR);
+  if (lane != 0) return;
+  // one atomic per sentence would serialise 64k updates of one address: skip it when the published
+  // maximum (monotonic, possibly stale) already covers this sentence
+  if (maxR > B.gstats[0]) atomicMax(&B.gstats[0], maxR);
   // EOS boundary
   B.bnd_first[bb0 + n + 2] = next;
   B.bnd_cnt[bb0 + n + 2] = 1;
@@ -70,23 +98,42 @@ __global__ void k_scan(const u32* in, u64* out, u32 n, const u64* base_ptr) {
   u32 lo = t * per;
   u32 hi = lo + per < n ? lo + per : n;
   u64 sum = 0;
-  for (u32 i = lo; i < hi; ++i) sum += in[i];
-  part[t] = sum;
-  __syncthreads();
-  if (t == 0) {
-    u64 acc = base_ptr ? *base_ptr : 0;
-    for (u32 k = 0; k < nt; ++k) {
-      u64 v = part[k];
-      part[k] = acc;
-      acc += v;
-    }
-    out[n] = acc;
+  for (u32 i = lo; i < hi; i += 8) {  // 8 independent loads in flight per lane
+    u32 v[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) v[q] = (i + q < hi) ? in[i + q] : 0u;
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) sum += v[q];
   }
+  // exclusive scan of the per-thread sums: wave scan + scan of the (<= 16) wave totals
+  const int lane = (int)(t & 63);
+  u64 incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u64 o = wave_shfl_u64(incl, lane >= d ? lane - d : lane);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) part[t >> 6] = incl;
   __syncthreads();
-  u64 acc = part[t];
-  for (u32 i = lo; i < hi; ++i) {
-    out[i] = acc;
-    acc += in[i];
+  u64 wbase = base_ptr ? *base_ptr : 0;
+  const u32 nw = (nt + 63) / 64;
+  u64 all = wbase;
+  for (u32 k = 0; k < nw; ++k) {
+    u64 v = part[k];
+    if (k < (t >> 6)) wbase += v;
+    all += v;
+  }
+  if (t == 0) out[n] = all;
+  u64 acc = wbase + incl - sum;
+  for (u32 i = lo; i < hi; i += 8) {
+    u32 v[8];
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) v[q] = (i + q < hi) ? in[i + q] : 0u;
+#pragma unroll
+    for (u32 q = 0; q < 8; ++q) {
+      if (i + q < hi) out[i + q] = acc;
+      acc += v[q];
+    }
   }
 }
 
@@ -102,88 +149,173 @@ __global__ void k_relocate(Batch B) {
 
 // reachability of the end of input through the emitted nodes.
 // PASS 1: sets the stage-2 flag; PASS 2: (flagged only) final verdict.
+// One wavefront per sentence.  Up to 63 codepoints the reachable set is one u64: lane i builds the mask
+// of the ends of the nodes starting at i, then the positions are swept in order.  Longer sentences run the
+// plain sequential pass on lane 0.
 template <int PASS>
-__global__ void k_connect(Batch B) {
-  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64 * kLatWaves) k_connect(Batch B) {
+  const int lane = (int)(threadIdx.x & 63);
+  const u32 s = blockIdx.x * kLatWaves + (threadIdx.x >> 6);
   if (s >= B.n_sent) return;
   if (B.sent_status[s] != ST_OK) return;
   if (PASS == 2 && (B.sent_flags[s] & 2) == 0) return;
-  u32 off = B.byte_off[s];
-  u32 g0 = off + s;
-  u32 bb0 = off + 4 * s;
-  u32 n = B.sent_ncp[s];
-  u8* reach = B.reach + g0;  // n + 1 entries
-  for (u32 i = 0; i <= n; ++i) reach[i] = 0;
-  reach[0] = 1;
+  const u32 off = B.byte_off[s];
+  const u32 g0 = off + s;
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_ncp[s];
   const NodeInfo* ni = B.node_info + B.node_base[s];
-  for (u32 i = 0; i < n; ++i) {
-    if (!reach[i]) continue;
-    u32 first = B.bnd_first[bb0 + i + 2];
-    u32 cnt = B.bnd_cnt[bb0 + i + 2];
-    for (u32 k = 0; k < cnt; ++k) reach[ni[first + k].end] = 1;
+  bool ok;
+  if (n <= 63) {
+    u64 mask = 0;
+    if ((u32)lane < n) {
+      const u32 first = B.bnd_first[bb0 + lane + 2];
+      const u32 cnt = B.bnd_cnt[bb0 + lane + 2];
+      for (u32 k = 0; k < cnt; k += 4) {
+        u16 e[4];
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) e[q] = (k + q < cnt) ? ni[first + k + q].end : (u16)0;
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q)
+          if (k + q < cnt) mask |= u64{1} << e[q];
+      }
+    }
+    u64 reach = 1;
+    for (u32 i = 0; i < n; ++i) {
+      u64 m = wave_shfl_u64(mask, (int)i);
+      if ((reach >> i) & 1) reach |= m;
+    }
+    ok = ((reach >> n) & 1) != 0;
+  } else {
+    if (lane != 0) return;
+    u8* reach = B.reach + g0;  // n + 1 entries
+    for (u32 i = 0; i <= n; ++i) reach[i] = 0;
+    reach[0] = 1;
+    for (u32 i = 0; i < n; ++i) {
+      if (!reach[i]) continue;
+      u32 first = B.bnd_first[bb0 + i + 2];
+      u32 cnt = B.bnd_cnt[bb0 + i + 2];
+      for (u32 k = 0; k < cnt; ++k) reach[ni[first + k].end] = 1;
+    }
+    ok = reach[n] != 0;
   }
-  if (!reach[n]) {
+  if (!ok && lane == 0) {
     if (PASS == 1) B.sent_flags[s] |= 2;
     else B.sent_status[s] = ST_NO_LATTICE;
   }
 }
 
-// BOS/EOS nodes, UNK entry pointers, ends lists.
-__global__ void k_ends(Batch B, Config cfg) {
-  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+// BOS/EOS nodes, UNK entry pointers, ends lists.  One wavefront per sentence: the node ends are staged
+// in LDS, then one lane per boundary collects the nodes ending there in node order (= seed order,
+// LatticeBuilder::fillEnds).  Sentences with more than kEndsNodeCap nodes run sequentially on lane 0.
+constexpr u32 kEndsNodeCap = 2048;
+
+__global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int wv = (int)(threadIdx.x >> 6);
+  const u32 s = blockIdx.x * kLatWaves + wv;
   if (s >= B.n_sent) return;
   if (B.sent_status[s] != ST_OK) return;
-  u32 off = B.byte_off[s];
-  u32 bb0 = off + 4 * s;
-  u32 n = B.sent_ncp[s];
-  u32 N = B.sent_nodes[s];
-  u64 nb = B.node_base[s];
+  const u32 off = B.byte_off[s];
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_ncp[s];
+  const u32 N = B.sent_nodes[s];
+  const u64 nb = B.node_base[s];
   NodeInfo* ni = B.node_info + nb;
   NodeAux* na = B.node_aux + nb;
-  ni[0] = NodeInfo{kEptrBOS, 0, 0};
-  ni[1] = NodeInfo{kEptrBOS, 0, 0};
-  ni[N - 1] = NodeInfo{kEptrEOS, (u16)n, (u16)n};
-  na[0] = na[1] = na[N - 1] = NodeAux{0, 0, 0, 0, 0, 0};
-  // per-boundary end counts
   u32* ecnt = B.end_cnt + bb0;
   u32* efirst = B.end_first + bb0;
-  for (u32 b = 0; b <= n + 2; ++b) ecnt[b] = 0;
-  ecnt[1] = 1;
-  ecnt[2] = 1;
-  i32 unk = 0;
-  for (u32 k = 2; k + 1 < N; ++k) {
-    NodeInfo x = ni[k];
-    if (x.eptr < 0) {
-      x.eptr = ~unk;
-      ++unk;
-      ni[k] = x;
-    }
-    ecnt[x.end + 2] += 1;
-  }
-  u32 acc = 0;
-  for (u32 b = 0; b <= n + 2; ++b) {
-    efirst[b] = acc;
-    acc += ecnt[b];
-    ecnt[b] = 0;
-  }
   u32* en = B.end_nodes + nb;
-  en[efirst[1] + ecnt[1]++] = 0;
-  en[efirst[2] + ecnt[2]++] = 1;
-  for (u32 k = 2; k + 1 < N; ++k) {
-    u32 b = (u32)ni[k].end + 2;
-    en[efirst[b] + ecnt[b]++] = k;
+  __shared__ u16 l_end_all[kLatWaves][kEndsNodeCap];
+  u16* l_end = l_end_all[wv];
+  if (lane == 0) {
+    ni[0] = NodeInfo{kEptrBOS, 0, 0};
+    ni[1] = NodeInfo{kEptrBOS, 0, 0};
+    ni[N - 1] = NodeInfo{kEptrEOS, (u16)n, (u16)n};
+    na[0] = na[1] = na[N - 1] = NodeAux{0, 0, 0, 0, 0, 0};
+  }
+  if (N <= kEndsNodeCap) {
+    // UNK entry pointers ~0, ~1, ... in node order; stage the ends
+    u32 unkBase = 0;
+    for (u32 k0 = 2; k0 + 1 < N; k0 += 64) {
+      const u32 k = k0 + (u32)lane;
+      const bool act = k + 1 < N;
+      NodeInfo x = act ? ni[k] : NodeInfo{0, 0, 0};
+      const bool isUnk = act && x.eptr < 0;
+      const u64 bal = wave_ballot(isUnk);
+      if (isUnk) {
+        x.eptr = ~(i32)(unkBase + (u32)popc64(bal & ((u64{1} << lane) - 1)));
+        ni[k] = x;
+      }
+      unkBase += (u32)popc64(bal);
+      if (act) l_end[k] = x.end;
+    }
+    wave_sync();
+    // lane per boundary: count, scan, fill
+    u32 carry = 0;
+    for (u32 b0 = 0; b0 <= n + 2; b0 += 64) {
+      const u32 b = b0 + (u32)lane;
+      const bool act = b <= n + 2;
+      u32 cnt = (act && (b == 1 || b == 2)) ? 1u : 0u;  // the two BOS nodes end at boundaries 1 and 2
+      if (act && b >= 2) {
+        const u32 want = b - 2;
+        for (u32 k = 2; k + 1 < N; ++k) cnt += (l_end[k] == want) ? 1u : 0u;
+      }
+      const u32 incl = wave_scan_incl_u32(cnt, lane);
+      const u32 first = carry + incl - cnt;
+      carry += wave_shfl_u32(incl, 63);
+      if (act) {
+        ecnt[b] = cnt;
+        efirst[b] = first;
+        B.bnd_meta[bb0 + b] = BndMeta{B.bnd_first[bb0 + b], B.bnd_cnt[bb0 + b], first, cnt};
+        u32 w = first;
+        if (b == 1) en[w++] = 0;
+        if (b == 2) en[w++] = 1;
+        if (b >= 2) {
+          const u32 want = b - 2;
+          for (u32 k = 2; k + 1 < N; ++k)
+            if (l_end[k] == want) en[w++] = k;
+        }
+      }
+    }
+  } else if (lane == 0) {
+    for (u32 b = 0; b <= n + 2; ++b) ecnt[b] = 0;
+    ecnt[1] = 1;
+    ecnt[2] = 1;
+    i32 unk = 0;
+    for (u32 k = 2; k + 1 < N; ++k) {
+      NodeInfo x = ni[k];
+      if (x.eptr < 0) {
+        x.eptr = ~unk;
+        ++unk;
+        ni[k] = x;
+      }
+      ecnt[x.end + 2] += 1;
+    }
+    u32 acc = 0;
+    for (u32 b = 0; b <= n + 2; ++b) {
+      efirst[b] = acc;
+      acc += ecnt[b];
+      ecnt[b] = 0;
+    }
+    en[efirst[1] + ecnt[1]++] = 0;
+    en[efirst[2] + ecnt[2]++] = 1;
+    for (u32 k = 2; k + 1 < N; ++k) {
+      u32 b = (u32)ni[k].end + 2;
+      en[efirst[b] + ecnt[b]++] = k;
+    }
+    for (u32 b = 0; b <= n + 2; ++b) B.bnd_meta[bb0 + b] = BndMeta{B.bnd_first[bb0 + b], B.bnd_cnt[bb0 + b], efirst[b], ecnt[b]};
   }
   // BOS beams (reference AnalyzerImpl::bootstrapAnalysis, analyzer_impl.cc:179-195)
   BeamSlot* bm = B.node_beam + nb * cfg.beam;
-  for (int q = 0; q < cfg.beam; ++q) {
-    bm[q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
-    bm[cfg.beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+  for (int q = lane; q < 2 * cfg.beam; q += 64) {
+    BeamSlot v{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+    if (q == 0) v = BeamSlot{0, 0, 0.f, 0xffffffffu, 0};
+    if (q == cfg.beam) v = BeamSlot{0, 0, 0.f, 0u, 0};
+    bm[q] = v;
   }
-  bm[0] = BeamSlot{0, 0, 0.f, 0xffffffffu, 0};
-  bm[cfg.beam] = BeamSlot{0, 0, 0.f, 0u, 0};
   // BOS patterns (LatticeConstructionContext::addBos, lattice_builder.cc:173-179)
   u64* pat = B.node_pat + nb * kPat;
-  for (int q = 0; q < 2 * kPat; ++q) pat[q] = (u64)(u32)kEptrBOS;
+  for (int q = lane; q < 2 * kPat; q += 64) pat[q] = (u64)(u32)kEptrBOS;
 }
 
 }  // namespace jpp

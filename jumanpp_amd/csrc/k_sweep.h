@@ -57,6 +57,31 @@ struct NgramTables {
 };
 constexpr NgramTables kNg{};
 
+// Developer-only phase timing (-DJPP_SWEEP_PROF): lane 0 of every wavefront adds the s_memtime
+// cycles it spent per phase to g_sweep_prof[]; read with the debug entry point jppgpu_debug_sweep_prof.
+#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
+__device__ unsigned long long g_sweep_dbg[16];
+#endif
+#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
+__device__ unsigned long long g_sweep_prof[16];
+#define JPP_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define JPP_PROF(i)                                          \
+  do {                                                       \
+    unsigned long long now_ = __builtin_readcyclecounter();  \
+    prof_acc[i] += now_ - prof_t;                            \
+    prof_t = now_;                                           \
+  } while (0)
+#define JPP_PROF_FLUSH                                                                 \
+  do {                                                                                 \
+    if (lane == 0)                                                                     \
+      for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_sweep_prof[q_], prof_acc[q_]);       \
+  } while (0)
+#else
+#define JPP_PROF_DECL
+#define JPP_PROF(i)
+#define JPP_PROF_FLUSH
+#endif
+
 #ifndef JPP_SWEEP_WAVES
 #define JPP_SWEEP_WAVES 4
 #endif
@@ -154,6 +179,8 @@ __device__ __forceinline__ float bi_sum2(const float* w, int lane, int j) {
   return wave_shfl_f32(r, gb) + wave_shfl_f32(r, gb + 1);
 }
 
+__device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32 q) { return g[q]; }
+
 // RM = capacity of right nodes per boundary staged in LDS (the host picks the variant from the batch maximum)
 template <int GM, int RM>
 __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
@@ -190,8 +217,19 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ u16 order[RM];
   __shared__ float biS[kChunk][GM];
   __shared__ float tot[kChunk][GM];
-  __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass
+  __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass (R > kChunk only)
   __shared__ float t0R[kChunk];
+  // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
+  // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
+#if defined(JPP_SWEEP_CAND256)
+  constexpr int kCandCap = 256;
+#else
+  constexpr int kCandCap = GM <= 8 ? 128 : 256;
+#endif
+  __shared__ __attribute__((aligned(16))) u64 pRn[2][kChunk][kPat];
+  __shared__ __attribute__((aligned(16))) float t0n[2][kChunk];
+  __shared__ __attribute__((aligned(16))) u32 enn[2][64];
+  __shared__ __attribute__((aligned(16))) BeamSlot cand[kCandCap];  // live beam slots of the left nodes
 
   const int grp = lane >> 3, gj = lane & 7;
   LaneBi lbi;
@@ -224,32 +262,156 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     if (lane == 0) B.bnd_ngb[bb0 + 2] = 0;
     return;
   }
-  for (u32 b = 2; b <= n + 2; ++b) {
-    const u32 R = B.bnd_cnt[bb0 + b];
-    if (R == 0) continue;
-    const u32 rfirst = B.bnd_first[bb0 + b];
-    const u32 L = B.end_cnt[bb0 + b];
-    const u32 efirst = B.end_first[bb0 + b];
+  // per-boundary layout records: a 64-entry LDS ring (slot b & 63), filled asynchronously; entries that
+  // are not resident (more than 63 boundaries ahead) are read from HBM
+  __shared__ __attribute__((aligned(16))) BndMeta meta[64];
+  const BndMeta* gmeta = B.bnd_meta + bb0;
+  u32 metaEnd = (n + 3) < 64u ? (n + 3) : 64u;  // records below metaEnd have been requested ...
+  lds_async_load<16>(&meta[0], gmeta + lane, (u32)lane < metaEnd);
+  lds_async_wait();
+  __syncthreads();
+  u32 metaReady = metaEnd;                      // ... and those below metaReady have landed
+#if defined(JPP_SWEEP_NO_RING)
+  metaReady = 0;
+  metaEnd = n + 3;
+#endif
+  // The HBM read sits behind a noinline call so that the two loads cannot be merged into one flat load
+  // through a selected pointer: flat access to the LDS aperture faults on this platform.
+#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
+  auto metaAt = [&](u32 q) -> BndMeta {
+    BndMeta g = load_bnd_meta(gmeta, q);
+    if (q < metaReady) {
+      BndMeta l = meta[q & 63];
+      if (l.first != g.first || l.cnt != g.cnt || l.efirst != g.efirst || l.ecnt != g.ecnt) {
+        if (atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
+          g_sweep_dbg[1] = s; g_sweep_dbg[2] = q; g_sweep_dbg[3] = metaReady; g_sweep_dbg[4] = metaEnd;
+          g_sweep_dbg[5] = n; g_sweep_dbg[6] = l.first; g_sweep_dbg[7] = g.first; g_sweep_dbg[8] = l.cnt;
+          g_sweep_dbg[9] = g.cnt; g_sweep_dbg[10] = (unsigned long long)lane;
+        }
+      }
+      return l;
+    }
+    return g;
+  };
+#else
+  auto metaAt = [&](u32 q) -> BndMeta {
+    if (q < metaReady) return meta[q & 63];
+    return load_bnd_meta(gmeta, q);
+  };
+#endif
+  auto next_nonempty = [&](u32 from) {
+    u32 q = from;
+    while (q <= n + 2 && metaAt(q).cnt == 0) ++q;
+    return q;
+  };
+  auto prefetch = [&](u32 bq, int buf) {
+    if (bq > n + 2) return;
+    const BndMeta mq = metaAt(bq);
+    const u32 Rq = mq.cnt, rf = mq.first, Lq = mq.ecnt, ef = mq.efirst;
+    const u32 nxr = Rq < (u32)kChunk ? Rq : (u32)kChunk;
+    static_assert(kPat * 8 % 16 == 0 && kChunk * kPat * 8 / 16 <= 64, "one dwordx4 per lane covers a chunk");
+    lds_async_load<16>(&pRn[buf][0][0], reinterpret_cast<const char*>(pats + (u64)rf * kPat) + lane * 16,
+                       (u32)lane < nxr * (kPat * 8 / 16));
+    lds_async_load<4>(&t0n[buf][0], t0s + rf + lane, (u32)lane < nxr);
+    lds_async_load<4>(&enn[buf][0], en + ef + lane, (u32)lane < (Lq < 64u ? Lq : 64u));
+  };
+  JPP_PROF_DECL;
+  u32 bn = next_nonempty(2);
+  int par = 0;
+  prefetch(bn, par);
+  for (u32 b = bn; b <= n + 2; b = bn, par ^= 1) {
+    // the records / rows requested during the previous boundary (or above) are needed from here on
+    lds_async_wait();
+    __syncthreads();
+    const BndMeta mb = metaAt(b);
+    const u32 R = mb.cnt;
+    const u32 rfirst = mb.first;
+    const u32 L = mb.ecnt;
+    const u32 efirst = mb.efirst;
     if (R > (u32)RM) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }
+    // the previous requests have landed (wait above); boundaries below b are done: recycle their ring
+    // slots for the records up to 63 ahead
+#if !defined(JPP_SWEEP_NO_RING)
+    metaReady = metaEnd;
+#endif
+    if (metaEnd < n + 3 && metaEnd < b + 64) {
+      const u32 lo = metaEnd, hi = (b + 64) < (n + 3) ? (b + 64) : (n + 3);
+      // slots lo..hi-1 (mod 64) may wrap: issue the two contiguous pieces separately
+      const u32 s0 = lo & 63, cntAll = hi - lo;
+      const u32 c0 = (s0 + cntAll) <= 64u ? cntAll : 64u - s0;
+      lds_async_load<16>(&meta[s0], gmeta + lo + lane, (u32)lane < c0);
+      lds_async_load<16>(&meta[0], gmeta + lo + c0 + lane, (u32)lane < cntAll - c0);
+      metaEnd = hi;
+    }
+#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
+    {  // developer build: the asynchronously staged copies must equal their HBM sources
+      bool badv = false;
+      u64 code = 0;
+      const u32 nxr = R < (u32)kChunk ? R : (u32)kChunk;
+      for (u32 q = lane; q < nxr * kPat; q += 64)
+        if (pRn[par][q / kPat][q % kPat] != pats[(u64)rfirst * kPat + q]) { badv = true; code = 100 + q; }
+      if ((u32)lane < nxr && t0n[par][lane] != t0s[rfirst + lane]) { badv = true; code = 300 + lane; }
+      if ((u32)lane < (L < 64u ? L : 64u) && enn[par][lane] != en[efirst + lane]) { badv = true; code = 400 + lane; }
+      if (wave_ballot(badv) != 0) {
+        if (badv && atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
+          g_sweep_dbg[1] = s; g_sweep_dbg[2] = b; g_sweep_dbg[3] = code; g_sweep_dbg[4] = par;
+          g_sweep_dbg[5] = n; g_sweep_dbg[6] = R; g_sweep_dbg[7] = L; g_sweep_dbg[10] = (unsigned long long)lane;
+        }
+        return;
+      }
+    }
+#endif
+    bn = next_nonempty(b + 1);
+    prefetch(bn, par ^ 1);
+    const u32* enL = enn[par];  // ends list of this boundary (first 64 entries)
 
+    JPP_PROF(0);
     // ---- 1. global beam: top-G of all live (left, slot) by the packed key ----
     int ngb = 0;
+    const u32 ncand = L * (u32)beam;
+    const bool fastCand = ncand <= (u32)kCandCap && L <= 64u;
+    if (fastCand) {
+      // the candidates' beam slots go straight to LDS (one dwordx4 per slot); they stay there for the winners
+      for (u32 q0 = 0; q0 < ncand; q0 += 64) {
+        const u32 q = q0 + (u32)lane;
+        const u32 l = q / (u32)beam, k = q - l * (u32)beam;
+        lds_async_load<16>(&cand[q0], &beams[(u64)enL[q < ncand ? l : 0] * beam + k], q < ncand);
+      }
+      lds_async_wait();
+      __syncthreads();
+#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
+      {
+        bool badv = false;
+        for (u32 q = lane; q < ncand; q += 64) {
+          const u32 l = q / (u32)beam, k = q - l * (u32)beam;
+          BeamSlot a = cand[q], g = beams[(u64)en[efirst + l] * beam + k];
+          if (a.left != g.left || a.beam != g.beam || a.prev_node != g.prev_node || f32_sortable(a.total) != f32_sortable(g.total)) badv = true;
+        }
+        if (wave_ballot(badv) != 0) {
+          if (badv && atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
+            g_sweep_dbg[1] = s; g_sweep_dbg[2] = b; g_sweep_dbg[3] = 900; g_sweep_dbg[4] = par;
+            g_sweep_dbg[5] = n; g_sweep_dbg[6] = R; g_sweep_dbg[7] = L; g_sweep_dbg[10] = (unsigned long long)lane;
+          }
+          return;
+        }
+      }
+#endif
+    }
     {
       u64 last = ~u64{0};
-      const u32 ncand = L * (u32)beam;
-      if (ncand <= 64u * 4) {
-        // common case: every lane keeps its <= 4 candidate keys in registers, one pass over HBM
-        u64 mykey[4];
+      if (fastCand) {
+        // every lane keeps its <= 4 candidate keys in registers
+        u64 mykey[kCandCap / 64];
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
+        for (int jx = 0; jx < kCandCap / 64; ++jx) {
           u32 q = (u32)lane + 64u * jx;
           u64 key = 0;
           if (q < ncand) {
             u32 l = q / (u32)beam, k = q - l * (u32)beam;
-            BeamSlot sl = beams[(u64)en[efirst + l] * beam + k];
+            BeamSlot sl = cand[q];
             if (!slot_fake(sl)) key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
           }
           mykey[jx] = key;
@@ -257,7 +419,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         for (int r = 0; r < G; ++r) {
           u64 best = 0;
 #pragma unroll
-          for (int jx = 0; jx < 4; ++jx)
+          for (int jx = 0; jx < kCandCap / 64; ++jx)
             if (mykey[jx] < last && mykey[jx] > best) best = mykey[jx];
           u64 win = wave_max_u64(best);
           if (win == 0) break;
@@ -288,13 +450,20 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     if (lane < ngb) {
       u64 key = gb_key[lane];
       u32 l = (u32)(key >> 16) & 0xffff, k = (u32)key & 0xffff;
-      u32 lnode = en[efirst + l];
-      BeamSlot sl = beams[(u64)lnode * beam + k];
+      u32 lnode;
+      u32 pnode;
+      if (fastCand) {
+        lnode = enL[l];
+        pnode = cand[l * (u32)beam + k].prev_node;
+      } else {
+        lnode = en[efirst + l];
+        pnode = beams[(u64)lnode * beam + k].prev_node;
+      }
       gb_left[lane] = (u16)l;
       gb_slot[lane] = (u16)k;
       gb_score[lane] = sortable_f32((u32)(key >> 32));
       gb_lnode[lane] = lnode;
-      gb_pnode[lane] = sl.prev_node;
+      gb_pnode[lane] = pnode;
       B.bnd_gbeam[(u64)(bb0 + b) * G + lane] = GbeamEntry{(u16)l, (u16)k, gb_score[lane]};
     }
     if (lane == 0) B.bnd_ngb[bb0 + b] = (u32)ngb;
@@ -310,6 +479,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       continue;
     }
 
+    JPP_PROF(1);
     // ---- 2. T1 dedup in first-seen order, gather T1 / T2 pattern rows ----
     if (lane == 0) {
       u32 U = 0;
@@ -340,6 +510,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     }
     __syncthreads();
 
+    JPP_PROF(2);
     // ---- 3. prescores for the first c gbeam entries over all right nodes ----
     int c = cfg.rcheck;
     if (c > (int)R) c = (int)R;
@@ -350,13 +521,17 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     }
     for (u32 tc = 0; tc < R && c > 0; tc += kChunk) {
       const u32 nx = (R - tc) < (u32)kChunk ? (R - tc) : (u32)kChunk;
-      for (u32 q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + tc) * kPat + q];
-      if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
-      __syncthreads();
+      const u64(*pRc)[kPat] = tc == 0 ? pRn[par] : pR;
+      const float* t0c = tc == 0 ? t0n[par] : t0R;
+      if (tc != 0) {
+        for (u32 q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + tc) * kPat + q];
+        if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
+        __syncthreads();
+      }
       for (int i = 0; i < c; ++i) {
         const bool act = (u32)grp < nx;
         const u32 t = tc + (u32)grp;
-        const u64* p0 = pR[act ? grp : 0];
+        const u64* p0 = pRc[act ? grp : 0];
         const u64* t1r = t1pat[gb_t1[i]];
         const u64* t2r = t2pat[i];
         float w[kBiPerLane];
@@ -375,7 +550,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 #pragma unroll
         for (int jj = 1; jj < spec::kNumTri; ++jj) tsum += wave_shfl_f32(g, gbase + jj);
         if (act && gj == 0) {
-          float sc = t0R[grp];
+          float sc = t0c[grp];
           sc += (t == R - 1) ? b4 : b8;
           sc += tsum;
           pres[(u32)i * R + t] = sc;
@@ -384,6 +559,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       __syncthreads();
     }
 
+    JPP_PROF(3);
     // ---- 4. right-node cutoff (std::nth_element semantics) ----
     const u32 K = (cfg.rcheck > 0) ? ((u32)cfg.rbeam < R ? (u32)cfg.rbeam : R) : R;
     for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
@@ -420,14 +596,21 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     }
     __syncthreads();
 
+    JPP_PROF(4);
     // ---- 5. score + beams, kChunk right nodes at a time in cutoff order ----
     const int ntail = ngb - c;
     for (u32 op0 = 0; op0 < R; op0 += kChunk) {
       const int nx = (int)((R - op0) < (u32)kChunk ? (R - op0) : (u32)kChunk);
-      // stage the patterns / T0 of this pass's right nodes (cutoff order)
-      for (int q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + order[op0 + q / kPat]) * kPat + q % kPat];
-      if (lane < nx) t0R[lane] = t0s[rfirst + order[op0 + lane]];
-      __syncthreads();
+      // patterns / T0 of this pass's right nodes in cutoff order: rows of the prefetched buffer when the
+      // whole boundary fits one chunk, staged from HBM otherwise
+      const bool small = R <= (u32)kChunk;
+      if (!small) {
+        for (int q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + order[op0 + q / kPat]) * kPat + q % kPat];
+        if (lane < nx) t0R[lane] = t0s[rfirst + order[op0 + lane]];
+        __syncthreads();
+      }
+      auto rowOf = [&](int x) -> const u64* { return small ? pRn[par][order[op0 + x]] : pR[x]; };
+      auto t0Of = [&](int x) -> float { return small ? t0n[par][order[op0 + x]] : t0R[x]; };
       // 5a. bigram sums per (kept node, unique T1 row) -- applyBiTriFullKernel rows
       if (ntail > 0) {
         const int units = nx * U;
@@ -437,13 +620,14 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           int x = act ? u / U : 0, tu = act ? u - x * U : 0;
           act = act && (op0 + x) < K;
           float w[kBiPerLane];
-          bi_gather(lbi, gj, pR[x], t1pat[tu], W, wmask, act, w);
+          bi_gather(lbi, gj, rowOf(x), t1pat[tu], W, wmask, act, w);
           const float s2 = bi_sum2(w, lane, gj);
           const float s4 = bi_sum4(w, lane, gj);
           if (act && gj == 0) biS[x][tu] = (tu == U - 1) ? s4 : s2;
         }
       }
       __syncthreads();
+      JPP_PROF(5);
       // 5b. cells and totals per (node, gbeam entry)
       for (int q = lane; q < nx * ngb; q += 64) {
         int x = q / ngb, i = q - x * ngb;
@@ -459,7 +643,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           v += gb_score[i];
           total = v;
         } else if (kept) {
-          const u64* p0 = pR[x];
+          const u64* p0 = rowOf(x);
           const u64* t1r = t1pat[gb_t1[i]];
           const u64* t2r = t2pat[i];
           float w[spec::kNumTri];
@@ -489,7 +673,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           }
           // copyT0Scores(tail, resultTail, t0Score)
           float v = res;
-          v += t0R[x];
+          v += t0Of(x);
           cell = v;
           v += gb_score[i];
           total = v;
@@ -502,6 +686,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         if (defined) B.node_cells[((nb + rfirst + t) * G + i) * cfg.nscorers] = cell;
       }
       __syncthreads();
+      JPP_PROF(6);
       // 5c. beams: stable descending rank among the node's candidates (makeT0Beam; for <= 16
       //     candidates std::sort is an insertion sort, i.e. stable)
       for (int q = lane; q < nx * GM; q += 64) {
@@ -540,8 +725,10 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
       }
       __syncthreads();
+      JPP_PROF(7);
     }
   }
+  JPP_PROF_FLUSH;
 }
 
 // top-1 path: follow the EOS beam's best slot back to BOS (AnalysisPath::fillIn,

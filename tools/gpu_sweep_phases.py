@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""(GPU box, developer tool) phase shares of k_sweep from a -DJPP_SWEEP_PROF build:
+   hipcc ... -DJPP_SWEEP_PROF ... -o build/libjppgpu_prof.so ; python tools/gpu_sweep_phases.py"""
+import ctypes
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import argparse
+import numpy as np
+import torch
+import bench
+import jumanpp_amd as J
+
+lib_path = os.path.join(ROOT, 'build', 'libjppgpu_prof.so')
+args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, sent_len=40, batch=65536, rnn=True,
+                          rnn_hidden=128, rnn_vocab=30000)
+cache = os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache')
+mdic, model, img = bench.make_workload(args, cache)
+corpus = bench.make_corpus(args, mdic, cache, args.batch * 2, args.seed + 1)
+batches = bench.load_batches(corpus, args.batch, np)
+ctx = J.Context(img, lib_path=lib_path, use_rnn=False)
+lib = ctypes.CDLL(lib_path)
+dev = torch.device('cuda', 0)
+text, offs = batches[0]
+t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+o = torch.from_numpy(offs.astype(np.int32)).to(dev)
+buf = (ctypes.c_ulonglong * 16)()
+for it in range(3):
+    r = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(offs) - 1, len(text), None)
+    ms = ctx.timings()
+    r.release()
+    lib.jppgpu_debug_sweep_prof(buf)
+vals = [buf[i] for i in range(8)]
+tot = sum(vals)
+names = ['loop head + prefetch issue', '1 candidates + global beam', '2 T1 dedup + T1/T2 rows', '3 prescores',
+         '4 cutoff', '5a tail bigrams', '5b cells (trigrams)', '5c beams']
+print('k_sweep ms', ms['sweep'])
+for n_, v in zip(names, vals):
+    print('%-30s %6.2f %%' % (n_, 100.0 * v / max(1, tot)))
