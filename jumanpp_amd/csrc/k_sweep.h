@@ -82,6 +82,16 @@ __device__ unsigned long long g_sweep_prof[16];
 #define JPP_PROF_FLUSH
 #endif
 
+// weight gathers: JPP_WLOAD_MODE 0 = plain load, 1 = non-temporal (nt) load
+#ifndef JPP_WLOAD_MODE
+#define JPP_WLOAD_MODE 0
+#endif
+#if JPP_WLOAD_MODE == 1 && !defined(JPP_EMU)
+#define JPP_WLOAD(W, i) __builtin_nontemporal_load(&(W)[i])
+#else
+#define JPP_WLOAD(W, i) ((W)[i])
+#endif
+
 #ifndef JPP_SWEEP_WAVES
 #define JPP_SWEEP_WAVES 4
 #endif
@@ -130,7 +140,7 @@ __device__ __forceinline__ void bi_gather(const LaneBi& t, int j, const u64* p0,
   for (int m = 0; m < kBiPerLane; ++m)
     idx[m] = (u32)hmix(hmix(JPP_LBI_PRE(t, m, j), p0[JPP_LBI_T0(t, m, j)]), t1r[JPP_LBI_T1(t, m, j)]) & wmask;
 #pragma unroll
-  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? W[idx[m]] : 0.f;
+  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? JPP_WLOAD(W, idx[m]) : 0.f;
 }
 
 // generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7
@@ -211,7 +221,10 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ u32 t1node[GM];
   __shared__ u32 sh_U;
   __shared__ u64 t1pat[GM][kPat];
-  __shared__ u64 t2pat[GM][kPat];
+  constexpr int kT2 = 4;  // pattern fields of the T2 node the trigrams read (indices 0..3)
+  static_assert(spec::kTri[0].t2 < kT2 && spec::kTri[1].t2 < kT2 && spec::kTri[2].t2 < kT2 && spec::kTri[3].t2 < kT2 && spec::kNumTri == 4,
+                "t2pat holds pattern fields 0..3 only");
+  __shared__ u64 t2pat[GM][kT2];
   __shared__ float pres[2 * RM];
   __shared__ float csum[RM];
   __shared__ u16 order[RM];
@@ -224,11 +237,12 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 #if defined(JPP_SWEEP_CAND256)
   constexpr int kCandCap = 256;
 #else
-  constexpr int kCandCap = GM <= 8 ? 128 : 256;
+  constexpr int kCandCap = GM <= 8 ? 64 : 256;
 #endif
   __shared__ __attribute__((aligned(16))) u64 pRn[2][kChunk][kPat];
   __shared__ __attribute__((aligned(16))) float t0n[2][kChunk];
-  __shared__ __attribute__((aligned(16))) u32 enn[2][64];
+  constexpr u32 kEnnCap = GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
+  __shared__ __attribute__((aligned(16))) u32 enn[2][kEnnCap];
   __shared__ __attribute__((aligned(16))) BeamSlot cand[kCandCap];  // live beam slots of the left nodes
 
   const int grp = lane >> 3, gj = lane & 7;
@@ -262,11 +276,12 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     if (lane == 0) B.bnd_ngb[bb0 + 2] = 0;
     return;
   }
-  // per-boundary layout records: a 64-entry LDS ring (slot b & 63), filled asynchronously; entries that
-  // are not resident (more than 63 boundaries ahead) are read from HBM
-  __shared__ __attribute__((aligned(16))) BndMeta meta[64];
+  // per-boundary layout records: a kRing-entry LDS ring (slot b mod kRing), filled asynchronously;
+  // entries that are not resident (kRing or more boundaries ahead) are read from HBM
+  constexpr u32 kRing = 32;
+  __shared__ __attribute__((aligned(16))) BndMeta meta[kRing];
   const BndMeta* gmeta = B.bnd_meta + bb0;
-  u32 metaEnd = (n + 3) < 64u ? (n + 3) : 64u;  // records below metaEnd have been requested ...
+  u32 metaEnd = (n + 3) < kRing ? (n + 3) : kRing;  // records below metaEnd have been requested ...
   lds_async_load<16>(&meta[0], gmeta + lane, (u32)lane < metaEnd);
   lds_async_wait();
   __syncthreads();
@@ -281,7 +296,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   auto metaAt = [&](u32 q) -> BndMeta {
     BndMeta g = load_bnd_meta(gmeta, q);
     if (q < metaReady) {
-      BndMeta l = meta[q & 63];
+      BndMeta l = meta[q & (kRing - 1)];
       if (l.first != g.first || l.cnt != g.cnt || l.efirst != g.efirst || l.ecnt != g.ecnt) {
         if (atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
           g_sweep_dbg[1] = s; g_sweep_dbg[2] = q; g_sweep_dbg[3] = metaReady; g_sweep_dbg[4] = metaEnd;
@@ -295,7 +310,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   };
 #else
   auto metaAt = [&](u32 q) -> BndMeta {
-    if (q < metaReady) return meta[q & 63];
+    if (q < metaReady) return meta[q & (kRing - 1)];
     return load_bnd_meta(gmeta, q);
   };
 #endif
@@ -313,7 +328,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     lds_async_load<16>(&pRn[buf][0][0], reinterpret_cast<const char*>(pats + (u64)rf * kPat) + lane * 16,
                        (u32)lane < nxr * (kPat * 8 / 16));
     lds_async_load<4>(&t0n[buf][0], t0s + rf + lane, (u32)lane < nxr);
-    lds_async_load<4>(&enn[buf][0], en + ef + lane, (u32)lane < (Lq < 64u ? Lq : 64u));
+    lds_async_load<4>(&enn[buf][0], en + ef + lane, (u32)lane < (Lq < kEnnCap ? Lq : kEnnCap));
   };
   JPP_PROF_DECL;
   u32 bn = next_nonempty(2);
@@ -337,11 +352,11 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 #if !defined(JPP_SWEEP_NO_RING)
     metaReady = metaEnd;
 #endif
-    if (metaEnd < n + 3 && metaEnd < b + 64) {
-      const u32 lo = metaEnd, hi = (b + 64) < (n + 3) ? (b + 64) : (n + 3);
+    if (metaEnd < n + 3 && metaEnd < b + kRing) {
+      const u32 lo = metaEnd, hi = (b + kRing) < (n + 3) ? (b + kRing) : (n + 3);
       // slots lo..hi-1 (mod 64) may wrap: issue the two contiguous pieces separately
-      const u32 s0 = lo & 63, cntAll = hi - lo;
-      const u32 c0 = (s0 + cntAll) <= 64u ? cntAll : 64u - s0;
+      const u32 s0 = lo & (kRing - 1), cntAll = hi - lo;
+      const u32 c0 = (s0 + cntAll) <= kRing ? cntAll : kRing - s0;
       lds_async_load<16>(&meta[s0], gmeta + lo + lane, (u32)lane < c0);
       lds_async_load<16>(&meta[0], gmeta + lo + c0 + lane, (u32)lane < cntAll - c0);
       metaEnd = hi;
@@ -354,7 +369,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       for (u32 q = lane; q < nxr * kPat; q += 64)
         if (pRn[par][q / kPat][q % kPat] != pats[(u64)rfirst * kPat + q]) { badv = true; code = 100 + q; }
       if ((u32)lane < nxr && t0n[par][lane] != t0s[rfirst + lane]) { badv = true; code = 300 + lane; }
-      if ((u32)lane < (L < 64u ? L : 64u) && enn[par][lane] != en[efirst + lane]) { badv = true; code = 400 + lane; }
+      if ((u32)lane < (L < kEnnCap ? L : kEnnCap) && enn[par][lane] != en[efirst + lane]) { badv = true; code = 400 + lane; }
       if (wave_ballot(badv) != 0) {
         if (badv && atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
           g_sweep_dbg[1] = s; g_sweep_dbg[2] = b; g_sweep_dbg[3] = code; g_sweep_dbg[4] = par;
@@ -372,7 +387,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     // ---- 1. global beam: top-G of all live (left, slot) by the packed key ----
     int ngb = 0;
     const u32 ncand = L * (u32)beam;
-    const bool fastCand = ncand <= (u32)kCandCap && L <= 64u;
+    const bool fastCand = ncand <= (u32)kCandCap && L <= kEnnCap;
     if (fastCand) {
       // the candidates' beam slots go straight to LDS (one dwordx4 per slot); they stay there for the winners
       for (u32 q0 = 0; q0 < ncand; q0 += 64) {
@@ -503,10 +518,14 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     }
     __syncthreads();
     const int U = (int)sh_U;
-    for (int q = lane; q < (U + ngb) * kPat; q += 64) {
-      int row = q / kPat, p = q - row * kPat;
-      if (row < U) t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
-      else t2pat[row - U][p] = pats[(u64)gb_pnode[row - U] * kPat + p];
+    for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
+      if (q < U * kPat) {
+        int row = q / kPat, p = q - row * kPat;
+        t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
+      } else {
+        int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
+        t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
+      }
     }
     __syncthreads();
 
@@ -540,7 +559,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         if (act && gj < spec::kNumTri) {
           u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[gj], p0[kNg.tri_t0[gj]]), t1r[kNg.tri_t1[gj]]),
                               t2r[kNg.tri_t2[gj]]) & wmask;
-          g += W[idx];
+          g += JPP_WLOAD(W, idx);
         }
         // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
         const float b8 = bi_sum8(w, lane, gj);
@@ -651,7 +670,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           for (int f = 0; f < spec::kNumTri; ++f) {
             u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[f], p0[kNg.tri_t0[f]]), t1r[kNg.tri_t1[f]]),
                                 t2r[kNg.tri_t2[f]]) & wmask;
-            w[f] = W[idx];
+            w[f] = JPP_WLOAD(W, idx);
           }
           static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
           float S = biS[x][gb_t1[i]];
