@@ -20,7 +20,15 @@ struct JumandicFields {
 
 constexpr int NormalizedPlaceholderIdx = 0;  // src/jumandic/shared/jumandic_spec.h:14
 
-class JumanFormat {
+// core::OutputFormat (src/core/env.h:73-79), per sentence of the last batch
+class OutputFormat {
+ public:
+  virtual ~OutputFormat() = default;
+  virtual Status format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment) = 0;
+  virtual StringPiece result() const = 0;
+};
+
+class JumanFormat : public OutputFormat {
   const ModelImage* model_ = nullptr;
   JumandicFields flds_;
   std::string printer_;
@@ -30,8 +38,8 @@ class JumanFormat {
  public:
   Status initialize(const ModelImage* model);
   // OutputFormat::format(const Analyzer&, StringPiece comment) for sentence i of the last batch
-  Status format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment);
-  StringPiece result() const { return StringPiece(printer_); }
+  Status format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment) override;
+  StringPiece result() const override { return StringPiece(printer_); }
   // JumanppExec::emptyResult (jumandic_env.cc:211-222)
   static StringPiece emptyResult() { return StringPiece("# ERROR\nEOS\n"); }
 };

@@ -17,6 +17,7 @@
 #include "gpu_analyzer.h"
 #include "juman_format.h"
 #include "lattice_format.h"
+#include "simple_formats.h"
 
 using namespace jumanpp_amd;
 
@@ -32,6 +33,8 @@ struct Conf {
   std::vector<std::string> inputs;
   bool timing = false;
   int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
+  enum { Juman, Morph, FullMorph, Segment } kind = Juman;
+  std::string segmentSeparator = " ";
 };
 
 bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
@@ -75,6 +78,11 @@ int main(int argc, const char** argv) {
     else if (argValue(argc, argv, i, "--output", &v) || argValue(argc, argv, i, "-o", &v)) conf.output = v;
     else if (argValue(argc, argv, i, "--lattice", &v) || argValue(argc, argv, i, "--specifics", &v) ||
              argValue(argc, argv, i, "-s", &v) || argValue(argc, argv, i, "-L", &v)) conf.lattice = std::atoi(v.c_str());
+    else if (argValue(argc, argv, i, "--segment-separator", &v)) conf.segmentSeparator = v;
+    else if (std::strcmp(argv[i], "--segment") == 0) conf.kind = Conf::Segment;
+    else if (std::strcmp(argv[i], "--morph") == 0 || std::strcmp(argv[i], "-M") == 0) conf.kind = Conf::Morph;
+    else if (std::strcmp(argv[i], "--full-morph") == 0 || std::strcmp(argv[i], "-F") == 0) conf.kind = Conf::FullMorph;
+    else if (std::strcmp(argv[i], "--juman") == 0 || std::strcmp(argv[i], "-j") == 0) conf.kind = Conf::Juman;
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -114,12 +122,29 @@ int main(int argc, const char** argv) {
     std::cerr << "failed to initialize the analyzer: " << s << "\n";
     return 1;
   }
-  // JumanppExec::initOutput (jumandic_env.cc:55-150): Juman by default, Lattice for -s N
-  JumanFormat format;
-  int latticeN = conf.lattice == -1 ? conf.beam : conf.lattice;
-  LatticeFormat latticeFormat(latticeN);
+  // JumanppExec::initOutput (jumandic_env.cc:55-150) and emptyResult (:211-222)
+  std::unique_ptr<OutputFormat> format;
+  StringPiece emptyResult = "# ERROR\nEOS\n";
   const bool useLattice = conf.lattice != 0;
-  s = useLattice ? latticeFormat.initialize(&model, def.scoreWeights) : format.initialize(&model);
+  if (useLattice) {
+    auto f = new LatticeFormat(conf.lattice == -1 ? conf.beam : conf.lattice);
+    format.reset(f);
+    s = f->initialize(&model, def.scoreWeights);
+  } else if (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph) {
+    auto f = new MorphFormat(conf.kind == Conf::FullMorph);
+    format.reset(f);
+    s = f->initialize(&model);
+    emptyResult = "# ERROR\n";
+  } else if (conf.kind == Conf::Segment) {
+    auto f = new SegmentedFormat();
+    format.reset(f);
+    s = f->initialize(&model, conf.segmentSeparator);
+    emptyResult = "";
+  } else {
+    auto f = new JumanFormat();
+    format.reset(f);
+    s = f->initialize(&model);
+  }
   if (!s) {
     std::cerr << "Failed to initialize I/O: " << s << "\n";
     return 1;
@@ -176,13 +201,13 @@ int main(int argc, const char** argv) {
       Status st = bs.isOk() ? analyzer.sentenceStatus(i) : bs;
       if (!st) {
         std::cerr << st;
-        *out << JumanFormat::emptyResult();
+        *out << emptyResult;
         continue;
       }
       StringPiece comment = batch[i].comment.size() < 2 ? StringPiece("") : StringPiece(batch[i].comment.data() + 2, batch[i].comment.size() - 2);
-      st = useLattice ? latticeFormat.format(analyzer, i, comment) : format.format(analyzer, i, comment);
+      st = format->format(analyzer, i, comment);
       if (!st) std::cerr << st;
-      else *out << (useLattice ? latticeFormat.result() : format.result());
+      else *out << format->result();
     }
     sentences += batch.size();
     batch.clear();

@@ -13,7 +13,7 @@
 
 namespace jumanpp_amd {
 
-class LatticeFormat {
+class LatticeFormat : public OutputFormat {
   // LatticeNodeInfo (lattice_format.h:17-25) keyed by sentence-local node id, which is already
   // ordered by (boundary, position) like publishResult's sort
   struct NodeInfo {
@@ -34,8 +34,8 @@ class LatticeFormat {
   explicit LatticeFormat(int32_t topN) : topN_(topN) {}
   // scoreWeights = ScorerDef::scoreWeights of the analyzer (lattice_format.cc:127)
   Status initialize(const ModelImage* model, const std::vector<float>& scoreWeights);
-  Status format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment);
-  StringPiece result() const { return StringPiece(printer_); }
+  Status format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment) override;
+  StringPiece result() const override { return StringPiece(printer_); }
 };
 
 }  // namespace jumanpp_amd

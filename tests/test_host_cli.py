@@ -203,6 +203,21 @@ def test_lattice_format_byte_identical_to_reference_cli(cli_emu, ref_tools, tmp_
         assert out == ref, n
 
 
+def test_morph_and_segmented_formats_byte_identical(cli_emu, ref_tools, tmp_path):
+    """-M / -F (MorphFormat) and --segment (SegmentedFormat), incl. comments and failing lines"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 14, 14, 31, length=32)
+    with open(os.path.join(tmp, 'w.txt'), 'ab') as f:
+        f.write('\n# S-ID:7\nすごーーい〜かぁっこいいねぇっッ！\n'.encode('utf-8') + b'\xe3\x81\n')
+    for flags in (['-M'], ['-F'], ['--segment'], ['--segment', '--segment-separator=|']):
+        ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt'))
+        rc, out, err = _run(cli_emu, ['--model=' + img] + flags + [os.path.join(tmp, 'w.txt')])
+        assert out == ref, flags
+
+
 def test_lattice_format_with_rnn(cli_emu, ref_tools, tmp_path):
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
