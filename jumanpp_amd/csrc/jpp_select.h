@@ -218,6 +218,67 @@ __device__ inline void std_sort(T* first, T* last, C comp) {
   }
 }
 
+
+// util::part_step / util::partition (src/util/stl_util.h:51-135): the quickselect makeT0Beam runs when
+// it has more than beam*4/3 candidates; returns the end of the part that is then std::sort-ed.
+template <typename T, typename C>
+__device__ inline T* jpp_part_step(T* start, T* end, C comp) {
+  long sz = end - start;
+  if (sz == 1) return end;
+  if (sz == 2) {
+    T* n = start + 1;
+    if (comp(*n, *start)) sel_swap(n, start);
+    return n;
+  }
+  if (sz == 3) {
+    T* n0 = start;
+    T* n1 = n0 + 1;
+    T* n2 = n1 + 1;
+    if (comp(*n1, *n0)) sel_swap(n1, n0);
+    if (comp(*n2, *n1)) sel_swap(n2, n1);
+    if (comp(*n1, *n0)) sel_swap(n1, n0);
+    return n1;
+  }
+  T* pivot = start + sz / 2;
+  --end;
+  sel_swap(pivot, end);
+  pivot = end;
+  --end;
+  while (start != end) {
+    if (comp(*start, *pivot)) {
+      ++start;
+    } else {
+      sel_swap(start, end);
+      --end;
+    }
+  }
+  if (comp(*pivot, *end)) {
+    sel_swap(pivot, end);
+  } else {
+    ++end;
+    sel_swap(pivot, end);
+  }
+  return end;
+}
+
+template <typename T, typename C>
+__device__ inline T* jpp_partition(T* start, T* end, C comp, long minSize, long maxSize) {
+  for (;;) {
+    T* mid = jpp_part_step(start, end, comp);
+    long sz = mid - start;
+    if (minSize <= sz && sz <= maxSize) return mid;
+    if (sz > maxSize) {
+      end = mid;
+      continue;
+    }
+    sz += 1;
+    start = mid + 1;
+    minSize -= sz;
+    maxSize -= sz;
+    if (minSize == 0) return start;
+  }
+}
+
 }  // namespace jpp
 
 #endif  // JPP_SELECT_H

@@ -203,10 +203,6 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED,
                 "jppgpu: beam / global beam > 32 is not supported");
-  if (c->global_beam > 0 && c->global_beam > c->beam * 4 / 3)
-    return fail(JPPGPU_NOT_IMPLEMENTED,
-                "jppgpu: global beam > beam*4/3 takes the reference's quickselect branch of makeT0Beam; not "
-                "implemented yet");
   if (m->num_features != spec::kNumDicFeatures || m->num_placeholders != spec::kNumPlaceholders)
     return fail(JPPGPU_INVALID_PARAMETER, "model does not have the jumandic entry layout");
   // the reference only accepts static feature code whose spec hash matches

@@ -31,6 +31,7 @@
 #define JPP_K_RNN_H
 
 #include "jpp_device.h"
+#include "jpp_select.h"
 #include "k_sweep.h"
 
 namespace jpp {
@@ -489,20 +490,44 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     prev_total[lane] = prevT;
   }
   wave_sync();
-  if (lane < kMaxGbeam) {
+  {
     BeamSlot* row = beams + (u64)(N - 1) * beam;
-    if (lane < ngb) {
-      float me = full[lane];
-      int rank = 0;
-      for (int j = 0; j < ngb; ++j) {
-        float o = full[j];
-        if (o > me || (o == me && j < lane)) ++rank;
+    const int partB = beam * 4 / 3;
+    if (ngb > 16 || ngb > partB) {
+      // makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16
+      if (lane == 0) {
+        u8 idx[kMaxGbeam];
+        for (int z = 0; z < ngb; ++z) idx[z] = (u8)z;
+        auto comp = [full](u8 a, u8 bb) { return full[a] > full[bb]; };
+        u8* itr = idx + ngb;
+        if (ngb > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
+        std_sort(idx, itr, comp);
+        const int have = (int)(itr - idx);
+        for (int z = 0; z < beam; ++z) {
+          if (z < have) {
+            GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + idx[z]];
+            row[z] = BeamSlot{ge.left, ge.beam, full[idx[z]], en[efirstE + ge.left], (u32)idx[z]};
+          } else {
+            row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+          }
+        }
       }
-      GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
-      if (rank < beam) row[rank] = BeamSlot{ge.left, ge.beam, me, en[efirstE + ge.left], (u32)lane};
-      B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
-    } else if (lane < beam) {
-      row[lane] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+      wave_sync();
+      if (lane < ngb) B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
+    } else if (lane < kMaxGbeam) {
+      if (lane < ngb) {
+        float me = full[lane];
+        int rank = 0;
+        for (int j = 0; j < ngb; ++j) {
+          float o = full[j];
+          if (o > me || (o == me && j < lane)) ++rank;
+        }
+        GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
+        if (rank < beam) row[rank] = BeamSlot{ge.left, ge.beam, me, en[efirstE + ge.left], (u32)lane};
+        B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
+      } else if (lane < beam) {
+        row[lane] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+      }
     }
   }
 }

@@ -714,16 +714,22 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         u32 t = order[op0 + x];
         int cnt = kept ? ngb : c;
         BeamSlot* row = beams + (u64)(rfirst + t) * beam;
-        if (GM > 16 && cnt > 16) {
-          // more than 16 candidates: libstdc++'s std::sort is an introsort (not stable); one lane per
-          // right node replays it on the index array exactly as makeT0Beam does
+        const int partB = beam * 4 / 3;  // makeT0Beam: partitionBoundary
+        if ((GM > 16 && cnt > 16) || cnt > partB) {
+          // more than 16 candidates: libstdc++'s std::sort is an introsort (not stable); more than
+          // beam*4/3: util::partition first.  One lane per right node replays both on the index array
+          // exactly as makeT0Beam does.
           if (i == 0) {
             u8 idx[GM];
             for (int z = 0; z < cnt; ++z) idx[z] = (u8)z;
             const float* tr = tot[x];
-            std_sort(idx, idx + cnt, [tr](u8 a, u8 bb) { return tr[a] > tr[bb]; });
+            auto comp = [tr](u8 a, u8 bb) { return tr[a] > tr[bb]; };
+            u8* itr = idx + cnt;
+            if (cnt > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
+            std_sort(idx, itr, comp);
+            const int have = (int)(itr - idx);
             for (int z = 0; z < beam; ++z) {
-              if (z < cnt) row[z] = BeamSlot{gb_left[idx[z]], gb_slot[idx[z]], tr[idx[z]], gb_lnode[idx[z]], (u32)idx[z]};
+              if (z < have) row[z] = BeamSlot{gb_left[idx[z]], gb_slot[idx[z]], tr[idx[z]], gb_lnode[idx[z]], (u32)idx[z]};
               else row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
             }
             B.node_kept[nb + rfirst + t] = kept ? 1 : 0;

@@ -61,6 +61,23 @@ def test_emulated_wide_beam_matches_live_reference(emu_lib, golden_dir, ref_tool
     assert not errs, errs[:10]
 
 
+@pytest.mark.parametrize('beams', [[5, 10, 1, 5], [3, 8, 2, 4], [6, 30, 1, 8]])
+def test_emulated_partition_branch_of_make_t0_beam(emu_lib, golden_dir, ref_tools, tmp_path, beams):
+    """global beam > beam*4/3: makeT0Beam quickselects (util::partition) before sorting
+    (score_processor.cc:434-437); exact replay incl. the order among equal scores."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    img, lines, gold_path = tg._fresh_workload(ref_tools, str(tmp_path), 2500, 10, 14, 9, length=40, beams=beams)
+    ctx = J.Context(img, lib_path=emu_lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
 def test_emulated_full_beam_matches_live_reference(emu_lib, golden_dir, ref_tools, tmp_path):
     """--global-beam 0: AnalyzerImpl::computeScoresFull (k_sweep_full)."""
     if ref_tools is None:
@@ -94,8 +111,8 @@ def test_config_validation_mirrors_reference(emu_lib, golden_dir):
         J.Context(img, lib_path=emu_lib, beam=0)
     with pytest.raises(J.JppGpuError, match='right global beam size'):
         J.Context(img, lib_path=emu_lib, right_check=1, right_beam=0)
-    with pytest.raises(J.JppGpuError, match='not implemented'):
-        J.Context(img, lib_path=emu_lib, beam=5, global_beam=8)   # quickselect branch of makeT0Beam
+    with pytest.raises(J.JppGpuError, match='not supported'):
+        J.Context(img, lib_path=emu_lib, beam=40, global_beam=40)
     with pytest.raises(J.JppGpuError, match='only with global beam'):
         J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=emu_lib, global_beam=0)
 

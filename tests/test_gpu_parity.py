@@ -122,6 +122,19 @@ def test_gpu_matches_live_reference_with_rnn(gpu_lib, ref_tools, tmp_path, hidde
     assert not errs, (len(errs), errs[:10])
 
 
+@pytest.mark.parametrize('beams,rnn', [([5, 10, 1, 5], None), ([4, 12, 2, 6], (64, 3000))])
+def test_gpu_partition_branch_of_make_t0_beam(gpu_lib, ref_tools, tmp_path, beams, rnn):
+    """global beam > beam*4/3 (util::partition before std::sort in makeT0Beam / remakeEosBeam)"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 20000, 500, 18, 171, rnn=rnn, beams=beams)
+    ctx = J.Context(img, lib_path=gpu_lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
+
+
 def test_gpu_long_sentences(gpu_lib, ref_tools, tmp_path):
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
