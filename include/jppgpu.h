@@ -183,6 +183,37 @@ int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offs
 /* Same, but text/offsets are already resident in device memory (HBM) and the
  * work is enqueued on `stream` (a hipStream_t, may be NULL).  total_bytes =
  * offsets[n].  Results stay on the device until fetched. */
+/* Partial annotation = the reference's only ScorePlugin (src/core/analysis/score_plugin.h:14-19,
+ * PexStreamReaderImpl::updateScore src/core/input/pex_stream_reader.cc:24-39, PartialExample::checkViolation
+ * src/core/input/partial_example.cc:23-73): a connection whose right node violates a constraint loses 1000
+ * (tag mismatch) or 10000 (word start/end on a no-break position, a required boundary inside the node,
+ * wrong length) from its score.  Constraints are CSR arrays over the sentences of the batch;
+ * boundaries count from 2 (two BOS boundaries) like LatticeNodePtr::boundary. */
+typedef struct {
+  uint16_t boundary;  /* NodeConstraint::boundary */
+  uint16_t length;    /* codepoints */
+  uint32_t tag_first; /* index of the first tag in jppgpu_partial::tags */
+  uint32_t tag_count;
+} jppgpu_node_constraint;
+typedef struct {
+  int32_t field;      /* TagConstraint::field: entry-row column */
+  int32_t value;      /* string pointer of the value, or hashUnkString(value) when the value is not in the dictionary */
+} jppgpu_tag_constraint;
+typedef struct {
+  const uint32_t* nobreak_offsets;   /* [n + 1] */
+  const uint16_t* nobreak;           /* PartialExample::noBreak_, ascending per sentence */
+  const uint32_t* boundary_offsets;  /* [n + 1] */
+  const uint16_t* boundaries;        /* PartialExample::boundaries_, ascending per sentence */
+  const uint32_t* node_offsets;      /* [n + 1] */
+  const jppgpu_node_constraint* nodes;
+  const jppgpu_tag_constraint* tags;
+  uint32_t num_tags;
+} jppgpu_partial;
+
+/* Analyzer::analyze(input, ScorePlugin*) with the partial-annotation plugin (analyzer.cc:45-53) */
+int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                 const jppgpu_partial* partial, jppgpu_result** out);
+
 int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                 uint32_t total_bytes, void* stream, jppgpu_result** out);
 /* Copy results to the host.  full=0: status, node table, UNK table, top-1 paths.

@@ -34,6 +34,17 @@ enum SentStatus : i32 {
 // UNK maker kinds: spec::UnkMakerType (reference src/core/spec/spec_types.h)
 enum UnkType : i32 { UNK_SINGLE = 1, UNK_CHUNKING = 2, UNK_ONOMATOPOEIA = 3, UNK_NUMERIC = 4, UNK_NORMALIZE = 5 };
 
+struct PcNode {
+  u16 boundary;
+  u16 length;
+  u32 tag_first;
+  u32 tag_count;
+};
+struct PcTag {
+  i32 field;
+  i32 value;
+};
+
 // the four per-boundary layout words k_sweep needs, in one 16-byte record
 struct alignas(16) BndMeta {
   u32 first;   // first node starting at the boundary
@@ -197,6 +208,15 @@ struct Batch {
   float* rnn_ctx;          // [bb][gbeam][EP] hidden state after each rnn node
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]
+  // partial annotation (ScorePlugin): CSR constraint arrays and the resulting per-node penalty (null: off)
+  const u32* pc_nb_off;
+  const u16* pc_nb;
+  const u32* pc_b_off;
+  const u16* pc_b;
+  const u32* pc_node_off;
+  const PcNode* pc_nodes;
+  const PcTag* pc_tags;
+  float* node_penalty;     // [node] 0, 1000 or 10000
   BndMeta* bnd_meta;       // [bb] {bnd_first, bnd_cnt, end_first, end_cnt} packed for k_sweep (written by k_ends)
   u32* bnd_ngb;            // [bb]
   // result

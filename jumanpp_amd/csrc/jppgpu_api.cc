@@ -166,6 +166,8 @@ struct jppgpu_ctx {
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
   DevBuf path_len, bnd_meta;
+  DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
+  bool partial_pending = false;  // constraints uploaded for the next analyze call
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
   DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
       path_nodes;
@@ -371,7 +373,8 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,
-                    &ctx->gstats,     &ctx->bnd_meta};
+                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
+                    &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   ctx->timer.destroy();
@@ -509,6 +512,20 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg);
   T.mark(3, st);
   JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  B.node_penalty = nullptr;
+  if (ctx->partial_pending) {
+    ctx->partial_pending = false;
+    if (!ctx->node_penalty.ensure((size_t)B.total_nodes * 4)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (partial)");
+    B.pc_nb_off = ctx->pc_nb_off.as<u32>();
+    B.pc_nb = ctx->pc_nb.as<u16>();
+    B.pc_b_off = ctx->pc_b_off.as<u32>();
+    B.pc_b = ctx->pc_b.as<u16>();
+    B.pc_node_off = ctx->pc_node_off.as<u32>();
+    B.pc_nodes = ctx->pc_nodes.as<PcNode>();
+    B.pc_tags = ctx->pc_tags.as<PcTag>();
+    B.node_penalty = ctx->node_penalty.as<float>();
+    JPP_LAUNCH(k_penalty, n, 64, st, B);
+  }
   T.mark(4, st);
   if (ctx->cfg.gbeam == 0) {
     JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
@@ -554,6 +571,39 @@ extern "C" int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uin
   rt_h2d(ctx->offs.p, offsets, ((size_t)n + 1) * 4, nullptr);
   rt_sync(nullptr);
   return jppgpu_analyze_batch_device(ctx, ctx->text.p, ctx->offs.p, n, total, nullptr, out);
+}
+
+extern "C" int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                            const jppgpu_partial* p, jppgpu_result** out) {
+  if (!ctx || !offsets || !out || !p) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (!p->nobreak_offsets || !p->boundary_offsets || !p->node_offsets)
+    return fail(JPPGPU_INVALID_PARAMETER, "partial annotation offsets are null");
+  static_assert(sizeof(jppgpu_node_constraint) == sizeof(PcNode) && sizeof(jppgpu_tag_constraint) == sizeof(PcTag),
+                "ABI and device constraint records must match");
+  const size_t nNb = p->nobreak_offsets[n], nB = p->boundary_offsets[n], nNodes = p->node_offsets[n];
+  for (size_t q = 0; q < nNodes; ++q) {
+    const jppgpu_node_constraint& c = p->nodes[q];
+    if ((size_t)c.tag_first + c.tag_count > p->num_tags) return fail(JPPGPU_INVALID_PARAMETER, "tag range outside tags[]");
+    for (uint32_t t = 0; t < c.tag_count; ++t) {
+      int32_t f = p->tags[c.tag_first + t].field;
+      if (f < 0 || f >= ctx->hmodel.num_features) return fail(JPPGPU_INVALID_PARAMETER, "tag field outside the entry row");
+    }
+  }
+  bool ok = ctx->pc_nb_off.ensure(((size_t)n + 1) * 4) && ctx->pc_b_off.ensure(((size_t)n + 1) * 4) &&
+            ctx->pc_node_off.ensure(((size_t)n + 1) * 4) && ctx->pc_nb.ensure(nNb * 2 + 2) && ctx->pc_b.ensure(nB * 2 + 2) &&
+            ctx->pc_nodes.ensure(nNodes * sizeof(PcNode) + 4) && ctx->pc_tags.ensure((size_t)p->num_tags * sizeof(PcTag) + 4);
+  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (partial)");
+  rt_h2d(ctx->pc_nb_off.p, p->nobreak_offsets, ((size_t)n + 1) * 4, nullptr);
+  rt_h2d(ctx->pc_b_off.p, p->boundary_offsets, ((size_t)n + 1) * 4, nullptr);
+  rt_h2d(ctx->pc_node_off.p, p->node_offsets, ((size_t)n + 1) * 4, nullptr);
+  if (nNb) rt_h2d(ctx->pc_nb.p, p->nobreak, nNb * 2, nullptr);
+  if (nB) rt_h2d(ctx->pc_b.p, p->boundaries, nB * 2, nullptr);
+  if (nNodes) rt_h2d(ctx->pc_nodes.p, p->nodes, nNodes * sizeof(PcNode), nullptr);
+  if (p->num_tags) rt_h2d(ctx->pc_tags.p, p->tags, (size_t)p->num_tags * sizeof(PcTag), nullptr);
+  ctx->partial_pending = true;
+  int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
+  ctx->partial_pending = false;
+  return rc;
 }
 
 #if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)

@@ -189,6 +189,66 @@ __device__ __forceinline__ float bi_sum2(const float* w, int lane, int j) {
   return wave_shfl_f32(r, gb) + wave_shfl_f32(r, gb + 1);
 }
 
+// Partial-annotation ScorePlugin: penalty of every lattice node, one lane per node.
+// PartialExample::checkViolation (src/core/input/partial_example.cc:23-73) decides from the RIGHT node of
+// a connection only, so PexStreamReaderImpl::updateScore (pex_stream_reader.cc:24-39) subtracts the same
+// amount from every connection into that node: 10000 for a word start/end on a no-break position, a required
+// boundary inside the node or a length mismatch, 1000 for a tag mismatch, nothing otherwise.
+__global__ void k_penalty(Batch B) {
+  const u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  const u32 N = B.sent_nodes[s];
+  const u64 nb = B.node_base[s];
+  const u32 nb0 = B.pc_nb_off[s], nb1 = B.pc_nb_off[s + 1];
+  const u32 b0 = B.pc_b_off[s], b1 = B.pc_b_off[s + 1];
+  const u32 n0 = B.pc_node_off[s], n1 = B.pc_node_off[s + 1];
+  for (u32 k = threadIdx.x; k < N; k += blockDim.x) {
+    float pen = 0.f;
+    if (k >= 2) {
+      const NodeInfo ni = B.node_info[nb + k];
+      const u32 boundary = (u32)ni.start + 2;
+      const u32 len = (u32)ni.end - ni.start;
+      const u32 end = boundary + len;
+      bool hard = false, tag = false, done = false;
+      for (u32 q = nb0; q < nb1 && !done; ++q) {
+        u32 bnd = B.pc_nb[q];
+        if (bnd == boundary || bnd == end) {
+          hard = true;
+          done = true;
+        } else if (bnd > end) {
+          break;
+        }
+      }
+      for (u32 q = b0; q < b1 && !done; ++q) {
+        u32 bnd = B.pc_b[q];
+        if (bnd <= boundary) continue;
+        if (bnd >= end) break;
+        hard = true;
+        done = true;
+      }
+      for (u32 q = n0; q < n1 && !done; ++q) {
+        PcNode c = B.pc_nodes[q];
+        if (c.boundary != boundary) continue;
+        if (len != c.length) {
+          hard = true;
+        } else {
+          const i32* row = B.node_entry + (nb + k) * spec::kNumDicFeatures;
+          for (u32 t = 0; t < c.tag_count; ++t) {
+            PcTag tg = B.pc_tags[c.tag_first + t];
+            if (row[tg.field] != tg.value) {
+              tag = true;
+              break;
+            }
+          }
+        }
+        done = true;  // std::find_if: only the first constraint at that boundary counts
+      }
+      pen = hard ? 10000.f : (tag ? 1000.f : 0.f);
+    }
+    B.node_penalty[nb + k] = pen;
+  }
+}
+
 __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32 q) { return g[q]; }
 
 // RM = capacity of right nodes per boundary staged in LDS (the host picks the variant from the batch maximum)
@@ -572,6 +632,8 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           float sc = t0c[grp];
           sc += (t == R - 1) ? b4 : b8;
           sc += tsum;
+          // applyPluginToPrescores (score_processor.cc:578-596)
+          if (B.node_penalty) sc -= B.node_penalty[nb + rfirst + t];
           pres[(u32)i * R + t] = sc;
         }
       }
@@ -690,8 +752,9 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
             q4 += w[3];
             res = S + (q1 + q2 + q3 + q4);
           }
-          // copyT0Scores(tail, resultTail, t0Score)
+          // applyPluginToGbeam (score_processor.cc:598-613), then copyT0Scores(tail, resultTail, t0Score)
           float v = res;
+          if (B.node_penalty) v -= B.node_penalty[nb + rfirst + t];
           v += t0Of(x);
           cell = v;
           v += gb_score[i];

@@ -81,6 +81,17 @@ Status GpuAnalyzer::analyze(StringPiece input) {
 }
 
 Status GpuAnalyzer::analyzeBatch(const std::vector<StringPiece>& inputs, bool fullLattice) {
+  return runBatch(inputs, fullLattice, nullptr);
+}
+
+Status GpuAnalyzer::analyzeBatchPartial(const std::vector<const PartialExample*>& examples, bool fullLattice) {
+  partial_.build(examples);
+  std::vector<StringPiece> inputs;
+  for (auto e : examples) inputs.push_back(e ? StringPiece(e->surface) : StringPiece(""));
+  return runBatch(inputs, fullLattice, &partial_.view);
+}
+
+Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial) {
   if (!ctx_) return Status::InvalidState("GpuAnalyzer was not initialized");
   releaseResult();
   inputs_ = inputs;
@@ -94,7 +105,8 @@ Status GpuAnalyzer::analyzeBatch(const std::vector<StringPiece>& inputs, bool fu
     text_.append(s.data(), s.size());
     offsets_.push_back((uint32_t)text_.size());
   }
-  int rc = jppgpu_analyze_batch(ctx_, text_.data(), offsets_.data(), (uint32_t)inputs.size(), &result_);
+  int rc = partial ? jppgpu_analyze_batch_partial(ctx_, text_.data(), offsets_.data(), (uint32_t)inputs.size(), partial, &result_)
+                   : jppgpu_analyze_batch(ctx_, text_.data(), offsets_.data(), (uint32_t)inputs.size(), &result_);
   if (rc != JPPGPU_OK) return fromCode(rc);
   rc = jppgpu_result_fetch(result_, fullLattice ? 1 : 0, &view_);
   if (rc != JPPGPU_OK) return fromCode(rc);

@@ -24,6 +24,7 @@
 #include "jpp_status.h"
 #include "jppgpu.h"
 #include "model_image.h"
+#include "partial_example.h"
 
 namespace jumanpp_amd {
 
@@ -82,6 +83,8 @@ class GpuAnalyzer {
   std::vector<uint32_t> cpOffsets_;      // concatenated per-sentence codepoint -> byte offset tables
   std::vector<uint64_t> cpOffsetsBase_;
   std::string singleInput_;
+  PartialBatch partial_;
+  Status runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial);
 
   void releaseResult();
 
@@ -97,6 +100,10 @@ class GpuAnalyzer {
   Status analyze(StringPiece input);
   // n sentences, one launch sequence; a failing sentence does not fail the batch (see sentenceStatus)
   Status analyzeBatch(const std::vector<StringPiece>& inputs, bool fullLattice = false);
+
+  // Analyzer::analyze(surface, plugin) with the partial-annotation ScorePlugin for every example
+  // (PexStreamReader::analyzeWith, pex_stream_reader.cc:61-66); a null entry is analysed as the empty string
+  Status analyzeBatchPartial(const std::vector<const PartialExample*>& examples, bool fullLattice = false);
 
   size_t numSentences() const { return inputs_.size(); }
   Status sentenceStatus(size_t i) const;

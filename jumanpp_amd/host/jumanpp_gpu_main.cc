@@ -35,6 +35,7 @@ struct Conf {
   int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
   enum { Juman, Morph, FullMorph, Segment } kind = Juman;
   std::string segmentSeparator = " ";
+  bool partialInput = false;  // --partial-input: InputType::PartiallyAnnotated
 };
 
 bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
@@ -60,6 +61,7 @@ struct Example {
   std::string comment;
   std::string input;
   Status readStatus;
+  PartialExample partial;
 };
 
 }  // namespace
@@ -83,6 +85,7 @@ int main(int argc, const char** argv) {
     else if (std::strcmp(argv[i], "--morph") == 0 || std::strcmp(argv[i], "-M") == 0) conf.kind = Conf::Morph;
     else if (std::strcmp(argv[i], "--full-morph") == 0 || std::strcmp(argv[i], "-F") == 0) conf.kind = Conf::FullMorph;
     else if (std::strcmp(argv[i], "--juman") == 0 || std::strcmp(argv[i], "-j") == 0) conf.kind = Conf::Juman;
+    else if (std::strcmp(argv[i], "--partial-input") == 0) conf.partialInput = true;
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -177,15 +180,32 @@ int main(int argc, const char** argv) {
   };
 
   const size_t maxInput = 65535, maxComment = 1024;  // rdr->setMaxSizes(65535, 1024), jumanpp.cc:72
+  TrainFieldsIndex tfi;
+  PartialExampleReader pexReader;
+  if (conf.partialInput) {  // PexStreamReader::initialize(core, '&'), jumanpp.cc:74-77
+    s = tfi.initialize(model);
+    if (s) s = pexReader.initialize(&tfi, U'&');
+    if (!s) {
+      std::cerr << "Failed to initialize I/O: " << s << "\n";
+      return 1;
+    }
+  }
   std::vector<Example> batch;
   std::vector<StringPiece> pieces;
   int result = 0;
   double gpuMs = 0;
   size_t sentences = 0;
   auto flush = [&]() {
-    pieces.clear();
-    for (auto& e : batch) pieces.push_back(e.readStatus.isOk() ? StringPiece(e.input) : StringPiece(""));
-    Status bs = analyzer.analyzeBatch(pieces, useLattice);
+    Status bs;
+    if (conf.partialInput) {
+      std::vector<const PartialExample*> exs;
+      for (auto& e : batch) exs.push_back(e.readStatus.isOk() ? &e.partial : nullptr);
+      bs = analyzer.analyzeBatchPartial(exs, useLattice);
+    } else {
+      pieces.clear();
+      for (auto& e : batch) pieces.push_back(e.readStatus.isOk() ? StringPiece(e.input) : StringPiece(""));
+      bs = analyzer.analyzeBatch(pieces, useLattice);
+    }
     if (conf.timing) {
       float ms[8];
       analyzer.lastTimings(ms);
@@ -205,6 +225,7 @@ int main(int argc, const char** argv) {
         continue;
       }
       StringPiece comment = batch[i].comment.size() < 2 ? StringPiece("") : StringPiece(batch[i].comment.data() + 2, batch[i].comment.size() - 2);
+      if (conf.partialInput) comment = StringPiece(batch[i].partial.comment);
       st = format->format(analyzer, i, comment);
       if (!st) std::cerr << st;
       else *out << format->result();
@@ -213,8 +234,14 @@ int main(int argc, const char** argv) {
     batch.clear();
   };
   while (hasNext()) {
-    // PlainStreamReader::readExample
     Example e;
+    if (conf.partialInput) {
+      e.readStatus = pexReader.readExample(in, &e.partial);
+      batch.push_back(std::move(e));
+      if (batch.size() >= conf.batch) flush();
+      continue;
+    }
+    // PlainStreamReader::readExample
     for (;;) {
       e.input.clear();
       std::getline(*in, e.input);

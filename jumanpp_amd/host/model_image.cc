@@ -9,7 +9,7 @@ namespace {
 
 enum : uint32_t {
   SEC_INFO = 1, SEC_TRIE = 2, SEC_ENTRY_PTRS = 3, SEC_ENTRY_DATA = 4, SEC_WEIGHTS = 5, SEC_UNK = 6,
-  SEC_FEATURES = 7, SEC_FIELDS = 8, SEC_STRINGS = 9, SEC_INTS = 10, SEC_RNN = 11, SEC_IDMAP = 12,
+  SEC_FEATURES = 7, SEC_FIELDS = 8, SEC_STRINGS = 9, SEC_INTS = 10, SEC_RNN = 11, SEC_IDMAP = 12, SEC_TRAIN = 13,
 };
 
 struct Cursor {
@@ -164,6 +164,19 @@ Status ModelImage::loadModel(StringPiece filename) {
         map[key2(v[0], v[1])] = key2(v[2], v[3]);
       }
     }
+  }
+  if (const Sec* ts = find(SEC_TRAIN, 0, true)) {
+    const char* b = ts->body.data();
+    Cursor c{b, b + ts->body.size()};
+    int32_t n = c.get<int32_t>();
+    for (int32_t i = 0; i < n && c.ok; ++i) {
+      TrainField tf;
+      tf.dicIdx = c.get<int32_t>();
+      tf.name = c.bytes((size_t)c.get<int32_t>()).str();
+      c.align8(b);
+      trainFields_.push_back(std::move(tf));
+    }
+    if (!c.ok) return Status::InvalidParameter() << "bad TRAIN section";
   }
   if (const Sec* rh = find(SEC_RNN, 100, false)) {
     Cursor c{rh->body.data(), rh->body.data() + rh->body.size()};

@@ -35,6 +35,12 @@ struct DictionaryField {
   std::string emptyValue;
 };
 
+// spec::TrainingField as TrainFieldsIndex needs it (src/core/input/training_io.cc:37-55)
+struct TrainField {
+  std::string name;   // dictionary field name
+  int32_t dicIdx = 0; // entry-row column
+};
+
 struct RnnScoreWeights {
   float perceptron = 1.0f;
   float rnn = 0.0f;
@@ -52,6 +58,7 @@ class ModelImage {
   RnnScoreWeights rnnWeights_;
   std::unordered_map<uint64_t, uint64_t> posMap_, conjMap_;
   bool hasIdMap_ = false;
+  std::vector<TrainField> trainFields_;
 
  public:
   ModelImage() = default;
@@ -73,6 +80,8 @@ class ModelImage {
   // DictionaryHolder::fieldByName (src/core/dic/dictionary.h)
   const DictionaryField* fieldByName(StringPiece name) const;
   StringPiece stringStorage(int32_t idx) const { return stringStorages_[idx]; }
+  size_t numStringStorages() const { return stringStorages_.size(); }
+  const std::vector<TrainField>& trainFields() const { return trainFields_; }
   StringPiece intStorage(int32_t idx) const { return intStorages_[idx]; }
   StringPiece entryData() const { return StringPiece((const char*)model_.entry_data, model_.entry_data_bytes); }
 

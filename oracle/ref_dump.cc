@@ -131,6 +131,7 @@ enum : u32 {
   SEC_INTS = 10,     // one per int storage
   SEC_RNN = 11,
   SEC_IDMAP = 12,    // aux 0: (pos, subpos) -> JUMAN ids, aux 1: (conjtype, conjform) -> JUMAN ids
+  SEC_TRAIN = 13,    // training fields (partial-annotation tags): entry-row column + dictionary field name
 };
 
 void section(Writer& w, u32 tag, u32 aux, const void* data, u64 size) {
@@ -296,6 +297,18 @@ int doExport(const char* modelFile, const char* out) {
       section(w, SEC_IDMAP, 1, b.buf.data(), b.buf.size());
       (void)na; (void)nb2;
     }
+  }
+  {  // spec.training.fields as TrainFieldsIndex::initialize reads them (src/core/input/training_io.cc:37-55)
+    Writer s;
+    s.put<i32>((i32)spec.training.fields.size());
+    for (auto& tf : spec.training.fields) {
+      auto& fldSpec = spec.dictionary.fields[tf.fieldIdx];
+      s.put<i32>(tf.dicIdx);
+      s.put<i32>((i32)fldSpec.name.size());
+      s.bytes(fldSpec.name.data(), fldSpec.name.size());
+      s.align8();
+    }
+    section(w, SEC_TRAIN, 0, s.buf.data(), s.buf.size());
   }
   if (auto rp = info.firstPartOf(model::ModelPartKind::Rnn)) {
     // RNN part blocks verbatim (src/core/analysis/rnn_scorer_gbeam.cc:375-398,426-470)

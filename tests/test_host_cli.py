@@ -264,3 +264,81 @@ def test_gpu_config5_lattice_output_with_rnn(cli_gpu, ref_tools, tmp_path):
     # long sentences carry many exactly tied paths (UNK makers that yield identical feature rows), so most
     # sentences only get the N-best-totals check; the structure check runs on the rest
     _lattice_lines_equal_up_to_float_noise(out, ref, gold, 8)
+
+
+# ---- partial annotation (--partial-input): ScorePlugin hooks, src/core/input/partial_example*.cc ----
+
+def _make_partial_input(lines, seed):
+    """random partially annotated examples over corpus lines: plain chunks with no-break marks (&),
+    node constraints with and without tags (existing values, unknown values, wrong lengths)"""
+    import random
+    rnd = random.Random(seed)
+    pos_values = ['名詞', '動詞', '助詞', '副詞', '形容詞', '未定義語', '存在しない品詞']
+    out = []
+    for i, line in enumerate(lines):
+        cps = list(line)
+        if i % 5 == 0:
+            out.append('# S-ID:%d' % i)
+        p = 0
+        while p < len(cps):
+            n = rnd.randint(1, 9)
+            chunk = cps[p:p + n]
+            p += n
+            kind = rnd.random()
+            if kind < 0.45:
+                s = []
+                for j, c in enumerate(chunk):
+                    if j > 0 and rnd.random() < 0.25:
+                        s.append('&')
+                    s.append(c)
+                out.append(''.join(s))
+            else:
+                fields = ['', ''.join(chunk)]
+                if kind > 0.7:
+                    fields.append('pos:' + rnd.choice(pos_values))
+                if kind > 0.9:
+                    fields.append('subpos:' + rnd.choice(['*', '普通名詞', '格助詞']))
+                out.append('\t'.join(fields))
+        out.append('')
+    return ('\n'.join(out) + '\n').encode('utf-8')
+
+
+def test_partial_annotation_plugin_byte_identical(cli_emu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 40, 14, 41, length=30)
+    data = _make_partial_input(lines, 7)
+    pex = os.path.join(tmp, 'pex.txt')
+    open(pex, 'wb').write(data)
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['--partial-input'], pex)
+    rc, out, err = _run(cli_emu, ['--model=' + img, '--partial-input', pex])
+    assert rc == 0, err[-300:]
+    assert out == ref
+    # the constraints must actually change analyses (otherwise this test shows nothing)
+    plain = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), [], os.path.join(tmp, 'w.txt'))
+    strip = lambda b: [x for x in _sentences(b)]
+    changed = sum(1 for a, b in zip(strip(ref), strip(plain)) if [l for l in a if not l.startswith(b'# ')] != b)
+    assert changed >= len(lines) // 2
+    # lattice output and a different beam configuration through the same plugin path
+    for flags in (['-s', '3'], ['--beam=3', '--global-beam=8', '--right-check=2', '--right-beam=4']):
+        ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['--partial-input'] + flags, pex)
+        rc, out, err = _run(cli_emu, ['--model=' + img, '--partial-input'] + flags + [pex])
+        assert out == ref, flags
+
+
+@pytest.mark.gpu
+def test_gpu_partial_annotation_plugin(cli_gpu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 20000, 800, 18, 43)
+    data = _make_partial_input(lines, 9)
+    pex = os.path.join(tmp, 'pex.txt')
+    open(pex, 'wb').write(data)
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['--partial-input'], pex)
+    rc, out, err = _run(cli_gpu, ['--model=' + img, '--partial-input', pex])
+    assert rc == 0, err[-300:]
+    assert out == ref
