@@ -81,7 +81,9 @@ Status TrainFieldsIndex::initialize(const ModelImage& model) {
     }
     auto& map = storages_[fld->stringStorage];
     if (map.empty()) {
-      // readStr2IdMap: StringStorageTraversal (src/core/dic/field_reader.h:215-239)
+      // readStr2IdMap (training_io.cc:12-35): the field's empty-value marker ("*") maps to pointer 0, then
+      // every string of the storage to its position (StringStorageTraversal, field_reader.h:215-239)
+      if (!fld->emptyValue.empty()) map[fld->emptyValue] = 0;
       StringPiece data = model.stringStorage(fld->stringStorage);
       const uint32_t align = 1u << fld->alignPower;
       VarintReader rdr(data, 0);
@@ -90,7 +92,7 @@ Status TrainFieldsIndex::initialize(const ModelImage& model) {
         int32_t pos = (int32_t)((size_t)(rdr.p - base) >> fld->alignPower);
         StringPiece sp;
         if (!rdr.readString(&sp)) break;
-        map.emplace(sp.str(), pos);
+        map[sp.str()] = pos;
         size_t off = (size_t)(rdr.p - base);
         off = (off + align - 1) & ~(size_t)(align - 1);
         rdr.p = base + (off < data.size() ? off : data.size());
