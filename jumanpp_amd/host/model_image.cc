@@ -55,8 +55,18 @@ Status ModelImage::loadModel(StringPiece filename) {
   // 8-byte aligned storage: every section payload starts on an 8-byte boundary of the file
   data_.assign((size_t)sz + 8, 0);
   if (!f.read(data_.data(), sz)) return Status::InvalidParameter() << "could not read model image " << fn;
+  fileSize_ = (size_t)sz;
   const char* base = data_.data();
-  if (sz < 24 || std::memcmp(base, "JPPGPUI1", 8) != 0) return Status::InvalidParameter() << fn << " is not a JPPGPUI1 model image";
+  if (sz >= 24 && std::memcmp(base, "jp2Mdl!", 8) == 0) return loadJppmdl(fn);
+  if (sz < 24 || std::memcmp(base, "JPPGPUI1", 8) != 0) {
+    return Status::InvalidParameter() << "model file " << fn << " has corrupted header";
+  }
+  return loadImage(fn);
+}
+
+Status ModelImage::loadImage(const std::string& fn) {
+  const char* base = data_.data();
+  const std::streamsize sz = (std::streamsize)fileSize_;
 
   struct Sec {
     uint32_t tag, aux;

@@ -1,5 +1,6 @@
-// Flat model image (JPPGPUI1) -> jppgpu_model + the dictionary field storages
-// the output formats read.  Plays the role of JumanppEnv::loadModel /
+// Model file -> jppgpu_model + the dictionary field storages the output formats read.
+// Accepts the reference's own `.jppmdl` container (jppmdl_reader.cc) and the flat model image
+// (JPPGPUI1) that `oracle/_ref/ref_dump export` writes for the tests.  Plays the role of JumanppEnv::loadModel /
 // CoreHolder for the host layer (src/core/env.cc:28-121, src/core/core.cc:11-40):
 // one immutable, shared object that must outlive every GpuAnalyzer.
 //
@@ -59,6 +60,10 @@ class ModelImage {
   std::unordered_map<uint64_t, uint64_t> posMap_, conjMap_;
   bool hasIdMap_ = false;
   std::vector<TrainField> trainFields_;
+  std::vector<char> ownedFeatureSpec_;
+  size_t fileSize_ = 0;
+  Status loadImage(const std::string& fn);
+  Status loadJppmdl(const std::string& fn);  // jppmdl_reader.cc
 
  public:
   ModelImage() = default;

@@ -12,6 +12,7 @@ python3 "$ROOT/tools/gen_dict.py" 2500 --seed 11 > "$TMP/mini.mdic"
 "$REF/jpp_jumandic_bootstrap" "$TMP/mini.mdic" "$TMP/mini.seed" > /dev/null 2>&1
 "$REF/ref_dump" mkmodel "$TMP/mini.seed" "$TMP/mini.model" 14 20260925 0.1
 "$REF/ref_dump" export "$TMP/mini.model" "$HERE/mini.img"
+cp "$TMP/mini.model" "$HERE/mini.jppmdl"   # the reference's own container, read natively by jumanpp_amd/host
 {
   python3 "$ROOT/tools/gen_corpus.py" "$TMP/mini.mdic" 20 --seed 21 --oov 0.15 --len 40
   python3 "$ROOT/tools/gen_corpus.py" "$TMP/mini.mdic" 2 --seed 22 --oov 0.2 --len 90
@@ -32,6 +33,7 @@ python3 "$ROOT/tools/gen_rnn.py" "$TMP/mini.mdic" "$TMP/mini_rnn" --vocab 600 --
     --rnn-model="$TMP/mini_rnn" --rnn-fields=surface,pos --rnn-nce-bias=5.6 --rnn-unk-constant=-3.47 \
     --rnn-unk-length=-2.93 --feature-weight-perceptron=1 --feature-weight-rnn=0.0176 > /dev/null 2>&1
 "$REF/ref_dump" export "$TMP/mini_rnn.model" "$HERE/mini_rnn.img"
+cp "$TMP/mini_rnn.model" "$HERE/mini_rnn.jppmdl"
 "$REF/ref_dump" dump "$TMP/mini_rnn.model" "$HERE/mini_rnn.gold" < "$HERE/mini.txt" 2> /dev/null
 "$REF/jumanpp_v2" --model="$TMP/mini_rnn.model" "$HERE/mini.txt" > "$HERE/mini_rnn.juman.txt"
 rm -rf "$TMP"

@@ -342,3 +342,54 @@ def test_gpu_partial_annotation_plugin(cli_gpu, ref_tools, tmp_path):
     rc, out, err = _run(cli_gpu, ['--model=' + img, '--partial-input', pex])
     assert rc == 0, err[-300:]
     assert out == ref
+
+
+# ---- native .jppmdl reader (jumanpp_amd/host/jppmdl_reader.cc) ----
+
+def test_native_jppmdl_reader_equals_exported_image(cli_emu, golden_dir):
+    """the reference's own model container, read without any reference-linked tool, must drive the
+    analysis to the same bytes as the image exported by ref_dump (and as the reference CLI)"""
+    ref = open(os.path.join(golden_dir, 'mini.juman.txt'), 'rb').read()
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.jppmdl'), os.path.join(golden_dir, 'mini.txt')])
+    assert rc == 0, err[-300:]
+    assert out == ref
+    for flags in (['-s', '3'], ['-F'], ['--segment']):
+        a = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini_rnn.jppmdl')] + flags + [os.path.join(golden_dir, 'mini.txt')])
+        b = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini_rnn.img')] + flags + [os.path.join(golden_dir, 'mini.txt')])
+        assert a[0] == 0 and a[1] == b[1], flags
+    # a truncated / foreign file is rejected with the reference's message
+    bad = os.path.join(golden_dir, 'mini.txt')
+    rc, out, err = _run(cli_emu, ['--model=' + bad])
+    assert rc == 1 and b'has corrupted header' in err
+
+
+def test_native_jppmdl_partial_input(cli_emu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 20, 14, 51, length=30)
+    data = _make_partial_input(lines, 3)
+    pex = os.path.join(tmp, 'pex.txt')
+    open(pex, 'wb').write(data)
+    model = os.path.join(tmp, 'w.model')
+    ref = _ref_cli(ref_tools, model, ['--partial-input'], pex)
+    rc, out, err = _run(cli_emu, ['--model=' + model, '--partial-input', pex])
+    assert rc == 0 and out == ref, err[-300:]
+
+
+@pytest.mark.gpu
+def test_gpu_cli_native_jppmdl_with_rnn(cli_gpu, ref_tools, tmp_path):
+    """jumanpp_gpu --model=<the reference's .jppmdl>, perceptron + RNN, on the MI355X"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 30000, 400, 20, 91, rnn=(128, 8000))
+    a = _run(cli_gpu, ['--model=' + os.path.join(tmp, 'w.model'), os.path.join(tmp, 'w.txt')])
+    b = _run(cli_gpu, ['--model=' + img, os.path.join(tmp, 'w.txt')])
+    assert a[0] == 0 and a[1] == b[1], a[2][-300:]
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), [], os.path.join(tmp, 'w.txt'))
+    meta, gold = G.read_gold(gold_path)
+    flips = _assert_juman_equal_up_to_ties(a[1], ref, gold)
+    assert flips <= 0.05 * len(lines)
