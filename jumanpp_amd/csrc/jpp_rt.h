@@ -107,6 +107,27 @@ __device__ __forceinline__ float wave_shfl_f32(float v, int src) {
   return r;
 }
 
+// value held by the lane N positions above this one (N = 1..15) inside its row of 16 lanes, as a DPP
+// modifier (row_shl:N) -- no LDS crossbar traffic, unlike __shfl/ds_bpermute.  Lanes whose source would
+// fall outside the row receive 0.  Used for the sums inside 8-lane groups: the group leader (lane 0 or 8
+// of the row) reads its members 1..7 this way.
+template <int N>
+__device__ __forceinline__ float row_shl_f32(float v) {
+  static_assert(N >= 1 && N <= 15, "row_shl:1..15");
+#if defined(JPP_EMU)
+  const int l = lane_id();
+  float r = wave_shfl_f32(v, (l + N) & 63);
+  return ((l & 15) + N) > 15 ? 0.f : r;
+#else
+  int x;
+  __builtin_memcpy(&x, &v, 4);
+  x = __builtin_amdgcn_update_dpp(0, x, 0x100 + N, 0xf, 0xf, false);
+  float r;
+  __builtin_memcpy(&r, &x, 4);
+  return r;
+#endif
+}
+
 // broadcast lane `src` (wave-uniform) of v to every lane: v_readlane_b32
 __device__ __forceinline__ float wave_bcast_f32(float v, int src) {
 #if defined(JPP_EMU)

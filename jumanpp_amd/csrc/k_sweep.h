@@ -88,6 +88,9 @@ __device__ unsigned long long g_sweep_prof[16];
 #endif
 #if JPP_WLOAD_MODE == 1 && !defined(JPP_EMU)
 #define JPP_WLOAD(W, i) __builtin_nontemporal_load(&(W)[i])
+#elif JPP_WLOAD_MODE == 2 && !defined(JPP_EMU)
+// timing experiment only (wrong results): every gather hits a 4 KB window, i.e. no cache-line traffic
+#define JPP_WLOAD(W, i) ((W)[(i) & 1023])
 #else
 #define JPP_WLOAD(W, i) ((W)[i])
 #endif
@@ -143,50 +146,56 @@ __device__ __forceinline__ void bi_gather(const LaneBi& t, int j, const u64* p0,
   for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? JPP_WLOAD(W, idx[m]) : 0.f;
 }
 
-// generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7
+// generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7.
+// The three sums below are valid on the group leader (gj == 0) only: it reads its members through
+// row_shl DPP modifiers in exactly the order of the scalar code.
 __device__ __forceinline__ float bi_sum8(const float* w, int lane, int j) {
   float f = 0.f;
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m)
     if (j + 8 * m < spec::kNumBi) f += w[m];
-  const int gb = lane & ~7;
-  float total = wave_shfl_f32(f, gb);
-#pragma unroll
-  for (int jj = 1; jj < 8; ++jj) total += wave_shfl_f32(f, gb + jj);
+  float total = f;
+  total += row_shl_f32<1>(f);
+  total += row_shl_f32<2>(f);
+  total += row_shl_f32<3>(f);
+  total += row_shl_f32<4>(f);
+  total += row_shl_f32<5>(f);
+  total += row_shl_f32<6>(f);
+  total += row_shl_f32<7>(f);
   return total;
 }
 
 // computeUnrolled4RawPerceptron: r_q = 0 + w_q + w_{q+4} + ... (q < 4), then ((r0 + r1) + r2) + r3.
 // Feature q + 4n sits in lane q (n even) or lane q + 4 (n odd) of the group.
 __device__ __forceinline__ float bi_sum4(const float* w, int lane, int j) {
-  const int gb = lane & ~7;
   float r = 0.f;
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
-    float other = wave_shfl_f32(w[m], gb + ((j + 4) & 7));
+    float other = row_shl_f32<4>(w[m]);  // lanes 0..3 of the group read lanes 4..7
     if (j + 8 * m < spec::kNumBi) r += w[m];
     if (j + 4 + 8 * m < spec::kNumBi) r += other;
   }
-  float total = wave_shfl_f32(r, gb);
-#pragma unroll
-  for (int q = 1; q < 4; ++q) total += wave_shfl_f32(r, gb + q);
+  float total = r;
+  total += row_shl_f32<1>(r);
+  total += row_shl_f32<2>(r);
+  total += row_shl_f32<3>(r);
   return total;
 }
 
 // applyBiTriFullKernel: r1 = 0 + w_0 + w_2 + ..., r2 = 0 + w_1 + w_3 + ..., result r1 + r2
+// (lane 0 of the group accumulates the even features, lane 1 the odd ones)
 __device__ __forceinline__ float bi_sum2(const float* w, int lane, int j) {
-  const int gb = lane & ~7;
   const int par = j & 1;
   float r = 0.f;
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v = wave_shfl_f32(w[m], gb + 2 * q + par);
-      if (2 * q + par + 8 * m < spec::kNumBi) r += v;
-    }
+    float v0 = w[m], v2 = row_shl_f32<2>(w[m]), v4 = row_shl_f32<4>(w[m]), v6 = row_shl_f32<6>(w[m]);
+    if (0 + par + 8 * m < spec::kNumBi) r += v0;
+    if (2 + par + 8 * m < spec::kNumBi) r += v2;
+    if (4 + par + 8 * m < spec::kNumBi) r += v4;
+    if (6 + par + 8 * m < spec::kNumBi) r += v6;
   }
-  return wave_shfl_f32(r, gb) + wave_shfl_f32(r, gb + 1);
+  return r + row_shl_f32<1>(r);
 }
 
 // Partial-annotation ScorePlugin: penalty of every lattice node, one lane per node.
@@ -252,6 +261,9 @@ __global__ void k_penalty(Batch B) {
 __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32 q) { return g[q]; }
 
 // RM = capacity of right nodes per boundary staged in LDS (the host picks the variant from the batch maximum)
+// The workgroup is one wavefront: the phases are separated by wave_sync() (compiler + LDS ordering only).
+// A __syncthreads() would additionally drain the vector-memory counter, i.e. wait for every outstanding
+// global store (beams, cells) ~12 times per boundary.
 template <int GM, int RM>
 __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
   const DevModel& M = *Mp;
@@ -279,7 +291,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ u32 gb_pnode[GM];
   __shared__ u32 gb_t1[GM];
   __shared__ u32 t1node[GM];
-  __shared__ u32 sh_U;
   __shared__ u64 t1pat[GM][kPat];
   constexpr int kT2 = 4;  // pattern fields of the T2 node the trigrams read (indices 0..3)
   static_assert(spec::kTri[0].t2 < kT2 && spec::kTri[1].t2 < kT2 && spec::kTri[2].t2 < kT2 && spec::kTri[3].t2 < kT2 && spec::kNumTri == 4,
@@ -304,6 +315,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   constexpr u32 kEnnCap = GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
   __shared__ __attribute__((aligned(16))) u32 enn[2][kEnnCap];
   __shared__ __attribute__((aligned(16))) BeamSlot cand[kCandCap];  // live beam slots of the left nodes
+  __shared__ u64 ckey[64];                                           // their keys (rank selection)
 
   const int grp = lane >> 3, gj = lane & 7;
   LaneBi lbi;
@@ -317,7 +329,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   }
   lbi.pre = s_bipre;
   lbi.t01 = s_bit01;
-  __syncthreads();
+  wave_sync();
 #else
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
@@ -344,7 +356,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   u32 metaEnd = (n + 3) < kRing ? (n + 3) : kRing;  // records below metaEnd have been requested ...
   lds_async_load<16>(&meta[0], gmeta + lane, (u32)lane < metaEnd);
   lds_async_wait();
-  __syncthreads();
+  wave_sync();
   u32 metaReady = metaEnd;                      // ... and those below metaReady have landed
 #if defined(JPP_SWEEP_NO_RING)
   metaReady = 0;
@@ -397,7 +409,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   for (u32 b = bn; b <= n + 2; b = bn, par ^= 1) {
     // the records / rows requested during the previous boundary (or above) are needed from here on
     lds_async_wait();
-    __syncthreads();
+    wave_sync();
     const BndMeta mb = metaAt(b);
     const u32 R = mb.cnt;
     const u32 rfirst = mb.first;
@@ -456,7 +468,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         lds_async_load<16>(&cand[q0], &beams[(u64)enL[q < ncand ? l : 0] * beam + k], q < ncand);
       }
       lds_async_wait();
-      __syncthreads();
+      wave_sync();
 #if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
       {
         bool badv = false;
@@ -491,16 +503,29 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           }
           mykey[jx] = key;
         }
-        for (int r = 0; r < G; ++r) {
-          u64 best = 0;
+        if (ncand <= 64u) {
+          // the keys are unique, so the global beam is "every key with fewer than G larger ones":
+          // each lane ranks its own key against the others (LDS broadcast reads)
+          ckey[lane] = mykey[0];
+          wave_sync();
+          const u64 me = mykey[0];
+          u32 rank = 0;
+          for (u32 z = 0; z < ncand; ++z) rank += ckey[z] > me ? 1u : 0u;
+          const int live = popc64(wave_ballot(me != 0));
+          ngb = live < G ? live : G;
+          if (me != 0 && rank < (u32)G) gb_key[rank] = me;
+        } else {
+          for (int r = 0; r < G; ++r) {
+            u64 best = 0;
 #pragma unroll
-          for (int jx = 0; jx < kCandCap / 64; ++jx)
-            if (mykey[jx] < last && mykey[jx] > best) best = mykey[jx];
-          u64 win = wave_max_u64(best);
-          if (win == 0) break;
-          if (lane == 0) gb_key[r] = win;
-          last = win;
-          ++ngb;
+            for (int jx = 0; jx < kCandCap / 64; ++jx)
+              if (mykey[jx] < last && mykey[jx] > best) best = mykey[jx];
+            u64 win = wave_max_u64(best);
+            if (win == 0) break;
+            if (lane == 0) gb_key[r] = win;
+            last = win;
+            ++ngb;
+          }
         }
       } else {
         for (int r = 0; r < G; ++r) {
@@ -521,7 +546,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         }
       }
     }
-    __syncthreads();
+    wave_sync();
     if (lane < ngb) {
       u64 key = gb_key[lane];
       u32 l = (u32)(key >> 16) & 0xffff, k = (u32)key & 0xffff;
@@ -542,7 +567,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       B.bnd_gbeam[(u64)(bb0 + b) * G + lane] = GbeamEntry{(u16)l, (u16)k, gb_score[lane]};
     }
     if (lane == 0) B.bnd_ngb[bb0 + b] = (u32)ngb;
-    __syncthreads();
+    wave_sync();
 
     if (ngb == 0) {
       // unreachable boundary: every right node gets an all-fake beam (makeT0Beam with an empty gbeam)
@@ -550,34 +575,36 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         beams[(u64)rfirst * beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
       }
       for (u32 q = lane; q < R; q += 64) B.node_kept[nb + rfirst + q] = 0;
-      __syncthreads();
+      wave_sync();
       continue;
     }
 
     JPP_PROF(1);
     // ---- 2. T1 dedup in first-seen order, gather T1 / T2 pattern rows ----
-    if (lane == 0) {
-      u32 U = 0;
-      for (int i = 0; i < ngb; ++i) {
-        int found = -1;
-        for (int j = 0; j < i; ++j) {
-          if (gb_left[j] == gb_left[i]) {
-            found = j;
+    int U;
+    {
+      // first occurrence of every left node among the gbeam entries; the unique T1 rows are numbered in
+      // first-seen order exactly like the sequential dedupT1
+      int first = lane;
+      if (lane < ngb) {
+        const u16 left = gb_left[lane];
+        for (int j = 0; j < lane; ++j) {
+          if (gb_left[j] == left) {
+            first = j;
             break;
           }
         }
-        if (found >= 0) {
-          gb_t1[i] = gb_t1[found];
-        } else {
-          gb_t1[i] = U;
-          t1node[U] = gb_lnode[i];
-          ++U;
-        }
       }
-      sh_U = U;
+      const bool isFirst = lane < ngb && first == lane;
+      const u64 fmask = wave_ballot(isFirst);
+      U = popc64(fmask);
+      if (lane < ngb) {
+        const u32 u = (u32)popc64(fmask & ((u64{1} << first) - 1));
+        gb_t1[lane] = u;
+        if (isFirst) t1node[u] = gb_lnode[lane];
+      }
     }
-    __syncthreads();
-    const int U = (int)sh_U;
+    wave_sync();
     for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
       if (q < U * kPat) {
         int row = q / kPat, p = q - row * kPat;
@@ -587,7 +614,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
       }
     }
-    __syncthreads();
+    wave_sync();
 
     JPP_PROF(2);
     // ---- 3. prescores for the first c gbeam entries over all right nodes ----
@@ -605,7 +632,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       if (tc != 0) {
         for (u32 q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + tc) * kPat + q];
         if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
-        __syncthreads();
+        wave_sync();
       }
       for (int i = 0; i < c; ++i) {
         const bool act = (u32)grp < nx;
@@ -624,10 +651,11 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
         const float b8 = bi_sum8(w, lane, gj);
         const float b4 = bi_sum4(w, lane, gj);
-        const int gbase = lane & ~7;
-        float tsum = wave_shfl_f32(g, gbase);
-#pragma unroll
-        for (int jj = 1; jj < spec::kNumTri; ++jj) tsum += wave_shfl_f32(g, gbase + jj);
+        static_assert(spec::kNumTri == 4, "the trigram sum below reads group members 1..3");
+        float tsum = g;
+        tsum += row_shl_f32<1>(g);
+        tsum += row_shl_f32<2>(g);
+        tsum += row_shl_f32<3>(g);
         if (act && gj == 0) {
           float sc = t0c[grp];
           sc += (t == R - 1) ? b4 : b8;
@@ -637,7 +665,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           pres[(u32)i * R + t] = sc;
         }
       }
-      __syncthreads();
+      wave_sync();
     }
 
     JPP_PROF(3);
@@ -650,7 +678,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         for (int i = 0; i < c; ++i) sc += pres[i * R + t];
         csum[t] = sc;
       }
-      __syncthreads();
+      wave_sync();
       // Fast path: only the SET of the first rbeam entries matters downstream (kept nodes are scored
       // independently).  If no tie straddles the cut, that set is the unique top-rbeam by score and a
       // parallel stable rank gives it; otherwise replay std::nth_element step by step on one lane.
@@ -663,19 +691,19 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         }
         order[rank] = (u16)t;
       }
-      __syncthreads();
+      wave_sync();
       const bool tieAtCut = csum[order[cfg.rbeam - 1]] == csum[order[cfg.rbeam]];
-      __syncthreads();
+      wave_sync();
       if (tieAtCut) {
         for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
-        __syncthreads();
+        wave_sync();
         if (lane == 0) {
           ScoreGreater cmp{csum};
           nth_element_u16(order, order + cfg.rbeam, order + R, cmp);
         }
       }
     }
-    __syncthreads();
+    wave_sync();
 
     JPP_PROF(4);
     // ---- 5. score + beams, kChunk right nodes at a time in cutoff order ----
@@ -688,7 +716,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       if (!small) {
         for (int q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + order[op0 + q / kPat]) * kPat + q % kPat];
         if (lane < nx) t0R[lane] = t0s[rfirst + order[op0 + lane]];
-        __syncthreads();
+        wave_sync();
       }
       auto rowOf = [&](int x) -> const u64* { return small ? pRn[par][order[op0 + x]] : pR[x]; };
       auto t0Of = [&](int x) -> float { return small ? t0n[par][order[op0 + x]] : t0R[x]; };
@@ -707,7 +735,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           if (act && gj == 0) biS[x][tu] = (tu == U - 1) ? s4 : s2;
         }
       }
-      __syncthreads();
+      wave_sync();
       JPP_PROF(5);
       // 5b. cells and totals per (node, gbeam entry)
       for (int q = lane; q < nx * ngb; q += 64) {
@@ -767,7 +795,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         tot[x][i] = total;
         if (defined) B.node_cells[((nb + rfirst + t) * G + i) * cfg.nscorers] = cell;
       }
-      __syncthreads();
+      wave_sync();
       JPP_PROF(6);
       // 5c. beams: stable descending rank among the node's candidates (makeT0Beam; for <= 16
       //     candidates std::sort is an insertion sort, i.e. stable)
@@ -812,7 +840,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         }
         if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
       }
-      __syncthreads();
+      wave_sync();
       JPP_PROF(7);
     }
   }
