@@ -527,11 +527,14 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     JPP_LAUNCH(k_penalty, n, 64, st, B);
   }
   T.mark(4, st);
+  // the <8, *> variants have no makeT0Beam replay (util::partition / introsort): they take the configurations
+  // whose beams are plain stable ranks, i.e. at most 8 candidates and global beam <= beam*4/3
+  const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
   if (ctx->cfg.gbeam == 0) {
     JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && maxR <= 64 && ctx->cfg.rcheck <= 2) {
+  } else if (narrow && maxR <= 64 && ctx->cfg.rcheck <= 2) {
     JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8) {
+  } else if (narrow) {
     JPP_LAUNCH((k_sweep<8, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else {
     JPP_LAUNCH((k_sweep<32, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
@@ -540,12 +543,18 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   if (ctx->cfg.nscorers == 2) {
     JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
                (const DevModel*)ctx->dmodel, ctx->cfg);
+    // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
+    const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
+    const DevModel* dm = (const DevModel*)ctx->dmodel;
     if (ctx->hmodel.rnn_EP == 64) {
-      JPP_LAUNCH((k_rnn_score<1, true>), (n + 15) / 16, 1024, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, true>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<1, true, false>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
     } else if (ctx->hmodel.rnn_EP == 128) {
-      JPP_LAUNCH((k_rnn_score<2, true>), (n + 15) / 16, 1024, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, true>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<2, true, false>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
     } else {
-      JPP_LAUNCH((k_rnn_score<4, false>), (n + 3) / 4, 256, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<4, false, true>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<4, false, false>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
     }
   }
   T.mark(6, st);

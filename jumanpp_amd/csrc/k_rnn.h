@@ -34,6 +34,10 @@
 #include "jpp_select.h"
 #include "k_sweep.h"
 
+#ifndef JPP_RNN_EXP
+#define JPP_RNN_EXP 0   // developer timing experiments only (1: no matvec, 2: no embedding-row misses)
+#endif
+
 namespace jpp {
 
 __device__ __forceinline__ u64 rnn_prime(u32 i) {
@@ -247,6 +251,19 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       wave_sync();
     }
   }
+  // gbeam index of every connection (= which score cell of the node it owns); published in the word-id
+  // scratch, which is no longer needed
+  wave_sync();
+  i32* g_gi = B.rnn_id + (u64)bb0 * G;
+  for (u32 q = lane; q < nq; q += 64) {
+    const u32 c = conn[q];
+    i32 gi = 0;
+    if (c != kNoConn) {
+      const u32 nd = c & 0x03ffffffu, k = c >> 26;
+      gi = (nd == N - 1) ? (i32)k : (i32)beams[(u64)nd * beam + k].pad;
+    }
+    g_gi[q] = gi;
+  }
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {
       g_conn[q] = conn[q];
@@ -284,7 +301,8 @@ __device__ __forceinline__ void rnn_matvec(const float* __restrict__ Wt, const f
 
 // WLDS: the padded transposed recurrent matrix lives in LDS and is shared by the 16 wavefronts
 // of the workgroup; otherwise (E > 128) W is streamed from L2.
-template <int J, bool WLDS>
+// SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
+template <int J, bool WLDS, bool SORT>
 __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, const DevModel* Mp, Config cfg) {
   constexpr int kWaves = WLDS ? 16 : 4;
   constexpr int EP = 64 * J;
@@ -321,10 +339,15 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * EP;
 
   // the per-node fields the boundary loop depends on are staged in LDS when they fit
-  constexpr u32 kCap = 320, kCapB = 56;
+  constexpr u32 kCap = 264, kCapB = 48;
   __shared__ u32 l_prev_all[kWaves][kCap];
   __shared__ i32 l_id_all[kWaves][kCap];
   __shared__ u32 l_cnt_all[kWaves][kCapB];
+  // per connection (boundary, path): lattice node | slot, rnn node, gbeam index, perceptron score cell
+  __shared__ u32 l_conn_all[kWaves][kCap];
+  __shared__ u8 l_assign_all[kWaves][kCap];
+  __shared__ u8 l_gi_all[kWaves][kCap];
+  __shared__ float l_cell0_all[kWaves][kCap];
   __shared__ float nscore_all[kWaves][kMaxGbeam];
   __shared__ float full_all[kWaves][kMaxGbeam];
   __shared__ float prev_total_all[kWaves][kMaxGbeam];
@@ -345,7 +368,22 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     rn_prev = l_prev_all[wv];
     rn_id = l_id_all[wv];
     rn_cnt = l_cnt_all[wv];
+    // connections: every load below is independent, so they are all in flight together
+    const i32* g_gi = B.rnn_id + (u64)bb0 * G;
+    for (u32 q = lane; q < nq; q += 64) {
+      const u32 c = conn[q];
+      const u32 gi = (u32)g_gi[q];
+      l_conn_all[wv][q] = c;
+      l_assign_all[wv][q] = (u8)assign[q];
+      l_gi_all[wv][q] = (u8)gi;
+      l_cell0_all[wv][q] = c != kNoConn ? B.node_cells[((nb + (c & 0x03ffffffu)) * G + gi) * S] : 0.f;
+    }
   }
+  const u32* l_conn = l_conn_all[wv];
+  const u8* l_assign = l_assign_all[wv];
+  const u8* l_gi = l_gi_all[wv];
+  const float* l_cell0 = l_cell0_all[wv];
+  float prevT = 0.f;  // running total of this lane's path (adjustBeamScores), BOS element total = 0
   // ---- C. contexts and scores, boundary by boundary ----
   // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
 #pragma unroll
@@ -386,8 +424,16 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
           for (int j = 0; j < J; ++j) {
             u32 i = (u32)lane * J + j;
             if (i < E) {
+#if JPP_RNN_EXP == 2   // timing experiment: rows from one hot line instead of the embedding tables
+              dot[p] += M.rnn_nce[i] * ctx[p][j];
+#else
               dot[p] += M.rnn_nce[(u64)eid * E + i] * ctx[p][j];
+#endif
+#if JPP_RNN_EXP == 2
+              if (b < bE) embv[p][j] = M.rnn_emb[i];
+#else
               if (b < bE) embv[p][j] = M.rnn_emb[(u64)eid * E + i];
+#endif
             }
           }
         }
@@ -432,12 +478,14 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
           for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
+#if JPP_RNN_EXP != 1
         switch (cn) {
           case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
           case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
           case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
           default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
         }
+#endif
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p) {
           if (p < cn) {
@@ -454,11 +502,37 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     }
     wave_sync();
     if (lane < ngb) {
-      u32 c = conn[(u64)b * G + lane];
-      if (c != kNoConn) {
-        u32 nd = c & 0x03ffffffu, k = c >> 26;
-        u32 gi = (nd == N - 1) ? k : beams[(u64)nd * beam + k].pad;
-        B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
+      if (inLds) {
+        // score cell of the connection and, fused, ScoreProcessor::adjustBeamScores for this boundary:
+        // everything it needs was staged, so the loop carries no dependent HBM access
+        const u32 q = b * (u32)G + (u32)lane;
+        const u32 c = l_conn[q];
+        if (c != kNoConn) {
+          const u32 nd = c & 0x03ffffffu, k = c >> 26;
+          const float rs = nscore[l_assign[q]];
+          B.node_cells[((nb + nd) * G + l_gi[q]) * S + 1] = rs;
+          if (b < bE) {
+            float local = 0.f;
+            local += l_cell0[q] * cfg.w_perceptron;
+            local += rs * cfg.w_rnn;
+            local += prevT;
+            beams[(u64)nd * beam + k].total = local;
+            prevT = local;
+          } else {
+            float local = 0.f;  // remakeEosBeam: fullScores[i] = localScore + beamScore
+            local += l_cell0[q] * cfg.w_perceptron;
+            local += rs * cfg.w_rnn;
+            full[lane] = local + prevT;
+            prev_total[lane] = prevT;
+          }
+        }
+      } else {
+        u32 c = conn[(u64)b * G + lane];
+        if (c != kNoConn) {
+          u32 nd = c & 0x03ffffffu, k = c >> 26;
+          u32 gi = (nd == N - 1) ? k : beams[(u64)nd * beam + k].pad;
+          B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
+        }
       }
     }
     wave_sync();
@@ -466,8 +540,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
 
   // ---- D. adjustBeamScores along the EOS paths ----
   const u32 efirstE = B.end_first[bb0 + bE];
-  if (lane < ngb) {
-    float prevT = 0.f;  // BOS element total
+  if (lane < ngb && !inLds) {
     for (u32 b = 2; b < bE; ++b) {
       u32 c = conn[(u64)b * G + lane];
       if (c == kNoConn) continue;
@@ -493,7 +566,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   {
     BeamSlot* row = beams + (u64)(N - 1) * beam;
     const int partB = beam * 4 / 3;
-    if (ngb > 16 || ngb > partB) {
+    if (SORT && (ngb > 16 || ngb > partB)) {
       // makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16
       if (lane == 0) {
         u8 idx[kMaxGbeam];

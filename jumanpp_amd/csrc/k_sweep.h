@@ -806,7 +806,9 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         int cnt = kept ? ngb : c;
         BeamSlot* row = beams + (u64)(rfirst + t) * beam;
         const int partB = beam * 4 / 3;  // makeT0Beam: partitionBoundary
-        if ((GM > 16 && cnt > 16) || cnt > partB) {
+        // (compiled only into the wide variant: the host sends every configuration with more than 16
+        // candidates or a global beam above beam*4/3 there, and the narrow one stays free of scratch)
+        if (GM > 16 && (cnt > 16 || cnt > partB)) {
           // more than 16 candidates: libstdc++'s std::sort is an introsort (not stable); more than
           // beam*4/3: util::partition first.  One lane per right node replays both on the index array
           // exactly as makeT0Beam does.
