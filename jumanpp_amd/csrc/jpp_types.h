@@ -93,6 +93,8 @@ struct DevModel {
   u32 rnn_order;             // maxent order
   u64 rnn_hash_max;          // maxentSize - vocabSize
   u64 rnn_hash_magic;        // floor((2^64 - 1) / rnn_hash_max) for fastmod_u64
+  u64 rnn_mx_base;           // maxent context hash of order i = rnn_mx_base + (prevId + 1) * rnn_mx_coef[i]
+  u64 rnn_mx_coef[4];        //   (MikolovIndexCalculator with every context slot = prevId, mikolov_rnn_impl.h:21-60)
   float rnn_nce_const;
   i32 rnn_unk_id;
   float rnn_unk_const;

@@ -341,6 +341,21 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     H.rnn_order = m->rnn_maxent_order;
     H.rnn_hash_max = m->rnn_maxent_size - V;
     H.rnn_hash_magic = ~0ull / H.rnn_hash_max;
+    {
+      // PRIMES (src/rnn/mikolov_rnn.h:18-25); hash_i = P0*P1 + sum_{j=1..i} P[(i*P[j] + j) % 36] * (ctx_j + 1),
+      // and every ctx_j is the previous word id (rnn_scorer_gbeam.cc:171-188), so the sum factors out
+      static const u64 P[36] = {108641969, 116049371, 125925907, 133333309, 145678979, 175308587, 197530793, 234567803,
+                                251851741, 264197411, 330864029, 399999781, 407407183, 459258997, 479012069, 545678687,
+                                560493491, 607407037, 629629243, 656789717, 716048933, 718518067, 725925469, 733332871,
+                                753085943, 755555077, 782715551, 790122953, 812345159, 814814293, 893826581, 923456189,
+                                940740127, 953085797, 985184539, 990122807};
+      H.rnn_mx_base = P[0] * P[1];
+      for (u64 i = 0; i < 4; ++i) {
+        u64 c = 0;
+        for (u64 j = 1; j <= i; ++j) c += P[(i * P[j] + j) % 36];
+        H.rnn_mx_coef[i] = c;
+      }
+    }
     H.rnn_nce_const = m->rnn_nce_constant;
     H.rnn_unk_id = m->rnn_unk_id;
     H.rnn_unk_const = m->rnn_unk_constant;

@@ -34,20 +34,34 @@
 #include "jpp_select.h"
 #include "k_sweep.h"
 
+#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
+#define JPP_RPROF_DECL unsigned long long rprof_t = __builtin_readcyclecounter(), rprof_acc[6] = {0, 0, 0, 0, 0, 0}; \
+  const unsigned long long rprof_start = rprof_t
+#define JPP_RPROF(i)                                         \
+  do {                                                       \
+    unsigned long long now_ = __builtin_readcyclecounter();  \
+    rprof_acc[i] += now_ - rprof_t;                          \
+    rprof_t = now_;                                          \
+  } while (0)
+#define JPP_RPROF_FLUSH                                                                    \
+  do {                                                                                     \
+    if (lane == 0) {                                                                       \
+      for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_sweep_prof[8 + q_], rprof_acc[q_]);      \
+      atomicAdd(&g_sweep_prof[14], __builtin_readcyclecounter() - rprof_start);            \
+      atomicAdd(&g_sweep_prof[15], 1ull);                                                  \
+    }                                                                                      \
+  } while (0)
+#else
+#define JPP_RPROF_DECL
+#define JPP_RPROF(i)
+#define JPP_RPROF_FLUSH
+#endif
+
 #ifndef JPP_RNN_EXP
 #define JPP_RNN_EXP 0   // developer timing experiments only (1: no matvec, 2: no embedding-row misses)
 #endif
 
 namespace jpp {
-
-__device__ __forceinline__ u64 rnn_prime(u32 i) {
-  const u64 P[36] = {108641969, 116049371, 125925907, 133333309, 145678979, 175308587, 197530793, 234567803,
-                     251851741, 264197411, 330864029, 399999781, 407407183, 459258997, 479012069, 545678687,
-                     560493491, 607407037, 629629243, 656789717, 716048933, 718518067, 725925469, 733332871,
-                     753085943, 755555077, 782715551, 790122953, 812345159, 814814293, 893826581, 923456189,
-                     940740127, 953085797, 985184539, 990122807};
-  return P[i];
-}
 
 // one byte at a time through a double array; returns false once a label mismatches
 __device__ __forceinline__ bool rnn_trie_byte(const u32* units, u32& id, u32& unit, u32 b) {
@@ -101,7 +115,7 @@ __device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
   return v ^ (v >> 32);
 }
 
-__global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const DevModel* Mp, Config cfg) {
+__global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
@@ -303,7 +317,7 @@ __device__ __forceinline__ void rnn_matvec(const float* __restrict__ Wt, const f
 // of the workgroup; otherwise (E > 128) W is streamed from L2.
 // SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
 template <int J, bool WLDS, bool SORT>
-__global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, const DevModel* Mp, Config cfg) {
+__global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   constexpr int kWaves = WLDS ? 16 : 4;
   constexpr int EP = 64 * J;
   const DevModel& M = *Mp;
@@ -331,6 +345,16 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   const int ngb = (int)B.bnd_ngb[bb0 + bE];
   if (ngb == 0) return;
   const u32 E = M.rnn_E;
+  // model scalars and table pointers, read once: going through `M` inside the loops makes the compiler
+  // re-issue the scalar loads after every store (it cannot prove the header is not aliased)
+  const float* __restrict__ embT = M.rnn_emb;
+  const float* __restrict__ nceT = M.rnn_nce;
+  const float* __restrict__ maxentT = M.rnn_maxent;
+  const u32 mxOrder = M.rnn_order;
+  const u64 hashMax = M.rnn_hash_max, hashMagic = M.rnn_hash_magic, mxBase = M.rnn_mx_base;
+  const u64 mxCoef[4] = {M.rnn_mx_coef[0], M.rnn_mx_coef[1], M.rnn_mx_coef[2], M.rnn_mx_coef[3]};
+  const float nceConst = M.rnn_nce_const, unkConst = M.rnn_unk_const, unkLen = M.rnn_unk_len;
+  const i32 unkId = M.rnn_unk_id;
   BeamSlot* beams = B.node_beam + nb * beam;
   const u32* en = B.end_nodes + nb;
   const u32* conn = B.rnn_conn + (u64)bb0 * G;
@@ -384,6 +408,8 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   const u8* l_gi = l_gi_all[wv];
   const float* l_cell0 = l_cell0_all[wv];
   float prevT = 0.f;  // running total of this lane's path (adjustBeamScores), BOS element total = 0
+  JPP_RPROF_DECL;
+  JPP_RPROF(0);
   // ---- C. contexts and scores, boundary by boundary ----
   // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
 #pragma unroll
@@ -391,7 +417,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     u32 i = (u32)lane * J + j;
     float v = 0.f;
     if (i < E) {
-      float x = 0.f + M.rnn_emb[i];
+      float x = 0.f + embT[i];
       v = 1.0f / (1.0f + expf(-x));
     }
     rn_ctx[(u64)1 * G * EP + i] = v;
@@ -402,6 +428,31 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     if (cnt == 0) continue;
     for (int c0 = 0; c0 < cnt; c0 += kRnnCN) {
       const int cn = (cnt - c0) < kRnnCN ? (cnt - c0) : kRnnCN;
+      // maxent part of the scores first: its gathers depend on the word ids only, so they are in flight
+      // together with the context / embedding loads below.  Every context slot holds prev->id (reference
+      // quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is base + (prevId + 1) * coef[i].
+      float mw[4] = {0.f, 0.f, 0.f, 0.f};  // consumed only when the scores are formed, after the other loads went out
+      i32 myid = 0;
+      if (lane < cn) {
+        myid = rn_id[(u64)b * G + c0 + lane];
+        const i32 pid = rn_id[rn_prev[(u64)b * G + c0 + lane]];
+        const u32 order = mxOrder;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) {
+          mw[i] = 0.f;
+          if (i < order) {
+            const u64 xx = mxBase + ((u64)(i64)pid + 1) * mxCoef[i];
+            const u64 h = fastmod_u64(xx, hashMax, hashMagic);
+            // (h + id) % hash_max: h < hash_max, so one conditional subtraction does it for any id below
+            // hash_max; the general path covers id = -1 (wraps) and oversized ids
+            u64 idx = h + (u64)(i64)myid;
+            if ((u64)(i64)myid < hashMax) idx = idx >= hashMax ? idx - hashMax : idx;
+            else idx = fastmod_u64(idx, hashMax, hashMagic);
+            mw[i] = maxentT[idx];
+          }
+        }
+      }
+      JPP_RPROF(1);
       float ctx[kRnnCN][J];
       float embv[kRnnCN][J];
       float dot[kRnnCN];
@@ -425,14 +476,14 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
             u32 i = (u32)lane * J + j;
             if (i < E) {
 #if JPP_RNN_EXP == 2   // timing experiment: rows from one hot line instead of the embedding tables
-              dot[p] += M.rnn_nce[i] * ctx[p][j];
+              dot[p] += nceT[i] * ctx[p][j];
 #else
-              dot[p] += M.rnn_nce[(u64)eid * E + i] * ctx[p][j];
+              dot[p] += nceT[(u64)eid * E + i] * ctx[p][j];
 #endif
 #if JPP_RNN_EXP == 2
-              if (b < bE) embv[p][j] = M.rnn_emb[i];
+              if (b < bE) embv[p][j] = embT[i];
 #else
-              if (b < bE) embv[p][j] = M.rnn_emb[(u64)eid * E + i];
+              if (b < bE) embv[p][j] = embT[(u64)eid * E + i];
 #endif
             }
           }
@@ -449,28 +500,19 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       if (lane < cn) {
         const int x = lane;
         float score = x == 0 ? dot[0] : x == 1 ? dot[1] : x == 2 ? dot[2] : dot[3];
-        const i32 id = rn_id[(u64)b * G + c0 + x];
-        // maxent: every context slot holds prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188)
-        float me = 0.f;
-        const u32 order = M.rnn_order;
-        const i32 pid = rn_id[rn_prev[(u64)b * G + c0 + x]];
-        for (u32 i = 0; i < order; ++i) {
-          u64 xx = rnn_prime(0) * rnn_prime(1);
-          for (u32 j = 1; j <= i; ++j) {
-            u64 pi = ((u64)i * rnn_prime(j) + j) % 36;
-            xx += rnn_prime((u32)pi) * ((u64)(i64)pid + 1);
-          }
-          u64 h = fastmod_u64(xx, M.rnn_hash_max, M.rnn_hash_magic);
-          u64 idx = fastmod_u64(h + (u64)(i64)id, M.rnn_hash_max, M.rnn_hash_magic);
-          float w = M.rnn_maxent[idx];
-          me = (i == 0) ? w : me + w;
-        }
+        const i32 id = myid;
+        const u32 order = mxOrder;
+        float me = mw[0];
+#pragma unroll
+        for (u32 i = 1; i < 4; ++i)
+          if (i < order) me += mw[i];
         if (order > 0) score += me;
         else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
-        score -= M.rnn_nce_const;
-        if (id == M.rnn_unk_id) score = M.rnn_unk_const + M.rnn_unk_len * (float)g_len[(u64)b * G + c0 + x];
+        score -= nceConst;
+        if (id == unkId) score = unkConst + unkLen * (float)g_len[(u64)b * G + c0 + x];
         nscore[c0 + x] = score;
       }
+      JPP_RPROF(2);
       // new contexts (GbeamRnnState::computeContext; not needed for EOS)
       if (b < bE) {
         float acc[kRnnCN][J];
@@ -500,6 +542,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         }
       }
     }
+    JPP_RPROF(3);
     wave_sync();
     if (lane < ngb) {
       if (inLds) {
@@ -538,6 +581,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     wave_sync();
   }
 
+  JPP_RPROF(4);
   // ---- D. adjustBeamScores along the EOS paths ----
   const u32 efirstE = B.end_first[bb0 + bE];
   if (lane < ngb && !inLds) {
@@ -603,6 +647,8 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       }
     }
   }
+  JPP_RPROF(5);
+  JPP_RPROF_FLUSH;
 }
 
 }  // namespace jpp

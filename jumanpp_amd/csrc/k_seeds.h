@@ -436,7 +436,7 @@ __device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk,
 // MODE 0: count (writes pos_cntA / pos_cnt2); MODE 1: emit stage 1; MODE 2: emit stage 1+2
 // for sentences with the stage-2 flag (into their relocated region).
 template <int MODE>
-__global__ void k_seeds(Batch B, const DevModel* Mp) {
+__global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
@@ -476,7 +476,7 @@ __global__ void k_seeds(Batch B, const DevModel* Mp) {
 
 // normalize maker: same modes.  Its nodes are the last stage-1 nodes of a start.
 template <int MODE>
-__global__ void k_norm(Batch B, const DevModel* Mp) {
+__global__ void k_norm(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;

@@ -265,7 +265,7 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // A __syncthreads() would additionally drain the vector-memory counter, i.e. wait for every outstanding
 // global store (beams, cells) ~12 times per boundary.
 template <int GM, int RM>
-__global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* Mp, Config cfg) {
+__global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;

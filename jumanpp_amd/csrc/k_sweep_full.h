@@ -20,7 +20,7 @@ namespace jpp {
 constexpr int kFullCand = 512;   // live (left, slot) candidates per boundary staged in LDS
 constexpr int kFullChunk = 4;    // right nodes per pass
 
-__global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* Mp, Config cfg) {
+__global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;

@@ -39,7 +39,7 @@ __host__ __device__ constexpr u64 tri_prefix(int index) {
   return hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)index), kTrigramSeed);
 }
 
-__global__ void k_t0(Batch B, const DevModel* Mp) {
+__global__ void k_t0(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;

@@ -21,7 +21,7 @@ cache = os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache')
 mdic, model, img = bench.make_workload(args, cache)
 corpus = bench.make_corpus(args, mdic, cache, args.batch * 2, args.seed + 1)
 batches = bench.load_batches(corpus, args.batch, np)
-ctx = J.Context(img, lib_path=lib_path, use_rnn=False)
+ctx = J.Context(img, lib_path=lib_path, use_rnn=('--rnn' in sys.argv))
 lib = ctypes.CDLL(lib_path)
 dev = torch.device('cuda', 0)
 text, offs = batches[0]
@@ -37,6 +37,13 @@ vals = [buf[i] for i in range(8)]
 tot = sum(vals)
 names = ['loop head + prefetch issue', '1 candidates + global beam', '2 T1 dedup + T1/T2 rows', '3 prescores',
          '4 cutoff', '5a tail bigrams', '5b cells (trigrams)', '5c beams']
-print('k_sweep ms', ms['sweep'])
+print('k_sweep ms', ms['sweep'], 'rnn ms', ms['rnn'])
+if '--rnn' in sys.argv:
+    rv = [buf[i] for i in range(8, 14)]
+    rt = sum(rv)
+    rn = ['stage W + bookkeeping', 'maxent', 'ctx/nce loads, dot, score', 'matvec + sigmoid + store', 'boundary tail (cells, totals)', 'EOS beam']
+    for n_, v in zip(rn, rv):
+        print('rnn %-30s %6.2f %%' % (n_, 100.0 * v / max(1, rt)))
+    print('rnn cycles per sentence (lane 0): %.0f' % (buf[14] / max(1, buf[15])))
 for n_, v in zip(names, vals):
     print('%-30s %6.2f %%' % (n_, 100.0 * v / max(1, tot)))
