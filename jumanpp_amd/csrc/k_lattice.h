@@ -88,53 +88,65 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_layout(Batch B) {
   }
 }
 
-// single-workgroup exclusive scan of u32 counts into u64 offsets (+ base);
-// out[n] receives the total.  n is at most a few hundred thousand.
-__global__ void k_scan(const u32* in, u64* out, u32 n, const u64* base_ptr) {
-  __shared__ u64 part[1024];
-  u32 t = threadIdx.x;
-  u32 nt = blockDim.x;
-  u32 per = (n + nt - 1) / nt;
-  u32 lo = t * per;
-  u32 hi = lo + per < n ? lo + per : n;
-  u64 sum = 0;
-  for (u32 i = lo; i < hi; i += 8) {  // 8 independent loads in flight per lane
-    u32 v[8];
-#pragma unroll
-    for (u32 q = 0; q < 8; ++q) v[q] = (i + q < hi) ? in[i + q] : 0u;
-#pragma unroll
-    for (u32 q = 0; q < 8; ++q) sum += v[q];
-  }
-  // exclusive scan of the per-thread sums: wave scan + scan of the (<= 16) wave totals
+// single-workgroup exclusive scan of u32 counts into u64 offsets (+ base); out[n] receives the total.
+// n is at most a few hundred thousand.  Tiles of 8 elements per thread go through LDS so that HBM is
+// read and written coalesced while every thread still scans a contiguous run.
+constexpr u32 kScanPer = 8;
+__global__ void __launch_bounds__(1024) k_scan(const u32* in, u64* out, u32 n, const u64* base_ptr) {
+  __shared__ u32 tile[1024 * kScanPer];
+  __shared__ u64 otile[1024 * kScanPer];
+  __shared__ u64 part[16];
+  const u32 t = threadIdx.x;
+  const u32 nt = blockDim.x;
   const int lane = (int)(t & 63);
-  u64 incl = sum;
+  const u32 tileN = nt * kScanPer;
+  u64 carry = base_ptr ? *base_ptr : 0;
+  for (u32 t0 = 0; t0 < n; t0 += tileN) {
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    u64 o = wave_shfl_u64(incl, lane >= d ? lane - d : lane);
-    if (lane >= d) incl += o;
-  }
-  if (lane == 63) part[t >> 6] = incl;
-  __syncthreads();
-  u64 wbase = base_ptr ? *base_ptr : 0;
-  const u32 nw = (nt + 63) / 64;
-  u64 all = wbase;
-  for (u32 k = 0; k < nw; ++k) {
-    u64 v = part[k];
-    if (k < (t >> 6)) wbase += v;
-    all += v;
-  }
-  if (t == 0) out[n] = all;
-  u64 acc = wbase + incl - sum;
-  for (u32 i = lo; i < hi; i += 8) {
-    u32 v[8];
+    for (u32 q = 0; q < kScanPer; ++q) {
+      u32 i = t0 + q * nt + t;
+      tile[q * nt + t] = i < n ? in[i] : 0u;
+    }
+    __syncthreads();
+    u32 v[kScanPer];
+    u64 sum = 0;
 #pragma unroll
-    for (u32 q = 0; q < 8; ++q) v[q] = (i + q < hi) ? in[i + q] : 0u;
+    for (u32 q = 0; q < kScanPer; ++q) {
+      v[q] = tile[t * kScanPer + q];
+      sum += v[q];
+    }
+    // exclusive scan of the per-thread sums: wave scan + scan of the (<= 16) wave totals
+    u64 incl = sum;
 #pragma unroll
-    for (u32 q = 0; q < 8; ++q) {
-      if (i + q < hi) out[i + q] = acc;
+    for (int d = 1; d < 64; d <<= 1) {
+      u64 o = wave_shfl_u64(incl, lane >= d ? lane - d : lane);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) part[t >> 6] = incl;
+    __syncthreads();
+    u64 wbase = carry, all = carry;
+    const u32 nw = (nt + 63) / 64;
+    for (u32 k = 0; k < nw; ++k) {
+      u64 pv = part[k];
+      if (k < (t >> 6)) wbase += pv;
+      all += pv;
+    }
+    u64 acc = wbase + incl - sum;
+#pragma unroll
+    for (u32 q = 0; q < kScanPer; ++q) {
+      otile[t * kScanPer + q] = acc;
       acc += v[q];
     }
+    __syncthreads();
+#pragma unroll
+    for (u32 q = 0; q < kScanPer; ++q) {
+      u32 i = t0 + q * nt + t;
+      if (i < n) out[i] = otile[q * nt + t];
+    }
+    carry = all;
+    __syncthreads();
   }
+  if (t == 0) out[n] = carry;
 }
 
 // relocate flagged sentences: node_base[s] = node_base2[s]
