@@ -146,6 +146,19 @@ __device__ __forceinline__ void bi_gather(const LaneBi& t, int j, const u64* p0,
   for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? JPP_WLOAD(W, idx[m]) : 0.f;
 }
 
+// same, from the cached first-stage states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
+__device__ __forceinline__ void bi_gather_s1(const LaneBi& t, int j, const u64* s1, const u64* t1r,
+                                             const float* __restrict__ W, u32 wmask, bool act, float* w) {
+  u32 idx[kBiPerLane];
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m) {
+    const int k = (j + 8 * m) < spec::kNumBi ? (j + 8 * m) : 0;
+    idx[m] = (u32)hmix(s1[k], t1r[JPP_LBI_T1(t, m, j)]) & wmask;
+  }
+#pragma unroll
+  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? JPP_WLOAD(W, idx[m]) : 0.f;
+}
+
 // generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7.
 // The three sums below are valid on the group leader (gj == 0) only: it reads its members through
 // row_shl DPP modifiers in exactly the order of the scalar code.
@@ -314,8 +327,22 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ __attribute__((aligned(16))) float t0n[2][kChunk];
   constexpr u32 kEnnCap = GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
   __shared__ __attribute__((aligned(16))) u32 enn[2][kEnnCap];
-  __shared__ __attribute__((aligned(16))) BeamSlot cand[kCandCap];  // live beam slots of the left nodes
-  __shared__ u64 ckey[64];                                           // their keys (rank selection)
+  // first-stage hash states of the right nodes of the current pass: every bigram / trigram index starts with
+  // hmix(prefix_k, p0[t0_k]), which depends on the right node only and is shared by all its T1 / T2 partners
+  constexpr int kS1 = 40;  // >= kNumBi, row stride
+  static_assert(spec::kNumBi <= kS1, "state row too short");
+  // The candidate slots / keys of phase 1 and the bigram states of phases 3-5 are never live together
+  // (the states die with the tail of a boundary, the candidates of the next one are requested after it),
+  // so they share one buffer.
+  constexpr u32 kCandBytes = kCandCap * sizeof(BeamSlot) + 64 * sizeof(u64);
+  constexpr u32 kS1Bytes = kChunk * kS1 * sizeof(u64);
+  __shared__ __attribute__((aligned(16))) unsigned char u_buf[kCandBytes > kS1Bytes ? kCandBytes : kS1Bytes];
+  BeamSlot* const cand = reinterpret_cast<BeamSlot*>(u_buf);                    // live beam slots of the left nodes
+  u64* const ckey = reinterpret_cast<u64*>(u_buf + kCandCap * sizeof(BeamSlot));  // their keys (rank selection)
+  u64(*const s1b)[kS1] = reinterpret_cast<u64(*)[kS1]>(u_buf);
+  __shared__ u64 s1t[kChunk][spec::kNumTri];
+  __shared__ u64 s_tripre[spec::kNumTri];
+  __shared__ u8 s_trit[spec::kNumTri][4];
 
   const int grp = lane >> 3, gj = lane & 7;
   LaneBi lbi;
@@ -326,6 +353,12 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   if (lane < spec::kNumBi) {
     s_bipre[lane] = kNg.bi_pre[lane];
     s_bit01[lane] = (u8)((kNg.bi_t0[lane] << 4) | kNg.bi_t1[lane]);
+  }
+  if (lane < spec::kNumTri) {
+    s_tripre[lane] = kNg.tri_pre[lane];
+    s_trit[lane][0] = (u8)kNg.tri_t0[lane];
+    s_trit[lane][1] = (u8)kNg.tri_t1[lane];
+    s_trit[lane][2] = (u8)kNg.tri_t2[lane];
   }
   lbi.pre = s_bipre;
   lbi.t01 = s_bit01;
@@ -401,6 +434,16 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
                        (u32)lane < nxr * (kPat * 8 / 16));
     lds_async_load<4>(&t0n[buf][0], t0s + rf + lane, (u32)lane < nxr);
     lds_async_load<4>(&enn[buf][0], en + ef + lane, (u32)lane < (Lq < kEnnCap ? Lq : kEnnCap));
+  };
+  static_assert(JPP_BI_TABLE_LDS == 1, "the state pass reads the feature tables from LDS");
+  // first-stage states of `nx` right nodes whose pattern rows are rows[0..nx): lane per (node, feature)
+  auto compute_s1 = [&](const u64(*rows)[kPat], u32 nx) {
+    constexpr u32 kF = spec::kNumBi + spec::kNumTri;
+    for (u32 q = lane; q < nx * kF; q += 64) {
+      const u32 x = q / kF, k = q - x * kF;
+      if (k < (u32)spec::kNumBi) s1b[x][k] = hmix(s_bipre[k], rows[x][s_bit01[k] >> 4]);
+      else s1t[x][k - spec::kNumBi] = hmix(s_tripre[k - spec::kNumBi], rows[x][s_trit[k - spec::kNumBi][0]]);
+    }
   };
   JPP_PROF_DECL;
   u32 bn = next_nonempty(2);
@@ -627,25 +670,25 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     }
     for (u32 tc = 0; tc < R && c > 0; tc += kChunk) {
       const u32 nx = (R - tc) < (u32)kChunk ? (R - tc) : (u32)kChunk;
-      const u64(*pRc)[kPat] = tc == 0 ? pRn[par] : pR;
       const float* t0c = tc == 0 ? t0n[par] : t0R;
       if (tc != 0) {
         for (u32 q = lane; q < nx * kPat; q += 64) pR[q / kPat][q % kPat] = pats[(u64)(rfirst + tc) * kPat + q];
         if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
         wave_sync();
       }
+      compute_s1(tc == 0 ? pRn[par] : pR, nx);
+      wave_sync();
       for (int i = 0; i < c; ++i) {
         const bool act = (u32)grp < nx;
         const u32 t = tc + (u32)grp;
-        const u64* p0 = pRc[act ? grp : 0];
+        const int xr = act ? grp : 0;
         const u64* t1r = t1pat[gb_t1[i]];
         const u64* t2r = t2pat[i];
         float w[kBiPerLane];
-        bi_gather(lbi, gj, p0, t1r, W, wmask, act, w);
+        bi_gather_s1(lbi, gj, s1b[xr], t1r, W, wmask, act, w);
         float g = 0.f;
         if (act && gj < spec::kNumTri) {
-          u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[gj], p0[kNg.tri_t0[gj]]), t1r[kNg.tri_t1[gj]]),
-                              t2r[kNg.tri_t2[gj]]) & wmask;
+          u32 idx = (u32)hmix(hmix(s1t[xr][gj], t1r[s_trit[gj][1]]), t2r[s_trit[gj][2]]) & wmask;
           g += JPP_WLOAD(W, idx);
         }
         // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
@@ -718,7 +761,16 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         if (lane < nx) t0R[lane] = t0s[rfirst + order[op0 + lane]];
         wave_sync();
       }
-      auto rowOf = [&](int x) -> const u64* { return small ? pRn[par][order[op0 + x]] : pR[x]; };
+      // first-stage states: in the small case they are those of the prescore pass (natural node order,
+      // addressed through the cutoff order); otherwise they are rebuilt for the rows just staged
+      if (!small) {
+        compute_s1(pR, (u32)nx);
+        wave_sync();
+      } else if (c == 0) {
+        compute_s1(pRn[par], (u32)nx);
+        wave_sync();
+      }
+      auto s1Row = [&](int x) -> int { return small ? (int)order[op0 + x] : x; };
       auto t0Of = [&](int x) -> float { return small ? t0n[par][order[op0 + x]] : t0R[x]; };
       // 5a. bigram sums per (kept node, unique T1 row) -- applyBiTriFullKernel rows
       if (ntail > 0) {
@@ -729,7 +781,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           int x = act ? u / U : 0, tu = act ? u - x * U : 0;
           act = act && (op0 + x) < K;
           float w[kBiPerLane];
-          bi_gather(lbi, gj, rowOf(x), t1pat[tu], W, wmask, act, w);
+          bi_gather_s1(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w);
           const float s2 = bi_sum2(w, lane, gj);
           const float s4 = bi_sum4(w, lane, gj);
           if (act && gj == 0) biS[x][tu] = (tu == U - 1) ? s4 : s2;
@@ -752,14 +804,13 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           v += gb_score[i];
           total = v;
         } else if (kept) {
-          const u64* p0 = rowOf(x);
+          const u64* st = s1t[s1Row(x)];
           const u64* t1r = t1pat[gb_t1[i]];
           const u64* t2r = t2pat[i];
           float w[spec::kNumTri];
 #pragma unroll
           for (int f = 0; f < spec::kNumTri; ++f) {
-            u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[f], p0[kNg.tri_t0[f]]), t1r[kNg.tri_t1[f]]),
-                                t2r[kNg.tri_t2[f]]) & wmask;
+            u32 idx = (u32)hmix(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]]) & wmask;
             w[f] = JPP_WLOAD(W, idx);
           }
           static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
