@@ -175,6 +175,11 @@ typedef struct {
 
 int jppgpu_ctx_create(const jppgpu_model* model, const jppgpu_config* config, jppgpu_ctx** out);
 void jppgpu_ctx_destroy(jppgpu_ctx* ctx);
+/* Changes the beam configuration of the following batches; the model stays resident.
+ * AnalyzerImpl::setGlobalBeam + the per-sentence beam of auto-beam mode
+ * (src/core/analysis/analyzer_impl.cc:311-331,350-361).  Same validation as jppgpu_ctx_create. */
+int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t global_beam, int32_t right_check,
+                         int32_t right_beam);
 const char* jppgpu_last_error(void);
 
 /* Analyse n sentences given as one UTF-8 buffer + n+1 byte offsets (host memory). */
@@ -218,6 +223,9 @@ int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void*
                                 uint32_t total_bytes, void* stream, jppgpu_result** out);
 /* Copy results to the host.  full=0: status, node table, UNK table, top-1 paths.
  * full=1: additionally the whole lattice (patterns, T0, beams, cells, global beams). */
+/* The arrays of a fetched view are host copies owned by the result: they stay valid until
+ * jppgpu_result_release, also across later batches on the same context (only the device-resident
+ * side -- further fetches, jppgpu_result_pack -- is invalidated by the next batch). */
 int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_view* view);
 /* Per-batch statistics without copying the lattice: total nodes, sum of path lengths. */
 int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path);

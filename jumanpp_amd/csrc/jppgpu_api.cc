@@ -138,6 +138,7 @@ struct jppgpu_result {
   jppgpu_ctx* ctx = nullptr;
   Batch B{};
   u64 generation = 0;
+  Config cfg{};  // configuration the batch was analysed with (jppgpu_ctx_set_beams may change the context's later)
   bool fetched_basic = false, fetched_full = false;
   // host copies
   std::vector<i32> status;
@@ -375,6 +376,25 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   return JPPGPU_OK;
 }
 
+extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t global_beam, int32_t right_check,
+                                    int32_t right_beam) {
+  if (!ctx) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  // the same checks as at construction (AnalyzerImpl::initScorers, analyzer_impl.cc:43-89)
+  if (beam <= 0) return fail(JPPGPU_INVALID_PARAMETER, "AnalyzerImpl: beam size can not be zero for scoring");
+  if (global_beam <= 0 && ctx->cfg.nscorers == 2)
+    return fail(JPPGPU_INVALID_STATE, "additional scorers are supported only with global beam enabled");
+  if (global_beam > 0 && right_check > 0 && right_beam <= 0)
+    return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
+  if (right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
+  if (beam > kMaxBeam || global_beam > kMaxGbeam)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: beam / global beam > 32 is not supported");
+  ctx->cfg.beam = beam;
+  ctx->cfg.gbeam = global_beam > 0 ? global_beam : 0;
+  ctx->cfg.rcheck = right_check;
+  ctx->cfg.rbeam = right_beam;
+  return JPPGPU_OK;
+}
+
 extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   if (!ctx) return;
   DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
@@ -427,6 +447,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   jppgpu_result& R = *Rp;
   R.ctx = ctx;
   R.generation = ctx->generation;
+  R.cfg = ctx->cfg;
   Batch& B = R.B;
   B.text = static_cast<const u8*>(d_utf8);
   B.byte_off = static_cast<const u32*>(d_offsets);
@@ -707,7 +728,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   const Batch& B = res->B;
   const u32 n = B.n_sent;
   const u64 N = B.total_nodes;
-  const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
+  const int G = res->cfg.gbeam, beam = res->cfg.beam;
   if (!res->fetched_basic) {
     pull(res->status, B.sent_status, n, st);
     pull(res->ncp, B.sent_ncp, n, st);
@@ -745,7 +766,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
     pull(res->patterns, B.node_pat, N * kPat, st);
     pull(res->t0, B.node_t0, N, st);
     pull(res->beams, B.node_beam, N * beam, st);
-    pull(res->cells, B.node_cells, N * G * ctx->cfg.nscorers, st);
+    pull(res->cells, B.node_cells, N * G * res->cfg.nscorers, st);
     pull(res->kept, B.node_kept, N, st);
     rt_sync(st);
     res->fetched_full = true;
@@ -761,7 +782,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   v->total_boundaries = NB;
   v->beam = beam;
   v->global_beam = G;
-  v->num_scorers = ctx->cfg.nscorers;
+  v->num_scorers = res->cfg.nscorers;
   v->path_len = res->path_len.data();
   v->path_nodes = res->path_nodes.data();
   v->nodes = res->nodes.data();

@@ -26,11 +26,11 @@ GpuAnalyzer::~GpuAnalyzer() {
 }
 
 void GpuAnalyzer::releaseResult() {
-  if (result_) {
-    jppgpu_result_release(result_);
-    result_ = nullptr;
-  }
-  std::memset(&view_, 0, sizeof(view_));
+  for (auto& g : groups_)
+    if (g.result) jppgpu_result_release(g.result);
+  groups_.clear();
+  groupOf_.clear();
+  localIdx_.clear();
 }
 
 Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cfg, const ScoringConfig& sconf,
@@ -47,8 +47,8 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
     return Status::InvalidParameter() << "ScorerDef has " << scorer->scoreWeights.size() << " score weights for "
                                       << nScorers << " scorers";
   }
-  if (cfg.autoBeamStep != 0 || cfg.autoBeamBase != 0 || cfg.autoBeamMax != 0) {
-    return Status::NotImplemented("auto beam is not implemented on the GPU path");
+  if (cfg.autoBeamStep < 0 || (cfg.autoBeamStep > 0 && (cfg.autoBeamBase <= 0 || cfg.autoBeamMax < cfg.autoBeamBase))) {
+    return Status::InvalidParameter("auto beam: step must be positive and base <= max");
   }
   jppgpu_config c{};
   c.beam = sconf.beamSize;
@@ -86,6 +86,7 @@ Status GpuAnalyzer::analyzeBatch(const std::vector<StringPiece>& inputs, bool fu
 
 Status GpuAnalyzer::analyzeBatchPartial(const std::vector<const PartialExample*>& examples, bool fullLattice) {
   partial_.build(examples);
+  partialExamples_ = examples;
   std::vector<StringPiece> inputs;
   for (auto e : examples) inputs.push_back(e ? StringPiece(e->surface) : StringPiece(""));
   return runBatch(inputs, fullLattice, &partial_.view);
@@ -95,43 +96,93 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
   if (!ctx_) return Status::InvalidState("GpuAnalyzer was not initialized");
   releaseResult();
   inputs_ = inputs;
-  text_.clear();
-  offsets_.assign(1, 0);
+  const size_t n = inputs.size();
   size_t total = 0;
   for (auto& s : inputs) total += s.size();
   if (total >= 0xffffffffull) return Status::InvalidParameter("batch is larger than 4 GiB");
-  text_.reserve(total);
-  for (auto& s : inputs) {
-    text_.append(s.data(), s.size());
-    offsets_.push_back((uint32_t)text_.size());
+  groupOf_.assign(n, 0);
+  localIdx_.assign(n, 0);
+  // sentences grouped by their beam: one group unless auto-beam is on
+  std::vector<int32_t> beams;               // beam of group g
+  std::vector<std::vector<uint32_t>> members;
+  if (cfg_.autoBeamStep > 0) {
+    for (size_t i = 0; i < n; ++i) {
+      size_t ncp = 0;  // AnalysisInput::numCodepoints (lead bytes)
+      for (size_t b = 0; b < inputs[i].size(); ++b) ncp += ((unsigned char)inputs[i][b] & 0xc0) != 0x80;
+      int32_t beam = cfg_.autoBeamBase + (int32_t)(ncp / (size_t)cfg_.autoBeamStep);
+      if (beam > cfg_.autoBeamMax) beam = cfg_.autoBeamMax;
+      size_t g = 0;
+      while (g < beams.size() && beams[g] != beam) ++g;
+      if (g == beams.size()) {
+        beams.push_back(beam);
+        members.emplace_back();
+      }
+      groupOf_[i] = (uint32_t)g;
+      localIdx_[i] = (uint32_t)members[g].size();
+      members[g].push_back((uint32_t)i);
+    }
+  } else {
+    beams.push_back(sconf_.beamSize);
+    members.emplace_back();
+    for (size_t i = 0; i < n; ++i) {
+      localIdx_[i] = (uint32_t)i;
+      members[0].push_back((uint32_t)i);
+    }
   }
-  int rc = partial ? jppgpu_analyze_batch_partial(ctx_, text_.data(), offsets_.data(), (uint32_t)inputs.size(), partial, &result_)
-                   : jppgpu_analyze_batch(ctx_, text_.data(), offsets_.data(), (uint32_t)inputs.size(), &result_);
-  if (rc != JPPGPU_OK) return fromCode(rc);
-  rc = jppgpu_result_fetch(result_, fullLattice ? 1 : 0, &view_);
-  if (rc != JPPGPU_OK) return fromCode(rc);
+  std::string text;
+  std::vector<uint32_t> offsets;
+  PartialBatch sub;
+  for (size_t g = 0; g < beams.size(); ++g) {
+    text.clear();
+    offsets.assign(1, 0);
+    for (uint32_t i : members[g]) {
+      text.append(inputs[i].data(), inputs[i].size());
+      offsets.push_back((uint32_t)text.size());
+    }
+    const jppgpu_partial* pg = partial;
+    if (cfg_.autoBeamStep > 0) {
+      int rc = jppgpu_ctx_set_beams(ctx_, beams[g], beams[g], cfg_.rightGbeamCheck, cfg_.rightGbeamSize);
+      if (rc != JPPGPU_OK) return fromCode(rc);
+      if (partial) {  // the group's slice of the constraints
+        std::vector<const PartialExample*> ex;
+        for (uint32_t i : members[g]) ex.push_back(partialExamples_[i]);
+        sub.build(ex);
+        pg = &sub.view;
+      }
+    }
+    groups_.emplace_back();
+    Group& G = groups_.back();
+    G.beam = beams[g];
+    const uint32_t ng = (uint32_t)members[g].size();
+    int rc = pg ? jppgpu_analyze_batch_partial(ctx_, text.data(), offsets.data(), ng, pg, &G.result)
+                : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
+    if (rc != JPPGPU_OK) return fromCode(rc);
+    // host copies are taken right away: the next group's batch invalidates the device side of this result
+    rc = jppgpu_result_fetch(G.result, fullLattice ? 1 : 0, &G.view);
+    if (rc != JPPGPU_OK) return fromCode(rc);
+  }
   // codepoint -> byte offset tables of the well-formed sentences (for surfaces)
   cpOffsets_.clear();
-  cpOffsetsBase_.assign(inputs.size() + 1, 0);
-  for (size_t i = 0; i < inputs.size(); ++i) {
+  cpOffsetsBase_.assign(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
     cpOffsetsBase_[i] = cpOffsets_.size();
-    if (view_.status[i] != JPPGPU_SENT_OK) continue;
+    if (groups_[groupOf_[i]].view.status[localIdx_[i]] != JPPGPU_SENT_OK) continue;
     const unsigned char* p = reinterpret_cast<const unsigned char*>(inputs[i].data());
-    size_t n = inputs[i].size();
-    for (size_t b = 0; b < n;) {
+    size_t nb = inputs[i].size();
+    for (size_t b = 0; b < nb;) {
       cpOffsets_.push_back((uint32_t)b);
       unsigned char c = p[b];
       b += c < 0x80 ? 1 : c < 0xe0 ? 2 : c < 0xf0 ? 3 : 4;
     }
-    cpOffsets_.push_back((uint32_t)n);
+    cpOffsets_.push_back((uint32_t)nb);
   }
-  cpOffsetsBase_[inputs.size()] = cpOffsets_.size();
+  cpOffsetsBase_[n] = cpOffsets_.size();
   return Status::Ok();
 }
 
 Status GpuAnalyzer::sentenceStatus(size_t i) const {
-  if (!result_ || i >= inputs_.size()) return Status::InvalidState("no result for this sentence");
-  switch (view_.status[i]) {
+  if (groups_.empty() || i >= inputs_.size()) return Status::InvalidState("no result for this sentence");
+  switch (groups_[groupOf_[i]].view.status[localIdx_[i]]) {
     case JPPGPU_SENT_OK: return Status::Ok();
     case JPPGPU_SENT_TOO_LONG:
       return Status::InvalidParameter() << "byte size of input string (" << inputs_[i].size()
@@ -144,13 +195,15 @@ Status GpuAnalyzer::sentenceStatus(size_t i) const {
 
 SentenceResult GpuAnalyzer::sentence(size_t i) const {
   SentenceResult r;
+  const jppgpu_result_view& v = groups_[groupOf_[i]].view;
+  const uint32_t k = localIdx_[i];
   r.input = inputs_[i];
-  r.numCodepoints = view_.n_codepoints[i];
-  r.numNodes = view_.n_nodes[i];
-  r.nodes = view_.nodes + view_.node_base[i];
-  r.unk = view_.unk + view_.node_base[i];
-  r.pathNodes = view_.path_nodes + view_.node_base[i];
-  r.pathLen = view_.path_len[i];
+  r.numCodepoints = v.n_codepoints[k];
+  r.numNodes = v.n_nodes[k];
+  r.nodes = v.nodes + v.node_base[k];
+  r.unk = v.unk + v.node_base[k];
+  r.pathNodes = v.path_nodes + v.node_base[k];
+  r.pathLen = v.path_len[k];
   r.cpByteOffsets = cpOffsets_.data() + cpOffsetsBase_[i];
   return r;
 }

@@ -28,7 +28,9 @@
 
 namespace jumanpp_amd {
 
-// core::analysis::AnalyzerConfig (analyzer.h:14-25); the auto-beam members are accepted only as 0
+// core::analysis::AnalyzerConfig (analyzer.h:14-25).  With autoBeamStep > 0 every sentence gets
+// beam = global beam = min(autoBeamBase + codepoints / autoBeamStep, autoBeamMax)
+// (AnalyzerImpl::autoBeamSizes, analyzer_impl.cc:350-361): the batch is analysed in groups of equal beam.
 struct AnalyzerConfig {
   size_t pageSize = 4 * 1024 * 1024;  // unused: device workspaces are sized per batch
   size_t maxInputBytes = 4 * 1024;
@@ -73,17 +75,22 @@ struct SentenceResult {
 class GpuAnalyzer {
   const ModelImage* model_ = nullptr;
   jppgpu_ctx* ctx_ = nullptr;
-  jppgpu_result* result_ = nullptr;
-  jppgpu_result_view view_{};
+  // one device result per group of sentences analysed with the same beam (a single group without auto-beam)
+  struct Group {
+    jppgpu_result* result = nullptr;
+    jppgpu_result_view view{};
+    int32_t beam = 0;
+  };
+  std::vector<Group> groups_;
+  std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
   AnalyzerConfig cfg_;
   ScoringConfig sconf_;
   std::vector<StringPiece> inputs_;
-  std::string text_;
-  std::vector<uint32_t> offsets_;
   std::vector<uint32_t> cpOffsets_;      // concatenated per-sentence codepoint -> byte offset tables
   std::vector<uint64_t> cpOffsetsBase_;
   std::string singleInput_;
   PartialBatch partial_;
+  std::vector<const PartialExample*> partialExamples_;
   Status runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial);
 
   void releaseResult();
@@ -108,7 +115,13 @@ class GpuAnalyzer {
   size_t numSentences() const { return inputs_.size(); }
   Status sentenceStatus(size_t i) const;
   SentenceResult sentence(size_t i) const;
-  const jppgpu_result_view& view() const { return view_; }
+  // the result view holding sentence i and its index inside that view
+  const jppgpu_result_view& viewOf(size_t i, uint32_t* local) const {
+    *local = localIdx_[i];
+    return groups_[groupOf_[i]].view;
+  }
+  // AnalyzerImpl::autoBeamSizes for sentence i: its beam in auto-beam mode, 0 otherwise
+  int32_t autoBeamSize(size_t i) const { return cfg_.autoBeamStep > 0 ? groups_[groupOf_[i]].beam : 0; }
   const ModelImage& model() const { return *model_; }
   const AnalyzerConfig& cfg() const { return cfg_; }
   const ScoringConfig& scoringConfig() const { return sconf_; }

@@ -6,6 +6,7 @@
 //
 // usage: jumanpp_gpu --model=MODEL.img [--beam=5] [--global-beam=6] [--right-check=1]
 //                    [--right-beam=5] [--no-rnn] [--batch=65536] [--device=0] [-o OUT] [INPUT...]
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -36,6 +37,7 @@ struct Conf {
   enum { Juman, Morph, FullMorph, Segment } kind = Juman;
   std::string segmentSeparator = " ";
   bool partialInput = false;  // --partial-input: InputType::PartiallyAnnotated
+  int autoStep = 0;           // --auto-nbest=base:step:max (jumanpp_args.cc:270-279)
 };
 
 bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
@@ -85,7 +87,16 @@ int main(int argc, const char** argv) {
     else if (std::strcmp(argv[i], "--morph") == 0 || std::strcmp(argv[i], "-M") == 0) conf.kind = Conf::Morph;
     else if (std::strcmp(argv[i], "--full-morph") == 0 || std::strcmp(argv[i], "-F") == 0) conf.kind = Conf::FullMorph;
     else if (std::strcmp(argv[i], "--juman") == 0 || std::strcmp(argv[i], "-j") == 0) conf.kind = Conf::Juman;
-    else if (std::strcmp(argv[i], "--partial-input") == 0) conf.partialInput = true;
+    else if (argValue(argc, argv, i, "--auto-nbest", &v)) {
+      // ^(\d+):(\d+):(\d+)$ -> beamSize, autoStep, globalBeam; anything else is ignored like the reference does
+      int a = 0, b = 0, c = 0;
+      char tail = 0;
+      if (std::sscanf(v.c_str(), "%d:%d:%d%c", &a, &b, &c, &tail) == 3 && a >= 0 && b >= 0 && c >= 0) {
+        conf.beam = a;
+        conf.autoStep = b;
+        conf.globalBeam = c;
+      }
+    } else if (std::strcmp(argv[i], "--partial-input") == 0) conf.partialInput = true;
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -108,6 +119,11 @@ int main(int argc, const char** argv) {
   acfg.globalBeamSize = conf.globalBeam;
   acfg.rightGbeamCheck = conf.rightCheck;
   acfg.rightGbeamSize = conf.rightBeam;
+  if (conf.autoStep > 0) {  // env.setAutoBeam(conf.beamSize, conf.autoStep, conf.globalBeam), jumandic_env.cc:34-36
+    acfg.autoBeamBase = conf.beam;
+    acfg.autoBeamStep = conf.autoStep;
+    acfg.autoBeamMax = conf.globalBeam;
+  }
   ScoringConfig sconf;
   sconf.beamSize = conf.beam;
   ScorerDef def;

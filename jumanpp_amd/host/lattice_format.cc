@@ -40,7 +40,8 @@ Status LatticeFormat::initialize(const ModelImage* model, const std::vector<floa
 Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, StringPiece comment) {
   printer_.clear();
   JPPA_RETURN_IF_ERROR(analysis.sentenceStatus(sentence));
-  const jppgpu_result_view& v = analysis.view();
+  uint32_t local = 0;
+  const jppgpu_result_view& v = analysis.viewOf(sentence, &local);
   if (v.beams == nullptr || v.cells == nullptr) {
     return Status::InvalidState("the lattice format needs analyzeBatch(inputs, fullLattice = true)");
   }
@@ -50,12 +51,13 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
     printer_ = "EOS\n";
     return Status::Ok();
   }
-  const uint64_t nb = v.node_base[sentence];
+  const uint64_t nb = v.node_base[local];
   const int32_t beam = v.beam, G = v.global_beam, S = v.num_scorers;
   const jppgpu_beam_slot* beams = v.beams + nb * (uint64_t)beam;
   const float* cells = v.cells + nb * (uint64_t)G * S;
   const uint32_t eos = s.numNodes - 1;
-  const int32_t outputN = topN_;
+  // lattice_format.cc:98-101: with auto-beam the number of printed paths is the sentence's beam
+  const int32_t outputN = analysis.autoBeamSize(sentence) > 0 ? analysis.autoBeamSize(sentence) : topN_;
 
   // LatticeFormatInfo::fillInfo (lattice_format.cc:13-43)
   info_.clear();

@@ -209,3 +209,55 @@ def test_oracle_restatement_is_pinned_by_reference_goldens(golden_dir):
                               os.path.join(golden_dir, gold)], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
         assert ' 0 mismatches' in out.stdout
+
+
+def _fuzz_lines(n, seed):
+    """short lines over a deliberately nasty alphabet: every character class of
+    util/characters.cc (digits and separators, alphabets, kana with prolong marks and small
+    kana, kanji numerals, symbols, brackets, spaces, 4-byte code points, Greek/Cyrillic...)"""
+    import random
+    rnd = random.Random(seed)
+    pools = [
+        'あいうえおかきくけこさしすせそたちつてとなにぬねのはひふへほまみむめもやゆよらりるれろわをんがぎぐげござじずぜぞだぢづでどばびぶべぼぱぴぷぺぽ',
+        'ぁぃぅぇぉっゃゅょゎー〜～ｰ',
+        'アイウエオカキクケコサシスセソタチツテトナニヌネノハヒフヘホマミムメモヤユヨラリルレロワヲンヴヵヶッャュョァィゥェォ',
+        '一二三四五六七八九十百千万億兆〇零何数幾', '0123456789０１２３４５６７８９', '.,．，・／/:：', 'abcXYZａｂｃＸＹＺ',
+        '漢字語彙形態素解析東京都大阪市食べる走った美しい', '　 \t', '！？!?、。「」（）()［］[]【】『』〈〉《》', '＋－＝×÷％＃＄＆＠※○●◎△▽☆★♪→←↑↓〒',
+        'αβγΩабвгД', '𠮷𩸽😀🎉', 'ｱｲｳｴｵｶﾞﾊﾟ', 'ゝゞヽヾ々〆',
+    ]
+    lines = []
+    for _ in range(n):
+        k = rnd.randint(1, 28)
+        s = []
+        while len(s) < k:
+            pool = rnd.choice(pools)
+            run = rnd.randint(1, 4)
+            for _ in range(run):
+                s.append(rnd.choice(pool))
+            if rnd.random() < 0.15:  # onomatopoeia-like repetitions
+                a, b = rnd.choice(pools[0]), rnd.choice(pools[0])
+                s.extend([a, b, a, b])
+        lines.append(''.join(s[:40]))
+    return lines
+
+
+def test_emulated_kernels_on_fuzzed_character_classes(emu_lib, ref_tools, tmp_path):
+    """300 fuzzed lines: node sets of every UNK maker, patterns, scores, beams and paths vs the live reference"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, _, _ = tg._fresh_workload(ref_tools, tmp, 2500, 2, 14, 61, length=10)
+    lines = _fuzz_lines(300, 5)
+    txt = os.path.join(tmp, 'fuzz.txt')
+    open(txt, 'w', encoding='utf-8').write('\n'.join(lines) + '\n')
+    with open(txt, 'rb') as f:
+        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', os.path.join(tmp, 'w.model'),
+                               os.path.join(tmp, 'fuzz.gold')], stdin=f, stderr=subprocess.DEVNULL)
+    meta, gold = G.read_gold(os.path.join(tmp, 'fuzz.gold'))
+    ctx = J.Context(img, lib_path=emu_lib)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, (len(errs), errs[:10])

@@ -393,3 +393,48 @@ def test_gpu_cli_native_jppmdl_with_rnn(cli_gpu, ref_tools, tmp_path):
     meta, gold = G.read_gold(gold_path)
     flips = _assert_juman_equal_up_to_ties(a[1], ref, gold)
     assert flips <= 0.05 * len(lines)
+
+
+# ---- auto beam (--auto-nbest=base:step:max): AnalyzerImpl::autoBeamSizes, analyzer_impl.cc:350-361 ----
+
+def test_auto_beam_byte_identical(cli_emu, ref_tools, tmp_path):
+    """every sentence gets beam = global beam = min(base + codepoints / step, max); sentences of several lengths"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 12, 14, 71, length=44)
+    more = [l[:k] for l, k in zip(lines, (3, 9, 14, 21, 27, 33, 38, 41, 5, 17, 25, 30))]
+    txt = os.path.join(tmp, 'auto.txt')
+    open(txt, 'w', encoding='utf-8').write('\n'.join(lines + more) + '\n\n')
+    model = os.path.join(tmp, 'w.model')
+    for flags in (['--auto-nbest=2:10:8'], ['--auto-nbest=2:10:8', '-s', '8'], ['--auto-nbest=3:7:20', '-s', '5'],
+                  ['--auto-nbest=1:6:5', '--right-check=2', '--right-beam=3', '-M']):
+        ref = _ref_cli(ref_tools, model, flags, txt)
+        rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
+        assert rc == 0 and out == ref, (flags, err[-300:])
+    # with partial annotation on top
+    data = _make_partial_input(lines, 13)
+    pex = os.path.join(tmp, 'pex.txt')
+    open(pex, 'wb').write(data)
+    flags = ['--auto-nbest=2:9:7', '--partial-input']
+    ref = _ref_cli(ref_tools, model, flags, pex)
+    rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [pex])
+    assert rc == 0 and out == ref, err[-300:]
+
+
+@pytest.mark.gpu
+def test_gpu_auto_beam(cli_gpu, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 20000, 400, 18, 73, length=60)
+    cut = [l[:(7 * i) % 60 + 1] for i, l in enumerate(lines)]
+    txt = os.path.join(tmp, 'auto.txt')
+    open(txt, 'w', encoding='utf-8').write('\n'.join(cut) + '\n')
+    model = os.path.join(tmp, 'w.model')
+    for flags in (['--auto-nbest=2:8:12'], ['--auto-nbest=3:10:9', '-s', '3']):
+        ref = _ref_cli(ref_tools, model, flags, txt)
+        rc, out, err = _run(cli_gpu, ['--model=' + model] + flags + [txt])
+        assert rc == 0 and out == ref, (flags, err[-300:])
