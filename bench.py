@@ -223,7 +223,7 @@ def main():
         if dist is not None:
             got = gather_packed(d_offs, d_items, dst=0)   # RCCL: sizes all-gather + payload gather to rank 0
             if rank == 0:
-                total_path += sum(int(g[0][-1]) for g in got)
+                total_path += int(torch.stack([g[0][-1] for g in got]).sum().item())  # one read-back
         else:
             total_path += int(d_offs[-1].item())          # forces completion of the batch
         for k, v in ctx.timings().items():

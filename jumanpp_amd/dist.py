@@ -9,10 +9,13 @@ Sentence order is preserved because shards are contiguous blocks.
 import torch
 import torch.distributed as dist
 
+_bufs = {}  # (device, world, length) -> receive buffers of rank `dst`, reused across calls
+
 
 def gather_packed(offsets, items, dst=0):
     """offsets: int32 [n+1] exclusive scan, items: int32 [m, 2] (8-byte morpheme records).
-    Returns on `dst` a list of (offsets, items) per rank in rank order, None elsewhere."""
+    Returns on `dst` a list of (offsets, items) per rank in rank order, None elsewhere.  The returned
+    tensors are views of receive buffers that the next call reuses."""
     world = dist.get_world_size()
     rank = dist.get_rank()
     dev = offsets.device
@@ -23,17 +26,25 @@ def gather_packed(offsets, items, dst=0):
     dist.all_gather(all_sizes, sizes)
     max_n = max(int(x[0]) for x in all_sizes)
     max_m = max(int(x[1]) for x in all_sizes)
-    payload = torch.zeros(max_n + 1 + 2 * max_m, dtype=torch.int32, device=dev)
+    length = max_n + 1 + 2 * max_m
+    payload = torch.empty(length, dtype=torch.int32, device=dev)
     payload[:n + 1] = offsets
     payload[max_n + 1:max_n + 1 + 2 * m] = items[:m].reshape(-1)
-    bufs = [torch.zeros_like(payload) for _ in range(world)] if rank == dst else None
+    bufs = None
+    if rank == dst:
+        key = (str(dev), world)
+        bufs = _bufs.get(key)
+        if bufs is None or bufs[0].numel() < length:
+            cap = length + length // 8  # slack: the per-batch sizes vary a little
+            bufs = _bufs[key] = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(world)]
+        bufs = [b[:length] for b in bufs]
     dist.gather(payload, bufs, dst=dst)
     if rank != dst:
         return None
     out = []
     for r in range(world):
         rn, rm = int(all_sizes[r][0]), int(all_sizes[r][1])
-        out.append((bufs[r][:rn + 1].clone(), bufs[r][max_n + 1:max_n + 1 + 2 * rm].reshape(-1, 2).clone()))
+        out.append((bufs[r][:rn + 1], bufs[r][max_n + 1:max_n + 1 + 2 * rm].reshape(-1, 2)))
     return out
 
 
