@@ -663,6 +663,11 @@ extern "C" int jppgpu_debug_sweep_dbg(unsigned long long* out16) {
 extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out16, HIP_SYMBOL(jpp::g_sweep_prof), 16 * sizeof(unsigned long long));
+  unsigned long long rc[2] = {0, 0};
+  hipMemcpyFromSymbol(rc, HIP_SYMBOL(g_rnn_cnt), sizeof(rc));
+  if (rc[0]) std::fprintf(stderr, "[jppgpu prof] rnn passes %llu nodes %llu (%.2f nodes per pass)\n", rc[0], rc[1], (double)rc[1] / (double)rc[0]);
+  unsigned long long z2[2] = {0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_cnt), z2, sizeof(z2));
   unsigned long long z[16] = {};
   hipMemcpyToSymbol(HIP_SYMBOL(jpp::g_sweep_prof), z, sizeof(z));
   return 0;

@@ -35,8 +35,10 @@
 #include "k_sweep.h"
 
 #if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
+__device__ unsigned long long g_rnn_cnt[2];
 #define JPP_RPROF_DECL unsigned long long rprof_t = __builtin_readcyclecounter(), rprof_acc[6] = {0, 0, 0, 0, 0, 0}; \
-  const unsigned long long rprof_start = rprof_t
+  const unsigned long long rprof_start = rprof_t; \
+  unsigned long long rprof_pass = 0, rprof_nodes = 0
 #define JPP_RPROF(i)                                         \
   do {                                                       \
     unsigned long long now_ = __builtin_readcyclecounter();  \
@@ -49,6 +51,8 @@
       for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_sweep_prof[8 + q_], rprof_acc[q_]);      \
       atomicAdd(&g_sweep_prof[14], __builtin_readcyclecounter() - rprof_start);            \
       atomicAdd(&g_sweep_prof[15], 1ull);                                                  \
+      atomicAdd(&g_rnn_cnt[0], rprof_pass);                                                \
+      atomicAdd(&g_rnn_cnt[1], rprof_nodes);                                               \
     }                                                                                      \
   } while (0)
 #else
@@ -453,6 +457,9 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         }
       }
       JPP_RPROF(1);
+#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
+      if (lane == 0) { rprof_pass += 1; rprof_nodes += (unsigned long long)cn; }
+#endif
       float ctx[kRnnCN][J];
       float embv[kRnnCN][J];
       float dot[kRnnCN];

@@ -112,41 +112,16 @@ __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == 
 // together.  The reference's summation orders are then rebuilt with shuffles.
 constexpr int kBiPerLane = (spec::kNumBi + 7) / 8;
 
-#ifndef JPP_BI_TABLE_LDS
+// tables in LDS (filled once per kernel)
 #define JPP_BI_TABLE_LDS 1
-#endif
-#if JPP_BI_TABLE_LDS
-// tables in LDS (filled once per kernel): keeps ~20 VGPRs free for occupancy
 struct LaneBi {
   const u64* pre;   // [kNumBi] hash prefixes
   const u8* t01;    // [kNumBi] (t0 << 4) | t1
 };
-#define JPP_LBI_PRE(t, m, j) ((t).pre[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0])
-#define JPP_LBI_T0(t, m, j) ((t).t01[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0] >> 4)
 #define JPP_LBI_T1(t, m, j) ((t).t01[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0] & 15)
-#else
-struct LaneBi {
-  u64 pre_[kBiPerLane];
-  int t0_[kBiPerLane];
-  int t1_[kBiPerLane];
-};
-#define JPP_LBI_PRE(t, m, j) ((t).pre_[m])
-#define JPP_LBI_T0(t, m, j) ((t).t0_[m])
-#define JPP_LBI_T1(t, m, j) ((t).t1_[m])
-#endif
 
-// weights of this lane's bigram features for (p0 = right patterns, t1 = left patterns), both in LDS
-__device__ __forceinline__ void bi_gather(const LaneBi& t, int j, const u64* p0, const u64* t1r,
-                                          const float* __restrict__ W, u32 wmask, bool act, float* w) {
-  u32 idx[kBiPerLane];
-#pragma unroll
-  for (int m = 0; m < kBiPerLane; ++m)
-    idx[m] = (u32)hmix(hmix(JPP_LBI_PRE(t, m, j), p0[JPP_LBI_T0(t, m, j)]), t1r[JPP_LBI_T1(t, m, j)]) & wmask;
-#pragma unroll
-  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? JPP_WLOAD(W, idx[m]) : 0.f;
-}
-
-// same, from the cached first-stage states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
+// weights of this lane's bigram features for one (right node, T1 row) pair, from the cached first-stage
+// states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
 __device__ __forceinline__ void bi_gather_s1(const LaneBi& t, int j, const u64* s1, const u64* t1r,
                                              const float* __restrict__ W, u32 wmask, bool act, float* w) {
   u32 idx[kBiPerLane];
@@ -346,7 +321,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 
   const int grp = lane >> 3, gj = lane & 7;
   LaneBi lbi;
-#if JPP_BI_TABLE_LDS
   __shared__ u64 s_bipre[spec::kNumBi];
   __shared__ u8 s_bit01[spec::kNumBi];
   static_assert(kPat <= 16, "pattern indices are packed in 4 bits");
@@ -363,16 +337,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   lbi.pre = s_bipre;
   lbi.t01 = s_bit01;
   wave_sync();
-#else
-#pragma unroll
-  for (int m = 0; m < kBiPerLane; ++m) {
-    int k = gj + 8 * m;
-    int kk = k < spec::kNumBi ? k : 0;
-    lbi.pre_[m] = kNg.bi_pre[kk];
-    lbi.t0_[m] = kNg.bi_t0[kk];
-    lbi.t1_[m] = kNg.bi_t1[kk];
-  }
-#endif
 
   if (n == 0) {
     // empty input: the reference returns before scoring anything

@@ -9,8 +9,8 @@
 //   PerceptronInfo                             src/core/impl/perceptron_io.h
 //   RnnModelHeader                             src/core/analysis/rnn_scorer_gbeam.cc:353-398,426-470
 //   JumandicIdResolver::initialize             src/jumandic/shared/jumandic_id_resolver.cc:32-78
-// and produces exactly the sections `oracle/ref_dump export` writes into a model image (checked
-// section by section in tests/test_model_reader.py).
+// and produces what `oracle/ref_dump export` writes into a model image; tests/test_host_cli.py runs the same
+// analyses from both and against the reference CLI.
 #include <cstring>
 #include <map>
 
