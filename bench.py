@@ -299,7 +299,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'u64 hashing + f32 adds',
+            'dtype': 'u64+f32',  # 64-bit integer hashing, f32 score sums
             'data': 'synthetic',
             'config': {
                 'workload': (('BASELINE configs[2]: 1xMI355X per rank, perceptron + RNNLM (E=%d), ' % args.rnn_hidden)
@@ -330,7 +330,7 @@ def main():
         }
         if perceptron_only is not None:
             out['perceptron_only'] = perceptron_only
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if dist is not None:

@@ -24,6 +24,10 @@
 #include "jpp_select.h"
 #include "k_decode.h"
 
+#ifndef JPP_SEEDS_EXP
+#define JPP_SEEDS_EXP 0  // developer timing experiments only (1: dictionary seeds only, 2: UNK makers only)
+#endif
+
 namespace jpp {
 
 struct SentView {
@@ -458,8 +462,12 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
       out.ni = nullptr;
       out.na = nullptr;
     }
+#if JPP_SEEDS_EXP != 2
     dic_seeds(M, S, i, out);
+#endif
+#if JPP_SEEDS_EXP != 1
     for (int m = 0; m < M.n_stage1; ++m) run_maker(M, M.makers[m], S, i, out);
+#endif
     if (MODE == 0) {
       B.pos_cnt1[g0 + i] = (u16)(out.n > 0xffff ? 0xffff : out.n);
       u32 n1 = out.n;
