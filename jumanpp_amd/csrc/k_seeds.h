@@ -91,35 +91,62 @@ __device__ __forceinline__ void for_each_entry(const DevModel& M, i32 v, F&& f) 
   }
 }
 
-__device__ __forceinline__ void dic_seeds(const DevModel& M, const SentView& S, u32 i, SeedSink& out) {
+// What the dictionary walk from one start learned about the prefixes of the input: the UNK makers ask the
+// same questions ("is this prefix a word / a prefix of a word / neither"), and every one of them would
+// otherwise walk the double array again from the same start.
+struct WalkInfo {
+  u32 ok_len;  // prefixes of up to ok_len codepoints are nodes of the trie (status != NoNode)
+  u64 leaf;    // bit (len - 1): the prefix of `len` codepoints is a dictionary key (status Ok)
+  bool valid;  // false if the walk went past 64 codepoints (makers then walk themselves)
+};
+
+__device__ __forceinline__ int walk_status(const WalkInfo& w, u32 len) {
+  if (len > w.ok_len) return TRIE_NONODE;
+  return ((w.leaf >> (len - 1)) & 1) ? TRIE_OK : TRIE_NOLEAF;
+}
+
+__device__ __forceinline__ WalkInfo dic_seeds(const DevModel& M, const SentView& S, u32 i, SeedSink& out) {
   TrieCursor c{0, 0};
+  WalkInfo w{0, 0, true};
   for (u32 j = i; j < S.n; ++j) {
     int st = step_cp(M, S, c, j);
+    if (st == TRIE_NONODE) break;
+    const u32 len = j - i + 1;
+    if (len > 64) {
+      w.valid = false;
+    } else {
+      w.ok_len = len;
+      if (st == TRIE_OK) w.leaf |= u64{1} << (len - 1);
+    }
     if (st == TRIE_OK) {
       u32 e = j + 1;
       for_each_entry(M, c.value, [&](i32 ptr) { out.dic(ptr, i, e); });
-    } else if (st == TRIE_NONODE) {
-      break;
     }
   }
+  return w;
 }
 
 __device__ __forceinline__ void single_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
-                                             u32 i, SeedSink& out) {
+                                             u32 i, const WalkInfo& w, SeedSink& out) {
   if ((S.cls[i] & mk.char_class) == 0) return;
-  TrieCursor c{0, 0};
-  int st = step_cp(M, S, c, i);
+  int st;
+  if (w.valid) {
+    st = walk_status(w, 1);
+  } else {
+    TrieCursor c{0, 0};
+    st = step_cp(M, S, c, i);
+  }
   if (st == TRIE_OK) return;
   emit_unk(M, mk, S, out, i, i + 1, st == TRIE_NONODE);
 }
 
 __device__ __forceinline__ void chunking_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
-                                               u32 i, SeedSink& out) {
+                                               u32 i, const WalkInfo& w, SeedSink& out) {
   if ((S.cls[i] & mk.char_class) == 0) return;
   TrieCursor c{0, 0};
   for (u32 j = i; j < S.n; ++j) {
     if ((S.cls[j] & mk.char_class) == 0) break;
-    int st = step_cp(M, S, c, j);
+    int st = w.valid ? walk_status(w, j - i + 1) : step_cp(M, S, c, j);
     if (st == TRIE_NONODE) {
       for (; j < S.n; ++j) {
         if ((S.cls[j] & mk.char_class) == 0) break;
@@ -240,9 +267,18 @@ __device__ __forceinline__ bool dic_pattern_matches(const DevModel& M, const Unk
 }
 
 __device__ __forceinline__ void numeric_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
-                                              u32 i, SeedSink& out) {
+                                              u32 i, const WalkInfo& w, SeedSink& out) {
   u32 length = num_find_longest(S, i, mk.char_class);
   if (length == 0) return;
+  if (w.valid) {
+    // the number is not a dictionary key: the walk already knows which of the two UNK flavours applies
+    // (a key needs the entry list, i.e. the real walk below)
+    const int ws = walk_status(w, length);
+    if (ws != TRIE_OK) {
+      emit_unk(M, mk, S, out, i, i + length, ws == TRIE_NONODE);
+      return;
+    }
+  }
   TrieCursor c{0, 0};
   int st = TRIE_NONODE;
   bool nonode = false;
@@ -300,11 +336,11 @@ __device__ __forceinline__ void onoma_maker(const DevModel& M, const UnkMaker& m
 }
 
 __device__ __forceinline__ void run_maker(const DevModel& M, const UnkMaker& mk, const SentView& S, u32 i,
-                                          SeedSink& out) {
+                                          const WalkInfo& w, SeedSink& out) {
   switch (mk.type) {
-    case UNK_SINGLE: single_maker(M, mk, S, i, out); break;
-    case UNK_CHUNKING: chunking_maker(M, mk, S, i, out); break;
-    case UNK_NUMERIC: numeric_maker(M, mk, S, i, out); break;
+    case UNK_SINGLE: single_maker(M, mk, S, i, w, out); break;
+    case UNK_CHUNKING: chunking_maker(M, mk, S, i, w, out); break;
+    case UNK_NUMERIC: numeric_maker(M, mk, S, i, w, out); break;
     case UNK_ONOMATOPOEIA: onoma_maker(M, mk, S, i, out); break;
     default: break;  // UNK_NORMALIZE is handled by k_norm
   }
@@ -462,22 +498,23 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
       out.ni = nullptr;
       out.na = nullptr;
     }
+    WalkInfo w{0, 0, false};
 #if JPP_SEEDS_EXP != 2
-    dic_seeds(M, S, i, out);
+    w = dic_seeds(M, S, i, out);
 #endif
 #if JPP_SEEDS_EXP != 1
-    for (int m = 0; m < M.n_stage1; ++m) run_maker(M, M.makers[m], S, i, out);
+    for (int m = 0; m < M.n_stage1; ++m) run_maker(M, M.makers[m], S, i, w, out);
 #endif
     if (MODE == 0) {
       B.pos_cnt1[g0 + i] = (u16)(out.n > 0xffff ? 0xffff : out.n);
       u32 n1 = out.n;
-      for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, out);
+      for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, w, out);
       B.pos_cnt2[g0 + i] = (u16)(out.n - n1);
     } else if (MODE == 2) {
       // stage-2 nodes follow the stage-1 nodes (incl. normalize) of this start
       u32 skip = B.pos_cntN[g0 + i];
       out.n += skip;
-      for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, out);
+      for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, w, out);
     }
   }
 }
