@@ -188,11 +188,36 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   }
   wave_sync();
   // ---- B. word ids of the connections ----
+  // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the
+  // first path that passes through it, and copied to the others.
   for (u32 q = lane; q < nq; q += 64) {
     u32 c = conn[q];
     if (c == kNoConn) continue;
-    u32 nd = c & 0x03ffffffu;
-    wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
+    const u32 nd = c & 0x03ffffffu;
+    const u32 b = q / (u32)G, p = q - b * (u32)G;
+    bool first = true;
+    for (u32 pp = 0; pp < p; ++pp) {
+      const u32 c2 = conn[(u64)b * G + pp];
+      if (c2 != kNoConn && (c2 & 0x03ffffffu) == nd) {
+        first = false;
+        break;
+      }
+    }
+    if (first) wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
+  }
+  wave_sync();
+  for (u32 q = lane; q < nq; q += 64) {
+    u32 c = conn[q];
+    if (c == kNoConn) continue;
+    const u32 nd = c & 0x03ffffffu;
+    const u32 b = q / (u32)G, p = q - b * (u32)G;
+    for (u32 pp = 0; pp < p; ++pp) {
+      const u32 c2 = conn[(u64)b * G + pp];
+      if (c2 != kNoConn && (c2 & 0x03ffffffu) == nd) {
+        wid[q] = wid[(u64)b * G + pp];  // pp is a first occurrence: the smallest path index with this node
+        break;
+      }
+    }
   }
   // BOS node (boundary 1): RnnIdContainer::addBos
   if (lane == 0) {
