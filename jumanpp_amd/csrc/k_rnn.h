@@ -187,6 +187,9 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
     }
   }
   wave_sync();
+#if JPP_RNN_EXP == 11
+  return;
+#endif
   // ---- B. word ids of the connections ----
   // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the
   // first path that passes through it, and copied to the others.
@@ -219,6 +222,9 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       }
     }
   }
+#if JPP_RNN_EXP == 12
+  return;
+#endif
   // BOS node (boundary 1): RnnIdContainer::addBos
   if (lane == 0) {
     rn_cnt[1] = 1;
@@ -294,6 +300,9 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       wave_sync();
     }
   }
+#if JPP_RNN_EXP == 13
+  return;
+#endif
   // gbeam index of every connection (= which score cell of the node it owns); published in the word-id
   // scratch, which is no longer needed
   wave_sync();
