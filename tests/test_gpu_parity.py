@@ -193,3 +193,57 @@ def test_gpu_batch_split_invariance(gpu_lib, golden_dir):
     nodes = res1.nodes[nb1 + res1.path_nodes[nb1:nb1 + pl]]
     one = tuple((int(x['start']), int(x['end']), int(x['eptr'])) for x in nodes)
     assert one == whole[3][0]
+
+
+def _packed(ctx, lines):
+    """(offsets, items) of the packed top-1 result of one batch, via the harness' host fetch"""
+    res = ctx.analyze(lines).fetch(full=False)
+    out = []
+    for s in range(len(lines)):
+        nb = int(res.node_base[s])
+        pl = int(res.path_len[s])
+        nodes = res.nodes[nb + res.path_nodes[nb:nb + pl][::-1]][:-1] if pl else res.nodes[:0]  # text order, EOS dropped
+        out.append(nodes.tobytes())
+    return res, out
+
+
+@pytest.mark.parametrize('model', ['mini.img', 'mini_rnn.img'])
+def test_gpu_full_batch_size_invariants(gpu_lib, golden_dir, model):
+    """BASELINE batch size (65 536 sentences of 40 codepoints) through size-independent properties:
+    every path tiles its sentence exactly, the analysis is deterministic, and analysing the batch in one
+    call, in two halves or in shuffled order gives the same per-sentence result."""
+    import random
+    import subprocess as sp
+    import hashlib
+    tmp = os.environ.get('TMPDIR', '/tmp')
+    mdic = os.path.join(tmp, 'fullsize.mdic')
+    with open(mdic, 'w', encoding='utf-8') as f:
+        sp.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), '2500', '--seed', '11'], stdout=f)
+    out = sp.check_output(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, '65536', '--seed', '99', '--oov', '0.08',
+                           '--len', '40'])
+    lines = out.decode('utf-8').split('\n')[:65536]
+    assert len(lines) == 65536
+    ctx = J.Context(os.path.join(golden_dir, model), lib_path=gpu_lib)
+    res, whole = _packed(ctx, lines)
+    assert int((res.status != 0).sum()) == 0
+    # the top-1 path tiles the input: consecutive spans from 0 to the number of codepoints
+    for s in range(0, 65536, 97):
+        spans = np.frombuffer(whole[s], dtype=[('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
+        assert spans['start'][0] == 0 and spans['end'][-1] == len(lines[s])
+        assert (spans['start'][1:] == spans['end'][:-1]).all()
+    digest = hashlib.sha256(b''.join(whole)).hexdigest()
+    # determinism
+    _, again = _packed(ctx, lines)
+    assert hashlib.sha256(b''.join(again)).hexdigest() == digest
+    # split invariance
+    _, a = _packed(ctx, lines[:30000])
+    _, b = _packed(ctx, lines[30000:])
+    assert hashlib.sha256(b''.join(a + b)).hexdigest() == digest
+    # order invariance
+    perm = list(range(65536))
+    random.Random(5).shuffle(perm)
+    _, sh = _packed(ctx, [lines[i] for i in perm])
+    back = [None] * 65536
+    for k, i in enumerate(perm):
+        back[i] = sh[k]
+    assert hashlib.sha256(b''.join(back)).hexdigest() == digest
