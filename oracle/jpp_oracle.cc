@@ -4,13 +4,18 @@
 // path: UTF-8 decode + character classes, entry rows, primitive/pattern
 // feature hashing, unigram (T0) scores, the global-beam boundary sweep with
 // bigram/trigram perceptron scores, right-node cutoff and per-node beams, and
-// the top-1 back-trace.  Each function names the reference code it follows
-// (paths relative to the ku-nlp/jumanpp tree).
+// the top-1 back-trace; and, for models with an RNN part, the RNNLM re-ranker:
+// RNN word ids, the RnnIdContainer path merge, Mikolov NCE contexts and scores
+// with the maxent hash, adjustBeamScores and remakeEosBeam.  Each function
+// names the reference code it follows (paths relative to the ku-nlp/jumanpp tree).
 //
 // Pinning: `jpp_oracle check <model.img> <corpus.txt> <file.gold>` recomputes
 // all of the above from the lattice node table of a golden file written by the
 // REAL reference (oracle/_ref/ref_dump) and requires bit-identical patterns,
-// T0 scores, global beams, beams (structure + float bits) and paths.  The
+// T0 scores, global beams, beams (structure + float bits), perceptron score
+// cells and paths; RNN score cells, RNN-adjusted totals and the re-made EOS
+// beam within the 1e-4 float contract (the reference computes them with Eigen's
+// vectorised exp and reductions, which a scalar loop matches only to ulps).  The
 // lattice *construction* (dictionary walk, UNK makers) is not restated here:
 // for that part the executable oracle is the reference itself (oracle/_ref),
 // see DESIGN.md section 5.  Uses libstdc++'s own std::nth_element/std::sort,
@@ -23,9 +28,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <fstream>
+#include <map>
 #include <numeric>
+#include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 
 typedef uint8_t u8;
@@ -48,6 +57,14 @@ struct Model {
   std::vector<std::vector<int>> uni, bi, tri;  // {index, pattern refs...}
   struct Unk { int type, cls, tmpl, prio, ph; u32 replace; };
   std::vector<Unk> unks;
+  // RNN part (RnnScorerGbeamFactory::load  src/core/analysis/rnn_scorer_gbeam.cc:426-470)
+  struct Rnn {
+    bool present = false;
+    u32 E = 0, order = 0; u64 msize = 0, vsize = 0;
+    float nce = 0; i32 unkId = 0; float unkConst = 0, unkLen = 0, wPerc = 1, wRnn = 1;
+    std::vector<u32> fields, known, unk;
+    std::vector<float> W, emb, nceEmb, maxent, bos;
+  } rnn;
 };
 
 static std::vector<char> readFile(const char* p) {
@@ -93,6 +110,24 @@ static Model loadModel(const char* path) {
       for (int i = 0; i < nn; ++i) {
         int idx = rd32(q); q += 4; auto r = ints(); r.insert(r.begin(), idx);
         (r.size() == 2 ? m.uni : r.size() == 3 ? m.bi : m.tri).push_back(r);
+      }
+    }
+    if (tag == 11) {
+      auto floats = [&](std::vector<float>& v) { v.resize(size / 4); memcpy(v.data(), p, size); };
+      auto words = [&](std::vector<u32>& v) { v.resize(size / 4); memcpy(v.data(), p, size); };
+      if (aux == 1) words(m.rnn.known);
+      if (aux == 2) words(m.rnn.unk);
+      if (aux == 3) floats(m.rnn.W);
+      if (aux == 4) floats(m.rnn.emb);
+      if (aux == 5) floats(m.rnn.nceEmb);
+      if (aux == 6) floats(m.rnn.maxent);
+      if (aux == 100) {
+        Model::Rnn& r = m.rnn; const char* q = p;
+        auto get = [&](void* out, size_t n) { memcpy(out, q, n); q += n; };
+        get(&r.E, 4); get(&r.order, 4); get(&r.msize, 8); get(&r.vsize, 8); get(&r.nce, 4); get(&r.unkId, 4);
+        get(&r.unkConst, 4); get(&r.unkLen, 4); get(&r.wPerc, 4); get(&r.wRnn, 4);
+        u32 nf; get(&nf, 4); r.fields.resize(nf); get(r.fields.data(), 4 * nf);
+        r.present = true;
       }
     }
     pos += size;
@@ -293,7 +328,7 @@ static float unigramScore(const Model& m, const std::vector<u64>& pat, bool last
 }
 
 // ------------------------------------------------------------- the sweep ----
-struct Slot { u16 left, beam; float total; int pb, pr; bool live; };
+struct Slot { u16 left, beam; float total; int pb, pr; bool live; int gi; };  // gi: index of (left, beam) in the boundary's global beam
 
 static inline u32 sortable(float f) { u32 v; memcpy(&v, &f, 4); return (v & 0x80000000u) ? ~v : (v ^ 0x80000000u); }
 
@@ -312,13 +347,248 @@ struct Scorer {
   }
 };
 
+
+// ------------------------------------------------------------ RNN re-rank ----
+// exact-match lookup in a darts-clone double array (DoubleArray::traversal().step == Ok,
+// src/core/dic/darts_trie.cc; unit layout of the darts-clone library the reference vendors)
+static bool daFind(const std::vector<u32>& units, const std::string& key, i32& value) {
+  if (units.empty()) return false;
+  auto off = [](u32 u) { return (u >> 10) << ((u & (1u << 9)) >> 6); };
+  u32 id = 0, unit = units[0];
+  for (unsigned char c : key) {
+    id ^= off(unit) ^ c;
+    if (id >= units.size()) return false;
+    unit = units[id];
+    if ((unit & ((1u << 31) | 0xFFu)) != c) return false;
+  }
+  if (((unit >> 8) & 1) == 0) return false;
+  value = (i32)(units[id ^ off(unit)] & 0x7fffffffu);
+  return true;
+}
+
+// a ConnectionPtr by value: ConnPtrHasher's equality compares the fields, and `previous` is a
+// function of (boundary, left, beam)  (rnn_id_resolver.h:88-103)
+struct Conn {
+  int b, r, left, beam;
+  bool operator<(const Conn& o) const { return std::tie(b, r, left, beam) < std::tie(o.b, o.r, o.left, o.beam); }
+};
+
+static const u64 kPrimes[36] = {  // src/rnn/mikolov_rnn.h:18-25
+    108641969, 116049371, 125925907, 133333309, 145678979, 175308587, 197530793, 234567803, 251851741,
+    264197411, 330864029, 399999781, 407407183, 459258997, 479012069, 545678687, 560493491, 607407037,
+    629629243, 656789717, 716048933, 718518067, 725925469, 733332871, 753085943, 755555077, 782715551,
+    790122953, 812345159, 814814293, 893826581, 923456189, 940740127, 953085797, 985184539, 990122807};
+
+struct RnnPass {
+  const Model& m;
+  const GSent& S;
+  const std::string& line;
+  const std::vector<u32>& boff;                               // byte offset of every codepoint (+ end)
+  const std::vector<std::vector<std::vector<i32>>>& rows;     // entry rows [b][r]
+  std::vector<std::vector<std::vector<Slot>>>& beams;
+  const std::vector<std::vector<Conn>>& gbeams;               // global beam of every boundary: {left node b, r, left index, its beam slot}
+  const std::vector<std::vector<std::vector<float>>>& cell0;  // perceptron score cells [b][r][gi]
+  std::vector<std::vector<std::vector<float>>>& cell1;        // out: rnn score cells [b][r][gi]
+
+  struct Node { i32 id, idx, boundary, length; int prev, nextInBnd; u64 hash; bool published; };
+  struct Score { Conn lat; int next, rnn; };
+  struct Bnd { int node = -1, scores = -1, nodeCnt = 0, scoreCnt = 0; };
+  struct Coord { int boundary, length; i32 id; };
+  std::vector<Node> nodes;
+  std::vector<Score> scores;
+  std::vector<Bnd> bnds;
+  std::map<std::tuple<int, int, i32>, int> crdCache;
+  std::map<Conn, int> ptrCache;
+  std::map<std::pair<int, int>, Coord> nodeCache;
+
+  Conn previousOf(const Conn& c) const {
+    auto e = S.bnds[c.b].ends[c.left];
+    const Slot& sl = beams[e.first][e.second][c.beam];
+    return Conn{e.first, e.second, sl.left, sl.beam};
+  }
+
+  // RnnIdResolver::reprOf + RnnIdContainer::resolveId  rnn_id_resolver.cc:157-171,291-323
+  // (RnnReprBuilder: addInt = varint of the u32, addString = bytes + varint(1), rnn_id_resolver.h:22-35)
+  const Coord& resolveId(const Conn& c) {
+    auto it = nodeCache.find({c.b, c.r});
+    if (it != nodeCache.end()) return it->second;
+    const GNode& n = S.bnds[c.b].nodes[c.r];
+    std::string repr;
+    for (u32 f : m.rnn.fields) {
+      i32 v = rows[c.b][c.r][f];
+      if (v >= 0) { u32 x = (u32)v; while (x >= 0x80) { repr.push_back((char)(x | 0x80)); x >>= 7; } repr.push_back((char)x); }
+      else { repr.append(line, boff[n.start], boff[n.end] - boff[n.start]); repr.push_back((char)1); }
+    }
+    i32 id;
+    if (!daFind(n.eptr >= 0 ? m.rnn.known : m.rnn.unk, repr, id)) id = m.rnn.unkId;
+    return nodeCache[{c.b, c.r}] = Coord{c.b, (int)(n.end - n.start), id};
+  }
+
+  void addScore(int node, const Conn& c) {  // :277-285
+    Bnd& b = bnds[nodes[node].boundary];
+    scores.push_back(Score{c, b.scores, node});
+    b.scores = (int)scores.size() - 1;
+    b.scoreCnt += 1;
+  }
+
+  // RnnIdContainer::addPrevChain  :206-251 -- returns (first, last) of the chain of rnn nodes for `c`;
+  // a hash hit attaches the connection to the NEWEST node of the coordinate (it->second), not to the
+  // node whose hash matched: that is what the reference does and what the scores depend on
+  std::pair<int, int> addPrevChain(const Conn& c) {
+    auto ins = ptrCache.emplace(c, -1);
+    if (!ins.second) return {ins.first->second, ins.first->second};
+    auto span = addPrevChain(previousOf(c));
+    int prev = span.second;
+    Coord crd = resolveId(c);
+    u64 data = (u64)(u32)crd.id | ((u64)(u32)crd.length << 32);
+    u64 v = (nodes[prev].hash ^ data) * 0x6eed0e9da4d94a4fULL;   // FastHash1::mix  src/util/fast_hash.h:46-51
+    u64 hash = v ^ (v >> 32);
+    auto it = crdCache.find(std::make_tuple(crd.boundary, crd.length, crd.id));
+    if (it != crdCache.end()) {
+      for (int cached = it->second; cached >= 0; cached = nodes[cached].nextInBnd) {
+        if (nodes[cached].hash == hash) {
+          ptrCache[c] = it->second;
+          addScore(it->second, c);
+          return {it->second, it->second};
+        }
+      }
+    }
+    nodes.push_back(Node{crd.id, -1, c.b, crd.length, prev, -1, hash, false});
+    int fresh = (int)nodes.size() - 1;
+    ptrCache[c] = fresh;
+    return {span.first, fresh};
+  }
+
+  void addPath(Conn c) {  // :253-275
+    auto path = addPrevChain(c);
+    for (int last = path.second; last != path.first; last = nodes[last].prev) {
+      Bnd& b = bnds[nodes[last].boundary];
+      nodes[last].idx = b.nodeCnt;
+      nodes[last].nextInBnd = b.node;
+      nodes[last].published = true;
+      b.node = last;
+      b.nodeCnt += 1;
+      addScore(last, c);
+      Coord crd = resolveId(c);
+      crdCache[std::make_tuple(crd.boundary, crd.length, crd.id)] = last;
+      c = previousOf(c);
+    }
+  }
+
+  // MikolovRnnImplParallel::computeNewContext  src/rnn/mikolov_rnn_impl.h:202-215
+  void newContext(const float* in, const float* emb, float* out) const {
+    const u32 E = m.rnn.E;
+    for (u32 i = 0; i < E; ++i) {
+      float acc = 0.f;
+      for (u32 k = 0; k < E; ++k) acc += m.rnn.W[(size_t)i * E + k] * in[k];
+      acc += emb[i];
+      out[i] = 1.0f / (1.0f + std::exp(-acc));
+    }
+  }
+
+  // MikolovIndexCalculator::calcIndices / MikolovScoreCalculator::calcScoresN  mikolov_rnn_impl.h:21-131
+  float maxent(const std::vector<i32>& ctx, i32 word) const {
+    const u64 hashMax = m.rnn.msize - m.rnn.vsize;
+    float res = 0.f;
+    for (size_t i = 0; i <= ctx.size(); ++i) {
+      u64 x = kPrimes[0] * kPrimes[1];
+      for (size_t j = 1; j <= i; ++j) x += kPrimes[(i * kPrimes[j] + j) % 36] * ((u64)(int64_t)ctx[j - 1] + 1);
+      u64 idx = ((x % hashMax) + (u64)(int64_t)word) % hashMax;
+      res = i == 0 ? m.rnn.maxent[idx] : res + m.rnn.maxent[idx];
+    }
+    return res;
+  }
+
+  void run(float wPerc, float wRnn) {
+    const int nb = (int)S.bnds.size(), eos = nb - 1;
+    const u32 E = m.rnn.E;
+    // RnnIdContainer::reset + addBos  :325-363
+    bnds.assign(nb, Bnd{});
+    nodes.push_back(Node{0, 0, 0, 0, -1, -1, 0, true});
+    nodes.push_back(Node{0, 0, 1, 0, 0, -1, 0xdeadbeef0000ULL, true});
+    bnds[1].node = 1; bnds[1].nodeCnt = 1;
+    crdCache[std::make_tuple(1, 0, 0)] = 1;
+    nodeCache[{1, 0}] = Coord{1, 0, 0};
+    nodeCache[{eos, 0}] = Coord{eos, 0, 0};
+    // RnnIdResolver::resolveIdsAtGbeam  :173-195 (one fake connection per EOS global-beam entry)
+    ptrCache[Conn{1, 0, 0, 0}] = 1;
+    const auto& eg = gbeams[eos];
+    for (size_t i = 0; i < eg.size(); ++i) addPath(Conn{eos, 0, eg[i].left, eg[i].beam});  // fakeConnection :365-375
+    // GbeamRnnState::computeContext  rnn_scorer_gbeam.cc:142-157 (bos state: computeBosState :37-46)
+    std::vector<std::vector<float>> ctx(nb);
+    ctx[1].assign(E, 0.f);
+    { std::vector<float> zero(E, 0.f); newContext(zero.data(), &m.rnn.emb[0], ctx[1].data()); }
+    for (int b = 2; b < eos; ++b) {
+      ctx[b].assign((size_t)bnds[b].nodeCnt * E, 0.f);
+      for (int nd = bnds[b].node; nd >= 0; nd = nodes[nd].nextInBnd) {
+        const Node& N = nodes[nd]; const Node& P = nodes[N.prev];
+        size_t embId = N.id == -1 ? 0 : (size_t)N.id;
+        newContext(&ctx[P.boundary][(size_t)P.idx * E], &m.rnn.emb[embId * E], &ctx[b][(size_t)N.idx * E]);
+      }
+    }
+    // scoreBoundary + copyScoresToLattice  :159-267 (every maxent history slot holds prev->id, :171-188)
+    for (int b = 2; b <= eos; ++b) {
+      if (bnds[b].nodeCnt == 0) continue;
+      for (int sc = bnds[b].scores; sc >= 0; sc = scores[sc].next) {
+        const Node& N = nodes[scores[sc].rnn]; const Node& P = nodes[N.prev];
+        float score;
+        if (N.id == m.rnn.unkId) score = m.rnn.unkConst + m.rnn.unkLen * N.length;
+        else {
+          size_t embId = N.id == -1 ? 0 : (size_t)N.id;
+          const float* c = &ctx[P.boundary][(size_t)P.idx * E]; const float* e = &m.rnn.nceEmb[embId * E];
+          float dot = 0.f; for (u32 k = 0; k < E; ++k) dot += e[k] * c[k];
+          std::vector<i32> hist(m.rnn.order - 1, P.id);
+          dot += maxent(hist, N.id);
+          score = dot - m.rnn.nce;
+        }
+        const Conn& lat = scores[sc].lat;
+        for (size_t i = 0; i < gbeams[b].size(); ++i)
+          if (gbeams[b][i].left == lat.left && gbeams[b][i].beam == lat.beam) cell1[b][lat.r][i] = score;
+      }
+    }
+    // ScoreProcessor::adjustBeamScores  src/core/analysis/score_processor.cc:521-549
+    for (int b = 3; b < nb; ++b)
+      for (const Conn& el : gbeams[b]) {
+        Slot& e = beams[el.b][el.r][el.beam];
+        float local = 0.f;
+        local += cell0[el.b][el.r][e.gi] * wPerc;
+        local += cell1[el.b][el.r][e.gi] * wRnn;
+        local += beams[e.pb][e.pr][e.beam].total;
+        e.total = local;
+      }
+    // ScoreProcessor::remakeEosBeam  :551-576 (+ makeT0Beam :426-469)
+    const int G = (int)eg.size();
+    std::vector<float> full(G);
+    for (int i = 0; i < G; ++i) {
+      float beamScore = beams[eg[i].b][eg[i].r][eg[i].beam].total;
+      float local = 0.f;
+      local += cell0[eos][0][i] * wPerc;
+      local += cell1[eos][0][i] * wRnn;
+      full[i] = local + beamScore;
+    }
+    std::vector<u32> idx(G); std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](u32 a, u32 bb) { return full[a] > full[bb]; });
+    auto& row = beams[eos][0];
+    for (size_t q = 0; q < row.size(); ++q) {
+      if (q < (size_t)G) { const Conn& el = eg[idx[q]]; row[q] = Slot{(u16)el.left, (u16)el.beam, full[idx[q]], el.b, el.r, true, (int)idx[q]}; }
+      else row[q].live = false;
+    }
+  }
+};
+
+static size_t G_eos(const std::vector<std::vector<Conn>>& gb, size_t nb) { return gb[nb - 1].size(); }
+
 int main(int argc, char** argv) {
   if (argc != 5) { fprintf(stderr, "usage: jpp_oracle check|time model.img corpus.txt file.gold\n"); return 2; }
   bool timing = std::string(argv[1]) == "time";
   Model m = loadModel(argv[2]);
   std::vector<std::string> lines; { std::ifstream f(argv[3]); std::string l; while (std::getline(f, l)) lines.push_back(l); }
   Gold g = loadGold(argv[4]);
-  if (g.nsc != 1) { fprintf(stderr, "jpp_oracle restates the perceptron path only (golden has %u scorers)\n", g.nsc); return 2; }
+  if (g.nsc > 2 || (g.nsc == 2 && !m.rnn.present)) { fprintf(stderr, "golden has %u scorers, the model %s RNN part\n", g.nsc, m.rnn.present ? "an" : "no"); return 2; }
+  if (g.nsc == 2 && (m.rnn.order < 1 || m.rnn.order > 4 || m.rnn.msize <= m.rnn.vsize)) { fprintf(stderr, "unsupported RNN header\n"); return 2; }
+  const bool rnn = g.nsc == 2;
+  const float kTol = 1e-4f;  // relative to max(1, |reference|): the float contract for RNN scores
+  auto close = [&](float a, float e) { return std::fabs(a - e) <= kTol * std::max(1.0f, std::fabs(e)); };
   Scorer sc{m};
   const int nbi = (int)m.bi.size(), ntri = (int)m.tri.size(), NP = (int)g.npat;
   long bad = 0, checked = 0;
@@ -338,12 +608,17 @@ int main(int argc, char** argv) {
     std::vector<std::vector<std::vector<u64>>> P(nb);
     std::vector<std::vector<float>> T0(nb);
     std::vector<std::vector<std::vector<Slot>>> beams(nb);
+    std::vector<std::vector<std::vector<i32>>> rows(nb);
+    std::vector<std::vector<Conn>> gbeams(nb);
+    std::vector<std::vector<std::vector<float>>> cell0(nb), cell1(nb);
     for (size_t b = 0; b < nb; ++b) {
       GBnd& B = S.bnds[b];
-      P[b].resize(B.R); T0[b].resize(B.R); beams[b].assign(B.R, std::vector<Slot>(g.beam, Slot{0, 0, 0.f, 0, 0, false}));
+      P[b].resize(B.R); T0[b].resize(B.R); beams[b].assign(B.R, std::vector<Slot>(g.beam, Slot{0, 0, 0.f, 0, 0, false, 0}));
+      rows[b].resize(B.R); cell0[b].resize(B.R); cell1[b].resize(B.R);
       for (u32 r = 0; r < B.R; ++r) {
         if (b < 2) { P[b][r].assign(NP, (u64)(u32)kBOS); continue; }  // LatticeConstructionContext::addBos lattice_builder.cc:173-179
         i32 row[16]; entryRow(m, B.nodes[r], row);
+        rows[b][r].assign(row, row + m.numFeatures);
         std::vector<u64> pat; patternsOf(m, B.nodes[r], row, cps, cls, pat);
         T0[b][r] = unigramScore(m, pat, r == B.R - 1);
         P[b][r].assign(pat.begin(), pat.begin() + NP);
@@ -356,8 +631,8 @@ int main(int argc, char** argv) {
       }
     }
     // AnalyzerImpl::bootstrapAnalysis  analyzer_impl.cc:179-195
-    beams[0][0][0] = Slot{0, 0, 0.f, -1, -1, true};
-    beams[1][0][0] = Slot{0, 0, 0.f, 0, 0, true};
+    beams[0][0][0] = Slot{0, 0, 0.f, -1, -1, true, 0};
+    beams[1][0][0] = Slot{0, 0, 0.f, 0, 0, true, 0};
     for (size_t b = 2; b < nb; ++b) {
       GBnd& B = S.bnds[b];
       const u32 R = B.R;
@@ -384,6 +659,7 @@ int main(int argc, char** argv) {
         t2[i] = P[sl.pb][sl.pr].data();                     // gatherT2 score_processor.cc:391-409
         int found = -1; for (int j = 0; j < i; ++j) if (gl[j] == gl[i]) { found = t1id[j]; break; }  // dedupT1 :363-377
         if (found >= 0) t1id[i] = found; else { t1id[i] = U++; firstOf.push_back(i); }
+        gbeams[b].push_back(Conn{lnode[i].first, lnode[i].second, gl[i], gs[i]});
       }
       if (!timing) {
         if ((size_t)G != B.gbLeft.size()) fail(si, "gbeam size", (int)b, 0);
@@ -415,7 +691,8 @@ int main(int argc, char** argv) {
         const u64* p0 = P[b][t].data();
         int cnt = kept ? G : c;
         std::vector<float> tot(cnt);
-        for (int i = 0; i < c; ++i) { float v = pres[i][t]; v += 0.f; v += gsc[i]; tot[i] = v; }  // copyT0Scores(head, 0) :411-424
+        cell0[b][t].assign(G, 0.f); cell1[b][t].assign(G, 0.f);
+        for (int i = 0; i < c; ++i) { float v = pres[i][t]; v += 0.f; cell0[b][t][i] = v; v += gsc[i]; tot[i] = v; }  // copyT0Scores(head, 0) :411-424
         if (kept && G > c) {
           // applyBiTriFullKernel  src/core/impl/feature_impl_ngram_partial_kernels.h:19-111
           std::vector<float> biS(U);
@@ -429,7 +706,7 @@ int main(int argc, char** argv) {
             float res;
             if (i < G - 1) { float r1 = 0, r2 = 0; for (int k = 0; k < ntri; ++k) (k & 1 ? r2 : r1) += wt[k]; res = biS[t1id[i]] + r1 + r2; }
             else res = biS[t1id[i]] + sc.rr(wt, 4);
-            float v = res; v += T0[b][t]; v += gsc[i]; tot[i] = v;    // copyT0Scores(tail, t0Score)
+            float v = res; v += T0[b][t]; cell0[b][t][i] = v; v += gsc[i]; tot[i] = v;    // copyT0Scores(tail, t0Score)
           }
         }
         // makeT0Beam :426-469 (std::sort on indices, like the reference)
@@ -437,24 +714,70 @@ int main(int argc, char** argv) {
         std::sort(idx.begin(), idx.end(), [&](u32 a, u32 bb) { return tot[a] > tot[bb]; });
         auto& row = beams[b][t];
         for (u32 q = 0; q < g.beam; ++q) {
-          if (q < (u32)cnt) row[q] = Slot{gl[idx[q]], gs[idx[q]], tot[idx[q]], lnode[idx[q]].first, lnode[idx[q]].second, true};
+          if (q < (u32)cnt) row[q] = Slot{gl[idx[q]], gs[idx[q]], tot[idx[q]], lnode[idx[q]].first, lnode[idx[q]].second, true, (int)idx[q]};
           else row[q].live = false;
         }
         if (!timing) {
           const GNode& gn = B.nodes[t];
           if (G > 0 && (gn.kept != 0) != kept) fail(si, "kept", (int)b, (int)t);
+          for (int i = 0; i < cnt; ++i)   // perceptron score cells of the connections that were scored
+            if (memcmp(&gn.cells[(size_t)i * g.nsc], &cell0[b][t][i], 4)) fail(si, "perceptron cell", (int)b, (int)t);
+          if (rnn && b == nb - 1) continue;   // the EOS beam is re-made after the RNN pass
           for (u32 q = 0; q < g.beam; ++q) {
             const auto& gsl = gn.beam[q];
             if ((gsl.valid != 0) != row[q].live) { fail(si, "beam liveness", (int)b, (int)t); continue; }
             if (!row[q].live) continue;
             if (gsl.cp[1] != row[q].left || gsl.cp[3] != row[q].beam || gsl.prev[0] != row[q].pb || gsl.prev[1] != row[q].pr ||
-                memcmp(&gsl.total, &row[q].total, 4)) fail(si, "beam slot", (int)b, (int)t);
+                (!rnn && memcmp(&gsl.total, &row[q].total, 4))) fail(si, "beam slot", (int)b, (int)t);
           }
         }
       }
     }
+    bool topTie = false;
+    if (rnn) {
+      // AnalyzerImpl::computeScoresGbeam's scorer loop  analyzer_impl.cc:286-294
+      std::vector<u32> boff; { std::vector<u32> c2; std::vector<i32> k2; size_t p = 0; const std::string& l = lines[si];
+        while (p < l.size()) { boff.push_back((u32)p); u8 b0 = (u8)l[p]; p += b0 > 0xef ? 4 : b0 > 0xdf ? 3 : b0 > 0x7f ? 2 : 1; } boff.push_back((u32)l.size()); }
+      RnnPass pass{m, S, lines[si], boff, rows, beams, gbeams, cell0, cell1};
+      pass.run(m.rnn.wPerc, m.rnn.wRnn);
+      if (!timing) {
+        // totals and RNN cells are defined on the connections of the surviving EOS paths only
+        const GNode& ge = S.bnds[nb - 1].nodes[0];
+        std::set<std::tuple<int, int, int>> onPath; std::vector<std::tuple<int, int, int>> stack;
+        for (u32 q = 0; q < g.beam; ++q) if (ge.beam[q].valid) stack.push_back(std::make_tuple((int)nb - 1, 0, (int)q));
+        while (!stack.empty()) {
+          auto key = stack.back(); stack.pop_back();
+          int b = std::get<0>(key), r = std::get<1>(key), q = std::get<2>(key);
+          if (b < 2 || !onPath.insert(key).second) continue;
+          const auto& gsl = S.bnds[b].nodes[r].beam[q];
+          stack.push_back(std::make_tuple((int)gsl.prev[0], (int)gsl.prev[1], (int)gsl.prev[2]));
+          if (b == (int)nb - 1) continue;
+          const Slot& sl = beams[b][r][q];
+          if (!sl.live) { fail(si, "on-path slot not live", b, r); continue; }
+          if (!close(sl.total, gsl.total)) fail(si, "rnn-adjusted total", b, r);
+          if (!close(cell1[b][r][sl.gi], S.bnds[b].nodes[r].cells[(size_t)sl.gi * 2 + 1])) fail(si, "rnn cell", b, r);
+        }
+        // re-made EOS beam: same candidates and totals; candidates tied within the tolerance may swap ranks
+        std::vector<std::tuple<int, int, float>> ref, dev;
+        for (u32 q = 0; q < g.beam; ++q) {
+          if (ge.beam[q].valid) ref.push_back(std::make_tuple((int)ge.beam[q].cp[1], (int)ge.beam[q].cp[3], ge.beam[q].total));
+          const Slot& sl = beams[nb - 1][0][q];
+          if (sl.live) dev.push_back(std::make_tuple((int)sl.left, (int)sl.beam, sl.total));
+        }
+        if (ref.size() != dev.size()) fail(si, "EOS beam size", (int)nb - 1, 0);
+        float cutoff = 0.f; for (auto& x : ref) cutoff = (&x == &ref[0]) ? std::get<2>(x) : std::min(cutoff, std::get<2>(x));
+        for (auto& x : ref) {
+          bool found = false;
+          for (auto& d : dev) if (std::get<0>(d) == std::get<0>(x) && std::get<1>(d) == std::get<1>(x)) { found = true; if (!close(std::get<2>(d), std::get<2>(x))) fail(si, "EOS total", (int)nb - 1, 0); }
+          if (!found && !close(std::get<2>(x), cutoff)) fail(si, "EOS candidate missing", (int)nb - 1, 0);
+        }
+        for (u32 i = 0; i < (u32)G_eos(gbeams, nb); ++i)
+          if (!close(cell1[nb - 1][0][i], ge.cells[(size_t)i * 2 + 1])) fail(si, "EOS rnn cell", (int)nb - 1, (int)i);
+        topTie = ref.size() > 1 && close(std::get<2>(ref[0]), std::get<2>(ref[1]));
+      }
+    }
     // top-1 path (AnalysisPath::fillIn  src/core/analysis/analysis_result.cc:25-76)
-    if (!timing) {
+    if (!timing && !topTie) {
       std::vector<std::pair<u16, u16>> path; int pb = (int)nb - 1, pr = 0; u32 slot = 0;
       while (pb >= 2 && beams[pb][pr][slot].live) { path.push_back({(u16)pb, (u16)pr}); Slot s = beams[pb][pr][slot]; pb = s.pb; pr = s.pr; slot = s.beam; }
       if (path != S.path) fail(si, "path", 0, 0);

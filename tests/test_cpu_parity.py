@@ -200,12 +200,13 @@ def test_product_library_fails_loudly_without_gpu(gpu_lib, golden_dir):
 
 def test_oracle_restatement_is_pinned_by_reference_goldens(golden_dir):
     """oracle/jpp_oracle.cc (plain C++ restatement of the scoring core, using libstdc++'s own
-    nth_element/sort) must reproduce the reference's golden vectors bit-for-bit."""
+    nth_element/sort) must reproduce the reference's golden vectors: bit-for-bit on the perceptron
+    path, and with the RNN re-ranker the same RNN lattice, score cells and totals within 1e-4."""
     import __graft_entry__ as ge
     ge.build_oracle_port()
     exe = os.path.join(ROOT, 'oracle', '_port', 'jpp_oracle')
-    for gold in ('mini.gold', 'mini_b3.gold'):
-        out = subprocess.run([exe, 'check', os.path.join(golden_dir, 'mini.img'), os.path.join(golden_dir, 'mini.txt'),
+    for image, gold in (('mini.img', 'mini.gold'), ('mini.img', 'mini_b3.gold'), ('mini_rnn.img', 'mini_rnn.gold')):
+        out = subprocess.run([exe, 'check', os.path.join(golden_dir, image), os.path.join(golden_dir, 'mini.txt'),
                               os.path.join(golden_dir, gold)], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
         assert ' 0 mismatches' in out.stdout
