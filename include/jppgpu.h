@@ -114,6 +114,10 @@ typedef struct {
   float weight_rnn;         /* ScorerDef::scoreWeights[1] */
 } jppgpu_config;
 
+/* EntryPtr::BOS() / EntryPtr::EOS() raw values (src/core/core_types.h:44-58) */
+#define JPPGPU_ENTRY_BOS ((int32_t)0x80000000)
+#define JPPGPU_ENTRY_EOS ((int32_t)0x80000002)
+
 typedef struct {
   int32_t entry_ptr;   /* EntryPtr raw: >=0 dictionary, BOS/EOS specials, otherwise ~(unk ordinal) */
   uint16_t start;      /* codepoint span */
@@ -221,8 +225,17 @@ int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, const uint32
 
 int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                 uint32_t total_bytes, void* stream, jppgpu_result** out);
-/* Copy results to the host.  full=0: status, node table, UNK table, top-1 paths.
- * full=1: additionally the whole lattice (patterns, T0, beams, cells, global beams). */
+/* Copy results to the host.  full=0 (JPPGPU_FETCH_BASIC): status, node table, UNK table, top-1 paths.
+ * full=1 (JPPGPU_FETCH_FULL): additionally the whole lattice (patterns, T0, beams, cells, global beams).
+ * full=2 (JPPGPU_FETCH_TOP1): only what AnalysisPath::fillIn + OutputManager::locate read for the best
+ *   analysis (analysis_result.cc:25-76, output.cc:69-111): the node and UNK tables hold just the nodes
+ *   of each sentence's top-1 path, compacted on the device, in path order (EOS first).  In this view
+ *   n_nodes[i] == path_len[i], node_base[i] is the sentence's offset in the compact tables and
+ *   path_nodes[node_base[i] + k] == k; BOS/EOS are recognised by their entry_ptr, not their index.
+ *   About 10x fewer bytes cross PCIe than with full=0. */
+#define JPPGPU_FETCH_BASIC 0
+#define JPPGPU_FETCH_FULL 1
+#define JPPGPU_FETCH_TOP1 2
 /* The arrays of a fetched view are host copies owned by the result: they stay valid until
  * jppgpu_result_release, also across later batches on the same context (only the device-resident
  * side -- further fetches, jppgpu_result_pack -- is invalidated by the next batch). */

@@ -139,7 +139,7 @@ struct jppgpu_result {
   Batch B{};
   u64 generation = 0;
   Config cfg{};  // configuration the batch was analysed with (jppgpu_ctx_set_beams may change the context's later)
-  bool fetched_basic = false, fetched_full = false;
+  bool fetched_basic = false, fetched_full = false, fetched_top1 = false;
   // host copies
   std::vector<i32> status;
   std::vector<u32> ncp, nnodes, path_len, path_nodes;
@@ -153,6 +153,12 @@ struct jppgpu_result {
   std::vector<jppgpu_beam_slot> beams;
   std::vector<u8> kept;
   std::vector<u32> byte_off;
+  // JPPGPU_FETCH_TOP1: compact tables of the top-1 paths
+  std::vector<i32> t1_status;
+  std::vector<u32> t1_ncp, t1_len, t1_idx;
+  std::vector<u64> t1_base, t1_zero;
+  std::vector<jppgpu_node> t1_nodes;
+  std::vector<jppgpu_unk> t1_unk;
 };
 
 struct jppgpu_ctx {
@@ -161,7 +167,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, top1_nodes, top1_aux, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, reach;
@@ -407,7 +413,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
@@ -734,6 +740,51 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   const u32 n = B.n_sent;
   const u64 N = B.total_nodes;
   const int G = res->cfg.gbeam, beam = res->cfg.beam;
+  if (full == JPPGPU_FETCH_TOP1) {
+    if (!res->fetched_top1) {
+      // an upper bound of the compact size: a path holds at most one node per codepoint, plus EOS
+      const u64 cap = (u64)B.total_bytes + n + 1;
+      if (!(ctx->pack_cnt.ensure(((size_t)n + 1) * 4) && ctx->pack_off.ensure(((size_t)n + 2) * 8) &&
+            ctx->top1_nodes.ensure(cap * sizeof(NodeInfo)) && ctx->top1_aux.ensure(cap * sizeof(NodeAux))))
+        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (top-1 fetch)");
+      if (n) JPP_LAUNCH(k_top1_count, (n + 255) / 256, 256, st, B, ctx->pack_cnt.as<u32>());
+      JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
+      if (n) JPP_LAUNCH(k_top1_gather, (n + 3) / 4, 256, st, B, (const u64*)ctx->pack_off.as<u64>(),
+                        ctx->top1_nodes.as<NodeInfo>(), ctx->top1_aux.as<NodeAux>());
+      pull(res->t1_status, B.sent_status, n, st);
+      pull(res->t1_ncp, B.sent_ncp, n, st);
+      pull(res->t1_len, ctx->pack_cnt.p, n, st);
+      pull(res->t1_base, ctx->pack_off.p, (size_t)n + 1, st);
+      rt_sync(st);
+      const u64 M = n ? res->t1_base[n] : 0;
+      pull(res->t1_nodes, ctx->top1_nodes.p, M, st);
+      pull(res->t1_unk, ctx->top1_aux.p, M, st);
+      // every sentence's path is 0, 1, 2, ... in its compact table
+      res->t1_idx.resize((size_t)M);
+      for (u32 s = 0; s < n; ++s)
+        for (u32 k = 0; k < res->t1_len[s]; ++k) res->t1_idx[res->t1_base[s] + k] = k;
+      res->t1_zero.assign(n, 0);
+      rt_sync(st);
+      res->fetched_top1 = true;
+    }
+    memset(v, 0, sizeof(*v));
+    v->n_sentences = n;
+    v->status = res->t1_status.data();
+    v->n_codepoints = res->t1_ncp.data();
+    v->n_nodes = res->t1_len.data();
+    v->node_base = res->t1_base.data();
+    v->bnd_base = res->t1_zero.data();
+    v->total_nodes = n ? res->t1_base[n] : 0;
+    v->total_boundaries = 0;
+    v->beam = beam;
+    v->global_beam = G;
+    v->num_scorers = res->cfg.nscorers;
+    v->path_len = res->t1_len.data();
+    v->path_nodes = res->t1_idx.data();
+    v->nodes = res->t1_nodes.data();
+    v->unk = res->t1_unk.data();
+    return JPPGPU_OK;
+  }
   if (!res->fetched_basic) {
     pull(res->status, B.sent_status, n, st);
     pull(res->ncp, B.sent_ncp, n, st);

@@ -913,6 +913,27 @@ __global__ void k_pack_write(Batch B, const u64* offs, u32* out_off, NodeInfo* i
   }
 }
 
+// jppgpu_result_fetch(JPPGPU_FETCH_TOP1): the node and UNK records of every sentence's top-1 path,
+// in path order (EOS first), compacted to offs[s]...  One wavefront per sentence.
+__global__ void k_top1_count(Batch B, u32* counts) {
+  u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B.n_sent) return;
+  counts[s] = B.sent_status[s] == ST_OK ? B.path_len[s] : 0;
+}
+
+__global__ void __launch_bounds__(256) k_top1_gather(Batch B, const u64* offs, NodeInfo* nodes, NodeAux* aux) {
+  const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const u32 lane = threadIdx.x & 63;
+  if (s >= B.n_sent || B.sent_status[s] != ST_OK) return;
+  const u32 pl = B.path_len[s];
+  const u64 nb = B.node_base[s], o = offs[s];
+  for (u32 k = lane; k < pl; k += 64) {
+    u32 node = B.path_nodes[nb + k];
+    nodes[o + k] = B.node_info[nb + node];
+    aux[o + k] = B.node_aux[nb + node];
+  }
+}
+
 }  // namespace jpp
 
 #endif  // JPP_K_SWEEP_H

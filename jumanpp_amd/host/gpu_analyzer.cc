@@ -158,7 +158,7 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
                 : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
     if (rc != JPPGPU_OK) return fromCode(rc);
     // host copies are taken right away: the next group's batch invalidates the device side of this result
-    rc = jppgpu_result_fetch(G.result, fullLattice ? 1 : 0, &G.view);
+    rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
     if (rc != JPPGPU_OK) return fromCode(rc);
   }
   // codepoint -> byte offset tables of the well-formed sentences (for surfaces)

@@ -61,7 +61,9 @@ struct SentenceResult {
   StringPiece input;
   uint32_t numCodepoints = 0;
   uint32_t numNodes = 0;
-  const jppgpu_node* nodes = nullptr;  // [numNodes], 0/1 = BOS, last = EOS
+  // [numNodes].  After analyzeBatch(inputs, fullLattice=true): the lattice's node table (0/1 = BOS,
+  // last = EOS); otherwise only the nodes of the top-1 path, in path order (JPPGPU_FETCH_TOP1)
+  const jppgpu_node* nodes = nullptr;
   const jppgpu_unk* unk = nullptr;     // [numNodes]
   const uint32_t* pathNodes = nullptr; // top-1 path, EOS first
   uint32_t pathLen = 0;

@@ -6,13 +6,21 @@
 //
 // usage: jumanpp_gpu --model=MODEL.img [--beam=5] [--global-beam=6] [--right-check=1]
 //                    [--right-beam=5] [--no-rnn] [--batch=65536] [--device=0] [-o OUT] [INPUT...]
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <mutex>
+#include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gpu_analyzer.h"
@@ -38,6 +46,8 @@ struct Conf {
   std::string segmentSeparator = " ";
   bool partialInput = false;  // --partial-input: InputType::PartiallyAnnotated
   int autoStep = 0;           // --auto-nbest=base:step:max (jumanpp_args.cc:270-279)
+  int threads = 0;            // --threads=N format workers (0: one per hardware thread, at most 32)
+  bool pipeline = true;       // --no-pipeline: one analyzer, read/analyse/format strictly in turn per batch
 };
 
 bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
@@ -64,6 +74,77 @@ struct Example {
   std::string input;
   Status readStatus;
   PartialExample partial;
+};
+
+// one batch on its way through read -> analyse -> format
+struct Job {
+  std::vector<Example> batch;
+  int analyzer = 0;
+  Status batchStatus;
+  double gpuMs = 0;
+};
+
+std::string statusText(const Status& s) {
+  std::ostringstream o;
+  o << s;
+  return o.str();
+}
+
+template <typename T>
+class BoundedQueue {
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<T> items_;
+  size_t cap_;
+  bool closed_ = false;
+
+ public:
+  explicit BoundedQueue(size_t cap) : cap_(cap) {}
+  void push(T v) {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return items_.size() < cap_; });
+    items_.push_back(std::move(v));
+    cv_.notify_all();
+  }
+  // false once the queue is closed and drained
+  bool pop(T* out) {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return !items_.empty() || closed_; });
+    if (items_.empty()) return false;
+    *out = std::move(items_.front());
+    items_.pop_front();
+    cv_.notify_all();
+    return true;
+  }
+  void close() {
+    std::lock_guard<std::mutex> l(mu_);
+    closed_ = true;
+    cv_.notify_all();
+  }
+};
+
+class Semaphore {
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int count_;
+
+ public:
+  explicit Semaphore(int n) : count_(n) {}
+  void acquire() {
+    std::unique_lock<std::mutex> l(mu_);
+    cv_.wait(l, [&] { return count_ > 0; });
+    --count_;
+  }
+  void release() {
+    std::lock_guard<std::mutex> l(mu_);
+    ++count_;
+    cv_.notify_one();
+  }
+};
+
+struct Clock {
+  std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count(); }
 };
 
 }  // namespace
@@ -98,6 +179,8 @@ int main(int argc, const char** argv) {
       }
     } else if (std::strcmp(argv[i], "--partial-input") == 0) conf.partialInput = true;
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
+    else if (argValue(argc, argv, i, "--threads", &v)) conf.threads = std::atoi(v.c_str());
+    else if (std::strcmp(argv[i], "--no-pipeline") == 0) conf.pipeline = false;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
       std::cerr << "unknown option " << argv[i] << "\n";
@@ -135,39 +218,32 @@ int main(int argc, const char** argv) {
     sconf.numScorers = 1;
     def.scoreWeights = {1.0f};
   }
-  GpuAnalyzer analyzer;
-  s = analyzer.initialize(&model, acfg, sconf, &def, conf.device);
-  if (!s) {
-    std::cerr << "failed to initialize the analyzer: " << s << "\n";
-    return 1;
-  }
-  // JumanppExec::initOutput (jumandic_env.cc:55-150) and emptyResult (:211-222)
-  std::unique_ptr<OutputFormat> format;
+  if (conf.threads <= 0) conf.threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  // JumanppExec::initOutput (jumandic_env.cc:55-150) and emptyResult (:211-222); one instance per format worker
   StringPiece emptyResult = "# ERROR\nEOS\n";
   const bool useLattice = conf.lattice != 0;
-  if (useLattice) {
-    auto f = new LatticeFormat(conf.lattice == -1 ? conf.beam : conf.lattice);
-    format.reset(f);
-    s = f->initialize(&model, def.scoreWeights);
-  } else if (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph) {
-    auto f = new MorphFormat(conf.kind == Conf::FullMorph);
-    format.reset(f);
-    s = f->initialize(&model);
-    emptyResult = "# ERROR\n";
-  } else if (conf.kind == Conf::Segment) {
-    auto f = new SegmentedFormat();
-    format.reset(f);
-    s = f->initialize(&model, conf.segmentSeparator);
-    emptyResult = "";
-  } else {
+  if (!useLattice && (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph)) emptyResult = "# ERROR\n";
+  if (!useLattice && conf.kind == Conf::Segment) emptyResult = "";
+  auto makeFormat = [&](Status* st) -> OutputFormat* {
+    if (useLattice) {
+      auto f = new LatticeFormat(conf.lattice == -1 ? conf.beam : conf.lattice);
+      *st = f->initialize(&model, def.scoreWeights);
+      return f;
+    }
+    if (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph) {
+      auto f = new MorphFormat(conf.kind == Conf::FullMorph);
+      *st = f->initialize(&model);
+      return f;
+    }
+    if (conf.kind == Conf::Segment) {
+      auto f = new SegmentedFormat();
+      *st = f->initialize(&model, conf.segmentSeparator);
+      return f;
+    }
     auto f = new JumanFormat();
-    format.reset(f);
-    s = f->initialize(&model);
-  }
-  if (!s) {
-    std::cerr << "Failed to initialize I/O: " << s << "\n";
-    return 1;
-  }
+    *st = f->initialize(&model);
+    return f;
+  };
 
   std::unique_ptr<std::ofstream> ofile;
   std::ostream* out = &std::cout;
@@ -206,74 +282,166 @@ int main(int argc, const char** argv) {
       return 1;
     }
   }
-  std::vector<Example> batch;
-  std::vector<StringPiece> pieces;
-  int result = 0;
-  double gpuMs = 0;
-  size_t sentences = 0;
-  auto flush = [&]() {
-    Status bs;
+  // Three stages, each on its own thread, joined by bounded queues: read a batch | analyse it on the
+  // GPU | format it (conf.threads workers, one OutputFormat each) and write it.  Two analyzers alternate
+  // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
+  // call, is being formatted.  Output order is the input order.
+  const int nAnalyzers = conf.pipeline ? 2 : 1;
+  std::vector<std::unique_ptr<GpuAnalyzer>> analyzers;
+  for (int a = 0; a < nAnalyzers; ++a) {
+    analyzers.emplace_back(new GpuAnalyzer());
+    s = analyzers.back()->initialize(&model, acfg, sconf, &def, conf.device);
+    if (!s) {
+      std::cerr << "failed to initialize the analyzer: " << s << "\n";
+      return 1;
+    }
+  }
+  std::vector<std::unique_ptr<OutputFormat>> formats;
+  for (int t = 0; t < conf.threads; ++t) {
+    formats.emplace_back(makeFormat(&s));
+    if (!s) {
+      std::cerr << "Failed to initialize I/O: " << s << "\n";
+      return 1;
+    }
+  }
+
+  BoundedQueue<std::unique_ptr<Job>> readQ(2), doneQ(1);
+  Semaphore freeAnalyzers(nAnalyzers);
+  Clock clock;
+  double readMs = 0, analyzeMs = 0, formatMs = 0, gpuMs = 0;
+
+  auto readBatch = [&](Job* job) {
+    auto& batch = job->batch;
+    while (batch.size() < conf.batch && hasNext()) {
+      Example e;
+      if (conf.partialInput) {
+        e.readStatus = pexReader.readExample(in, &e.partial);
+        batch.push_back(std::move(e));
+        continue;
+      }
+      // PlainStreamReader::readExample (stream_reader.cc:12-38): "# " lines are the comment of the next other line
+      for (;;) {
+        e.input.clear();
+        std::getline(*in, e.input);
+        if (e.input.size() > 2 && e.input[0] == '#' && e.input[1] == ' ') std::swap(e.comment, e.input);
+        else break;
+      }
+      if (e.comment.size() > maxComment) {
+        e.readStatus = Status::InvalidParameter() << "Comment size was: " << e.comment.size() << " which is more than max: " << maxComment;
+      } else if (e.input.size() > maxInput) {
+        e.readStatus = Status::InvalidParameter() << "Input size was: " << e.input.size() << " which is more than max: " << maxInput;
+      }
+      batch.push_back(std::move(e));
+    }
+  };
+
+  auto analyzeJob = [&](Job* job) {
+    GpuAnalyzer& analyzer = *analyzers[job->analyzer];
     if (conf.partialInput) {
       std::vector<const PartialExample*> exs;
-      for (auto& e : batch) exs.push_back(e.readStatus.isOk() ? &e.partial : nullptr);
-      bs = analyzer.analyzeBatchPartial(exs, useLattice);
+      for (auto& e : job->batch) exs.push_back(e.readStatus.isOk() ? &e.partial : nullptr);
+      job->batchStatus = analyzer.analyzeBatchPartial(exs, useLattice);
     } else {
-      pieces.clear();
-      for (auto& e : batch) pieces.push_back(e.readStatus.isOk() ? StringPiece(e.input) : StringPiece(""));
-      bs = analyzer.analyzeBatch(pieces, useLattice);
+      std::vector<StringPiece> pieces;
+      for (auto& e : job->batch) pieces.push_back(e.readStatus.isOk() ? StringPiece(e.input) : StringPiece(""));
+      job->batchStatus = analyzer.analyzeBatch(pieces, useLattice);
     }
-    if (conf.timing) {
-      float ms[8];
-      analyzer.lastTimings(ms);
-      gpuMs += ms[7];
-    }
-    for (size_t i = 0; i < batch.size(); ++i) {
-      if (!batch[i].readStatus.isOk()) {
-        std::cerr << "failed to read an example: " << batch[i].readStatus;
-        result = 1;
-        continue;
-      }
-      result = 0;
-      Status st = bs.isOk() ? analyzer.sentenceStatus(i) : bs;
-      if (!st) {
-        std::cerr << st;
-        *out << emptyResult;
-        continue;
-      }
-      StringPiece comment = batch[i].comment.size() < 2 ? StringPiece("") : StringPiece(batch[i].comment.data() + 2, batch[i].comment.size() - 2);
-      if (conf.partialInput) comment = StringPiece(batch[i].partial.comment);
-      st = format->format(analyzer, i, comment);
-      if (!st) std::cerr << st;
-      else *out << format->result();
-    }
-    sentences += batch.size();
-    batch.clear();
+    float ms[8];
+    analyzer.lastTimings(ms);
+    job->gpuMs = ms[7];
   };
-  while (hasNext()) {
-    Example e;
-    if (conf.partialInput) {
-      e.readStatus = pexReader.readExample(in, &e.partial);
-      batch.push_back(std::move(e));
-      if (batch.size() >= conf.batch) flush();
-      continue;
+
+  // sentences [lo, hi) of a job -> text for stdout and stderr
+  auto formatRange = [&](OutputFormat* format, const Job& job, size_t lo, size_t hi, std::string* text, std::string* errors) {
+    const GpuAnalyzer& analyzer = *analyzers[job.analyzer];
+    for (size_t i = lo; i < hi; ++i) {
+      const Example& e = job.batch[i];
+      if (!e.readStatus.isOk()) {
+        *errors += "failed to read an example: " + statusText(e.readStatus);
+        continue;
+      }
+      Status st = job.batchStatus.isOk() ? analyzer.sentenceStatus(i) : job.batchStatus;
+      if (!st) {
+        *errors += statusText(st);
+        text->append(emptyResult.data(), emptyResult.size());
+        continue;
+      }
+      StringPiece comment = e.comment.size() < 2 ? StringPiece("") : StringPiece(e.comment.data() + 2, e.comment.size() - 2);
+      if (conf.partialInput) comment = StringPiece(e.partial.comment);
+      st = format->format(analyzer, i, comment);
+      if (!st) *errors += statusText(st);
+      else {
+        StringPiece r = format->result();
+        text->append(r.data(), r.size());
+      }
     }
-    // PlainStreamReader::readExample
+  };
+
+  std::thread reader([&]() {
     for (;;) {
-      e.input.clear();
-      std::getline(*in, e.input);
-      if (e.input.size() > 2 && e.input[0] == '#' && e.input[1] == ' ') std::swap(e.comment, e.input);
-      else break;
+      std::unique_ptr<Job> job(new Job());
+      double t0 = clock.ms();
+      readBatch(job.get());
+      readMs += clock.ms() - t0;
+      if (job->batch.empty()) break;
+      readQ.push(std::move(job));
     }
-    if (e.comment.size() > maxComment) {
-      e.readStatus = Status::InvalidParameter() << "Comment size was: " << e.comment.size() << " which is more than max: " << maxComment;
-    } else if (e.input.size() > maxInput) {
-      e.readStatus = Status::InvalidParameter() << "Input size was: " << e.input.size() << " which is more than max: " << maxInput;
+    readQ.close();
+  });
+  std::thread gpu([&]() {
+    std::unique_ptr<Job> job;
+    int next = 0;
+    while (readQ.pop(&job)) {
+      freeAnalyzers.acquire();
+      job->analyzer = next;
+      next = (next + 1) % nAnalyzers;
+      double t0 = clock.ms();
+      analyzeJob(job.get());
+      analyzeMs += clock.ms() - t0;
+      doneQ.push(std::move(job));
     }
-    batch.push_back(std::move(e));
-    if (batch.size() >= conf.batch) flush();
+    doneQ.close();
+  });
+
+  int result = 0;
+  size_t sentences = 0;
+  const size_t kChunk = 64;  // sentences a format worker takes at a time
+  std::unique_ptr<Job> job;
+  while (doneQ.pop(&job)) {
+    double t0 = clock.ms();
+    const size_t n = job->batch.size();
+    const size_t nChunks = (n + kChunk - 1) / kChunk;
+    std::vector<std::string> text(nChunks), errors(nChunks);
+    const int workers = (int)std::min<size_t>((size_t)conf.threads, nChunks);
+    std::atomic<size_t> nextChunk(0);
+    auto work = [&](int t) {
+      for (size_t c; (c = nextChunk.fetch_add(1)) < nChunks;)
+        formatRange(formats[t].get(), *job, c * kChunk, std::min(n, (c + 1) * kChunk), &text[c], &errors[c]);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < workers; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    for (size_t c = 0; c < nChunks; ++c) {
+      if (!errors[c].empty()) std::cerr << errors[c];
+      out->write(text[c].data(), (std::streamsize)text[c].size());
+    }
+    if (conf.batch <= 16) out->flush();  // interactive use: a line's answer does not wait for the next line
+    // the reference's exit code is that of the last example read
+    result = job->batch.back().readStatus.isOk() ? 0 : 1;
+    sentences += n;
+    gpuMs += job->gpuMs;
+    freeAnalyzers.release();
+    formatMs += clock.ms() - t0;
   }
-  if (!batch.empty()) flush();
+  reader.join();
+  gpu.join();
   out->flush();
-  if (conf.timing) std::cerr << "sentences=" << sentences << " gpu_ms=" << gpuMs << "\n";
+  if (conf.timing) {
+    double wall = clock.ms();
+    std::cerr << "sentences=" << sentences << " gpu_ms=" << gpuMs << " wall_ms=" << wall << " read_ms=" << readMs
+              << " analyze_ms=" << analyzeMs << " format_write_ms=" << formatMs << " threads=" << conf.threads
+              << " pipeline=" << (conf.pipeline ? 1 : 0) << " sent_per_s=" << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
+  }
   return result;
 }

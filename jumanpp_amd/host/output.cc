@@ -89,7 +89,7 @@ bool OutputManager::locate(const SentenceResult& s, uint32_t k, NodeWalker* w) c
   w->aliasRows_ = false;
   w->remaining_ = 0;
   w->unkSurface_ = StringPiece();
-  if (k < 2 || k + 1 == s.numNodes) {  // BOS / EOS: fillFeaturesWithValue(ptr), fillDataWithValue(0)
+  if (nd.entry_ptr == JPPGPU_ENTRY_BOS || nd.entry_ptr == JPPGPU_ENTRY_EOS) {  // fillFeaturesWithValue(ptr), fillDataWithValue(0)
     for (int i = 0; i < nf; ++i) w->features_[i] = nd.entry_ptr;
     for (int i = 0; i < ndata; ++i) w->data_[i] = 0;
     w->special_ = true;

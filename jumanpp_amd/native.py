@@ -128,9 +128,10 @@ class Result:
         buf = (C.c_char * (np.dtype(dtype).itemsize * count)).from_address(ptr)
         return np.frombuffer(buf, dtype=dtype, count=count)
 
-    def fetch(self, full=False):
+    def fetch(self, full=False, top1=False):
+        """full: the whole lattice; top1: only the top-1 path's nodes, compacted (JPPGPU_FETCH_TOP1)"""
         v = ResultView()
-        rc = self.ctx.lib.jppgpu_result_fetch(self.handle, 1 if full else 0, C.byref(v))
+        rc = self.ctx.lib.jppgpu_result_fetch(self.handle, 2 if top1 else 1 if full else 0, C.byref(v))
         if rc != 0:
             raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
         self.view = v
@@ -146,7 +147,7 @@ class Result:
         self.path_nodes = self._arr(v.path_nodes, '<u4', N)
         self.nodes = self._arr(v.nodes, NODE_DT, N)
         self.unk = self._arr(v.unk, UNK_DT, N)
-        if full:
+        if full and not top1:
             self.bnd_first = self._arr(v.bnd_first, '<u4', NB)
             self.bnd_count = self._arr(v.bnd_count, '<u4', NB)
             self.end_first = self._arr(v.end_first, '<u4', NB)

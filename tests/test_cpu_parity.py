@@ -117,6 +117,37 @@ def test_config_validation_mirrors_reference(emu_lib, golden_dir):
         J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=emu_lib, global_beam=0)
 
 
+def check_top1_fetch_equals_basic_fetch(ctx, lines):
+    """JPPGPU_FETCH_TOP1 (device-compacted path nodes) against the node table of the basic fetch"""
+    import numpy as np
+    r = ctx.analyze(lines)
+    b = r.fetch()
+    status, nbase, plen = b.status.copy(), b.node_base.copy(), b.path_len.copy()
+    pnodes, nodes, unk = b.path_nodes.copy(), b.nodes.copy(), b.unk.copy()
+    t = r.fetch(top1=True)
+    assert t.n == len(lines) and np.array_equal(t.status, status) and np.array_equal(t.path_len, plen)
+    assert np.array_equal(t.nnodes, plen)
+    assert int(t.view.total_nodes) == int(plen.sum())
+    for s in range(len(lines)):
+        o, n0 = int(t.node_base[s]), int(nbase[s])
+        L = int(plen[s])
+        assert np.array_equal(t.path_nodes[o:o + L], np.arange(L))
+        idx = n0 + pnodes[n0:n0 + L].astype(np.int64)
+        assert np.array_equal(t.nodes[o:o + L], nodes[idx]), s
+        assert np.array_equal(t.unk[o:o + L], unk[idx]), s
+        if L:
+            assert int(t.nodes[o]['eptr']) == -0x7ffffffe  # EOS first
+    return int(plen.sum())
+
+
+def test_top1_fetch_equals_basic_fetch(emu_lib, golden_dir):
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    lines = lines[:10] + [b'', b'\xff\xfe bad utf-8'] + lines[10:]
+    assert check_top1_fetch_equals_basic_fetch(ctx, lines) > 100
+    assert check_top1_fetch_equals_basic_fetch(ctx, []) == 0
+
+
 def test_result_invalidated_by_next_batch(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     r1 = ctx.analyze(['あいう'])

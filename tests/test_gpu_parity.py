@@ -247,3 +247,14 @@ def test_gpu_full_batch_size_invariants(gpu_lib, golden_dir, model):
     for k, i in enumerate(perm):
         back[i] = sh[k]
     assert hashlib.sha256(b''.join(back)).hexdigest() == digest
+
+
+@pytest.mark.parametrize('model', ['mini.img', 'mini_rnn.img'])
+def test_gpu_top1_fetch_equals_basic_fetch(gpu_lib, golden_dir, model):
+    """JPPGPU_FETCH_TOP1: the device-compacted top-1 tables equal the path nodes of the basic fetch
+    (3 000 sentences incl. empty and malformed ones)"""
+    import test_cpu_parity as tc
+    ctx = J.Context(os.path.join(golden_dir, model), lib_path=gpu_lib)
+    lines = [l.rstrip('\n').encode('utf-8') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    lines = (lines + [b'', b'\xe3\x81', lines[3][:9]]) * 100
+    assert tc.check_top1_fetch_equals_basic_fetch(ctx, lines) > 10000

@@ -103,6 +103,25 @@ def test_cli_comments_errors_and_batching_like_reference(cli_emu, golden_dir, re
         assert rc == ref.returncode
 
 
+def test_cli_pipeline_and_format_threads_keep_the_output(cli_emu, ref_tools, tmp_path):
+    """several batches in flight (two analyzers alternating) and several format workers per batch
+    (64-sentence chunks) must give the bytes of the strictly serial run and of the reference CLI"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 260, 12, 29, length=14)
+    path = os.path.join(tmp, 'w.txt')
+    ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + os.path.join(tmp, 'w.model'), path],
+                         capture_output=True)
+    rc, serial, err = _run(cli_emu, ['--model=' + img, '--threads=1', '--no-pipeline', path])
+    assert rc == 0 and serial == ref.stdout, err[-300:]
+    for args in (['--batch=200', '--threads=4'], ['--batch=50', '--threads=3']):
+        rc, out, err = _run(cli_emu, ['--model=' + img] + args + ['--timing', path])
+        assert rc == 0 and out == serial, (args, err[-300:])
+        assert b'sentences=260' in err
+
+
 def test_gpu_analyzer_initialize_validates_like_the_reference(cli_emu, golden_dir):
     # unknown model file / missing model option: the CLI's own messages
     rc, out, err = _run(cli_emu, [])
