@@ -1,5 +1,9 @@
 #include "gpu_analyzer.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <cstring>
 
 namespace jumanpp_amd {
@@ -132,6 +136,9 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
   std::string text;
   std::vector<uint32_t> offsets;
   PartialBatch sub;
+  const bool hostTiming = std::getenv("JPPGPU_HOST_TIMING") != nullptr;  // developer: stage times to stderr
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tStart = now(), tAnalyze = 0, tFetch = 0;
   for (size_t g = 0; g < beams.size(); ++g) {
     text.clear();
     offsets.assign(1, 0);
@@ -154,29 +161,33 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
     Group& G = groups_.back();
     G.beam = beams[g];
     const uint32_t ng = (uint32_t)members[g].size();
+    double t0 = now();
     int rc = pg ? jppgpu_analyze_batch_partial(ctx_, text.data(), offsets.data(), ng, pg, &G.result)
                 : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
     if (rc != JPPGPU_OK) return fromCode(rc);
+    double t1 = now();
+    tAnalyze += t1 - t0;
     // host copies are taken right away: the next group's batch invalidates the device side of this result
     rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
     if (rc != JPPGPU_OK) return fromCode(rc);
+    tFetch += now() - t1;
   }
-  // codepoint -> byte offset tables of the well-formed sentences (for surfaces)
-  cpOffsets_.clear();
+  double tGroups = now();
+  // codepoint -> byte offset tables (for surfaces): sized here, filled by the first sentence(i) call,
+  // which may come from any format worker (distinct sentences write distinct ranges)
   cpOffsetsBase_.assign(n + 1, 0);
+  uint64_t cpTotal = 0;
   for (size_t i = 0; i < n; ++i) {
-    cpOffsetsBase_[i] = cpOffsets_.size();
-    if (groups_[groupOf_[i]].view.status[localIdx_[i]] != JPPGPU_SENT_OK) continue;
-    const unsigned char* p = reinterpret_cast<const unsigned char*>(inputs[i].data());
-    size_t nb = inputs[i].size();
-    for (size_t b = 0; b < nb;) {
-      cpOffsets_.push_back((uint32_t)b);
-      unsigned char c = p[b];
-      b += c < 0x80 ? 1 : c < 0xe0 ? 2 : c < 0xf0 ? 3 : 4;
-    }
-    cpOffsets_.push_back((uint32_t)nb);
+    cpOffsetsBase_[i] = cpTotal;
+    const jppgpu_result_view& v = groups_[groupOf_[i]].view;
+    if (v.status[localIdx_[i]] == JPPGPU_SENT_OK) cpTotal += (uint64_t)v.n_codepoints[localIdx_[i]] + 1;
   }
-  cpOffsetsBase_[n] = cpOffsets_.size();
+  cpOffsets_.assign(cpTotal, 0);
+  cpOffsetsReady_.assign(n, 0);
+  cpOffsetsBase_[n] = cpTotal;
+  if (hostTiming)
+    std::fprintf(stderr, "runBatch n=%zu total=%.2f ms: prepare %.2f analyze %.2f fetch %.2f offsets %.2f\n", n, now() - tStart,
+                 tGroups - tStart - tAnalyze - tFetch, tAnalyze, tFetch, now() - tGroups);
   return Status::Ok();
 }
 
@@ -204,7 +215,20 @@ SentenceResult GpuAnalyzer::sentence(size_t i) const {
   r.unk = v.unk + v.node_base[k];
   r.pathNodes = v.path_nodes + v.node_base[k];
   r.pathLen = v.path_len[k];
-  r.cpByteOffsets = cpOffsets_.data() + cpOffsetsBase_[i];
+  uint32_t* offs = cpOffsets_.data() + cpOffsetsBase_[i];
+  if (!cpOffsetsReady_[i] && v.status[k] == JPPGPU_SENT_OK) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(inputs_[i].data());
+    const size_t nb = inputs_[i].size();
+    uint32_t* o = offs;
+    for (size_t b = 0; b < nb;) {
+      *o++ = (uint32_t)b;
+      unsigned char c = p[b];
+      b += c < 0x80 ? 1 : c < 0xe0 ? 2 : c < 0xf0 ? 3 : 4;
+    }
+    *o = (uint32_t)nb;
+    cpOffsetsReady_[i] = 1;
+  }
+  r.cpByteOffsets = offs;
   return r;
 }
 

@@ -88,7 +88,8 @@ class GpuAnalyzer {
   AnalyzerConfig cfg_;
   ScoringConfig sconf_;
   std::vector<StringPiece> inputs_;
-  std::vector<uint32_t> cpOffsets_;      // concatenated per-sentence codepoint -> byte offset tables
+  mutable std::vector<uint32_t> cpOffsets_;  // concatenated per-sentence codepoint -> byte offset tables
+  mutable std::vector<uint8_t> cpOffsetsReady_;
   std::vector<uint64_t> cpOffsetsBase_;
   std::string singleInput_;
   PartialBatch partial_;

@@ -84,6 +84,11 @@ struct Job {
   double gpuMs = 0;
 };
 
+// the text of one formatted batch, in chunks of consecutive sentences
+struct Formatted {
+  std::vector<std::string> text, errors;
+};
+
 std::string statusText(const Status& s) {
   std::ostringstream o;
   o << s;
@@ -282,8 +287,8 @@ int main(int argc, const char** argv) {
       return 1;
     }
   }
-  // Three stages, each on its own thread, joined by bounded queues: read a batch | analyse it on the
-  // GPU | format it (conf.threads workers, one OutputFormat each) and write it.  Two analyzers alternate
+  // Four stages, each on its own thread, joined by bounded queues: read a batch | analyse it on the
+  // GPU | format it (conf.threads workers, one OutputFormat each) | write it.  Two analyzers alternate
   // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
   // call, is being formatted.  Output order is the input order.
   const int nAnalyzers = conf.pipeline ? 2 : 1;
@@ -306,6 +311,7 @@ int main(int argc, const char** argv) {
   }
 
   BoundedQueue<std::unique_ptr<Job>> readQ(2), doneQ(1);
+  BoundedQueue<std::unique_ptr<Formatted>> writeQ(2);
   Semaphore freeAnalyzers(nAnalyzers);
   Clock clock;
   double readMs = 0, analyzeMs = 0, formatMs = 0, gpuMs = 0;
@@ -403,6 +409,20 @@ int main(int argc, const char** argv) {
     doneQ.close();
   });
 
+  double writeMs = 0;
+  std::thread writer([&]() {
+    std::unique_ptr<Formatted> f;
+    while (writeQ.pop(&f)) {
+      double t0 = clock.ms();
+      for (size_t c = 0; c < f->text.size(); ++c) {
+        if (!f->errors[c].empty()) std::cerr << f->errors[c];
+        out->write(f->text[c].data(), (std::streamsize)f->text[c].size());
+      }
+      if (conf.batch <= 16) out->flush();  // interactive use: a line's answer does not wait for the next line
+      writeMs += clock.ms() - t0;
+    }
+  });
+
   int result = 0;
   size_t sentences = 0;
   const size_t kChunk = 64;  // sentences a format worker takes at a time
@@ -411,7 +431,11 @@ int main(int argc, const char** argv) {
     double t0 = clock.ms();
     const size_t n = job->batch.size();
     const size_t nChunks = (n + kChunk - 1) / kChunk;
-    std::vector<std::string> text(nChunks), errors(nChunks);
+    std::unique_ptr<Formatted> formatted(new Formatted());
+    formatted->text.resize(nChunks);
+    formatted->errors.resize(nChunks);
+    std::vector<std::string>& text = formatted->text;
+    std::vector<std::string>& errors = formatted->errors;
     const int workers = (int)std::min<size_t>((size_t)conf.threads, nChunks);
     std::atomic<size_t> nextChunk(0);
     auto work = [&](int t) {
@@ -422,25 +446,23 @@ int main(int argc, const char** argv) {
     for (int t = 1; t < workers; ++t) pool.emplace_back(work, t);
     work(0);
     for (auto& th : pool) th.join();
-    for (size_t c = 0; c < nChunks; ++c) {
-      if (!errors[c].empty()) std::cerr << errors[c];
-      out->write(text[c].data(), (std::streamsize)text[c].size());
-    }
-    if (conf.batch <= 16) out->flush();  // interactive use: a line's answer does not wait for the next line
     // the reference's exit code is that of the last example read
     result = job->batch.back().readStatus.isOk() ? 0 : 1;
     sentences += n;
     gpuMs += job->gpuMs;
     freeAnalyzers.release();
     formatMs += clock.ms() - t0;
+    writeQ.push(std::move(formatted));
   }
+  writeQ.close();
   reader.join();
   gpu.join();
+  writer.join();
   out->flush();
   if (conf.timing) {
     double wall = clock.ms();
     std::cerr << "sentences=" << sentences << " gpu_ms=" << gpuMs << " wall_ms=" << wall << " read_ms=" << readMs
-              << " analyze_ms=" << analyzeMs << " format_write_ms=" << formatMs << " threads=" << conf.threads
+              << " analyze_ms=" << analyzeMs << " format_ms=" << formatMs << " write_ms=" << writeMs << " threads=" << conf.threads
               << " pipeline=" << (conf.pipeline ? 1 : 0) << " sent_per_s=" << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
   }
   return result;

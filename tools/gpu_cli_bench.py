@@ -35,6 +35,8 @@ def main():
     runs = [('serial: 1 format thread, no pipeline', ['--threads=1', '--no-pipeline']),
             ('format threads only', ['--no-pipeline']),
             ('pipeline + format threads (default)', []),
+            ('pipeline, 64 format threads', ['--threads=64']),
+            ('pipeline, 16 format threads', ['--threads=16']),
             ('default, native .jppmdl model', ['MODEL'])]
     first = None
     for name, extra in runs:
