@@ -41,6 +41,8 @@ void rt_free(void* p) { free(p); }
 void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t) { memcpy(d, h, n); }
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
 void rt_sync(jpp_stream_t) {}
+jpp_stream_t rt_stream_create() { return nullptr; }
+void rt_stream_destroy(jpp_stream_t) {}
 struct Timer {
   void init() {}
   void destroy() {}
@@ -65,6 +67,15 @@ void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
   (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
 }
 void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
+// a context's own stream: contexts used from different host threads do not serialise on the null stream
+jpp_stream_t rt_stream_create() {
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return s;
+}
+void rt_stream_destroy(jpp_stream_t s) {
+  if (s) (void)hipStreamDestroy(s);
+}
 struct Timer {
   hipEvent_t ev[9];
   bool have = false;
@@ -182,6 +193,7 @@ struct jppgpu_ctx {
   Timer timer;
   float last_ms[8] = {0};
   jpp_stream_t last_stream = nullptr;
+  jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
   bool timing_pending = false;
 };
 
@@ -377,6 +389,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   }
   rt_h2d(ctx->dmodel, &H, sizeof(DevModel), nullptr);
   rt_sync(nullptr);
+  ctx->own_stream = rt_stream_create();
   ctx->timer.init();
   *out = ctx;
   return JPPGPU_OK;
@@ -418,6 +431,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
+  rt_stream_destroy(ctx->own_stream);
   ctx->timer.destroy();
   delete ctx;
 }
@@ -618,10 +632,10 @@ extern "C" int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uin
   u32 total = offsets[n];
   if (!(ctx->text.ensure((size_t)total + 64) && ctx->offs.ensure(((size_t)n + 1) * 4)))
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (input)");
-  if (total) rt_h2d(ctx->text.p, utf8, total, nullptr);
-  rt_h2d(ctx->offs.p, offsets, ((size_t)n + 1) * 4, nullptr);
-  rt_sync(nullptr);
-  return jppgpu_analyze_batch_device(ctx, ctx->text.p, ctx->offs.p, n, total, nullptr, out);
+  if (total) rt_h2d(ctx->text.p, utf8, total, ctx->own_stream);
+  rt_h2d(ctx->offs.p, offsets, ((size_t)n + 1) * 4, ctx->own_stream);
+  rt_sync(ctx->own_stream);
+  return jppgpu_analyze_batch_device(ctx, ctx->text.p, ctx->offs.p, n, total, ctx->own_stream, out);
 }
 
 extern "C" int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
@@ -644,13 +658,13 @@ extern "C" int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, c
             ctx->pc_node_off.ensure(((size_t)n + 1) * 4) && ctx->pc_nb.ensure(nNb * 2 + 2) && ctx->pc_b.ensure(nB * 2 + 2) &&
             ctx->pc_nodes.ensure(nNodes * sizeof(PcNode) + 4) && ctx->pc_tags.ensure((size_t)p->num_tags * sizeof(PcTag) + 4);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (partial)");
-  rt_h2d(ctx->pc_nb_off.p, p->nobreak_offsets, ((size_t)n + 1) * 4, nullptr);
-  rt_h2d(ctx->pc_b_off.p, p->boundary_offsets, ((size_t)n + 1) * 4, nullptr);
-  rt_h2d(ctx->pc_node_off.p, p->node_offsets, ((size_t)n + 1) * 4, nullptr);
-  if (nNb) rt_h2d(ctx->pc_nb.p, p->nobreak, nNb * 2, nullptr);
-  if (nB) rt_h2d(ctx->pc_b.p, p->boundaries, nB * 2, nullptr);
-  if (nNodes) rt_h2d(ctx->pc_nodes.p, p->nodes, nNodes * sizeof(PcNode), nullptr);
-  if (p->num_tags) rt_h2d(ctx->pc_tags.p, p->tags, (size_t)p->num_tags * sizeof(PcTag), nullptr);
+  rt_h2d(ctx->pc_nb_off.p, p->nobreak_offsets, ((size_t)n + 1) * 4, ctx->own_stream);
+  rt_h2d(ctx->pc_b_off.p, p->boundary_offsets, ((size_t)n + 1) * 4, ctx->own_stream);
+  rt_h2d(ctx->pc_node_off.p, p->node_offsets, ((size_t)n + 1) * 4, ctx->own_stream);
+  if (nNb) rt_h2d(ctx->pc_nb.p, p->nobreak, nNb * 2, ctx->own_stream);
+  if (nB) rt_h2d(ctx->pc_b.p, p->boundaries, nB * 2, ctx->own_stream);
+  if (nNodes) rt_h2d(ctx->pc_nodes.p, p->nodes, nNodes * sizeof(PcNode), ctx->own_stream);
+  if (p->num_tags) rt_h2d(ctx->pc_tags.p, p->tags, (size_t)p->num_tags * sizeof(PcTag), ctx->own_stream);
   ctx->partial_pending = true;
   int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
   ctx->partial_pending = false;

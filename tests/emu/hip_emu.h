@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #define __global__
@@ -146,8 +147,16 @@ inline void run_block(unsigned nthreads) {
   }
 }
 
+// launches are serialised: the emulator has one fiber state, and the host layer may drive two
+// contexts from two threads (jumanpp_gpu's alternating analyzers)
+inline std::mutex& launch_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+
 template <typename F>
 void launch(dim3 grid, dim3 block, F&& f) {
+  std::lock_guard<std::mutex> lock(launch_mutex());
   State& s = st();
   s.grid = grid;
   s.block = block;
