@@ -4,8 +4,10 @@
 // replaced by batched GpuAnalyzer::analyzeBatch.  Output is byte-identical to
 // `jumanpp_v2 --model=... ` in the JUMAN format.
 //
-// usage: jumanpp_gpu --model=MODEL.img [--beam=5] [--global-beam=6] [--right-check=1]
-//                    [--right-beam=5] [--no-rnn] [--batch=65536] [--device=0] [-o OUT] [INPUT...]
+// usage: jumanpp_gpu --model=MODEL.jppmdl [--beam=5] [--global-beam=6] [--right-check=1]
+//                    [--right-beam=5] [--no-rnn] [-s N | -M | -F | --segment] [--partial-input]
+//                    [--auto-nbest=B:S:M] [--batch=65536] [--threads=N] [--no-pipeline]
+//                    [--device=0] [--timing] [-o OUT] [INPUT...]
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -287,11 +289,10 @@ int main(int argc, const char** argv) {
       return 1;
     }
   }
-  // Four stages joined by bounded queues: read a batch | analyse it on the GPU | format it
-  // (conf.threads workers, one OutputFormat each) | write it.  Two analyzers, each with its own thread,
-  // context and stream, take the batches in turn: batch k+1 is uploaded, analysed and fetched while
-  // batch k, whose results stay valid until its analyzer's next call, is being formatted, and the two
-  // batches' kernels share the GPU.  Output order is the input order.
+  // Four stages, each on its own thread, joined by bounded queues: read a batch | analyse it on the
+  // GPU | format it (conf.threads workers, one OutputFormat each) | write it.  Two analyzers alternate
+  // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
+  // call, is being formatted.  Output order is the input order.
   const int nAnalyzers = conf.pipeline ? 2 : 1;
   std::vector<std::unique_ptr<GpuAnalyzer>> analyzers;
   for (int a = 0; a < nAnalyzers; ++a) {
@@ -311,16 +312,9 @@ int main(int argc, const char** argv) {
     }
   }
 
-  // batch k goes through analyzer k % nAnalyzers
-  std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<Job>>>> readQ, doneQ;
-  std::vector<std::unique_ptr<Semaphore>> analyzerFree;
-  for (int a = 0; a < nAnalyzers; ++a) {
-    readQ.emplace_back(new BoundedQueue<std::unique_ptr<Job>>(1));
-    doneQ.emplace_back(new BoundedQueue<std::unique_ptr<Job>>(1));
-    analyzerFree.emplace_back(new Semaphore(1));
-  }
+  BoundedQueue<std::unique_ptr<Job>> readQ(2), doneQ(1);
   BoundedQueue<std::unique_ptr<Formatted>> writeQ(2);
-  std::mutex statMu;
+  Semaphore freeAnalyzers(nAnalyzers);
   Clock clock;
   double readMs = 0, analyzeMs = 0, formatMs = 0, gpuMs = 0;
 
@@ -392,33 +386,30 @@ int main(int argc, const char** argv) {
   };
 
   std::thread reader([&]() {
-    for (int k = 0;; k = (k + 1) % nAnalyzers) {
+    for (;;) {
       std::unique_ptr<Job> job(new Job());
       double t0 = clock.ms();
       readBatch(job.get());
       readMs += clock.ms() - t0;
       if (job->batch.empty()) break;
-      job->analyzer = k;
-      readQ[k]->push(std::move(job));
+      readQ.push(std::move(job));
     }
-    for (auto& q : readQ) q->close();
+    readQ.close();
   });
-  std::vector<std::thread> gpu;
-  for (int a = 0; a < nAnalyzers; ++a)
-    gpu.emplace_back([&, a]() {
-      std::unique_ptr<Job> job;
-      while (readQ[a]->pop(&job)) {
-        analyzerFree[a]->acquire();  // its previous batch has been formatted
-        double t0 = clock.ms();
-        analyzeJob(job.get());
-        {
-          std::lock_guard<std::mutex> l(statMu);
-          analyzeMs += clock.ms() - t0;
-        }
-        doneQ[a]->push(std::move(job));
-      }
-      doneQ[a]->close();
-    });
+  std::thread gpu([&]() {
+    std::unique_ptr<Job> job;
+    int next = 0;
+    while (readQ.pop(&job)) {
+      freeAnalyzers.acquire();
+      job->analyzer = next;
+      next = (next + 1) % nAnalyzers;
+      double t0 = clock.ms();
+      analyzeJob(job.get());
+      analyzeMs += clock.ms() - t0;
+      doneQ.push(std::move(job));
+    }
+    doneQ.close();
+  });
 
   double writeMs = 0;
   std::thread writer([&]() {
@@ -438,7 +429,7 @@ int main(int argc, const char** argv) {
   size_t sentences = 0;
   const size_t kChunk = 64;  // sentences a format worker takes at a time
   std::unique_ptr<Job> job;
-  for (int k = 0; doneQ[k]->pop(&job); k = (k + 1) % nAnalyzers) {
+  while (doneQ.pop(&job)) {
     double t0 = clock.ms();
     const size_t n = job->batch.size();
     const size_t nChunks = (n + kChunk - 1) / kChunk;
@@ -461,13 +452,13 @@ int main(int argc, const char** argv) {
     result = job->batch.back().readStatus.isOk() ? 0 : 1;
     sentences += n;
     gpuMs += job->gpuMs;
-    analyzerFree[job->analyzer]->release();
+    freeAnalyzers.release();
     formatMs += clock.ms() - t0;
     writeQ.push(std::move(formatted));
   }
   writeQ.close();
   reader.join();
-  for (auto& t : gpu) t.join();
+  gpu.join();
   writer.join();
   out->flush();
   if (conf.timing) {
