@@ -457,3 +457,63 @@ def test_gpu_auto_beam(cli_gpu, ref_tools, tmp_path):
         ref = _ref_cli(ref_tools, model, flags, txt)
         rc, out, err = _run(cli_gpu, ['--model=' + model] + flags + [txt])
         assert rc == 0 and out == ref, (flags, err[-300:])
+
+
+def _parallel_reference(ref_tools, model, path, tmp, procs=16):
+    """jumanpp_v2 has no threading: split the corpus, one process per part, concatenate in order"""
+    lines = open(path, 'rb').read().split(b'\n')
+    if lines and lines[-1] == b'':
+        lines.pop()
+    per = (len(lines) + procs - 1) // procs
+    ps = []
+    for k in range(procs):
+        part = os.path.join(tmp, 'part%d.txt' % k)
+        with open(part, 'wb') as f:
+            f.write(b''.join(l + b'\n' for l in lines[k * per:(k + 1) * per]))
+        ps.append(subprocess.Popen([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + model, part],
+                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+    return lines, b''.join(p.communicate()[0] for p in ps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rnn', [False, True])
+def test_gpu_cli_at_scale_on_the_bench_workload(cli_gpu, ref_tools, tmp_path, rnn):
+    """bench.py's own model (300 k dictionary entries, 2^22 weights, E=128 RNN) and corpus generator:
+    60 000 (perceptron) / 20 000 (RNN) sentences through jumanpp_gpu vs jumanpp_v2.  Perceptron output
+    must be byte-identical; with the RNN every differing sentence must be a reference EOS tie."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import argparse
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    tmp = str(tmp_path)
+    args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, rnn=rnn, rnn_hidden=128,
+                              rnn_vocab=30000, sent_len=40)
+    cache = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'jppgpu_bench_cache')
+    mdic, model, img = bench.make_workload(args, cache)
+    n = 20000 if rnn else 60000
+    corpus = bench.make_corpus(args, mdic, cache, n, 4242)
+    lines, ref = _parallel_reference(ref_tools, model, corpus, tmp)
+    rc, out, err = _run(cli_gpu, ['--model=' + model, '--batch=16384', corpus])  # native .jppmdl, 4 batches in the pipeline
+    assert rc == 0, err[-500:]
+    if not rnn:
+        assert out == ref
+        return
+    bo, br = _sentences(out), _sentences(ref)
+    assert len(bo) == len(br) == n
+    diff = [i for i in range(n) if bo[i] != br[i]]
+    assert len(diff) <= n // 100, len(diff)
+    if diff:
+        # golden dump of just those sentences: the reference's own EOS beam must tie within 1e-4
+        sub = os.path.join(tmp, 'sub.txt')
+        with open(sub, 'wb') as f:
+            f.write(b''.join(lines[i] + b'\n' for i in diff))
+        with open(sub, 'rb') as f:
+            subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', model, os.path.join(tmp, 'sub.gold')],
+                                  stdin=f, stderr=subprocess.DEVNULL)
+        meta, gold = G.read_gold(os.path.join(tmp, 'sub.gold'))
+        for k, i in enumerate(diff):
+            eos = gold[k].bnds[len(gold[k].bnds) - 1]['nodes'][0]['beam']
+            tot = [float(x['total']) for x in eos if x['valid']]
+            assert len(tot) > 1 and abs(tot[0] - tot[1]) <= 1e-4 * max(1.0, abs(tot[0])), (i, tot[:3])
