@@ -32,6 +32,7 @@
 
 #include "jpp_device.h"
 #include "jpp_select.h"
+#include "k_lattice.h"
 #include "k_sweep.h"
 
 #if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
@@ -66,6 +67,16 @@ __device__ unsigned long long g_rnn_cnt[2];
 #endif
 
 namespace jpp {
+
+// sum over the 64 lanes, the same value on every lane: DPP row shifts inside the rows of 16, then the four
+// row sums through v_readlane -- no LDS crossbar round trips (a ds_bpermute butterfly costs six)
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += row_shl_f32<8>(v);
+  v += row_shl_f32<4>(v);
+  v += row_shl_f32<2>(v);
+  v += row_shl_f32<1>(v);
+  return (wave_bcast_f32(v, 0) + wave_bcast_f32(v, 16)) + (wave_bcast_f32(v, 32) + wave_bcast_f32(v, 48));
+}
 
 // one byte at a time through a double array; returns false once a label mismatches
 __device__ __forceinline__ bool rnn_trie_byte(const u32* units, u32& id, u32& unit, u32 b) {
@@ -351,6 +362,141 @@ __device__ __forceinline__ void rnn_matvec(const float* __restrict__ Wt, const f
   }
 }
 
+#if !defined(JPP_EMU)
+typedef float rnn_f2 __attribute__((ext_vector_type(2)));
+#endif
+
+// index of W^T[k][i] in the LDS copy (EP = 64 J, J <= 2): rows are interleaved in pairs so that one read
+// gives a lane the 2 J weights of rows k, k+1 for its J outputs -- [k/2][lane][k&1][j]
+template <int J>
+__device__ __forceinline__ u32 rnn_w2_index(u32 k, u32 i) {
+  return ((((k >> 1) * 64u + i / J) * 2u) + (k & 1u)) * J + (i % J);
+}
+
+// same sum, same order as rnn_matvec (k ascending), on the pair-interleaved LDS copy: half the LDS
+// reads, and for J = 2 both outputs of a lane advance in one packed FMA
+template <int J, int CN>
+__device__ __forceinline__ void rnn_matvec_lds(const float* __restrict__ W2, const float (&ctx)[kRnnCN][J],
+                                               float (&acc)[kRnnCN][J], int lane) {
+  static_assert(J == 1 || J == 2, "the LDS copy exists for E <= 128 only");
+  constexpr int EP = 64 * J;
+#pragma unroll 8
+  for (int kp = 0; kp < EP / 2; ++kp) {
+    const float* row = W2 + (kp * 64 + lane) * 2 * J;
+    float w[2][J];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < J; ++j) w[r][j] = row[r * J + j];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int src = J == 2 ? kp : 2 * kp + r;   // lane holding ctx element k = 2 kp + r
+      constexpr int kZero = 0;
+      const int j2 = J == 2 ? r : kZero;
+#pragma unroll
+      for (int p = 0; p < CN; ++p) {
+        const float c = wave_bcast_f32(j2 == 0 ? ctx[p][0] : ctx[p][J - 1], src);
+#if !defined(JPP_EMU)
+        if (J == 2) {
+          rnn_f2 a = {acc[p][0], acc[p][J - 1]};
+          const rnn_f2 ww = {w[r][0], w[r][J - 1]};
+          const rnn_f2 cc = {c, c};
+          a = __builtin_elementwise_fma(ww, cc, a);
+          acc[p][0] = a.x;
+          acc[p][J - 1] = a.y;
+          continue;
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[p][j] = __builtin_fmaf(w[r][j], c, acc[p][j]);
+      }
+    }
+  }
+}
+
+// one context, staged in LDS (lctx[k], k < EP): out[:] += W^T[k][:] * lctx[k], k ascending like rnn_matvec.
+// The four context elements of a step arrive by one broadcast read, the weights of two rows by another.
+template <int J>
+__device__ __forceinline__ void rnn_matvec_lds1(const float* __restrict__ W2, const float* __restrict__ lctx,
+                                                float (&acc)[J], int lane) {
+  static_assert(J == 1 || J == 2, "the LDS copy exists for E <= 128 only");
+  constexpr int EP = 64 * J;
+  constexpr int KB = 16;       // context elements per block
+  constexpr int NB = EP / KB;
+  struct Blk {
+    float c[KB];
+    float w[KB / 2][2 * J];
+  };
+  // all reads of a block are issued back to back and consumed in order as they return (the other three
+  // wavefronts of the SIMD cover what latency is left); a second block in flight does not fit 128 VGPRs
+  auto load = [&](int blk, Blk& b) {
+#pragma unroll
+    for (int t = 0; t < KB; ++t) b.c[t] = lctx[blk * KB + t];
+#pragma unroll
+    for (int h = 0; h < KB / 2; ++h) {
+      const float* row = W2 + ((blk * (KB / 2) + h) * 64 + lane) * 2 * J;
+#pragma unroll
+      for (int x = 0; x < 2 * J; ++x) b.w[h][x] = row[x];
+    }
+  };
+  auto consume = [&](const Blk& b) {
+#pragma unroll
+    for (int h = 0; h < KB / 2; ++h) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float cc1 = b.c[2 * h + r];
+#if !defined(JPP_EMU)
+        if (J == 2) {
+          rnn_f2 a = {acc[0], acc[J - 1]};
+          const rnn_f2 ww = {b.w[h][r * J], b.w[h][r * J + J - 1]};
+          const rnn_f2 cc = {cc1, cc1};
+          a = __builtin_elementwise_fma(ww, cc, a);
+          acc[0] = a.x;
+          acc[J - 1] = a.y;
+          continue;
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = __builtin_fmaf(b.w[h][r * J + j], cc1, acc[j]);
+      }
+    }
+  };
+#pragma unroll 1
+  for (int blk = 0; blk < NB; ++blk) {
+    Blk b;
+    load(blk, b);
+    consume(b);
+  }
+}
+
+template <int J, int CN, bool WLDS>
+__device__ __forceinline__ void rnn_matvec_any(const float* __restrict__ Wt, const float (&ctx)[kRnnCN][J],
+                                               float (&acc)[kRnnCN][J], int lane) {
+  if constexpr (WLDS) rnn_matvec_lds<J, CN>(Wt, ctx, acc, lane);
+  else rnn_matvec<J, CN>(Wt, ctx, acc, lane);
+}
+
+// MikolovIndexCalculator::calcIndices + the weight gathers of MikolovScoreCalculator::calcScoresN for one
+// (word, history) pair; the caller adds w[0] + w[1] + ... left to right.  Every history slot holds
+// prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is
+// base + (prevId + 1) * coef[i].
+__device__ __forceinline__ void rnn_maxent_gather(const float* __restrict__ maxentT, i32 myid, i32 pid, u32 order, u64 mxBase,
+                                                  const u64 (&mxCoef)[4], u64 hashMax, u64 hashMagic, float (&w)[4]) {
+#pragma unroll
+  for (u32 i = 0; i < 4; ++i) {
+    if (i < order) {
+      const u64 xx = mxBase + ((u64)(i64)pid + 1) * mxCoef[i];
+      const u64 h = fastmod_u64(xx, hashMax, hashMagic);
+      // (h + id) % hash_max: h < hash_max, so one conditional subtraction does it for any id below
+      // hash_max; the general path covers id = -1 (wraps) and oversized ids
+      u64 idx = h + (u64)(i64)myid;
+      if ((u64)(i64)myid < hashMax) idx = idx >= hashMax ? idx - hashMax : idx;
+      else idx = fastmod_u64(idx, hashMax, hashMagic);
+      w[i] = maxentT[idx];
+    }
+  }
+}
+
 // WLDS: the padded transposed recurrent matrix lives in LDS and is shared by the 16 wavefronts
 // of the workgroup; otherwise (E > 128) W is streamed from L2.
 // SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
@@ -363,7 +509,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   const int lane = (int)(threadIdx.x & 63);
   __shared__ float s_W[WLDS ? EP * EP : 1];
   if (WLDS) {
-    for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[q] = M.rnn_wt[q];
+    for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[rnn_w2_index<(J <= 2 ? J : 1)>(q / EP, q % EP)] = M.rnn_wt[q];
     __syncthreads();
   }
   const float* __restrict__ Wt = WLDS ? s_W : M.rnn_wt;
@@ -402,14 +548,17 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
 
   // the per-node fields the boundary loop depends on are staged in LDS when they fit
   constexpr u32 kCap = 264, kCapB = 48;
-  __shared__ u32 l_prev_all[kWaves][kCap];
+  __shared__ u16 l_prev_all[kWaves][kCap];
   __shared__ i32 l_id_all[kWaves][kCap];
-  __shared__ u32 l_cnt_all[kWaves][kCapB];
-  // per connection (boundary, path): lattice node | slot, rnn node, gbeam index, perceptron score cell
+  __shared__ u8 l_cnt_all[kWaves][kCapB];
+  // per connection (boundary, path): lattice node | slot << 16 | rnn node << 22 | gbeam index << 27, perceptron score cell
   __shared__ u32 l_conn_all[kWaves][kCap];
-  __shared__ u8 l_assign_all[kWaves][kCap];
-  __shared__ u8 l_gi_all[kWaves][kCap];
+  __shared__ float l_ctx_all[kWaves][WLDS ? EP : 1];   // the context a matvec multiplies, read back as broadcasts
   __shared__ float l_cell0_all[kWaves][kCap];
+  __shared__ float l_mx_all[kWaves][kCap];
+  constexpr u32 kPassCap = 2 * kCapB;
+  __shared__ u16 l_pass_all[kWaves][kPassCap];
+  __shared__ u32 l_npass_all[kWaves];
   __shared__ float nscore_all[kWaves][kMaxGbeam];
   __shared__ float full_all[kWaves][kMaxGbeam];
   __shared__ float prev_total_all[kWaves][kMaxGbeam];
@@ -417,33 +566,27 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   float* full = full_all[wv];
   float* prev_total = prev_total_all[wv];
   const u32 nq = (bE + 1) * (u32)G;
-  const bool inLds = nq <= kCap && (bE + 1) <= kCapB;
+  const bool inLds = nq <= kCap && (bE + 1) <= kCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kCapB && G <= 32 && beam <= 64 && N <= 65535;
   const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
   const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
   const u32* rn_cnt = B.rnn_cnt + bb0;
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {
-      l_prev_all[wv][q] = rn_prev[q];
+      l_prev_all[wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
       l_id_all[wv][q] = rn_id[q];
     }
-    for (u32 q = lane; q <= bE; q += 64) l_cnt_all[wv][q] = rn_cnt[q];
-    rn_prev = l_prev_all[wv];
+    for (u32 q = lane; q <= bE; q += 64) l_cnt_all[wv][q] = (u8)rn_cnt[q];
     rn_id = l_id_all[wv];
-    rn_cnt = l_cnt_all[wv];
     // connections: every load below is independent, so they are all in flight together
     const i32* g_gi = B.rnn_id + (u64)bb0 * G;
     for (u32 q = lane; q < nq; q += 64) {
       const u32 c = conn[q];
       const u32 gi = (u32)g_gi[q];
-      l_conn_all[wv][q] = c;
-      l_assign_all[wv][q] = (u8)assign[q];
-      l_gi_all[wv][q] = (u8)gi;
+      l_conn_all[wv][q] = c == kNoConn ? kNoConn : ((c & 0xffffu) | ((c >> 26) << 16) | ((assign[q] & 31u) << 22) | ((gi & 31u) << 27));
       l_cell0_all[wv][q] = c != kNoConn ? B.node_cells[((nb + (c & 0x03ffffffu)) * G + gi) * S] : 0.f;
     }
   }
   const u32* l_conn = l_conn_all[wv];
-  const u8* l_assign = l_assign_all[wv];
-  const u8* l_gi = l_gi_all[wv];
   const float* l_cell0 = l_cell0_all[wv];
   float prevT = 0.f;  // running total of this lane's path (adjustBeamScores), BOS element total = 0
   JPP_RPROF_DECL;
@@ -461,140 +604,190 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     rn_ctx[(u64)1 * G * EP + i] = v;
   }
   wave_sync();
-  for (u32 b = 2; b <= bE; ++b) {
-    const int cnt = (int)rn_cnt[b];
-    if (cnt == 0) continue;
-    for (int c0 = 0; c0 < cnt; c0 += kRnnCN) {
-      const int cn = (cnt - c0) < kRnnCN ? (cnt - c0) : kRnnCN;
-      // maxent part of the scores first: its gathers depend on the word ids only, so they are in flight
-      // together with the context / embedding loads below.  Every context slot holds prev->id (reference
-      // quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is base + (prevId + 1) * coef[i].
-      float mw[4] = {0.f, 0.f, 0.f, 0.f};  // consumed only when the scores are formed, after the other loads went out
-      i32 myid = 0;
-      if (lane < cn) {
-        myid = rn_id[(u64)b * G + c0 + lane];
-        const i32 pid = rn_id[rn_prev[(u64)b * G + c0 + lane]];
-        const u32 order = mxOrder;
+  if (inLds) {
+    // Every word id is known before the recurrence starts, so everything that depends on ids only is
+    // taken off the serial chain: the maxent sums of all rnn nodes are computed here, one lane per node,
+    // and the embedding / NCE rows of pass i+1 are requested while pass i runs its matvec.
+    float* l_mx = l_mx_all[wv];
+    const u16* l_prev = l_prev_all[wv];
+    const u8* l_cnt = l_cnt_all[wv];
+    {
+      // all gathers of all rounds go out before the first sum (one HBM round trip, not one per round)
+      constexpr u32 kRounds = (kCap + 63) / 64;
+      float mw[kRounds][4];
 #pragma unroll
-        for (u32 i = 0; i < 4; ++i) {
-          mw[i] = 0.f;
-          if (i < order) {
-            const u64 xx = mxBase + ((u64)(i64)pid + 1) * mxCoef[i];
-            const u64 h = fastmod_u64(xx, hashMax, hashMagic);
-            // (h + id) % hash_max: h < hash_max, so one conditional subtraction does it for any id below
-            // hash_max; the general path covers id = -1 (wraps) and oversized ids
-            u64 idx = h + (u64)(i64)myid;
-            if ((u64)(i64)myid < hashMax) idx = idx >= hashMax ? idx - hashMax : idx;
-            else idx = fastmod_u64(idx, hashMax, hashMagic);
-            mw[i] = maxentT[idx];
+      for (u32 r = 0; r < kRounds; ++r) {
+        const u32 q = (u32)lane + 64u * r;
+        const u32 bq = q / (u32)G, iq = q - bq * (u32)G;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) mw[r][i] = 0.f;
+        if (q < nq && bq >= 2 && bq <= bE && iq < l_cnt[bq])
+          rnn_maxent_gather(maxentT, rn_id[q], rn_id[l_prev[q]], mxOrder, mxBase, mxCoef, hashMax, hashMagic, mw[r]);
+      }
+#pragma unroll
+      for (u32 r = 0; r < kRounds; ++r) {
+        const u32 q = (u32)lane + 64u * r;
+        float me = mw[r][0];
+#pragma unroll
+        for (u32 i = 1; i < 4; ++i)
+          if (i < mxOrder) me += mw[r][i];
+        if (q < nq) l_mx[q] = me;
+      }
+    }
+    // pass list: boundary | first node << 6 | (nodes - 1) << 11 | last pass of the boundary << 13
+    u16* l_pass = l_pass_all[wv];
+    {
+      // lane b lists the passes of boundary b (bE + 1 <= kCapB <= 64) at the offset an exclusive scan gives it
+      const u32 bq = (u32)lane;
+      const u32 cnt = (bq >= 2 && bq <= bE) ? l_cnt[bq] : 0u;
+      const u32 mine = (cnt + kRnnCN - 1) / kRnnCN;
+      const u32 incl = wave_scan_incl_u32(mine, lane);
+      u32 np = incl - mine;
+      for (u32 c0 = 0; c0 < cnt; c0 += kRnnCN) {
+        const u32 cn = (cnt - c0) < (u32)kRnnCN ? (cnt - c0) : (u32)kRnnCN;
+        l_pass[np++] = (u16)(bq | (c0 << 6) | ((cn - 1) << 11) | ((c0 + kRnnCN >= cnt ? 1u : 0u) << 13));
+      }
+      if (lane == 63) l_npass_all[wv] = incl;
+    }
+    wave_sync();
+    const u32 npass = l_npass_all[wv];
+    JPP_RPROF(1);
+    float nceR[kRnnCN][J], embR[kRnnCN][J];   // rows of the current pass
+    float lastOut[kRnnCN][J];                 // contexts produced by the previous pass, kept in registers
+    u32 lastBase = 0xffffffffu, lastCn = 0;
+#pragma unroll
+    for (int p = 0; p < kRnnCN; ++p)
+#pragma unroll
+      for (int j = 0; j < J; ++j) nceR[p][j] = embR[p][j] = lastOut[p][j] = 0.f;
+    // NCE rows (consumed by the dot product) / embedding rows (consumed after the matvec) of one pass
+    auto load_rows = [&](u32 pe, const float* __restrict__ table, bool wanted, float (&out)[kRnnCN][J]) {
+      const u32 b = pe & 63u, c0 = (pe >> 6) & 31u, cn = ((pe >> 11) & 3u) + 1;
+#pragma unroll
+      for (int p = 0; p < kRnnCN; ++p) {
+        if ((u32)p < cn) {
+          const i32 id = rn_id[b * (u32)G + c0 + p];
+          const u32 eid = id == -1 ? 0u : (u32)id;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const u32 i = (u32)lane * J + j;
+            out[p][j] = (i < E && wanted) ? table[(u64)eid * E + i] : 0.f;
           }
         }
       }
-      JPP_RPROF(1);
+    };
+    if (npass) load_rows(l_pass[0], nceT, true, nceR);
+    for (u32 pi = 0; pi < npass; ++pi) {
+      const u32 pe = l_pass[pi];
+      const u32 b = pe & 63u, c0 = (pe >> 6) & 31u;
+      const int cn = (int)((pe >> 11) & 3u) + 1;
+      const bool lastOfBnd = ((pe >> 13) & 1u) != 0;
+      // contexts of the predecessors: straight from the registers when the previous pass made them,
+      // otherwise from HBM/L2 (written at least one boundary, i.e. one wave_sync, ago).  Load order
+      // matters because loads return in order: contexts first, then this pass's embedding rows (needed
+      // only after the matvec); the NCE rows of the next pass go out after the dot product, so they
+      // travel during the matvec and nothing on the chain ever waits for a table row.
+      float ctx[kRnnCN][J];
+#pragma unroll
+      for (int p = 0; p < kRnnCN; ++p) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) ctx[p][j] = 0.f;
+        if (p < cn) {
+          const u32 hnd = l_prev[b * (u32)G + c0 + p];
+          const u32 rel = hnd - lastBase;
+          if (rel < lastCn) {
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+              ctx[p][j] = rel == 0 ? lastOut[0][j] : rel == 1 ? lastOut[1][j] : rel == 2 ? lastOut[2][j] : lastOut[3][j];
+          } else {
+            const float* cp = rn_ctx + (u64)hnd * EP + (u32)lane * J;
+#pragma unroll
+            for (int j = 0; j < J; ++j) ctx[p][j] = cp[j];
+          }
+        }
+      }
+      load_rows(pe, embT, b < bE, embR);
 #if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
       if (lane == 0) { rprof_pass += 1; rprof_nodes += (unsigned long long)cn; }
 #endif
-      float ctx[kRnnCN][J];
-      float embv[kRnnCN][J];
       float dot[kRnnCN];
 #pragma unroll
       for (int p = 0; p < kRnnCN; ++p) {
         dot[p] = 0.f;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          ctx[p][j] = 0.f;
-          embv[p][j] = 0.f;
-        }
-        if (p < cn) {
-          const u32 hnd = rn_prev[(u64)b * G + c0 + p];
-          const i32 id = rn_id[(u64)b * G + c0 + p];
-          const u32 eid = id == -1 ? 0u : (u32)id;
-          const float* cp = rn_ctx + (u64)hnd * EP + (u32)lane * J;
-#pragma unroll
-          for (int j = 0; j < J; ++j) ctx[p][j] = cp[j];
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            u32 i = (u32)lane * J + j;
-            if (i < E) {
-#if JPP_RNN_EXP == 2   // timing experiment: rows from one hot line instead of the embedding tables
-              dot[p] += nceT[i] * ctx[p][j];
-#else
-              dot[p] += nceT[(u64)eid * E + i] * ctx[p][j];
-#endif
-#if JPP_RNN_EXP == 2
-              if (b < bE) embv[p][j] = embT[i];
-#else
-              if (b < bE) embv[p][j] = embT[(u64)eid * E + i];
-#endif
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < kRnnCN; ++p) {
         if (p < cn) {
 #pragma unroll
-          for (int o = 32; o > 0; o >>= 1) dot[p] += wave_shfl_f32(dot[p], lane ^ o);
+          for (int j = 0; j < J; ++j) dot[p] += nceR[p][j] * ctx[p][j];
+          dot[p] = wave_sum_f32(dot[p]);
         }
       }
-      // score of rnn node c0 + x on lane x
-      if (lane < cn) {
+      if (lane < cn) {  // score of rnn node c0 + x on lane x
         const int x = lane;
         float score = x == 0 ? dot[0] : x == 1 ? dot[1] : x == 2 ? dot[2] : dot[3];
-        const i32 id = myid;
-        const u32 order = mxOrder;
-        float me = mw[0];
-#pragma unroll
-        for (u32 i = 1; i < 4; ++i)
-          if (i < order) me += mw[i];
-        if (order > 0) score += me;
+        const i32 id = rn_id[b * (u32)G + c0 + x];
+        if (mxOrder > 0) score += l_mx[b * (u32)G + c0 + x];
         else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
         score -= nceConst;
         if (id == unkId) score = unkConst + unkLen * (float)g_len[(u64)b * G + c0 + x];
         nscore[c0 + x] = score;
       }
+      if (pi + 1 < npass) load_rows(l_pass[pi + 1], nceT, true, nceR);
       JPP_RPROF(2);
-      // new contexts (GbeamRnnState::computeContext; not needed for EOS)
-      if (b < bE) {
+      if (b < bE) {  // new contexts (GbeamRnnState::computeContext; not needed for EOS)
         float acc[kRnnCN][J];
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
           for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
-#if JPP_RNN_EXP != 1
-        switch (cn) {
-          case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
-          case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
-          case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
-          default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
+        if constexpr (WLDS) {
+          // one node at a time: its context goes to LDS once and comes back as broadcast reads, four
+          // elements per read, instead of one v_readlane (+ hazard slots) per element
+          float* l_ctx = l_ctx_all[wv];
+#pragma unroll
+          for (int p = 0; p < kRnnCN; ++p) {
+            if (p < cn) {
+#pragma unroll
+              for (int j = 0; j < J; ++j) l_ctx[lane * J + j] = ctx[p][j];
+              wave_sync();
+              rnn_matvec_lds1<J>(Wt, l_ctx, acc[p], lane);
+              wave_sync();
+            }
+          }
+        } else {
+          switch (cn) {
+            case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
+            case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
+            case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
+            default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
+          }
         }
-#endif
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p) {
           if (p < cn) {
             float* op = rn_ctx + ((u64)b * G + c0 + p) * EP + (u32)lane * J;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-              u32 i = (u32)lane * J + j;
-              float x = acc[p][j] + embv[p][j];
-              op[j] = i < E ? 1.0f / (1.0f + expf(-x)) : 0.f;
+              const u32 i = (u32)lane * J + j;
+              const float x = acc[p][j] + embR[p][j];
+              const float y = i < E ? 1.0f / (1.0f + expf(-x)) : 0.f;
+              op[j] = y;
+              lastOut[p][j] = y;
             }
           }
         }
+        lastBase = b * (u32)G + c0;
+        lastCn = (u32)cn;
       }
-    }
-    JPP_RPROF(3);
-    wave_sync();
-    if (lane < ngb) {
-      if (inLds) {
+      JPP_RPROF(3);
+      if (!lastOfBnd) continue;
+      wave_sync();
+      if (lane < ngb) {
         // score cell of the connection and, fused, ScoreProcessor::adjustBeamScores for this boundary:
         // everything it needs was staged, so the loop carries no dependent HBM access
         const u32 q = b * (u32)G + (u32)lane;
         const u32 c = l_conn[q];
         if (c != kNoConn) {
-          const u32 nd = c & 0x03ffffffu, k = c >> 26;
-          const float rs = nscore[l_assign[q]];
-          B.node_cells[((nb + nd) * G + l_gi[q]) * S + 1] = rs;
+          const u32 nd = c & 0xffffu, k = (c >> 16) & 63u;
+          const float rs = nscore[(c >> 22) & 31u];
+          B.node_cells[((nb + nd) * G + (c >> 27)) * S + 1] = rs;
           if (b < bE) {
             float local = 0.f;
             local += l_cell0[q] * cfg.w_perceptron;
@@ -610,7 +803,136 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
             prev_total[lane] = prevT;
           }
         }
-      } else {
+      }
+      wave_sync();
+      JPP_RPROF(4);
+    }
+  } else {
+    for (u32 b = 2; b <= bE; ++b) {
+      const int cnt = (int)rn_cnt[b];
+      if (cnt == 0) continue;
+      for (int c0 = 0; c0 < cnt; c0 += kRnnCN) {
+        const int cn = (cnt - c0) < kRnnCN ? (cnt - c0) : kRnnCN;
+        // maxent part of the scores first: its gathers depend on the word ids only, so they are in flight
+        // together with the context / embedding loads below.  Every context slot holds prev->id (reference
+        // quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is base + (prevId + 1) * coef[i].
+        float mw[4] = {0.f, 0.f, 0.f, 0.f};  // consumed only when the scores are formed, after the other loads went out
+        i32 myid = 0;
+        if (lane < cn) {
+          myid = rn_id[(u64)b * G + c0 + lane];
+          const i32 pid = rn_id[rn_prev[(u64)b * G + c0 + lane]];
+          const u32 order = mxOrder;
+#pragma unroll
+          for (u32 i = 0; i < 4; ++i) {
+            mw[i] = 0.f;
+            if (i < order) {
+              const u64 xx = mxBase + ((u64)(i64)pid + 1) * mxCoef[i];
+              const u64 h = fastmod_u64(xx, hashMax, hashMagic);
+              // (h + id) % hash_max: h < hash_max, so one conditional subtraction does it for any id below
+              // hash_max; the general path covers id = -1 (wraps) and oversized ids
+              u64 idx = h + (u64)(i64)myid;
+              if ((u64)(i64)myid < hashMax) idx = idx >= hashMax ? idx - hashMax : idx;
+              else idx = fastmod_u64(idx, hashMax, hashMagic);
+              mw[i] = maxentT[idx];
+            }
+          }
+        }
+        JPP_RPROF(1);
+#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
+        if (lane == 0) { rprof_pass += 1; rprof_nodes += (unsigned long long)cn; }
+#endif
+        float ctx[kRnnCN][J];
+        float embv[kRnnCN][J];
+        float dot[kRnnCN];
+#pragma unroll
+        for (int p = 0; p < kRnnCN; ++p) {
+          dot[p] = 0.f;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            ctx[p][j] = 0.f;
+            embv[p][j] = 0.f;
+          }
+          if (p < cn) {
+            const u32 hnd = rn_prev[(u64)b * G + c0 + p];
+            const i32 id = rn_id[(u64)b * G + c0 + p];
+            const u32 eid = id == -1 ? 0u : (u32)id;
+            const float* cp = rn_ctx + (u64)hnd * EP + (u32)lane * J;
+#pragma unroll
+            for (int j = 0; j < J; ++j) ctx[p][j] = cp[j];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+              u32 i = (u32)lane * J + j;
+              if (i < E) {
+#if JPP_RNN_EXP == 2   // timing experiment: rows from one hot line instead of the embedding tables
+                dot[p] += nceT[i] * ctx[p][j];
+#else
+                dot[p] += nceT[(u64)eid * E + i] * ctx[p][j];
+#endif
+#if JPP_RNN_EXP == 2
+                if (b < bE) embv[p][j] = embT[i];
+#else
+                if (b < bE) embv[p][j] = embT[(u64)eid * E + i];
+#endif
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < kRnnCN; ++p) {
+          if (p < cn) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dot[p] += wave_shfl_f32(dot[p], lane ^ o);
+          }
+        }
+        // score of rnn node c0 + x on lane x
+        if (lane < cn) {
+          const int x = lane;
+          float score = x == 0 ? dot[0] : x == 1 ? dot[1] : x == 2 ? dot[2] : dot[3];
+          const i32 id = myid;
+          const u32 order = mxOrder;
+          float me = mw[0];
+#pragma unroll
+          for (u32 i = 1; i < 4; ++i)
+            if (i < order) me += mw[i];
+          if (order > 0) score += me;
+          else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+          score -= nceConst;
+          if (id == unkId) score = unkConst + unkLen * (float)g_len[(u64)b * G + c0 + x];
+          nscore[c0 + x] = score;
+        }
+        JPP_RPROF(2);
+        // new contexts (GbeamRnnState::computeContext; not needed for EOS)
+        if (b < bE) {
+          float acc[kRnnCN][J];
+#pragma unroll
+          for (int p = 0; p < kRnnCN; ++p)
+#pragma unroll
+            for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
+#if JPP_RNN_EXP != 1
+          switch (cn) {
+            case 1: rnn_matvec_any<J, 1, WLDS>(Wt, ctx, acc, lane); break;
+            case 2: rnn_matvec_any<J, 2, WLDS>(Wt, ctx, acc, lane); break;
+            case 3: rnn_matvec_any<J, 3, WLDS>(Wt, ctx, acc, lane); break;
+            default: rnn_matvec_any<J, 4, WLDS>(Wt, ctx, acc, lane); break;
+          }
+#endif
+#pragma unroll
+          for (int p = 0; p < kRnnCN; ++p) {
+            if (p < cn) {
+              float* op = rn_ctx + ((u64)b * G + c0 + p) * EP + (u32)lane * J;
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                u32 i = (u32)lane * J + j;
+                float x = acc[p][j] + embv[p][j];
+                op[j] = i < E ? 1.0f / (1.0f + expf(-x)) : 0.f;
+              }
+            }
+          }
+        }
+      }
+      JPP_RPROF(3);
+      wave_sync();
+      if (lane < ngb) {
         u32 c = conn[(u64)b * G + lane];
         if (c != kNoConn) {
           u32 nd = c & 0x03ffffffu, k = c >> 26;
@@ -618,10 +940,10 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
           B.node_cells[((nb + nd) * G + gi) * S + 1] = nscore[assign[(u64)b * G + lane]];
         }
       }
+      wave_sync();
     }
-    wave_sync();
-  }
 
+  }
   JPP_RPROF(4);
   // ---- D. adjustBeamScores along the EOS paths ----
   const u32 efirstE = B.end_first[bb0 + bE];
