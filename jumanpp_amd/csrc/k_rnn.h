@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   __shared__ i32 l_id_all[kRnnPrepWaves][kCap];
   __shared__ u32 l_len_all[kRnnPrepWaves][kCap];
   __shared__ u32 l_cnt_all[kRnnPrepWaves][kCapB];
+  __shared__ u16 l_clen_all[kRnnPrepWaves][kCap];   // codepoints of every connection's lattice node
   const u32 nq = (bE + 1) * (u32)G;
   const bool inLds = nq <= kCap && (bE + 1) <= kCapB;
   u32* g_conn = B.rnn_conn + (u64)bb0 * G;
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   i32* rn_id = inLds ? l_id_all[wv] : g_id;
   u32* rn_len = inLds ? l_len_all[wv] : g_len;
   u32* rn_cnt = inLds ? l_cnt_all[wv] : g_cnt;                  // rnn nodes per boundary
+  u16* clen = inLds ? l_clen_all[wv] : nullptr;
 
   // ---- A. connection of every EOS path at every boundary ----
   for (u32 q = lane; q < nq; q += 64) conn[q] = kNoConn;
@@ -224,6 +226,8 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
     u32 c = conn[q];
     if (c == kNoConn) continue;
     const u32 nd = c & 0x03ffffffu;
+    // the node length the replay below hashes: fetched here, lane per connection, not on its serial chain
+    if (clen) clen[q] = (nd == N - 1) ? (u16)0 : (u16)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
     const u32 b = q / (u32)G, p = q - b * (u32)G;
     for (u32 pp = 0; pp < p; ++pp) {
       const u32 c2 = conn[(u64)b * G + pp];
@@ -271,7 +275,8 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
           } else {
             u32 nd = c & 0x03ffffffu;
             i32 id = wid[(u64)b * G + p];
-            u32 len = (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
+            u32 len = clen ? (u32)clen[(u64)b * G + p]
+                           : (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
             u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
             u32 cnt = rn_cnt[b];
             // crdCache_.find(coord): newest published node with the same (boundary, length, id)
