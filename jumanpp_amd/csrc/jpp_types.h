@@ -181,6 +181,7 @@ struct Batch {
   u16* pos_cnt1;           // dictionary + stage-1 maker nodes (w/o normalize) starting at position g
   u16* pos_cntN;           // normalize-maker nodes starting at position g
   u16* pos_cnt2;           // stage-2 maker nodes starting at position g
+  u64* pos_ends;           // bit e set: a stage-1 node starting at position g ends at codepoint e (e <= 63), from the count pass
   u8* reach;               // [g] connectivity scratch
   u32* sent_nodes;         // nodes of sentence incl. 2 BOS + EOS (after stage decision)
   u32* sent_nodes2;        // node count with stage 2 (scratch for the relocation scan)

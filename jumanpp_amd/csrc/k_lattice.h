@@ -71,6 +71,18 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_layout(Batch B) {
     if (m > maxR) maxR = m;
     overflow = overflow || wave_ballot(ovf) != 0;
   }
+  if (STAGE == 1 && n > 0 && n <= 63 && B.sent_status[s] == ST_OK) {
+    // does the end of input connect through dictionary + stage-1 nodes?  Their ends are known from the
+    // count pass, so a sentence that needs the stage-2 makers is flagged before anything is emitted and
+    // its nodes are written once (k_seeds<2>) instead of twice.  Longer sentences: k_connect<1>.
+    const u64 mask = (u32)lane < n ? B.pos_ends[g0 + lane] : u64{0};
+    u64 reach = 1;
+    for (u32 i = 0; i < n; ++i) {
+      const u64 m = wave_shfl_u64(mask, (int)i);
+      if ((reach >> i) & 1) reach |= m;
+    }
+    if (((reach >> n) & 1) == 0 && lane == 0) B.sent_flags[s] |= 2;
+  }
   if (lane != 0) return;
   // one atomic per sentence would serialise 64k updates of one address: skip it when the published
   // maximum (monotonic, possibly stale) already covers this sentence
@@ -171,6 +183,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_connect(Batch B) {
   if (s >= B.n_sent) return;
   if (B.sent_status[s] != ST_OK) return;
   if (PASS == 2 && (B.sent_flags[s] & 2) == 0) return;
+  if (PASS == 1 && (B.sent_flags[s] & 2) != 0) return;  // flagged by k_layout<1>: nothing was emitted for it yet
   const u32 off = B.byte_off[s];
   const u32 g0 = off + s;
   const u32 bb0 = off + 4 * s;

@@ -43,7 +43,10 @@ struct SeedSink {
   NodeInfo* ni;
   NodeAux* na;
   u32 n;
+  u64 ends;  // count pass: bit e for every node end e <= 63 (reachability without emitting, k_layout<1>)
+  __device__ __forceinline__ void mark_end(u32 e) { ends |= e < 64 ? (u64{1} << e) : u64{0}; }
   __device__ __forceinline__ void dic(i32 eptr, u32 s, u32 e) {
+    mark_end(e);
     if (emit) {
       ni[n] = NodeInfo{eptr, (u16)s, (u16)e};
       na[n] = NodeAux{0, 0, 0, 0, 0, 0};
@@ -51,6 +54,7 @@ struct SeedSink {
     ++n;
   }
   __device__ __forceinline__ void unk(i32 tmpl, i32 hash, i32 ph0, i32 ph1, u32 maker, u32 s, u32 e) {
+    mark_end(e);
     if (emit) {
       ni[n] = NodeInfo{-1, (u16)s, (u16)e};  // final ~index is assigned by k_ends
       na[n] = NodeAux{tmpl, hash, (u16)ph0, (u16)ph1, (u16)maker, 0};
@@ -71,6 +75,7 @@ __device__ __forceinline__ i32 surface_hash(const SentView& S, u32 s, u32 e) {
 __device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, const SentView& S,
                                          SeedSink& out, u32 s, u32 e, bool notPrefix) {
   if (!out.emit) {
+    out.mark_end(e);
     ++out.n;
     return;
   }
@@ -481,6 +486,7 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
   if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
+  if (MODE == 1 && (B.sent_flags[s] & 2) != 0) return;  // known from the count pass to need stage 2: emitted once, by MODE 2
   u32 off = B.byte_off[s];
   u32 g0 = off + s;
   u32 bb0 = off + 4 * s;
@@ -490,6 +496,7 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
     SeedSink out;
     out.emit = MODE != 0;
     out.n = 0;
+    out.ends = 0;
     if (MODE != 0) {
       u32 first = B.bnd_first[bb0 + i + 2];
       out.ni = B.node_info + nbase + first;
@@ -507,6 +514,7 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
 #endif
     if (MODE == 0) {
       B.pos_cnt1[g0 + i] = (u16)(out.n > 0xffff ? 0xffff : out.n);
+      B.pos_ends[g0 + i] = out.ends;   // stage-1 ends only; k_norm<0> adds the normalized nodes'
       u32 n1 = out.n;
       for (int m = M.n_stage1; m < M.n_unk; ++m) run_maker(M, M.makers[m], S, i, w, out);
       B.pos_cnt2[g0 + i] = (u16)(out.n - n1);
@@ -536,6 +544,7 @@ __global__ void k_norm(Batch B, const DevModel* __restrict__ Mp) {
   }
   if (!applicable) return;
   if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
+  if (MODE == 1 && (B.sent_flags[s] & 2) != 0) return;
   SentView S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, n};
   const UnkMaker& mk = M.makers[M.norm_maker];
   u64 nbase = MODE == 0 ? 0 : B.node_base[s];
@@ -548,9 +557,13 @@ __global__ void k_norm(Batch B, const DevModel* __restrict__ Mp) {
     }
     if (MODE == 0) {
       B.pos_cntN[g0 + i] = (u16)nr;
+      u64 ends = 0;
+      for (int k = 0; k < nr; ++k) ends |= res[k].end < 64 ? (u64{1} << res[k].end) : u64{0};
+      if (ends) B.pos_ends[g0 + i] |= ends;   // k_seeds<0> of this launch sequence wrote the word already
     } else {
       SeedSink out;
       out.emit = true;
+      out.ends = 0;
       u32 first = B.bnd_first[bb0 + i + 2] + B.pos_cnt1[g0 + i];
       out.ni = B.node_info + nbase + first;
       out.na = B.node_aux + nbase + first;
