@@ -293,3 +293,21 @@ def test_emulated_kernels_on_fuzzed_character_classes(emu_lib, ref_tools, tmp_pa
     for s in range(len(lines)):
         errs += G.compare_sentence(res, s, gold[s], meta)
     assert not errs, (len(errs), errs[:10])
+
+
+def test_emulated_maximum_size_sentences(emu_lib, ref_tools, tmp_path):
+    """1 300 codepoints (≈3.9 KB, just under maxInputBytes = 4096): every LDS-staged path falls back to
+    its long-sentence branch (u64 reach mask, LDS ends lists, RNN bookkeeping) and must still match."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    img, lines, gold_path = tg._fresh_workload(ref_tools, str(tmp_path), 2500, 2, 14, 5, length=1300)
+    assert all(3500 < len(l.encode('utf-8')) <= 4096 for l in lines)
+    ctx = J.Context(img, lib_path=emu_lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    assert list(res.status) == [0, 0]
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]

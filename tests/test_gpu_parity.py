@@ -258,3 +258,20 @@ def test_gpu_top1_fetch_equals_basic_fetch(gpu_lib, golden_dir, model):
     lines = [l.rstrip('\n').encode('utf-8') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
     lines = (lines + [b'', b'\xe3\x81', lines[3][:9]]) * 100
     assert tc.check_top1_fetch_equals_basic_fetch(ctx, lines) > 10000
+
+
+@pytest.mark.parametrize('rnn', [None, (64, 3000)])
+def test_gpu_maximum_size_sentences(gpu_lib, ref_tools, tmp_path, rnn):
+    """1 300-codepoint sentences (just under maxInputBytes = 4096), perceptron and RNN: the long-sentence
+    branches of every kernel against the live reference"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 2500, 6, 14, 5, length=1300, rnn=rnn)
+    ctx = J.Context(img, lib_path=gpu_lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    assert int((res.status != 0).sum()) == 0
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
