@@ -5,7 +5,7 @@
 // `jumanpp_v2 --model=... ` in the JUMAN format.
 //
 // usage: jumanpp_gpu --model=MODEL.jppmdl [--beam=5] [--global-beam=6] [--right-check=1]
-//                    [--right-beam=5] [--no-rnn] [-s N | -M | -F | --segment] [--partial-input]
+//                    [--right-beam=5] [--no-rnn] [-s N | -M | -F | --segment | --dic-subset] [--partial-input]
 //                    [--auto-nbest=B:S:M] [--batch=65536] [--threads=N] [--no-pipeline]
 //                    [--device=0] [--timing] [-o OUT] [INPUT...]
 #include <algorithm>
@@ -44,7 +44,7 @@ struct Conf {
   std::vector<std::string> inputs;
   bool timing = false;
   int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
-  enum { Juman, Morph, FullMorph, Segment } kind = Juman;
+  enum { Juman, Morph, FullMorph, Segment, DicSubset } kind = Juman;
   std::string segmentSeparator = " ";
   bool partialInput = false;  // --partial-input: InputType::PartiallyAnnotated
   int autoStep = 0;           // --auto-nbest=base:step:max (jumanpp_args.cc:270-279)
@@ -172,6 +172,7 @@ int main(int argc, const char** argv) {
              argValue(argc, argv, i, "-s", &v) || argValue(argc, argv, i, "-L", &v)) conf.lattice = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--segment-separator", &v)) conf.segmentSeparator = v;
     else if (std::strcmp(argv[i], "--segment") == 0) conf.kind = Conf::Segment;
+    else if (std::strcmp(argv[i], "--dic-subset") == 0) conf.kind = Conf::DicSubset;
     else if (std::strcmp(argv[i], "--morph") == 0 || std::strcmp(argv[i], "-M") == 0) conf.kind = Conf::Morph;
     else if (std::strcmp(argv[i], "--full-morph") == 0 || std::strcmp(argv[i], "-F") == 0) conf.kind = Conf::FullMorph;
     else if (std::strcmp(argv[i], "--juman") == 0 || std::strcmp(argv[i], "-j") == 0) conf.kind = Conf::Juman;
@@ -228,17 +229,23 @@ int main(int argc, const char** argv) {
   if (conf.threads <= 0) conf.threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   // JumanppExec::initOutput (jumandic_env.cc:55-150) and emptyResult (:211-222); one instance per format worker
   StringPiece emptyResult = "# ERROR\nEOS\n";
-  const bool useLattice = conf.lattice != 0;
-  if (!useLattice && (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph)) emptyResult = "# ERROR\n";
-  if (!useLattice && conf.kind == Conf::Segment) emptyResult = "";
+  const bool latticeFormat = conf.lattice != 0;
+  const bool useLattice = latticeFormat || conf.kind == Conf::DicSubset;  // formats that read the whole lattice
+  if (!latticeFormat && (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph)) emptyResult = "# ERROR\n";
+  if (!latticeFormat && (conf.kind == Conf::Segment || conf.kind == Conf::DicSubset)) emptyResult = "";
   auto makeFormat = [&](Status* st) -> OutputFormat* {
-    if (useLattice) {
+    if (latticeFormat) {
       auto f = new LatticeFormat(conf.lattice == -1 ? conf.beam : conf.lattice);
       *st = f->initialize(&model, def.scoreWeights);
       return f;
     }
     if (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph) {
       auto f = new MorphFormat(conf.kind == Conf::FullMorph);
+      *st = f->initialize(&model);
+      return f;
+    }
+    if (conf.kind == Conf::DicSubset) {
+      auto f = new SubsetFormat();
       *st = f->initialize(&model);
       return f;
     }

@@ -223,7 +223,8 @@ def test_lattice_format_byte_identical_to_reference_cli(cli_emu, ref_tools, tmp_
 
 
 def test_morph_and_segmented_formats_byte_identical(cli_emu, ref_tools, tmp_path):
-    """-M / -F (MorphFormat) and --segment (SegmentedFormat), incl. comments and failing lines"""
+    """-M / -F (MorphFormat), --segment (SegmentedFormat) and --dic-subset (SubsetFormat = full morph +
+    every dictionary node of the lattice as a dictionary CSV line), incl. comments and failing lines"""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     import test_gpu_parity as tg
@@ -231,7 +232,7 @@ def test_morph_and_segmented_formats_byte_identical(cli_emu, ref_tools, tmp_path
     img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 14, 14, 31, length=32)
     with open(os.path.join(tmp, 'w.txt'), 'ab') as f:
         f.write('\n# S-ID:7\nすごーーい〜かぁっこいいねぇっッ！\n'.encode('utf-8') + b'\xe3\x81\n')
-    for flags in (['-M'], ['-F'], ['--segment'], ['--segment', '--segment-separator=|']):
+    for flags in (['-M'], ['-F'], ['--segment'], ['--segment', '--segment-separator=|'], ['--dic-subset']):
         ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt'))
         rc, out, err = _run(cli_emu, ['--model=' + img] + flags + [os.path.join(tmp, 'w.txt')])
         assert out == ref, flags
@@ -517,3 +518,26 @@ def test_gpu_cli_at_scale_on_the_bench_workload(cli_gpu, ref_tools, tmp_path, rn
             eos = gold[k].bnds[len(gold[k].bnds) - 1]['nodes'][0]['beam']
             tot = [float(x['total']) for x in eos if x['valid']]
             assert len(tot) > 1 and abs(tot[0] - tot[1]) <= 1e-4 * max(1.0, abs(tot[0])), (i, tot[:3])
+
+
+def test_dic_subset_csv_quoting(cli_emu, ref_tools, tmp_path):
+    """--dic-subset with dictionary fields that contain commas and quotes (CSV quoting of MdicFormat)"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    tmp = str(tmp_path)
+    mdic = os.path.join(tmp, 'd.mdic')
+    with open(mdic, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), '300', '--seed', '3'], stdout=f)
+        f.write('引用符,0,0,0,名詞,普通名詞,*,*,引用符,"いん,よう",引用符/いんようふ,"代表表記:引用符/いん""よう カテゴリ:抽象物,記号"\n')
+        f.write('コンマ,0,0,0,名詞,普通名詞,*,*,"コ""ンマ",こんま,コンマ/こんま,代表表記:コンマ/こんま\n')
+    subprocess.check_call([os.path.join(ref_tools, 'jpp_jumandic_bootstrap'), mdic, os.path.join(tmp, 'd.seed')],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    model = os.path.join(tmp, 'd.model')
+    subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'mkmodel', os.path.join(tmp, 'd.seed'), model, '14', '3', '0.1'])
+    txt = os.path.join(tmp, 't.txt')
+    with open(txt, 'w', encoding='utf-8') as f:
+        f.write('引用符とコンマ\n# a comment\nコンマ引用符コンマ\n')
+    ref = _ref_cli(ref_tools, model, ['--dic-subset'], txt)
+    rc, out, err = _run(cli_emu, ['--model=' + model, '--dic-subset', txt])
+    assert rc == 0 and out == ref, err[-300:]
+    assert b'"' in out and b'""' in out
