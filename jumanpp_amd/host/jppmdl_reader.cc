@@ -434,12 +434,18 @@ Status ModelImage::loadJppmdl(const std::string& fn) {
       if (defined) *defined = flag != 0;
       return v;
     };
-    (void)cfgFloat(nullptr);  // nceBias
-    m.rnn_unk_constant = cfgFloat(nullptr);
-    m.rnn_unk_length = cfgFloat(nullptr);
-    rnnWeights_.perceptron = cfgFloat(nullptr);
-    bool rnnWeightDefined = false;
-    rnnWeights_.rnn = cfgFloat(&rnnWeightDefined);
+    RnnConfigOverride& sc = savedRnnConfig_;
+    sc.nceBias = cfgFloat(&sc.hasNceBias);
+    sc.unkConstantTerm = cfgFloat(&sc.hasUnkConstantTerm);
+    sc.unkLengthPenalty = cfgFloat(&sc.hasUnkLengthPenalty);
+    sc.perceptronWeight = cfgFloat(&sc.hasPerceptronWeight);
+    sc.rnnWeight = cfgFloat(&sc.hasRnnWeight);
+    hasSavedRnnConfig_ = true;
+    m.rnn_unk_constant = sc.unkConstantTerm;
+    m.rnn_unk_length = sc.unkLengthPenalty;
+    rnnWeights_.perceptron = sc.perceptronWeight;
+    rnnWeights_.rnn = sc.rnnWeight;
+    const bool rnnWeightDefined = sc.hasRnnWeight;
     (void)r.varint(); (void)r.str();   // eosSymbol
     (void)r.varint(); (void)r.str();   // unkSymbol
     (void)r.varint(); (void)r.strs();  // rnnFields
@@ -467,6 +473,38 @@ Status ModelImage::loadJppmdl(const std::string& fn) {
     m.has_rnn = 1;
     hasRnn_ = true;
   }
+  return Status::Ok();
+}
+
+Status ModelImage::applyRnnConfig(const RnnConfigOverride& o, bool* useRnn, RnnScoreWeights* weights) {
+  if (!hasRnn_) return Status::InvalidState("the model has no RNN part");
+  if (!hasSavedRnnConfig_)
+    return Status::NotImplemented("RNN parameter overrides need the model's saved RNN configuration: load the .jppmdl file");
+  if (o.rnnWeight == 0.0f) {  // JumanppEnv::setRnnConfig: "disable rnn"
+    *useRnn = false;
+    weights->perceptron = o.perceptronWeight;
+    weights->rnn = 0.0f;
+    return Status::Ok();
+  }
+  // state_->config.mergeWith(config): a given value replaces the saved one
+  RnnConfigOverride& sc = savedRnnConfig_;
+  auto merge = [](float& v, bool& has, float ov, bool ohas) {
+    if (ohas) {
+      v = ov;
+      has = true;
+    }
+  };
+  merge(sc.nceBias, sc.hasNceBias, o.nceBias, o.hasNceBias);
+  merge(sc.unkConstantTerm, sc.hasUnkConstantTerm, o.unkConstantTerm, o.hasUnkConstantTerm);
+  merge(sc.unkLengthPenalty, sc.hasUnkLengthPenalty, o.unkLengthPenalty, o.hasUnkLengthPenalty);
+  merge(sc.perceptronWeight, sc.hasPerceptronWeight, o.perceptronWeight, o.hasPerceptronWeight);
+  merge(sc.rnnWeight, sc.hasRnnWeight, o.rnnWeight, o.hasRnnWeight);
+  if (sc.hasNceBias) model_.rnn_nce_constant = sc.nceBias;  // setNceConstant(config.nceBias) when it is not default
+  model_.rnn_unk_constant = sc.unkConstantTerm;
+  model_.rnn_unk_length = sc.unkLengthPenalty;
+  *useRnn = true;
+  weights->perceptron = o.perceptronWeight;  // scoreWeights come from the override itself, not from the merge
+  weights->rnn = o.rnnWeight;
   return Status::Ok();
 }
 

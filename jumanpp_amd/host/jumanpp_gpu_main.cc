@@ -5,6 +5,8 @@
 // `jumanpp_v2 --model=... ` in the JUMAN format.
 //
 // usage: jumanpp_gpu --model=MODEL.jppmdl [--beam=5] [--global-beam=6] [--right-check=1]
+//                    [-c CONFIG] [--rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X
+//                    --feature-weight-perceptron=X --feature-weight-rnn=X]
 //                    [--right-beam=5] [--no-rnn] [-s N | -M | -F | --segment | --dic-subset] [--partial-input]
 //                    [--auto-nbest=B:S:M] [--batch=65536] [--threads=N] [--no-pipeline]
 //                    [--device=0] [--timing] [-o OUT] [INPUT...]
@@ -48,6 +50,8 @@ struct Conf {
   std::string segmentSeparator = " ";
   bool partialInput = false;  // --partial-input: InputType::PartiallyAnnotated
   int autoStep = 0;           // --auto-nbest=base:step:max (jumanpp_args.cc:270-279)
+  std::string configFile;     // -c / --config: file of whitespace-separated arguments, read before the command line
+  RnnConfigOverride rnn;  // --rnn-nce-bias, --rnn-unk-constant, --rnn-unk-length, --feature-weight-*
   int threads = 0;            // --threads=N format workers (0: one per hardware thread, at most 32)
   bool pipeline = true;       // --no-pipeline: one analyzer, read/analyse/format strictly in turn per batch
 };
@@ -154,11 +158,14 @@ struct Clock {
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - start).count(); }
 };
 
-}  // namespace
-
-int main(int argc, const char** argv) {
-  Conf conf;
-  for (int i = 1; i < argc; ++i) {
+// one list of arguments (a config file's tokens or the command line without argv[0]) into `conf`;
+// later lists override earlier ones, like JumanppConf::mergeWith (jumanpp_args.cc:343-400)
+bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
+  std::vector<const char*> ptrs;
+  for (auto& a : args) ptrs.push_back(a.c_str());
+  const int argc = (int)ptrs.size();
+  const char** argv = ptrs.data();
+  for (int i = 0; i < argc; ++i) {
     std::string v;
     if (argValue(argc, argv, i, "--model", &v)) conf.model = v;
     else if (argValue(argc, argv, i, "--beam", &v)) conf.beam = std::atoi(v.c_str());
@@ -187,13 +194,66 @@ int main(int argc, const char** argv) {
       }
     } else if (std::strcmp(argv[i], "--partial-input") == 0) conf.partialInput = true;
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
+    else if (argValue(argc, argv, i, "--config", &v) || argValue(argc, argv, i, "-c", &v)) conf.configFile = v;
+    else if (argValue(argc, argv, i, "--rnn-nce-bias", &v)) { conf.rnn.nceBias = std::strtof(v.c_str(), nullptr); conf.rnn.hasNceBias = true; }
+    else if (argValue(argc, argv, i, "--rnn-unk-constant", &v)) { conf.rnn.unkConstantTerm = std::strtof(v.c_str(), nullptr); conf.rnn.hasUnkConstantTerm = true; }
+    else if (argValue(argc, argv, i, "--rnn-unk-length", &v)) { conf.rnn.unkLengthPenalty = std::strtof(v.c_str(), nullptr); conf.rnn.hasUnkLengthPenalty = true; }
+    else if (argValue(argc, argv, i, "--feature-weight-perceptron", &v)) { conf.rnn.perceptronWeight = std::strtof(v.c_str(), nullptr); conf.rnn.hasPerceptronWeight = true; }
+    else if (argValue(argc, argv, i, "--feature-weight-rnn", &v)) { conf.rnn.rnnWeight = std::strtof(v.c_str(), nullptr); conf.rnn.hasRnnWeight = true; }
     else if (argValue(argc, argv, i, "--threads", &v)) conf.threads = std::atoi(v.c_str());
     else if (std::strcmp(argv[i], "--no-pipeline") == 0) conf.pipeline = false;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
       std::cerr << "unknown option " << argv[i] << "\n";
-      return 1;
+      return false;
     } else conf.inputs.push_back(argv[i]);
+  }
+  return true;
+}
+
+// JppArgsParser::parseFile (jumanpp_args.cc:183-211): the file's text split at white space
+bool readConfigFile(const std::string& path, std::vector<std::string>* tokens) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::string tok;
+  while (f >> tok) tokens->push_back(tok);
+  return true;
+}
+
+bool fileExists(const std::string& p) { return std::ifstream(p, std::ios::binary).good(); }
+
+}  // namespace
+
+int main(int argc, const char** argv) {
+  Conf conf;
+  std::vector<std::string> cmdline(argv + 1, argv + argc);
+  {
+    // the config file named on the command line, else ~/.config/jumanpp/jumandic.config, is read first
+    Conf probe;
+    if (!parseArgList(cmdline, probe)) return 1;
+    std::string cfgPath = probe.configFile;
+    bool explicitCfg = !cfgPath.empty();
+    if (!explicitCfg) {
+      if (const char* home = std::getenv("HOME")) cfgPath = std::string(home) + "/.config/jumanpp/jumandic.config";
+    }
+    std::vector<std::string> tokens;
+    if (!cfgPath.empty() && readConfigFile(cfgPath, &tokens)) {
+      if (!parseArgList(tokens, conf)) {
+        std::cerr << "failed to parse provided config at: " << cfgPath << "\n";
+        return 1;
+      }
+      conf.configFile = cfgPath;
+    } else if (explicitCfg) {
+      std::cerr << "failed to parse provided config at: " << cfgPath << "\n";
+      return 1;
+    }
+    if (!parseArgList(cmdline, conf)) return 1;
+    // fixupModelPath (jumanpp_args.cc:302-338): a relative model path that does not exist is tried next to the config file
+    if (!conf.configFile.empty() && !conf.model.empty() && conf.model[0] != '/' && !fileExists(conf.model)) {
+      size_t slash = conf.configFile.find_last_of('/');
+      std::string rel = (slash == std::string::npos ? std::string(".") : conf.configFile.substr(0, slash)) + "/" + conf.model;
+      if (fileExists(rel)) conf.model = rel;
+    }
   }
   if (conf.model.empty()) {
     std::cerr << "Model file was not specified\n";
@@ -219,9 +279,22 @@ int main(int argc, const char** argv) {
   sconf.beamSize = conf.beam;
   ScorerDef def;
   def.useRnn = model.hasRnn() && !conf.noRnn;
+  RnnScoreWeights weights = model.savedScoreWeights();
+  if (def.useRnn && !conf.rnn.isDefault()) {  // JumanppExec::init: env.setRnnConfig(conf.rnnConfig), jumandic_env.cc:40-42
+    bool useRnn = true;
+    s = model.applyRnnConfig(conf.rnn, &useRnn, &weights);
+    if (!s) {
+      std::cerr << "failed to apply the RNN configuration: " << s << "\n";
+      return 1;
+    }
+    def.useRnn = useRnn;
+  }
   if (def.useRnn) {
     sconf.numScorers = 2;
-    def.scoreWeights = {model.savedScoreWeights().perceptron, model.savedScoreWeights().rnn};
+    def.scoreWeights = {weights.perceptron, weights.rnn};
+  } else if (model.hasRnn() && !conf.noRnn) {
+    sconf.numScorers = 1;
+    def.scoreWeights = {weights.perceptron};  // RNN switched off by --feature-weight-rnn=0: one scorer, its given weight
   } else {
     sconf.numScorers = 1;
     def.scoreWeights = {1.0f};

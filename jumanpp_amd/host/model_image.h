@@ -47,6 +47,17 @@ struct RnnScoreWeights {
   float rnn = 0.0f;
 };
 
+// analysis::rnn::RnnInferenceConfig as command-line / config-file flags give it (rnn_arg_parse.h):
+// value + "was it given" for the five numeric parameters
+struct RnnConfigOverride {
+  float nceBias = -9.0f, unkConstantTerm = -6.0f, unkLengthPenalty = -1.5f, perceptronWeight = 1.0f, rnnWeight = 1.0f;
+  bool hasNceBias = false, hasUnkConstantTerm = false, hasUnkLengthPenalty = false, hasPerceptronWeight = false,
+       hasRnnWeight = false;
+  bool isDefault() const {
+    return !(hasNceBias || hasUnkConstantTerm || hasUnkLengthPenalty || hasPerceptronWeight || hasRnnWeight);
+  }
+};
+
 class ModelImage {
   std::vector<char> data_;
   jppgpu_model model_{};
@@ -57,6 +68,9 @@ class ModelImage {
   int32_t numFeatures_ = 0, numData_ = 0, numPlaceholders_ = 0;
   bool hasRnn_ = false;
   RnnScoreWeights rnnWeights_;
+  // the RNN part's saved RnnInferenceConfig as read (jppmdl only)
+  bool hasSavedRnnConfig_ = false;
+  RnnConfigOverride savedRnnConfig_;
   std::unordered_map<uint64_t, uint64_t> posMap_, conjMap_;
   bool hasIdMap_ = false;
   std::vector<TrainField> trainFields_;
@@ -74,6 +88,12 @@ class ModelImage {
 
   const jppgpu_model& cmodel() const { return model_; }
   bool hasRnn() const { return hasRnn_; }
+  // JumanppEnv::setRnnConfig + RnnScorerGbeamFactory::setConfig (src/core/env.cc:81-107,
+  // rnn_scorer_gbeam.cc:339-346) for a model that carries an RNN: the given values override the ones saved
+  // in the model, the NCE constant follows the merged nceBias, and the score weights become the
+  // *override's* perceptron / RNN weights (1.0 where not given -- what the reference does).
+  // A given RNN weight of 0 switches the RNN off (*useRnn = false).  Only for natively loaded .jppmdl.
+  Status applyRnnConfig(const RnnConfigOverride& o, bool* useRnn, RnnScoreWeights* weights);
   // ScorerDef::scoreWeights saved with the model (RnnInferenceConfig, src/core/env.cc:86-100)
   RnnScoreWeights savedScoreWeights() const { return rnnWeights_; }
   int32_t numFeatures() const { return numFeatures_; }

@@ -541,3 +541,51 @@ def test_dic_subset_csv_quoting(cli_emu, ref_tools, tmp_path):
     rc, out, err = _run(cli_emu, ['--model=' + model, '--dic-subset', txt])
     assert rc == 0 and out == ref, err[-300:]
     assert b'"' in out and b'""' in out
+
+
+def _fold_unk_ties(out):
+    """two UNK makers give nodes with identical feature rows and therefore exactly tied paths; which of the
+    twins wins an RNN-rescored tie is inside the 1e-4 float contract.  Fold their only visible difference."""
+    import re
+    return re.sub('"未知語:[^"]*"'.encode('utf-8'), b'"UNK"', out)
+
+
+def test_cli_rnn_config_overrides_and_config_file(cli_emu, ref_tools, golden_dir, tmp_path):
+    """--rnn-nce-bias / --rnn-unk-constant / --rnn-unk-length / --feature-weight-{perceptron,rnn} and
+    -c CONFIG behave like the reference's JumanppEnv::setRnnConfig (incl. score weights falling back to 1.0
+    when only another RNN flag is given, and RNN weight 0 switching the RNN off)"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    model = os.path.join(golden_dir, 'mini_rnn.jppmdl')
+    txt = os.path.join(golden_dir, 'mini.txt')
+    base = _ref_cli(ref_tools, model, [], txt)
+    seen = {base}
+    for flags in (['--rnn-nce-bias=3.0'], ['--feature-weight-rnn=0.05', '--feature-weight-perceptron=2'],
+                  ['--feature-weight-rnn=0'], ['--feature-weight-rnn=0', '--feature-weight-perceptron=3'],
+                  ['--rnn-unk-constant=-1', '--rnn-unk-length=-0.5'],
+                  ['--rnn-nce-bias=5.6', '--rnn-unk-constant=-3.47', '--rnn-unk-length=-2.93',
+                   '--feature-weight-perceptron=1', '--feature-weight-rnn=0.0176']):
+        ref = _ref_cli(ref_tools, model, flags, txt)
+        rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
+        assert rc == 0, err[-300:]
+        assert _fold_unk_ties(out) == _fold_unk_ties(ref), flags
+        seen.add(ref)
+    assert len(seen) >= 4  # the flags do change the analysis
+    # config file (whitespace-separated arguments), overridden by the command line
+    conf = os.path.join(str(tmp_path), 'jumandic.conf')
+    with open(conf, 'w') as f:
+        f.write('--model=%s\n--rnn-nce-bias=5.6 --feature-weight-rnn=0.02\n  --beam=4\n' % model)
+    for extra in ([], ['--beam=6', '--feature-weight-rnn=0.5']):
+        ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '-c', conf] + extra + [txt], capture_output=True).stdout
+        rc, out, err = _run(cli_emu, ['-c', conf] + extra + [txt])
+        assert rc == 0 and len(ref) > 1000 and _fold_unk_ties(out) == _fold_unk_ties(ref), extra
+    # a relative model path is looked up next to the config file
+    import shutil
+    shutil.copy(model, os.path.join(str(tmp_path), 'm.jppmdl'))
+    with open(conf, 'w') as f:
+        f.write('--model=m.jppmdl\n')
+    rc, out, err = _run(cli_emu, ['--config=' + conf, txt])
+    assert rc == 0 and _fold_unk_ties(out) == _fold_unk_ties(base)
+    # flat images carry only the resolved values: overrides are refused instead of guessed
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini_rnn.img'), '--rnn-nce-bias=1', txt])
+    assert rc == 1 and b'failed to apply the RNN configuration' in err
