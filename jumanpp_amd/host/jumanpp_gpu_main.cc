@@ -180,6 +180,19 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--segment-separator", &v)) conf.segmentSeparator = v;
     else if (std::strcmp(argv[i], "--segment") == 0) conf.kind = Conf::Segment;
     else if (std::strcmp(argv[i], "--dic-subset") == 0) conf.kind = Conf::DicSubset;
+    else if (argValue(argc, argv, i, "--format", &v)) {  // format_map(), jumanpp_args.cc:48-63 (no protobuf formats here)
+      conf.lattice = 0;
+      if (v == "juman") conf.kind = Conf::Juman;
+      else if (v == "segment") conf.kind = Conf::Segment;
+      else if (v == "morph") conf.kind = Conf::Morph;
+      else if (v == "full-morph") conf.kind = Conf::FullMorph;
+      else if (v == "dic-subset") conf.kind = Conf::DicSubset;
+      else if (v == "lattice") conf.lattice = 1;  // beamOutput keeps its default of 1 (jumanpp_args.h:51)
+      else {
+        std::cerr << "unknown output format " << v << " (juman, segment, morph, full-morph, dic-subset, lattice)\n";
+        return false;
+      }
+    }
     else if (std::strcmp(argv[i], "--morph") == 0 || std::strcmp(argv[i], "-M") == 0) conf.kind = Conf::Morph;
     else if (std::strcmp(argv[i], "--full-morph") == 0 || std::strcmp(argv[i], "-F") == 0) conf.kind = Conf::FullMorph;
     else if (std::strcmp(argv[i], "--juman") == 0 || std::strcmp(argv[i], "-j") == 0) conf.kind = Conf::Juman;
@@ -248,6 +261,8 @@ int main(int argc, const char** argv) {
       return 1;
     }
     if (!parseArgList(cmdline, conf)) return 1;
+    // -s N asks for N paths: the beam is widened to N if it is narrower (jumanpp_args.cc:253-256)
+    if (conf.lattice > 0 && conf.autoStep == 0 && conf.beam < conf.lattice) conf.beam = conf.lattice;
     // fixupModelPath (jumanpp_args.cc:302-338): a relative model path that does not exist is tried next to the config file
     if (!conf.configFile.empty() && !conf.model.empty() && conf.model[0] != '/' && !fileExists(conf.model)) {
       size_t slash = conf.configFile.find_last_of('/');

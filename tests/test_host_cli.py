@@ -543,6 +543,20 @@ def test_dic_subset_csv_quoting(cli_emu, ref_tools, tmp_path):
     assert b'"' in out and b'""' in out
 
 
+def test_cli_format_names_and_lattice_beam_widening(cli_emu, ref_tools, golden_dir):
+    """--format=NAME for every non-protobuf name, and `-s N` widening the beam to N (jumanpp_args.cc:253-256)"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    model = os.path.join(golden_dir, 'mini.jppmdl')
+    txt = os.path.join(golden_dir, 'mini.txt')
+    for flags in (['--format=juman'], ['--format=segment'], ['--format=morph'], ['--format=full-morph'],
+                  ['--format=dic-subset'], ['--format=lattice'], ['-s', '8'], ['-s', '8', '--global-beam=12'],
+                  ['-s', '3', '--beam=2'], ['-s7', '--beam=6']):
+        ref = _ref_cli(ref_tools, model, flags, txt)
+        rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
+        assert rc == 0 and len(ref) > 1000 and out == ref, flags
+
+
 def _fold_unk_ties(out):
     """two UNK makers give nodes with identical feature rows and therefore exactly tied paths; which of the
     twins wins an RNN-rescored tie is inside the 1e-4 float contract.  Fold their only visible difference."""
