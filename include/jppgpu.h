@@ -177,6 +177,10 @@ typedef struct {
   const uint32_t* gbeam;             /* [total_boundaries][global_beam][2]: (left | beam<<16), score bits */
 } jppgpu_result_view;
 
+/* Threading: like the reference (one Analyzer per thread over a shared read-only JumanppEnv), a context
+ * is used by one thread at a time.  Different contexts are independent -- each owns its model copy, its
+ * workspaces and the HIP stream its host-buffer entry points run on -- and may be driven from different
+ * threads; jppgpu_last_error is per thread. */
 int jppgpu_ctx_create(const jppgpu_model* model, const jppgpu_config* config, jppgpu_ctx** out);
 void jppgpu_ctx_destroy(jppgpu_ctx* ctx);
 /* Changes the beam configuration of the following batches; the model stays resident.
