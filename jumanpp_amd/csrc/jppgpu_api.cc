@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,8 @@ void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
 void rt_sync(jpp_stream_t) {}
 jpp_stream_t rt_stream_create() { return nullptr; }
 void rt_stream_destroy(jpp_stream_t) {}
+void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
+void rt_host_free(void* p) { free(p); }
 struct Timer {
   void init() {}
   void destroy() {}
@@ -75,6 +78,16 @@ jpp_stream_t rt_stream_create() {
 }
 void rt_stream_destroy(jpp_stream_t s) {
   if (s) (void)hipStreamDestroy(s);
+}
+// page-locked host memory: device-to-host copies of the result tables run at PCIe speed instead of
+// through the driver's staging buffer (a beam-32 lattice of one batch is gigabytes)
+void* rt_host_alloc(size_t n) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void rt_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 struct Timer {
   hipEvent_t ev[9];
@@ -145,31 +158,104 @@ u64 host_varint(const u8* p, size_t& pos) {
 
 }  // namespace
 
+// Host copies of a result live in page-locked blocks that a context recycles across batches (allocating
+// them is slow, the per-batch sizes repeat).  A block goes back to its pool when the result is released;
+// the pool is freed with the context.
+struct HostPool {
+  struct Block {
+    void* p;
+    size_t cap;
+  };
+  std::vector<Block> free_blocks;
+  Block take(size_t bytes) {
+    int best = -1;
+    for (int i = 0; i < (int)free_blocks.size(); ++i)
+      if (free_blocks[i].cap >= bytes && (best < 0 || free_blocks[i].cap < free_blocks[best].cap)) best = i;
+    if (best >= 0 && free_blocks[best].cap <= 2 * bytes + 4096) {
+      Block b = free_blocks[best];
+      free_blocks.erase(free_blocks.begin() + best);
+      return b;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    return Block{rt_host_alloc(want), want};
+  }
+  void give(Block b) {
+    if (b.p) free_blocks.push_back(b);
+  }
+  void clear() {
+    for (auto& b : free_blocks) rt_host_free(b.p);
+    free_blocks.clear();
+  }
+  ~HostPool() { clear(); }
+};
+
+template <typename T>
+struct HostVec {
+  HostPool* pool = nullptr;
+  HostPool::Block blk{nullptr, 0};
+  size_t n = 0;
+  HostVec() = default;
+  HostVec(const HostVec&) = delete;
+  HostVec& operator=(const HostVec&) = delete;
+  ~HostVec() {
+    if (pool) pool->give(blk);
+    else rt_host_free(blk.p);
+  }
+  // contents are unspecified after a resize (always followed by a full copy or fill)
+  bool resize(size_t count) {
+    if (count * sizeof(T) > blk.cap) {
+      if (pool) pool->give(blk);
+      else rt_host_free(blk.p);
+      blk = pool ? pool->take(count * sizeof(T)) : HostPool::Block{rt_host_alloc(count * sizeof(T)), count * sizeof(T)};
+      if (!blk.p) {
+        blk.cap = 0;
+        n = 0;
+        return false;
+      }
+    }
+    n = count;
+    return true;
+  }
+  void assign(size_t count, T v) {
+    if (resize(count))
+      for (size_t i = 0; i < count; ++i) data()[i] = v;
+  }
+  T* data() { return static_cast<T*>(blk.p); }
+  const T* data() const { return static_cast<const T*>(blk.p); }
+  T& operator[](size_t i) { return data()[i]; }
+  const T& operator[](size_t i) const { return data()[i]; }
+  size_t size() const { return n; }
+};
+
 struct jppgpu_result {
+  // declared first = destroyed last: a result released after its context keeps the pool alive until its
+  // own blocks are back in it
+  std::shared_ptr<HostPool> pool_ref;
   jppgpu_ctx* ctx = nullptr;
   Batch B{};
   u64 generation = 0;
   Config cfg{};  // configuration the batch was analysed with (jppgpu_ctx_set_beams may change the context's later)
   bool fetched_basic = false, fetched_full = false, fetched_top1 = false;
   // host copies
-  std::vector<i32> status;
-  std::vector<u32> ncp, nnodes, path_len, path_nodes;
-  std::vector<u64> node_base, bnd_base;
-  std::vector<jppgpu_node> nodes;
-  std::vector<jppgpu_unk> unk;
-  std::vector<u32> bnd_first, bnd_cnt, end_first, end_cnt, end_nodes, ngb, gbeam;
-  std::vector<i32> entry_rows;
-  std::vector<u64> patterns;
-  std::vector<float> t0, cells;
-  std::vector<jppgpu_beam_slot> beams;
-  std::vector<u8> kept;
-  std::vector<u32> byte_off;
+  HostVec<i32> status;
+  HostVec<u32> ncp, nnodes, path_len, path_nodes;
+  HostVec<u64> node_base, bnd_base;
+  HostVec<jppgpu_node> nodes;
+  HostVec<jppgpu_unk> unk;
+  HostVec<u32> bnd_first, bnd_cnt, end_first, end_cnt, end_nodes, ngb, gbeam;
+  HostVec<i32> entry_rows;
+  HostVec<u64> patterns;
+  HostVec<float> t0, cells;
+  HostVec<jppgpu_beam_slot> beams;
+  HostVec<u8> kept;
+  HostVec<u32> byte_off;
   // JPPGPU_FETCH_TOP1: compact tables of the top-1 paths
-  std::vector<i32> t1_status;
-  std::vector<u32> t1_ncp, t1_len, t1_idx;
-  std::vector<u64> t1_base, t1_zero;
-  std::vector<jppgpu_node> t1_nodes;
-  std::vector<jppgpu_unk> t1_unk;
+  HostVec<i32> t1_status;
+  HostVec<u32> t1_ncp, t1_len, t1_idx;
+  HostVec<u64> t1_base, t1_zero;
+  HostVec<jppgpu_node> t1_nodes;
+  HostVec<jppgpu_unk> t1_unk;
+  void bind(HostPool* pool);
 };
 
 struct jppgpu_ctx {
@@ -194,12 +280,23 @@ struct jppgpu_ctx {
   float last_ms[8] = {0};
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
+  std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>();
   bool timing_pending = false;
 };
 
 static_assert(sizeof(jppgpu_node) == sizeof(NodeInfo), "node layout");
 static_assert(sizeof(jppgpu_unk) == sizeof(NodeAux), "unk layout");
 static_assert(sizeof(jppgpu_beam_slot) == sizeof(BeamSlot), "beam layout");
+
+void jppgpu_result::bind(HostPool* pool) {
+  status.pool = pool; ncp.pool = pool; nnodes.pool = pool; path_len.pool = pool; path_nodes.pool = pool;
+  node_base.pool = pool; bnd_base.pool = pool; nodes.pool = pool; unk.pool = pool;
+  bnd_first.pool = pool; bnd_cnt.pool = pool; end_first.pool = pool; end_cnt.pool = pool; end_nodes.pool = pool;
+  ngb.pool = pool; gbeam.pool = pool; entry_rows.pool = pool; patterns.pool = pool; t0.pool = pool; cells.pool = pool;
+  beams.pool = pool; kept.pool = pool; byte_off.pool = pool;
+  t1_status.pool = pool; t1_ncp.pool = pool; t1_len.pool = pool; t1_idx.pool = pool; t1_base.pool = pool;
+  t1_zero.pool = pool; t1_nodes.pool = pool; t1_unk.pool = pool;
+}
 
 extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
 
@@ -432,6 +529,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
+  ctx->host_pool->clear();
   ctx->timer.destroy();
   delete ctx;
 }
@@ -464,6 +562,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
 
   ctx->generation++;
   jppgpu_result* Rp = new jppgpu_result();
+  Rp->pool_ref = ctx->host_pool;
+  Rp->bind(ctx->host_pool.get());
   jppgpu_result& R = *Rp;
   R.ctx = ctx;
   R.generation = ctx->generation;
@@ -708,6 +808,12 @@ extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
 
 namespace {
 template <typename T>
+bool pull(HostVec<T>& v, const void* d, size_t count, jpp_stream_t st) {
+  if (!v.resize(count)) return false;
+  if (count) rt_d2h(v.data(), d, count * sizeof(T), st);
+  return true;
+}
+template <typename T>
 void pull(std::vector<T>& v, const void* d, size_t count, jpp_stream_t st) {
   v.resize(count);
   if (count) rt_d2h(v.data(), d, count * sizeof(T), st);
@@ -755,6 +861,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   const u32 n = B.n_sent;
   const u64 N = B.total_nodes;
   const int G = res->cfg.gbeam, beam = res->cfg.beam;
+  bool ok = true;  // page-locked host blocks obtained
   if (full == JPPGPU_FETCH_TOP1) {
     if (!res->fetched_top1) {
       // an upper bound of the compact size: a path holds at most one node per codepoint, plus EOS
@@ -766,22 +873,24 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
       JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
       if (n) JPP_LAUNCH(k_top1_gather, (n + 3) / 4, 256, st, B, (const u64*)ctx->pack_off.as<u64>(),
                         ctx->top1_nodes.as<NodeInfo>(), ctx->top1_aux.as<NodeAux>());
-      pull(res->t1_status, B.sent_status, n, st);
-      pull(res->t1_ncp, B.sent_ncp, n, st);
-      pull(res->t1_len, ctx->pack_cnt.p, n, st);
-      pull(res->t1_base, ctx->pack_off.p, (size_t)n + 1, st);
+      ok &= pull(res->t1_status, B.sent_status, n, st);
+      ok &= pull(res->t1_ncp, B.sent_ncp, n, st);
+      ok &= pull(res->t1_len, ctx->pack_cnt.p, n, st);
+      ok &= pull(res->t1_base, ctx->pack_off.p, (size_t)n + 1, st);
       rt_sync(st);
+      if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
       const u64 M = n ? res->t1_base[n] : 0;
-      pull(res->t1_nodes, ctx->top1_nodes.p, M, st);
-      pull(res->t1_unk, ctx->top1_aux.p, M, st);
+      ok &= pull(res->t1_nodes, ctx->top1_nodes.p, M, st);
+      ok &= pull(res->t1_unk, ctx->top1_aux.p, M, st);
       // every sentence's path is 0, 1, 2, ... in its compact table
-      res->t1_idx.resize((size_t)M);
+      if (!(ok && res->t1_idx.resize((size_t)M))) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
       for (u32 s = 0; s < n; ++s)
         for (u32 k = 0; k < res->t1_len[s]; ++k) res->t1_idx[res->t1_base[s] + k] = k;
       res->t1_zero.assign(n, 0);
       rt_sync(st);
       res->fetched_top1 = true;
     }
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
     memset(v, 0, sizeof(*v));
     v->n_sentences = n;
     v->status = res->t1_status.data();
@@ -801,20 +910,20 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
     return JPPGPU_OK;
   }
   if (!res->fetched_basic) {
-    pull(res->status, B.sent_status, n, st);
-    pull(res->ncp, B.sent_ncp, n, st);
-    pull(res->nnodes, B.sent_nodes, n, st);
-    pull(res->node_base, B.node_base, n, st);
-    pull(res->path_len, B.path_len, n, st);
-    pull(res->byte_off, B.byte_off, (size_t)n + 1, st);
+    ok &= pull(res->status, B.sent_status, n, st);
+    ok &= pull(res->ncp, B.sent_ncp, n, st);
+    ok &= pull(res->nnodes, B.sent_nodes, n, st);
+    ok &= pull(res->node_base, B.node_base, n, st);
+    ok &= pull(res->path_len, B.path_len, n, st);
+    ok &= pull(res->byte_off, B.byte_off, (size_t)n + 1, st);
     if (n) {
       // nodes live in [0, seed region end); copy the whole region that holds any sentence
-      pull(res->nodes, B.node_info, N, st);
-      pull(res->unk, B.node_aux, N, st);
-      pull(res->path_nodes, B.path_nodes, N, st);
+      ok &= pull(res->nodes, B.node_info, N, st);
+      ok &= pull(res->unk, B.node_aux, N, st);
+      ok &= pull(res->path_nodes, B.path_nodes, N, st);
     }
     rt_sync(st);
-    res->bnd_base.resize(n);
+    if (!(ok && res->bnd_base.resize(n))) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
     for (u32 s = 0; s < n; ++s) res->bnd_base[s] = (u64)res->byte_off[s] + 4ull * s;
     for (u32 s = 0; s < n; ++s) {
       if (res->status[s] != ST_OK) {
@@ -826,22 +935,23 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   }
   const u64 NB = n ? (u64)B.total_bytes + 4ull * n : 0;
   if (full && !res->fetched_full && n) {
-    pull(res->bnd_first, B.bnd_first, NB, st);
-    pull(res->bnd_cnt, B.bnd_cnt, NB, st);
-    pull(res->end_first, B.end_first, NB, st);
-    pull(res->end_cnt, B.end_cnt, NB, st);
-    pull(res->ngb, B.bnd_ngb, NB, st);
-    pull(res->gbeam, B.bnd_gbeam, NB * G * 2, st);
-    pull(res->end_nodes, B.end_nodes, N, st);
-    pull(res->entry_rows, B.node_entry, N * spec::kNumDicFeatures, st);
-    pull(res->patterns, B.node_pat, N * kPat, st);
-    pull(res->t0, B.node_t0, N, st);
-    pull(res->beams, B.node_beam, N * beam, st);
-    pull(res->cells, B.node_cells, N * G * res->cfg.nscorers, st);
-    pull(res->kept, B.node_kept, N, st);
+    ok &= pull(res->bnd_first, B.bnd_first, NB, st);
+    ok &= pull(res->bnd_cnt, B.bnd_cnt, NB, st);
+    ok &= pull(res->end_first, B.end_first, NB, st);
+    ok &= pull(res->end_cnt, B.end_cnt, NB, st);
+    ok &= pull(res->ngb, B.bnd_ngb, NB, st);
+    ok &= pull(res->gbeam, B.bnd_gbeam, NB * G * 2, st);
+    ok &= pull(res->end_nodes, B.end_nodes, N, st);
+    ok &= pull(res->entry_rows, B.node_entry, N * spec::kNumDicFeatures, st);
+    ok &= pull(res->patterns, B.node_pat, N * kPat, st);
+    ok &= pull(res->t0, B.node_t0, N, st);
+    ok &= pull(res->beams, B.node_beam, N * beam, st);
+    ok &= pull(res->cells, B.node_cells, N * G * res->cfg.nscorers, st);
+    ok &= pull(res->kept, B.node_kept, N, st);
     rt_sync(st);
     res->fetched_full = true;
   }
+  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
   memset(v, 0, sizeof(*v));
   v->n_sentences = n;
   v->status = res->status.data();

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] shape on one GPU: beam 32 / global beam 32 / right beam 32, >= 200-codepoint
+sentences, RNNLM on; device-resident analysis and the CLI with lattice output (-s 5), next to the
+reference CLI on a sample.  Developer measurement; numbers go to DESIGN.md section 4.
+
+  gpurun -- 'python tools/gpu_config5.py > gpurun_out/config5.txt 2>&1'
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import bench  # noqa: E402
+import jumanpp_amd as J  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--len', type=int, default=220)
+    ap.add_argument('--ref-sample', type=int, default=200)
+    a = ap.parse_args()
+    args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, rnn=True, rnn_hidden=128,
+                              rnn_vocab=30000, sent_len=a.len)
+    cache = '/tmp/jppgpu_bench_cache'
+    mdic, model, img = bench.make_workload(args, cache)
+    corpus = bench.make_corpus(args, mdic, cache, a.batch * 2, 31)
+    batches = bench.load_batches(corpus, a.batch, np)
+    dev = torch.device('cuda', 0)
+    ctx = J.Context(img, beam=32, global_beam=32, right_check=1, right_beam=32)
+    d = []
+    for text, offs in batches:
+        d.append((torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev),
+                  torch.from_numpy(offs.astype(np.int32)).to(dev), len(offs) - 1, len(text)))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        t, o, n, nb = d[i % len(d)]
+        return ctx.analyze_device(t.data_ptr(), o.data_ptr(), n, nb, stream)
+
+    step(0).release()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms = {}
+    for i in range(a.steps):
+        r = step(i + 1)
+        for k, v in ctx.timings().items():
+            ms[k] = ms.get(k, 0.0) + v / a.steps
+        r.release()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    r = step(0).fetch()
+    print('device-resident: %d sentences x %d codepoints per step, %.1f ms/step, %.0f sentences/s, %.0f nodes/sentence, failed %d'
+          % (a.batch, a.len, el / a.steps * 1e3, a.batch * a.steps / el, float(r.nnodes.mean()), int((r.status != 0).sum())))
+    print('kernel ms/step:', {k: round(v, 2) for k, v in ms.items()})
+    r.release()
+    del ctx
+    # CLI, lattice output
+    import __graft_entry__ as ge
+    cli = ge.build_host()
+    flags = ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '5']
+    t0 = time.time()
+    p = subprocess.run([cli, '--model=' + model, '--batch=%d' % a.batch, '--timing', '-o', '/tmp/c5.txt'] + flags + [corpus],
+                       capture_output=True, text=True)
+    print('jumanpp_gpu %s: rc=%d wall %.2fs\n   %s' % (' '.join(flags), p.returncode, time.time() - t0,
+                                                       p.stderr.strip().splitlines()[-1] if p.stderr.strip() else ''))
+    sample = '/tmp/c5_sample.txt'
+    with open(corpus, 'rb') as f, open(sample, 'wb') as g:
+        for i, line in enumerate(f):
+            if i >= a.ref_sample:
+                break
+            g.write(line)
+    t0 = time.time()
+    ref = subprocess.run([os.path.join(bench.REF, 'jumanpp_v2'), '--model=' + model] + flags + [sample], capture_output=True)
+    dt = time.time() - t0
+    print('reference jumanpp_v2 %s, 1 thread: %d lines in %.2fs = %.1f sentences/s' % (' '.join(flags), a.ref_sample, dt, a.ref_sample / dt))
+    ours = open('/tmp/c5.txt', 'rb').read().split(b'EOS\n')[:a.ref_sample]
+    refs = ref.stdout.split(b'EOS\n')[:a.ref_sample]
+    print('identical lattice blocks on the sample: %d of %d' % (sum(1 for x, y in zip(ours, refs) if x == y), len(refs)))
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, 'c5_ours.txt'), 'wb') as f:
+        f.write(b'EOS\n'.join(ours[:30]))
+    with open(os.path.join(out_dir, 'c5_ref.txt'), 'wb') as f:
+        f.write(b'EOS\n'.join(refs[:30]))
+
+
+if __name__ == '__main__':
+    main()
