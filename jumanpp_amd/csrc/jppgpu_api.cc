@@ -79,16 +79,12 @@ jpp_stream_t rt_stream_create() {
 void rt_stream_destroy(jpp_stream_t s) {
   if (s) (void)hipStreamDestroy(s);
 }
-// page-locked host memory: device-to-host copies of the result tables run at PCIe speed instead of
-// through the driver's staging buffer (a beam-32 lattice of one batch is gigabytes)
-void* rt_host_alloc(size_t n) {
-  void* p = nullptr;
-  if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
-  return p;
-}
-void rt_host_free(void* p) {
-  if (p) (void)hipHostFree(p);
-}
+// host blocks for the result copies.  Page-locking them (hipHostMalloc) was measured and rejected: the
+// copies got faster but pinning tens of megabytes per batch made the analysis stage 2-3x slower and
+// erratic; ordinary memory, recycled through HostPool so that it is neither re-allocated nor re-zeroed
+// per batch, is what is used.
+void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
+void rt_host_free(void* p) { free(p); }
 struct Timer {
   hipEvent_t ev[9];
   bool have = false;
@@ -158,9 +154,9 @@ u64 host_varint(const u8* p, size_t& pos) {
 
 }  // namespace
 
-// Host copies of a result live in page-locked blocks that a context recycles across batches (allocating
-// them is slow, the per-batch sizes repeat).  A block goes back to its pool when the result is released;
-// the pool is freed with the context.
+// Host copies of a result live in blocks that a context recycles across batches (the per-batch sizes
+// repeat; a fresh std::vector would be allocated and zero-filled every time).  A block goes back to its
+// pool when the result is released; the pool is freed with the context.
 struct HostPool {
   struct Block {
     void* p;
@@ -861,7 +857,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   const u32 n = B.n_sent;
   const u64 N = B.total_nodes;
   const int G = res->cfg.gbeam, beam = res->cfg.beam;
-  bool ok = true;  // page-locked host blocks obtained
+  bool ok = true;  // host blocks obtained
   if (full == JPPGPU_FETCH_TOP1) {
     if (!res->fetched_top1) {
       // an upper bound of the compact size: a path holds at most one node per codepoint, plus EOS
