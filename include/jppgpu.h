@@ -244,6 +244,33 @@ int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void*
  * jppgpu_result_release, also across later batches on the same context (only the device-resident
  * side -- further fetches, jppgpu_result_pack -- is invalidated by the next batch). */
 int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_view* view);
+
+/* The n best analyses, as jumandic::output::LatticeFormat consumes them (LatticeFormatInfo::fillInfo,
+ * src/jumandic/shared/lattice_format.cc:13-43; score lookup :129-141): for every EOS beam slot i < n_best
+ * the connections of its path from the EOS side back to BOS, each with the beam slot, the node and UNK
+ * records and the score cells of that connection.  Gathered on the device, so that a lattice-format run
+ * does not copy the whole lattice (beam 32: gigabytes per batch) to the host. */
+typedef struct {
+  uint32_t node;           /* sentence-local node index, as in the full view */
+  uint32_t slot;           /* beam slot of that node on the path */
+  jppgpu_beam_slot beam;   /* beams[node][slot]; .pad = index of its score cells in the boundary's global beam */
+  jppgpu_node info;
+  jppgpu_unk unk;
+  float cells[2];          /* cells[node][beam.pad][0..num_scorers) */
+} jppgpu_nbest_item;
+
+typedef struct {
+  uint32_t n_sentences;
+  int32_t n_best, beam, global_beam, num_scorers;
+  const int32_t* status;            /* [n_sentences] */
+  const uint32_t* n_codepoints;     /* [n_sentences] */
+  const uint32_t* n_nodes;          /* [n_sentences] lattice nodes (<= 3: empty input) */
+  const jppgpu_beam_slot* eos;      /* [n_sentences][n_best] EOS beam slots, fake beyond the live ones */
+  const uint64_t* path_first;       /* [n_sentences * n_best + 1] offsets into items */
+  const jppgpu_nbest_item* items;   /* path (s, i) = items[path_first[s*n_best+i] .. path_first[s*n_best+i+1]) */
+} jppgpu_nbest_view;
+
+int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jppgpu_nbest_view* view);
 /* Per-batch statistics without copying the lattice: total nodes, sum of path lengths. */
 int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path);
 /* Packed top-1 output written to caller-provided DEVICE buffers (e.g. to be gathered

@@ -251,6 +251,13 @@ struct jppgpu_result {
   HostVec<u64> t1_base, t1_zero;
   HostVec<jppgpu_node> t1_nodes;
   HostVec<jppgpu_unk> t1_unk;
+  // jppgpu_result_fetch_nbest
+  int nb_n = 0;
+  HostVec<i32> nb_status;
+  HostVec<u32> nb_ncp, nb_nnodes;
+  HostVec<u64> nb_first;
+  HostVec<jppgpu_beam_slot> nb_eos;
+  HostVec<jppgpu_nbest_item> nb_items;
   void bind(HostPool* pool);
 };
 
@@ -260,7 +267,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, top1_nodes, top1_aux, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, reach;
@@ -292,6 +299,7 @@ void jppgpu_result::bind(HostPool* pool) {
   beams.pool = pool; kept.pool = pool; byte_off.pool = pool;
   t1_status.pool = pool; t1_ncp.pool = pool; t1_len.pool = pool; t1_idx.pool = pool; t1_base.pool = pool;
   t1_zero.pool = pool; t1_nodes.pool = pool; t1_unk.pool = pool;
+  nb_status.pool = pool; nb_ncp.pool = pool; nb_nnodes.pool = pool; nb_first.pool = pool; nb_eos.pool = pool; nb_items.pool = pool;
 }
 
 extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
@@ -519,7 +527,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
@@ -979,6 +987,63 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
     v->gbeam_count = res->ngb.data();
     v->gbeam = res->gbeam.data();
   }
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jppgpu_nbest_view* v) {
+  if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (n_best <= 0 || n_best > 64) return fail(JPPGPU_INVALID_PARAMETER, "n_best must be in 1..64");
+  static_assert(sizeof(jppgpu_nbest_item) == sizeof(NbestItem), "nbest item layout");
+  jppgpu_ctx* ctx = res->ctx;
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  if (res->nb_n != n_best) {
+    if (res->generation != ctx->generation)
+      return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+    jpp_stream_t st = ctx->last_stream;
+    const u64 paths = (u64)n * (u32)n_best;
+    if (paths >= 0xffffffffull) return fail(JPPGPU_INVALID_PARAMETER, "too many paths");
+    if (!(ctx->nbest_cnt.ensure((paths + 1) * 4) && ctx->nbest_off.ensure((paths + 2) * 8) &&
+          ctx->nbest_eos.ensure((paths + 1) * sizeof(BeamSlot))))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (n-best fetch)");
+    bool ok = true;
+    if (n) {
+      JPP_LAUNCH((k_nbest<false>), (n + 3) / 4, 256, st, B, res->cfg, (int)n_best, ctx->nbest_cnt.as<u32>(),
+                 (const u64*)nullptr, (NbestItem*)nullptr, (BeamSlot*)nullptr);
+    }
+    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->nbest_cnt.as<u32>(), ctx->nbest_off.as<u64>(), (u32)paths, (const u64*)nullptr);
+    ok &= pull(res->nb_first, ctx->nbest_off.p, (size_t)paths + 1, st);
+    rt_sync(st);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
+    const u64 M = res->nb_first[paths];
+    if (!ctx->nbest_items.ensure((M + 1) * sizeof(NbestItem))) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (n-best fetch)");
+    if (n) {
+      JPP_LAUNCH((k_nbest<true>), (n + 3) / 4, 256, st, B, res->cfg, (int)n_best, ctx->nbest_cnt.as<u32>(),
+                 (const u64*)ctx->nbest_off.as<u64>(), ctx->nbest_items.as<NbestItem>(), ctx->nbest_eos.as<BeamSlot>());
+    }
+    ok &= pull(res->nb_status, B.sent_status, n, st);
+    ok &= pull(res->nb_ncp, B.sent_ncp, n, st);
+    ok &= pull(res->nb_nnodes, B.sent_nodes, n, st);
+    ok &= pull(res->nb_eos, ctx->nbest_eos.p, (size_t)paths, st);
+    ok &= pull(res->nb_items, ctx->nbest_items.p, (size_t)M, st);
+    rt_sync(st);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
+    for (u32 s = 0; s < n; ++s)
+      if (res->nb_status[s] != ST_OK) res->nb_nnodes[s] = 0;
+    res->nb_n = n_best;
+  }
+  memset(v, 0, sizeof(*v));
+  v->n_sentences = n;
+  v->n_best = n_best;
+  v->beam = res->cfg.beam;
+  v->global_beam = res->cfg.gbeam;
+  v->num_scorers = res->cfg.nscorers;
+  v->status = res->nb_status.data();
+  v->n_codepoints = res->nb_ncp.data();
+  v->n_nodes = res->nb_nnodes.data();
+  v->eos = res->nb_eos.data();
+  v->path_first = res->nb_first.data();
+  v->items = res->nb_items.data();
   return JPPGPU_OK;
 }
 

@@ -934,6 +934,65 @@ __global__ void __launch_bounds__(256) k_top1_gather(Batch B, const u64* offs, N
   }
 }
 
+// jppgpu_result_fetch_nbest: what the lattice output format reads -- the beam slots, node records and
+// score cells along the n best paths from EOS -- compacted on the device (LatticeFormatInfo::fillInfo,
+// src/jumandic/shared/lattice_format.cc:13-43, walks exactly these).  One wavefront per sentence, lane i =
+// path i.  WRITE = false counts the items of every path, WRITE = true emits them at the scanned offsets.
+struct NbestItem {
+  u32 node;       // sentence-local lattice node
+  u32 slot;       // its beam slot the path runs through
+  BeamSlot beam;  // that slot
+  NodeInfo info;
+  NodeAux aux;
+  float cells[2];  // score cells of the connection (one per scorer)
+};
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_nbest(Batch B, Config cfg, int n_best, u32* counts, const u64* offs,
+                                               NbestItem* items, BeamSlot* eos_slots) {
+  const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  if (s >= B.n_sent) return;
+  if (lane >= n_best) return;
+  const u64 q = (u64)s * (u32)n_best + (u32)lane;
+  const BeamSlot fake{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+  if (B.sent_status[s] != ST_OK || B.sent_nodes[s] <= 3) {
+    if (!WRITE) counts[q] = 0;
+    else eos_slots[q] = fake;
+    return;
+  }
+  const int beam = cfg.beam, G = cfg.gbeam, S = cfg.nscorers;
+  const u64 nb = B.node_base[s];
+  const u32 N = B.sent_nodes[s];
+  const BeamSlot* beams = B.node_beam + nb * beam;
+  BeamSlot el = lane < beam ? beams[(u64)(N - 1) * beam + lane] : fake;
+  if (WRITE) eos_slots[q] = el;
+  u32 cnt = 0;
+  if (!(el.left == kFake16 && el.beam == kFake16)) {
+    u64 o = WRITE ? offs[q] : 0;
+    u32 node = el.prev_node, slot = el.beam;
+    while (node >= 2 && node != 0xffffffffu && cnt <= N) {
+      const BeamSlot c = beams[(u64)node * beam + slot];
+      if (WRITE) {
+        NbestItem it;
+        it.node = node;
+        it.slot = slot;
+        it.beam = c;
+        it.info = B.node_info[nb + node];
+        it.aux = B.node_aux[nb + node];
+        const float* cell = B.node_cells + ((nb + node) * G + c.pad) * S;
+        it.cells[0] = G > 0 ? cell[0] : 0.f;
+        it.cells[1] = (G > 0 && S > 1) ? cell[1] : 0.f;
+        items[o + cnt] = it;
+      }
+      ++cnt;
+      node = c.prev_node;
+      slot = c.beam;
+    }
+  }
+  if (!WRITE) counts[q] = cnt;
+}
+
 }  // namespace jpp
 
 #endif  // JPP_K_SWEEP_H

@@ -1,5 +1,6 @@
 #include "gpu_analyzer.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -168,8 +169,23 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
     double t1 = now();
     tAnalyze += t1 - t0;
     // host copies are taken right away: the next group's batch invalidates the device side of this result
-    rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
-    if (rc != JPPGPU_OK) return fromCode(rc);
+    if (fullLattice && latticeNBest_ > 0) {
+      const int32_t nBest = std::min<int32_t>(64, cfg_.autoBeamStep > 0 ? G.beam : latticeNBest_);
+      rc = jppgpu_result_fetch_nbest(G.result, nBest, &G.nbest);
+      if (rc != JPPGPU_OK) return fromCode(rc);
+      G.hasNbest = true;
+      G.view = jppgpu_result_view{};
+      G.view.n_sentences = G.nbest.n_sentences;
+      G.view.status = G.nbest.status;
+      G.view.n_codepoints = G.nbest.n_codepoints;
+      G.view.n_nodes = G.nbest.n_nodes;
+      G.view.beam = G.nbest.beam;
+      G.view.global_beam = G.nbest.global_beam;
+      G.view.num_scorers = G.nbest.num_scorers;
+    } else {
+      rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
+      if (rc != JPPGPU_OK) return fromCode(rc);
+    }
     tFetch += now() - t1;
   }
   double tGroups = now();
@@ -211,10 +227,12 @@ SentenceResult GpuAnalyzer::sentence(size_t i) const {
   r.input = inputs_[i];
   r.numCodepoints = v.n_codepoints[k];
   r.numNodes = v.n_nodes[k];
-  r.nodes = v.nodes + v.node_base[k];
-  r.unk = v.unk + v.node_base[k];
-  r.pathNodes = v.path_nodes + v.node_base[k];
-  r.pathLen = v.path_len[k];
+  if (v.node_base != nullptr) {  // (n-best mode carries no node table: the paths' node records are in the n-best items)
+    r.nodes = v.nodes + v.node_base[k];
+    r.unk = v.unk + v.node_base[k];
+    r.pathNodes = v.path_nodes + v.node_base[k];
+    r.pathLen = v.path_len[k];
+  }
   uint32_t* offs = cpOffsets_.data() + cpOffsetsBase_[i];
   if (!cpOffsetsReady_[i] && v.status[k] == JPPGPU_SENT_OK) {
     const unsigned char* p = reinterpret_cast<const unsigned char*>(inputs_[i].data());

@@ -81,8 +81,11 @@ class GpuAnalyzer {
   struct Group {
     jppgpu_result* result = nullptr;
     jppgpu_result_view view{};
+    jppgpu_nbest_view nbest{};   // filled instead of the lattice arrays of `view` in n-best mode
+    bool hasNbest = false;
     int32_t beam = 0;
   };
+  int32_t latticeNBest_ = 0;
   std::vector<Group> groups_;
   std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
   AnalyzerConfig cfg_;
@@ -114,6 +117,17 @@ class GpuAnalyzer {
   // Analyzer::analyze(surface, plugin) with the partial-annotation ScorePlugin for every example
   // (PexStreamReader::analyzeWith, pex_stream_reader.cc:61-66); a null entry is analysed as the empty string
   Status analyzeBatchPartial(const std::vector<const PartialExample*>& examples, bool fullLattice = false);
+
+  // With n > 0, analyzeBatch(inputs, fullLattice = true) copies only what the lattice output format reads
+  // -- the n best paths' beam slots, nodes and score cells, gathered on the device
+  // (jppgpu_result_fetch_nbest) -- instead of the whole lattice; with auto-beam n is the sentence's beam.
+  void setLatticeNBest(int32_t n) { latticeNBest_ = n; }
+  // the n-best view holding sentence i (nullptr unless the batch was fetched in n-best mode)
+  const jppgpu_nbest_view* nbestOf(size_t i, uint32_t* local) const {
+    *local = localIdx_[i];
+    const Group& g = groups_[groupOf_[i]];
+    return g.hasNbest ? &g.nbest : nullptr;
+  }
 
   size_t numSentences() const { return inputs_.size(); }
   Status sentenceStatus(size_t i) const;

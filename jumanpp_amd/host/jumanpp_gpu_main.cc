@@ -392,6 +392,8 @@ int main(int argc, const char** argv) {
   std::vector<std::unique_ptr<GpuAnalyzer>> analyzers;
   for (int a = 0; a < nAnalyzers; ++a) {
     analyzers.emplace_back(new GpuAnalyzer());
+    // the lattice format reads the N best paths only: they are gathered on the device (N = what it prints)
+    if (latticeFormat) analyzers.back()->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
     s = analyzers.back()->initialize(&model, acfg, sconf, &def, conf.device);
     if (!s) {
       std::cerr << "failed to initialize the analyzer: " << s << "\n";

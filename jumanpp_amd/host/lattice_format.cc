@@ -42,7 +42,8 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
   JPPA_RETURN_IF_ERROR(analysis.sentenceStatus(sentence));
   uint32_t local = 0;
   const jppgpu_result_view& v = analysis.viewOf(sentence, &local);
-  if (v.beams == nullptr || v.cells == nullptr) {
+  const jppgpu_nbest_view* nbv = analysis.nbestOf(sentence, &local);
+  if (nbv == nullptr && (v.beams == nullptr || v.cells == nullptr)) {
     return Status::InvalidState("the lattice format needs analyzeBatch(inputs, fullLattice = true)");
   }
   if (v.global_beam <= 0) return Status::NotImplemented("lattice format needs the global beam (score cells)");
@@ -51,24 +52,63 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
     printer_ = "EOS\n";
     return Status::Ok();
   }
-  const uint64_t nb = v.node_base[local];
   const int32_t beam = v.beam, G = v.global_beam, S = v.num_scorers;
-  const jppgpu_beam_slot* beams = v.beams + nb * (uint64_t)beam;
-  const float* cells = v.cells + nb * (uint64_t)G * S;
-  const uint32_t eos = s.numNodes - 1;
   // lattice_format.cc:98-101: with auto-beam the number of printed paths is the sentence's beam
   const int32_t outputN = analysis.autoBeamSize(sentence) > 0 ? analysis.autoBeamSize(sentence) : topN_;
+  // Two sources for the same lattice reads: the full arrays, or the n best paths gathered on the device
+  // (jppgpu_result_fetch_nbest), indexed here by (node, slot).
+  const jppgpu_beam_slot* beams = nullptr;
+  const float* cells = nullptr;
+  uint32_t eos = 0;
+  const jppgpu_beam_slot fakeSlot{0xffff, 0xffff, 0.f, 0xffffffffu, 0};
+  nbItems_.clear();
+  if (nbv != nullptr) {
+    if (nbv->n_best < std::min<int32_t>(beam, outputN)) return Status::InvalidState("n-best view holds fewer paths than the format prints");
+    const uint64_t p0 = (uint64_t)local * (uint32_t)nbv->n_best;
+    for (uint64_t q = nbv->path_first[p0]; q < nbv->path_first[p0 + (uint32_t)nbv->n_best]; ++q) {
+      const jppgpu_nbest_item& it = nbv->items[q];
+      nbItems_.emplace(((uint64_t)it.node << 8) | it.slot, &it);
+    }
+  } else {
+    const uint64_t nb = v.node_base[local];
+    beams = v.beams + nb * (uint64_t)beam;
+    cells = v.cells + nb * (uint64_t)G * S;
+    eos = s.numNodes - 1;
+  }
+  auto itemOf = [&](uint32_t node, uint32_t slot) -> const jppgpu_nbest_item* {
+    auto f = nbItems_.find(((uint64_t)node << 8) | slot);
+    return f == nbItems_.end() ? nullptr : f->second;
+  };
+  auto eosSlot = [&](int32_t i) -> const jppgpu_beam_slot& {
+    if (nbv != nullptr) return i < nbv->n_best ? nbv->eos[(uint64_t)local * (uint32_t)nbv->n_best + (uint32_t)i] : fakeSlot;
+    return beams[(uint64_t)eos * beam + i];
+  };
+  auto slotOf = [&](uint32_t node, uint32_t slot) -> const jppgpu_beam_slot& {
+    if (nbv != nullptr) {
+      const jppgpu_nbest_item* it = itemOf(node, slot);
+      return it ? it->beam : fakeSlot;
+    }
+    return beams[(uint64_t)node * beam + slot];
+  };
+  auto cellsOf = [&](uint32_t node, uint32_t slot) -> const float* {
+    if (nbv != nullptr) {
+      const jppgpu_nbest_item* it = itemOf(node, slot);
+      return it ? it->cells : fakeCells_;
+    }
+    return cells + ((uint64_t)node * G + beams[(uint64_t)node * beam + slot].pad) * S;
+  };
 
   // LatticeFormatInfo::fillInfo (lattice_format.cc:13-43)
   info_.clear();
   const int32_t maxN = std::min<int32_t>(beam, outputN);
   for (int32_t i = 0; i < maxN; ++i) {
-    const jppgpu_beam_slot& el = beams[(uint64_t)eos * beam + i];
+    const jppgpu_beam_slot& el = eosSlot(i);
     if (isFake(el)) break;
     uint32_t node = el.prev_node;
     uint32_t slot = el.beam;
     while (node >= 2 && node != 0xffffffffu) {
-      const jppgpu_beam_slot& c = beams[(uint64_t)node * beam + slot];
+      const jppgpu_beam_slot& c = slotOf(node, slot);
+      if (isFake(c)) return Status::InvalidState("n-best view does not cover a path of the lattice format");
       NodeInfo& ni = info_[node];
       ni.ranks.push_back((uint16_t)i);
       if (std::find(ni.slots.begin(), ni.slots.end(), slot) == ni.slots.end()) ni.slots.push_back(slot);
@@ -97,7 +137,7 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
   } else {
     put(printer, "# MA-SCORE\t");
     for (int32_t i = 0; i < outputN && i < beam; ++i) {
-      const jppgpu_beam_slot& bel = beams[(uint64_t)eos * beam + i];
+      const jppgpu_beam_slot& bel = eosSlot(i);
       if (isFake(bel)) break;
       put(printer, "rank");
       putInt(printer, i + 1);
@@ -112,13 +152,15 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
   for (auto& kv : info_) {
     const uint32_t node = kv.first;
     const NodeInfo& ni = kv.second;
-    if (!om.locate(s, node, &walker_)) {
-      return Status::InvalidState() << "failed to locate node: " << (s.nodes[node].start + 2) << ":" << node;
+    const jppgpu_nbest_item* rec = nbv != nullptr ? itemOf(node, ni.slots[0]) : nullptr;
+    const jppgpu_node& nd = rec ? rec->info : s.nodes[node];
+    if (!(rec ? om.locate(s, rec->info, rec->unk, &walker_) : om.locate(s, node, &walker_))) {
+      return Status::InvalidState() << "failed to locate node: " << (nd.start + 2) << ":" << node;
     }
     // std::max_element with `total1 > total2` as the ordering (lattice_format.cc:129-141) selects the
     // connection with the SMALLEST weighted score among those the N best paths use (first one on ties)
     auto total = [&](uint32_t slot) {
-      const float* sc = cells + ((uint64_t)node * G + beams[(uint64_t)node * beam + slot].pad) * S;
+      const float* sc = cellsOf(node, slot);
       float t = 0;
       for (size_t i = 0; i < weights_.size(); ++i) t += sc[i] * weights_[i];
       return t;
@@ -132,8 +174,7 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
         bestTotal = t;
       }
     }
-    const float* scores = cells + ((uint64_t)node * G + beams[(uint64_t)node * beam + best].pad) * S;
-    const jppgpu_node& nd = s.nodes[node];
+    const float* scores = cellsOf(node, best);
     while (walker_.next()) {
       put(printer, "-\t");
       putInt(printer, ni.id);

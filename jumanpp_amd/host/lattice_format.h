@@ -1,11 +1,13 @@
 // Lattice output format (`-s N` / `--lattice N`): the N best paths as a graph of
 // morphemes, byte-for-byte what jumandic::output::LatticeFormat prints
-// (src/jumandic/shared/lattice_format.{h,cc}).  Needs the full lattice view
-// (beams + score cells), i.e. GpuAnalyzer::analyzeBatch(inputs, /*fullLattice=*/true).
+// (src/jumandic/shared/lattice_format.{h,cc}).  Reads either the full lattice view (beams + score
+// cells: analyzeBatch(inputs, fullLattice = true)) or, after GpuAnalyzer::setLatticeNBest(n), the n best
+// paths gathered on the device.
 #ifndef JUMANPP_AMD_HOST_LATTICE_FORMAT_H
 #define JUMANPP_AMD_HOST_LATTICE_FORMAT_H
 
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,8 @@ class LatticeFormat : public OutputFormat {
   std::string printer_;
   NodeWalker walker_;
   std::map<uint32_t, NodeInfo> info_;
+  std::unordered_map<uint64_t, const jppgpu_nbest_item*> nbItems_;  // (node << 8 | slot) of the n-best view
+  float fakeCells_[2] = {0.f, 0.f};
   int32_t topN_ = 1;
   std::vector<float> weights_;
 

@@ -78,8 +78,11 @@ Status OutputManager::kvListField(StringPiece name, KVListField* result) const {
 }
 
 bool OutputManager::locate(const SentenceResult& s, uint32_t k, NodeWalker* w) const {
-  if (k >= s.numNodes) return false;
-  const jppgpu_node& nd = s.nodes[k];
+  if (k >= s.numNodes || s.nodes == nullptr) return false;
+  return locate(s, s.nodes[k], s.unk[k], w);
+}
+
+bool OutputManager::locate(const SentenceResult& s, const jppgpu_node& nd, const jppgpu_unk& unk, NodeWalker* w) const {
   const int32_t nf = model_->numFeatures(), ndata = model_->numData();
   if (nf + ndata + 1 > kMaxDicFields) return false;
   w->numFeatures_ = nf;
@@ -99,10 +102,10 @@ bool OutputManager::locate(const SentenceResult& s, uint32_t k, NodeWalker* w) c
   int32_t actual = nd.entry_ptr;
   if (nd.entry_ptr < 0) {  // UNK: template row, surface-bearing features replaced
     w->special_ = true;
-    actual = s.unk[k].template_ptr;
+    actual = unk.template_ptr;
     w->unkSurface_ = s.surface(nd);
-    w->placeholders_[0] = s.unk[k].placeholder[0];
-    w->placeholders_[1] = s.unk[k].placeholder[1];
+    w->placeholders_[0] = unk.placeholder[0];
+    w->placeholders_[1] = unk.placeholder[1];
   }
   // DicEntryBuffer::fillFromStorage (dic_entries.h:102-127)
   const bool alias = (actual & 1) != 0;
@@ -126,9 +129,9 @@ bool OutputManager::locate(const SentenceResult& s, uint32_t k, NodeWalker* w) c
   }
   if (nd.entry_ptr < 0) {
     // ExtraNodesContext node content: the maker's replaced fields carry the (negative) surface hash
-    const uint32_t mask = model_->unkMaker(s.unk[k].maker).replace_mask;
+    const uint32_t mask = model_->unkMaker(unk.maker).replace_mask;
     for (int i = 0; i < nf; ++i)
-      if ((mask >> i) & 1) w->features_[i] = s.unk[k].content_hash;
+      if ((mask >> i) & 1) w->features_[i] = unk.content_hash;
   }
   return true;
 }

@@ -123,6 +123,8 @@ class OutputManager {
   Status kvListField(StringPiece name, KVListField* result) const;
   // OutputManager::locate (output.cc:65-105) for node `k` of a sentence
   bool locate(const SentenceResult& s, uint32_t k, NodeWalker* result) const;
+  // the same for a node given by its records (s: input text and codepoint offsets for UNK surfaces)
+  bool locate(const SentenceResult& s, const jppgpu_node& nd, const jppgpu_unk& unk, NodeWalker* result) const;
 };
 
 }  // namespace jumanpp_amd
