@@ -30,8 +30,8 @@ def main():
                               rnn_vocab=30000, sent_len=a.len)
     cache = '/tmp/jppgpu_bench_cache'
     mdic, model, img = bench.make_workload(args, cache)
-    corpus = bench.make_corpus(args, mdic, cache, a.batch * 2, 31)
-    batches = bench.load_batches(corpus, a.batch, np)
+    corpus = bench.make_corpus(args, mdic, cache, a.batch * 8, 31)   # 8 batches: the CLI's first batch per analyzer is warm-up
+    batches = bench.load_batches(corpus, a.batch, np)[:2]
     dev = torch.device('cuda', 0)
     ctx = J.Context(img, beam=32, global_beam=32, right_check=1, right_beam=32)
     d = []
