@@ -61,10 +61,19 @@ class ResultView(C.Structure):
                 ('gbeam_count', C.c_void_p), ('gbeam', C.c_void_p)]
 
 
+class NbestView(C.Structure):
+    _fields_ = [('n_sentences', C.c_uint32), ('n_best', C.c_int32), ('beam', C.c_int32), ('global_beam', C.c_int32),
+                ('num_scorers', C.c_int32),
+                ('status', C.c_void_p), ('n_codepoints', C.c_void_p), ('n_nodes', C.c_void_p),
+                ('eos', C.c_void_p), ('path_first', C.c_void_p), ('items', C.c_void_p)]
+
+
 NODE_DT = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
 UNK_DT = np.dtype([('tmpl', '<i4'), ('hash', '<i4'), ('ph0', '<u2'), ('ph1', '<u2'), ('maker', '<u2'), ('pad', '<u2')])
 BEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('total', '<f4'), ('prev_node', '<u4'), ('pad', '<u4')])
 GBEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('score', '<f4')])
+NBEST_DT = np.dtype([('node', '<u4'), ('slot', '<u4'), ('beam', BEAM_DT), ('info', NODE_DT), ('unk', UNK_DT),
+                     ('cells', '<f4', (2,))])
 
 _libs = {}
 
@@ -84,6 +93,7 @@ def load_library(path=None):
     lib.jppgpu_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                 C.c_void_p, C.POINTER(C.c_void_p)]
     lib.jppgpu_result_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(ResultView)]
+    lib.jppgpu_result_fetch_nbest.argtypes = [C.c_void_p, C.c_int32, C.POINTER(NbestView)]
     lib.jppgpu_result_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.jppgpu_result_release.argtypes = [C.c_void_p]
     lib.jppgpu_result_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -162,6 +172,18 @@ class Result:
             self.gbeam_count = self._arr(v.gbeam_count, '<u4', NB)
             self.gbeam_entries = self._arr(v.gbeam, GBEAM_DT, NB * v.global_beam).reshape(NB if v.global_beam else 0, v.global_beam)
         return self
+
+    def fetch_nbest(self, n_best):
+        """(eos slots [n, n_best], path_first [n * n_best + 1], items) of jppgpu_result_fetch_nbest"""
+        v = NbestView()
+        rc = self.ctx.lib.jppgpu_result_fetch_nbest(self.handle, n_best, C.byref(v))
+        if rc != 0:
+            raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
+        n = v.n_sentences
+        first = self._arr(v.path_first, '<u8', n * n_best + 1)
+        total = int(first[-1]) if n else 0
+        return (self._arr(v.eos, BEAM_DT, n * n_best).reshape(n, n_best), first, self._arr(v.items, NBEST_DT, total),
+                self._arr(v.n_nodes, '<u4', n))
 
     def stats(self):
         a, b = C.c_uint64(), C.c_uint64()

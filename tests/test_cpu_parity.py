@@ -140,6 +140,49 @@ def check_top1_fetch_equals_basic_fetch(ctx, lines):
     return int(plen.sum())
 
 
+def check_nbest_fetch_equals_full_lattice(ctx, lines, n_best):
+    """jppgpu_result_fetch_nbest (device-gathered paths) against a walk through the full lattice arrays"""
+    import numpy as np
+    r = ctx.analyze(lines)
+    f = r.fetch(full=True)
+    status, nbase, nnodes = f.status.copy(), f.node_base.copy(), f.nnodes.copy()
+    beams, cells, nodes, unk = f.beams.copy(), f.cells.copy(), f.nodes.copy(), f.unk.copy()
+    eos, first, items, nn = r.fetch_nbest(n_best)
+    assert np.array_equal(nn, nnodes)
+    walked = 0
+    for s in range(len(lines)):
+        for i in range(n_best):
+            lo, hi = int(first[s * n_best + i]), int(first[s * n_best + i + 1])
+            if status[s] != 0 or nnodes[s] <= 3:
+                assert lo == hi and eos[s, i]['left'] == 0xffff
+                continue
+            nb, N = int(nbase[s]), int(nnodes[s])
+            el = beams[nb + N - 1][i] if i < beams.shape[1] else None
+            if el is None or (el['left'] == 0xffff and el['beam'] == 0xffff):
+                assert lo == hi and eos[s, i]['left'] == 0xffff and eos[s, i]['beam'] == 0xffff
+                continue
+            assert eos[s, i] == el
+            node, slot, k = int(el['prev_node']), int(el['beam']), lo
+            while node >= 2 and node != 0xffffffff:
+                c = beams[nb + node][slot]
+                it = items[k]
+                assert k < hi and it['node'] == node and it['slot'] == slot and it['beam'] == c
+                assert it['info'] == nodes[nb + node] and it['unk'] == unk[nb + node]
+                assert np.array_equal(it['cells'][:cells.shape[2]].view('<u4'), cells[nb + node][int(c['pad'])].view('<u4'))
+                node, slot, k = int(c['prev_node']), int(c['beam']), k + 1
+            assert k == hi
+            walked += hi - lo
+    return walked
+
+
+def test_nbest_fetch_equals_full_lattice(emu_lib, golden_dir):
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    lines = lines[:6] + ['', b'\xff bad'] + lines[6:14]
+    for image, n_best in (('mini.img', 5), ('mini_rnn.img', 3), ('mini.img', 9)):   # 9 > beam: the extra paths are empty
+        ctx = J.Context(os.path.join(golden_dir, image), lib_path=emu_lib)
+        assert check_nbest_fetch_equals_full_lattice(ctx, lines, n_best) > 100
+
+
 def test_top1_fetch_equals_basic_fetch(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]

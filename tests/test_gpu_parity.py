@@ -275,3 +275,12 @@ def test_gpu_maximum_size_sentences(gpu_lib, ref_tools, tmp_path, rnn):
     for s in range(len(lines)):
         errs += G.compare_sentence(res, s, gold[s], meta)
     assert not errs, errs[:10]
+
+
+def test_gpu_nbest_fetch_equals_full_lattice(gpu_lib, golden_dir):
+    """jppgpu_result_fetch_nbest on the device against the full lattice arrays (1 500 sentences, RNN model)"""
+    import test_cpu_parity as tc
+    ctx = J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=gpu_lib)
+    lines = [l.rstrip('\n').encode('utf-8') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    lines = (lines + [b'', b'\xe3\x81']) * 50
+    assert tc.check_nbest_fetch_equals_full_lattice(ctx, lines, 5) > 50000
