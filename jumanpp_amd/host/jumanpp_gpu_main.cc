@@ -79,7 +79,7 @@ struct Example {
   std::string comment;
   std::string input;
   Status readStatus;
-  PartialExample partial;
+  std::unique_ptr<PartialExample> partial;  // --partial-input only
 };
 
 // one batch on its way through read -> analyse -> format
@@ -420,7 +420,8 @@ int main(int argc, const char** argv) {
     while (batch.size() < conf.batch && hasNext()) {
       Example e;
       if (conf.partialInput) {
-        e.readStatus = pexReader.readExample(in, &e.partial);
+        e.partial.reset(new PartialExample());
+        e.readStatus = pexReader.readExample(in, e.partial.get());
         batch.push_back(std::move(e));
         continue;
       }
@@ -444,7 +445,7 @@ int main(int argc, const char** argv) {
     GpuAnalyzer& analyzer = *analyzers[job->analyzer];
     if (conf.partialInput) {
       std::vector<const PartialExample*> exs;
-      for (auto& e : job->batch) exs.push_back(e.readStatus.isOk() ? &e.partial : nullptr);
+      for (auto& e : job->batch) exs.push_back(e.readStatus.isOk() ? e.partial.get() : nullptr);
       job->batchStatus = analyzer.analyzeBatchPartial(exs, useLattice);
     } else {
       std::vector<StringPiece> pieces;
@@ -472,7 +473,7 @@ int main(int argc, const char** argv) {
         continue;
       }
       StringPiece comment = e.comment.size() < 2 ? StringPiece("") : StringPiece(e.comment.data() + 2, e.comment.size() - 2);
-      if (conf.partialInput) comment = StringPiece(e.partial.comment);
+      if (conf.partialInput) comment = StringPiece(e.partial->comment);
       st = format->format(analyzer, i, comment);
       if (!st) *errors += statusText(st);
       else {
