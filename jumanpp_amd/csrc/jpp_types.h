@@ -134,6 +134,18 @@ struct NodeAux {
 // One beam slot: the index form of ConnectionBeamElement
 // (src/core/analysis/lattice_config.h:37-79).  `prev_node` (sentence-local
 // node id of the left node) replaces the host pointer `previous`.
+// What the count pass (k_seeds<0>) learned walking the double array from one start: which prefixes are
+// trie nodes / dictionary keys and the entry-list pointers of the keys.  The emit passes replay it instead
+// of walking again (one 48-byte read instead of a chain of dependent 4-byte loads per input byte).
+constexpr int kWalkCacheVals = 8;
+struct WalkCache {
+  u64 leaf;                  // bit (len - 1): the prefix of len codepoints is a key
+  i32 vals[kWalkCacheVals];  // trie values of the first keys, by increasing length
+  u8 ok_len;                 // prefixes up to this length are trie nodes
+  u8 cached;                 // 1: complete (walk <= 64 codepoints, <= kWalkCacheVals keys)
+  u8 pad[6];
+};
+
 struct BeamSlot {
   u16 left;       // index into ends[boundary]
   u16 beam;       // slot index inside the left node's beam
@@ -181,6 +193,7 @@ struct Batch {
   u16* pos_cnt1;           // dictionary + stage-1 maker nodes (w/o normalize) starting at position g
   u16* pos_cntN;           // normalize-maker nodes starting at position g
   u16* pos_cnt2;           // stage-2 maker nodes starting at position g
+  WalkCache* pos_walk;     // the count pass's dictionary walk from position g, replayed by the emit passes
   u64* pos_ends;           // bit e set: a stage-1 node starting at position g ends at codepoint e (e <= 63), from the count pass
   u8* reach;               // [g] connectivity scratch
   u32* sent_nodes;         // nodes of sentence incl. 2 BOS + EOS (after stage decision)

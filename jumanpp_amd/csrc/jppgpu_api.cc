@@ -270,7 +270,7 @@ struct jppgpu_ctx {
   DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
   // workspace
   DevBuf text, offs;
-  DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, reach;
+  DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, pos_walk, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
   DevBuf path_len, bnd_meta;
   DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
@@ -519,7 +519,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   if (!ctx) return;
   DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
                     &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
-                    &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->reach,     &ctx->sent_ncp,
+                    &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
                     &ctx->sent_status, &ctx->sent_flags, &ctx->sent_nodes, &ctx->sent_nodes2, &ctx->node_base,
                     &ctx->node_base2, &ctx->path_len,  &ctx->bnd_first,  &ctx->bnd_cnt,   &ctx->end_first,
                     &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
@@ -548,7 +548,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
   bool ok = ctx->cp_code.ensure(cpN * 4) && ctx->cp_class.ensure(cpN * 4) && ctx->cp_boff.ensure(cpN * 2) &&
             ctx->cl_nodes.ensure(cpN * sizeof(ClNodes)) && ctx->pos_cnt1.ensure(cpN * 2) &&
-            ctx->pos_cntN.ensure(cpN * 2) && ctx->pos_cnt2.ensure(cpN * 2) && ctx->pos_ends.ensure(cpN * 8) && ctx->reach.ensure(cpN) &&
+            ctx->pos_cntN.ensure(cpN * 2) && ctx->pos_cnt2.ensure(cpN * 2) && ctx->pos_ends.ensure(cpN * 8) && ctx->pos_walk.ensure(cpN * sizeof(WalkCache)) && ctx->reach.ensure(cpN) &&
             ctx->sent_ncp.ensure((n + 1) * 4) && ctx->sent_status.ensure((n + 1) * 4) &&
             ctx->sent_flags.ensure((n + 1) * 4) && ctx->sent_nodes.ensure((n + 1) * 4) &&
             ctx->sent_nodes2.ensure((n + 1) * 4) && ctx->node_base.ensure((n + 2) * 8) &&
@@ -585,6 +585,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.pos_cntN = ctx->pos_cntN.as<u16>();
   B.pos_cnt2 = ctx->pos_cnt2.as<u16>();
   B.pos_ends = ctx->pos_ends.as<u64>();
+  B.pos_walk = ctx->pos_walk.as<WalkCache>();
   B.reach = ctx->reach.as<u8>();
   B.sent_ncp = ctx->sent_ncp.as<u32>();
   B.sent_status = ctx->sent_status.as<i32>();

@@ -354,6 +354,9 @@ int main(int argc, const char** argv) {
     out = ofile.get();
   }
   std::ios::sync_with_stdio(false);
+  // std::cin is tied to std::cout by default: every read would flush std::cout from the reader thread
+  // while the writer thread is inside it
+  std::cin.tie(nullptr);
 
   size_t fileIdx = 0;
   std::unique_ptr<std::ifstream> ifile;
