@@ -110,14 +110,13 @@ __device__ __forceinline__ int walk_status(const WalkInfo& w, u32 len) {
   return ((w.leaf >> (len - 1)) & 1) ? TRIE_OK : TRIE_NOLEAF;
 }
 
-// `rec` (count pass): where to record the walk for the emit passes
+// `rec` (count pass): where to record the walk for the emit passes.  The record is written straight to
+// memory: a local WalkCache indexed by the running key count would live in scratch.
 __device__ __forceinline__ WalkInfo dic_seeds(const DevModel& M, const SentView& S, u32 i, SeedSink& out,
                                               WalkCache* rec = nullptr) {
   TrieCursor c{0, 0};
   WalkInfo w{0, 0, true};
-  WalkCache wc;
   u32 nvals = 0;
-  bool complete = true;
   for (u32 j = i; j < S.n; ++j) {
     int st = step_cp(M, S, c, j);
     if (st == TRIE_NONODE) break;
@@ -129,34 +128,31 @@ __device__ __forceinline__ WalkInfo dic_seeds(const DevModel& M, const SentView&
       if (st == TRIE_OK) w.leaf |= u64{1} << (len - 1);
     }
     if (st == TRIE_OK) {
-      if (nvals < (u32)kWalkCacheVals) wc.vals[nvals] = c.value;
-      else complete = false;
+      if (rec && nvals < (u32)kWalkCacheVals) rec->vals[nvals] = c.value;
       ++nvals;
       u32 e = j + 1;
       for_each_entry(M, c.value, [&](i32 ptr) { out.dic(ptr, i, e); });
     }
   }
   if (rec) {
-    wc.leaf = w.leaf;
-    wc.ok_len = (u8)w.ok_len;
-    wc.cached = (complete && w.valid) ? 1 : 0;
-    for (u32 k = nvals; k < (u32)kWalkCacheVals; ++k) wc.vals[k] = 0;
-    for (int k = 0; k < 6; ++k) wc.pad[k] = 0;
-    *rec = wc;
+    rec->leaf = w.leaf;
+    rec->ok_len = (u8)w.ok_len;
+    rec->cached = (nvals <= (u32)kWalkCacheVals && w.valid) ? 1 : 0;
   }
   return w;
 }
 
 // the same seeds from the recorded walk: no trie access
-__device__ __forceinline__ WalkInfo dic_seeds_replay(const DevModel& M, const WalkCache& wc, u32 i, SeedSink& out) {
-  WalkInfo w{wc.ok_len, wc.leaf, true};
-  u64 bits = wc.leaf;
+__device__ __forceinline__ WalkInfo dic_seeds_replay(const DevModel& M, const WalkCache* wc, u64 leaf, u32 ok_len, u32 i,
+                                                     SeedSink& out) {
+  WalkInfo w{ok_len, leaf, true};
+  u64 bits = leaf;
   u32 k = 0;
   while (bits) {
     const u32 len = (u32)__builtin_ctzll(bits) + 1;
     bits &= bits - 1;
     const u32 e = i + len;
-    for_each_entry(M, wc.vals[k], [&](i32 ptr) { out.dic(ptr, i, e); });
+    for_each_entry(M, wc->vals[k], [&](i32 ptr) { out.dic(ptr, i, e); });
     ++k;
   }
   return w;
@@ -541,8 +537,8 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
     if (MODE == 0) {
       w = dic_seeds(M, S, i, out, &B.pos_walk[g0 + i]);
     } else {
-      const WalkCache wc = B.pos_walk[g0 + i];
-      w = wc.cached ? dic_seeds_replay(M, wc, i, out) : dic_seeds(M, S, i, out);
+      const WalkCache* wc = &B.pos_walk[g0 + i];
+      w = wc->cached ? dic_seeds_replay(M, wc, wc->leaf, wc->ok_len, i, out) : dic_seeds(M, S, i, out);
     }
 #endif
 #if JPP_SEEDS_EXP != 1
