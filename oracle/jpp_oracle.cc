@@ -327,6 +327,60 @@ static float unigramScore(const Model& m, const std::vector<u64>& pat, bool last
   return part[0] + part[1] + part[2] + part[3];
 }
 
+// util::part_step / util::partition  src/util/stl_util.h:51-135: a quickselect that stops as soon as
+// between minSize and maxSize of the best elements stand in front; makeT0Beam sorts only those.
+// Restated over indices [lo, hi) of `v`; returns the index one past the selected front.
+template <typename Cmp>
+static size_t partStep(std::vector<u32>& v, size_t lo, size_t hi, Cmp comp) {
+  const size_t sz = hi - lo;
+  if (sz == 1) return hi;
+  if (sz == 2) {
+    if (comp(v[lo + 1], v[lo])) std::swap(v[lo + 1], v[lo]);
+    return lo + 1;
+  }
+  if (sz == 3) {
+    if (comp(v[lo + 1], v[lo])) std::swap(v[lo + 1], v[lo]);
+    if (comp(v[lo + 2], v[lo + 1])) std::swap(v[lo + 2], v[lo + 1]);
+    if (comp(v[lo + 1], v[lo])) std::swap(v[lo + 1], v[lo]);
+    return lo + 1;
+  }
+  size_t pivot = hi - 1;               // the middle element goes to the last place and is the pivot
+  std::swap(v[lo + sz / 2], v[pivot]);
+  size_t a = lo, b = hi - 2;           // a walks up over elements better than the pivot, b collects the others
+  while (a != b) {
+    if (comp(v[a], v[pivot])) ++a;
+    else { std::swap(v[a], v[b]); --b; }
+  }
+  if (comp(v[pivot], v[b])) std::swap(v[pivot], v[b]);
+  else { ++b; std::swap(v[pivot], v[b]); }
+  return b;
+}
+
+template <typename Cmp>
+static size_t partitionFront(std::vector<u32>& v, size_t lo, size_t hi, Cmp comp, size_t minSize, size_t maxSize) {
+  for (;;) {
+    const size_t mid = partStep(v, lo, hi, comp);
+    size_t sz = mid - lo;
+    if (minSize <= sz && sz <= maxSize) return mid;
+    if (sz > maxSize) { hi = mid; continue; }
+    sz += 1;
+    lo = mid + 1;
+    minSize -= sz;
+    maxSize -= sz;
+    if (minSize == 0) return lo;
+  }
+}
+
+// ScoreProcessor::makeT0Beam's ordering  score_processor.cc:426-441: best `beam` candidates first
+static size_t beamOrder(std::vector<u32>& idx, const std::vector<float>& tot, u32 beam) {
+  auto comp = [&](u32 a, u32 b) { return tot[a] > tot[b]; };
+  size_t end = idx.size();
+  const size_t bound = (size_t)beam * 4 / 3;
+  if (idx.size() > bound) end = partitionFront(idx, 0, idx.size(), comp, beam, bound);
+  std::sort(idx.begin(), idx.begin() + end, comp);
+  return end;
+}
+
 // ------------------------------------------------------------- the sweep ----
 struct Slot { u16 left, beam; float total; int pb, pr; bool live; int gi; };  // gi: index of (left, beam) in the boundary's global beam
 
@@ -567,10 +621,10 @@ struct RnnPass {
       full[i] = local + beamScore;
     }
     std::vector<u32> idx(G); std::iota(idx.begin(), idx.end(), 0);
-    std::sort(idx.begin(), idx.end(), [&](u32 a, u32 bb) { return full[a] > full[bb]; });
+    const size_t have = beamOrder(idx, full, (u32)beams[eos][0].size());
     auto& row = beams[eos][0];
     for (size_t q = 0; q < row.size(); ++q) {
-      if (q < (size_t)G) { const Conn& el = eg[idx[q]]; row[q] = Slot{(u16)el.left, (u16)el.beam, full[idx[q]], el.b, el.r, true, (int)idx[q]}; }
+      if (q < have) { const Conn& el = eg[idx[q]]; row[q] = Slot{(u16)el.left, (u16)el.beam, full[idx[q]], el.b, el.r, true, (int)idx[q]}; }
       else row[q].live = false;
     }
   }
@@ -709,12 +763,12 @@ int main(int argc, char** argv) {
             float v = res; v += T0[b][t]; cell0[b][t][i] = v; v += gsc[i]; tot[i] = v;    // copyT0Scores(tail, t0Score)
           }
         }
-        // makeT0Beam :426-469 (std::sort on indices, like the reference)
+        // makeT0Beam :426-469
         std::vector<u32> idx(cnt); std::iota(idx.begin(), idx.end(), 0);
-        std::sort(idx.begin(), idx.end(), [&](u32 a, u32 bb) { return tot[a] > tot[bb]; });
+        const size_t have = beamOrder(idx, tot, g.beam);
         auto& row = beams[b][t];
         for (u32 q = 0; q < g.beam; ++q) {
-          if (q < (u32)cnt) row[q] = Slot{gl[idx[q]], gs[idx[q]], tot[idx[q]], lnode[idx[q]].first, lnode[idx[q]].second, true, (int)idx[q]};
+          if (q < (u32)have) row[q] = Slot{gl[idx[q]], gs[idx[q]], tot[idx[q]], lnode[idx[q]].first, lnode[idx[q]].second, true, (int)idx[q]};
           else row[q].live = false;
         }
         if (!timing) {

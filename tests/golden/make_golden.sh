@@ -26,6 +26,8 @@ cp "$TMP/mini.model" "$HERE/mini.jppmdl"   # the reference's own container, read
 } > "$HERE/mini.txt"
 "$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini.gold" < "$HERE/mini.txt"
 "$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini_b3.gold" 3 4 2 3 < "$HERE/mini.txt"
+# beam 4 / global beam 12: makeT0Beam's quickselect branch (more candidates than beam*4/3), first 8 lines
+head -8 "$HERE/mini.txt" | "$REF/ref_dump" dump "$TMP/mini.model" "$HERE/mini_b4g12.gold" 4 12 1 4
 "$REF/jumanpp_v2" --model="$TMP/mini.model" "$HERE/mini.txt" > "$HERE/mini.juman.txt"
 # perceptron + synthetic RNNLM (faster-rnnlm NCE format), embedded by the reference's own trainer binary
 python3 "$ROOT/tools/gen_rnn.py" "$TMP/mini.mdic" "$TMP/mini_rnn" --vocab 600 --hidden 32 --maxent-size 16384 --seed 31
@@ -35,6 +37,7 @@ python3 "$ROOT/tools/gen_rnn.py" "$TMP/mini.mdic" "$TMP/mini_rnn" --vocab 600 --
 "$REF/ref_dump" export "$TMP/mini_rnn.model" "$HERE/mini_rnn.img"
 cp "$TMP/mini_rnn.model" "$HERE/mini_rnn.jppmdl"
 "$REF/ref_dump" dump "$TMP/mini_rnn.model" "$HERE/mini_rnn.gold" < "$HERE/mini.txt" 2> /dev/null
+head -8 "$HERE/mini.txt" | "$REF/ref_dump" dump "$TMP/mini_rnn.model" "$HERE/mini_rnn_b4g12.gold" 4 12 1 4 2> /dev/null
 "$REF/jumanpp_v2" --model="$TMP/mini_rnn.model" "$HERE/mini.txt" > "$HERE/mini_rnn.juman.txt"
 rm -rf "$TMP"
 ls -la "$HERE"

@@ -15,9 +15,9 @@ import jumanpp_amd as J
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_golden(lib, golden_dir, gold_name, image='mini.img', **cfg):
+def _run_golden(lib, golden_dir, gold_name, image='mini.img', n_lines=None, **cfg):
     ctx = J.Context(os.path.join(golden_dir, image), lib_path=lib, **cfg)
-    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')][:n_lines]
     meta, gold = G.read_gold(os.path.join(golden_dir, gold_name))
     assert meta['nsent'] == len(lines)
     res = ctx.analyze(lines).fetch(full=True)
@@ -36,6 +36,14 @@ def test_emulated_kernels_match_reference_default_config(emu_lib, golden_dir):
 def test_emulated_kernels_match_reference_other_beam_config(emu_lib, golden_dir):
     # beam 3, global beam 4, right-check 2, right-beam 3
     _run_golden(emu_lib, golden_dir, 'mini_b3.gold', beam=3, global_beam=4, right_check=2, right_beam=3)
+
+
+def test_emulated_kernels_match_reference_quickselect_goldens(emu_lib, golden_dir):
+    # beam 4 / global beam 12: makeT0Beam takes util::partition (whose result is not always the true top-N,
+    # which the goldens pin), perceptron and RNN (remakeEosBeam goes through the same routine)
+    _run_golden(emu_lib, golden_dir, 'mini_b4g12.gold', n_lines=8, beam=4, global_beam=12, right_check=1, right_beam=4)
+    _run_golden(emu_lib, golden_dir, 'mini_rnn_b4g12.gold', image='mini_rnn.img', n_lines=8, beam=4, global_beam=12,
+                right_check=1, right_beam=4)
 
 
 def test_emulated_kernels_match_reference_with_rnn(emu_lib, golden_dir):
@@ -279,7 +287,9 @@ def test_oracle_restatement_is_pinned_by_reference_goldens(golden_dir):
     import __graft_entry__ as ge
     ge.build_oracle_port()
     exe = os.path.join(ROOT, 'oracle', '_port', 'jpp_oracle')
-    for image, gold in (('mini.img', 'mini.gold'), ('mini.img', 'mini_b3.gold'), ('mini_rnn.img', 'mini_rnn.gold')):
+    for image, gold in (('mini.img', 'mini.gold'), ('mini.img', 'mini_b3.gold'), ('mini_rnn.img', 'mini_rnn.gold'),
+                        ('mini.img', 'mini_b4g12.gold'), ('mini_rnn.img', 'mini_rnn_b4g12.gold')):
+        # (the quickselect goldens hold the first 8 sentences; the checker stops at the shorter of corpus and golden)
         out = subprocess.run([exe, 'check', os.path.join(golden_dir, image), os.path.join(golden_dir, 'mini.txt'),
                               os.path.join(golden_dir, gold)], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr

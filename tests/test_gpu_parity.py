@@ -41,6 +41,18 @@ def test_gpu_matches_reference_other_beam_config(gpu_lib, golden_dir):
     assert not errs, errs[:10]
 
 
+@pytest.mark.parametrize('image,gold_name', [('mini.img', 'mini_b4g12.gold'), ('mini_rnn.img', 'mini_rnn_b4g12.gold')])
+def test_gpu_matches_reference_quickselect_goldens(gpu_lib, golden_dir, image, gold_name):
+    """beam 4 / global beam 12: makeT0Beam's util::partition branch (also at remakeEosBeam with the RNN)"""
+    ctx = J.Context(os.path.join(golden_dir, image), lib_path=gpu_lib, beam=4, global_beam=12, right_check=1, right_beam=4)
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')][:8]
+    meta, gold = G.read_gold(os.path.join(golden_dir, gold_name))
+    assert meta['nsent'] == 8 and meta['beam'] == 4 and meta['gbeam'] == 12
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, errs[:10]
+
+
 def test_gpu_matches_reference_with_rnn(gpu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=gpu_lib)
     lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
