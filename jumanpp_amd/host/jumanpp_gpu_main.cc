@@ -45,6 +45,7 @@ struct Conf {
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
+  bool help = false;
   int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
   enum { Juman, Morph, FullMorph, Segment, DicSubset } kind = Juman;
   std::string segmentSeparator = " ";
@@ -216,6 +217,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--threads", &v)) conf.threads = std::atoi(v.c_str());
     else if (std::strcmp(argv[i], "--no-pipeline") == 0) conf.pipeline = false;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
+    else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
       std::cerr << "unknown option " << argv[i] << "\n";
       return false;
@@ -269,6 +271,18 @@ int main(int argc, const char** argv) {
       std::string rel = (slash == std::string::npos ? std::string(".") : conf.configFile.substr(0, slash)) + "/" + conf.model;
       if (fileExists(rel)) conf.model = rel;
     }
+  }
+  if (conf.help) {
+    std::cerr << "jumanpp_gpu: Juman++ v2 analysis on an MI355X, the batched sibling of jumanpp_v2\n"
+                 "  jumanpp_gpu --model=MODEL.jppmdl [options] [INPUT...]   (standard input without INPUT)\n"
+                 "General:   -c/--config FILE   -o/--output FILE   --partial-input   --device=N\n"
+                 "Output:    -j/--juman (default)  -M/--morph  -F/--full-morph  --segment [--segment-separator=S]\n"
+                 "           -s/-L/--lattice/--specifics N   --dic-subset   --format=NAME\n"
+                 "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
+                 "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
+                 "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
+                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing\n";
+    return 1;
   }
   if (conf.model.empty()) {
     std::cerr << "Model file was not specified\n";
