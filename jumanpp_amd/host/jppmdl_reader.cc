@@ -476,6 +476,33 @@ Status ModelImage::loadJppmdl(const std::string& fn) {
   return Status::Ok();
 }
 
+void ModelImage::attachExternalRnn(const jppgpu_model& part, const RnnConfigOverride& o, RnnScoreWeights* weights) {
+  model_.has_rnn = 1;
+  model_.rnn_layer_size = part.rnn_layer_size;
+  model_.rnn_maxent_order = part.rnn_maxent_order;
+  model_.rnn_maxent_size = part.rnn_maxent_size;
+  model_.rnn_vocab_size = part.rnn_vocab_size;
+  model_.rnn_nce_constant = o.hasNceBias ? o.nceBias : part.rnn_nce_constant;
+  model_.rnn_unk_id = part.rnn_unk_id;
+  model_.rnn_unk_constant = o.unkConstantTerm;
+  model_.rnn_unk_length = o.unkLengthPenalty;
+  model_.rnn_num_fields = part.rnn_num_fields;
+  for (uint32_t i = 0; i < part.rnn_num_fields && i < 8; ++i) model_.rnn_fields[i] = part.rnn_fields[i];
+  model_.rnn_known_index = part.rnn_known_index;
+  model_.rnn_known_index_bytes = part.rnn_known_index_bytes;
+  model_.rnn_unk_index = part.rnn_unk_index;
+  model_.rnn_unk_index_bytes = part.rnn_unk_index_bytes;
+  model_.rnn_matrix = part.rnn_matrix;
+  model_.rnn_embeddings = part.rnn_embeddings;
+  model_.rnn_nce_embeddings = part.rnn_nce_embeddings;
+  model_.rnn_maxent = part.rnn_maxent;
+  hasRnn_ = true;
+  hasSavedRnnConfig_ = false;
+  rnnWeights_.perceptron = o.perceptronWeight;
+  rnnWeights_.rnn = o.rnnWeight;
+  *weights = rnnWeights_;
+}
+
 Status ModelImage::applyRnnConfig(const RnnConfigOverride& o, bool* useRnn, RnnScoreWeights* weights) {
   if (!hasRnn_) return Status::InvalidState("the model has no RNN part");
   if (!hasSavedRnnConfig_)

@@ -30,6 +30,7 @@
 #include "gpu_analyzer.h"
 #include "juman_format.h"
 #include "lattice_format.h"
+#include "rnn_external.h"
 #include "simple_formats.h"
 
 using namespace jumanpp_amd;
@@ -52,6 +53,8 @@ struct Conf {
   bool partialInput = false;  // --partial-input: InputType::PartiallyAnnotated
   int autoStep = 0;           // --auto-nbest=base:step:max (jumanpp_args.cc:270-279)
   std::string configFile;     // -c / --config: file of whitespace-separated arguments, read before the command line
+  std::string rnnModel;       // --rnn-model: a separate faster-rnnlm model (PATH + PATH.nnet) instead of an embedded one
+  ExternalRnnConfig rnnNames; // --rnn-fields, --rnn-separator, --rnn-unk, --rnn-eos
   RnnConfigOverride rnn;  // --rnn-nce-bias, --rnn-unk-constant, --rnn-unk-length, --feature-weight-*
   int threads = 0;            // --threads=N format workers (0: one per hardware thread, at most 32)
   bool pipeline = true;       // --no-pipeline: one analyzer, read/analyse/format strictly in turn per batch
@@ -209,6 +212,19 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     } else if (std::strcmp(argv[i], "--partial-input") == 0) conf.partialInput = true;
     else if (std::strcmp(argv[i], "--no-rnn") == 0) conf.noRnn = true;
     else if (argValue(argc, argv, i, "--config", &v) || argValue(argc, argv, i, "-c", &v)) conf.configFile = v;
+    else if (argValue(argc, argv, i, "--rnn-model", &v)) conf.rnnModel = v;
+    else if (argValue(argc, argv, i, "--rnn-fields", &v)) {
+      conf.rnnNames.fields.clear();
+      for (size_t p = 0;;) {
+        size_t e = v.find(',', p);
+        conf.rnnNames.fields.push_back(v.substr(p, e == std::string::npos ? std::string::npos : e - p));
+        if (e == std::string::npos) break;
+        p = e + 1;
+      }
+    }
+    else if (argValue(argc, argv, i, "--rnn-separator", &v)) conf.rnnNames.separator = v;
+    else if (argValue(argc, argv, i, "--rnn-unk", &v)) conf.rnnNames.unkSymbol = v;
+    else if (argValue(argc, argv, i, "--rnn-eos", &v)) conf.rnnNames.eosSymbol = v;
     else if (argValue(argc, argv, i, "--rnn-nce-bias", &v)) { conf.rnn.nceBias = std::strtof(v.c_str(), nullptr); conf.rnn.hasNceBias = true; }
     else if (argValue(argc, argv, i, "--rnn-unk-constant", &v)) { conf.rnn.unkConstantTerm = std::strtof(v.c_str(), nullptr); conf.rnn.hasUnkConstantTerm = true; }
     else if (argValue(argc, argv, i, "--rnn-unk-length", &v)) { conf.rnn.unkLengthPenalty = std::strtof(v.c_str(), nullptr); conf.rnn.hasUnkLengthPenalty = true; }
@@ -307,9 +323,19 @@ int main(int argc, const char** argv) {
   ScoringConfig sconf;
   sconf.beamSize = conf.beam;
   ScorerDef def;
-  def.useRnn = model.hasRnn() && !conf.noRnn;
   RnnScoreWeights weights = model.savedScoreWeights();
-  if (def.useRnn && !conf.rnn.isDefault()) {  // JumanppExec::init: env.setRnnConfig(conf.rnnConfig), jumandic_env.cc:40-42
+  ExternalRnn externalRnn;  // owns the arrays the model points to: lives as long as the analyzers are created from it
+  const bool newRnn = !conf.rnnModel.empty() && !conf.noRnn;
+  if (newRnn) {  // JumanppExec::init: rnnFactory.make + env.setRnnHolder (jumandic_env.cc:38-48)
+    s = externalRnn.load(conf.rnnModel, model, conf.rnnNames);
+    if (!s) {
+      std::cerr << "failed to load the RNN model: " << s << "\n";
+      return 1;
+    }
+    model.attachExternalRnn(externalRnn.part(), conf.rnn, &weights);
+  }
+  def.useRnn = model.hasRnn() && !conf.noRnn;
+  if (def.useRnn && !newRnn && !conf.rnn.isDefault()) {  // JumanppExec::init: env.setRnnConfig(conf.rnnConfig), jumandic_env.cc:40-42
     bool useRnn = true;
     s = model.applyRnnConfig(conf.rnn, &useRnn, &weights);
     if (!s) {

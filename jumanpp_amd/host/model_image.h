@@ -94,6 +94,11 @@ class ModelImage {
   // *override's* perceptron / RNN weights (1.0 where not given -- what the reference does).
   // A given RNN weight of 0 switches the RNN off (*useRnn = false).  Only for natively loaded .jppmdl.
   Status applyRnnConfig(const RnnConfigOverride& o, bool* useRnn, RnnScoreWeights* weights);
+  // JumanppEnv::setRnnHolder for a scorer made from a separate RNN model file (jumandic_env.cc:44-48,
+  // env.cc:65-79, rnn_scorer_gbeam.cc:312-346): `part` supplies the rnn_* members (see ExternalRnn), the
+  // numeric parameters are the given ones or the RnnInferenceConfig defaults, the NCE constant is the
+  // file's unless --rnn-nce-bias is given.  Replaces an embedded RNN.
+  void attachExternalRnn(const jppgpu_model& part, const RnnConfigOverride& o, RnnScoreWeights* weights);
   // ScorerDef::scoreWeights saved with the model (RnnInferenceConfig, src/core/env.cc:86-100)
   RnnScoreWeights savedScoreWeights() const { return rnnWeights_; }
   int32_t numFeatures() const { return numFeatures_; }

@@ -603,3 +603,34 @@ def test_cli_rnn_config_overrides_and_config_file(cli_emu, ref_tools, golden_dir
     # flat images carry only the resolved values: overrides are refused instead of guessed
     rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini_rnn.img'), '--rnn-nce-bias=1', txt])
     assert rc == 1 and b'failed to apply the RNN configuration' in err
+
+
+def test_cli_external_rnn_model(cli_emu, ref_tools, golden_dir, tmp_path):
+    """--rnn-model=PATH (faster-rnnlm vocabulary + PATH.nnet) on a perceptron-only model: the host builds the
+    word-id double arrays itself (RnnIdResolver::build) and must analyse like the reference does"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    tmp = str(tmp_path)
+    mdic = os.path.join(tmp, 'mini.mdic')
+    with open(mdic, 'w', encoding='utf-8') as f:  # the dictionary of tests/golden/mini.jppmdl (make_golden.sh)
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), '2500', '--seed', '11'], stdout=f)
+    rnn = os.path.join(tmp, 'rnn')
+    subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_rnn.py'), mdic, rnn, '--vocab', '600', '--hidden', '32',
+                           '--maxent-size', '16384', '--seed', '31'], stdout=subprocess.DEVNULL)
+    model = os.path.join(golden_dir, 'mini.jppmdl')
+    txt = os.path.join(golden_dir, 'mini.txt')
+    plain = _ref_cli(ref_tools, model, [], txt)
+    for flags in (['--rnn-model=' + rnn, '--rnn-fields=surface,pos'],
+                  ['--rnn-model=' + rnn, '--rnn-fields=surface,pos', '--rnn-nce-bias=5.6', '--rnn-unk-constant=-3.47',
+                   '--rnn-unk-length=-2.93', '--feature-weight-perceptron=1', '--feature-weight-rnn=0.0176']):
+        ref = _ref_cli(ref_tools, model, flags, txt)
+        rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
+        assert rc == 0, err[-300:]
+        assert ref != plain and _fold_unk_ties(out) == _fold_unk_ties(ref), flags
+    # the same RNN embedded in the model by the reference's trainer gives the same analysis
+    emb = _ref_cli(ref_tools, os.path.join(golden_dir, 'mini_rnn.jppmdl'), [], txt)
+    assert _fold_unk_ties(out) == _fold_unk_ties(emb)
+    rc, out, err = _run(cli_emu, ['--model=' + model, '--rnn-model=' + rnn + '.missing', '--rnn-fields=surface,pos', txt])
+    assert rc == 1 and b'failed to load the RNN model' in err
+    rc, out, err = _run(cli_emu, ['--model=' + model, '--rnn-model=' + rnn, '--rnn-fields=nosuchfield', txt])
+    assert rc == 1 and b'could not find a field' in err
