@@ -605,6 +605,12 @@ def test_cli_rnn_config_overrides_and_config_file(cli_emu, ref_tools, golden_dir
     assert rc == 1 and b'failed to apply the RNN configuration' in err
 
 
+@pytest.mark.gpu
+def test_gpu_cli_external_rnn_model(cli_gpu, ref_tools, golden_dir, tmp_path):
+    """the same on the MI355X: the device walks the double arrays the host built"""
+    test_cli_external_rnn_model(cli_gpu, ref_tools, golden_dir, tmp_path)
+
+
 def test_cli_external_rnn_model(cli_emu, ref_tools, golden_dir, tmp_path):
     """--rnn-model=PATH (faster-rnnlm vocabulary + PATH.nnet) on a perceptron-only model: the host builds the
     word-id double arrays itself (RnnIdResolver::build) and must analyse like the reference does"""
