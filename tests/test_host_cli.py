@@ -640,3 +640,16 @@ def test_cli_external_rnn_model(cli_emu, ref_tools, golden_dir, tmp_path):
     assert rc == 1 and b'failed to load the RNN model' in err
     rc, out, err = _run(cli_emu, ['--model=' + model, '--rnn-model=' + rnn, '--rnn-fields=nosuchfield', txt])
     assert rc == 1 and b'could not find a field' in err
+
+
+def test_double_array_builder_on_random_keys(emu_lib, tmp_path):
+    """the host's darts-clone-layout builder (rnn_external.cc): 120 000 random keys incl. prefixes of each other,
+    all found with their values, near-misses rejected, every probe inside the array"""
+    host = os.path.join(ROOT, 'jumanpp_amd', 'host')
+    srcs = [os.path.join(host, f) for f in sorted(os.listdir(host)) if f.endswith('.cc') and 'main' not in f]
+    exe = os.path.join(str(tmp_path), 'da_builder_test')
+    subprocess.check_call(['g++', '-std=c++14', '-O2', '-pthread', '-I' + os.path.join(ROOT, 'include'), '-I' + host,
+                           os.path.join(ROOT, 'tests', 'host', 'da_builder_test.cc')] + srcs +
+                          ['-o', exe, '-L' + os.path.dirname(emu_lib), '-l:libjppgpu_emu.so', '-Wl,-rpath,' + os.path.dirname(emu_lib)])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-500:]
