@@ -14,6 +14,13 @@
  *       src/core/analysis/lattice_types.h, lattice_config.h:37-79      -> jppgpu_result views
  *   ExtraNodesContext::node(EntryPtr) (UNK nodes)
  *       src/core/analysis/extra_nodes.h:79-87                           -> jppgpu_node.unk_*
+ *   AnalysisPath::fillIn + OutputManager::locate (what the 1-best formats read)
+ *       src/core/analysis/analysis_result.cc:25-76, output.cc:69-111     -> jppgpu_result_fetch(JPPGPU_FETCH_TOP1)
+ *   LatticeFormatInfo::fillInfo (what the N-best lattice format reads)
+ *       src/jumandic/shared/lattice_format.cc:13-43,129-141             -> jppgpu_result_fetch_nbest
+ *   ScorePlugin (partial annotation)  src/core/analysis/score_plugin.h:14-19,
+ *       src/core/input/partial_example.cc                                -> jppgpu_analyze_batch_partial
+ *   AnalyzerImpl::setGlobalBeam / autoBeamSizes  analyzer_impl.cc:311-361 -> jppgpu_ctx_set_beams
  *   Status kinds returned by analyze()
  *       analysis_input.cc:12-33, characters.cc:267-269, analyzer_impl.cc:133-135 -> status codes
  */
