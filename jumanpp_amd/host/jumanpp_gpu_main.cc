@@ -233,6 +233,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--threads", &v)) conf.threads = std::atoi(v.c_str());
     else if (std::strcmp(argv[i], "--no-pipeline") == 0) conf.pipeline = false;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
+    else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
       std::cerr << "unknown option " << argv[i] << "\n";
