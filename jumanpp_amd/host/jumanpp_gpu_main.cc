@@ -433,16 +433,19 @@ int main(int argc, const char** argv) {
   // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
   // call, is being formatted.  Output order is the input order.
   const int nAnalyzers = conf.pipeline ? 2 : 1;
-  std::vector<std::unique_ptr<GpuAnalyzer>> analyzers;
-  for (int a = 0; a < nAnalyzers; ++a) {
-    analyzers.emplace_back(new GpuAnalyzer());
+  // the second analyzer (a second copy of the model in HBM) is made when a second batch shows up: a short
+  // input pays for one
+  std::vector<std::unique_ptr<GpuAnalyzer>> analyzers((size_t)nAnalyzers);
+  auto makeAnalyzer = [&](int a) -> Status {
+    analyzers[a].reset(new GpuAnalyzer());
     // the lattice format reads the N best paths only: they are gathered on the device (N = what it prints)
-    if (latticeFormat) analyzers.back()->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
-    s = analyzers.back()->initialize(&model, acfg, sconf, &def, conf.device);
-    if (!s) {
-      std::cerr << "failed to initialize the analyzer: " << s << "\n";
-      return 1;
-    }
+    if (latticeFormat) analyzers[a]->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
+    return analyzers[a]->initialize(&model, acfg, sconf, &def, conf.device);
+  };
+  s = makeAnalyzer(0);
+  if (!s) {
+    std::cerr << "failed to initialize the analyzer: " << s << "\n";
+    return 1;
   }
   std::vector<std::unique_ptr<OutputFormat>> formats;
   for (int t = 0; t < conf.threads; ++t) {
@@ -456,6 +459,7 @@ int main(int argc, const char** argv) {
   BoundedQueue<std::unique_ptr<Job>> readQ(2), doneQ(1);
   BoundedQueue<std::unique_ptr<Formatted>> writeQ(2);
   Semaphore freeAnalyzers(nAnalyzers);
+  int live = nAnalyzers;  // analyzers in rotation (GPU thread only)
   Clock clock;
   double readMs = 0, analyzeMs = 0, formatMs = 0, gpuMs = 0;
 
@@ -544,8 +548,19 @@ int main(int argc, const char** argv) {
     while (readQ.pop(&job)) {
       freeAnalyzers.acquire();
       job->analyzer = next;
-      next = (next + 1) % nAnalyzers;
       double t0 = clock.ms();
+      if (!analyzers[job->analyzer]) {
+        Status made = makeAnalyzer(job->analyzer);
+        if (!made) {
+          // (e.g. no HBM for a second model copy) carry on with the first analyzer alone: take the second
+          // token out of circulation, which also waits until the first analyzer's batch has been formatted
+          analyzers[job->analyzer].reset();
+          freeAnalyzers.acquire();
+          live = 1;
+          job->analyzer = 0;
+        }
+      }
+      next = (job->analyzer + 1) % live;
       analyzeJob(job.get());
       analyzeMs += clock.ms() - t0;
       doneQ.push(std::move(job));
