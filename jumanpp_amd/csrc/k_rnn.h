@@ -124,6 +124,18 @@ constexpr int kRnnPrepWaves = 4;    // sentences (wavefronts) per k_rnn_prep wor
 constexpr int kRnnCN = 4;           // rnn nodes of one boundary evaluated per pass
 constexpr u32 kNoConn = 0xffffffffu;
 
+// `localScore += scores.at(i) * scoreWeights.at(i)` of adjustBeamScores / remakeEosBeam
+// (score_processor.cc:536-538,567-569), i = perceptron, RNN.  GCC contracts each step into one fused
+// multiply-add on an FMA target (the reference's recommended -march=native build; oracle/_ref:
+// `vfmadd231ss` in both functions), i.e. the products are NOT rounded before they are added.  The device
+// does the same so that totals built from bit-equal cells are bit-equal to the reference's, and two EOS
+// paths that tie exactly there tie exactly here.
+__device__ __forceinline__ float weighted_score2(float perceptron, float rnn, const Config& cfg) {
+  float local = __builtin_fmaf(perceptron, cfg.w_perceptron, 0.f);
+  local = __builtin_fmaf(rnn, cfg.w_rnn, local);
+  return local;
+}
+
 // FastHash1::mix (src/util/fast_hash.h:39-64)
 __device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
   u64 v = (state ^ data) * kHashMult;
@@ -794,17 +806,12 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
           const float rs = nscore[(c >> 22) & 31u];
           B.node_cells[((nb + nd) * G + (c >> 27)) * S + 1] = rs;
           if (b < bE) {
-            float local = 0.f;
-            local += l_cell0[q] * cfg.w_perceptron;
-            local += rs * cfg.w_rnn;
-            local += prevT;
+            const float local = weighted_score2(l_cell0[q], rs, cfg) + prevT;
             beams[(u64)nd * beam + k].total = local;
             prevT = local;
           } else {
-            float local = 0.f;  // remakeEosBeam: fullScores[i] = localScore + beamScore
-            local += l_cell0[q] * cfg.w_perceptron;
-            local += rs * cfg.w_rnn;
-            full[lane] = local + prevT;
+            // remakeEosBeam: fullScores[i] = localScore + beamScore
+            full[lane] = weighted_score2(l_cell0[q], rs, cfg) + prevT;
             prev_total[lane] = prevT;
           }
         }
@@ -959,27 +966,32 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       u32 nd = c & 0x03ffffffu, k = c >> 26;
       BeamSlot* sl = &beams[(u64)nd * beam + k];
       const float* cell = B.node_cells + ((nb + nd) * G + sl->pad) * S;
-      float local = 0.f;
-      local += cell[0] * cfg.w_perceptron;
-      local += cell[1] * cfg.w_rnn;
-      local += prevT;
+      const float local = weighted_score2(cell[0], cell[1], cfg) + prevT;
       sl->total = local;
       prevT = local;
     }
     // ---- E. remakeEosBeam ----
     const float* cell = B.node_cells + ((nb + N - 1) * G + lane) * S;
-    float local = 0.f;
-    local += cell[0] * cfg.w_perceptron;
-    local += cell[1] * cfg.w_rnn;
-    full[lane] = local + prevT;
+    full[lane] = weighted_score2(cell[0], cell[1], cfg) + prevT;
     prev_total[lane] = prevT;
   }
   wave_sync();
   {
     BeamSlot* row = beams + (u64)(N - 1) * beam;
     const int partB = beam * 4 / 3;
+    // makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16.  Both only
+    // permute, so with pairwise distinct totals the stable rank below is their result (see k_sweep 5c); the
+    // step-by-step replay runs only when two candidates tie exactly.
+    bool replay = false;
     if (SORT && (ngb > 16 || ngb > partB)) {
-      // makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16
+      bool tie = false;
+      if (lane < ngb) {
+        const float me = full[lane];
+        for (int j = 0; j < ngb; ++j) tie = tie || (j != lane && full[j] == me);
+      }
+      replay = wave_ballot(tie) != 0;
+    }
+    if (replay) {
       if (lane == 0) {
         u8 idx[kMaxGbeam];
         for (int z = 0; z < ngb; ++z) idx[z] = (u8)z;

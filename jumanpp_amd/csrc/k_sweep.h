@@ -289,6 +289,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ u16 order[RM];
   __shared__ float biS[kChunk][GM];
   __shared__ float tot[kChunk][GM];
+  __shared__ u8 sidx[GM > 16 ? kChunk : 1][GM];   // index arrays of the makeT0Beam replay (wide variant, ties only)
   __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass (R > kChunk only)
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
@@ -814,48 +815,80 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       JPP_PROF(6);
       // 5c. beams: stable descending rank among the node's candidates (makeT0Beam; for <= 16
       //     candidates std::sort is an insertion sort, i.e. stable)
-      for (int q = lane; q < nx * GM; q += 64) {
-        int x = q / GM, i = q - x * GM;
-        bool kept = (op0 + x) < K;
-        u32 t = order[op0 + x];
-        int cnt = kept ? ngb : c;
-        BeamSlot* row = beams + (u64)(rfirst + t) * beam;
-        const int partB = beam * 4 / 3;  // makeT0Beam: partitionBoundary
-        // (compiled only into the wide variant: the host sends every configuration with more than 16
-        // candidates or a global beam above beam*4/3 there, and the narrow one stays free of scratch)
-        if (GM > 16 && (cnt > 16 || cnt > partB)) {
-          // more than 16 candidates: libstdc++'s std::sort is an introsort (not stable); more than
-          // beam*4/3: util::partition first.  One lane per right node replays both on the index array
-          // exactly as makeT0Beam does.
-          if (i == 0) {
-            u8 idx[GM];
-            for (int z = 0; z < cnt; ++z) idx[z] = (u8)z;
-            const float* tr = tot[x];
-            auto comp = [tr](u8 a, u8 bb) { return tr[a] > tr[bb]; };
-            u8* itr = idx + cnt;
-            if (cnt > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
-            std_sort(idx, itr, comp);
-            const int have = (int)(itr - idx);
-            for (int z = 0; z < beam; ++z) {
-              if (z < have) row[z] = BeamSlot{gb_left[idx[z]], gb_slot[idx[z]], tr[idx[z]], gb_lnode[idx[z]], (u32)idx[z]};
-              else row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
-            }
-            B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
-          }
-          continue;
-        }
-        if (i < cnt) {
-          float me = tot[x][i];
+      const int partB = beam * 4 / 3;  // makeT0Beam: partitionBoundary
+      if constexpr (GM > 16) {
+        // Wide variant (the host sends every configuration with more than 16 candidates or a global beam
+        // above beam*4/3 here; the narrow one stays free of scratch).  Beyond 16 candidates libstdc++'s
+        // std::sort is an introsort (not stable), beyond beam*4/3 util::partition runs first
+        // (score_processor.cc:434-437).  Both only permute: when the node's candidate totals are pairwise
+        // distinct, the front util::partition leaves is the true top-sz for some sz >= beam and the sorted
+        // order is the unique descending one, so the parallel rank below IS makeT0Beam's result.  Only a
+        // node that holds two equal totals replays the two algorithms step by step on one lane.
+        static_assert(GM == 32, "one half-wave per right node");
+        for (int q0 = 0; q0 < nx * GM; q0 += 64) {
+          const int q = q0 + lane;
+          const bool in = q < nx * GM;
+          const int x = in ? q / GM : 0, i = in ? q - x * GM : GM;
+          const bool kept = (op0 + x) < K;
+          const u32 t = order[op0 + x];
+          const int cnt = kept ? ngb : c;
+          BeamSlot* row = beams + (u64)(rfirst + t) * beam;
+          const bool wide = cnt > 16 || cnt > partB;
+          float me = 0.f;
           int rank = 0;
-          for (int jx = 0; jx < cnt; ++jx) {
-            float o = tot[x][jx];
-            if (o > me || (o == me && jx < i)) ++rank;
+          bool tie = false;
+          if (i < cnt) {
+            me = tot[x][i];
+            for (int jx = 0; jx < cnt; ++jx) {
+              const float o = tot[x][jx];
+              if (o > me || (o == me && jx < i)) ++rank;
+              tie = tie || (o == me && jx != i);
+            }
           }
-          if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
-        } else if (i < beam) {
-          row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+          const u64 tb = wave_ballot(wide && tie);
+          const bool replay = wide && ((tb >> (lane & 32)) & 0xffffffffull) != 0;
+          if (replay) {
+            if (i == 0) {
+              u8* idx = sidx[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
+              for (int z = 0; z < cnt; ++z) idx[z] = (u8)z;
+              const float* tr = tot[x];
+              auto comp = [tr](u8 a, u8 bb) { return tr[a] > tr[bb]; };
+              u8* itr = idx + cnt;
+              if (cnt > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
+              std_sort(idx, itr, comp);
+              const int have = (int)(itr - idx);
+              for (int z = 0; z < beam; ++z) {
+                if (z < have) row[z] = BeamSlot{gb_left[idx[z]], gb_slot[idx[z]], tr[idx[z]], gb_lnode[idx[z]], (u32)idx[z]};
+                else row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+              }
+            }
+          } else if (i < cnt) {
+            if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
+          } else if (i < beam) {
+            row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+          }
+          if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
         }
-        if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
+      } else {
+        for (int q = lane; q < nx * GM; q += 64) {
+          int x = q / GM, i = q - x * GM;
+          bool kept = (op0 + x) < K;
+          u32 t = order[op0 + x];
+          int cnt = kept ? ngb : c;
+          BeamSlot* row = beams + (u64)(rfirst + t) * beam;
+          if (i < cnt) {
+            float me = tot[x][i];
+            int rank = 0;
+            for (int jx = 0; jx < cnt; ++jx) {
+              float o = tot[x][jx];
+              if (o > me || (o == me && jx < i)) ++rank;
+            }
+            if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
+          } else if (i < beam) {
+            row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+          }
+          if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
+        }
       }
       wave_sync();
       JPP_PROF(7);

@@ -604,9 +604,11 @@ struct RnnPass {
     for (int b = 3; b < nb; ++b)
       for (const Conn& el : gbeams[b]) {
         Slot& e = beams[el.b][el.r][el.beam];
+        // `localScore += scores.at(i) * scoreWeights.at(i)`: one fused multiply-add per scorer on an FMA
+        // target (GCC contracts it; vfmadd231ss in the reference's -march=haswell/native object code)
         float local = 0.f;
-        local += cell0[el.b][el.r][e.gi] * wPerc;
-        local += cell1[el.b][el.r][e.gi] * wRnn;
+        local = std::fma(cell0[el.b][el.r][e.gi], wPerc, local);
+        local = std::fma(cell1[el.b][el.r][e.gi], wRnn, local);
         local += beams[e.pb][e.pr][e.beam].total;
         e.total = local;
       }
@@ -616,8 +618,8 @@ struct RnnPass {
     for (int i = 0; i < G; ++i) {
       float beamScore = beams[eg[i].b][eg[i].r][eg[i].beam].total;
       float local = 0.f;
-      local += cell0[eos][0][i] * wPerc;
-      local += cell1[eos][0][i] * wRnn;
+      local = std::fma(cell0[eos][0][i], wPerc, local);
+      local = std::fma(cell1[eos][0][i], wRnn, local);
       full[i] = local + beamScore;
     }
     std::vector<u32> idx(G); std::iota(idx.begin(), idx.end(), 0);

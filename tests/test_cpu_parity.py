@@ -207,6 +207,61 @@ def test_result_invalidated_by_next_batch(emu_lib, golden_dir):
         r1.fetch()
 
 
+def test_make_t0_beam_is_a_rank_when_totals_are_distinct(tmp_path):
+    """k_sweep<32,512> 5c / remakeEosBeam fast path: with pairwise distinct totals, util::partition
+    (beyond beam*4/3) followed by std::sort (introsort beyond 16) yields the first `beam` entries of the
+    unique descending order, i.e. the parallel rank.  Checked against the step-by-step replay."""
+    src = tmp_path / 'rank.cc'
+    src.write_text(r'''
+#include <algorithm>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "jpp_select.h"
+int main() {
+  std::mt19937 rng(777);
+  long bad = 0, cases = 0;
+  for (int beam = 1; beam <= 32; ++beam) {
+    const int partB = beam * 4 / 3;
+    for (int cnt = 1; cnt <= 32; ++cnt) {
+      for (int rep = 0; rep < 40; ++rep) {
+        std::vector<float> tot(cnt);
+        for (int i = 0; i < cnt; ++i) tot[i] = (float)i * 0.37f - 3.f;   // distinct
+        std::shuffle(tot.begin(), tot.end(), rng);
+        u8 idx[32];
+        for (int z = 0; z < cnt; ++z) idx[z] = (u8)z;
+        const float* tr = tot.data();
+        auto comp = [tr](u8 a, u8 b) { return tr[a] > tr[b]; };
+        u8* itr = idx + cnt;
+        if (cnt > partB) itr = jpp::jpp_partition(idx, itr, comp, (long)beam, (long)partB);
+        jpp::std_sort(idx, itr, comp);
+        const int have = (int)(itr - idx);
+        // parallel rank
+        std::vector<int> slot(beam, -1);
+        for (int i = 0; i < cnt; ++i) {
+          int rank = 0;
+          for (int j = 0; j < cnt; ++j) if (tot[j] > tot[i] || (tot[j] == tot[i] && j < i)) ++rank;
+          if (rank < beam) slot[rank] = i;
+        }
+        ++cases;
+        for (int z = 0; z < beam; ++z) {
+          int want = z < have ? (int)idx[z] : -1;
+          if (slot[z] != want) { ++bad; break; }
+        }
+      }
+    }
+  }
+  printf("%ld %ld\n", cases, bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / 'rank'
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-DJPP_EMU', '-I', os.path.join(ROOT, 'tests', 'emu'),
+                           '-I', os.path.join(ROOT, 'jumanpp_amd', 'csrc'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) > 30000 and int(out[1]) == 0
+
+
 def test_nth_element_restatement_matches_libstdcxx(tmp_path):
     src = tmp_path / 'sel.cc'
     src.write_text(r'''

@@ -15,13 +15,15 @@ import bench
 import jumanpp_amd as J
 
 lib_path = os.path.join(ROOT, 'build', 'libjppgpu_prof.so')
-args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, sent_len=40, batch=65536, rnn=True,
-                          rnn_hidden=128, rnn_vocab=30000)
+C5 = '--config5' in sys.argv   # BASELINE configs[4] shape: beam 32, 220-codepoint sentences, 4096 per batch
+args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, sent_len=220 if C5 else 40,
+                          batch=4096 if C5 else 65536, rnn=True, rnn_hidden=128, rnn_vocab=30000)
 cache = os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache')
 mdic, model, img = bench.make_workload(args, cache)
-corpus = bench.make_corpus(args, mdic, cache, args.batch * 2, args.seed + 1)
+corpus = bench.make_corpus(args, mdic, cache, args.batch * 2, 31 if C5 else args.seed + 1)
 batches = bench.load_batches(corpus, args.batch, np)
-ctx = J.Context(img, lib_path=lib_path, use_rnn=('--rnn' in sys.argv))
+cfg = dict(beam=32, global_beam=32, right_check=1, right_beam=32) if C5 else {}
+ctx = J.Context(img, lib_path=lib_path, use_rnn=('--rnn' in sys.argv), **cfg)
 lib = ctypes.CDLL(lib_path)
 dev = torch.device('cuda', 0)
 text, offs = batches[0]
