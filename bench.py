@@ -32,25 +32,29 @@ def make_workload(args, cache_dir):
     """synthetic dictionary + random perceptron + corpus, built with the
     reference's own offline tools (oracle/_ref) -- untimed setup."""
     os.makedirs(cache_dir, exist_ok=True)
+    dkey = 'd%d_s%d' % (args.dict_entries, args.seed)
     key = 'd%d_w%d_s%d%s' % (args.dict_entries, args.weights_exp, args.seed, '_rnn%d' % args.rnn_hidden if args.rnn else '')
-    mdic = os.path.join(cache_dir, key + '.mdic')
+    mdic = os.path.join(cache_dir, dkey + '.mdic')
+    seed_model = os.path.join(cache_dir, dkey + '.seed')
     model = os.path.join(cache_dir, key + '.model')
     img = os.path.join(cache_dir, key + '.img')
-    if not os.path.exists(img):
+    if not os.path.exists(seed_model):
         with open(mdic, 'w', encoding='utf-8') as f:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_dict.py'), str(args.dict_entries),
                                    '--seed', str(args.seed)], stdout=f)
-        seed_model = os.path.join(cache_dir, key + '.seed')
-        subprocess.check_call([os.path.join(REF, 'jpp_jumandic_bootstrap'), mdic, seed_model],
+        subprocess.check_call([os.path.join(REF, 'jpp_jumandic_bootstrap'), mdic, seed_model + '.tmp'],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        os.rename(seed_model + '.tmp', seed_model)
+    if not os.path.exists(img):
         subprocess.check_call([os.path.join(REF, 'ref_dump'), 'mkmodel', seed_model, model, str(args.weights_exp),
                                str(args.seed), '0.1'])
         if args.rnn:
             # BASELINE configs[2]: + synthetic faster-rnnlm NCE model embedded by the reference's trainer binary
-            rnn = os.path.join(cache_dir, key + '.rnnlm')
-            subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_rnn.py'), mdic, rnn, '--vocab',
-                                   str(args.rnn_vocab), '--hidden', str(args.rnn_hidden), '--maxent-size',
-                                   str(1 << 22), '--seed', str(args.seed)], stdout=subprocess.DEVNULL)
+            rnn = os.path.join(cache_dir, dkey + '_rnn%d.rnnlm' % args.rnn_hidden)
+            if not os.path.exists(rnn):
+                subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_rnn.py'), mdic, rnn, '--vocab',
+                                       str(args.rnn_vocab), '--hidden', str(args.rnn_hidden), '--maxent-size',
+                                       str(1 << 22), '--seed', str(args.seed)], stdout=subprocess.DEVNULL)
             pmodel = model + '.perceptron'
             os.rename(model, pmodel)
             subprocess.check_call([os.path.join(REF, 'jumanpp_v2_train'), '--model-input=' + pmodel,
@@ -58,7 +62,8 @@ def make_workload(args, cache_dir):
                                    '--rnn-nce-bias=5.62844432562', '--rnn-unk-constant=-3.4748115191',
                                    '--rnn-unk-length=-2.92994951022', '--feature-weight-perceptron=1',
                                    '--feature-weight-rnn=0.0176'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        subprocess.check_call([os.path.join(REF, 'ref_dump'), 'export', model, img], stderr=subprocess.DEVNULL)
+        subprocess.check_call([os.path.join(REF, 'ref_dump'), 'export', model, img + '.tmp'], stderr=subprocess.DEVNULL)
+        os.rename(img + '.tmp', img)
     return mdic, model, img
 
 
@@ -124,22 +129,134 @@ def algorithmic_bytes(res, cfg_beam, cfg_gbeam, rcheck, rbeam, np):
     return dict(t0=int(t0_bytes), sweep=int(sweep.sum()), nodes=N)
 
 
+def _cpu_flags():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('flags'):
+                return set(line.split(':', 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def reference_build():
+    """oracle/_ref is built for haswell-class CPUs (-O3 -march=haswell); oracle/_ref/v4 is the same reference
+    built -O3 -march=x86-64-v4 (AVX-512).  /root/reference is not on the GPU box, so `-march=native` there
+    means: the most specific of the two this host can run."""
+    v4 = os.path.join(REF, 'v4')
+    need = {'avx512f', 'avx512bw', 'avx512vl', 'avx512dq', 'avx512cd'}
+    if os.path.exists(os.path.join(v4, 'ref_dump')) and need <= _cpu_flags():
+        return v4, 'g++ -O3 -march=x86-64-v4'
+    return REF, 'g++ -O3 -march=haswell'
+
+
+def _ref_time(ref_dir, model, corpus):
+    with open(corpus, 'rb') as f:
+        out = subprocess.check_output([os.path.join(ref_dir, 'ref_dump'), 'time', model], stdin=f)
+    return json.loads(out.decode())
+
+
 def cpu_baseline(args, model, mdic, cache_dir):
+    """The real reference (Analyzer::analyze in a loop, oracle/ref_dump.cc `time`) on this box's host cores:
+    one thread on the timed workload (with the RNN), one thread perceptron-only, and every core at once
+    (one process per core -- the reference has no threading)."""
+    ref_dir, flags = reference_build()
     corpus = make_corpus(args, mdic, cache_dir, args.cpu_sample, args.seed + 1000)
     t = time.time()
-    with open(corpus, 'rb') as f:
-        out = subprocess.check_output([os.path.join(REF, 'ref_dump'), 'time', model], stdin=f)
-    r = json.loads(out.decode())
-    return {
+    r = _ref_time(ref_dir, model, corpus)
+    out = {
         'value': round(r['sent_per_s_analyze'], 1),
         'unit': 'sentences/s',
         'cores': 1,
         'kind': 'reference',
         'sample': '%d sentences of the same synthetic workload through the reference Analyzer::analyze '
-                  '(oracle/_ref, g++ -O2 -march=haswell, 1 thread, best of 3; %.1f s wall)'
-                  % (r['sentences'], time.time() - t),
+                  '(oracle/_ref, %s, 1 thread, best of 3; %.1f s wall)'
+                  % (r['sentences'], flags, time.time() - t),
         'with_juman_format': round(r['sent_per_s_total'], 1),
     }
+    pmodel = model + '.perceptron'
+    if args.rnn and os.path.exists(pmodel):
+        rp = _ref_time(ref_dir, pmodel, corpus)
+        out['perceptron_only'] = {'value': round(rp['sent_per_s_analyze'], 1), 'unit': 'sentences/s', 'cores': 1,
+                                  'what': 'same sample, same model without the RNN part (BASELINE configs[0]/[1] scorer)'}
+    # all cores: one process per hardware thread, each analysing the same sample (identical work per process,
+    # so the aggregate is what a split corpus would give); rates are taken while all processes run
+    ncore = os.cpu_count() or 1
+    small = make_corpus(args, mdic, cache_dir, max(2000, args.cpu_sample // 4), args.seed + 1001)
+    t = time.time()
+    procs = []
+    for _ in range(ncore):
+        f = open(small, 'rb')
+        procs.append((subprocess.Popen([os.path.join(ref_dir, 'ref_dump'), 'time', model], stdin=f,
+                                       stdout=subprocess.PIPE), f))
+    agg, nsent = 0.0, 0
+    for pr, f in procs:
+        o, _ = pr.communicate()
+        f.close()
+        if pr.returncode == 0:
+            rr = json.loads(o.decode())
+            agg += rr['sent_per_s_analyze']
+            nsent += rr['sentences'] * 3
+    wall = time.time() - t
+    out['all_cores'] = {'value': round(agg, 1), 'unit': 'sentences/s', 'cores': ncore,
+                        'what': 'one reference process per hardware thread, %d sentences each (3 passes), sum of the '
+                                'per-process rates; %.1f s wall incl. %d model loads (wall-clock rate %.0f/s)'
+                                % (nsent // (3 * max(1, ncore)), wall, ncore, nsent / wall)}
+    return out
+
+
+def realism_legs(args, cache, local_rank, np, torch, J):
+    """Extra legs beside the headline (never `value`): the same step on (i) a 1M-entry dictionary, (ii) weight
+    tables of 2^24 (64 MB: beyond the aggregate L2) and 2^26 floats (256 MB: the size of the Infinity Cache),
+    so the gathers of k_t0 / k_sweep leave the caches the headline's 16 MB table lives in."""
+    import copy
+    legs = {}
+    dev = torch.device('cuda', local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, over in (('dict_1m', {'dict_entries': 1000000}), ('weights_2e24', {'weights_exp': 24}),
+                       ('weights_2e26', {'weights_exp': 26})):
+        try:
+            a = copy.copy(args)
+            for k, v in over.items():
+                setattr(a, k, v)
+            t = time.time()
+            mdic, model, img = make_workload(a, cache)
+            corpus = make_corpus(a, mdic, cache, args.batch * 2, a.seed + 1 + a.dict_entries % 7)
+            batches = load_batches(corpus, args.batch, np)
+            setup_s = time.time() - t
+            ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank,
+                            use_rnn=None if args.rnn else False)
+            d = [(torch.frombuffer(bytearray(tx), dtype=torch.uint8).to(dev),
+                  torch.from_numpy(of.astype(np.int32)).to(dev), len(of) - 1, len(tx)) for tx, of in batches]
+
+            def run(i):
+                tt, oo, n, nbytes = d[i % len(d)]
+                return ctx.analyze_device(tt.data_ptr(), oo.data_ptr(), n, nbytes, stream)
+            run(0).release()
+            torch.cuda.synchronize()
+            k = 4
+            km = {}
+            t0 = time.perf_counter()
+            for i in range(k):
+                r = run(1 + i)
+                torch.cuda.synchronize()
+                for kk, v in ctx.timings().items():
+                    km[kk] = km.get(kk, 0.0) + v
+                r.release()
+            el = time.perf_counter() - t0
+            r = run(0).fetch()
+            legs[name] = {'value': round(args.batch * k / el, 1), 'unit': 'sentences/s', 'steps': k,
+                          'ms_per_step': round(el / k * 1e3, 3),
+                          'nodes_per_sentence': round(float(r.nnodes.sum()) / args.batch, 1),
+                          'failed_sentences_in_batch': int((r.status != 0).sum()),
+                          'kernel_ms_per_step': {kk: round(v / k, 3) for kk, v in km.items()},
+                          'dict_entries': a.dict_entries, 'weights_exp': a.weights_exp, 'setup_s': round(setup_s, 1)}
+            r.release()
+            del ctx, d
+            torch.cuda.empty_cache()
+        except Exception as e:  # an extra leg must never take the main line down
+            legs[name] = {'error': str(e)[:200]}
+    return legs
 
 
 def main():
@@ -155,6 +272,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='skip the extra two-batches-in-flight measurement')
+    ap.add_argument('--no-realism', action='store_true',
+                    help='skip the extra workload legs (1M-entry dictionary, 2^24 and 2^26 weights; SURVEY 8(d))')
     ap.add_argument('--rnn', dest='rnn', action='store_true', default=True,
                     help='BASELINE configs[2] (default; the metric is quoted on jumandic+RNNLM): perceptron + RNNLM re-ranker')
     ap.add_argument('--no-rnn', dest='rnn', action='store_false', help='BASELINE configs[1]: perceptron only')
@@ -376,6 +495,8 @@ def main():
             out['perceptron_only'] = perceptron_only
         if overlapped is not None:
             out['overlapped_two_streams'] = overlapped
+        if not args.no_realism and world == 1:
+            out['realism'] = realism_legs(args, cache, local_rank, np, torch, J)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
         print(json.dumps(out, ensure_ascii=False), flush=True)

@@ -26,7 +26,22 @@ typedef uint64_t u64;
 typedef int32_t i32;
 typedef int64_t i64;
 
+// Pointers read out of a structure in memory (DevModel) are generic to the compiler, and loads through
+// them become flat_load: those tick the LDS counter as well as the vector-memory counter, so every wait for
+// an LDS read behind a weight gather would also wait for the gather's HBM round trip.  The model tables are
+// re-typed as global (address space 1) where the hot kernels pick them up.
+#if defined(JPP_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#define JPP_GLOBAL
+#else
+#define JPP_GLOBAL __attribute__((address_space(1)))
+#endif
+
 namespace jpp {
+
+template <typename T>
+__device__ __forceinline__ const T JPP_GLOBAL* as_global(const T* p) {
+  return (const T JPP_GLOBAL*)p;
+}
 
 // ---- wavefront (64 lanes) helpers -------------------------------------------
 __device__ __forceinline__ int lane_id() {

@@ -694,6 +694,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
   if (ctx->cfg.gbeam == 0) {
     JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else if (narrow && maxR <= 64 && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5) {
+    JPP_LAUNCH((k_sweep<8, 64, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);   // the CLI defaults
   } else if (narrow && maxR <= 64 && ctx->cfg.rcheck <= 2) {
     JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow) {

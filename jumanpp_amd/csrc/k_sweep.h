@@ -98,6 +98,9 @@ __device__ unsigned long long g_sweep_prof[16];
 #ifndef JPP_SWEEP_WAVES
 #define JPP_SWEEP_WAVES 4
 #endif
+#ifndef JPP_SWEEP_HEADWAIT
+#define JPP_SWEEP_HEADWAIT 0
+#endif
 constexpr int kChunk = 8;       // right nodes processed per pass (= 8-lane groups per wave)
 constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
@@ -123,7 +126,7 @@ struct LaneBi {
 // weights of this lane's bigram features for one (right node, T1 row) pair, from the cached first-stage
 // states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
 __device__ __forceinline__ void bi_gather_s1(const LaneBi& t, int j, const u64* s1, const u64* t1r,
-                                             const float* __restrict__ W, u32 wmask, bool act, float* w) {
+                                             const float JPP_GLOBAL* __restrict__ W, u32 wmask, bool act, float* w) {
   u32 idx[kBiPerLane];
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
@@ -252,7 +255,10 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // The workgroup is one wavefront: the phases are separated by wave_sync() (compiler + LDS ordering only).
 // A __syncthreads() would additionally drain the vector-memory counter, i.e. wait for every outstanding
 // global store (beams, cells) ~12 times per boundary.
-template <int GM, int RM>
+// DEF: the configuration is the CLI default (beam 5, global beam 6, right-check 1, right-beam 5,
+// jumanpp_args.h:50-54): the four numbers become compile-time constants (no runtime divisions by the beam
+// size, fixed trip counts); any other configuration runs the same code with the values read from `cfg`.
+template <int GM, int RM, bool DEF = false>
 __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
@@ -262,9 +268,12 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   const u32 bb0 = off + 4 * s;
   const u32 n = B.sent_ncp[s];
   const u64 nb = B.node_base[s];
-  const int beam = cfg.beam;
-  const int G = cfg.gbeam;
-  const float* __restrict__ W = M.weights;
+  static_assert(!DEF || GM >= 6, "default configuration needs a global beam of 6");
+  const int beam = DEF ? 5 : cfg.beam;
+  const int G = DEF ? 6 : cfg.gbeam;
+  const int rcheck = DEF ? 1 : cfg.rcheck;
+  const int rbeam = DEF ? 5 : cfg.rbeam;
+  const float JPP_GLOBAL* __restrict__ W = as_global(M.weights);
   const u32 wmask = M.wmask;
   const u32* en = B.end_nodes + nb;
   BeamSlot* beams = B.node_beam + nb * beam;
@@ -414,9 +423,15 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   u32 bn = next_nonempty(2);
   int par = 0;
   prefetch(bn, par);
+  lds_async_wait();
   for (u32 b = bn; b <= n + 2; b = bn, par ^= 1) {
-    // the records / rows requested during the previous boundary (or above) are needed from here on
+    // The records / rows requested during the previous boundary are needed from here on.  They were
+    // requested before that boundary's candidate slots / pattern rows, and vector memory operations complete
+    // in order, so the waits of phases 1-2 have covered them: no wait here -- it would only drain the beam
+    // and cell stores the previous boundary has just issued (every path that skips those phases waits itself).
+#if JPP_SWEEP_HEADWAIT
     lds_async_wait();
+#endif
     wave_sync();
     const BndMeta mb = metaAt(b);
     const u32 R = mb.cnt;
@@ -536,6 +551,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
           }
         }
       } else {
+        lds_async_wait();
         for (int r = 0; r < G; ++r) {
           u64 best = 0;
           for (u32 q = lane; q < ncand; q += 64) {
@@ -583,6 +599,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         beams[(u64)rfirst * beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
       }
       for (u32 q = lane; q < R; q += 64) B.node_kept[nb + rfirst + q] = 0;
+      lds_async_wait();
       wave_sync();
       continue;
     }
@@ -626,7 +643,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 
     JPP_PROF(2);
     // ---- 3. prescores for the first c gbeam entries over all right nodes ----
-    int c = cfg.rcheck;
+    int c = rcheck;
     if (c > (int)R) c = (int)R;
     if (c > ngb) c = ngb;
     if ((u32)c * R > (u32)(2 * RM)) {
@@ -678,9 +695,9 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 
     JPP_PROF(3);
     // ---- 4. right-node cutoff (std::nth_element semantics) ----
-    const u32 K = (cfg.rcheck > 0) ? ((u32)cfg.rbeam < R ? (u32)cfg.rbeam : R) : R;
+    const u32 K = (rcheck > 0) ? ((u32)rbeam < R ? (u32)rbeam : R) : R;
     for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
-    if (cfg.rcheck > 0 && R > (u32)cfg.rbeam) {
+    if (rcheck > 0 && R > (u32)rbeam) {
       for (u32 t = lane; t < R; t += 64) {
         float sc = 0.f;
         for (int i = 0; i < c; ++i) sc += pres[i * R + t];
@@ -700,14 +717,14 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         order[rank] = (u16)t;
       }
       wave_sync();
-      const bool tieAtCut = csum[order[cfg.rbeam - 1]] == csum[order[cfg.rbeam]];
+      const bool tieAtCut = csum[order[rbeam - 1]] == csum[order[rbeam]];
       wave_sync();
       if (tieAtCut) {
         for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
         wave_sync();
         if (lane == 0) {
           ScoreGreater cmp{csum};
-          nth_element_u16(order, order + cfg.rbeam, order + R, cmp);
+          nth_element_u16(order, order + rbeam, order + R, cmp);
         }
       }
     }

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
   const u32 n = B.sent_ncp[s];
   const u64 nb = B.node_base[s];
   const int beam = cfg.beam;
-  const float* __restrict__ W = M.weights;
+  const float JPP_GLOBAL* __restrict__ W = as_global(M.weights);
   const u32 wmask = M.wmask;
   const u32* en = B.end_nodes + nb;
   BeamSlot* beams = B.node_beam + nb * beam;

@@ -155,7 +155,7 @@ __global__ void k_t0(Batch B, const DevModel* __restrict__ Mp) {
 #pragma unroll
     for (int u = 0; u < spec::kNumUni; ++u) {
       u32 idx = (u32)hmix(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0]) & M.wmask;
-      w[u] = M.weights[idx];
+      w[u] = as_global(M.weights)[idx];
     }
     float part[4];
     if (isLast) {
