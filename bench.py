@@ -139,6 +139,30 @@ def _cpu_flags():
     return set()
 
 
+def usable_cores():
+    """hardware threads this process may really use: affinity mask and cgroup CPU quota, not just what is visible"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def reference_build():
     """oracle/_ref is built for haswell-class CPUs (-O3 -march=haswell); oracle/_ref/v4 is the same reference
     built -O3 -march=x86-64-v4 (AVX-512).  /root/reference is not on the GPU box, so `-march=native` there
@@ -181,7 +205,7 @@ def cpu_baseline(args, model, mdic, cache_dir):
                                   'what': 'same sample, same model without the RNN part (BASELINE configs[0]/[1] scorer)'}
     # all cores: one process per hardware thread, each analysing the same sample (identical work per process,
     # so the aggregate is what a split corpus would give); rates are taken while all processes run
-    ncore = os.cpu_count() or 1
+    ncore = usable_cores()
     small = make_corpus(args, mdic, cache_dir, max(2000, args.cpu_sample // 4), args.seed + 1001)
     t = time.time()
     procs = []
@@ -198,7 +222,7 @@ def cpu_baseline(args, model, mdic, cache_dir):
             agg += rr['sent_per_s_analyze']
             nsent += rr['sentences'] * 3
     wall = time.time() - t
-    out['all_cores'] = {'value': round(agg, 1), 'unit': 'sentences/s', 'cores': ncore,
+    out['all_cores'] = {'value': round(agg, 1), 'unit': 'sentences/s', 'cores': ncore, 'visible_cpus': os.cpu_count(),
                         'what': 'one reference process per hardware thread, %d sentences each (3 passes), sum of the '
                                 'per-process rates; %.1f s wall incl. %d model loads (wall-clock rate %.0f/s)'
                                 % (nsent // (3 * max(1, ncore)), wall, ncore, nsent / wall)}

@@ -1,0 +1,41 @@
+// DEVELOPER BUILDS ONLY (-DJPP_DEV_PROF): per-phase cycle counters of k_sweep and k_rnn_score.
+// Lane 0 of every wavefront adds the s_memtime cycles it spent per phase to g_sweep_prof[]; read with
+// the debug entry point jppgpu_debug_sweep_prof (tools/gpu_sweep_phases.py).  The shipped library is
+// built without this header: the JPP_PROF* / JPP_RPROF* macros are then empty (jpp_rt.h).
+#ifndef JPP_DEV_PROF_H
+#define JPP_DEV_PROF_H
+__device__ unsigned long long g_sweep_prof[16];
+__device__ unsigned long long g_rnn_cnt[2];
+#define JPP_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define JPP_PROF(i)                                          \
+  do {                                                       \
+    unsigned long long now_ = __builtin_readcyclecounter();  \
+    prof_acc[i] += now_ - prof_t;                            \
+    prof_t = now_;                                           \
+  } while (0)
+#define JPP_PROF_FLUSH                                                                 \
+  do {                                                                                 \
+    if (lane == 0)                                                                     \
+      for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_sweep_prof[q_], prof_acc[q_]);       \
+  } while (0)
+#define JPP_RPROF_DECL unsigned long long rprof_t = __builtin_readcyclecounter(), rprof_acc[6] = {0, 0, 0, 0, 0, 0}; \
+  const unsigned long long rprof_start = rprof_t; \
+  unsigned long long rprof_pass = 0, rprof_nodes = 0
+#define JPP_RPROF(i)                                         \
+  do {                                                       \
+    unsigned long long now_ = __builtin_readcyclecounter();  \
+    rprof_acc[i] += now_ - rprof_t;                          \
+    rprof_t = now_;                                          \
+  } while (0)
+#define JPP_RPROF_COUNT(cn) do { if (lane == 0) { rprof_pass += 1; rprof_nodes += (unsigned long long)(cn); } } while (0)
+#define JPP_RPROF_FLUSH                                                                    \
+  do {                                                                                     \
+    if (lane == 0) {                                                                       \
+      for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_sweep_prof[8 + q_], rprof_acc[q_]);      \
+      atomicAdd(&g_sweep_prof[14], __builtin_readcyclecounter() - rprof_start);            \
+      atomicAdd(&g_sweep_prof[15], 1ull);                                                  \
+      atomicAdd(&g_rnn_cnt[0], rprof_pass);                                                \
+      atomicAdd(&g_rnn_cnt[1], rprof_nodes);                                               \
+    }                                                                                      \
+  } while (0)
+#endif  // JPP_DEV_PROF_H

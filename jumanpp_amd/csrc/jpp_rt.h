@@ -19,6 +19,19 @@ typedef hipStream_t jpp_stream_t;
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
 
+// developer phase timers: real only in a -DJPP_DEV_PROF build of the HIP library (dev/jpp_dev_prof.h)
+#if defined(JPP_DEV_PROF) && !defined(JPP_EMU)
+#include "dev/jpp_dev_prof.h"
+#else
+#define JPP_PROF_DECL
+#define JPP_PROF(i)
+#define JPP_PROF_FLUSH
+#define JPP_RPROF_DECL
+#define JPP_RPROF(i)
+#define JPP_RPROF_COUNT(cn)
+#define JPP_RPROF_FLUSH
+#endif
+
 typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;

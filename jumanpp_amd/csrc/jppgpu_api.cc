@@ -34,6 +34,15 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+// HIP's current device is a property of the calling host thread.  A process may hold contexts on several
+// GPUs (jumanpp_gpu --devices=...) and drive them from several threads, so every entry point that touches
+// the device first binds the thread to its context's GPU.
+#if defined(JPP_EMU)
+inline void bind_device(int) {}
+#else
+inline void bind_device(int device) { (void)hipSetDevice(device); }
+#endif
+
 // ---- thin device-memory layer ------------------------------------------------
 #if defined(JPP_EMU)
 bool rt_ok(int) { return true; }
@@ -517,6 +526,7 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
 
 extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   if (!ctx) return;
+  bind_device(ctx->device);
   DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
                     &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
                     &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
@@ -541,6 +551,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
 extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                            uint32_t total_bytes, void* stream_, jppgpu_result** out) {
   if (!ctx || !out || (!d_utf8 && total_bytes) || !d_offsets) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  bind_device(ctx->device);
   jpp_stream_t st = static_cast<jpp_stream_t>(stream_);
   *out = nullptr;
   const size_t cpN = (size_t)total_bytes + n + 8;
@@ -737,6 +748,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
 extern "C" int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
                                     jppgpu_result** out) {
   if (!ctx || !offsets || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  bind_device(ctx->device);
   u32 total = offsets[n];
   if (!(ctx->text.ensure((size_t)total + 64) && ctx->offs.ensure(((size_t)n + 1) * 4)))
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (input)");
@@ -751,6 +763,7 @@ extern "C" int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, c
   if (!ctx || !offsets || !out || !p) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   if (!p->nobreak_offsets || !p->boundary_offsets || !p->node_offsets)
     return fail(JPPGPU_INVALID_PARAMETER, "partial annotation offsets are null");
+  bind_device(ctx->device);
   static_assert(sizeof(jppgpu_node_constraint) == sizeof(PcNode) && sizeof(jppgpu_tag_constraint) == sizeof(PcTag),
                 "ABI and device constraint records must match");
   const size_t nNb = p->nobreak_offsets[n], nB = p->boundary_offsets[n], nNodes = p->node_offsets[n];
@@ -779,31 +792,25 @@ extern "C" int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, c
   return rc;
 }
 
-#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
-extern "C" int jppgpu_debug_sweep_dbg(unsigned long long* out16) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out16, HIP_SYMBOL(jpp::g_sweep_dbg), 16 * sizeof(unsigned long long));
-  return 0;
-}
-#endif
-#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
-// developer build only: cycles per k_sweep phase accumulated since the last call (then reset)
+#if defined(JPP_DEV_PROF) && !defined(JPP_EMU)
+// developer build only (dev/jpp_dev_prof.h): cycles per k_sweep phase accumulated since the last call (then reset)
 extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out16, HIP_SYMBOL(jpp::g_sweep_prof), 16 * sizeof(unsigned long long));
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sweep_prof), 16 * sizeof(unsigned long long));
   unsigned long long rc[2] = {0, 0};
   hipMemcpyFromSymbol(rc, HIP_SYMBOL(g_rnn_cnt), sizeof(rc));
   if (rc[0]) std::fprintf(stderr, "[jppgpu prof] rnn passes %llu nodes %llu (%.2f nodes per pass)\n", rc[0], rc[1], (double)rc[1] / (double)rc[0]);
   unsigned long long z2[2] = {0, 0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_cnt), z2, sizeof(z2));
   unsigned long long z[16] = {};
-  hipMemcpyToSymbol(HIP_SYMBOL(jpp::g_sweep_prof), z, sizeof(z));
+  hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_prof), z, sizeof(z));
   return 0;
 }
 #endif
 
 extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
   if (!ctx || !ms) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  bind_device(ctx->device);
   if (ctx->timing_pending) {
     rt_sync(ctx->last_stream);
     ctx->timer.collect(ctx->last_ms);
@@ -830,6 +837,7 @@ void pull(std::vector<T>& v, const void* d, size_t count, jpp_stream_t st) {
 extern "C" int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path) {
   if (!res || !res->ctx) return fail(JPPGPU_INVALID_PARAMETER, "null result");
   if (res->generation != res->ctx->generation) return fail(JPPGPU_INVALID_STATE, "result was invalidated");
+  bind_device(res->ctx->device);
   jpp_stream_t st = res->ctx->last_stream;
   std::vector<u32> pl;
   pull(pl, res->B.path_len, res->B.n_sent, st);
@@ -845,6 +853,7 @@ extern "C" int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_i
   if (!res || !res->ctx || !d_offsets || (!d_items && cap_items)) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   jppgpu_ctx* ctx = res->ctx;
   if (res->generation != ctx->generation) return fail(JPPGPU_INVALID_STATE, "result was invalidated");
+  bind_device(ctx->device);
   const Batch& B = res->B;
   const u32 n = B.n_sent;
   if (!(ctx->pack_cnt.ensure(((size_t)n + 1) * 4) && ctx->pack_off.ensure(((size_t)n + 2) * 8)))
@@ -863,6 +872,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   jppgpu_ctx* ctx = res->ctx;
   if (res->generation != ctx->generation)
     return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+  bind_device(ctx->device);
   jpp_stream_t st = ctx->last_stream;
   const Batch& B = res->B;
   const u32 n = B.n_sent;
@@ -998,6 +1008,7 @@ extern "C" int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jpp
   if (n_best <= 0 || n_best > 64) return fail(JPPGPU_INVALID_PARAMETER, "n_best must be in 1..64");
   static_assert(sizeof(jppgpu_nbest_item) == sizeof(NbestItem), "nbest item layout");
   jppgpu_ctx* ctx = res->ctx;
+  bind_device(ctx->device);
   const Batch& B = res->B;
   const u32 n = B.n_sent;
   if (res->nb_n != n_best) {

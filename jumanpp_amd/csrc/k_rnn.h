@@ -35,36 +35,6 @@
 #include "k_lattice.h"
 #include "k_sweep.h"
 
-#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
-__device__ unsigned long long g_rnn_cnt[2];
-#define JPP_RPROF_DECL unsigned long long rprof_t = __builtin_readcyclecounter(), rprof_acc[6] = {0, 0, 0, 0, 0, 0}; \
-  const unsigned long long rprof_start = rprof_t; \
-  unsigned long long rprof_pass = 0, rprof_nodes = 0
-#define JPP_RPROF(i)                                         \
-  do {                                                       \
-    unsigned long long now_ = __builtin_readcyclecounter();  \
-    rprof_acc[i] += now_ - rprof_t;                          \
-    rprof_t = now_;                                          \
-  } while (0)
-#define JPP_RPROF_FLUSH                                                                    \
-  do {                                                                                     \
-    if (lane == 0) {                                                                       \
-      for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_sweep_prof[8 + q_], rprof_acc[q_]);      \
-      atomicAdd(&g_sweep_prof[14], __builtin_readcyclecounter() - rprof_start);            \
-      atomicAdd(&g_sweep_prof[15], 1ull);                                                  \
-      atomicAdd(&g_rnn_cnt[0], rprof_pass);                                                \
-      atomicAdd(&g_rnn_cnt[1], rprof_nodes);                                               \
-    }                                                                                      \
-  } while (0)
-#else
-#define JPP_RPROF_DECL
-#define JPP_RPROF(i)
-#define JPP_RPROF_FLUSH
-#endif
-
-#ifndef JPP_RNN_EXP
-#define JPP_RNN_EXP 0   // developer timing experiments only (1: no matvec, 2: no embedding-row misses)
-#endif
 
 namespace jpp {
 
@@ -212,9 +182,6 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
     }
   }
   wave_sync();
-#if JPP_RNN_EXP == 11
-  return;
-#endif
   // ---- B. word ids of the connections ----
   // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the
   // first path that passes through it, and copied to the others.
@@ -249,9 +216,6 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       }
     }
   }
-#if JPP_RNN_EXP == 12
-  return;
-#endif
   // BOS node (boundary 1): RnnIdContainer::addBos
   if (lane == 0) {
     rn_cnt[1] = 1;
@@ -328,9 +292,6 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       wave_sync();
     }
   }
-#if JPP_RNN_EXP == 13
-  return;
-#endif
   // gbeam index of every connection (= which score cell of the node it owns); published in the word-id
   // scratch, which is no longer needed
   wave_sync();
@@ -497,7 +458,7 @@ __device__ __forceinline__ void rnn_matvec_any(const float* __restrict__ Wt, con
 // (word, history) pair; the caller adds w[0] + w[1] + ... left to right.  Every history slot holds
 // prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is
 // base + (prevId + 1) * coef[i].
-__device__ __forceinline__ void rnn_maxent_gather(const float* __restrict__ maxentT, i32 myid, i32 pid, u32 order, u64 mxBase,
+__device__ __forceinline__ void rnn_maxent_gather(const float JPP_GLOBAL* __restrict__ maxentT, i32 myid, i32 pid, u32 order, u64 mxBase,
                                                   const u64 (&mxCoef)[4], u64 hashMax, u64 hashMagic, float (&w)[4]) {
 #pragma unroll
   for (u32 i = 0; i < 4; ++i) {
@@ -514,6 +475,36 @@ __device__ __forceinline__ void rnn_maxent_gather(const float* __restrict__ maxe
   }
 }
 
+// MikolovRnnImplParallel::computeContextScores (mikolov_rnn_impl.h:216-223): the element-wise products of
+// the NCE row and the context, each rounded to float, added one after the other for k ascending from 0 --
+// the order the oracle build's plain loop over `cwiseProduct(...).colwise().sum()` has.  One lane per rnn
+// node; the chain is sequential by definition, the loads run ahead of it.
+__device__ __forceinline__ float rnn_dot_seq(const float JPP_GLOBAL* __restrict__ nce, const float* __restrict__ ctx, u32 E) {
+  float s = 0.f;
+  u32 k = 0;
+  if ((E & 3u) == 0 && ((size_t)nce & 15u) == 0 && ((size_t)ctx & 15u) == 0) {
+    struct alignas(16) F4 {
+      float v[4];
+    };
+    const F4 JPP_GLOBAL* a4 = (const F4 JPP_GLOBAL*)nce;
+    const F4* c4 = reinterpret_cast<const F4*>(ctx);
+#pragma unroll 4
+    for (; k + 4 <= E; k += 4) {
+      const F4 a = a4[k >> 2], c = c4[k >> 2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float pr = a.v[t] * c.v[t];
+        s += pr;
+      }
+    }
+  }
+  for (; k < E; ++k) {
+    const float pr = nce[k] * ctx[k];
+    s += pr;
+  }
+  return s;
+}
+
 // WLDS: the padded transposed recurrent matrix lives in LDS and is shared by the 16 wavefronts
 // of the workgroup; otherwise (E > 128) W is streamed from L2.
 // SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
@@ -525,10 +516,12 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   __shared__ float s_W[WLDS ? EP * EP : 1];
+  __shared__ u64 s_exptab[kExp2fN];   // 2^(i/32) table of expf_libm: lanes index it divergently
+  if (threadIdx.x < (u32)kExp2fN) s_exptab[threadIdx.x] = exp2f_tab((int)threadIdx.x);
   if (WLDS) {
     for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[rnn_w2_index<(J <= 2 ? J : 1)>(q / EP, q % EP)] = M.rnn_wt[q];
-    __syncthreads();
   }
+  __syncthreads();
   const float* __restrict__ Wt = WLDS ? s_W : M.rnn_wt;
   const u32 s = blockIdx.x * kWaves + wv;
   if (s >= B.n_sent) return;
@@ -548,9 +541,9 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   const u32 E = M.rnn_E;
   // model scalars and table pointers, read once: going through `M` inside the loops makes the compiler
   // re-issue the scalar loads after every store (it cannot prove the header is not aliased)
-  const float* __restrict__ embT = M.rnn_emb;
-  const float* __restrict__ nceT = M.rnn_nce;
-  const float* __restrict__ maxentT = M.rnn_maxent;
+  const float JPP_GLOBAL* __restrict__ embT = as_global(M.rnn_emb);
+  const float JPP_GLOBAL* __restrict__ nceT = as_global(M.rnn_nce);
+  const float JPP_GLOBAL* __restrict__ maxentT = as_global(M.rnn_maxent);
   const u32 mxOrder = M.rnn_order;
   const u64 hashMax = M.rnn_hash_max, hashMagic = M.rnn_hash_magic, mxBase = M.rnn_mx_base;
   const u64 mxCoef[4] = {M.rnn_mx_coef[0], M.rnn_mx_coef[1], M.rnn_mx_coef[2], M.rnn_mx_coef[3]};
@@ -576,6 +569,9 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   constexpr u32 kPassCap = 2 * kCapB;
   __shared__ u16 l_pass_all[kWaves][kPassCap];
   __shared__ u32 l_npass_all[kWaves];
+  constexpr u32 kNodeCap = 96;
+  __shared__ u16 l_node_all[kWaves][kNodeCap];   // rnn nodes (boundary * G + index) in boundary order
+  __shared__ u32 l_nnode_all[kWaves];
   __shared__ float nscore_all[kWaves][kMaxGbeam];
   __shared__ float full_all[kWaves][kMaxGbeam];
   __shared__ float prev_total_all[kWaves][kMaxGbeam];
@@ -583,10 +579,14 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   float* full = full_all[wv];
   float* prev_total = prev_total_all[wv];
   const u32 nq = (bE + 1) * (u32)G;
-  const bool inLds = nq <= kCap && (bE + 1) <= kCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kCapB && G <= 32 && beam <= 64 && N <= 65535;
   const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
   const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
   const u32* rn_cnt = B.rnn_cnt + bb0;
+  bool inLds = nq <= kCap && (bE + 1) <= kCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kCapB && G <= 32 && beam <= 64 && N <= 65535;
+  if (inLds) {  // ... and the rnn nodes fit the node list (bE + 1 <= 64: one boundary per lane)
+    const u32 mine = ((u32)lane >= 2 && (u32)lane <= bE) ? rn_cnt[lane] : 0u;
+    inLds = wave_sum_u32(mine) <= kNodeCap;
+  }
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {
       l_prev_all[wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
@@ -616,15 +616,17 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     float v = 0.f;
     if (i < E) {
       float x = 0.f + embT[i];
-      v = 1.0f / (1.0f + expf(-x));
+      v = sigmoid_ref(x, s_exptab);
     }
     rn_ctx[(u64)1 * G * EP + i] = v;
   }
   wave_sync();
   if (inLds) {
-    // Every word id is known before the recurrence starts, so everything that depends on ids only is
-    // taken off the serial chain: the maxent sums of all rnn nodes are computed here, one lane per node,
-    // and the embedding / NCE rows of pass i+1 are requested while pass i runs its matvec.
+    // Every word id is known before the recurrence starts, so everything that does not feed the next
+    // context is taken off the serial chain.  Prologue: the maxent sums of all rnn nodes, one lane per
+    // node, the pass list and the node list.  Chain: context -> matvec -> sigmoid -> store, nothing else.
+    // Epilogue: the NCE dot products and scores, one lane per rnn node (the contexts are all in HBM/L2 by
+    // then), the score cells, and adjustBeamScores along the paths.
     float* l_mx = l_mx_all[wv];
     const u16* l_prev = l_prev_all[wv];
     const u8* l_cnt = l_cnt_all[wv];
@@ -644,17 +646,19 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
 #pragma unroll
       for (u32 r = 0; r < kRounds; ++r) {
         const u32 q = (u32)lane + 64u * r;
-        float me = mw[r][0];
+        float me = mw[r][0];   // calcScoresN: w0 + w1 + ... left to right
 #pragma unroll
         for (u32 i = 1; i < 4; ++i)
           if (i < mxOrder) me += mw[r][i];
         if (q < nq) l_mx[q] = me;
       }
     }
-    // pass list: boundary | first node << 6 | (nodes - 1) << 11 | last pass of the boundary << 13
+    // pass list: boundary | first node << 6 | (nodes - 1) << 11 | last pass of the boundary << 13;
+    // node list: q = boundary * G + index of every rnn node, in boundary order
     u16* l_pass = l_pass_all[wv];
+    u16* l_node = l_node_all[wv];
     {
-      // lane b lists the passes of boundary b (bE + 1 <= kCapB <= 64) at the offset an exclusive scan gives it
+      // lane b lists the passes / nodes of boundary b (bE + 1 <= kCapB <= 64) at the offsets exclusive scans give it
       const u32 bq = (u32)lane;
       const u32 cnt = (bq >= 2 && bq <= bE) ? l_cnt[bq] : 0u;
       const u32 mine = (cnt + kRnnCN - 1) / kRnnCN;
@@ -664,20 +668,26 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         const u32 cn = (cnt - c0) < (u32)kRnnCN ? (cnt - c0) : (u32)kRnnCN;
         l_pass[np++] = (u16)(bq | (c0 << 6) | ((cn - 1) << 11) | ((c0 + kRnnCN >= cnt ? 1u : 0u) << 13));
       }
-      if (lane == 63) l_npass_all[wv] = incl;
+      const u32 inclN = wave_scan_incl_u32(cnt, lane);
+      u32 nn = inclN - cnt;
+      for (u32 i = 0; i < cnt; ++i) l_node[nn++] = (u16)(bq * (u32)G + i);
+      if (lane == 63) {
+        l_npass_all[wv] = incl;
+        l_nnode_all[wv] = inclN;
+      }
     }
     wave_sync();
     const u32 npass = l_npass_all[wv];
+    const u32 nnode = l_nnode_all[wv];
     JPP_RPROF(1);
-    float nceR[kRnnCN][J], embR[kRnnCN][J];   // rows of the current pass
+    float embR[kRnnCN][J];                    // embedding rows of the current pass
     float lastOut[kRnnCN][J];                 // contexts produced by the previous pass, kept in registers
     u32 lastBase = 0xffffffffu, lastCn = 0;
 #pragma unroll
     for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
-      for (int j = 0; j < J; ++j) nceR[p][j] = embR[p][j] = lastOut[p][j] = 0.f;
-    // NCE rows (consumed by the dot product) / embedding rows (consumed after the matvec) of one pass
-    auto load_rows = [&](u32 pe, const float* __restrict__ table, bool wanted, float (&out)[kRnnCN][J]) {
+      for (int j = 0; j < J; ++j) embR[p][j] = lastOut[p][j] = 0.f;
+    auto load_rows = [&](u32 pe, const float JPP_GLOBAL* __restrict__ table, bool wanted, float (&out)[kRnnCN][J]) {
       const u32 b = pe & 63u, c0 = (pe >> 6) & 31u, cn = ((pe >> 11) & 3u) + 1;
 #pragma unroll
       for (int p = 0; p < kRnnCN; ++p) {
@@ -692,17 +702,13 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         }
       }
     };
-    if (npass) load_rows(l_pass[0], nceT, true, nceR);
     for (u32 pi = 0; pi < npass; ++pi) {
       const u32 pe = l_pass[pi];
       const u32 b = pe & 63u, c0 = (pe >> 6) & 31u;
       const int cn = (int)((pe >> 11) & 3u) + 1;
-      const bool lastOfBnd = ((pe >> 13) & 1u) != 0;
+      if (b >= bE) break;   // the EOS nodes are only scored; passes are in boundary order, so nothing follows
       // contexts of the predecessors: straight from the registers when the previous pass made them,
-      // otherwise from HBM/L2 (written at least one boundary, i.e. one wave_sync, ago).  Load order
-      // matters because loads return in order: contexts first, then this pass's embedding rows (needed
-      // only after the matvec); the NCE rows of the next pass go out after the dot product, so they
-      // travel during the matvec and nothing on the chain ever waits for a table row.
+      // otherwise from HBM/L2 (written at least one boundary, i.e. one wave_sync, ago)
       float ctx[kRnnCN][J];
 #pragma unroll
       for (int p = 0; p < kRnnCN; ++p) {
@@ -722,33 +728,10 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
           }
         }
       }
-      load_rows(pe, embT, b < bE, embR);
-#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
-      if (lane == 0) { rprof_pass += 1; rprof_nodes += (unsigned long long)cn; }
-#endif
-      float dot[kRnnCN];
-#pragma unroll
-      for (int p = 0; p < kRnnCN; ++p) {
-        dot[p] = 0.f;
-        if (p < cn) {
-#pragma unroll
-          for (int j = 0; j < J; ++j) dot[p] += nceR[p][j] * ctx[p][j];
-          dot[p] = wave_sum_f32(dot[p]);
-        }
-      }
-      if (lane < cn) {  // score of rnn node c0 + x on lane x
-        const int x = lane;
-        float score = x == 0 ? dot[0] : x == 1 ? dot[1] : x == 2 ? dot[2] : dot[3];
-        const i32 id = rn_id[b * (u32)G + c0 + x];
-        if (mxOrder > 0) score += l_mx[b * (u32)G + c0 + x];
-        else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
-        score -= nceConst;
-        if (id == unkId) score = unkConst + unkLen * (float)g_len[(u64)b * G + c0 + x];
-        nscore[c0 + x] = score;
-      }
-      if (pi + 1 < npass) load_rows(l_pass[pi + 1], nceT, true, nceR);
+      load_rows(pe, embT, true, embR);
+      JPP_RPROF_COUNT(cn);
       JPP_RPROF(2);
-      if (b < bE) {  // new contexts (GbeamRnnState::computeContext; not needed for EOS)
+      {  // new contexts (GbeamRnnState::computeContext)
         float acc[kRnnCN][J];
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p)
@@ -784,7 +767,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
             for (int j = 0; j < J; ++j) {
               const u32 i = (u32)lane * J + j;
               const float x = acc[p][j] + embR[p][j];
-              const float y = i < E ? 1.0f / (1.0f + expf(-x)) : 0.f;
+              const float y = i < E ? sigmoid_ref(x, s_exptab) : 0.f;
               op[j] = y;
               lastOut[p][j] = y;
             }
@@ -794,31 +777,62 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         lastCn = (u32)cn;
       }
       JPP_RPROF(3);
-      if (!lastOfBnd) continue;
-      wave_sync();
-      if (lane < ngb) {
-        // score cell of the connection and, fused, ScoreProcessor::adjustBeamScores for this boundary:
-        // everything it needs was staged, so the loop carries no dependent HBM access
+    }
+    wave_sync();
+    // ---- scores: one lane per rnn node ----
+    // computeContextScores: (nce row .* context).colwise().sum() = the rounded products added for k ascending;
+    // computeMaxentScores: += w0 + w1 + ...; applyNceConstant: -= c   (mikolov_rnn_impl.h:216-243);
+    // the UNK word scores unkConstantTerm + unkLengthPenalty * length (one fused multiply-add on the
+    // reference's FMA build, rnn_scorer_gbeam.cc:239)
+    for (u32 k0 = 0; k0 < nnode; k0 += 64) {
+      const u32 k = k0 + (u32)lane;
+      if (k < nnode) {
+        const u32 q = l_node[k];
+        const i32 id = rn_id[q];
+        float score;
+        if (id == unkId) {
+          score = __builtin_fmaf(unkLen, (float)g_len[q], unkConst);
+        } else if (mxOrder == 0) {
+          score = 0.f - nceConst;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+        } else {
+          const u32 eid = id == -1 ? 0u : (u32)id;
+          score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)l_prev[q] * EP, E);
+          score += l_mx[q];
+          score -= nceConst;
+        }
+        l_mx[q] = score;
+      }
+    }
+    wave_sync();
+    JPP_RPROF(4);
+    // ---- score cells of the connections (one lane per connection) ----
+    for (u32 q = lane; q < nq; q += 64) {
+      const u32 c = l_conn[q];
+      if (c != kNoConn) {
+        const u32 b = q / (u32)G;
+        B.node_cells[((nb + (c & 0xffffu)) * G + (c >> 27)) * S + 1] = l_mx[b * (u32)G + ((c >> 22) & 31u)];
+      }
+    }
+    // ---- ScoreProcessor::adjustBeamScores along the EOS paths (lane = path), remakeEosBeam inputs ----
+    if (lane < ngb) {
+      for (u32 b = 2; b <= bE; ++b) {
         const u32 q = b * (u32)G + (u32)lane;
         const u32 c = l_conn[q];
-        if (c != kNoConn) {
-          const u32 nd = c & 0xffffu, k = (c >> 16) & 63u;
-          const float rs = nscore[(c >> 22) & 31u];
-          B.node_cells[((nb + nd) * G + (c >> 27)) * S + 1] = rs;
-          if (b < bE) {
-            const float local = weighted_score2(l_cell0[q], rs, cfg) + prevT;
-            beams[(u64)nd * beam + k].total = local;
-            prevT = local;
-          } else {
-            // remakeEosBeam: fullScores[i] = localScore + beamScore
-            full[lane] = weighted_score2(l_cell0[q], rs, cfg) + prevT;
-            prev_total[lane] = prevT;
-          }
+        if (c == kNoConn) continue;
+        const u32 nd = c & 0xffffu, k = (c >> 16) & 63u;
+        const float rs = l_mx[b * (u32)G + ((c >> 22) & 31u)];
+        const float local = weighted_score2(l_cell0[q], rs, cfg);
+        if (b < bE) {
+          const float tot = local + prevT;
+          beams[(u64)nd * beam + k].total = tot;
+          prevT = tot;
+        } else {
+          full[lane] = local + prevT;  // remakeEosBeam: fullScores[i] = localScore + beamScore
+          prev_total[lane] = prevT;
         }
       }
-      wave_sync();
-      JPP_RPROF(4);
     }
+    wave_sync();
   } else {
     for (u32 b = 2; b <= bE; ++b) {
       const int cnt = (int)rn_cnt[b];
@@ -850,15 +864,11 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
           }
         }
         JPP_RPROF(1);
-#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
-        if (lane == 0) { rprof_pass += 1; rprof_nodes += (unsigned long long)cn; }
-#endif
+        JPP_RPROF_COUNT(cn);
         float ctx[kRnnCN][J];
         float embv[kRnnCN][J];
-        float dot[kRnnCN];
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p) {
-          dot[p] = 0.f;
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             ctx[p][j] = 0.f;
@@ -874,42 +884,31 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
 #pragma unroll
             for (int j = 0; j < J; ++j) {
               u32 i = (u32)lane * J + j;
-              if (i < E) {
-#if JPP_RNN_EXP == 2   // timing experiment: rows from one hot line instead of the embedding tables
-                dot[p] += nceT[i] * ctx[p][j];
-#else
-                dot[p] += nceT[(u64)eid * E + i] * ctx[p][j];
-#endif
-#if JPP_RNN_EXP == 2
-                if (b < bE) embv[p][j] = embT[i];
-#else
-                if (b < bE) embv[p][j] = embT[(u64)eid * E + i];
-#endif
-              }
+              if (i < E && b < bE) embv[p][j] = embT[(u64)eid * E + i];
             }
           }
         }
-#pragma unroll
-        for (int p = 0; p < kRnnCN; ++p) {
-          if (p < cn) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) dot[p] += wave_shfl_f32(dot[p], lane ^ o);
-          }
-        }
-        // score of rnn node c0 + x on lane x
+        // score of rnn node c0 + x on lane x: the sequential NCE dot product (see rnn_dot_seq), the maxent
+        // sum, the NCE constant; the UNK word's score is one fused multiply-add (rnn_scorer_gbeam.cc:239)
         if (lane < cn) {
           const int x = lane;
-          float score = x == 0 ? dot[0] : x == 1 ? dot[1] : x == 2 ? dot[2] : dot[3];
           const i32 id = myid;
           const u32 order = mxOrder;
-          float me = mw[0];
+          float score;
+          if (id == unkId) {
+            score = __builtin_fmaf(unkLen, (float)g_len[(u64)b * G + c0 + x], unkConst);
+          } else if (order == 0) {
+            score = 0.f - nceConst;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+          } else {
+            const u32 eid = id == -1 ? 0u : (u32)id;
+            score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)rn_prev[(u64)b * G + c0 + x] * EP, E);
+            float me = mw[0];
 #pragma unroll
-          for (u32 i = 1; i < 4; ++i)
-            if (i < order) me += mw[i];
-          if (order > 0) score += me;
-          else score = 0.f;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
-          score -= nceConst;
-          if (id == unkId) score = unkConst + unkLen * (float)g_len[(u64)b * G + c0 + x];
+            for (u32 i = 1; i < 4; ++i)
+              if (i < order) me += mw[i];
+            score += me;
+            score -= nceConst;
+          }
           nscore[c0 + x] = score;
         }
         JPP_RPROF(2);
@@ -920,14 +919,12 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
           for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
-#if JPP_RNN_EXP != 1
           switch (cn) {
             case 1: rnn_matvec_any<J, 1, WLDS>(Wt, ctx, acc, lane); break;
             case 2: rnn_matvec_any<J, 2, WLDS>(Wt, ctx, acc, lane); break;
             case 3: rnn_matvec_any<J, 3, WLDS>(Wt, ctx, acc, lane); break;
             default: rnn_matvec_any<J, 4, WLDS>(Wt, ctx, acc, lane); break;
           }
-#endif
 #pragma unroll
           for (int p = 0; p < kRnnCN; ++p) {
             if (p < cn) {
@@ -936,7 +933,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
               for (int j = 0; j < J; ++j) {
                 u32 i = (u32)lane * J + j;
                 float x = acc[p][j] + embv[p][j];
-                op[j] = i < E ? 1.0f / (1.0f + expf(-x)) : 0.f;
+                op[j] = i < E ? sigmoid_ref(x, s_exptab) : 0.f;
               }
             }
           }

@@ -24,10 +24,6 @@
 #include "jpp_select.h"
 #include "k_decode.h"
 
-#ifndef JPP_SEEDS_EXP
-#define JPP_SEEDS_EXP 0  // developer timing experiments only (1: dictionary seeds only, 2: UNK makers only)
-#endif
-
 namespace jpp {
 
 struct SentView {
@@ -533,17 +529,13 @@ __global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
       out.na = nullptr;
     }
     WalkInfo w{0, 0, false};
-#if JPP_SEEDS_EXP != 2
     if (MODE == 0) {
       w = dic_seeds(M, S, i, out, &B.pos_walk[g0 + i]);
     } else {
       const WalkCache* wc = &B.pos_walk[g0 + i];
       w = wc->cached ? dic_seeds_replay(M, wc, wc->leaf, wc->ok_len, i, out) : dic_seeds(M, S, i, out);
     }
-#endif
-#if JPP_SEEDS_EXP != 1
     for (int m = 0; m < M.n_stage1; ++m) run_maker(M, M.makers[m], S, i, w, out);
-#endif
     if (MODE == 0) {
       B.pos_cnt1[g0 + i] = (u16)(out.n > 0xffff ? 0xffff : out.n);
       B.pos_ends[g0 + i] = out.ends;   // stage-1 ends only; k_norm<0> adds the normalized nodes'

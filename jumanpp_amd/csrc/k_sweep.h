@@ -57,50 +57,7 @@ struct NgramTables {
 };
 constexpr NgramTables kNg{};
 
-// Developer-only phase timing (-DJPP_SWEEP_PROF): lane 0 of every wavefront adds the s_memtime
-// cycles it spent per phase to g_sweep_prof[]; read with the debug entry point jppgpu_debug_sweep_prof.
-#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
-__device__ unsigned long long g_sweep_dbg[16];
-#endif
-#if defined(JPP_SWEEP_PROF) && !defined(JPP_EMU)
-__device__ unsigned long long g_sweep_prof[16];
-#define JPP_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define JPP_PROF(i)                                          \
-  do {                                                       \
-    unsigned long long now_ = __builtin_readcyclecounter();  \
-    prof_acc[i] += now_ - prof_t;                            \
-    prof_t = now_;                                           \
-  } while (0)
-#define JPP_PROF_FLUSH                                                                 \
-  do {                                                                                 \
-    if (lane == 0)                                                                     \
-      for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_sweep_prof[q_], prof_acc[q_]);       \
-  } while (0)
-#else
-#define JPP_PROF_DECL
-#define JPP_PROF(i)
-#define JPP_PROF_FLUSH
-#endif
-
-// weight gathers: JPP_WLOAD_MODE 0 = plain load, 1 = non-temporal (nt) load
-#ifndef JPP_WLOAD_MODE
-#define JPP_WLOAD_MODE 0
-#endif
-#if JPP_WLOAD_MODE == 1 && !defined(JPP_EMU)
-#define JPP_WLOAD(W, i) __builtin_nontemporal_load(&(W)[i])
-#elif JPP_WLOAD_MODE == 2 && !defined(JPP_EMU)
-// timing experiment only (wrong results): every gather hits a 4 KB window, i.e. no cache-line traffic
-#define JPP_WLOAD(W, i) ((W)[(i) & 1023])
-#else
-#define JPP_WLOAD(W, i) ((W)[i])
-#endif
-
-#ifndef JPP_SWEEP_WAVES
-#define JPP_SWEEP_WAVES 4
-#endif
-#ifndef JPP_SWEEP_HEADWAIT
-#define JPP_SWEEP_HEADWAIT 0
-#endif
+constexpr int kSweepWaves = 4;  // wavefronts per SIMD the LDS footprint of the narrow variant allows
 constexpr int kChunk = 8;       // right nodes processed per pass (= 8-lane groups per wave)
 constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
@@ -116,7 +73,6 @@ __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == 
 constexpr int kBiPerLane = (spec::kNumBi + 7) / 8;
 
 // tables in LDS (filled once per kernel)
-#define JPP_BI_TABLE_LDS 1
 struct LaneBi {
   const u64* pre;   // [kNumBi] hash prefixes
   const u8* t01;    // [kNumBi] (t0 << 4) | t1
@@ -134,7 +90,7 @@ __device__ __forceinline__ void bi_gather_s1(const LaneBi& t, int j, const u64* 
     idx[m] = (u32)hmix(s1[k], t1r[JPP_LBI_T1(t, m, j)]) & wmask;
   }
 #pragma unroll
-  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? JPP_WLOAD(W, idx[m]) : 0.f;
+  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? W[idx[m]] : 0.f;
 }
 
 // generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7.
@@ -259,7 +215,7 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // jumanpp_args.h:50-54): the four numbers become compile-time constants (no runtime divisions by the beam
 // size, fixed trip counts); any other configuration runs the same code with the values read from `cfg`.
 template <int GM, int RM, bool DEF = false>
-__global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
+__global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
@@ -303,11 +259,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
   // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
-#if defined(JPP_SWEEP_CAND256)
-  constexpr int kCandCap = 256;
-#else
   constexpr int kCandCap = GM <= 8 ? 64 : 256;
-#endif
   __shared__ __attribute__((aligned(16))) u64 pRn[2][kChunk][kPat];
   __shared__ __attribute__((aligned(16))) float t0n[2][kChunk];
   constexpr u32 kEnnCap = GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
@@ -365,34 +317,12 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
   lds_async_wait();
   wave_sync();
   u32 metaReady = metaEnd;                      // ... and those below metaReady have landed
-#if defined(JPP_SWEEP_NO_RING)
-  metaReady = 0;
-  metaEnd = n + 3;
-#endif
   // The HBM read sits behind a noinline call so that the two loads cannot be merged into one flat load
   // through a selected pointer: flat access to the LDS aperture faults on this platform.
-#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
-  auto metaAt = [&](u32 q) -> BndMeta {
-    BndMeta g = load_bnd_meta(gmeta, q);
-    if (q < metaReady) {
-      BndMeta l = meta[q & (kRing - 1)];
-      if (l.first != g.first || l.cnt != g.cnt || l.efirst != g.efirst || l.ecnt != g.ecnt) {
-        if (atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
-          g_sweep_dbg[1] = s; g_sweep_dbg[2] = q; g_sweep_dbg[3] = metaReady; g_sweep_dbg[4] = metaEnd;
-          g_sweep_dbg[5] = n; g_sweep_dbg[6] = l.first; g_sweep_dbg[7] = g.first; g_sweep_dbg[8] = l.cnt;
-          g_sweep_dbg[9] = g.cnt; g_sweep_dbg[10] = (unsigned long long)lane;
-        }
-      }
-      return l;
-    }
-    return g;
-  };
-#else
   auto metaAt = [&](u32 q) -> BndMeta {
     if (q < metaReady) return meta[q & (kRing - 1)];
     return load_bnd_meta(gmeta, q);
   };
-#endif
   auto next_nonempty = [&](u32 from) {
     u32 q = from;
     while (q <= n + 2 && metaAt(q).cnt == 0) ++q;
@@ -409,7 +339,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     lds_async_load<4>(&t0n[buf][0], t0s + rf + lane, (u32)lane < nxr);
     lds_async_load<4>(&enn[buf][0], en + ef + lane, (u32)lane < (Lq < kEnnCap ? Lq : kEnnCap));
   };
-  static_assert(JPP_BI_TABLE_LDS == 1, "the state pass reads the feature tables from LDS");
   // first-stage states of `nx` right nodes whose pattern rows are rows[0..nx): lane per (node, feature)
   auto compute_s1 = [&](const u64(*rows)[kPat], u32 nx) {
     constexpr u32 kF = spec::kNumBi + spec::kNumTri;
@@ -429,9 +358,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     // requested before that boundary's candidate slots / pattern rows, and vector memory operations complete
     // in order, so the waits of phases 1-2 have covered them: no wait here -- it would only drain the beam
     // and cell stores the previous boundary has just issued (every path that skips those phases waits itself).
-#if JPP_SWEEP_HEADWAIT
-    lds_async_wait();
-#endif
     wave_sync();
     const BndMeta mb = metaAt(b);
     const u32 R = mb.cnt;
@@ -444,9 +370,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
     }
     // the previous requests have landed (wait above); boundaries below b are done: recycle their ring
     // slots for the records up to 63 ahead
-#if !defined(JPP_SWEEP_NO_RING)
     metaReady = metaEnd;
-#endif
     if (metaEnd < n + 3 && metaEnd < b + kRing) {
       const u32 lo = metaEnd, hi = (b + kRing) < (n + 3) ? (b + kRing) : (n + 3);
       // slots lo..hi-1 (mod 64) may wrap: issue the two contiguous pieces separately
@@ -456,24 +380,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       lds_async_load<16>(&meta[0], gmeta + lo + c0 + lane, (u32)lane < cntAll - c0);
       metaEnd = hi;
     }
-#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
-    {  // developer build: the asynchronously staged copies must equal their HBM sources
-      bool badv = false;
-      u64 code = 0;
-      const u32 nxr = R < (u32)kChunk ? R : (u32)kChunk;
-      for (u32 q = lane; q < nxr * kPat; q += 64)
-        if (pRn[par][q / kPat][q % kPat] != pats[(u64)rfirst * kPat + q]) { badv = true; code = 100 + q; }
-      if ((u32)lane < nxr && t0n[par][lane] != t0s[rfirst + lane]) { badv = true; code = 300 + lane; }
-      if ((u32)lane < (L < kEnnCap ? L : kEnnCap) && enn[par][lane] != en[efirst + lane]) { badv = true; code = 400 + lane; }
-      if (wave_ballot(badv) != 0) {
-        if (badv && atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
-          g_sweep_dbg[1] = s; g_sweep_dbg[2] = b; g_sweep_dbg[3] = code; g_sweep_dbg[4] = par;
-          g_sweep_dbg[5] = n; g_sweep_dbg[6] = R; g_sweep_dbg[7] = L; g_sweep_dbg[10] = (unsigned long long)lane;
-        }
-        return;
-      }
-    }
-#endif
     bn = next_nonempty(b + 1);
     prefetch(bn, par ^ 1);
     const u32* enL = enn[par];  // ends list of this boundary (first 64 entries)
@@ -492,23 +398,6 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
       }
       lds_async_wait();
       wave_sync();
-#if defined(JPP_SWEEP_CHECKMETA) && !defined(JPP_EMU)
-      {
-        bool badv = false;
-        for (u32 q = lane; q < ncand; q += 64) {
-          const u32 l = q / (u32)beam, k = q - l * (u32)beam;
-          BeamSlot a = cand[q], g = beams[(u64)en[efirst + l] * beam + k];
-          if (a.left != g.left || a.beam != g.beam || a.prev_node != g.prev_node || f32_sortable(a.total) != f32_sortable(g.total)) badv = true;
-        }
-        if (wave_ballot(badv) != 0) {
-          if (badv && atomicAdd(&g_sweep_dbg[0], 1ull) == 0) {
-            g_sweep_dbg[1] = s; g_sweep_dbg[2] = b; g_sweep_dbg[3] = 900; g_sweep_dbg[4] = par;
-            g_sweep_dbg[5] = n; g_sweep_dbg[6] = R; g_sweep_dbg[7] = L; g_sweep_dbg[10] = (unsigned long long)lane;
-          }
-          return;
-        }
-      }
-#endif
     }
     {
       u64 last = ~u64{0};
@@ -671,7 +560,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
         float g = 0.f;
         if (act && gj < spec::kNumTri) {
           u32 idx = (u32)hmix(hmix(s1t[xr][gj], t1r[s_trit[gj][1]]), t2r[s_trit[gj][2]]) & wmask;
-          g += JPP_WLOAD(W, idx);
+          g += W[idx];
         }
         // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
         const float b8 = bi_sum8(w, lane, gj);
@@ -793,7 +682,7 @@ __global__ void __launch_bounds__(64, JPP_SWEEP_WAVES) k_sweep(Batch B, const De
 #pragma unroll
           for (int f = 0; f < spec::kNumTri; ++f) {
             u32 idx = (u32)hmix(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]]) & wmask;
-            w[f] = JPP_WLOAD(W, idx);
+            w[f] = W[idx];
           }
           static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
           float S = biS[x][gb_t1[i]];

@@ -9,7 +9,12 @@
 //                    --feature-weight-perceptron=X --feature-weight-rnn=X]
 //                    [--right-beam=5] [--no-rnn] [-s N | -M | -F | --segment | --dic-subset] [--partial-input]
 //                    [--auto-nbest=B:S:M] [--batch=65536] [--threads=N] [--no-pipeline]
-//                    [--device=0] [--timing] [-o OUT] [INPUT...]
+//                    [--device=0 | --devices=0-7] [--timing] [-o OUT] [INPUT...]
+//
+// --devices=LIST (e.g. 0-7 or 0,2,5) replaces the reference's one-thread loop over sentences
+// (jumanpp.cc:156-179) by one analysis thread per GPU: batches are dealt to the devices in turn, every
+// device has its own pair of analyzers, and the formatter consumes the batches in input order, so the
+// output is the same byte string for any device list.  Sentences are independent: no collective.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -43,6 +48,7 @@ struct Conf {
   bool noRnn = false;
   size_t batch = 65536;
   int device = 0;
+  std::vector<int> devices;   // --devices=LIST: one analysis thread (and analyzer pair) per listed GPU
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
@@ -89,7 +95,8 @@ struct Example {
 // one batch on its way through read -> analyse -> format
 struct Job {
   std::vector<Example> batch;
-  int analyzer = 0;
+  int device = 0;    // index into the device list
+  int analyzer = 0;  // which of that device's analyzers
   Status batchStatus;
   double gpuMs = 0;
 };
@@ -177,6 +184,25 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--right-check", &v)) conf.rightCheck = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--right-beam", &v)) conf.rightBeam = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--batch", &v)) conf.batch = (size_t)std::atoll(v.c_str());
+    else if (argValue(argc, argv, i, "--devices", &v)) {
+      // comma-separated ordinals and ranges: 0-7, 0,2,5, 0-3,6
+      conf.devices.clear();
+      for (size_t p = 0; p <= v.size();) {
+        size_t e = v.find(',', p);
+        if (e == std::string::npos) e = v.size();
+        std::string part = v.substr(p, e - p);
+        size_t dash = part.find('-');
+        int lo = std::atoi(part.c_str()), hi = dash == std::string::npos ? lo : std::atoi(part.c_str() + dash + 1);
+        bool digits = !part.empty() && part.find_first_not_of("0123456789-") == std::string::npos && part[0] != '-' &&
+                      part[part.size() - 1] != '-' && (dash == std::string::npos || part.find('-', dash + 1) == std::string::npos);
+        if (!digits || lo < 0 || hi < lo || hi - lo > 1023) {
+          std::cerr << "bad device list " << v << "\n";
+          return false;
+        }
+        for (int d = lo; d <= hi; ++d) conf.devices.push_back(d);
+        p = e + 1;
+      }
+    }
     else if (argValue(argc, argv, i, "--device", &v)) conf.device = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--output", &v) || argValue(argc, argv, i, "-o", &v)) conf.output = v;
     else if (argValue(argc, argv, i, "--lattice", &v) || argValue(argc, argv, i, "--specifics", &v) ||
@@ -292,7 +318,7 @@ int main(int argc, const char** argv) {
   if (conf.help) {
     std::cerr << "jumanpp_gpu: Juman++ v2 analysis on an MI355X, the batched sibling of jumanpp_v2\n"
                  "  jumanpp_gpu --model=MODEL.jppmdl [options] [INPUT...]   (standard input without INPUT)\n"
-                 "General:   -c/--config FILE   -o/--output FILE   --partial-input   --device=N\n"
+                 "General:   -c/--config FILE   -o/--output FILE   --partial-input   --device=N | --devices=0-7\n"
                  "Output:    -j/--juman (default)  -M/--morph  -F/--full-morph  --segment [--segment-separator=S]\n"
                  "           -s/-L/--lattice/--specifics N   --dic-subset   --format=NAME\n"
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
@@ -433,19 +459,24 @@ int main(int argc, const char** argv) {
   // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
   // call, is being formatted.  Output order is the input order.
   const int nAnalyzers = conf.pipeline ? 2 : 1;
-  // the second analyzer (a second copy of the model in HBM) is made when a second batch shows up: a short
-  // input pays for one
-  std::vector<std::unique_ptr<GpuAnalyzer>> analyzers((size_t)nAnalyzers);
-  auto makeAnalyzer = [&](int a) -> Status {
-    analyzers[a].reset(new GpuAnalyzer());
+  if (conf.devices.empty()) conf.devices.push_back(conf.device);
+  const int nDev = (int)conf.devices.size();
+  // per device: the second analyzer (a second copy of the model in HBM) is made when a second batch shows
+  // up there: a short input pays for one
+  std::vector<std::vector<std::unique_ptr<GpuAnalyzer>>> analyzers((size_t)nDev);
+  for (auto& v : analyzers) v.resize((size_t)nAnalyzers);
+  auto makeAnalyzer = [&](int d, int a) -> Status {
+    analyzers[d][a].reset(new GpuAnalyzer());
     // the lattice format reads the N best paths only: they are gathered on the device (N = what it prints)
-    if (latticeFormat) analyzers[a]->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
-    return analyzers[a]->initialize(&model, acfg, sconf, &def, conf.device);
+    if (latticeFormat) analyzers[d][a]->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
+    return analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d]);
   };
-  s = makeAnalyzer(0);
-  if (!s) {
-    std::cerr << "failed to initialize the analyzer: " << s << "\n";
-    return 1;
+  for (int d = 0; d < nDev; ++d) {
+    s = makeAnalyzer(d, 0);
+    if (!s) {
+      std::cerr << "failed to initialize the analyzer on device " << conf.devices[d] << ": " << s << "\n";
+      return 1;
+    }
   }
   std::vector<std::unique_ptr<OutputFormat>> formats;
   for (int t = 0; t < conf.threads; ++t) {
@@ -456,12 +487,19 @@ int main(int argc, const char** argv) {
     }
   }
 
-  BoundedQueue<std::unique_ptr<Job>> readQ(2), doneQ(1);
+  // batch j goes to device j mod nDev and comes back through that device's queue: popping the done queues
+  // in the same rotation restores the input order without sequence numbers
+  std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<Job>>>> readQ, doneQ;
+  std::vector<std::unique_ptr<Semaphore>> freeAnalyzers;
+  for (int d = 0; d < nDev; ++d) {
+    readQ.emplace_back(new BoundedQueue<std::unique_ptr<Job>>(2));
+    doneQ.emplace_back(new BoundedQueue<std::unique_ptr<Job>>(1));
+    freeAnalyzers.emplace_back(new Semaphore(nAnalyzers));
+  }
   BoundedQueue<std::unique_ptr<Formatted>> writeQ(2);
-  Semaphore freeAnalyzers(nAnalyzers);
-  int live = nAnalyzers;  // analyzers in rotation (GPU thread only)
   Clock clock;
-  double readMs = 0, analyzeMs = 0, formatMs = 0, gpuMs = 0;
+  double readMs = 0, formatMs = 0, gpuMs = 0;
+  std::vector<double> analyzeMsDev((size_t)nDev, 0.0);
 
   auto readBatch = [&](Job* job) {
     auto& batch = job->batch;
@@ -490,7 +528,7 @@ int main(int argc, const char** argv) {
   };
 
   auto analyzeJob = [&](Job* job) {
-    GpuAnalyzer& analyzer = *analyzers[job->analyzer];
+    GpuAnalyzer& analyzer = *analyzers[job->device][job->analyzer];
     if (conf.partialInput) {
       std::vector<const PartialExample*> exs;
       for (auto& e : job->batch) exs.push_back(e.readStatus.isOk() ? e.partial.get() : nullptr);
@@ -507,7 +545,7 @@ int main(int argc, const char** argv) {
 
   // sentences [lo, hi) of a job -> text for stdout and stderr
   auto formatRange = [&](OutputFormat* format, const Job& job, size_t lo, size_t hi, std::string* text, std::string* errors) {
-    const GpuAnalyzer& analyzer = *analyzers[job.analyzer];
+    const GpuAnalyzer& analyzer = *analyzers[job.device][job.analyzer];
     for (size_t i = lo; i < hi; ++i) {
       const Example& e = job.batch[i];
       if (!e.readStatus.isOk()) {
@@ -532,41 +570,47 @@ int main(int argc, const char** argv) {
   };
 
   std::thread reader([&]() {
-    for (;;) {
+    for (size_t j = 0;; ++j) {
       std::unique_ptr<Job> job(new Job());
       double t0 = clock.ms();
       readBatch(job.get());
       readMs += clock.ms() - t0;
       if (job->batch.empty()) break;
-      readQ.push(std::move(job));
+      job->device = (int)(j % (size_t)nDev);
+      readQ[job->device]->push(std::move(job));
     }
-    readQ.close();
+    for (auto& q : readQ) q->close();
   });
-  std::thread gpu([&]() {
-    std::unique_ptr<Job> job;
-    int next = 0;
-    while (readQ.pop(&job)) {
-      freeAnalyzers.acquire();
-      job->analyzer = next;
-      double t0 = clock.ms();
-      if (!analyzers[job->analyzer]) {
-        Status made = makeAnalyzer(job->analyzer);
-        if (!made) {
-          // (e.g. no HBM for a second model copy) carry on with the first analyzer alone: take the second
-          // token out of circulation, which also waits until the first analyzer's batch has been formatted
-          analyzers[job->analyzer].reset();
-          freeAnalyzers.acquire();
-          live = 1;
-          job->analyzer = 0;
+  // one analysis thread per device (HIP's current device is per host thread; the library binds it per call)
+  std::vector<std::thread> gpus;
+  for (int d = 0; d < nDev; ++d) {
+    gpus.emplace_back([&, d]() {
+      std::unique_ptr<Job> job;
+      int next = 0;
+      int live = nAnalyzers;  // analyzers in rotation on this device
+      while (readQ[d]->pop(&job)) {
+        freeAnalyzers[d]->acquire();
+        job->analyzer = next;
+        double t0 = clock.ms();
+        if (!analyzers[d][job->analyzer]) {
+          Status made = makeAnalyzer(d, job->analyzer);
+          if (!made) {
+            // (e.g. no HBM for a second model copy) carry on with the first analyzer alone: take the second
+            // token out of circulation, which also waits until the first analyzer's batch has been formatted
+            analyzers[d][job->analyzer].reset();
+            freeAnalyzers[d]->acquire();
+            live = 1;
+            job->analyzer = 0;
+          }
         }
+        next = (job->analyzer + 1) % live;
+        analyzeJob(job.get());
+        analyzeMsDev[d] += clock.ms() - t0;
+        doneQ[d]->push(std::move(job));
       }
-      next = (job->analyzer + 1) % live;
-      analyzeJob(job.get());
-      analyzeMs += clock.ms() - t0;
-      doneQ.push(std::move(job));
-    }
-    doneQ.close();
-  });
+      doneQ[d]->close();
+    });
+  }
 
   double writeMs = 0;
   std::thread writer([&]() {
@@ -586,7 +630,7 @@ int main(int argc, const char** argv) {
   size_t sentences = 0;
   const size_t kChunk = 64;  // sentences a format worker takes at a time
   std::unique_ptr<Job> job;
-  while (doneQ.pop(&job)) {
+  for (size_t j = 0; doneQ[j % (size_t)nDev]->pop(&job); ++j) {
     double t0 = clock.ms();
     const size_t n = job->batch.size();
     const size_t nChunks = (n + kChunk - 1) / kChunk;
@@ -609,18 +653,20 @@ int main(int argc, const char** argv) {
     result = job->batch.back().readStatus.isOk() ? 0 : 1;
     sentences += n;
     gpuMs += job->gpuMs;
-    freeAnalyzers.release();
+    freeAnalyzers[job->device]->release();
     formatMs += clock.ms() - t0;
     writeQ.push(std::move(formatted));
   }
   writeQ.close();
   reader.join();
-  gpu.join();
+  for (auto& t : gpus) t.join();
   writer.join();
   out->flush();
   if (conf.timing) {
     double wall = clock.ms();
-    std::cerr << "sentences=" << sentences << " gpu_ms=" << gpuMs << " wall_ms=" << wall << " read_ms=" << readMs
+    double analyzeMs = 0;  // the busiest device's analysis stage
+    for (double v : analyzeMsDev) analyzeMs = std::max(analyzeMs, v);
+    std::cerr << "devices=" << nDev << " sentences=" << sentences << " gpu_ms=" << gpuMs << " wall_ms=" << wall << " read_ms=" << readMs
               << " analyze_ms=" << analyzeMs << " format_ms=" << formatMs << " write_ms=" << writeMs << " threads=" << conf.threads
               << " pipeline=" << (conf.pipeline ? 1 : 0) << " sent_per_s=" << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
   }

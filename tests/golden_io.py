@@ -66,9 +66,15 @@ def read_gold(path):
     return meta, sents
 
 
-def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
+def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True, rnn_exact=True):
     """Compare sentence `s` of a fully fetched jumanpp_amd Result with golden `g`.
-    Returns a list of mismatch strings (empty == parity)."""
+    Returns a list of mismatch strings (empty == parity).
+
+    rnn_exact (default): RNN score cells, RNN-adjusted totals, the re-made EOS beam (order included) and the
+    top-1 path must equal the reference's bit for bit -- the device evaluates the RNN with the oracle build's
+    arithmetic (k-ascending fused multiply-adds, glibc's expf, the sequential NCE dot product, the fused
+    weighted sums of adjustBeamScores).  rnn_exact=False is the 1e-4 contract of north_star, kept for
+    reference builds whose Eigen is not the loop stand-in."""
     errs = []
 
     def bad(msg):
@@ -97,7 +103,12 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
             on_path.add(key)
             sl = g.bnds[key[0]]['nodes'][key[1]]['beam'][key[2]]
             stack.append((int(sl['prev'][0]), int(sl['prev'][1]), int(sl['prev'][2])))
-    rtol = 1e-4
+    rtol = 0.0 if rnn_exact else 1e-4
+
+    def close(a, e):
+        if rnn_exact:
+            return np.float32(a).view('<u4') == np.float32(e).view('<u4')
+        return abs(float(a) - float(e)) <= rtol * max(1.0, abs(float(e)))
     nbase = int(res.node_base[s])
     bbase = int(res.bnd_base[s])
     beam = meta['beam']
@@ -165,7 +176,7 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
                     bad('b%d n%d: T0 %r vs %r' % (b, r, float(a), float(e)))
             if int(res.kept[k]) != int(gn['kept']) and len(gb['gbeam']) > 0:
                 bad('b%d n%d: kept %d vs %d' % (b, r, res.kept[k], gn['kept']))
-            eos_rnn = meta['nscorers'] == 2 and b == nb - 1
+            eos_rnn = meta['nscorers'] == 2 and b == nb - 1 and not rnn_exact
             if eos_rnn:
                 # RNN totals carry a 1e-4 tolerance, so candidates whose totals differ by less may swap
                 # ranks; require the same candidate set, matching totals, and a non-increasing order.
@@ -206,9 +217,9 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
                     a, e = np.float32(sl['total']), np.float32(gs['total'])
                     if (tol == 0.0 and a.view('<u4') != e.view('<u4')) or (tol > 0 and abs(float(a) - float(e)) > tol):
                         bad('b%d n%d slot %d: total %r vs %r' % (b, r, q, float(a), float(e)))
-                if check_scores and meta['nscorers'] == 2 and (b, r, q) in on_path:
+                if check_scores and meta['nscorers'] == 2 and ((b, r, q) in on_path or b == nb - 1):
                     a, e = float(sl['total']), float(gs['total'])
-                    if abs(a - e) > rtol * max(1.0, abs(e)):
+                    if not close(a, e):
                         bad('b%d n%d slot %d: rnn-adjusted total %r vs %r' % (b, r, q, a, e))
                     # score cells of this connection: [perceptron, rnn]
                     gi = None
@@ -220,12 +231,12 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True):
                         c_dev = res.cells[k][gi]
                         if np.float32(c_ref[0]).view('<u4') != np.float32(c_dev[0]).view('<u4'):
                             bad('b%d n%d slot %d: perceptron cell %r vs %r' % (b, r, q, float(c_dev[0]), float(c_ref[0])))
-                        if abs(float(c_ref[1]) - float(c_dev[1])) > rtol * max(1.0, abs(float(c_ref[1]))):
+                        if not close(c_dev[1], c_ref[1]):
                             bad('b%d n%d slot %d: rnn cell %r vs %r' % (b, r, q, float(c_dev[1]), float(c_ref[1])))
     # top-1 path
     if meta['nscorers'] == 2 and nb > 3:
         eb = [float(x['total']) for x in g.bnds[nb - 1]['nodes'][0]['beam'] if x['valid']]
-        if len(eb) > 1 and abs(eb[0] - eb[1]) <= rtol * max(1.0, abs(eb[0])):
+        if not rnn_exact and len(eb) > 1 and abs(eb[0] - eb[1]) <= rtol * max(1.0, abs(eb[0])):
             return errs  # best two paths tie within the RNN tolerance: the top-1 choice is not defined
     plen = int(res.path_len[s])
     if plen != len(g.path):

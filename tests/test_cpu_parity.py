@@ -207,6 +207,66 @@ def test_result_invalidated_by_next_batch(emu_lib, golden_dir):
         r1.fetch()
 
 
+def test_oracle_rnn_arithmetic_is_pinned_by_the_legacy_evaluator(ref_tools, tmp_path):
+    """the oracle build's RNN (src/rnn/mikolov_rnn.cc over the Eigen stand-in) against the
+    reference's in-tree legacy faster-rnnlm evaluator (src/rnn/legacy/rnnlmlib_static.cpp) on a synthetic
+    model: hidden states and log10 scores within 1e-4 over seeded random word chains (oracle/legacy_check.cc)."""
+    if ref_tools is None or not os.path.exists(os.path.join(ref_tools, 'legacy_check')):
+        pytest.skip('oracle/_ref/legacy_check not built')
+    mdic = tmp_path / 'd.mdic'
+    with open(mdic, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), '3000', '--seed', '5'], stdout=f)
+    for hidden, order in ((128, 3), (48, 2)):
+        rnn = str(tmp_path / ('rnn%d' % hidden))
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_rnn.py'), str(mdic), rnn, '--vocab', '2000',
+                               '--hidden', str(hidden), '--maxent-order', str(order), '--maxent-size', str(1 << 16),
+                               '--seed', '9'], stdout=subprocess.DEVNULL)
+        out = subprocess.run([os.path.join(ref_tools, 'legacy_check'), rnn, '150', '8', '3'], capture_output=True)
+        assert out.returncode == 0, (out.stdout[-300:], out.stderr[-500:])
+        r = __import__('json').loads(out.stdout.decode().strip().splitlines()[-1])
+        assert r['steps'] == 1200 and r['mismatches'] == 0 and r['max_abs_context_diff'] < 1e-5
+
+
+def test_device_expf_is_the_host_libms(tmp_path):
+    """expf_libm (jpp_device.h) restates glibc's expf with the contractions of its x86-64 FMA build: it must
+    return this host's expf() bit for bit (the RNN sigmoid of the reference goes through std::exp)."""
+    src = tmp_path / 'e.cc'
+    src.write_text(r'''
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include "jpp_device.h"
+int main() {
+  u64 tab[jpp::kExp2fN];
+  for (int i = 0; i < jpp::kExp2fN; ++i) tab[i] = jpp::exp2f_tab(i);
+  unsigned long long seed = 88172645463325252ULL;
+  long bad = 0, n = 30000000;
+  for (long i = 0; i < n; ++i) {
+    seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17;
+    float x;
+    if (i % 4 == 0) { unsigned b = (unsigned)seed; memcpy(&x, &b, 4); if (!(x == x)) continue; }
+    else x = (float)(((double)(seed >> 11) / 9007199254740992.0 - 0.5) * ((i % 4 == 1) ? 60.0 : (i % 4 == 2) ? 8.0 : 220.0));
+    volatile float xv = x;
+    float e = expf(xv), m = jpp::expf_libm(x, tab);
+    if (memcmp(&e, &m, 4) != 0) { if (bad < 5) printf("x=%a libm=%a mine=%a\n", x, e, m); ++bad; }
+  }
+  // the sigmoid of MikolovRnnImplParallel::computeNewContext on a grid
+  for (int i = -4000; i <= 4000; ++i) {
+    volatile float x = (float)i * 0.01f;
+    float e = 1.0f / (1.0f + expf(-x)), m = jpp::sigmoid_ref(x, tab);
+    if (memcmp(&e, &m, 4) != 0) ++bad;
+  }
+  printf("%ld %ld\n", n, bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / 'e'
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-ffp-contract=off', '-DJPP_EMU', '-I', os.path.join(ROOT, 'tests', 'emu'),
+                           '-I', os.path.join(ROOT, 'jumanpp_amd', 'csrc'), str(src), '-o', str(exe), '-lm'])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[-1]) == 0, out
+
+
 def test_make_t0_beam_is_a_rank_when_totals_are_distinct(tmp_path):
     """k_sweep<32,512> 5c / remakeEosBeam fast path: with pairwise distinct totals, util::partition
     (beyond beam*4/3) followed by std::sort (introsort beyond 16) yields the first `beam` entries of the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""(GPU box, developer tool) phase shares of k_sweep from a -DJPP_SWEEP_PROF build:
-   hipcc ... -DJPP_SWEEP_PROF ... -o build/libjppgpu_prof.so ; python tools/gpu_sweep_phases.py"""
+"""(GPU box, developer tool) phase shares of k_sweep from a -DJPP_DEV_PROF build:
+   hipcc ... -DJPP_DEV_PROF ... -o build/libjppgpu_prof.so ; python tools/gpu_sweep_phases.py"""
 import ctypes
 import os
 import sys
