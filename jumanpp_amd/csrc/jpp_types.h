@@ -233,6 +233,11 @@ struct Batch {
   const PcNode* pc_nodes;
   const PcTag* pc_tags;
   float* node_penalty;     // [node] 0, 1000 or 10000
+  // k_sweep<*, 0> only (a boundary with more right nodes than the LDS variants stage): per-sentence slice
+  // for the prescores, their sums and the cutoff order
+  unsigned char* sweep_scratch;
+  u64 sweep_scratch_stride;
+  u32 sweep_scratch_maxr;
   BndMeta* bnd_meta;       // [bb] {bnd_first, bnd_cnt, end_first, end_cnt} packed for k_sweep (written by k_ends)
   u32* bnd_ngb;            // [bb]
   // result

@@ -281,7 +281,7 @@ struct jppgpu_ctx {
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, pos_walk, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
-  DevBuf path_len, bnd_meta;
+  DevBuf path_len, bnd_meta, sweep_scratch;
   DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
   bool partial_pending = false;  // constraints uploaded for the next analyze call
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
@@ -538,7 +538,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
-                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
+                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
@@ -703,8 +703,26 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   // the <8, *> variants have no makeT0Beam replay (util::partition / introsort): they take the configurations
   // whose beams are plain stable ranks, i.e. at most 8 candidates and global beam <= beam*4/3
   const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
+  // wider than the LDS variants stage (or more prescores than they hold): the per-right-node arrays go to HBM
+  const bool unbounded = maxR > (u32)kMaxRight || (u64)ctx->cfg.rcheck * maxR > 2u * (u64)kMaxRight;
+  B.sweep_scratch = nullptr;
+  B.sweep_scratch_stride = 0;
+  B.sweep_scratch_maxr = 0;
+  if (ctx->cfg.gbeam != 0 && unbounded) {
+    const u64 rc = ctx->cfg.rcheck > 0 ? (u64)ctx->cfg.rcheck : 1;
+    const u64 stride = (((rc + 1) * maxR * 4 + (u64)maxR * 2) + 63) & ~u64{63};
+    if (!ctx->sweep_scratch.ensure((size_t)(stride * n)))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (wide-lattice scratch)");
+    B.sweep_scratch = ctx->sweep_scratch.as<unsigned char>();
+    B.sweep_scratch_stride = stride;
+    B.sweep_scratch_maxr = maxR;
+  }
   if (ctx->cfg.gbeam == 0) {
     JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else if (unbounded && narrow) {
+    JPP_LAUNCH((k_sweep<8, 0>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else if (unbounded) {
+    JPP_LAUNCH((k_sweep<32, 0>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow && maxR <= 64 && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5) {
     JPP_LAUNCH((k_sweep<8, 64, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);   // the CLI defaults
   } else if (narrow && maxR <= 64 && ctx->cfg.rcheck <= 2) {

@@ -249,9 +249,23 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   static_assert(spec::kTri[0].t2 < kT2 && spec::kTri[1].t2 < kT2 && spec::kTri[2].t2 < kT2 && spec::kTri[3].t2 < kT2 && spec::kNumTri == 4,
                 "t2pat holds pattern fields 0..3 only");
   __shared__ u64 t2pat[GM][kT2];
-  __shared__ float pres[2 * RM];
-  __shared__ float csum[RM];
-  __shared__ u16 order[RM];
+  // the three per-right-node arrays: in LDS (capacity RM), or -- RM == 0, the host picks this variant when a
+  // boundary of the batch has more right nodes than the LDS variants stage -- in an HBM scratch slice of the
+  // sentence sized from the batch maximum, so that no lattice is ever too wide (the reference has no limit,
+  // lattice_builder.cc:70-93)
+  constexpr int kRMs = RM > 0 ? RM : 1;
+  __shared__ float pres_lds[2 * kRMs];
+  __shared__ float csum_lds[kRMs];
+  __shared__ u16 order_lds[kRMs];
+  float* pres = pres_lds;
+  float* csum = csum_lds;
+  u16* order = order_lds;
+  if constexpr (RM == 0) {
+    unsigned char* base = B.sweep_scratch + (u64)blockIdx.x * B.sweep_scratch_stride;
+    pres = reinterpret_cast<float*>(base);                                   // [rcheck][maxR]
+    csum = pres + (size_t)(cfg.rcheck > 0 ? cfg.rcheck : 1) * B.sweep_scratch_maxr;   // [maxR]
+    order = reinterpret_cast<u16*>(csum + B.sweep_scratch_maxr);           // [maxR]
+  }
   __shared__ float biS[kChunk][GM];
   __shared__ float tot[kChunk][GM];
   __shared__ u8 sidx[GM > 16 ? kChunk : 1][GM];   // index arrays of the makeT0Beam replay (wide variant, ties only)
@@ -364,7 +378,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     const u32 rfirst = mb.first;
     const u32 L = mb.ecnt;
     const u32 efirst = mb.efirst;
-    if (R > (u32)RM) {
+    if (RM > 0 && R > (u32)RM) {   // cannot happen: the host chose RM from the batch maximum
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }
@@ -535,7 +549,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     int c = rcheck;
     if (c > (int)R) c = (int)R;
     if (c > ngb) c = ngb;
-    if ((u32)c * R > (u32)(2 * RM)) {
+    if (RM > 0 && (u32)c * R > (u32)(2 * RM)) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }

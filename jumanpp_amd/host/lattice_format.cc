@@ -1,6 +1,7 @@
 #include "lattice_format.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 
 namespace jumanpp_amd {
@@ -161,8 +162,11 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
     // connection with the SMALLEST weighted score among those the N best paths use (first one on ties)
     auto total = [&](uint32_t slot) {
       const float* sc = cellsOf(node, slot);
+      // `total += s[i] * weights[i]`: one fused multiply-add per scorer in the reference's FMA build
+      // (-march=native / haswell; the same contraction as in adjustBeamScores), so near-equal connections
+      // compare as they do there
       float t = 0;
-      for (size_t i = 0; i < weights_.size(); ++i) t += sc[i] * weights_[i];
+      for (size_t i = 0; i < weights_.size(); ++i) t = std::fma(sc[i], weights_[i], t);
       return t;
     };
     uint32_t best = ni.slots[0];

@@ -103,6 +103,47 @@ def test_emulated_full_beam_matches_live_reference(emu_lib, golden_dir, ref_tool
     assert not errs, errs[:10]
 
 
+def _wide_boundary_workload(ref_tools, tmp, beams, n_homographs=600):
+    """a dictionary that puts more right nodes on one boundary than the LDS variants of k_sweep stage
+    (kMaxRight = 512): `n_homographs` distinct readings of one surface"""
+    mdic = os.path.join(tmp, 'wide.mdic')
+    with open(mdic, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), '1500', '--seed', '13'], stdout=f)
+        for i in range(n_homographs):
+            f.write('かき,0,0,0,名詞,普通名詞,*,*,かき,よみ%d,かき/よみ%d,代表表記:かき/よみ%d\n' % (i, i, i))
+    subprocess.check_call([os.path.join(ref_tools, 'jpp_jumandic_bootstrap'), mdic, os.path.join(tmp, 'wide.seed')],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'mkmodel', os.path.join(tmp, 'wide.seed'),
+                           os.path.join(tmp, 'wide.model'), '16', '7', '0.1'])
+    subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'export', os.path.join(tmp, 'wide.model'),
+                           os.path.join(tmp, 'wide.img')], stderr=subprocess.DEVNULL)
+    lines = ['かきをかきかきとかきく', 'あかきい', 'かき']
+    txt = os.path.join(tmp, 'wide.txt')
+    open(txt, 'w', encoding='utf-8').write('\n'.join(lines) + '\n')
+    with open(txt, 'rb') as f:
+        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', os.path.join(tmp, 'wide.model'),
+                               os.path.join(tmp, 'wide.gold')] + [str(x) for x in beams], stdin=f, stderr=subprocess.DEVNULL)
+    return os.path.join(tmp, 'wide.img'), lines, os.path.join(tmp, 'wide.gold')
+
+
+@pytest.mark.parametrize('beams', [[5, 6, 1, 5], [5, 6, 3, 5], [20, 24, 1, 20]])
+def test_emulated_lattice_wider_than_the_lds_staging(emu_lib, ref_tools, tmp_path, beams):
+    """> 512 nodes starting at one boundary: the reference has no such limit (lattice_builder.cc:70-93);
+    k_sweep<*, 0> keeps the per-right-node arrays in HBM instead of failing the sentence."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _wide_boundary_workload(ref_tools, str(tmp_path), beams)
+    ctx = J.Context(img, lib_path=emu_lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    assert list(res.status) == [0, 0, 0]
+    assert int(res.bnd_count.max()) > 512
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     # reference: invalid UTF-8 -> InvalidParameter (characters.cc:267-269);

@@ -296,3 +296,18 @@ def test_gpu_nbest_fetch_equals_full_lattice(gpu_lib, golden_dir):
     lines = [l.rstrip('\n').encode('utf-8') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
     lines = (lines + [b'', b'\xe3\x81']) * 50
     assert tc.check_nbest_fetch_equals_full_lattice(ctx, lines, 5) > 50000
+
+
+@pytest.mark.parametrize('beams', [[5, 6, 1, 5], [20, 24, 2, 20]])
+def test_gpu_lattice_wider_than_the_lds_staging(gpu_lib, ref_tools, tmp_path, beams):
+    """> 512 nodes starting at one boundary (k_sweep<*, 0>: per-right-node arrays in HBM) vs the live reference"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    img, lines, gold_path = tc._wide_boundary_workload(ref_tools, str(tmp_path), beams, n_homographs=700)
+    ctx = J.Context(img, lib_path=gpu_lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    assert list(res.status) == [0, 0, 0] and int(res.bnd_count.max()) > 512
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, errs[:10]
