@@ -684,7 +684,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(2, st);
   JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg);
   T.mark(3, st);
-  JPP_LAUNCH(k_t0, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   B.node_penalty = nullptr;
   if (ctx->partial_pending) {
     ctx->partial_pending = false;
@@ -724,7 +725,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   } else if (unbounded) {
     JPP_LAUNCH((k_sweep<32, 0>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow && maxR <= 64 && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5) {
-    JPP_LAUNCH((k_sweep<8, 64, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);   // the CLI defaults
+    // the CLI defaults; weight tables of up to 2^24 entries get the 24-bit index arithmetic
+    if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH((k_sweep<8, 64, true, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    else JPP_LAUNCH((k_sweep<8, 64, true, false>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow && maxR <= 64 && ctx->cfg.rcheck <= 2) {
     JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow) {

@@ -81,13 +81,14 @@ struct LaneBi {
 
 // weights of this lane's bigram features for one (right node, T1 row) pair, from the cached first-stage
 // states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
+template <bool W24>
 __device__ __forceinline__ void bi_gather_s1(const LaneBi& t, int j, const u64* s1, const u64* t1r,
                                              const float JPP_GLOBAL* __restrict__ W, u32 wmask, bool act, float* w) {
   u32 idx[kBiPerLane];
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
     const int k = (j + 8 * m) < spec::kNumBi ? (j + 8 * m) : 0;
-    idx[m] = (u32)hmix(s1[k], t1r[JPP_LBI_T1(t, m, j)]) & wmask;
+    idx[m] = hmix_index<W24>(s1[k], t1r[JPP_LBI_T1(t, m, j)], wmask);
   }
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? W[idx[m]] : 0.f;
@@ -214,7 +215,8 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // DEF: the configuration is the CLI default (beam 5, global beam 6, right-check 1, right-beam 5,
 // jumanpp_args.h:50-54): the four numbers become compile-time constants (no runtime divisions by the beam
 // size, fixed trip counts); any other configuration runs the same code with the values read from `cfg`.
-template <int GM, int RM, bool DEF = false>
+// W24: the weight table has at most 2^24 entries (hmix_index).
+template <int GM, int RM, bool DEF = false, bool W24 = false>
 __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
@@ -267,13 +269,18 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     order = reinterpret_cast<u16*>(csum + B.sweep_scratch_maxr);           // [maxR]
   }
   __shared__ float biS[kChunk][GM];
+  // default configuration: tail-association bigram sum of (right node t, T1 row 0), formed in the prescore pass
+  constexpr bool kHeadShare = DEF && RM > 0;
+  __shared__ float biS0[kHeadShare ? RM : 1];
   __shared__ float tot[kChunk][GM];
-  __shared__ u8 sidx[GM > 16 ? kChunk : 1][GM];   // index arrays of the makeT0Beam replay (wide variant, ties only)
+  // makeT0Beam replay (wide variant, ties only): (total bits << 32 | candidate index) per candidate, so that a
+  // comparison of the step-by-step sort costs one LDS read per side instead of two dependent ones
+  __shared__ u64 skey[GM > 16 ? kChunk : 1][GM];
   __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass (R > kChunk only)
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
   // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
-  constexpr int kCandCap = GM <= 8 ? 64 : 256;
+  constexpr int kCandCap = GM <= 8 ? 64 : 512;   // candidate slots (left nodes x beam) staged in LDS per boundary
   __shared__ __attribute__((aligned(16))) u64 pRn[2][kChunk][kPat];
   __shared__ __attribute__((aligned(16))) float t0n[2][kChunk];
   constexpr u32 kEnnCap = GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
@@ -337,14 +344,18 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     if (q < metaReady) return meta[q & (kRing - 1)];
     return load_bnd_meta(gmeta, q);
   };
-  auto next_nonempty = [&](u32 from) {
+  // the next boundary at or after `from` where nodes start, and its record (read once, carried into the
+  // prefetch and into the next iteration)
+  auto next_nonempty = [&](u32 from, BndMeta& out) {
     u32 q = from;
-    while (q <= n + 2 && metaAt(q).cnt == 0) ++q;
+    for (; q <= n + 2; ++q) {
+      out = metaAt(q);
+      if (out.cnt != 0) break;
+    }
     return q;
   };
-  auto prefetch = [&](u32 bq, int buf) {
+  auto prefetch = [&](u32 bq, const BndMeta& mq, int buf) {
     if (bq > n + 2) return;
-    const BndMeta mq = metaAt(bq);
     const u32 Rq = mq.cnt, rf = mq.first, Lq = mq.ecnt, ef = mq.efirst;
     const u32 nxr = Rq < (u32)kChunk ? Rq : (u32)kChunk;
     static_assert(kPat * 8 % 16 == 0 && kChunk * kPat * 8 / 16 <= 64, "one dwordx4 per lane covers a chunk");
@@ -363,9 +374,10 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     }
   };
   JPP_PROF_DECL;
-  u32 bn = next_nonempty(2);
+  BndMeta mbn{0, 0, 0, 0};
+  u32 bn = next_nonempty(2, mbn);
   int par = 0;
-  prefetch(bn, par);
+  prefetch(bn, mbn, par);
   lds_async_wait();
   for (u32 b = bn; b <= n + 2; b = bn, par ^= 1) {
     // The records / rows requested during the previous boundary are needed from here on.  They were
@@ -373,7 +385,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     // in order, so the waits of phases 1-2 have covered them: no wait here -- it would only drain the beam
     // and cell stores the previous boundary has just issued (every path that skips those phases waits itself).
     wave_sync();
-    const BndMeta mb = metaAt(b);
+    const BndMeta mb = mbn;
     const u32 R = mb.cnt;
     const u32 rfirst = mb.first;
     const u32 L = mb.ecnt;
@@ -385,7 +397,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     // the previous requests have landed (wait above); boundaries below b are done: recycle their ring
     // slots for the records up to 63 ahead
     metaReady = metaEnd;
-    if (metaEnd < n + 3 && metaEnd < b + kRing) {
+    if (metaEnd < n + 3 && metaEnd <= b + kRing / 2) {   // refill when half of the window is used up
       const u32 lo = metaEnd, hi = (b + kRing) < (n + 3) ? (b + kRing) : (n + 3);
       // slots lo..hi-1 (mod 64) may wrap: issue the two contiguous pieces separately
       const u32 s0 = lo & (kRing - 1), cntAll = hi - lo;
@@ -394,8 +406,8 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       lds_async_load<16>(&meta[0], gmeta + lo + c0 + lane, (u32)lane < cntAll - c0);
       metaEnd = hi;
     }
-    bn = next_nonempty(b + 1);
-    prefetch(bn, par ^ 1);
+    bn = next_nonempty(b + 1, mbn);
+    prefetch(bn, mbn, par ^ 1);
     const u32* enL = enn[par];  // ends list of this boundary (first 64 entries)
 
     JPP_PROF(0);
@@ -570,15 +582,22 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         const u64* t1r = t1pat[gb_t1[i]];
         const u64* t2r = t2pat[i];
         float w[kBiPerLane];
-        bi_gather_s1(lbi, gj, s1b[xr], t1r, W, wmask, act, w);
+        bi_gather_s1<W24>(lbi, gj, s1b[xr], t1r, W, wmask, act, w);
         float g = 0.f;
         if (act && gj < spec::kNumTri) {
-          u32 idx = (u32)hmix(hmix(s1t[xr][gj], t1r[s_trit[gj][1]]), t2r[s_trit[gj][2]]) & wmask;
+          u32 idx = hmix_index<W24>(hmix(s1t[xr][gj], t1r[s_trit[gj][1]]), t2r[s_trit[gj][2]], wmask);
           g += W[idx];
         }
         // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
         const float b8 = bi_sum8(w, lane, gj);
         const float b4 = bi_sum4(w, lane, gj);
+        if constexpr (kHeadShare) {
+          // The tail (5a) adds up the same 37 weights of (right node, T1 row 0) again, only in the
+          // association of applyBiTriFullKernel: form that sum here, from the weights already gathered,
+          // and 5a skips row 0 (with one head entry, c == 1, its row is always row 0).
+          const float tailS = (U == 1) ? b4 : bi_sum2(w, lane, gj);   // row 0 is the last T1 row iff U == 1
+          if (act && gj == 0) biS0[t] = tailS;
+        }
         static_assert(spec::kNumTri == 4, "the trigram sum below reads group members 1..3");
         float tsum = g;
         tsum += row_shl_f32<1>(g);
@@ -659,14 +678,17 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       auto t0Of = [&](int x) -> float { return small ? t0n[par][order[op0 + x]] : t0R[x]; };
       // 5a. bigram sums per (kept node, unique T1 row) -- applyBiTriFullKernel rows
       if (ntail > 0) {
-        const int units = nx * U;
+        // (kHeadShare: row 0 came out of the prescore pass, the units cover rows 1 .. U-1)
+        const int Ur = kHeadShare ? U - 1 : U;
+        const int units = nx * Ur;
         for (int base = 0; base < units; base += 8) {
           int u = base + grp;
           bool act = u < units;
-          int x = act ? u / U : 0, tu = act ? u - x * U : 0;
+          int x = act ? u / Ur : 0, tu = act ? u - x * Ur : 0;
+          if (kHeadShare) tu += 1;
           act = act && (op0 + x) < K;
           float w[kBiPerLane];
-          bi_gather_s1(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w);
+          bi_gather_s1<W24>(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w);
           const float s2 = bi_sum2(w, lane, gj);
           const float s4 = bi_sum4(w, lane, gj);
           if (act && gj == 0) biS[x][tu] = (tu == U - 1) ? s4 : s2;
@@ -695,11 +717,13 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
           float w[spec::kNumTri];
 #pragma unroll
           for (int f = 0; f < spec::kNumTri; ++f) {
-            u32 idx = (u32)hmix(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]]) & wmask;
+            u32 idx = hmix_index<W24>(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]], wmask);
             w[f] = W[idx];
           }
           static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
-          float S = biS[x][gb_t1[i]];
+          float S;
+          if (kHeadShare && gb_t1[i] == 0) S = biS0[t];
+          else S = biS[x][gb_t1[i]];
           float res;
           if (i < ngb - 1) {
             float r1 = 0.f, r2 = 0.f;
@@ -769,17 +793,32 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
           const bool replay = wide && ((tb >> (lane & 32)) & 0xffffffffull) != 0;
           if (replay) {
             if (i == 0) {
-              u8* idx = sidx[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
-              for (int z = 0; z < cnt; ++z) idx[z] = (u8)z;
+              u64* keys = skey[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
               const float* tr = tot[x];
-              auto comp = [tr](u8 a, u8 bb) { return tr[a] > tr[bb]; };
-              u8* itr = idx + cnt;
-              if (cnt > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
-              std_sort(idx, itr, comp);
-              const int have = (int)(itr - idx);
+              for (int z = 0; z < cnt; ++z) {
+                u32 bits;
+                __builtin_memcpy(&bits, &tr[z], 4);
+                keys[z] = ((u64)bits << 32) | (u32)z;
+              }
+              // the reference sorts indices with `scores[i1] > scores[i2]`: the same predicate on the packed totals
+              auto comp = [](u64 a, u64 bb) {
+                const u32 xa = (u32)(a >> 32), xb = (u32)(bb >> 32);
+                float fa, fb;
+                __builtin_memcpy(&fa, &xa, 4);
+                __builtin_memcpy(&fb, &xb, 4);
+                return fa > fb;
+              };
+              u64* itr = keys + cnt;
+              if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
+              std_sort(keys, itr, comp);
+              const int have = (int)(itr - keys);
               for (int z = 0; z < beam; ++z) {
-                if (z < have) row[z] = BeamSlot{gb_left[idx[z]], gb_slot[idx[z]], tr[idx[z]], gb_lnode[idx[z]], (u32)idx[z]};
-                else row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+                if (z < have) {
+                  const u32 iz = (u32)keys[z] & 0xffu;
+                  row[z] = BeamSlot{gb_left[iz], gb_slot[iz], tr[iz], gb_lnode[iz], iz};
+                } else {
+                  row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+                }
               }
             }
           } else if (i < cnt) {

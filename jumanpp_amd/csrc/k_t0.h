@@ -39,6 +39,7 @@ __host__ __device__ constexpr u64 tri_prefix(int index) {
   return hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)index), kTrigramSeed);
 }
 
+template <bool W24>   // W24: at most 2^24 weights (hmix_index)
 __global__ void k_t0(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
@@ -154,7 +155,7 @@ __global__ void k_t0(Batch B, const DevModel* __restrict__ Mp) {
     float w[spec::kNumUni];
 #pragma unroll
     for (int u = 0; u < spec::kNumUni; ++u) {
-      u32 idx = (u32)hmix(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0]) & M.wmask;
+      u32 idx = hmix_index<W24>(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0], M.wmask);
       w[u] = as_global(M.weights)[idx];
     }
     float part[4];
