@@ -219,6 +219,50 @@ __device__ inline void std_sort(T* first, T* last, C comp) {
 }
 
 
+// The partitioning half of std_sort above, without the final insertion pass.  libstdc++'s
+// __final_insertion_sort is a STABLE sort of whatever the introsort loop leaves (strict comparisons, elements
+// only move past strictly smaller ones), so std::sort(first, last) == stable_sort(the array as partitioned):
+// a caller that can rank in parallel runs only this serial part -- a handful of Hoare partitions for the
+// 17..32 candidates of a beam -- and then takes "number of greater elements + number of equal elements at
+// smaller positions" as the final position.  Returns false if the depth limit was hit (heap-sort fallback,
+// which is not stable): the caller then has to replay std_sort in full.
+template <typename T, typename C>
+__device__ inline bool std_sort_partition_only(T* first, T* last, C comp) {
+  if (first == last) return true;
+  long n = last - first;
+  long lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  T* stF[24];
+  T* stL[24];
+  long stD[24];
+  int sp = 0;
+  stF[sp] = first;
+  stL[sp] = last;
+  stD[sp] = lg * 2;
+  ++sp;
+  while (sp > 0) {
+    --sp;
+    T* f = stF[sp];
+    T* l = stL[sp];
+    long depth = stD[sp];
+    while (l - f > 16) {
+      if (depth == 0) return false;
+      --depth;
+      T* mid = f + (l - f) / 2;
+      sel_move_median_to_first(f, f + 1, mid, l - 1, comp);
+      T* cut = sel_unguarded_partition(f + 1, l, f, comp);
+      if (sp < 24) {
+        stF[sp] = cut;
+        stL[sp] = l;
+        stD[sp] = depth;
+        ++sp;
+      }
+      l = cut;
+    }
+  }
+  return true;
+}
+
 // util::part_step / util::partition (src/util/stl_util.h:51-135): the quickselect makeT0Beam runs when
 // it has more than beam*4/3 candidates; returns the end of the part that is then std::sort-ed.
 template <typename T, typename C>

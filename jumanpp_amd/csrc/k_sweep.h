@@ -276,6 +276,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   // makeT0Beam replay (wide variant, ties only): (total bits << 32 | candidate index) per candidate, so that a
   // comparison of the step-by-step sort costs one LDS read per side instead of two dependent ones
   __shared__ u64 skey[GM > 16 ? kChunk : 1][GM];
+  __shared__ u8 shave[GM > 16 ? kChunk : 1];   // per node of the pass: length of the sorted range | 0x80 if already in final order
   __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass (R > kChunk only)
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
@@ -453,16 +454,41 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
           ngb = live < G ? live : G;
           if (me != 0 && rank < (u32)G) gb_key[rank] = me;
         } else {
-          for (int r = 0; r < G; ++r) {
-            u64 best = 0;
+          // More than 64 candidates (wide beams): the G-th largest key by a bitwise threshold search -- per
+          // bit one compare per register-resident key and a ballot count, no cross-lane reduction chain --
+          // then the selected keys are compacted and ranked among themselves (the keys are unique).
+          int live = 0;
 #pragma unroll
-            for (int jx = 0; jx < kCandCap / 64; ++jx)
-              if (mykey[jx] < last && mykey[jx] > best) best = mykey[jx];
-            u64 win = wave_max_u64(best);
-            if (win == 0) break;
-            if (lane == 0) gb_key[r] = win;
-            last = win;
-            ++ngb;
+          for (int jx = 0; jx < kCandCap / 64; ++jx) live += popc64(wave_ballot(mykey[jx] != 0));
+          ngb = live < G ? live : G;
+          u64 thr = 1;   // every live key is >= 1
+          if (live > G) {
+            thr = 0;
+            // bits that can be set in a key: 63..32 total, 16 + log2(kEnnCap).. 16 left index, 4..0 (beam <= 32) slot
+            for (int bit = 63; bit >= 0; --bit) {
+              if (bit < 32 && !((bit >= 16 && bit <= 22) || bit <= 5)) continue;
+              const u64 c2 = thr | (u64{1} << bit);
+              int cntGe = 0;
+#pragma unroll
+              for (int jx = 0; jx < kCandCap / 64; ++jx) cntGe += popc64(wave_ballot(mykey[jx] >= c2));
+              if (cntGe >= G) thr = c2;
+            }
+          }
+          // compaction: position = number of selected keys in earlier registers / lower lanes
+          int base = 0;
+#pragma unroll
+          for (int jx = 0; jx < kCandCap / 64; ++jx) {
+            const bool sel = mykey[jx] != 0 && mykey[jx] >= thr;
+            const u64 m = wave_ballot(sel);
+            if (sel) ckey[base + popc64(m & ((u64{1} << lane) - 1))] = mykey[jx];
+            base += popc64(m);
+          }
+          wave_sync();
+          if (lane < ngb) {
+            const u64 me = ckey[lane];
+            u32 rank = 0;
+            for (int z = 0; z < ngb; ++z) rank += ckey[z] > me ? 1u : 0u;
+            gb_key[rank] = me;
           }
         }
       } else {
@@ -791,36 +817,67 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
           }
           const u64 tb = wave_ballot(wide && tie);
           const bool replay = wide && ((tb >> (lane & 32)) & 0xffffffffull) != 0;
-          if (replay) {
-            if (i == 0) {
-              u64* keys = skey[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
-              const float* tr = tot[x];
+          // Ties: one lane replays the partitioning steps of the reference's sort (util::partition beyond
+          // beam*4/3, then the Hoare partitions of introsort while a range is longer than 16).  What follows
+          // in std::sort is libstdc++'s final insertion pass, a STABLE sort of the array as partitioned -- i.e.
+          // a rank again: greater totals first, equal totals in their order after partitioning -- taken in
+          // parallel by the node's 32 lanes below (std_sort_partition_only, jpp_select.h).
+          if (replay && i == 0) {
+            u64* keys = skey[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
+            const float* tr = tot[x];
+            // the reference sorts indices with `scores[i1] > scores[i2]`: the same predicate on the packed totals
+            auto comp = [](u64 a, u64 bb) {
+              const u32 xa = (u32)(a >> 32), xb = (u32)(bb >> 32);
+              float fa, fb;
+              __builtin_memcpy(&fa, &xa, 4);
+              __builtin_memcpy(&fb, &xb, 4);
+              return fa > fb;
+            };
+            auto fill = [&]() {
               for (int z = 0; z < cnt; ++z) {
                 u32 bits;
                 __builtin_memcpy(&bits, &tr[z], 4);
                 keys[z] = ((u64)bits << 32) | (u32)z;
               }
-              // the reference sorts indices with `scores[i1] > scores[i2]`: the same predicate on the packed totals
-              auto comp = [](u64 a, u64 bb) {
-                const u32 xa = (u32)(a >> 32), xb = (u32)(bb >> 32);
-                float fa, fb;
-                __builtin_memcpy(&fa, &xa, 4);
-                __builtin_memcpy(&fb, &xb, 4);
-                return fa > fb;
-              };
-              u64* itr = keys + cnt;
+            };
+            fill();
+            u64* itr = keys + cnt;
+            if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
+            bool sorted = false;
+            if (!std_sort_partition_only(keys, itr, comp)) {
+              // depth limit of introsort hit (heap-sort fallback, not stable): replay all of it from the start
+              fill();
+              itr = keys + cnt;
               if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
               std_sort(keys, itr, comp);
-              const int have = (int)(itr - keys);
-              for (int z = 0; z < beam; ++z) {
-                if (z < have) {
-                  const u32 iz = (u32)keys[z] & 0xffu;
-                  row[z] = BeamSlot{gb_left[iz], gb_slot[iz], tr[iz], gb_lnode[iz], iz};
-                } else {
-                  row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+              sorted = true;
+            }
+            shave[x] = (u8)((itr - keys) | (sorted ? 0x80 : 0));
+          }
+          wave_sync();
+          if (replay) {
+            const int have = shave[x] & 0x7f;
+            const bool sorted = (shave[x] & 0x80) != 0;
+            if (i < have) {
+              const u64 mine = skey[x][i];
+              const u32 vb = (u32)(mine >> 32);
+              float mv;
+              __builtin_memcpy(&mv, &vb, 4);
+              int pos = i;
+              if (!sorted) {
+                pos = 0;
+                for (int p2 = 0; p2 < have; ++p2) {
+                  const u32 ob = (u32)(skey[x][p2] >> 32);
+                  float ov;
+                  __builtin_memcpy(&ov, &ob, 4);
+                  if (ov > mv || (ov == mv && p2 < i)) ++pos;
                 }
               }
+              const u32 iz = (u32)mine & 0xffu;
+              if (pos < beam) row[pos] = BeamSlot{gb_left[iz], gb_slot[iz], mv, gb_lnode[iz], iz};
             }
+            // slots beyond the sorted range stay fake (have >= beam whenever util::partition ran)
+            if (i >= have && i < beam) row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
           } else if (i < cnt) {
             if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
           } else if (i < beam) {

@@ -308,6 +308,56 @@ int main() {
     assert int(out[-1]) == 0, out
 
 
+def test_std_sort_is_partitioning_plus_a_stable_rank(tmp_path):
+    """k_sweep<32,*> 5c with ties: libstdc++'s std::sort = the introsort partitions followed by a final
+    insertion pass that is a stable sort of the partitioned array.  The kernel replays only the partitions
+    serially (std_sort_partition_only) and ranks in parallel; here that is checked against std::sort itself
+    on tie-heavy inputs (and the heap-sort fallback is reported, not mis-sorted)."""
+    src = tmp_path / 'ps.cc'
+    src.write_text(r'''
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "jpp_select.h"
+int main() {
+  std::mt19937 rng(4242);
+  long bad = 0, cases = 0, fallback = 0;
+  for (int n = 1; n <= 64; ++n) {
+    for (int rep = 0; rep < 400; ++rep) {
+      int levels = 1 + rng() % (rep % 3 == 0 ? 3 : rep % 3 == 1 ? 8 : 40);
+      std::vector<float> sc(n);
+      for (auto& x : sc) x = (float)(rng() % levels) * 0.5f - 1.f;
+      std::vector<unsigned> ref(n);
+      for (int i = 0; i < n; ++i) ref[i] = i;
+      std::sort(ref.begin(), ref.end(), [&](unsigned a, unsigned b) { return sc[a] > sc[b]; });
+      std::vector<u64> keys(n);
+      for (int i = 0; i < n; ++i) { u32 bits; memcpy(&bits, &sc[i], 4); keys[i] = ((u64)bits << 32) | (u32)i; }
+      auto comp = [](u64 a, u64 b) { u32 xa = (u32)(a >> 32), xb = (u32)(b >> 32); float fa, fb; memcpy(&fa, &xa, 4); memcpy(&fb, &xb, 4); return fa > fb; };
+      ++cases;
+      if (!jpp::std_sort_partition_only(keys.data(), keys.data() + n, comp)) { ++fallback; continue; }
+      std::vector<unsigned> mine(n);
+      for (int i = 0; i < n; ++i) {
+        u32 vb = (u32)(keys[i] >> 32); float mv; memcpy(&mv, &vb, 4);
+        int pos = 0;
+        for (int p = 0; p < n; ++p) { u32 ob = (u32)(keys[p] >> 32); float ov; memcpy(&ov, &ob, 4); if (ov > mv || (ov == mv && p < i)) ++pos; }
+        mine[pos] = (unsigned)(keys[i] & 0xff);
+      }
+      if (mine != ref) ++bad;
+    }
+  }
+  printf("%ld %ld %ld\n", cases, bad, fallback);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / 'ps'
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-DJPP_EMU', '-I', os.path.join(ROOT, 'tests', 'emu'),
+                           '-I', os.path.join(ROOT, 'jumanpp_amd', 'csrc'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) > 20000 and int(out[1]) == 0 and int(out[2]) < int(out[0]) // 20, out
+
+
 def test_make_t0_beam_is_a_rank_when_totals_are_distinct(tmp_path):
     """k_sweep<32,512> 5c / remakeEosBeam fast path: with pairwise distinct totals, util::partition
     (beyond beam*4/3) followed by std::sort (introsort beyond 16) yields the first `beam` entries of the
