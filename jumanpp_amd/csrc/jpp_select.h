@@ -263,6 +263,31 @@ __device__ inline bool std_sort_partition_only(T* first, T* last, C comp) {
   return true;
 }
 
+// The same for at most 32 elements, without the explicit stack (a private array would live in scratch memory
+// on the device, one HBM round trip per push and pop).  With n <= 32 at most one side of a partition is longer
+// than 16, and a side of 16 or fewer elements is not touched again before the final insertion pass, so the
+// recursion of __introsort_loop degenerates to "partition the one long range that is left"; the depth budget
+// shrinks by one per partition on either side, exactly as in the recursive form.
+template <typename T, typename C>
+__device__ inline bool std_sort_partition_only_le32(T* first, T* last, C comp) {
+  long n = last - first;
+  long lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  long depth = lg * 2;
+  T* f = first;
+  T* l = last;
+  while (l - f > 16) {
+    if (depth == 0) return false;
+    --depth;
+    T* mid = f + (l - f) / 2;
+    sel_move_median_to_first(f, f + 1, mid, l - 1, comp);
+    T* cut = sel_unguarded_partition(f + 1, l, f, comp);
+    if (l - cut > 16) f = cut;   // the right part is the long one (the left one is then short: done)
+    else l = cut;                // otherwise carry on with the left part
+  }
+  return true;
+}
+
 // util::part_step / util::partition (src/util/stl_util.h:51-135): the quickselect makeT0Beam runs when
 // it has more than beam*4/3 candidates; returns the end of the part that is then std::sort-ed.
 template <typename T, typename C>

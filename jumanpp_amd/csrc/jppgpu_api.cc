@@ -732,6 +732,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow) {
     JPP_LAUNCH((k_sweep<8, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+  } else if (maxR <= 64 && ctx->cfg.rcheck <= 2) {   // 6 KB less LDS per wavefront than the 512-wide staging
+    JPP_LAUNCH((k_sweep<32, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else {
     JPP_LAUNCH((k_sweep<32, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   }

@@ -844,7 +844,8 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
             u64* itr = keys + cnt;
             if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
             bool sorted = false;
-            if (!std_sort_partition_only(keys, itr, comp)) {
+            static_assert(GM <= 32, "stackless partition replay covers at most 32 candidates");
+            if (!std_sort_partition_only_le32(keys, itr, comp)) {
               // depth limit of introsort hit (heap-sort fallback, not stable): replay all of it from the start
               fill();
               itr = keys + cnt;

@@ -336,6 +336,13 @@ int main() {
       for (int i = 0; i < n; ++i) { u32 bits; memcpy(&bits, &sc[i], 4); keys[i] = ((u64)bits << 32) | (u32)i; }
       auto comp = [](u64 a, u64 b) { u32 xa = (u32)(a >> 32), xb = (u32)(b >> 32); float fa, fb; memcpy(&fa, &xa, 4); memcpy(&fb, &xb, 4); return fa > fb; };
       ++cases;
+      if (n <= 32) {  // the stackless form the kernel uses must leave the same array
+        std::vector<u64> k2(keys);
+        bool ok2 = jpp::std_sort_partition_only_le32(k2.data(), k2.data() + n, comp);
+        std::vector<u64> k1(keys);
+        bool ok1 = jpp::std_sort_partition_only(k1.data(), k1.data() + n, comp);
+        if (ok1 != ok2 || (ok1 && k1 != k2)) ++bad;
+      }
       if (!jpp::std_sort_partition_only(keys.data(), keys.data() + n, comp)) { ++fallback; continue; }
       std::vector<unsigned> mine(n);
       for (int i = 0; i < n; ++i) {

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--len', type=int, default=220)
     ap.add_argument('--ref-sample', type=int, default=200)
+    ap.add_argument('--device-only', action='store_true', help='only the device-resident measurement (for rocprofv3 runs)')
     a = ap.parse_args()
     args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, rnn=True, rnn_hidden=128,
                               rnn_vocab=30000, sent_len=a.len)
@@ -61,6 +62,8 @@ def main():
     print('kernel ms/step:', {k: round(v, 2) for k, v in ms.items()})
     r.release()
     del ctx
+    if a.device_only:
+        return
     # CLI, lattice output
     import __graft_entry__ as ge
     cli = ge.build_host()
