@@ -317,6 +317,66 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
         return {'error': str(e)[:200]}
 
 
+def config5_leg(args, cache, local_rank, np, torch, J):
+    """BASELINE configs[4] on one GPU (never `value`): beam = global beam = right beam = 32, right-check 1,
+    220-codepoint sentences, RNNLM on, 4,096 sentences per batch, same model as the headline.  Reports the
+    device-resident rate and the roofline of its dominant kernel (k_sweep<32, *>); the algorithmic bytes come
+    from the fully fetched lattice of the first 256 sentences, scaled by the node count."""
+    import copy
+    try:
+        a = copy.copy(args)
+        a.sent_len = 220
+        batch = 4096
+        mdic, model, img = make_workload(a, cache)
+        corpus = make_corpus(a, mdic, cache, batch * 2, 31)
+        batches = load_batches(corpus, batch, np)
+        dev = torch.device('cuda', local_rank)
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx = J.Context(img, beam=32, global_beam=32, right_check=1, right_beam=32, device=local_rank,
+                        use_rnn=None if args.rnn else False)
+        d = [(torch.frombuffer(bytearray(tx), dtype=torch.uint8).to(dev),
+              torch.from_numpy(of.astype(np.int32)).to(dev), len(of) - 1, len(tx)) for tx, of in batches]
+
+        def run(i):
+            tt, oo, n, nbytes = d[i % len(d)]
+            return ctx.analyze_device(tt.data_ptr(), oo.data_ptr(), n, nbytes, stream)
+        run(0).release()
+        run(1).release()
+        torch.cuda.synchronize()
+        k = 4
+        km = {}
+        t0 = time.perf_counter()
+        for i in range(k):
+            r = run(i)
+            torch.cuda.synchronize()
+            for kk, v in ctx.timings().items():
+                km[kk] = km.get(kk, 0.0) + v / k
+            r.release()
+        el = time.perf_counter() - t0
+        r = run(0).fetch()
+        nodes = float(r.nnodes.sum())
+        bad = int((r.status != 0).sum())
+        r.release()
+        # algorithmic bytes of k_sweep from a fully fetched sub-batch
+        sub = 256
+        lines = open(corpus, 'rb').read().split(b'\n')[:sub]
+        rs = ctx.analyze(lines).fetch(full=True)
+        ab = algorithmic_bytes(rs, 32, 32, 1, 32, np)
+        rs.release()
+        sweep_bytes = ab['sweep'] * nodes / max(1.0, ab['nodes'])
+        ach = sweep_bytes / (km['sweep'] * 1e-3) / 1e9
+        return {'workload': 'BASELINE configs[4] shape, one GPU: beam=gbeam=rbeam=32 rcheck=1, %d sentences x 220 codepoints '
+                            'per step, perceptron + RNNLM' % batch,
+                'value': round(batch * k / el, 1), 'unit': 'sentences/s', 'steps': k, 'ms_per_step': round(el / k * 1e3, 3),
+                'nodes_per_sentence': round(nodes / batch, 1), 'failed_sentences_in_batch': bad,
+                'kernel_ms_per_step': {kk: round(v, 3) for kk, v in km.items()},
+                'roofline': {'bound': 'hbm', 'kernel': 'k_sweep<32,*>', 'achieved': round(ach, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': round(ach / 8000.0, 5), 'algorithmic_bytes_per_launch': int(sweep_bytes),
+                             'avg_launch_ms': round(km['sweep'], 3)}}
+    except Exception as e:  # an extra leg must never take the main line down
+        return {'error': str(e)[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -330,6 +390,8 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='skip the extra two-batches-in-flight measurement')
+    ap.add_argument('--no-config5', action='store_true',
+                    help="skip the BASELINE configs[4] leg (beam 32, 220-codepoint sentences, one GPU's share)")
     ap.add_argument('--no-cli', action='store_true', help='skip the end-to-end jumanpp_gpu run (file in, JUMAN text out)')
     ap.add_argument('--no-realism', action='store_true',
                     help='skip the extra workload legs (1M-entry dictionary, 2^24 and 2^26 weights; SURVEY 8(d))')
@@ -558,6 +620,8 @@ def main():
             del ctx
             torch.cuda.empty_cache()
             out['cli_end_to_end'] = cli_end_to_end(args, model, corpus, args.batch * len(batches), ge)
+        if not args.no_config5 and world == 1:
+            out['config5'] = config5_leg(args, cache, local_rank, np, torch, J)
         if not args.no_realism and world == 1:
             out['realism'] = realism_legs(args, cache, local_rank, np, torch, J)
         if not args.no_cpu_baseline and world == 1:

@@ -20,6 +20,8 @@
  *       src/jumandic/shared/lattice_format.cc:13-43,129-141             -> jppgpu_result_fetch_nbest
  *   ScorePlugin (partial annotation)  src/core/analysis/score_plugin.h:14-19,
  *       src/core/input/partial_example.cc                                -> jppgpu_analyze_batch_partial
+ *   ScorePlugin::updateScore as an extension point (any right-node-dependent plugin)
+ *       src/core/analysis/score_plugin.h:14-19, score_processor.cc:578-613 -> jppgpu_analyze_batch_plugin
  *   AnalyzerImpl::setGlobalBeam / autoBeamSizes  analyzer_impl.cc:311-361 -> jppgpu_ctx_set_beams
  *   Status kinds returned by analyze()
  *       analysis_input.cc:12-33, characters.cc:267-269, analyzer_impl.cc:133-135 -> status codes
@@ -233,6 +235,32 @@ typedef struct {
 /* Analyzer::analyze(input, ScorePlugin*) with the partial-annotation plugin (analyzer.cc:45-53) */
 int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
                                  const jppgpu_partial* partial, jppgpu_result** out);
+
+/* The ScorePlugin extension point itself (src/core/analysis/score_plugin.h:14-19): the reference calls
+ * ScorePlugin::updateScore(lattice, connection, &score) for every connection it scores
+ * (applyPluginToPrescores / applyPluginToGbeam, score_processor.cc:578-613).  A device kernel cannot call
+ * back into host code per connection; the batched form of the hook is: the lattice is built (nodes, UNK
+ * records, entry rows), the plugin sees it once per batch on the host and fills `penalty[node]`, and that
+ * amount is subtracted from the score of EVERY connection into the node, at the two places the reference
+ * applies its plugin.  This covers every plugin whose adjustment depends on the right node of the connection
+ * only -- the partial-annotation plugin above is one (PartialExample::checkViolation looks at nothing else)
+ * and jppgpu_analyze_batch_partial is its device-side specialisation.  With global_beam == 0 the hook has no
+ * effect, as in the reference (analyzer_impl.cc:236-238). */
+typedef struct {
+  uint32_t n_sentences;
+  int32_t num_features;            /* width of an entry row */
+  const int32_t* status;           /* [n_sentences] JPPGPU_SENT_* so far (failed sentences have no nodes) */
+  const uint32_t* n_codepoints;    /* [n_sentences] */
+  const uint32_t* n_nodes;         /* [n_sentences] 0/1 = BOS, last = EOS */
+  const uint64_t* node_base;       /* [n_sentences] */
+  uint64_t total_nodes;
+  const jppgpu_node* nodes;        /* [total_nodes] */
+  const jppgpu_unk* unk;           /* [total_nodes] */
+  const int32_t* entry_rows;       /* [total_nodes][num_features] */
+} jppgpu_lattice_nodes;
+typedef void (*jppgpu_score_plugin_fn)(void* user, const jppgpu_lattice_nodes* lattice, float* penalty /* [total_nodes], zeroed */);
+int jppgpu_analyze_batch_plugin(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                jppgpu_score_plugin_fn plugin, void* user, jppgpu_result** out);
 
 int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                 uint32_t total_bytes, void* stream, jppgpu_result** out);

@@ -221,6 +221,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
+  if (B.sweep_redo && B.sweep_redo[s] == 0) return;   // second launch after k_sweep2: only the sentences it handed over
   const int lane = (int)threadIdx.x;
   const u32 off = B.byte_off[s];
   const u32 bb0 = off + 4 * s;

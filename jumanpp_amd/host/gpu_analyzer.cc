@@ -89,15 +89,90 @@ Status GpuAnalyzer::analyzeBatch(const std::vector<StringPiece>& inputs, bool fu
   return runBatch(inputs, fullLattice, nullptr);
 }
 
+namespace {
+
+// PexStreamReaderImpl::updateScore + PartialExample::checkViolation (pex_stream_reader.cc:24-39,
+// partial_example.cc:23-73) as a host-side ScorePlugin of the batched form: the same decision the device
+// makes in k_penalty, taken here per lattice node.  Used when JPPGPU_PARTIAL_VIA_PLUGIN is set (tests of the
+// generic plugin entry point); the default path evaluates the constraints on the device.
+class PartialExamplePlugin : public ScorePlugin {
+  const std::vector<const PartialExample*>& examples_;
+
+ public:
+  explicit PartialExamplePlugin(const std::vector<const PartialExample*>& ex) : examples_(ex) {}
+  void nodePenalties(const jppgpu_lattice_nodes& lat, const std::vector<uint32_t>& ids, float* penalty) override {
+    for (uint32_t s = 0; s < lat.n_sentences; ++s) {
+      const PartialExample* ex = examples_[ids[s]];
+      if (ex == nullptr) continue;
+      for (uint32_t k = 2; k < lat.n_nodes[s]; ++k) {
+        const jppgpu_node& nd = lat.nodes[lat.node_base[s] + k];
+        const int32_t boundary = (int32_t)nd.start + 2, len = (int32_t)nd.end - nd.start, end = boundary + len;
+        bool hard = false, tag = false, done = false;
+        for (int32_t b : ex->noBreak) {
+          if (b == boundary || b == end) {
+            hard = done = true;
+            break;
+          }
+          if (b > end) break;
+        }
+        if (!done)
+          for (int32_t b : ex->boundaries) {
+            if (b <= boundary) continue;
+            if (b >= end) break;
+            hard = done = true;
+            break;
+          }
+        if (!done)
+          for (const NodeConstraint& c : ex->nodes) {
+            if (c.boundary != boundary) continue;
+            if (len != c.length) hard = true;
+            else {
+              const int32_t* row = lat.entry_rows + (lat.node_base[s] + k) * (uint64_t)lat.num_features;
+              for (const TagConstraint& t : c.tags)
+                if (row[t.field] != t.value) {
+                  tag = true;
+                  break;
+                }
+            }
+            break;  // std::find_if: only the first constraint at that boundary counts
+          }
+        penalty[lat.node_base[s] + k] = hard ? 10000.f : (tag ? 1000.f : 0.f);
+      }
+    }
+  }
+};
+
+struct PluginCall {
+  ScorePlugin* plugin;
+  const std::vector<uint32_t>* ids;
+};
+
+void pluginTrampoline(void* user, const jppgpu_lattice_nodes* lattice, float* penalty) {
+  auto* c = static_cast<PluginCall*>(user);
+  c->plugin->nodePenalties(*lattice, *c->ids, penalty);
+}
+
+}  // namespace
+
+Status GpuAnalyzer::analyzeBatch(const std::vector<StringPiece>& inputs, ScorePlugin* plugin, bool fullLattice) {
+  return runBatch(inputs, fullLattice, nullptr, plugin);
+}
+
 Status GpuAnalyzer::analyzeBatchPartial(const std::vector<const PartialExample*>& examples, bool fullLattice) {
-  partial_.build(examples);
   partialExamples_ = examples;
   std::vector<StringPiece> inputs;
   for (auto e : examples) inputs.push_back(e ? StringPiece(e->surface) : StringPiece(""));
+  static const bool viaPlugin = std::getenv("JPPGPU_PARTIAL_VIA_PLUGIN") != nullptr;
+  if (viaPlugin) {
+    PartialExamplePlugin plugin(partialExamples_);
+    return runBatch(inputs, fullLattice, nullptr, &plugin);
+  }
+  partial_.build(examples);
   return runBatch(inputs, fullLattice, &partial_.view);
 }
 
-Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial) {
+Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial,
+                             ScorePlugin* plugin) {
   if (!ctx_) return Status::InvalidState("GpuAnalyzer was not initialized");
   releaseResult();
   inputs_ = inputs;
@@ -163,8 +238,10 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
     G.beam = beams[g];
     const uint32_t ng = (uint32_t)members[g].size();
     double t0 = now();
-    int rc = pg ? jppgpu_analyze_batch_partial(ctx_, text.data(), offsets.data(), ng, pg, &G.result)
-                : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
+    PluginCall call{plugin, &members[g]};
+    int rc = pg       ? jppgpu_analyze_batch_partial(ctx_, text.data(), offsets.data(), ng, pg, &G.result)
+             : plugin ? jppgpu_analyze_batch_plugin(ctx_, text.data(), offsets.data(), ng, pluginTrampoline, &call, &G.result)
+                      : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
     if (rc != JPPGPU_OK) return fromCode(rc);
     double t1 = now();
     tAnalyze += t1 - t0;

@@ -57,6 +57,18 @@ struct ScorerDef {
   std::vector<float> scoreWeights;
 };
 
+// core::analysis::ScorePlugin (score_plugin.h:14-19) in its batched form: the reference asks the plugin for
+// every scored connection (updateScore(lattice, connection, &score)); here the plugin sees the built lattice
+// of a batch once and says per node what every connection INTO that node loses (jppgpu_analyze_batch_plugin).
+class ScorePlugin {
+ public:
+  virtual ~ScorePlugin() = default;
+  // lattice.n_sentences sentences in the order of the batch (or of one beam group of it, see groupSentences);
+  // penalty[lattice.node_base[i] + k] belongs to node k of sentence i and arrives zeroed
+  virtual void nodePenalties(const jppgpu_lattice_nodes& lattice, const std::vector<uint32_t>& sentenceIds,
+                             float* penalty) = 0;
+};
+
 struct SentenceResult {
   StringPiece input;
   uint32_t numCodepoints = 0;
@@ -97,7 +109,8 @@ class GpuAnalyzer {
   std::string singleInput_;
   PartialBatch partial_;
   std::vector<const PartialExample*> partialExamples_;
-  Status runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial);
+  Status runBatch(const std::vector<StringPiece>& inputs, bool fullLattice, const jppgpu_partial* partial,
+                  ScorePlugin* plugin = nullptr);
 
   void releaseResult();
 
@@ -113,6 +126,9 @@ class GpuAnalyzer {
   Status analyze(StringPiece input);
   // n sentences, one launch sequence; a failing sentence does not fail the batch (see sentenceStatus)
   Status analyzeBatch(const std::vector<StringPiece>& inputs, bool fullLattice = false);
+
+  // Analyzer::analyze(input, plugin) for a batch, with any plugin of the batched form above
+  Status analyzeBatch(const std::vector<StringPiece>& inputs, ScorePlugin* plugin, bool fullLattice = false);
 
   // Analyzer::analyze(surface, plugin) with the partial-annotation ScorePlugin for every example
   // (PexStreamReader::analyzeWith, pex_stream_reader.cc:61-66); a null entry is analysed as the empty string

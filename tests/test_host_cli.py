@@ -381,6 +381,15 @@ def test_partial_annotation_plugin_byte_identical(cli_emu, ref_tools, tmp_path):
         ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['--partial-input'] + flags, pex)
         rc, out, err = _run(cli_emu, ['--model=' + img, '--partial-input'] + flags + [pex])
         assert out == ref, flags
+    # the generic ScorePlugin entry point (jppgpu_analyze_batch_plugin, GpuAnalyzer::analyzeBatch(inputs, plugin)):
+    # the same constraints evaluated per lattice node by a host-side plugin instead of the device kernel
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['--partial-input'], pex)
+    env = dict(os.environ, JPPGPU_PARTIAL_VIA_PLUGIN='1')
+    for flags in ([], ['--batch=7'], ['--auto-nbest=2:9:7']):
+        p = subprocess.run([cli_emu, '--model=' + img, '--partial-input'] + flags + [pex], capture_output=True, env=env)
+        want = ref if not flags or flags[0].startswith('--batch') else _ref_cli(ref_tools, os.path.join(tmp, 'w.model'),
+                                                                                 ['--partial-input'] + flags, pex)
+        assert p.returncode == 0 and p.stdout == want, (flags, p.stderr[-300:])
 
 
 @pytest.mark.gpu
@@ -397,6 +406,10 @@ def test_gpu_partial_annotation_plugin(cli_gpu, ref_tools, tmp_path):
     rc, out, err = _run(cli_gpu, ['--model=' + img, '--partial-input', pex])
     assert rc == 0, err[-300:]
     assert out == ref
+    # ... and through the generic plugin entry point (host-side plugin, per-node penalties uploaded per batch)
+    p = subprocess.run([cli_gpu, '--model=' + img, '--partial-input', '--batch=300', pex], capture_output=True,
+                       env=dict(os.environ, JPPGPU_PARTIAL_VIA_PLUGIN='1'))
+    assert p.returncode == 0 and p.stdout == ref, p.stderr[-300:]
 
 
 # ---- native .jppmdl reader (jumanpp_amd/host/jppmdl_reader.cc) ----

@@ -45,7 +45,7 @@ def main():
         tj = {'batch': int(sys.argv[2]), 'sent_len': int(sys.argv[3]), 'dict_entries': int(sys.argv[4]),
               'rnn': sys.argv[5] == '1', 'kernels': per_kernel,
               'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py`, '
-                      'avg per launch; bytes = 2 x FETCH_SIZE KB (gfx950 64-B tally of 128-B requests) + WRITE_SIZE KB'}
+                      'avg per launch; bytes = 2 x FETCH_SIZE KB (gfx950 tallies a 128-B request at 64 B; calibrated for streaming reads by the guide and for random 4-byte gathers by tools/micro/gather_calib.hip, profiles/r02_f_gather_calib.txt) + WRITE_SIZE KB'}
         with open(os.path.join(out, 'traffic.json'), 'w') as f:
             json.dump(tj, f, indent=1, sort_keys=True)
 
