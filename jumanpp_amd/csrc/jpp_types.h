@@ -235,7 +235,6 @@ struct Batch {
   float* node_penalty;     // [node] 0, 1000 or 10000
   // k_sweep<*, 0> only (a boundary with more right nodes than the LDS variants stage): per-sentence slice
   // for the prescores, their sums and the cutoff order
-  u32* sweep_redo;         // [n] k_sweep2 -> k_sweep hand-over: sentences beyond the two-per-wavefront kernel's staging (null: off)
   unsigned char* sweep_scratch;
   u64 sweep_scratch_stride;
   u32 sweep_scratch_maxr;

@@ -20,7 +20,6 @@
 #include "k_rnn.h"
 #include "k_seeds.h"
 #include "k_sweep.h"
-#include "k_sweep2.h"
 #include "k_sweep_full.h"
 #include "k_t0.h"
 
@@ -52,7 +51,6 @@ void rt_free(void* p) { free(p); }
 void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t) { memcpy(d, h, n); }
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
 void rt_sync(jpp_stream_t) {}
-void rt_memset(void* d, int v, size_t n, jpp_stream_t) { memset(d, v, n); }
 jpp_stream_t rt_stream_create() { return nullptr; }
 void rt_stream_destroy(jpp_stream_t) {}
 void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
@@ -81,7 +79,6 @@ void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
   (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
 }
 void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
-void rt_memset(void* d, int v, size_t n, jpp_stream_t s) { (void)hipMemsetAsync(d, v, n, s); }
 // a context's own stream: contexts used from different host threads do not serialise on the null stream
 jpp_stream_t rt_stream_create() {
   hipStream_t s = nullptr;
@@ -284,7 +281,7 @@ struct jppgpu_ctx {
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, pos_walk, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
-  DevBuf path_len, bnd_meta, sweep_scratch, sweep_redo;
+  DevBuf path_len, bnd_meta, sweep_scratch;
   DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
   bool partial_pending = false;  // constraints uploaded for the next analyze call
   jppgpu_score_plugin_fn plugin_fn = nullptr;  // host plugin of the next analyze call (jppgpu_analyze_batch_plugin)
@@ -543,7 +540,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
-                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->sweep_redo,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
+                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
@@ -753,7 +750,6 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
   // wider than the LDS variants stage (or more prescores than they hold): the per-right-node arrays go to HBM
   const bool unbounded = maxR > (u32)kMaxRight || (u64)ctx->cfg.rcheck * maxR > 2u * (u64)kMaxRight;
-  B.sweep_redo = nullptr;
   B.sweep_scratch = nullptr;
   B.sweep_scratch_stride = 0;
   B.sweep_scratch_maxr = 0;
@@ -773,18 +769,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   } else if (unbounded) {
     JPP_LAUNCH((k_sweep<32, 0>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow && maxR <= 64 && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5) {
-    // the CLI defaults: two sentences per wavefront (k_sweep2); a sentence with a boundary beyond its staging
-    // (> 32 left nodes or > 128 candidate slots) is flagged and done again by the one-sentence kernel.  Weight
-    // tables of up to 2^24 entries get the 24-bit index arithmetic.
-    if (!ctx->sweep_redo.ensure(((size_t)n + 1) * 4)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (sweep)");
-    rt_memset(ctx->sweep_redo.p, 0, ((size_t)n + 1) * 4, st);
-    B.sweep_redo = ctx->sweep_redo.as<u32>();
-    const bool w24 = ctx->hmodel.wmask <= 0xffffffu;
-    if (w24) JPP_LAUNCH((k_sweep2<true>), (n + 1) / 2, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-    else JPP_LAUNCH((k_sweep2<false>), (n + 1) / 2, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-    if (w24) JPP_LAUNCH((k_sweep<8, 64, true, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    // the CLI defaults; weight tables of up to 2^24 entries get the 24-bit index arithmetic
+    if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH((k_sweep<8, 64, true, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
     else JPP_LAUNCH((k_sweep<8, 64, true, false>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-    B.sweep_redo = nullptr;
   } else if (narrow && maxR <= 64 && ctx->cfg.rcheck <= 2) {
     JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
   } else if (narrow) {

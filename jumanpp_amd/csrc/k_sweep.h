@@ -221,7 +221,6 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   const DevModel& M = *Mp;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
-  if (B.sweep_redo && B.sweep_redo[s] == 0) return;   // second launch after k_sweep2: only the sentences it handed over
   const int lane = (int)threadIdx.x;
   const u32 off = B.byte_off[s];
   const u32 bb0 = off + 4 * s;
@@ -572,22 +571,58 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       }
     }
     wave_sync();
-    for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
-      if (q < U * kPat) {
-        int row = q / kPat, p = q - row * kPat;
-        t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
-      } else {
-        int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
-        t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
+    int c = rcheck;
+    if (c > (int)R) c = (int)R;
+    if (c > ngb) c = ngb;
+    bool s1Done = false;   // first-stage states of the first chunk of right nodes already in LDS
+    if constexpr (GM <= 8) {
+      // The T1 / T2 rows are requested into registers; while they travel, the first-stage hash states of the
+      // first chunk of right nodes are computed (they depend on the prefetched right-node patterns only), then
+      // the rows go to LDS.  One HBM round trip of the boundary's chain overlaps ~120 VALU instructions.
+      constexpr int kRowIters = (GM * kPat + GM * kT2 + 63) / 64;
+      u64 rowv[kRowIters];
+#pragma unroll
+      for (int it = 0; it < kRowIters; ++it) {
+        const int q = lane + 64 * it;
+        rowv[it] = 0;
+        if (q < U * kPat) {
+          int row = q / kPat, p = q - row * kPat;
+          rowv[it] = pats[(u64)t1node[row] * kPat + p];
+        } else if (q < U * kPat + ngb * kT2) {
+          int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
+          rowv[it] = pats[(u64)gb_pnode[r2] * kPat + p];
+        }
+      }
+      if (c > 0) {
+        compute_s1(pRn[par], R < (u32)kChunk ? R : (u32)kChunk);
+        s1Done = true;
+      }
+#pragma unroll
+      for (int it = 0; it < kRowIters; ++it) {
+        const int q = lane + 64 * it;
+        if (q < U * kPat) {
+          int row = q / kPat, p = q - row * kPat;
+          t1pat[row][p] = rowv[it];
+        } else if (q < U * kPat + ngb * kT2) {
+          int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
+          t2pat[r2][p] = rowv[it];
+        }
+      }
+    } else {
+      for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
+        if (q < U * kPat) {
+          int row = q / kPat, p = q - row * kPat;
+          t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
+        } else {
+          int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
+          t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
+        }
       }
     }
     wave_sync();
 
     JPP_PROF(2);
     // ---- 3. prescores for the first c gbeam entries over all right nodes ----
-    int c = rcheck;
-    if (c > (int)R) c = (int)R;
-    if (c > ngb) c = ngb;
     if (RM > 0 && (u32)c * R > (u32)(2 * RM)) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
@@ -600,8 +635,10 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
         wave_sync();
       }
-      compute_s1(tc == 0 ? pRn[par] : pR, nx);
-      wave_sync();
+      if (!(tc == 0 && s1Done)) {
+        compute_s1(tc == 0 ? pRn[par] : pR, nx);
+        wave_sync();
+      }
       for (int i = 0; i < c; ++i) {
         const bool act = (u32)grp < nx;
         const u32 t = tc + (u32)grp;
@@ -703,6 +740,27 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       }
       auto s1Row = [&](int x) -> int { return small ? (int)order[op0 + x] : x; };
       auto t0Of = [&](int x) -> float { return small ? t0n[par][order[op0 + x]] : t0R[x]; };
+      // (narrow variant) the trigram weights of 5b are requested before the bigram pass 5a, so that both sets of
+      // gathers are in flight together instead of one HBM round trip after the other; nx * ngb <= 64: the lane
+      // that requests them is the lane that sums them in 5b
+      float wtri[spec::kNumTri] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (GM <= 8) {
+        static_assert(kChunk * GM <= 64 || GM > 8, "one lane per (node, entry) of a pass");
+        const int q = lane;
+        if (q < nx * ngb) {
+          const int x = q / ngb, i = q - x * ngb;
+          if (i >= c && (op0 + x) < K) {
+            const u64* st = s1t[s1Row(x)];
+            const u64* t1r = t1pat[gb_t1[i]];
+            const u64* t2r = t2pat[i];
+#pragma unroll
+            for (int f = 0; f < spec::kNumTri; ++f) {
+              u32 idx = hmix_index<W24>(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]], wmask);
+              wtri[f] = W[idx];
+            }
+          }
+        }
+      }
       // 5a. bigram sums per (kept node, unique T1 row) -- applyBiTriFullKernel rows
       if (ntail > 0) {
         // (kHeadShare: row 0 came out of the prescore pass, the units cover rows 1 .. U-1)
@@ -742,10 +800,16 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
           const u64* t1r = t1pat[gb_t1[i]];
           const u64* t2r = t2pat[i];
           float w[spec::kNumTri];
+          if constexpr (GM <= 8) {
+            (void)st; (void)t1r; (void)t2r;
 #pragma unroll
-          for (int f = 0; f < spec::kNumTri; ++f) {
-            u32 idx = hmix_index<W24>(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]], wmask);
-            w[f] = W[idx];
+            for (int f = 0; f < spec::kNumTri; ++f) w[f] = wtri[f];   // requested before 5a
+          } else {
+#pragma unroll
+            for (int f = 0; f < spec::kNumTri; ++f) {
+              u32 idx = hmix_index<W24>(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]], wmask);
+              w[f] = W[idx];
+            }
           }
           static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
           float S;
