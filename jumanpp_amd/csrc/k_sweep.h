@@ -571,58 +571,25 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       }
     }
     wave_sync();
-    int c = rcheck;
-    if (c > (int)R) c = (int)R;
-    if (c > ngb) c = ngb;
-    bool s1Done = false;   // first-stage states of the first chunk of right nodes already in LDS
-    if constexpr (GM <= 8) {
-      // The T1 / T2 rows are requested into registers; while they travel, the first-stage hash states of the
-      // first chunk of right nodes are computed (they depend on the prefetched right-node patterns only), then
-      // the rows go to LDS.  One HBM round trip of the boundary's chain overlaps ~120 VALU instructions.
-      constexpr int kRowIters = (GM * kPat + GM * kT2 + 63) / 64;
-      u64 rowv[kRowIters];
-#pragma unroll
-      for (int it = 0; it < kRowIters; ++it) {
-        const int q = lane + 64 * it;
-        rowv[it] = 0;
-        if (q < U * kPat) {
-          int row = q / kPat, p = q - row * kPat;
-          rowv[it] = pats[(u64)t1node[row] * kPat + p];
-        } else if (q < U * kPat + ngb * kT2) {
-          int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
-          rowv[it] = pats[(u64)gb_pnode[r2] * kPat + p];
-        }
-      }
-      if (c > 0) {
-        compute_s1(pRn[par], R < (u32)kChunk ? R : (u32)kChunk);
-        s1Done = true;
-      }
-#pragma unroll
-      for (int it = 0; it < kRowIters; ++it) {
-        const int q = lane + 64 * it;
-        if (q < U * kPat) {
-          int row = q / kPat, p = q - row * kPat;
-          t1pat[row][p] = rowv[it];
-        } else if (q < U * kPat + ngb * kT2) {
-          int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
-          t2pat[r2][p] = rowv[it];
-        }
-      }
-    } else {
-      for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
-        if (q < U * kPat) {
-          int row = q / kPat, p = q - row * kPat;
-          t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
-        } else {
-          int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
-          t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
-        }
+    // (Requesting these rows into registers and computing the first-stage hash states of the right nodes while
+    // they travel was measured in round 2: 6.92 -> 7.11 ms.  The extra live registers cost more than the
+    // overlapped round trip saves at 128 VGPRs.)
+    for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
+      if (q < U * kPat) {
+        int row = q / kPat, p = q - row * kPat;
+        t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
+      } else {
+        int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
+        t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
       }
     }
     wave_sync();
 
     JPP_PROF(2);
     // ---- 3. prescores for the first c gbeam entries over all right nodes ----
+    int c = rcheck;
+    if (c > (int)R) c = (int)R;
+    if (c > ngb) c = ngb;
     if (RM > 0 && (u32)c * R > (u32)(2 * RM)) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
@@ -635,10 +602,8 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
         wave_sync();
       }
-      if (!(tc == 0 && s1Done)) {
-        compute_s1(tc == 0 ? pRn[par] : pR, nx);
-        wave_sync();
-      }
+      compute_s1(tc == 0 ? pRn[par] : pR, nx);
+      wave_sync();
       for (int i = 0; i < c; ++i) {
         const bool act = (u32)grp < nx;
         const u32 t = tc + (u32)grp;
