@@ -16,10 +16,19 @@
 //       AnalyzerImpl::computeScoresGbeam (src/core/analysis/analyzer_impl.cc:250-297)
 //       through the reference's own ScoreProcessor so T0 can be captured per
 //       boundary.
+//   ref_dump shim    <model.jppmdl> <libjppgpu(.so|_emu.so)> <lattice-N|0> [beam gbeam rcheck rbeam] < corpus
+//       the drop-in claim of SURVEY 8(b), executed: the model is handed to the C ABI from the reference's own
+//       structures, the batch is analysed by the library, and for every sentence a
+//       reference Lattice is re-materialised from the result view inside an ordinary reference Analyzer (seeds
+//       from the device node table through the reference's LatticeBuilder, beams and score cells written with
+//       host pointers rebuilt from the index form).  The reference's UNMODIFIED
+//       JumanFormat / LatticeFormat then format that analyzer; the bytes must equal those of a plain
+//       Analyzer::analyze run.  Prints one JSON line, exit code 0 iff everything is identical.
 //   ref_dump time    <model.jppmdl> [beam gbeam rcheck rbeam] < corpus
 //       wall-clock of Analyzer::analyze (+JumanFormat) over the corpus, phases split
 //       as BASELINE.md section 3.
 #include <chrono>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -45,6 +54,8 @@
 #include "core/impl/perceptron_io.h"
 #include "jpp_jumandic_cg.h"
 #include "jumandic/shared/juman_format.h"
+#include "jumandic/shared/lattice_format.h"
+#include "../include/jppgpu.h"
 #include "util/serialization.h"
 
 using namespace jumanpp;
@@ -705,11 +716,308 @@ int doTime(const char* modelFile, char** extra, int nextra) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------ shim ---
+struct GpuLib {
+  void* h = nullptr;
+  decltype(&jppgpu_ctx_create) ctx_create = nullptr;
+  decltype(&jppgpu_ctx_destroy) ctx_destroy = nullptr;
+  decltype(&jppgpu_analyze_batch) analyze_batch = nullptr;
+  decltype(&jppgpu_result_fetch) result_fetch = nullptr;
+  decltype(&jppgpu_result_release) result_release = nullptr;
+  decltype(&jppgpu_last_error) last_error = nullptr;
+  bool open(const char* path) {
+    h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      std::cerr << "dlopen failed: " << dlerror() << "\n";
+      return false;
+    }
+#define JPP_SYM(n) n = reinterpret_cast<decltype(n)>(dlsym(h, "jppgpu_" #n)); if (!n) { std::cerr << "missing symbol jppgpu_" #n "\n"; return false; }
+    JPP_SYM(ctx_create) JPP_SYM(ctx_destroy) JPP_SYM(analyze_batch) JPP_SYM(result_fetch) JPP_SYM(result_release) JPP_SYM(last_error)
+#undef JPP_SYM
+    return true;
+  }
+};
+
+// the flattened FeaturesSpec the library compares with its built-in tables (same bytes as SEC_FEATURES above)
+void flattenFeatures(const spec::AnalysisSpec& spec, Writer& s) {
+  auto& fs_ = spec.features;
+  s.put<i32>((i32)fs_.primitive.size());
+  for (auto& p : fs_.primitive) {
+    s.put<i32>((i32)p.kind);
+    putInts(s, p.references);
+  }
+  s.put<i32>((i32)fs_.computation.size());
+  for (auto& c : fs_.computation) {
+    s.put<i32>(c.primitiveFeature);
+    putInts(s, c.trueBranch);
+    putInts(s, c.falseBranch);
+  }
+  s.put<i32>((i32)fs_.pattern.size());
+  for (auto& p : fs_.pattern) {
+    s.put<i32>(p.index);
+    putInts(s, p.references);
+  }
+  s.put<i32>((i32)fs_.ngram.size());
+  for (auto& n : fs_.ngram) {
+    s.put<i32>(n.index);
+    putInts(s, n.references);
+  }
+}
+
+int doShim(const char* modelFile, const char* libPath, int latticeN, char** extra, int nextra) {
+  Env e;
+  e.init(modelFile, extra, nextra);
+  GpuLib lib;
+  if (!lib.open(libPath)) return 2;
+
+  // ---- the model handed over from the reference's own structures ----
+  std::string modelS{modelFile};
+  model::FilesystemModel fs;
+  CHECK_OK(fs.open(StringPiece{modelS}));
+  model::ModelInfo info;
+  CHECK_OK(fs.load(&info));
+  dic::BuiltDictionary bd;
+  CHECK_OK(bd.restoreDictionary(info));
+  auto& spec = bd.spec;
+  jppgpu_model m{};
+  m.trie = bd.trieContent.data();
+  m.trie_bytes = bd.trieContent.size();
+  m.entry_ptrs = bd.entryPointers.data();
+  m.entry_ptrs_bytes = bd.entryPointers.size();
+  m.entry_data = bd.entryData.data();
+  m.entry_data_bytes = bd.entryData.size();
+  auto pp = info.firstPartOf(model::ModelPartKind::Perceprton);
+  if (!pp) {
+    std::cerr << "model has no perceptron\n";
+    return 2;
+  }
+  {
+    util::serialization::Loader ldr{pp->data[0]};
+    PerceptronInfo pi{};
+    if (!ldr.load(&pi)) return 2;
+    m.weights = reinterpret_cast<const float*>(pp->data[1].data());
+    m.weight_exponent = (u32)pi.modelSizeExponent;
+  }
+  m.num_features = spec.features.numDicFeatures;
+  m.num_placeholders = spec.features.numPlaceholders;
+  std::vector<jppgpu_unk_maker> unk;
+  for (auto& u : spec.unkCreators) {
+    u32 mask = 0;
+    for (auto f : u.replaceFields) mask |= 1u << f;
+    unk.push_back(jppgpu_unk_maker{(i32)u.type, (i32)u.charClass, u.patternPtr, u.priority,
+                                   u.features.empty() ? -1 : u.features[0].targetPlaceholder, mask});
+  }
+  m.unk_makers = unk.data();
+  m.num_unk_makers = (i32)unk.size();
+  Writer flat;
+  flattenFeatures(spec, flat);
+  m.feature_spec = flat.buf.data();
+  m.feature_spec_bytes = flat.buf.size();
+  auto sconf = e.env.scorers();
+  const bool rnn = sconf->scoreWeights.size() == 2;
+  OracleRnnHeader rh;
+  if (rnn) {
+    auto rp = info.firstPartOf(model::ModelPartKind::Rnn);
+    util::serialization::Loader l{rp->data[0]};
+    if (!l.load(&rh)) return 2;
+    m.has_rnn = 1;
+    m.rnn_known_index = rp->data[1].data();
+    m.rnn_known_index_bytes = rp->data[1].size();
+    m.rnn_unk_index = rp->data[2].data();
+    m.rnn_unk_index_bytes = rp->data[2].size();
+    m.rnn_matrix = reinterpret_cast<const float*>(rp->data[3].data());
+    m.rnn_embeddings = reinterpret_cast<const float*>(rp->data[4].data());
+    m.rnn_nce_embeddings = reinterpret_cast<const float*>(rp->data[5].data());
+    m.rnn_maxent = reinterpret_cast<const float*>(rp->data[6].data());
+    m.rnn_layer_size = rh.rnnHeader.layerSize;
+    m.rnn_maxent_order = rh.rnnHeader.maxentOrder;
+    m.rnn_maxent_size = rh.rnnHeader.maxentSize;
+    m.rnn_vocab_size = rh.rnnHeader.vocabSize;
+    float nce = rh.rnnHeader.nceLnz;
+    if (rh.config.rnnWeight.defined()) nce = rh.config.rnnWeight;   // RnnScorerGbeamFactory::load, :465-467
+    m.rnn_nce_constant = nce;
+    m.rnn_unk_id = rh.unkIdx;
+    m.rnn_unk_constant = rh.config.unkConstantTerm;
+    m.rnn_unk_length = rh.config.unkLengthPenalty;
+    m.rnn_num_fields = (u32)rh.fields.size();
+    for (size_t i = 0; i < rh.fields.size() && i < 8; ++i) m.rnn_fields[i] = rh.fields[i];
+  }
+  jppgpu_config c{};
+  c.beam = e.beam;
+  c.global_beam = e.gbeam;
+  c.right_check = e.rcheck;
+  c.right_beam = e.rbeam;
+  c.max_input_bytes = 4096;
+  c.device = 0;
+  c.use_rnn = rnn ? 1 : 0;
+  c.weight_perceptron = sconf->scoreWeights[0];
+  c.weight_rnn = rnn ? sconf->scoreWeights[1] : 0.f;
+  jppgpu_ctx* ctx = nullptr;
+  if (lib.ctx_create(&m, &c, &ctx) != JPPGPU_OK) {
+    std::cerr << "jppgpu_ctx_create: " << lib.last_error() << "\n";
+    return 2;
+  }
+
+  // ---- one batched call instead of the per-line loop ----
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(std::cin, line)) lines.push_back(line);
+  std::string text;
+  std::vector<uint32_t> offs{0};
+  for (auto& l : lines) {
+    text += l;
+    offs.push_back((uint32_t)text.size());
+  }
+  jppgpu_result* res = nullptr;
+  if (lib.analyze_batch(ctx, text.data(), offs.data(), (uint32_t)lines.size(), &res) != JPPGPU_OK) {
+    std::cerr << "jppgpu_analyze_batch: " << lib.last_error() << "\n";
+    return 2;
+  }
+  jppgpu_result_view v{};
+  if (lib.result_fetch(res, JPPGPU_FETCH_FULL, &v) != JPPGPU_OK) {
+    std::cerr << "jppgpu_result_fetch: " << lib.last_error() << "\n";
+    return 2;
+  }
+
+  // ---- the Analyzer shim ----
+  // (refAn2: a second ordinary reference analyzer.  LatticeFormat chooses among exactly tied connections of a node
+  // by iterating a set hashed on host addresses, lattice_config.h:109-124, so two reference analyzers may print
+  // different lattice lines for the same sentence; such sentences are counted, not held against the shim.)
+  Analyzer refAn, refAn2, shimAn;
+  CHECK_OK(e.env.makeAnalyzer(&refAn));
+  CHECK_OK(e.env.makeAnalyzer(&refAn2));
+  CHECK_OK(e.env.makeAnalyzer(&shimAn));
+  jumandic::output::JumanFormat jRef, jShim;
+  CHECK_OK(jRef.initialize(refAn.output()));
+  CHECK_OK(jShim.initialize(shimAn.output()));
+  jumandic::output::LatticeFormat lRef(latticeN > 0 ? latticeN : 1), lRef2(latticeN > 0 ? latticeN : 1),
+      lShim(latticeN > 0 ? latticeN : 1);
+  if (latticeN > 0) {
+    CHECK_OK(lRef.initialize(refAn.output()));
+    CHECK_OK(lRef2.initialize(refAn2.output()));
+    CHECK_OK(lShim.initialize(shimAn.output()));
+  }
+  const int beam = v.beam, G = v.global_beam, S = v.num_scorers;
+  long same = 0, sameLattice = 0, failed = 0, statusMismatch = 0, refUnstable = 0;
+  for (size_t si = 0; si < lines.size(); ++si) {
+    Status rs = refAn.analyze(lines[si]);
+    if (!rs || v.status[si] != JPPGPU_SENT_OK) {
+      if ((bool)rs != (v.status[si] == JPPGPU_SENT_OK)) ++statusMismatch;
+      ++failed;
+      continue;
+    }
+    CHECK_OK(jRef.format(refAn, StringPiece{""}));
+    std::string expect = jRef.result().str();
+    std::string expectLattice, expectLattice2;
+    if (latticeN > 0) {
+      CHECK_OK(lRef.format(refAn, StringPiece{""}));
+      expectLattice = lRef.result().str();
+      CHECK_OK(refAn2.analyze(lines[si]));
+      CHECK_OK(lRef2.format(refAn2, StringPiece{""}));
+      expectLattice2 = lRef2.result().str();
+      if (expectLattice2 != expectLattice) ++refUnstable;
+    }
+    // -- re-materialise --
+    AnalyzerImpl* impl = shimAn.impl();
+    CHECK_OK(impl->resetForInput(lines[si]));
+    const uint64_t nb = v.node_base[si], bb = v.bnd_base[si];
+    const uint32_t N = v.n_nodes[si], ncp = v.n_codepoints[si];
+    auto* xtra = impl->extraNodesContext();
+    auto& input = impl->input();
+    for (uint32_t k = 2; k + 1 < N; ++k) {
+      const jppgpu_node& nd = v.nodes[nb + k];
+      if (nd.entry_ptr >= 0) {
+        impl->latticeBldr()->appendSeed(EntryPtr{nd.entry_ptr}, nd.start, nd.end);
+      } else {
+        const jppgpu_unk& u = v.unk[nb + k];
+        auto node = xtra->makeZeroedUnk();
+        auto data = xtra->nodeContent(node);
+        for (int f = 0; f < (int)data.size(); ++f) data.at(f) = v.entry_rows[(nb + k) * 8 + f];
+        node->header.unk.surface = input.surface(nd.start, nd.end);
+        node->header.unk.contentHash = u.content_hash;
+        node->header.unk.templatePtr = EntryPtr{u.template_ptr};
+        xtra->putPlaceholderData(node, 0, (i32)u.placeholder[0]);
+        xtra->putPlaceholderData(node, 1, (i32)u.placeholder[1]);
+        impl->latticeBldr()->appendSeed(node->ptr(), nd.start, nd.end);
+      }
+    }
+    if (!impl->latticeBldr()->checkConnectability()) {
+      std::cerr << "sentence " << si << ": device lattice is not connected\n";
+      return 1;
+    }
+    CHECK_OK(impl->latticeBldr()->prepare());
+    CHECK_OK(impl->buildLattice());
+    CHECK_OK(impl->bootstrapAnalysis());
+    Lattice* lat = impl->lattice();
+    if ((uint32_t)lat->createdBoundaryCount() != ncp + 3) {
+      std::cerr << "sentence " << si << ": boundary count\n";
+      return 1;
+    }
+    // node index -> (boundary, position)
+    auto locate = [&](uint32_t node, u16* bnd, u16* pos) {
+      if (node == 0) { *bnd = 0; *pos = 0; return; }
+      if (node == 1) { *bnd = 1; *pos = 0; return; }
+      const uint32_t b = (node + 1 == N) ? ncp + 2 : (uint32_t)v.nodes[nb + node].start + 2;
+      *bnd = (u16)b;
+      *pos = (u16)(node - v.bnd_first[bb + b]);
+    };
+    for (uint32_t b = 2; b <= ncp + 2; ++b) {
+      const uint32_t R = v.bnd_count[bb + b], first = v.bnd_first[bb + b];
+      auto bnd = lat->boundary(b);
+      if (bnd->localNodeCount() != R) {
+        std::cerr << "sentence " << si << " boundary " << b << ": node count\n";
+        return 1;
+      }
+      if (R == 0) continue;
+      auto beams = bnd->starts()->beamData();
+      const uint32_t ngb = v.gbeam_count[bb + b];
+      for (uint32_t r = 0; r < R; ++r) {
+        const uint64_t k = nb + first + r;
+        auto row = beams.row(r);
+        for (int q = 0; q < beam; ++q) {
+          const jppgpu_beam_slot& sl = v.beams[k * beam + q];
+          if (sl.left == 0xffff && sl.beam == 0xffff) {
+            std::memset(&row.at(q), 0xff, sizeof(ConnectionBeamElement));
+            continue;
+          }
+          u16 pb, pr;
+          locate(sl.prev_node, &pb, &pr);
+          const ConnectionPtr* prev = &lat->boundary(pb)->starts()->beamData().row(pr).at(sl.beam).ptr;
+          row.at(q) = ConnectionBeamElement{ConnectionPtr{(u16)b, sl.left, (u16)r, sl.beam, prev}, sl.total};
+        }
+        // score cells: (beam, left) of global-beam entry i -> cells[node][i][scorer]
+        auto ns = bnd->scores()->nodeScores(r);
+        for (uint32_t i = 0; i < ngb; ++i) {
+          const uint32_t lb = v.gbeam[((bb + b) * G + i) * 2];   // left | beam << 16
+          auto dst = ns.beamLeft((i32)(lb >> 16), (i32)(lb & 0xffff));
+          for (int sc = 0; sc < S; ++sc) dst.at(sc) = v.cells[(k * G + i) * S + sc];
+        }
+      }
+    }
+    // the reference's formatters, unmodified, on the shim analyzer
+    CHECK_OK(jShim.format(shimAn, StringPiece{""}));
+    if (jShim.result().str() == expect) ++same;
+    else if (same + 3 > (long)si) std::cerr << "sentence " << si << " differs:\n" << expect << "---\n" << jShim.result().str();
+    if (latticeN > 0) {
+      CHECK_OK(lShim.format(shimAn, StringPiece{""}));
+      if (lShim.result().str() == expectLattice || lShim.result().str() == expectLattice2) ++sameLattice;
+    }
+  }
+  lib.result_release(res);
+  lib.ctx_destroy(ctx);
+  const long ok = (long)lines.size() - failed;
+  std::printf("{\"sentences\": %zu, \"analysed\": %ld, \"status_mismatch\": %ld, \"juman_identical\": %ld, "
+              "\"lattice_n\": %d, \"lattice_identical\": %ld, \"lattice_unstable_in_reference\": %ld}\n",
+              lines.size(), ok, statusMismatch, same, latticeN, sameLattice, refUnstable);
+  return (statusMismatch == 0 && same == ok) ? 0 : 1;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::cerr << "usage: ref_dump export|mkmodel|dump|time ...\n";
+    std::cerr << "usage: ref_dump export|mkmodel|dump|time|shim ...\n";
     return 2;
   }
   std::string cmd = argv[1];
@@ -719,6 +1027,7 @@ int main(int argc, char** argv) {
                      (float)atof(argv[6]));
   if (cmd == "dump" && argc >= 4) return doDump(argv[2], argv[3], argv + 4, argc - 4);
   if (cmd == "time" && argc >= 3) return doTime(argv[2], argv + 3, argc - 3);
+  if (cmd == "shim" && argc >= 5) return doShim(argv[2], argv[3], atoi(argv[4]), argv + 5, argc - 5);
   std::cerr << "bad arguments\n";
   return 2;
 }

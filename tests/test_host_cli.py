@@ -201,6 +201,51 @@ def test_gpu_cli_devices_list(cli_gpu, ref_tools, tmp_path):
     assert out == ref.stdout
 
 
+# ---- the drop-in boundary itself: the reference's UNMODIFIED formatters on a re-materialised Lattice ----
+
+def _shim_check(ref_tools, model, lib, text_path, lattice_n, beams=()):
+    """oracle/ref_dump.cc `shim`: model handed to the C ABI from the reference's structures,
+    batch analysed by `lib`, reference Lattice rebuilt from the result view inside a reference Analyzer
+    (INTEGRATION 4), reference JumanFormat / LatticeFormat run on it, compared with plain Analyzer::analyze."""
+    import json
+    with open(text_path, 'rb') as f:
+        p = subprocess.run([os.path.join(ref_tools, 'ref_dump'), 'shim', model, lib, str(lattice_n)] + [str(b) for b in beams],
+                           stdin=f, capture_output=True)
+    assert p.returncode in (0, 1), p.stderr[-500:]
+    r = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert r['status_mismatch'] == 0 and r['juman_identical'] == r['analysed'] > 0, (r, p.stderr[-500:])
+    # lattice lines: identical except where two reference analyzers disagree among themselves
+    # (address-hashed choice among exactly tied connections, lattice_config.h:109-124)
+    if lattice_n > 0:
+        assert r['lattice_identical'] >= r['analysed'] - r['lattice_unstable_in_reference'], r
+    return r
+
+
+def test_reference_formatters_on_rematerialised_lattice(emu_lib, ref_tools, golden_dir, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    txt = os.path.join(golden_dir, 'mini.txt')
+    r = _shim_check(ref_tools, os.path.join(golden_dir, 'mini.jppmdl'), emu_lib, txt, 3)
+    assert r['analysed'] == 28 and r['lattice_identical'] == 28
+    _shim_check(ref_tools, os.path.join(golden_dir, 'mini_rnn.jppmdl'), emu_lib, txt, 5)
+    _shim_check(ref_tools, os.path.join(golden_dir, 'mini.jppmdl'), emu_lib, txt, 0, beams=(3, 8, 2, 4))
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    tg._fresh_workload(ref_tools, tmp, 3000, 120, 14, 17, length=30, rnn=(48, 800))
+    _shim_check(ref_tools, os.path.join(tmp, 'w.model'), emu_lib, os.path.join(tmp, 'w.txt'), 4)
+
+
+@pytest.mark.gpu
+def test_gpu_reference_formatters_on_rematerialised_lattice(gpu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    tg._fresh_workload(ref_tools, tmp, 30000, 1500, 20, 19, rnn=(128, 8000))
+    r = _shim_check(ref_tools, os.path.join(tmp, 'w.model'), gpu_lib, os.path.join(tmp, 'w.txt'), 5)
+    assert r['analysed'] == 1500
+
+
 # ---- lattice format (-s N): src/jumandic/shared/lattice_format.cc ----
 
 def _ref_cli(ref_tools, model, args, path):
