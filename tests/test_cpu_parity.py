@@ -86,6 +86,26 @@ def test_emulated_partition_branch_of_make_t0_beam(emu_lib, golden_dir, ref_tool
     assert not errs, errs[:10]
 
 
+@pytest.mark.parametrize('hidden', [48, 128])
+def test_emulated_rnn_staged_and_unstaged_sentences_in_one_batch(emu_lib, ref_tools, tmp_path, hidden):
+    """k_rnn_prep / k_rnn_score stage a sentence's beam records in LDS when it has at most 45 codepoints (global
+    beam 6) and read them from HBM otherwise: a batch with both kinds, bit-exact RNN scores (E = 48 and 128)."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    img, lines, gold_path = tg._fresh_workload(ref_tools, str(tmp_path), 2500, 14, 14, 23, length=40,
+                                               rnn=(hidden, 600), join=5)
+    assert max(len(l) for l in lines) > 180 and min(len(l) for l in lines) < 60
+    ctx = J.Context(img, lib_path=emu_lib)
+    meta, gold = G.read_gold(gold_path)
+    assert meta['nscorers'] == 2
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
 def test_emulated_full_beam_matches_live_reference(emu_lib, golden_dir, ref_tools, tmp_path):
     """--global-beam 0: AnalyzerImpl::computeScoresFull (k_sweep_full)."""
     if ref_tools is None:

@@ -70,7 +70,7 @@ def test_gpu_status_codes(gpu_lib, golden_dir):
     assert list(res.status) == [2, 0, 2, 1, 0]
 
 
-def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None, beams=None):
+def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None, beams=None, join=0):
     mdic = os.path.join(tmp, 'w.mdic')
     with open(mdic, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)],
@@ -96,12 +96,36 @@ def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rn
     with open(txt, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines), '--seed',
                                str(seed + 1), '--oov', '0.08', '--len', str(length)], stdout=f)
+    if join:
+        # every other output line is `join` generated sentences glued together
+        src = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
+        out, i = [], 0
+        while i < len(src):
+            out.append(src[i])
+            out.append(''.join(src[i + 1:i + 1 + join]))
+            i += 1 + join
+        open(txt, 'w', encoding='utf-8').write('\n'.join(l for l in out if l) + '\n')
     with open(txt, 'rb') as f:
         subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', os.path.join(tmp, 'w.model'),
                                os.path.join(tmp, 'w.gold')] + [str(x) for x in (beams or [])],
                               stdin=f, stderr=subprocess.DEVNULL)
     lines = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
     return os.path.join(tmp, 'w.img'), lines, os.path.join(tmp, 'w.gold')
+
+
+def test_gpu_rnn_staged_and_unstaged_sentences_in_one_batch(gpu_lib, ref_tools, tmp_path):
+    """k_rnn_prep / k_rnn_score stage a sentence's beam records in LDS when it has at most 45 codepoints
+    (global beam 6) and read them from HBM otherwise: both kinds in one batch (40 and ~240 codepoints),
+    every RNN score and the re-ranked EOS beam bit-identical to the reference."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _fresh_workload(ref_tools, str(tmp_path), 30000, 700, 20, 91, rnn=(128, 3000), join=6)
+    assert max(len(l) for l in lines) > 200 and min(len(l) for l in lines) < 60
+    ctx = J.Context(img, lib_path=gpu_lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
 
 
 def test_gpu_matches_live_reference_on_fresh_workload(gpu_lib, ref_tools, tmp_path):
