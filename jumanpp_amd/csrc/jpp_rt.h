@@ -30,6 +30,9 @@ typedef hipStream_t jpp_stream_t;
 #define JPP_RPROF(i)
 #define JPP_RPROF_COUNT(cn)
 #define JPP_RPROF_FLUSH
+#define JPP_LPROF_DECL
+#define JPP_LPROF(i)
+#define JPP_LPROF_FLUSH(rounds)
 #endif
 
 typedef uint8_t u8;
@@ -107,6 +110,57 @@ __device__ __forceinline__ void lds_async_wait() {
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   asm volatile("" ::: "memory");
+#endif
+}
+
+// wait for every outstanding global load / store of this wavefront
+__device__ __forceinline__ void vm_wait_all() {
+#if !defined(JPP_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
+#endif
+}
+
+// workgroup barrier that orders LDS traffic only: outstanding global loads / stores of the wavefront stay in flight
+// (__syncthreads() drains them: its workgroup-scope release waits for vmcnt(0)).  For phases that hand data to other
+// wavefronts through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+#if defined(JPP_EMU)
+  __syncthreads();
+#elif defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// the SIMD (0..3) of the compute unit this wavefront runs on: HW_ID bits 5:4
+__device__ __forceinline__ u32 wave_simd_id() {
+#if defined(JPP_EMU)
+  return (threadIdx.x >> 6) & 3u;
+#elif defined(__HIP_DEVICE_COMPILE__)
+  return (u32)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // 2 bits at offset 4 of HW_REG_HW_ID
+#else
+  return 0;
+#endif
+}
+
+// v_mfma_f32_16x16x4_f32: D = A(16x4) * B(4x16) + C on the matrix cores.  Lane l supplies A[l & 15][l >> 4] and
+// B[l >> 4][l & 15] and holds D[4 * (l >> 4) + i][l & 15] in element i.  Every D element is the f32 fused chain
+// fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, c)))): one rounding per step, k ascending, nothing wider inside.
+struct MfmaAcc {
+  float v[4];
+};
+__device__ __forceinline__ MfmaAcc mfma_f32_16x16x4(float a, float b, MfmaAcc c) {
+#if defined(JPP_EMU)
+  return MfmaAcc{hip_emu::mfma_f32_16x16x4(a, b, c.v[0], 0), hip_emu::mfma_f32_16x16x4(a, b, c.v[1], 1),
+                 hip_emu::mfma_f32_16x16x4(a, b, c.v[2], 2), hip_emu::mfma_f32_16x16x4(a, b, c.v[3], 3)};
+#elif defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  f32x4_t cc = {c.v[0], c.v[1], c.v[2], c.v[3]};
+  cc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, cc, 0, 0, 0);
+  return MfmaAcc{cc[0], cc[1], cc[2], cc[3]};
+#else
+  (void)a;
+  (void)b;
+  return c;
 #endif
 }
 

@@ -221,6 +221,10 @@ struct Batch {
   i32* rnn_nid;            // [bb][gbeam] word id of the rnn node
   u32* rnn_nlen;           // [bb][gbeam] codepoint length of the rnn node
   u32* rnn_cnt;            // [bb] rnn nodes per boundary
+  u32* rnn_order;          // [n_sent] sentences grouped by the length of their recurrence (k_rnn_order_*), or null
+  u32* rnn_key;            // [n_sent] that length, capped
+  u32* rnn_offs;           // [kRnnOrderBins] next free slot of every length class
+  u32* rnn_hist;           // [kRnnOrderBins] sentences per length class (all zero between batches)
   float* rnn_ctx;          // [bb][gbeam][EP] hidden state after each rnn node
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]

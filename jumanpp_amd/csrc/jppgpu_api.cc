@@ -276,7 +276,8 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
+  void* rnn_ord_zeroed = nullptr;   // the rnn_ord allocation whose histogram has been zeroed
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, pos_walk, reach;
@@ -539,7 +540,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
@@ -572,7 +573,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
             (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) &&
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
-              ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) &&
+              ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins) * 4) &&
               ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_EP * 4)));
   ok = ok && ctx->gstats.ensure(64);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
@@ -624,6 +625,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_nid = ctx->rnn_nid.as<i32>();
   B.rnn_nlen = ctx->rnn_nlen.as<u32>();
   B.rnn_cnt = ctx->rnn_cnt.as<u32>();
+  B.rnn_order = nullptr;
+  B.rnn_hist = ctx->rnn_ord.as<u32>();
+  B.rnn_offs = B.rnn_hist ? B.rnn_hist + kRnnOrderBins : nullptr;
+  B.rnn_key = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins : nullptr;
   B.rnn_ctx = ctx->rnn_ctx.as<float>();
   if (n == 0) {
     B.total_nodes = 0;
@@ -783,17 +788,38 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   T.mark(5, st);
   if (ctx->cfg.nscorers == 2) {
+    JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
     JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
                (const DevModel*)ctx->dmodel, ctx->cfg);
     // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
     const DevModel* dm = (const DevModel*)ctx->dmodel;
-    if (ctx->hmodel.rnn_EP == 64) {
+    static const bool ldsW = getenv("JPPGPU_RNN_LDSW") != nullptr;   // (measurement only)
+    if (ctx->hmodel.rnn_EP <= 128 && !ldsW && getenv("JPPGPU_RNN_NOORDER") == nullptr) {
+      // lock-step workgroups take sentences of equal chain length
+      B.rnn_order = B.rnn_key + n;
+      if (ctx->rnn_ord_zeroed != ctx->rnn_ord.p) {   // a fresh allocation: the histogram starts at zero, k_rnn_order_scan keeps it there
+        JPP_LAUNCH(k_rnn_order_zero, 1, kRnnOrderBins, st, B.rnn_hist);
+        ctx->rnn_ord_zeroed = ctx->rnn_ord.p;
+      }
+      JPP_LAUNCH(k_rnn_order_key, (n + 255) / 256, 256, st, B, ctx->cfg);
+      JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
+      JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
+    }
+    if (ctx->hmodel.rnn_EP == 64 && ldsW) {
       if (sortE) JPP_LAUNCH((k_rnn_score<1, true, true>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<1, true, false>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-    } else if (ctx->hmodel.rnn_EP == 128) {
+    } else if (ctx->hmodel.rnn_EP == 128 && ldsW) {
       if (sortE) JPP_LAUNCH((k_rnn_score<2, true, true>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<2, true, false>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
+    } else if (ctx->hmodel.rnn_EP == 64) {
+      JPP_LAUNCH((k_rnn_score<1, true, false, 1>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<1, true, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+    } else if (ctx->hmodel.rnn_EP == 128) {
+      JPP_LAUNCH((k_rnn_score<2, true, false, 1>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<2, true, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
     } else {
       if (sortE) JPP_LAUNCH((k_rnn_score<4, false, true>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<4, false, false>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
@@ -879,6 +905,16 @@ extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
   if (rc[0]) std::fprintf(stderr, "[jppgpu prof] rnn passes %llu nodes %llu (%.2f nodes per pass)\n", rc[0], rc[1], (double)rc[1] / (double)rc[0]);
   unsigned long long z2[2] = {0, 0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_cnt), z2, sizeof(z2));
+  unsigned long long lp[8] = {};
+  hipMemcpyFromSymbol(lp, HIP_SYMBOL(g_lock_prof), sizeof(lp));
+  if (lp[7]) {
+    const double w = (double)lp[7];
+    std::fprintf(stderr, "[jppgpu prof] rnn lock step, cycles per wavefront: setup %.0f | write B %.0f | barrier %.0f | fetch + mfma %.0f | "
+                 "barrier %.0f | sigmoid + store %.0f ; rounds per workgroup %.1f\n", lp[0] / w, lp[1] / w, lp[2] / w, lp[3] / w, lp[4] / w,
+                 lp[5] / w, lp[6] / w);
+  }
+  unsigned long long z8[8] = {};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_lock_prof), z8, sizeof(z8));
   unsigned long long z[16] = {};
   hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_prof), z, sizeof(z));
   return 0;

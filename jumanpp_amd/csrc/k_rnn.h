@@ -112,6 +112,42 @@ __device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
   return v ^ (v >> 32);
 }
 
+// The lattice connection of every surviving EOS path at every boundary (RnnIdContainer::addPath walks them the same
+// way, rnn_id_resolver.cc): one thread per (sentence, path) follows the beam pointers back from EOS -- a chain of
+// dependent HBM reads, so it runs as its own launch with every path of the batch in flight at once instead of on
+// six lanes of the wavefront that builds the rnn lattice.  conn[b][p] = node | beam slot << 26, or kNoConn.
+__global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
+  const u32 G = (u32)cfg.gbeam;
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 s = t / G, p = t - s * G;
+  if (s >= B.n_sent || B.sent_status[s] != ST_OK) return;
+  const u32 n = B.sent_ncp[s];
+  if (n == 0) return;
+  const u32 bb0 = B.byte_off[s] + 4 * s;
+  const u32 bE = n + 2;
+  const u32 ngb = B.bnd_ngb[bb0 + bE];
+  if (ngb == 0) return;
+  const u32 N = B.sent_nodes[s];
+  const u64 nb = B.node_base[s];
+  const u32 beam = (u32)cfg.beam;
+  u32* conn = B.rnn_conn + (u64)bb0 * G;
+  for (u32 b = 0; b <= bE; ++b) conn[(u64)b * G + p] = kNoConn;
+  if (p >= ngb) return;
+  const BeamSlot* beams = B.node_beam + nb * beam;
+  const GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + p];
+  conn[(u64)bE * G + p] = (N - 1) | (p << 26);  // fake EOS connection, "slot" = path index
+  u32 nd = B.end_nodes[nb + B.end_first[bb0 + bE] + ge.left];
+  u32 k = ge.beam;
+  u32 guard = 0;
+  while (nd >= 2 && guard++ <= n) {
+    const u32 b = (u32)B.node_info[nb + nd].start + 2;
+    const BeamSlot sl = beams[(u64)nd * beam + k];
+    conn[(u64)b * G + p] = nd | (k << 26);
+    nd = sl.prev_node;
+    k = sl.beam;
+  }
+}
+
 __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
@@ -162,25 +198,10 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   u32* rn_cnt = inLds ? l_cnt_all[wv] : g_cnt;                  // rnn nodes per boundary
   u16* clen = inLds ? l_clen_all[wv] : nullptr;
 
-  // ---- A. connection of every EOS path at every boundary ----
-  for (u32 q = lane; q < nq; q += 64) conn[q] = kNoConn;
+  // ---- A. connection of every EOS path at every boundary: made by k_rnn_paths ----
+  if (inLds)
+    for (u32 q = lane; q < nq; q += 64) conn[q] = g_conn[q];
   for (u32 q = lane; q <= bE; q += 64) rn_cnt[q] = 0;
-  wave_sync();
-  const u32 efirstE = B.end_first[bb0 + bE];
-  if (lane < ngb) {
-    GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
-    conn[(u64)bE * G + lane] = (N - 1) | ((u32)lane << 26);  // fake EOS connection, "slot" = path index
-    u32 nd = en[efirstE + ge.left];
-    u32 k = ge.beam;
-    u32 guard = 0;
-    while (nd >= 2 && guard++ <= n) {
-      u32 b = (u32)B.node_info[nb + nd].start + 2;
-      conn[(u64)b * G + lane] = nd | (k << 26);
-      BeamSlot sl = beams[(u64)nd * beam + k];
-      nd = sl.prev_node;
-      k = sl.beam;
-    }
-  }
   wave_sync();
   // ---- B. word ids of the connections ----
   // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the
@@ -505,39 +526,271 @@ __device__ __forceinline__ float rnn_dot_seq(const float JPP_GLOBAL* __restrict_
   return s;
 }
 
+// ---- grouping sentences by the length of their recurrence ----
+// A lock-step workgroup runs as many rounds as its longest chain, so the sentences are handed to workgroups in
+// order of chain length (a counting sort over kRnnOrderBins classes; which sentence shares a workgroup with which
+// has no influence on any result).  Sentences k_rnn_score does not stage in LDS form the last class.
+constexpr u32 kRnnOrderBins = 128;
+constexpr u32 kRnnStageCap = 264, kRnnStageCapB = 48;   // k_rnn_score's staging limits (connections, boundaries)
+
+__global__ void __launch_bounds__(256) k_rnn_order_key(Batch B, Config cfg) {
+  __shared__ u32 h[kRnnOrderBins];
+  if (threadIdx.x < kRnnOrderBins) h[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < B.n_sent) {
+    u32 key = 0;
+    const u32 n = B.sent_status[s] == ST_OK ? B.sent_ncp[s] : 0u;
+    if (n) {
+      const u32 bb0 = B.byte_off[s] + 4 * s;
+      const u32 bE = n + 2;
+      if (B.bnd_ngb[bb0 + bE]) {
+        if (bE + 1 > kRnnStageCapB || (bE + 1) * (u32)cfg.gbeam > kRnnStageCap) {
+          key = kRnnOrderBins - 1;
+        } else {
+          u32 c = 0;
+          for (u32 b = 2; b < bE; ++b) c += B.rnn_cnt[bb0 + b];
+          key = c < kRnnOrderBins - 2 ? c : kRnnOrderBins - 2;
+        }
+      }
+    }
+    B.rnn_key[s] = key;
+    atomicAdd(&h[key], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kRnnOrderBins && h[threadIdx.x]) atomicAdd(&B.rnn_hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// one workgroup of kRnnOrderBins threads: class sizes -> first slots; leaves the histogram zeroed for the next batch
+__global__ void __launch_bounds__(kRnnOrderBins) k_rnn_order_scan(Batch B) {
+  __shared__ u32 h[kRnnOrderBins];
+  h[threadIdx.x] = B.rnn_hist[threadIdx.x];
+  B.rnn_hist[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 run = 0;
+    for (u32 i = 0; i < kRnnOrderBins; ++i) {
+      const u32 x = h[i];
+      h[i] = run;
+      run += x;
+    }
+  }
+  __syncthreads();
+  B.rnn_offs[threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ void k_rnn_order_zero(u32* hist) { hist[threadIdx.x] = 0; }
+
+__global__ void __launch_bounds__(256) k_rnn_order_fill(Batch B) {
+  // ranks within the workgroup from LDS counters, then one global add per class and workgroup
+  __shared__ u32 h[kRnnOrderBins], base[kRnnOrderBins];
+  if (threadIdx.x < kRnnOrderBins) h[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 key = 0, local = 0;
+  if (s < B.n_sent) {
+    key = B.rnn_key[s];
+    local = atomicAdd(&h[key], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kRnnOrderBins && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&B.rnn_offs[threadIdx.x], h[threadIdx.x]);
+  __syncthreads();
+  if (s < B.n_sent) B.rnn_order[base[key] + local] = s;
+}
+
+// The recurrence of the 16 sentences of a workgroup in lock step (k_rnn_score<.., MFMA = true>).
+// Round r: a wavefront whose sentence has an r-th chained rnn node (the nodes before EOS, in boundary order, so a
+// node's predecessor always belongs to an earlier round) writes that node's input context into column `wv` of the
+// B tile; wavefront t < EP/16 then forms rows 16t..16t+15 of W * tile with EP/4 v_mfma_f32_16x16x4_f32 steps --
+// per output the same k-ascending fused chain as rnn_matvec (GbeamRnnState::computeContext, Eigen's gemv with the
+// reference's build flags) -- and parks the 16 x 16 results in LDS, where each owner picks up its column, adds the
+// embedding row, applies the sigmoid and stores the new context.
+// B tile layout: element (k, n) at ((k >> 4) * 64 + (k & 3) * 16 + n) * 4 + ((k >> 2) & 3), so that the lane
+// l = (k & 3) * 16 + n of a compute wavefront reads the operands of four consecutive steps with one 16-byte read.
+template <int J>
+__device__ __forceinline__ void rnn_chain_lockstep(const float* __restrict__ WtG, const float JPP_GLOBAL* __restrict__ embT, u32 E,
+                                                   float* rn_ctx, const u16* l_node, const u16* l_prev, const i32* l_id,
+                                                   u32 nchain, const u64* exptab, int wv, int lane) {
+  constexpr int EP = 64 * J;
+  // Four wavefronts do the matrix work, one per SIMD (each SIMD has its own matrix pipe; which wavefronts of a
+  // workgroup share a SIMD is the dispatcher's choice, so the roles follow HW_ID).  With E = 128 each of them has two
+  // row tiles of W, i.e. two independent accumulator chains: a single chain waits 40 cycles per 32-cycle step.
+  constexpr int MT = 4;
+  constexpr int TPW = EP / 16 / MT;
+  constexpr int kOutStride = EP + 4;
+  __shared__ __attribute__((aligned(16))) float s_B[EP * 16];
+  __shared__ __attribute__((aligned(16))) float s_out[16 * kOutStride];
+  __shared__ u32 s_rounds;
+  struct alignas(16) F4 {
+    float x, y, z, w;
+  };
+  __shared__ u32 s_first[4];        // lowest wavefront of the workgroup on every SIMD
+  JPP_LPROF_DECL;
+  for (u32 i = threadIdx.x; i < (u32)(EP * 16); i += blockDim.x) s_B[i] = 0.f;
+  if (threadIdx.x == 0) s_rounds = 0;
+  if (threadIdx.x < 4) s_first[threadIdx.x] = 0xffffffffu;
+  __syncthreads();
+  const u32 simd = wave_simd_id();
+  if (lane == 0) {
+    if (nchain) atomicMax(&s_rounds, nchain);
+    atomicMin(&s_first[simd], (u32)wv);
+  }
+  __syncthreads();
+  // (a workgroup that does not reach all four SIMDs falls back to its first four wavefronts)
+  const bool spread = s_first[0] != 0xffffffffu && s_first[1] != 0xffffffffu && s_first[2] != 0xffffffffu && s_first[3] != 0xffffffffu;
+  const int role = spread ? (s_first[simd] == (u32)wv ? (int)simd : -1) : (wv < MT ? wv : -1);
+  // A operands of this wavefront's row tiles: lane l holds W[16 (TPW role + t) + (l & 15)][4 kk + (l >> 4)] for every step kk
+  float wA[TPW][EP / 4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int kk = 0; kk < EP / 4; ++kk)
+      wA[t][kk] = role >= 0 ? WtG[(u32)(4 * kk + (lane >> 4)) * EP + 16u * (u32)(TPW * role + t) + (u32)(lane & 15)] : 0.f;
+  const u32 rounds = s_rounds;
+  float lastY[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) lastY[j] = 0.f;
+  u32 lastQ = 0xffffffffu;
+  // The loads of round r + 1 (embedding row, predecessor's context) are issued before the matrix work of round r, so
+  // that a round's critical path is write B | MFMA | sigmoid only.  Every wavefront issues the same number of
+  // global loads and stores per round whether it has a node or not (idle ones use row 0 of the context array, the
+  // b = 0 row no rnn node owns): with a fixed count the s_waitcnt before a use leaves the younger stores in flight
+  // instead of draining them (vmcnt is in order; behind a branch the compiler has to assume vmcnt(0)).
+  u32 q1 = 0, hnd1 = 0;
+  float emb1[J], c1[J];
+  auto fetch = [&](u32 r) {
+    const bool h1 = r < nchain;
+    u32 eid = 0;
+    q1 = hnd1 = 0;
+    if (h1) {
+      q1 = l_node[r];
+      hnd1 = l_prev[q1];
+      const i32 id = l_id[q1];
+      eid = id == -1 ? 0u : (u32)id;
+    }
+    // (this lane owns elements lane and lane + 64; the context is needed first)
+#pragma unroll
+    for (int j = 0; j < J; ++j) c1[j] = rn_ctx[(u64)hnd1 * EP + (u32)lane + 64u * j];   // (stale when round r is still making that row: then lastY is used)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const u32 k = (u32)lane + 64u * j;
+      emb1[j] = embT[(u64)eid * E + (k < E ? k : 0u)];
+    }
+  };
+  fetch(0);
+  vm_wait_all();   // (the loop is entered with nothing in flight: its waits are then the ones of the steady state)
+  JPP_LPROF(0);
+  for (u32 r = 0; r < rounds; ++r) {
+    const bool has = r < nchain;
+    const u32 q = q1;
+    float embv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) embv[j] = emb1[j];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {   // (a wavefront without a node writes its column too: nobody looks at the result)
+      const u32 k = (u32)lane + 64u * j;
+      s_B[((k >> 4) * 64 + (k & 3) * 16 + (u32)wv) * 4 + ((k >> 2) & 3)] = hnd1 == lastQ ? lastY[j] : c1[j];
+    }
+    JPP_LPROF(1);
+    lds_barrier();
+    JPP_LPROF(2);
+    fetch(r + 1);
+    if (role >= 0) {
+      MfmaAcc acc[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) acc[t] = MfmaAcc{{0.f, 0.f, 0.f, 0.f}};
+      const F4* bt = reinterpret_cast<const F4*>(s_B);
+#pragma unroll
+      for (int g = 0; g < EP / 16; ++g) {
+        const F4 b4 = bt[g * 64 + lane];
+        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[t] = mfma_f32_16x16x4(wA[t][4 * g + x], bv[x], acc[t]);
+      }
+      // D[4 (l >> 4) + i][l & 15]: outputs 16 tile + 4 (l >> 4) + i of the sentence in column l & 15
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        *reinterpret_cast<F4*>(&s_out[(lane & 15) * kOutStride + 16 * (TPW * role + t) + 4 * (lane >> 4)]) =
+            F4{acc[t].v[0], acc[t].v[1], acc[t].v[2], acc[t].v[3]};
+    }
+    JPP_LPROF(3);
+    lds_barrier();
+    JPP_LPROF(4);
+    float y[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) y[j] = 0.f;
+    if (has) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const u32 k = (u32)lane + 64u * j;
+        const float x = s_out[wv * kOutStride + (int)k] + embv[j];
+        y[j] = k < E ? sigmoid_ref(x, exptab) : 0.f;
+        lastY[j] = y[j];
+      }
+      lastQ = q;
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) rn_ctx[(u64)q * EP + (u32)lane + 64u * j] = y[j];   // (q = 0, the parking row, without a node)
+    JPP_LPROF(5);
+  }
+  JPP_LPROF_FLUSH(rounds);
+}
+
 // WLDS: the padded transposed recurrent matrix lives in LDS and is shared by the 16 wavefronts
 // of the workgroup; otherwise (E > 128) W is streamed from L2.
 // SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
-template <int J, bool WLDS, bool SORT>
-__global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
-  constexpr int kWaves = WLDS ? 16 : 4;
+// MODE 0: one kernel does everything (E > 128: W streamed from L2; E <= 128 with W in LDS is kept for reference).
+// MODE 1 + MODE 2 (E <= 128): the recurrence and the scoring are two launches.
+// MODE 1 = the recurrence only, in lock step over the 16 sentences of the workgroup.  Each
+// round every wavefront puts the context of its next rnn node into one column of a 128 x 16 LDS tile, and
+// wavefront t < EP/16 multiplies rows 16t .. 16t+15 of W -- held in 32 registers per lane for the whole kernel --
+// with that tile on the matrix cores (v_mfma_f32_16x16x4_f32: bitwise the k-ascending fused chain of rnn_matvec).
+// W is not copied to LDS at all; the LDS traffic per rnn node drops from 64 KB (W^T) to 4 KB (the B operands).
+// MODE 2 = everything but the recurrence (maxent sums, NCE dot products, score cells, adjustBeamScores, remakeEosBeam)
+// for the sentences MODE 1 handled, reading the contexts it left in HBM/L2; four wavefronts per workgroup and no
+// workgroup barrier, so several workgroups per CU hide each other's load latency.  Sentences beyond the LDS staging
+// limits get the complete boundary-by-boundary path here (W streamed from L2).
+template <int J, bool WLDS, bool SORT, int MODE = 0>
+__global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
+  constexpr bool MFMA = MODE == 1;
+  static_assert(MODE == 0 || (WLDS && J <= 2), "the lock-step variant covers E <= 128");
+  constexpr int kWaves = (WLDS && MODE != 2) ? 16 : 4;
   constexpr int EP = 64 * J;
+  constexpr bool kWinLds = WLDS && MODE == 0;
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
-  __shared__ float s_W[WLDS ? EP * EP : 1];
+  __shared__ float s_W[kWinLds ? EP * EP : 1];
   __shared__ u64 s_exptab[kExp2fN];   // 2^(i/32) table of expf_libm: lanes index it divergently
   if (threadIdx.x < (u32)kExp2fN) s_exptab[threadIdx.x] = exp2f_tab((int)threadIdx.x);
-  if (WLDS) {
+  if (kWinLds) {
     for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[rnn_w2_index<(J <= 2 ? J : 1)>(q / EP, q % EP)] = M.rnn_wt[q];
   }
   __syncthreads();
-  const float* __restrict__ Wt = WLDS ? s_W : M.rnn_wt;
-  const u32 s = blockIdx.x * kWaves + wv;
-  if (s >= B.n_sent) return;
-  if (B.sent_status[s] != ST_OK) return;
-  const u32 off = B.byte_off[s];
-  const u32 bb0 = off + 4 * s;
-  const u32 n = B.sent_ncp[s];
-  if (n == 0) return;
-  const u32 N = B.sent_nodes[s];
-  const u64 nb = B.node_base[s];
+  const float* __restrict__ Wt = kWinLds ? s_W : M.rnn_wt;
+  const u32 slot = blockIdx.x * kWaves + wv;
+  const u32 s = (MFMA && B.rnn_order && slot < B.n_sent) ? B.rnn_order[slot] : slot;
+  // `own`: this wavefront has a sentence to score.  Without MFMA the others leave; with it they stay for the
+  // workgroup barriers and the matrix work of the lock-step rounds.
+  bool own = s < B.n_sent && B.sent_status[s < B.n_sent ? s : 0] == ST_OK;
+  if (!MFMA && !own) return;
+  const u32 sc = own ? s : 0u;
+  const u32 off = B.byte_off[sc];
+  const u32 bb0 = off + 4 * sc;
+  const u32 n = own ? B.sent_ncp[sc] : 0u;
+  own = own && n != 0;
+  if (!MFMA && !own) return;
+  const u32 N = B.sent_nodes[sc];
+  const u64 nb = B.node_base[sc];
   const int beam = cfg.beam;
   const int G = cfg.gbeam;
   const int S = cfg.nscorers;
   const u32 bE = n + 2;
-  const int ngb = (int)B.bnd_ngb[bb0 + bE];
-  if (ngb == 0) return;
+  const int ngb = own ? (int)B.bnd_ngb[bb0 + bE] : 0;
+  own = own && ngb != 0;
+  if (!MFMA && !own) return;
   const u32 E = M.rnn_E;
   // model scalars and table pointers, read once: going through `M` inside the loops makes the compiler
   // re-issue the scalar loads after every store (it cannot prove the header is not aliased)
@@ -557,13 +810,13 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * EP;
 
   // the per-node fields the boundary loop depends on are staged in LDS when they fit
-  constexpr u32 kCap = 264, kCapB = 48;
+  constexpr u32 kCap = kRnnStageCap, kCapB = kRnnStageCapB;
   __shared__ u16 l_prev_all[kWaves][kCap];
   __shared__ i32 l_id_all[kWaves][kCap];
   __shared__ u8 l_cnt_all[kWaves][kCapB];
   // per connection (boundary, path): lattice node | slot << 16 | rnn node << 22 | gbeam index << 27, perceptron score cell
   __shared__ u32 l_conn_all[kWaves][kCap];
-  __shared__ float l_ctx_all[kWaves][WLDS ? EP : 1];   // the context a matvec multiplies, read back as broadcasts
+  __shared__ float l_ctx_all[kWaves][kWinLds ? EP : 1];   // the context a matvec multiplies, read back as broadcasts
   __shared__ float l_cell0_all[kWaves][kCap];
   __shared__ float l_mx_all[kWaves][kCap];
   constexpr u32 kPassCap = 2 * kCapB;
@@ -582,7 +835,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
   const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
   const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
   const u32* rn_cnt = B.rnn_cnt + bb0;
-  bool inLds = nq <= kCap && (bE + 1) <= kCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kCapB && G <= 32 && beam <= 64 && N <= 65535;
+  bool inLds = own && nq <= kCap && (bE + 1) <= kCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kCapB && G <= 32 && beam <= 64 && N <= 65535;
   if (inLds) {  // ... and the rnn nodes fit the node list (bE + 1 <= 64: one boundary per lane)
     const u32 mine = ((u32)lane >= 2 && (u32)lane <= bE) ? rn_cnt[lane] : 0u;
     inLds = wave_sum_u32(mine) <= kNodeCap;
@@ -596,7 +849,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     rn_id = l_id_all[wv];
     // connections: every load below is independent, so they are all in flight together
     const i32* g_gi = B.rnn_id + (u64)bb0 * G;
-    for (u32 q = lane; q < nq; q += 64) {
+    for (u32 q = lane; MODE != 1 && q < nq; q += 64) {
       const u32 c = conn[q];
       const u32 gi = (u32)g_gi[q];
       l_conn_all[wv][q] = c == kNoConn ? kNoConn : ((c & 0xffffu) | ((c >> 26) << 16) | ((assign[q] & 31u) << 22) | ((gi & 31u) << 27));
@@ -618,19 +871,22 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       float x = 0.f + embT[i];
       v = sigmoid_ref(x, s_exptab);
     }
-    rn_ctx[(u64)1 * G * EP + i] = v;
+    if (own && (MODE != 2 || !inLds)) rn_ctx[(u64)1 * G * EP + i] = v;
   }
   wave_sync();
+  float* l_mx = l_mx_all[wv];
+  const u16* l_prev = l_prev_all[wv];
+  const u8* l_cnt = l_cnt_all[wv];
+  u16* l_pass = l_pass_all[wv];
+  u16* l_node = l_node_all[wv];
+  u32 npass = 0, nnode = 0;
   if (inLds) {
     // Every word id is known before the recurrence starts, so everything that does not feed the next
     // context is taken off the serial chain.  Prologue: the maxent sums of all rnn nodes, one lane per
     // node, the pass list and the node list.  Chain: context -> matvec -> sigmoid -> store, nothing else.
     // Epilogue: the NCE dot products and scores, one lane per rnn node (the contexts are all in HBM/L2 by
     // then), the score cells, and adjustBeamScores along the paths.
-    float* l_mx = l_mx_all[wv];
-    const u16* l_prev = l_prev_all[wv];
-    const u8* l_cnt = l_cnt_all[wv];
-    {
+    if constexpr (MODE != 1) {
       // all gathers of all rounds go out before the first sum (one HBM round trip, not one per round)
       constexpr u32 kRounds = (kCap + 63) / 64;
       float mw[kRounds][4];
@@ -655,8 +911,6 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
     }
     // pass list: boundary | first node << 6 | (nodes - 1) << 11 | last pass of the boundary << 13;
     // node list: q = boundary * G + index of every rnn node, in boundary order
-    u16* l_pass = l_pass_all[wv];
-    u16* l_node = l_node_all[wv];
     {
       // lane b lists the passes / nodes of boundary b (bE + 1 <= kCapB <= 64) at the offsets exclusive scans give it
       const u32 bq = (u32)lane;
@@ -677,9 +931,16 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       }
     }
     wave_sync();
-    const u32 npass = l_npass_all[wv];
-    const u32 nnode = l_nnode_all[wv];
-    JPP_RPROF(1);
+    npass = l_npass_all[wv];
+    nnode = l_nnode_all[wv];
+  }
+  JPP_RPROF(1);
+  if constexpr (MFMA) {
+    rnn_chain_lockstep<J>(M.rnn_wt, embT, E, rn_ctx, l_node, l_prev, l_id_all[wv], inLds ? nnode - l_cnt[bE] : 0u, s_exptab, wv, lane);
+    JPP_RPROF(3);
+    JPP_RPROF_FLUSH;
+    return;
+  } else if (inLds && MODE == 0) {
     float embR[kRnnCN][J];                    // embedding rows of the current pass
     float lastOut[kRnnCN][J];                 // contexts produced by the previous pass, kept in registers
     u32 lastBase = 0xffffffffu, lastCn = 0;
@@ -737,7 +998,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
         for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
           for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
-        if constexpr (WLDS) {
+        if constexpr (kWinLds) {
           // one node at a time: its context goes to LDS once and comes back as broadcast reads, four
           // elements per read, instead of one v_readlane (+ hazard slots) per element
           float* l_ctx = l_ctx_all[wv];
@@ -778,6 +1039,8 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       }
       JPP_RPROF(3);
     }
+  }
+  if (inLds) {
     wave_sync();
     // ---- scores: one lane per rnn node ----
     // computeContextScores: (nce row .* context).colwise().sum() = the rounded products added for k ascending;
@@ -833,7 +1096,7 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
       }
     }
     wave_sync();
-  } else {
+  } else if (own) {
     for (u32 b = 2; b <= bE; ++b) {
       const int cnt = (int)rn_cnt[b];
       if (cnt == 0) continue;
@@ -920,10 +1183,10 @@ __global__ void __launch_bounds__(64 * (WLDS ? 16 : 4)) k_rnn_score(Batch B, con
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
           switch (cn) {
-            case 1: rnn_matvec_any<J, 1, WLDS>(Wt, ctx, acc, lane); break;
-            case 2: rnn_matvec_any<J, 2, WLDS>(Wt, ctx, acc, lane); break;
-            case 3: rnn_matvec_any<J, 3, WLDS>(Wt, ctx, acc, lane); break;
-            default: rnn_matvec_any<J, 4, WLDS>(Wt, ctx, acc, lane); break;
+            case 1: rnn_matvec_any<J, 1, kWinLds>(Wt, ctx, acc, lane); break;
+            case 2: rnn_matvec_any<J, 2, kWinLds>(Wt, ctx, acc, lane); break;
+            case 3: rnn_matvec_any<J, 3, kWinLds>(Wt, ctx, acc, lane); break;
+            default: rnn_matvec_any<J, 4, kWinLds>(Wt, ctx, acc, lane); break;
           }
 #pragma unroll
           for (int p = 0; p < kRnnCN; ++p) {

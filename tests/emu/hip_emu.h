@@ -13,6 +13,7 @@
 
 #include <ucontext.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -200,12 +201,42 @@ inline uint64_t ballot(bool p) {
   wave_barrier();
   return r;
 }
+// element `i` of a lane's v_mfma_f32_16x16x4_f32 result: the lanes publish (a, b), then lane l forms
+// D[4 * (l >> 4) + i][l & 15] as the k-ascending fused chain the matrix core computes
+inline float mfma_f32_16x16x4(float a, float b, float c, int i) {
+  State& s = st();
+  int base = s.cur - s.cur % kWave;
+  uint32_t ua, ub;
+  std::memcpy(&ua, &a, 4);
+  std::memcpy(&ub, &b, 4);
+  s.xchg[s.cur] = (uint64_t)ua | ((uint64_t)ub << 32);
+  wave_barrier();
+  const int l = s.cur % kWave;
+  const int m = 4 * (l >> 4) + i, n = l & 15;
+  float acc = c;
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t xa = (uint32_t)s.xchg[base + k * 16 + m];
+    const uint32_t xb = (uint32_t)(s.xchg[base + k * 16 + n] >> 32);
+    float fa, fb;
+    std::memcpy(&fa, &xa, 4);
+    std::memcpy(&fb, &xb, 4);
+    acc = std::fma(fa, fb, acc);
+  }
+  wave_barrier();
+  return acc;
+}
 }  // namespace hip_emu
 
 template <typename T>
 inline T atomicAdd(T* p, T v) {
   T o = *p;
   *p = o + v;
+  return o;
+}
+template <typename T>
+inline T atomicMin(T* p, T v) {
+  T o = *p;
+  if (v < o) *p = v;
   return o;
 }
 template <typename T>
