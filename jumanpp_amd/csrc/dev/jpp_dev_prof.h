@@ -6,7 +6,6 @@
 #define JPP_DEV_PROF_H
 __device__ unsigned long long g_sweep_prof[16];
 __device__ unsigned long long g_rnn_cnt[2];
-__device__ unsigned long long g_lock_prof[8];   // rnn_chain_lockstep: setup, write B, barrier, fetch + MFMA, barrier, sigmoid + store, rounds, waves
 #define JPP_PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define JPP_PROF(i)                                          \
   do {                                                       \
@@ -37,21 +36,6 @@ __device__ unsigned long long g_lock_prof[8];   // rnn_chain_lockstep: setup, wr
       atomicAdd(&g_sweep_prof[15], 1ull);                                                  \
       atomicAdd(&g_rnn_cnt[0], rprof_pass);                                                \
       atomicAdd(&g_rnn_cnt[1], rprof_nodes);                                               \
-    }                                                                                      \
-  } while (0)
-#define JPP_LPROF_DECL unsigned long long lprof_t = __builtin_readcyclecounter(), lprof_acc[6] = {0, 0, 0, 0, 0, 0}
-#define JPP_LPROF(i)                                         \
-  do {                                                       \
-    unsigned long long now_ = __builtin_readcyclecounter();  \
-    lprof_acc[i] += now_ - lprof_t;                          \
-    lprof_t = now_;                                          \
-  } while (0)
-#define JPP_LPROF_FLUSH(rounds)                                                            \
-  do {                                                                                     \
-    if (lane == 0) {                                                                       \
-      for (int q_ = 0; q_ < 6; ++q_) atomicAdd(&g_lock_prof[q_], lprof_acc[q_]);           \
-      atomicAdd(&g_lock_prof[6], (unsigned long long)(rounds));                            \
-      atomicAdd(&g_lock_prof[7], 1ull);                                                    \
     }                                                                                      \
   } while (0)
 #endif  // JPP_DEV_PROF_H

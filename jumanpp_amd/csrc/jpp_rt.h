@@ -30,9 +30,6 @@ typedef hipStream_t jpp_stream_t;
 #define JPP_RPROF(i)
 #define JPP_RPROF_COUNT(cn)
 #define JPP_RPROF_FLUSH
-#define JPP_LPROF_DECL
-#define JPP_LPROF(i)
-#define JPP_LPROF_FLUSH(rounds)
 #endif
 
 typedef uint8_t u8;

@@ -794,8 +794,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
     const DevModel* dm = (const DevModel*)ctx->dmodel;
-    static const bool ldsW = getenv("JPPGPU_RNN_LDSW") != nullptr;   // (measurement only)
-    if (ctx->hmodel.rnn_EP <= 128 && !ldsW && getenv("JPPGPU_RNN_NOORDER") == nullptr) {
+    if (ctx->hmodel.rnn_EP <= 128) {
       // lock-step workgroups take sentences of equal chain length
       B.rnn_order = B.rnn_key + n;
       if (ctx->rnn_ord_zeroed != ctx->rnn_ord.p) {   // a fresh allocation: the histogram starts at zero, k_rnn_order_scan keeps it there
@@ -806,23 +805,17 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
-    if (ctx->hmodel.rnn_EP == 64 && ldsW) {
-      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, true>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<1, true, false>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-    } else if (ctx->hmodel.rnn_EP == 128 && ldsW) {
-      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, true>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<2, true, false>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-    } else if (ctx->hmodel.rnn_EP == 64) {
-      JPP_LAUNCH((k_rnn_score<1, true, false, 1>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<1, true, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+    if (ctx->hmodel.rnn_EP == 64) {
+      JPP_LAUNCH((k_rnn_chain<1>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<1, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
     } else if (ctx->hmodel.rnn_EP == 128) {
-      JPP_LAUNCH((k_rnn_score<2, true, false, 1>), (n + 15) / 16, 1024, st, B, dm, ctx->cfg);
-      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<2, true, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      JPP_LAUNCH((k_rnn_chain<2>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<2, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
     } else {
-      if (sortE) JPP_LAUNCH((k_rnn_score<4, false, true>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<4, false, false>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<4, true, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<4, false, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
     }
   }
   T.mark(6, st);
@@ -905,16 +898,6 @@ extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
   if (rc[0]) std::fprintf(stderr, "[jppgpu prof] rnn passes %llu nodes %llu (%.2f nodes per pass)\n", rc[0], rc[1], (double)rc[1] / (double)rc[0]);
   unsigned long long z2[2] = {0, 0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_cnt), z2, sizeof(z2));
-  unsigned long long lp[8] = {};
-  hipMemcpyFromSymbol(lp, HIP_SYMBOL(g_lock_prof), sizeof(lp));
-  if (lp[7]) {
-    const double w = (double)lp[7];
-    std::fprintf(stderr, "[jppgpu prof] rnn lock step, cycles per wavefront: setup %.0f | write B %.0f | barrier %.0f | fetch + mfma %.0f | "
-                 "barrier %.0f | sigmoid + store %.0f ; rounds per workgroup %.1f\n", lp[0] / w, lp[1] / w, lp[2] / w, lp[3] / w, lp[4] / w,
-                 lp[5] / w, lp[6] / w);
-  }
-  unsigned long long z8[8] = {};
-  hipMemcpyToSymbol(HIP_SYMBOL(g_lock_prof), z8, sizeof(z8));
   unsigned long long z[16] = {};
   hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_prof), z, sizeof(z));
   return 0;

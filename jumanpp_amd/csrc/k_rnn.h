@@ -361,120 +361,6 @@ __device__ __forceinline__ void rnn_matvec(const float* __restrict__ Wt, const f
   }
 }
 
-#if !defined(JPP_EMU)
-typedef float rnn_f2 __attribute__((ext_vector_type(2)));
-#endif
-
-// index of W^T[k][i] in the LDS copy (EP = 64 J, J <= 2): rows are interleaved in pairs so that one read
-// gives a lane the 2 J weights of rows k, k+1 for its J outputs -- [k/2][lane][k&1][j]
-template <int J>
-__device__ __forceinline__ u32 rnn_w2_index(u32 k, u32 i) {
-  return ((((k >> 1) * 64u + i / J) * 2u) + (k & 1u)) * J + (i % J);
-}
-
-// same sum, same order as rnn_matvec (k ascending), on the pair-interleaved LDS copy: half the LDS
-// reads, and for J = 2 both outputs of a lane advance in one packed FMA
-template <int J, int CN>
-__device__ __forceinline__ void rnn_matvec_lds(const float* __restrict__ W2, const float (&ctx)[kRnnCN][J],
-                                               float (&acc)[kRnnCN][J], int lane) {
-  static_assert(J == 1 || J == 2, "the LDS copy exists for E <= 128 only");
-  constexpr int EP = 64 * J;
-#pragma unroll 8
-  for (int kp = 0; kp < EP / 2; ++kp) {
-    const float* row = W2 + (kp * 64 + lane) * 2 * J;
-    float w[2][J];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int j = 0; j < J; ++j) w[r][j] = row[r * J + j];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int src = J == 2 ? kp : 2 * kp + r;   // lane holding ctx element k = 2 kp + r
-      constexpr int kZero = 0;
-      const int j2 = J == 2 ? r : kZero;
-#pragma unroll
-      for (int p = 0; p < CN; ++p) {
-        const float c = wave_bcast_f32(j2 == 0 ? ctx[p][0] : ctx[p][J - 1], src);
-#if !defined(JPP_EMU)
-        if (J == 2) {
-          rnn_f2 a = {acc[p][0], acc[p][J - 1]};
-          const rnn_f2 ww = {w[r][0], w[r][J - 1]};
-          const rnn_f2 cc = {c, c};
-          a = __builtin_elementwise_fma(ww, cc, a);
-          acc[p][0] = a.x;
-          acc[p][J - 1] = a.y;
-          continue;
-        }
-#endif
-#pragma unroll
-        for (int j = 0; j < J; ++j) acc[p][j] = __builtin_fmaf(w[r][j], c, acc[p][j]);
-      }
-    }
-  }
-}
-
-// one context, staged in LDS (lctx[k], k < EP): out[:] += W^T[k][:] * lctx[k], k ascending like rnn_matvec.
-// The four context elements of a step arrive by one broadcast read, the weights of two rows by another.
-template <int J>
-__device__ __forceinline__ void rnn_matvec_lds1(const float* __restrict__ W2, const float* __restrict__ lctx,
-                                                float (&acc)[J], int lane) {
-  static_assert(J == 1 || J == 2, "the LDS copy exists for E <= 128 only");
-  constexpr int EP = 64 * J;
-  constexpr int KB = 16;       // context elements per block
-  constexpr int NB = EP / KB;
-  struct Blk {
-    float c[KB];
-    float w[KB / 2][2 * J];
-  };
-  // all reads of a block are issued back to back and consumed in order as they return (the other three
-  // wavefronts of the SIMD cover what latency is left); a second block in flight does not fit 128 VGPRs
-  auto load = [&](int blk, Blk& b) {
-#pragma unroll
-    for (int t = 0; t < KB; ++t) b.c[t] = lctx[blk * KB + t];
-#pragma unroll
-    for (int h = 0; h < KB / 2; ++h) {
-      const float* row = W2 + ((blk * (KB / 2) + h) * 64 + lane) * 2 * J;
-#pragma unroll
-      for (int x = 0; x < 2 * J; ++x) b.w[h][x] = row[x];
-    }
-  };
-  auto consume = [&](const Blk& b) {
-#pragma unroll
-    for (int h = 0; h < KB / 2; ++h) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const float cc1 = b.c[2 * h + r];
-#if !defined(JPP_EMU)
-        if (J == 2) {
-          rnn_f2 a = {acc[0], acc[J - 1]};
-          const rnn_f2 ww = {b.w[h][r * J], b.w[h][r * J + J - 1]};
-          const rnn_f2 cc = {cc1, cc1};
-          a = __builtin_elementwise_fma(ww, cc, a);
-          acc[0] = a.x;
-          acc[J - 1] = a.y;
-          continue;
-        }
-#endif
-#pragma unroll
-        for (int j = 0; j < J; ++j) acc[j] = __builtin_fmaf(b.w[h][r * J + j], cc1, acc[j]);
-      }
-    }
-  };
-#pragma unroll 1
-  for (int blk = 0; blk < NB; ++blk) {
-    Blk b;
-    load(blk, b);
-    consume(b);
-  }
-}
-
-template <int J, int CN, bool WLDS>
-__device__ __forceinline__ void rnn_matvec_any(const float* __restrict__ Wt, const float (&ctx)[kRnnCN][J],
-                                               float (&acc)[kRnnCN][J], int lane) {
-  if constexpr (WLDS) rnn_matvec_lds<J, CN>(Wt, ctx, acc, lane);
-  else rnn_matvec<J, CN>(Wt, ctx, acc, lane);
-}
-
 // MikolovIndexCalculator::calcIndices + the weight gathers of MikolovScoreCalculator::calcScoresN for one
 // (word, history) pair; the caller adds w[0] + w[1] + ... left to right.  Every history slot holds
 // prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is
@@ -598,44 +484,120 @@ __global__ void __launch_bounds__(256) k_rnn_order_fill(Batch B) {
   if (s < B.n_sent) B.rnn_order[base[key] + local] = s;
 }
 
-// The recurrence of the 16 sentences of a workgroup in lock step (k_rnn_score<.., MFMA = true>).
-// Round r: a wavefront whose sentence has an r-th chained rnn node (the nodes before EOS, in boundary order, so a
-// node's predecessor always belongs to an earlier round) writes that node's input context into column `wv` of the
-// B tile; wavefront t < EP/16 then forms rows 16t..16t+15 of W * tile with EP/4 v_mfma_f32_16x16x4_f32 steps --
-// per output the same k-ascending fused chain as rnn_matvec (GbeamRnnState::computeContext, Eigen's gemv with the
-// reference's build flags) -- and parks the 16 x 16 results in LDS, where each owner picks up its column, adds the
-// embedding row, applies the sigmoid and stores the new context.
+constexpr u32 kRnnNodeCap = 96;   // rnn nodes of a staged sentence
+
+// whether a sentence's rnn lattice is staged in LDS (k_rnn_chain and k_rnn_score<.., 2> must agree); all lanes call it
+__device__ __forceinline__ bool rnn_stageable(u32 nq, u32 bE, int G, int beam, u32 N, const u32* rn_cnt, int lane) {
+  bool ok = nq <= kRnnStageCap && (bE + 1) <= kRnnStageCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kRnnStageCapB &&
+            G <= 32 && beam <= 64 && N <= 65535;
+  if (ok) {  // ... and the rnn nodes fit the node list (bE + 1 <= 64: one boundary per lane)
+    const u32 mine = ((u32)lane >= 2 && (u32)lane <= bE) ? rn_cnt[lane] : 0u;
+    ok = wave_sum_u32(mine) <= kRnnNodeCap;
+  }
+  return ok;
+}
+
+// ---- the recurrence (GbeamRnnState::computeContext for every rnn node before EOS), E <= 128 ----
+// A workgroup of 16 wavefronts runs 32 sentences in lock step, as two groups of 16 (wavefront w owns sentence w of
+// either group).  A group's round r: every owner writes the input context of its r-th chained rnn node (the nodes
+// before EOS in boundary order, so a node's predecessor always belongs to an earlier round) into column w of the
+// group's 128 x 16 B tile; four wavefronts, one per SIMD (each SIMD has its own matrix pipe; the roles follow
+// HW_ID because which wavefronts share a SIMD is the dispatcher's choice), multiply their rows of W -- held in
+// registers for the whole kernel -- with the tile: EP/4 v_mfma_f32_16x16x4_f32 steps per row tile, per output
+// bitwise the k-ascending fused chain of rnn_matvec (Eigen's gemv with the reference's build flags); the 16 x 16
+// results are parked in LDS, where each owner picks up its column, adds the embedding row, applies the sigmoid and
+// stores the new context.  The two groups alternate: while the matrix pipes work on one group's tile the owners
+// finish the other group's previous round and write its next tile, so a half step costs about one tile product.
+// LDS traffic per rnn node: the 4 KB of B operands (a per-sentence matvec would read the 64 KB of W^T per node).
 // B tile layout: element (k, n) at ((k >> 4) * 64 + (k & 3) * 16 + n) * 4 + ((k >> 2) & 3), so that the lane
-// l = (k & 3) * 16 + n of a compute wavefront reads the operands of four consecutive steps with one 16-byte read.
+// l = (k & 3) * 16 + n of a computing wavefront reads the operands of four consecutive steps with one 16-byte read.
+// Global loads and stores are issued in the same number by every wavefront and half step whether it has a node or
+// not (idle ones use row 0 of the context array, the b = 0 row no rnn node owns): with a fixed count the s_waitcnt
+// before a use leaves the younger stores in flight instead of draining them (vmcnt is in order; behind a branch the
+// compiler has to assume vmcnt(0)).
 template <int J>
-__device__ __forceinline__ void rnn_chain_lockstep(const float* __restrict__ WtG, const float JPP_GLOBAL* __restrict__ embT, u32 E,
-                                                   float* rn_ctx, const u16* l_node, const u16* l_prev, const i32* l_id,
-                                                   u32 nchain, const u64* exptab, int wv, int lane) {
+__global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   constexpr int EP = 64 * J;
-  // Four wavefronts do the matrix work, one per SIMD (each SIMD has its own matrix pipe; which wavefronts of a
-  // workgroup share a SIMD is the dispatcher's choice, so the roles follow HW_ID).  With E = 128 each of them has two
-  // row tiles of W, i.e. two independent accumulator chains: a single chain waits 40 cycles per 32-cycle step.
-  constexpr int MT = 4;
-  constexpr int TPW = EP / 16 / MT;
+  constexpr int kWaves = 16, NG = 2;
+  constexpr int MT = 4;                 // computing wavefronts
+  constexpr int TPW = EP / 16 / MT;     // row tiles of W each (two independent accumulator chains for E = 128:
+                                        // a single chain waits 40 cycles per 32-cycle step)
   constexpr int kOutStride = EP + 4;
-  __shared__ __attribute__((aligned(16))) float s_B[EP * 16];
-  __shared__ __attribute__((aligned(16))) float s_out[16 * kOutStride];
+  const DevModel& M = *Mp;
+  const int wv = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  __shared__ u64 s_exptab[kExp2fN];
+  __shared__ u16 l_prev_all[NG][kWaves][kRnnStageCap];
+  __shared__ i32 l_id_all[NG][kWaves][kRnnStageCap];
+  __shared__ u16 l_node_all[NG][kWaves][kRnnNodeCap];   // rnn nodes (boundary * G + index) in boundary order
+  __shared__ __attribute__((aligned(16))) float s_B[NG][EP * 16];
+  __shared__ __attribute__((aligned(16))) float s_out[NG][16 * kOutStride];
   __shared__ u32 s_rounds;
+  __shared__ u32 s_first[4];            // lowest wavefront of the workgroup on every SIMD
   struct alignas(16) F4 {
     float x, y, z, w;
   };
-  __shared__ u32 s_first[4];        // lowest wavefront of the workgroup on every SIMD
-  JPP_LPROF_DECL;
-  for (u32 i = threadIdx.x; i < (u32)(EP * 16); i += blockDim.x) s_B[i] = 0.f;
+  if (threadIdx.x < (u32)kExp2fN) s_exptab[threadIdx.x] = exp2f_tab((int)threadIdx.x);
+  for (u32 i = threadIdx.x; i < (u32)(NG * EP * 16); i += blockDim.x) (&s_B[0][0])[i] = 0.f;
   if (threadIdx.x == 0) s_rounds = 0;
   if (threadIdx.x < 4) s_first[threadIdx.x] = 0xffffffffu;
   __syncthreads();
+  const int G = cfg.gbeam;
+  const u32 E = M.rnn_E;
+  const float JPP_GLOBAL* __restrict__ embT = as_global(M.rnn_emb);
+
+  // ---- per sentence: stage predecessor handles and word ids, BOS state, node list ----
+  u32 nchain[NG];
+  float* rn_ctx[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const u32 slot = (blockIdx.x * NG + (u32)g) * kWaves + (u32)wv;
+    const u32 s = slot < B.n_sent ? B.rnn_order[slot] : 0u;
+    bool own = slot < B.n_sent && B.sent_status[s] == ST_OK;
+    const u32 n = own ? B.sent_ncp[s] : 0u;
+    const u32 bb0 = B.byte_off[s] + 4 * s;
+    const u32 bE = n + 2;
+    own = own && n != 0 && B.bnd_ngb[bb0 + bE] != 0;
+    rn_ctx[g] = B.rnn_ctx + (u64)bb0 * G * EP;   // (not own: some sentence's row 0 serves as the parking row)
+    nchain[g] = 0;
+    const u32 nq = (bE + 1) * (u32)G;
+    const u32* rn_cnt = B.rnn_cnt + bb0;
+    if (own && rnn_stageable(nq, bE, G, cfg.beam, B.sent_nodes[s], rn_cnt, lane)) {
+      const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
+      const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
+      for (u32 q = lane; q < nq; q += 64) {
+        l_prev_all[g][wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
+        l_id_all[g][wv][q] = rn_id[q];
+      }
+      // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const u32 i = (u32)lane + 64u * j;
+        float v = 0.f;
+        if (i < E) {
+          const float x = 0.f + embT[i];
+          v = sigmoid_ref(x, s_exptab);
+        }
+        rn_ctx[g][(u64)1 * G * EP + i] = v;
+      }
+      // lane b lists the rnn nodes of boundary b at the offset an exclusive scan gives it
+      const u32 bq = (u32)lane;
+      const u32 cnt = (bq >= 2 && bq <= bE) ? rn_cnt[bq] : 0u;
+      const u32 incl = wave_scan_incl_u32(cnt, lane);
+      u32 nn = incl - cnt;
+      for (u32 i = 0; i < cnt; ++i) l_node_all[g][wv][nn++] = (u16)(bq * (u32)G + i);
+      nchain[g] = wave_shfl_u32(incl - cnt, (int)bE);   // nodes before the EOS boundary
+    }
+  }
+  wave_sync();
   const u32 simd = wave_simd_id();
   if (lane == 0) {
-    if (nchain) atomicMax(&s_rounds, nchain);
+    const u32 m = nchain[0] > nchain[1] ? nchain[0] : nchain[1];
+    if (m) atomicMax(&s_rounds, m);
     atomicMin(&s_first[simd], (u32)wv);
   }
   __syncthreads();
+  const u32 rounds = s_rounds;
   // (a workgroup that does not reach all four SIMDs falls back to its first four wavefronts)
   const bool spread = s_first[0] != 0xffffffffu && s_first[1] != 0xffffffffu && s_first[2] != 0xffffffffu && s_first[3] != 0xffffffffu;
   const int role = spread ? (s_first[simd] == (u32)wv ? (int)simd : -1) : (wv < MT ? wv : -1);
@@ -645,152 +607,144 @@ __device__ __forceinline__ void rnn_chain_lockstep(const float* __restrict__ WtG
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int kk = 0; kk < EP / 4; ++kk)
-      wA[t][kk] = role >= 0 ? WtG[(u32)(4 * kk + (lane >> 4)) * EP + 16u * (u32)(TPW * role + t) + (u32)(lane & 15)] : 0.f;
-  const u32 rounds = s_rounds;
-  float lastY[J];
+      wA[t][kk] = role >= 0 ? M.rnn_wt[(u32)(4 * kk + (lane >> 4)) * EP + 16u * (u32)(TPW * role + t) + (u32)(lane & 15)] : 0.f;
+
+  float lastY[NG][J], emb1[NG][J], c1[NG][J], embv[NG][J];
+  u32 lastQ[NG], q1[NG], hnd1[NG], qcur[NG];
+  bool has[NG];
 #pragma unroll
-  for (int j = 0; j < J; ++j) lastY[j] = 0.f;
-  u32 lastQ = 0xffffffffu;
-  // The loads of round r + 1 (embedding row, predecessor's context) are issued before the matrix work of round r, so
-  // that a round's critical path is write B | MFMA | sigmoid only.  Every wavefront issues the same number of
-  // global loads and stores per round whether it has a node or not (idle ones use row 0 of the context array, the
-  // b = 0 row no rnn node owns): with a fixed count the s_waitcnt before a use leaves the younger stores in flight
-  // instead of draining them (vmcnt is in order; behind a branch the compiler has to assume vmcnt(0)).
-  u32 q1 = 0, hnd1 = 0;
-  float emb1[J], c1[J];
-  auto fetch = [&](u32 r) {
-    const bool h1 = r < nchain;
+  for (int g = 0; g < NG; ++g) {
+    lastQ[g] = 0xffffffffu;
+    q1[g] = hnd1[g] = qcur[g] = 0;
+    has[g] = false;
+#pragma unroll
+    for (int j = 0; j < J; ++j) lastY[g][j] = emb1[g][j] = c1[g][j] = embv[g][j] = 0.f;
+  }
+  // loads of group g's round r: predecessor's context (this lane owns elements lane and lane + 64) and embedding row
+  auto fetch = [&](int g, u32 r) {
     u32 eid = 0;
-    q1 = hnd1 = 0;
-    if (h1) {
-      q1 = l_node[r];
-      hnd1 = l_prev[q1];
-      const i32 id = l_id[q1];
+    q1[g] = hnd1[g] = 0;
+    if (r < nchain[g]) {
+      q1[g] = l_node_all[g][wv][r];
+      hnd1[g] = l_prev_all[g][wv][q1[g]];
+      const i32 id = l_id_all[g][wv][q1[g]];
       eid = id == -1 ? 0u : (u32)id;
     }
-    // (this lane owns elements lane and lane + 64; the context is needed first)
 #pragma unroll
-    for (int j = 0; j < J; ++j) c1[j] = rn_ctx[(u64)hnd1 * EP + (u32)lane + 64u * j];   // (stale when round r is still making that row: then lastY is used)
+    for (int j = 0; j < J; ++j) c1[g][j] = rn_ctx[g][(u64)hnd1[g] * EP + (u32)lane + 64u * j];   // (stale while that row is being made: then lastY is used)
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       const u32 k = (u32)lane + 64u * j;
-      emb1[j] = embT[(u64)eid * E + (k < E ? k : 0u)];
+      emb1[g][j] = embT[(u64)eid * E + (k < E ? k : 0u)];
     }
   };
-  fetch(0);
-  vm_wait_all();   // (the loop is entered with nothing in flight: its waits are then the ones of the steady state)
-  JPP_LPROF(0);
-  for (u32 r = 0; r < rounds; ++r) {
-    const bool has = r < nchain;
-    const u32 q = q1;
-    float embv[J];
+  // group g's round r: column of the B tile (a wavefront without a node writes its column too: nobody looks at the result)
+  auto write_b = [&](int g, u32 r) {
+    has[g] = r < nchain[g];
+    qcur[g] = q1[g];
 #pragma unroll
-    for (int j = 0; j < J; ++j) embv[j] = emb1[j];
-#pragma unroll
-    for (int j = 0; j < J; ++j) {   // (a wavefront without a node writes its column too: nobody looks at the result)
+    for (int j = 0; j < J; ++j) {
       const u32 k = (u32)lane + 64u * j;
-      s_B[((k >> 4) * 64 + (k & 3) * 16 + (u32)wv) * 4 + ((k >> 2) & 3)] = hnd1 == lastQ ? lastY[j] : c1[j];
+      embv[g][j] = emb1[g][j];
+      s_B[g][((k >> 4) * 64 + (k & 3) * 16 + (u32)wv) * 4 + ((k >> 2) & 3)] = hnd1[g] == lastQ[g] ? lastY[g][j] : c1[g][j];
     }
-    JPP_LPROF(1);
-    lds_barrier();
-    JPP_LPROF(2);
-    fetch(r + 1);
-    if (role >= 0) {
-      MfmaAcc acc[TPW];
+  };
+  auto tile_product = [&](int g) {
+    MfmaAcc acc[TPW];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[t] = MfmaAcc{{0.f, 0.f, 0.f, 0.f}};
-      const F4* bt = reinterpret_cast<const F4*>(s_B);
+    for (int t = 0; t < TPW; ++t) acc[t] = MfmaAcc{{0.f, 0.f, 0.f, 0.f}};
+    const F4* bt = reinterpret_cast<const F4*>(s_B[g]);
 #pragma unroll
-      for (int g = 0; g < EP / 16; ++g) {
-        const F4 b4 = bt[g * 64 + lane];
-        const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+    for (int x4 = 0; x4 < EP / 16; ++x4) {
+      const F4 b4 = bt[x4 * 64 + lane];
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+      for (int x = 0; x < 4; ++x)
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[t] = mfma_f32_16x16x4(wA[t][4 * g + x], bv[x], acc[t]);
-      }
-      // D[4 (l >> 4) + i][l & 15]: outputs 16 tile + 4 (l >> 4) + i of the sentence in column l & 15
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-        *reinterpret_cast<F4*>(&s_out[(lane & 15) * kOutStride + 16 * (TPW * role + t) + 4 * (lane >> 4)]) =
-            F4{acc[t].v[0], acc[t].v[1], acc[t].v[2], acc[t].v[3]};
+        for (int t = 0; t < TPW; ++t) acc[t] = mfma_f32_16x16x4(wA[t][4 * x4 + x], bv[x], acc[t]);
     }
-    JPP_LPROF(3);
-    lds_barrier();
-    JPP_LPROF(4);
+    // D[4 (l >> 4) + i][l & 15]: outputs 16 tile + 4 (l >> 4) + i of the sentence in column l & 15
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      *reinterpret_cast<F4*>(&s_out[g][(lane & 15) * kOutStride + 16 * (TPW * role + t) + 4 * (lane >> 4)]) =
+          F4{acc[t].v[0], acc[t].v[1], acc[t].v[2], acc[t].v[3]};
+  };
+  // group g's pending round: column of the product + embedding row -> sigmoid -> the node's context
+  auto finish = [&](int g) {
     float y[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) y[j] = 0.f;
-    if (has) {
+    if (has[g]) {
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const u32 k = (u32)lane + 64u * j;
-        const float x = s_out[wv * kOutStride + (int)k] + embv[j];
-        y[j] = k < E ? sigmoid_ref(x, exptab) : 0.f;
-        lastY[j] = y[j];
+        const float x = s_out[g][wv * kOutStride + (int)k] + embv[g][j];
+        y[j] = k < E ? sigmoid_ref(x, s_exptab) : 0.f;
+        lastY[g][j] = y[j];
       }
-      lastQ = q;
+      lastQ[g] = qcur[g];
     }
 #pragma unroll
-    for (int j = 0; j < J; ++j) rn_ctx[(u64)q * EP + (u32)lane + 64u * j] = y[j];   // (q = 0, the parking row, without a node)
-    JPP_LPROF(5);
+    for (int j = 0; j < J; ++j) rn_ctx[g][(u64)qcur[g] * EP + (u32)lane + 64u * j] = y[j];   // (row 0, the parking row, without a node)
+    has[g] = false;
+    qcur[g] = 0;
+  };
+  fetch(0, 0);
+  fetch(1, 0);
+  vm_wait_all();   // (the loop is entered with nothing in flight: its waits are then the ones of the steady state)
+  write_b(0, 0);
+  lds_barrier();
+  for (u32 r = 0; r < rounds; ++r) {
+    // matrix pipes: group 0, round r | owners: finish group 1's round r - 1, write its round r
+    fetch(0, r + 1);
+    if (role >= 0) tile_product(0);
+    finish(1);
+    write_b(1, r);
+    lds_barrier();
+    // matrix pipes: group 1, round r | owners: finish group 0's round r, write its round r + 1
+    fetch(1, r + 1);
+    if (role >= 0) tile_product(1);
+    finish(0);
+    write_b(0, r + 1);
+    lds_barrier();
   }
-  JPP_LPROF_FLUSH(rounds);
+  finish(1);
 }
 
-// WLDS: the padded transposed recurrent matrix lives in LDS and is shared by the 16 wavefronts
-// of the workgroup; otherwise (E > 128) W is streamed from L2.
 // SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
-// MODE 0: one kernel does everything (E > 128: W streamed from L2; E <= 128 with W in LDS is kept for reference).
-// MODE 1 + MODE 2 (E <= 128): the recurrence and the scoring are two launches.
-// MODE 1 = the recurrence only, in lock step over the 16 sentences of the workgroup.  Each
-// round every wavefront puts the context of its next rnn node into one column of a 128 x 16 LDS tile, and
-// wavefront t < EP/16 multiplies rows 16t .. 16t+15 of W -- held in 32 registers per lane for the whole kernel --
-// with that tile on the matrix cores (v_mfma_f32_16x16x4_f32: bitwise the k-ascending fused chain of rnn_matvec).
-// W is not copied to LDS at all; the LDS traffic per rnn node drops from 64 KB (W^T) to 4 KB (the B operands).
-// MODE 2 = everything but the recurrence (maxent sums, NCE dot products, score cells, adjustBeamScores, remakeEosBeam)
-// for the sentences MODE 1 handled, reading the contexts it left in HBM/L2; four wavefronts per workgroup and no
-// workgroup barrier, so several workgroups per CU hide each other's load latency.  Sentences beyond the LDS staging
-// limits get the complete boundary-by-boundary path here (W streamed from L2).
-template <int J, bool WLDS, bool SORT, int MODE = 0>
-__global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
-  constexpr bool MFMA = MODE == 1;
-  static_assert(MODE == 0 || (WLDS && J <= 2), "the lock-step variant covers E <= 128");
-  constexpr int kWaves = (WLDS && MODE != 2) ? 16 : 4;
+// MODE 0 (E > 128): one launch does everything, W streamed from L2.
+// MODE 2 (E <= 128, after k_rnn_chain): everything but the recurrence (maxent sums, NCE dot products, score cells,
+// adjustBeamScores, remakeEosBeam) for the sentences k_rnn_chain handled, reading the contexts it left in HBM/L2.
+// Sentences beyond the LDS staging limits get the complete boundary-by-boundary path here (W streamed from L2).
+// Four wavefronts (sentences) per workgroup and no workgroup barrier after the start: several workgroups per CU
+// hide each other's load latency.
+template <int J, bool SORT, int MODE>
+__global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
+  static_assert(MODE == 0 || (MODE == 2 && J <= 2), "k_rnn_chain covers E <= 128");
+  constexpr int kWaves = 4;
   constexpr int EP = 64 * J;
-  constexpr bool kWinLds = WLDS && MODE == 0;
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
-  __shared__ float s_W[kWinLds ? EP * EP : 1];
   __shared__ u64 s_exptab[kExp2fN];   // 2^(i/32) table of expf_libm: lanes index it divergently
   if (threadIdx.x < (u32)kExp2fN) s_exptab[threadIdx.x] = exp2f_tab((int)threadIdx.x);
-  if (kWinLds) {
-    for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[rnn_w2_index<(J <= 2 ? J : 1)>(q / EP, q % EP)] = M.rnn_wt[q];
-  }
   __syncthreads();
-  const float* __restrict__ Wt = kWinLds ? s_W : M.rnn_wt;
-  const u32 slot = blockIdx.x * kWaves + wv;
-  const u32 s = (MFMA && B.rnn_order && slot < B.n_sent) ? B.rnn_order[slot] : slot;
-  // `own`: this wavefront has a sentence to score.  Without MFMA the others leave; with it they stay for the
-  // workgroup barriers and the matrix work of the lock-step rounds.
-  bool own = s < B.n_sent && B.sent_status[s < B.n_sent ? s : 0] == ST_OK;
-  if (!MFMA && !own) return;
-  const u32 sc = own ? s : 0u;
-  const u32 off = B.byte_off[sc];
-  const u32 bb0 = off + 4 * sc;
-  const u32 n = own ? B.sent_ncp[sc] : 0u;
-  own = own && n != 0;
-  if (!MFMA && !own) return;
-  const u32 N = B.sent_nodes[sc];
-  const u64 nb = B.node_base[sc];
+  const float* __restrict__ Wt = M.rnn_wt;
+  const u32 s = blockIdx.x * kWaves + wv;
+  if (s >= B.n_sent) return;
+  if (B.sent_status[s] != ST_OK) return;
+  const u32 off = B.byte_off[s];
+  const u32 bb0 = off + 4 * s;
+  const u32 n = B.sent_ncp[s];
+  if (n == 0) return;
+  const u32 N = B.sent_nodes[s];
+  const u64 nb = B.node_base[s];
   const int beam = cfg.beam;
   const int G = cfg.gbeam;
   const int S = cfg.nscorers;
   const u32 bE = n + 2;
-  const int ngb = own ? (int)B.bnd_ngb[bb0 + bE] : 0;
-  own = own && ngb != 0;
-  if (!MFMA && !own) return;
+  const int ngb = (int)B.bnd_ngb[bb0 + bE];
+  if (ngb == 0) return;
   const u32 E = M.rnn_E;
   // model scalars and table pointers, read once: going through `M` inside the loops makes the compiler
   // re-issue the scalar loads after every store (it cannot prove the header is not aliased)
@@ -816,13 +770,12 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
   __shared__ u8 l_cnt_all[kWaves][kCapB];
   // per connection (boundary, path): lattice node | slot << 16 | rnn node << 22 | gbeam index << 27, perceptron score cell
   __shared__ u32 l_conn_all[kWaves][kCap];
-  __shared__ float l_ctx_all[kWaves][kWinLds ? EP : 1];   // the context a matvec multiplies, read back as broadcasts
   __shared__ float l_cell0_all[kWaves][kCap];
   __shared__ float l_mx_all[kWaves][kCap];
   constexpr u32 kPassCap = 2 * kCapB;
   __shared__ u16 l_pass_all[kWaves][kPassCap];
   __shared__ u32 l_npass_all[kWaves];
-  constexpr u32 kNodeCap = 96;
+  constexpr u32 kNodeCap = kRnnNodeCap;
   __shared__ u16 l_node_all[kWaves][kNodeCap];   // rnn nodes (boundary * G + index) in boundary order
   __shared__ u32 l_nnode_all[kWaves];
   __shared__ float nscore_all[kWaves][kMaxGbeam];
@@ -835,11 +788,7 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
   const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
   const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
   const u32* rn_cnt = B.rnn_cnt + bb0;
-  bool inLds = own && nq <= kCap && (bE + 1) <= kCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kCapB && G <= 32 && beam <= 64 && N <= 65535;
-  if (inLds) {  // ... and the rnn nodes fit the node list (bE + 1 <= 64: one boundary per lane)
-    const u32 mine = ((u32)lane >= 2 && (u32)lane <= bE) ? rn_cnt[lane] : 0u;
-    inLds = wave_sum_u32(mine) <= kNodeCap;
-  }
+  const bool inLds = rnn_stageable(nq, bE, G, beam, N, rn_cnt, lane);
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {
       l_prev_all[wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
@@ -849,7 +798,7 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
     rn_id = l_id_all[wv];
     // connections: every load below is independent, so they are all in flight together
     const i32* g_gi = B.rnn_id + (u64)bb0 * G;
-    for (u32 q = lane; MODE != 1 && q < nq; q += 64) {
+    for (u32 q = lane; q < nq; q += 64) {
       const u32 c = conn[q];
       const u32 gi = (u32)g_gi[q];
       l_conn_all[wv][q] = c == kNoConn ? kNoConn : ((c & 0xffffu) | ((c >> 26) << 16) | ((assign[q] & 31u) << 22) | ((gi & 31u) << 27));
@@ -871,7 +820,7 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
       float x = 0.f + embT[i];
       v = sigmoid_ref(x, s_exptab);
     }
-    if (own && (MODE != 2 || !inLds)) rn_ctx[(u64)1 * G * EP + i] = v;
+    if (MODE != 2 || !inLds) rn_ctx[(u64)1 * G * EP + i] = v;   // (k_rnn_chain made the staged sentences' BOS state)
   }
   wave_sync();
   float* l_mx = l_mx_all[wv];
@@ -886,7 +835,7 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
     // node, the pass list and the node list.  Chain: context -> matvec -> sigmoid -> store, nothing else.
     // Epilogue: the NCE dot products and scores, one lane per rnn node (the contexts are all in HBM/L2 by
     // then), the score cells, and adjustBeamScores along the paths.
-    if constexpr (MODE != 1) {
+    {
       // all gathers of all rounds go out before the first sum (one HBM round trip, not one per round)
       constexpr u32 kRounds = (kCap + 63) / 64;
       float mw[kRounds][4];
@@ -935,12 +884,7 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
     nnode = l_nnode_all[wv];
   }
   JPP_RPROF(1);
-  if constexpr (MFMA) {
-    rnn_chain_lockstep<J>(M.rnn_wt, embT, E, rn_ctx, l_node, l_prev, l_id_all[wv], inLds ? nnode - l_cnt[bE] : 0u, s_exptab, wv, lane);
-    JPP_RPROF(3);
-    JPP_RPROF_FLUSH;
-    return;
-  } else if (inLds && MODE == 0) {
+  if (inLds && MODE == 0) {
     float embR[kRnnCN][J];                    // embedding rows of the current pass
     float lastOut[kRnnCN][J];                 // contexts produced by the previous pass, kept in registers
     u32 lastBase = 0xffffffffu, lastCn = 0;
@@ -998,28 +942,12 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
         for (int p = 0; p < kRnnCN; ++p)
 #pragma unroll
           for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
-        if constexpr (kWinLds) {
-          // one node at a time: its context goes to LDS once and comes back as broadcast reads, four
-          // elements per read, instead of one v_readlane (+ hazard slots) per element
-          float* l_ctx = l_ctx_all[wv];
-#pragma unroll
-          for (int p = 0; p < kRnnCN; ++p) {
-            if (p < cn) {
-#pragma unroll
-              for (int j = 0; j < J; ++j) l_ctx[lane * J + j] = ctx[p][j];
-              wave_sync();
-              rnn_matvec_lds1<J>(Wt, l_ctx, acc[p], lane);
-              wave_sync();
-            }
-          }
-        } else {
           switch (cn) {
             case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
             case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
             case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
             default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
           }
-        }
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p) {
           if (p < cn) {
@@ -1096,7 +1024,7 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
       }
     }
     wave_sync();
-  } else if (own) {
+  } else {
     for (u32 b = 2; b <= bE; ++b) {
       const int cnt = (int)rn_cnt[b];
       if (cnt == 0) continue;
@@ -1183,10 +1111,10 @@ __global__ void __launch_bounds__(64 * ((WLDS && MODE != 2) ? 16 : 4)) k_rnn_sco
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
           switch (cn) {
-            case 1: rnn_matvec_any<J, 1, kWinLds>(Wt, ctx, acc, lane); break;
-            case 2: rnn_matvec_any<J, 2, kWinLds>(Wt, ctx, acc, lane); break;
-            case 3: rnn_matvec_any<J, 3, kWinLds>(Wt, ctx, acc, lane); break;
-            default: rnn_matvec_any<J, 4, kWinLds>(Wt, ctx, acc, lane); break;
+            case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
+            case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
+            case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
+            default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
           }
 #pragma unroll
           for (int p = 0; p < kRnnCN; ++p) {
