@@ -117,6 +117,13 @@ __device__ __forceinline__ void vm_wait_all() {
 #endif
 }
 
+// occupancy target of a kernel (wavefronts per SIMD): caps its VGPRs accordingly
+#if defined(JPP_EMU)
+#define JPP_WAVES_PER_EU(n)
+#else
+#define JPP_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+
 // workgroup barrier that orders LDS traffic only: outstanding global loads / stores of the wavefront stay in flight
 // (__syncthreads() drains them: its workgroup-scope release waits for vmcnt(0)).  For phases that hand data to other
 // wavefronts through LDS alone.

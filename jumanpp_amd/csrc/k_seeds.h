@@ -503,8 +503,10 @@ __device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk,
 
 // MODE 0: count (writes pos_cntA / pos_cnt2); MODE 1: emit stage 1; MODE 2: emit stage 1+2
 // for sentences with the stage-2 flag (into their relocated region).
+// (the trie walk is a chain of dependent loads: 8 wavefronts per SIMD at 64 VGPRs and a few spilled registers beat
+// 4 at 97 -- count pass 642 -> 491 us, emit pass 722 -> 668 us; the rarely taken stage-2 pass gains nothing)
 template <int MODE>
-__global__ void k_seeds(Batch B, const DevModel* __restrict__ Mp) {
+__global__ void __launch_bounds__(64) JPP_WAVES_PER_EU(MODE == 2 ? 4 : 8) k_seeds(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;

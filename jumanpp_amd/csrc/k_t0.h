@@ -39,8 +39,9 @@ __host__ __device__ constexpr u64 tri_prefix(int index) {
   return hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)index), kTrigramSeed);
 }
 
+// (more wavefronts per SIMD do not help here: 5 at 94 VGPRs 2.01 ms, 6 at 80 2.05 ms, 8 at 64 with spills 2.68 ms)
 template <bool W24>   // W24: at most 2^24 weights (hmix_index)
-__global__ void k_t0(Batch B, const DevModel* __restrict__ Mp) {
+__global__ void __launch_bounds__(64) k_t0(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
