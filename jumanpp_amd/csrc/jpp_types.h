@@ -14,6 +14,7 @@ constexpr int kMaxBeam = 32;
 constexpr int kMaxRight = 512;    // right nodes per boundary staged in LDS by the sweep kernel
 constexpr int kMaxNormStates = 64;
 constexpr int kMaxNormResults = 160;
+constexpr int kNormCache = 8;        // normalized-node results per start kept from the count pass for the emit passes
 constexpr int kMaxRnnE = 256;      // RNN hidden size staged per lane (E/64 <= 4)
 
 // entry pointers (reference src/core/core_types.h:44-58)
@@ -192,6 +193,7 @@ struct Batch {
   // seeds
   u16* pos_cnt1;           // dictionary + stage-1 maker nodes (w/o normalize) starting at position g
   u16* pos_cntN;           // normalize-maker nodes starting at position g
+  u64* pos_norm;           // [cp][kNormCache] NormResult of the count pass (starts with at most kNormCache results)
   u16* pos_cnt2;           // stage-2 maker nodes starting at position g
   WalkCache* pos_walk;     // the count pass's dictionary walk from position g, replayed by the emit passes
   u64* pos_ends;           // bit e set: a stage-1 node starting at position g ends at codepoint e (e <= 63), from the count pass
@@ -215,6 +217,8 @@ struct Batch {
   float* node_cells;       // [gn][gbeam][nscorers]
   u32* rnn_conn;           // [bb][gbeam] connection of EOS path p at boundary b: node | slot<<28, or ~0
   i32* rnn_id;             // [bb][gbeam] RNN vocabulary id of that node
+  u32* rnn_gi;             // [bb][gbeam] global-beam index of the connection (= which score cell of its node it owns)
+  u32* rnn_clen;           // [bb][gbeam] codepoints of the connection's lattice node
   u32* rnn_assign;         // [bb][gbeam] rnn node (index within boundary) a connection is scored with
   u32* rnn_prev;           // [bb][gbeam] rnn node -> prev rnn node handle (b * G + idx)
   u64* rnn_hash;           // [bb][gbeam] prefix hash of the rnn node
@@ -225,6 +229,7 @@ struct Batch {
   u32* rnn_key;            // [n_sent] that length, capped
   u32* rnn_offs;           // [kRnnOrderBins] next free slot of every length class
   u32* rnn_hist;           // [kRnnOrderBins] sentences per length class (all zero between batches)
+  u32* rnn_slow;           // [2] first slot and number of the sentences of the last class (not staged in LDS)
   float* rnn_ctx;          // [bb][gbeam][EP] hidden state after each rnn node
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]

@@ -46,7 +46,11 @@ inline void bind_device(int device) { (void)hipSetDevice(device); }
 // ---- thin device-memory layer ------------------------------------------------
 #if defined(JPP_EMU)
 bool rt_ok(int) { return true; }
-void* rt_malloc(size_t n) { return calloc(1, n ? n : 1); }
+void* rt_malloc(size_t n) {   // (hipMalloc does not zero either: reads of never-written memory should show up here too)
+  void* p = malloc(n ? n : 1);
+  if (p) memset(p, 0xA5, n ? n : 1);
+  return p;
+}
 void rt_free(void* p) { free(p); }
 void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t) { memcpy(d, h, n); }
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
@@ -276,11 +280,11 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_clen, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
   void* rnn_ord_zeroed = nullptr;   // the rnn_ord allocation whose histogram has been zeroed
   // workspace
   DevBuf text, offs;
-  DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_cnt2, pos_ends, pos_walk, reach;
+  DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
   DevBuf path_len, bnd_meta, sweep_scratch;
   DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
@@ -532,13 +536,13 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   bind_device(ctx->device);
   DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
                     &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
-                    &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
+                    &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_norm,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
                     &ctx->sent_status, &ctx->sent_flags, &ctx->sent_nodes, &ctx->sent_nodes2, &ctx->node_base,
                     &ctx->node_base2, &ctx->path_len,  &ctx->bnd_first,  &ctx->bnd_cnt,   &ctx->end_first,
                     &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
                     &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
-                    &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,
+                    &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,  &ctx->rnn_clen,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
@@ -562,7 +566,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
   bool ok = ctx->cp_code.ensure(cpN * 4) && ctx->cp_class.ensure(cpN * 4) && ctx->cp_boff.ensure(cpN * 2) &&
             ctx->cl_nodes.ensure(cpN * sizeof(ClNodes)) && ctx->pos_cnt1.ensure(cpN * 2) &&
-            ctx->pos_cntN.ensure(cpN * 2) && ctx->pos_cnt2.ensure(cpN * 2) && ctx->pos_ends.ensure(cpN * 8) && ctx->pos_walk.ensure(cpN * sizeof(WalkCache)) && ctx->reach.ensure(cpN) &&
+            ctx->pos_cntN.ensure(cpN * 2) && ctx->pos_norm.ensure(cpN * 8 * kNormCache) && ctx->pos_cnt2.ensure(cpN * 2) && ctx->pos_ends.ensure(cpN * 8) && ctx->pos_walk.ensure(cpN * sizeof(WalkCache)) && ctx->reach.ensure(cpN) &&
             ctx->sent_ncp.ensure((n + 1) * 4) && ctx->sent_status.ensure((n + 1) * 4) &&
             ctx->sent_flags.ensure((n + 1) * 4) && ctx->sent_nodes.ensure((n + 1) * 4) &&
             ctx->sent_nodes2.ensure((n + 1) * 4) && ctx->node_base.ensure((n + 2) * 8) &&
@@ -570,10 +574,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
             ctx->bnd_first.ensure(bbN * 4) && ctx->bnd_cnt.ensure(bbN * 4) && ctx->end_first.ensure(bbN * 4) &&
             ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) && ctx->bnd_meta.ensure(bbN * sizeof(BndMeta)) &&
             ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry)) &&
-            (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) &&
+            (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) && ctx->rnn_gi.ensure(bbN * G * 4) && ctx->rnn_clen.ensure(bbN * G * 4) &&
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
-              ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins) * 4) &&
+              ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
               ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_EP * 4)));
   ok = ok && ctx->gstats.ensure(64);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
@@ -597,6 +601,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.cl_nodes = ctx->cl_nodes.as<ClNodes>();
   B.pos_cnt1 = ctx->pos_cnt1.as<u16>();
   B.pos_cntN = ctx->pos_cntN.as<u16>();
+  B.pos_norm = ctx->pos_norm.as<u64>();
   B.pos_cnt2 = ctx->pos_cnt2.as<u16>();
   B.pos_ends = ctx->pos_ends.as<u64>();
   B.pos_walk = ctx->pos_walk.as<WalkCache>();
@@ -619,6 +624,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.gstats = ctx->gstats.as<u32>();
   B.rnn_conn = ctx->rnn_conn.as<u32>();
   B.rnn_id = ctx->rnn_id.as<i32>();
+  B.rnn_gi = ctx->rnn_gi.as<u32>();
+  B.rnn_clen = ctx->rnn_clen.as<u32>();
   B.rnn_assign = ctx->rnn_assign.as<u32>();
   B.rnn_prev = ctx->rnn_prev.as<u32>();
   B.rnn_hash = ctx->rnn_hash.as<u64>();
@@ -628,7 +635,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_order = nullptr;
   B.rnn_hist = ctx->rnn_ord.as<u32>();
   B.rnn_offs = B.rnn_hist ? B.rnn_hist + kRnnOrderBins : nullptr;
-  B.rnn_key = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins : nullptr;
+  B.rnn_slow = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins : nullptr;
+  B.rnn_key = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins + 2 : nullptr;
   B.rnn_ctx = ctx->rnn_ctx.as<float>();
   if (n == 0) {
     B.total_nodes = 0;
@@ -805,14 +813,19 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
+    const u32 slowGrid = (n + 3) / 4 < 512u ? (n + 3) / 4 : 512u;   // k_rnn_score<.., 3> loops over its list
     if (ctx->hmodel.rnn_EP == 64) {
       JPP_LAUNCH((k_rnn_chain<1>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
       if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<1, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<1, false, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
     } else if (ctx->hmodel.rnn_EP == 128) {
       JPP_LAUNCH((k_rnn_chain<2>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
       if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<2, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<2, false, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
     } else {
       if (sortE) JPP_LAUNCH((k_rnn_score<4, true, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<4, false, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);

@@ -115,7 +115,8 @@ __device__ __forceinline__ u64 fh1_mix(u64 state, u64 data) {
 // The lattice connection of every surviving EOS path at every boundary (RnnIdContainer::addPath walks them the same
 // way, rnn_id_resolver.cc): one thread per (sentence, path) follows the beam pointers back from EOS -- a chain of
 // dependent HBM reads, so it runs as its own launch with every path of the batch in flight at once instead of on
-// six lanes of the wavefront that builds the rnn lattice.  conn[b][p] = node | beam slot << 26, or kNoConn.
+// six lanes of the wavefront that builds the rnn lattice.  conn[b][p] = node | beam slot << 26, or kNoConn; the
+// connection's global-beam index (BeamSlot::pad) and the node's length come from the same records.
 __global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
   const u32 G = (u32)cfg.gbeam;
   const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,18 +132,25 @@ __global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
   const u64 nb = B.node_base[s];
   const u32 beam = (u32)cfg.beam;
   u32* conn = B.rnn_conn + (u64)bb0 * G;
-  for (u32 b = 0; b <= bE; ++b) conn[(u64)b * G + p] = kNoConn;
+  u32* gi = B.rnn_gi + (u64)bb0 * G;
+  u32* clen = B.rnn_clen + (u64)bb0 * G;
+  for (u32 b = 0; b <= bE; ++b) conn[(u64)b * G + p] = kNoConn;   // (gi / clen are read only where a connection exists)
   if (p >= ngb) return;
   const BeamSlot* beams = B.node_beam + nb * beam;
   const GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + p];
   conn[(u64)bE * G + p] = (N - 1) | (p << 26);  // fake EOS connection, "slot" = path index
+  gi[(u64)bE * G + p] = p;
+  clen[(u64)bE * G + p] = 0;
   u32 nd = B.end_nodes[nb + B.end_first[bb0 + bE] + ge.left];
   u32 k = ge.beam;
   u32 guard = 0;
   while (nd >= 2 && guard++ <= n) {
-    const u32 b = (u32)B.node_info[nb + nd].start + 2;
+    const NodeInfo ni = B.node_info[nb + nd];
+    const u32 b = (u32)ni.start + 2;
     const BeamSlot sl = beams[(u64)nd * beam + k];
     conn[(u64)b * G + p] = nd | (k << 26);
+    gi[(u64)b * G + p] = sl.pad;
+    clen[(u64)b * G + p] = (u32)(ni.end - ni.start);
     nd = sl.prev_node;
     k = sl.beam;
   }
@@ -188,6 +196,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   i32* g_id = B.rnn_nid + (u64)bb0 * G;
   u32* g_len = B.rnn_nlen + (u64)bb0 * G;
   u32* g_cnt = B.rnn_cnt + bb0;
+  const u32* g_clen = B.rnn_clen + (u64)bb0 * G;
   u32* conn = inLds ? l_conn_all[wv] : g_conn;                  // lattice connection of path p at boundary b
   i32* wid = inLds ? l_wid_all[wv] : B.rnn_id + (u64)bb0 * G;   // word id of that connection's lattice node
   u32* assign = inLds ? l_assign_all[wv] : g_assign;            // rnn node (index within boundary) scoring it
@@ -206,28 +215,44 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   // ---- B. word ids of the connections ----
   // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the
   // first path that passes through it, and copied to the others.
-  for (u32 q = lane; q < nq; q += 64) {
-    u32 c = conn[q];
-    if (c == kNoConn) continue;
-    const u32 nd = c & 0x03ffffffu;
-    const u32 b = q / (u32)G, p = q - b * (u32)G;
-    bool first = true;
-    for (u32 pp = 0; pp < p; ++pp) {
-      const u32 c2 = conn[(u64)b * G + pp];
-      if (c2 != kNoConn && (c2 & 0x03ffffffu) == nd) {
-        first = false;
-        break;
+  // The first occurrences are gathered into a dense list first (in `assign`, not needed before B2): resolving an
+  // id is a chain of a dozen dependent loads through the double array, paid once per 64 list entries instead of
+  // once per 64 (boundary, path) slots, most of which are empty or repeats.
+  u32 nfirst = 0;
+  for (u32 q0 = 0; q0 < nq; q0 += 64) {
+    const u32 q = q0 + (u32)lane;
+    bool first = false;
+    if (q < nq) {
+      const u32 c = conn[q];
+      if (c != kNoConn) {
+        const u32 nd = c & 0x03ffffffu;
+        const u32 b = q / (u32)G, p = q - b * (u32)G;
+        first = true;
+        for (u32 pp = 0; pp < p; ++pp) {
+          const u32 c2 = conn[(u64)b * G + pp];
+          if (c2 != kNoConn && (c2 & 0x03ffffffu) == nd) {
+            first = false;
+            break;
+          }
+        }
       }
     }
-    if (first) wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
+    const u64 m = wave_ballot(first);
+    if (first) assign[nfirst + (u32)popc64(m & ((u64{1} << lane) - 1))] = q;
+    nfirst += (u32)popc64(m);
+  }
+  wave_sync();
+  for (u32 i = lane; i < nfirst; i += 64) {
+    const u32 q = assign[i];
+    const u32 nd = conn[q] & 0x03ffffffu;
+    wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
   }
   wave_sync();
   for (u32 q = lane; q < nq; q += 64) {
     u32 c = conn[q];
     if (c == kNoConn) continue;
     const u32 nd = c & 0x03ffffffu;
-    // the node length the replay below hashes: fetched here, lane per connection, not on its serial chain
-    if (clen) clen[q] = (nd == N - 1) ? (u16)0 : (u16)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
+    if (clen) clen[q] = (u16)g_clen[q];   // the node length the replay below hashes (k_rnn_paths)
     const u32 b = q / (u32)G, p = q - b * (u32)G;
     for (u32 pp = 0; pp < p; ++pp) {
       const u32 c2 = conn[(u64)b * G + pp];
@@ -272,8 +297,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
           } else {
             u32 nd = c & 0x03ffffffu;
             i32 id = wid[(u64)b * G + p];
-            u32 len = clen ? (u32)clen[(u64)b * G + p]
-                           : (nd == N - 1) ? 0u : (u32)(B.node_info[nb + nd].end - B.node_info[nb + nd].start);
+            u32 len = clen ? (u32)clen[(u64)b * G + p] : g_clen[(u64)b * G + p];
             u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
             u32 cnt = rn_cnt[b];
             // crdCache_.find(coord): newest published node with the same (boundary, length, id)
@@ -313,19 +337,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       wave_sync();
     }
   }
-  // gbeam index of every connection (= which score cell of the node it owns); published in the word-id
-  // scratch, which is no longer needed
   wave_sync();
-  i32* g_gi = B.rnn_id + (u64)bb0 * G;
-  for (u32 q = lane; q < nq; q += 64) {
-    const u32 c = conn[q];
-    i32 gi = 0;
-    if (c != kNoConn) {
-      const u32 nd = c & 0x03ffffffu, k = c >> 26;
-      gi = (nd == N - 1) ? (i32)k : (i32)beams[(u64)nd * beam + k].pad;
-    }
-    g_gi[q] = gi;
-  }
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {
       g_conn[q] = conn[q];
@@ -417,7 +429,18 @@ __device__ __forceinline__ float rnn_dot_seq(const float JPP_GLOBAL* __restrict_
 // order of chain length (a counting sort over kRnnOrderBins classes; which sentence shares a workgroup with which
 // has no influence on any result).  Sentences k_rnn_score does not stage in LDS form the last class.
 constexpr u32 kRnnOrderBins = 128;
-constexpr u32 kRnnStageCap = 264, kRnnStageCapB = 48;   // k_rnn_score's staging limits (connections, boundaries)
+constexpr u32 kRnnStageCap = 288, kRnnStageCapB = 48;   // k_rnn_chain's / k_rnn_score's staging limits (connections, boundaries)
+constexpr u32 kRnnNodeCap = kRnnStageCap;               // rnn nodes of a staged sentence: at most one per connection
+// (a cap of 96 nodes used to send one or two 40-codepoint sentences per 65536 down the serial path -- 0.4 ms for the
+// batch, because that launch then lasts as long as its slowest sentence)
+
+// whether a sentence's rnn lattice is staged in LDS by k_rnn_chain / k_rnn_score<.., 2>.  k_rnn_order_key files the
+// others in the last class, which k_rnn_score<.., 3> serves.
+__device__ __forceinline__ bool rnn_stageable(u32 bE, int G, int beam, u32 N) {
+  const u32 nq = (bE + 1) * (u32)G;
+  return nq <= kRnnStageCap && (bE + 1) <= kRnnStageCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kRnnStageCapB &&
+         G <= 32 && beam <= 64 && N <= 65535;
+}
 
 __global__ void __launch_bounds__(256) k_rnn_order_key(Batch B, Config cfg) {
   __shared__ u32 h[kRnnOrderBins];
@@ -431,9 +454,8 @@ __global__ void __launch_bounds__(256) k_rnn_order_key(Batch B, Config cfg) {
       const u32 bb0 = B.byte_off[s] + 4 * s;
       const u32 bE = n + 2;
       if (B.bnd_ngb[bb0 + bE]) {
-        if (bE + 1 > kRnnStageCapB || (bE + 1) * (u32)cfg.gbeam > kRnnStageCap) {
-          key = kRnnOrderBins - 1;
-        } else {
+        key = kRnnOrderBins - 1;
+        if (rnn_stageable(bE, cfg.gbeam, cfg.beam, B.sent_nodes[s])) {
           u32 c = 0;
           for (u32 b = 2; b < bE; ++b) c += B.rnn_cnt[bb0 + b];
           key = c < kRnnOrderBins - 2 ? c : kRnnOrderBins - 2;
@@ -463,6 +485,10 @@ __global__ void __launch_bounds__(kRnnOrderBins) k_rnn_order_scan(Batch B) {
   }
   __syncthreads();
   B.rnn_offs[threadIdx.x] = h[threadIdx.x];
+  if (threadIdx.x == kRnnOrderBins - 1) {
+    B.rnn_slow[0] = h[threadIdx.x];
+    B.rnn_slow[1] = B.n_sent - h[threadIdx.x];   // the last class ends the order
+  }
 }
 
 __global__ void k_rnn_order_zero(u32* hist) { hist[threadIdx.x] = 0; }
@@ -482,19 +508,6 @@ __global__ void __launch_bounds__(256) k_rnn_order_fill(Batch B) {
   if (threadIdx.x < kRnnOrderBins && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&B.rnn_offs[threadIdx.x], h[threadIdx.x]);
   __syncthreads();
   if (s < B.n_sent) B.rnn_order[base[key] + local] = s;
-}
-
-constexpr u32 kRnnNodeCap = 96;   // rnn nodes of a staged sentence
-
-// whether a sentence's rnn lattice is staged in LDS (k_rnn_chain and k_rnn_score<.., 2> must agree); all lanes call it
-__device__ __forceinline__ bool rnn_stageable(u32 nq, u32 bE, int G, int beam, u32 N, const u32* rn_cnt, int lane) {
-  bool ok = nq <= kRnnStageCap && (bE + 1) <= kRnnStageCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kRnnStageCapB &&
-            G <= 32 && beam <= 64 && N <= 65535;
-  if (ok) {  // ... and the rnn nodes fit the node list (bE + 1 <= 64: one boundary per lane)
-    const u32 mine = ((u32)lane >= 2 && (u32)lane <= bE) ? rn_cnt[lane] : 0u;
-    ok = wave_sum_u32(mine) <= kRnnNodeCap;
-  }
-  return ok;
 }
 
 // ---- the recurrence (GbeamRnnState::computeContext for every rnn node before EOS), E <= 128 ----
@@ -562,7 +575,7 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
     nchain[g] = 0;
     const u32 nq = (bE + 1) * (u32)G;
     const u32* rn_cnt = B.rnn_cnt + bb0;
-    if (own && rnn_stageable(nq, bE, G, cfg.beam, B.sent_nodes[s], rn_cnt, lane)) {
+    if (own && rnn_stageable(bE, G, cfg.beam, B.sent_nodes[s])) {
       const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
       const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
       for (u32 q = lane; q < nq; q += 64) {
@@ -715,12 +728,14 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
 // MODE 0 (E > 128): one launch does everything, W streamed from L2.
 // MODE 2 (E <= 128, after k_rnn_chain): everything but the recurrence (maxent sums, NCE dot products, score cells,
 // adjustBeamScores, remakeEosBeam) for the sentences k_rnn_chain handled, reading the contexts it left in HBM/L2.
-// Sentences beyond the LDS staging limits get the complete boundary-by-boundary path here (W streamed from L2).
+// MODE 3 (E <= 128): the complete boundary-by-boundary path (W streamed from L2) for the sentences beyond the LDS
+// staging limits, which the other two kernels skip; a launch of its own so that its registers do not set MODE 2's
+// occupancy.
 // Four wavefronts (sentences) per workgroup and no workgroup barrier after the start: several workgroups per CU
 // hide each other's load latency.
 template <int J, bool SORT, int MODE>
 __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
-  static_assert(MODE == 0 || (MODE == 2 && J <= 2), "k_rnn_chain covers E <= 128");
+  static_assert(MODE == 0 || ((MODE == 2 || MODE == 3) && J <= 2), "k_rnn_chain covers E <= 128");
   constexpr int kWaves = 4;
   constexpr int EP = 64 * J;
   const DevModel& M = *Mp;
@@ -730,7 +745,13 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
   if (threadIdx.x < (u32)kExp2fN) s_exptab[threadIdx.x] = exp2f_tab((int)threadIdx.x);
   __syncthreads();
   const float* __restrict__ Wt = M.rnn_wt;
-  const u32 s = blockIdx.x * kWaves + wv;
+  // MODE 3: a fixed, small grid walks the sentences of the last class (the tail of the chain-length order; usually
+  // there are none, and a full-size launch of empty workgroups costs more than the other RNN kernels' early exits)
+  u32 slot = blockIdx.x * kWaves + wv;
+  const u32 nslow = MODE == 3 ? B.rnn_slow[1] : 0u;
+  if (MODE == 3 && slot >= nslow) return;
+  do {
+  const u32 s = MODE == 3 ? B.rnn_order[B.rnn_slow[0] + slot] : slot;
   if (s >= B.n_sent) return;
   if (B.sent_status[s] != ST_OK) return;
   const u32 off = B.byte_off[s];
@@ -788,7 +809,9 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
   const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
   const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
   const u32* rn_cnt = B.rnn_cnt + bb0;
-  const bool inLds = rnn_stageable(nq, bE, G, beam, N, rn_cnt, lane);
+  const bool staged = MODE != 3 && rnn_stageable(bE, G, beam, N);
+  if (MODE == 2 && !staged) return;   // (k_rnn_score<.., 3> takes it)
+  const bool inLds = MODE == 2 || (MODE == 0 && staged);   // a compile-time constant in MODE 2 and 3
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {
       l_prev_all[wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
@@ -797,7 +820,7 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
     for (u32 q = lane; q <= bE; q += 64) l_cnt_all[wv][q] = (u8)rn_cnt[q];
     rn_id = l_id_all[wv];
     // connections: every load below is independent, so they are all in flight together
-    const i32* g_gi = B.rnn_id + (u64)bb0 * G;
+    const u32* g_gi = B.rnn_gi + (u64)bb0 * G;
     for (u32 q = lane; q < nq; q += 64) {
       const u32 c = conn[q];
       const u32 gi = (u32)g_gi[q];
@@ -820,7 +843,7 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
       float x = 0.f + embT[i];
       v = sigmoid_ref(x, s_exptab);
     }
-    if (MODE != 2 || !inLds) rn_ctx[(u64)1 * G * EP + i] = v;   // (k_rnn_chain made the staged sentences' BOS state)
+    if (MODE != 2) rn_ctx[(u64)1 * G * EP + i] = v;   // (k_rnn_chain made the staged sentences' BOS state)
   }
   wave_sync();
   float* l_mx = l_mx_all[wv];
@@ -1217,6 +1240,9 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
   }
   JPP_RPROF(5);
   JPP_RPROF_FLUSH;
+  wave_sync();
+  slot += gridDim.x * kWaves;
+  } while (MODE == 3 && slot < nslow);
 }
 
 }  // namespace jpp

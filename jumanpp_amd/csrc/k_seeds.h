@@ -574,18 +574,34 @@ __global__ void k_norm(Batch B, const DevModel* __restrict__ Mp) {
   SentView S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, n};
   const UnkMaker& mk = M.makers[M.norm_maker];
   u64 nbase = MODE == 0 ? 0 : B.node_base[s];
+  static_assert(sizeof(NormResult) == 8, "cached as one 64-bit word");
+  NormResult* cache = reinterpret_cast<NormResult*>(B.pos_norm) + (u64)g0 * kNormCache;
   for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
     NormResult res[kMaxNormResults];
-    int nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
-    if (nr < 0) {
-      atomicMax(&B.sent_status[s], (i32)ST_CAPACITY);
-      nr = 0;
+    int nr;
+    if (MODE == 0) {
+      nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
+      if (nr < 0) {
+        atomicMax(&B.sent_status[s], (i32)ST_CAPACITY);
+        nr = 0;
+      }
+    } else {
+      // the count pass left the number of results and, for short lists, the results themselves
+      nr = (int)B.pos_cntN[g0 + i];
+      if (nr == 0) continue;
+      if (nr <= kNormCache) {
+        for (int k = 0; k < nr; ++k) res[k] = cache[(u64)i * kNormCache + k];
+      } else {
+        nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
+      }
     }
     if (MODE == 0) {
       B.pos_cntN[g0 + i] = (u16)nr;
       u64 ends = 0;
       for (int k = 0; k < nr; ++k) ends |= res[k].end < 64 ? (u64{1} << res[k].end) : u64{0};
       if (ends) B.pos_ends[g0 + i] |= ends;   // k_seeds<0> of this launch sequence wrote the word already
+      if (nr <= kNormCache)
+        for (int k = 0; k < nr; ++k) cache[(u64)i * kNormCache + k] = res[k];
     } else {
       SeedSink out;
       out.emit = true;
