@@ -217,8 +217,7 @@ struct Batch {
   float* node_cells;       // [gn][gbeam][nscorers]
   u32* rnn_conn;           // [bb][gbeam] connection of EOS path p at boundary b: node | slot<<28, or ~0
   i32* rnn_id;             // [bb][gbeam] RNN vocabulary id of that node
-  u32* rnn_gi;             // [bb][gbeam] global-beam index of the connection (= which score cell of its node it owns)
-  u32* rnn_clen;           // [bb][gbeam] codepoints of the connection's lattice node
+  u32* rnn_gi;             // [bb][gbeam] global-beam index of the connection (= which score cell of its node it owns) | codepoints of its lattice node << 16
   u32* rnn_assign;         // [bb][gbeam] rnn node (index within boundary) a connection is scored with
   u32* rnn_prev;           // [bb][gbeam] rnn node -> prev rnn node handle (b * G + idx)
   u64* rnn_hash;           // [bb][gbeam] prefix hash of the rnn node

@@ -280,7 +280,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_clen, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
   void* rnn_ord_zeroed = nullptr;   // the rnn_ord allocation whose histogram has been zeroed
   // workspace
   DevBuf text, offs;
@@ -542,7 +542,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
                     &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
-                    &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,  &ctx->rnn_clen,
+                    &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
@@ -574,7 +574,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
             ctx->bnd_first.ensure(bbN * 4) && ctx->bnd_cnt.ensure(bbN * 4) && ctx->end_first.ensure(bbN * 4) &&
             ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) && ctx->bnd_meta.ensure(bbN * sizeof(BndMeta)) &&
             ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry)) &&
-            (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) && ctx->rnn_gi.ensure(bbN * G * 4) && ctx->rnn_clen.ensure(bbN * G * 4) &&
+            (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) && ctx->rnn_gi.ensure(bbN * G * 4) &&
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
@@ -625,7 +625,6 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_conn = ctx->rnn_conn.as<u32>();
   B.rnn_id = ctx->rnn_id.as<i32>();
   B.rnn_gi = ctx->rnn_gi.as<u32>();
-  B.rnn_clen = ctx->rnn_clen.as<u32>();
   B.rnn_assign = ctx->rnn_assign.as<u32>();
   B.rnn_prev = ctx->rnn_prev.as<u32>();
   B.rnn_hash = ctx->rnn_hash.as<u64>();

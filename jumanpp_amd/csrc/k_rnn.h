@@ -132,15 +132,13 @@ __global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
   const u64 nb = B.node_base[s];
   const u32 beam = (u32)cfg.beam;
   u32* conn = B.rnn_conn + (u64)bb0 * G;
-  u32* gi = B.rnn_gi + (u64)bb0 * G;
-  u32* clen = B.rnn_clen + (u64)bb0 * G;
+  u32* gi = B.rnn_gi + (u64)bb0 * G;   // global-beam index | node length << 16
   for (u32 b = 0; b <= bE; ++b) conn[(u64)b * G + p] = kNoConn;   // (gi / clen are read only where a connection exists)
   if (p >= ngb) return;
   const BeamSlot* beams = B.node_beam + nb * beam;
   const GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + p];
   conn[(u64)bE * G + p] = (N - 1) | (p << 26);  // fake EOS connection, "slot" = path index
-  gi[(u64)bE * G + p] = p;
-  clen[(u64)bE * G + p] = 0;
+  gi[(u64)bE * G + p] = p;   // (length 0)
   u32 nd = B.end_nodes[nb + B.end_first[bb0 + bE] + ge.left];
   u32 k = ge.beam;
   u32 guard = 0;
@@ -149,8 +147,7 @@ __global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
     const u32 b = (u32)ni.start + 2;
     const BeamSlot sl = beams[(u64)nd * beam + k];
     conn[(u64)b * G + p] = nd | (k << 26);
-    gi[(u64)b * G + p] = sl.pad;
-    clen[(u64)b * G + p] = (u32)(ni.end - ni.start);
+    gi[(u64)b * G + p] = (sl.pad & 0xffffu) | ((u32)(ni.end - ni.start) << 16);
     nd = sl.prev_node;
     k = sl.beam;
   }
@@ -196,7 +193,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   i32* g_id = B.rnn_nid + (u64)bb0 * G;
   u32* g_len = B.rnn_nlen + (u64)bb0 * G;
   u32* g_cnt = B.rnn_cnt + bb0;
-  const u32* g_clen = B.rnn_clen + (u64)bb0 * G;
+  const u32* g_clen = B.rnn_gi + (u64)bb0 * G;   // (k_rnn_paths: global-beam index | node length << 16)
   u32* conn = inLds ? l_conn_all[wv] : g_conn;                  // lattice connection of path p at boundary b
   i32* wid = inLds ? l_wid_all[wv] : B.rnn_id + (u64)bb0 * G;   // word id of that connection's lattice node
   u32* assign = inLds ? l_assign_all[wv] : g_assign;            // rnn node (index within boundary) scoring it
@@ -252,7 +249,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
     u32 c = conn[q];
     if (c == kNoConn) continue;
     const u32 nd = c & 0x03ffffffu;
-    if (clen) clen[q] = (u16)g_clen[q];   // the node length the replay below hashes (k_rnn_paths)
+    if (clen) clen[q] = (u16)(g_clen[q] >> 16);   // the node length the replay below hashes
     const u32 b = q / (u32)G, p = q - b * (u32)G;
     for (u32 pp = 0; pp < p; ++pp) {
       const u32 c2 = conn[(u64)b * G + pp];
@@ -297,7 +294,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
           } else {
             u32 nd = c & 0x03ffffffu;
             i32 id = wid[(u64)b * G + p];
-            u32 len = clen ? (u32)clen[(u64)b * G + p] : g_clen[(u64)b * G + p];
+            u32 len = clen ? (u32)clen[(u64)b * G + p] : (g_clen[(u64)b * G + p] >> 16);
             u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
             u32 cnt = rn_cnt[b];
             // crdCache_.find(coord): newest published node with the same (boundary, length, id)
@@ -823,7 +820,7 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
     const u32* g_gi = B.rnn_gi + (u64)bb0 * G;
     for (u32 q = lane; q < nq; q += 64) {
       const u32 c = conn[q];
-      const u32 gi = (u32)g_gi[q];
+      const u32 gi = g_gi[q] & 0xffffu;
       l_conn_all[wv][q] = c == kNoConn ? kNoConn : ((c & 0xffffu) | ((c >> 26) << 16) | ((assign[q] & 31u) << 22) | ((gi & 31u) << 27));
       l_cell0_all[wv][q] = c != kNoConn ? B.node_cells[((nb + (c & 0x03ffffffu)) * G + gi) * S] : 0.f;
     }
