@@ -122,14 +122,14 @@ def test_cli_multi_device_keeps_the_output_and_its_order(cli_emu, ref_tools, tmp
         pytest.skip('oracle/_ref not built')
     import test_gpu_parity as tg
     tmp = str(tmp_path)
-    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 230, 12, 31, length=14, rnn=(32, 600))
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 90, 12, 31, length=14, rnn=(32, 600))
     path = os.path.join(tmp, 'w.txt')
     rc, single, err = _run(cli_emu, ['--model=' + img, '--batch=16', path])
     assert rc == 0, err[-300:]
-    for devs, batch in (('0,1', '16'), ('0-2', '7'), ('0,1', '500'), ('1', '16')):
+    for devs, batch in (('0,1', '16'), ('0-2', '7'), ('1', '500')):
         rc, out, err = _run(cli_emu, ['--model=' + img, '--devices=' + devs, '--batch=' + batch, '--timing', path])
         assert rc == 0 and out == single, (devs, batch, err[-300:])
-        assert ('devices=%d sentences=230' % {'0,1': 2, '0-2': 3, '1': 1}[devs]).encode() in err
+        assert ('devices=%d sentences=90' % {'0,1': 2, '0-2': 3, '1': 1}[devs]).encode() in err
     # perceptron only: byte-identical to the reference CLI as well
     rc, out, err = _run(cli_emu, ['--model=' + img, '--no-rnn', '--devices=0-3', '--batch=9', path])
     ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + os.path.join(tmp, 'p.model'), path],
