@@ -812,19 +812,19 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
-    const u32 slowGrid = (n + 3) / 4 < 512u ? (n + 3) / 4 : 512u;   // k_rnn_score<.., 3> loops over its list
+    const u32 slowGrid = (n + 15) / 16 < 512u ? (n + 15) / 16 : 512u;   // k_rnn_score<.., 3> (16 sentences per workgroup) loops over its list
     if (ctx->hmodel.rnn_EP == 64) {
       JPP_LAUNCH((k_rnn_chain<1>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
       if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<1, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<1, false, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<1, false, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
     } else if (ctx->hmodel.rnn_EP == 128) {
       JPP_LAUNCH((k_rnn_chain<2>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
       if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<2, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<2, false, 3>), slowGrid, 256, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score<2, false, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
     } else {
       if (sortE) JPP_LAUNCH((k_rnn_score<4, true, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<4, false, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);

@@ -370,6 +370,65 @@ __device__ __forceinline__ void rnn_matvec(const float* __restrict__ Wt, const f
   }
 }
 
+#if !defined(JPP_EMU)
+typedef float rnn_f2 __attribute__((ext_vector_type(2)));
+#endif
+
+// index of W^T[k][i] in the LDS copy (EP = 64 J, J <= 2): rows are interleaved in pairs so that one read
+// gives a lane the 2 J weights of rows k, k+1 for its J outputs -- [k/2][lane][k&1][j]
+template <int J>
+__device__ __forceinline__ u32 rnn_w2_index(u32 k, u32 i) {
+  return ((((k >> 1) * 64u + i / J) * 2u) + (k & 1u)) * J + (i % J);
+}
+
+// same sum, same order as rnn_matvec (k ascending), on the pair-interleaved LDS copy: half the LDS
+// reads, and for J = 2 both outputs of a lane advance in one packed FMA
+template <int J, int CN>
+__device__ __forceinline__ void rnn_matvec_lds(const float* __restrict__ W2, const float (&ctx)[kRnnCN][J],
+                                               float (&acc)[kRnnCN][J], int lane) {
+  static_assert(J == 1 || J == 2, "the LDS copy exists for E <= 128 only");
+  constexpr int EP = 64 * J;
+#pragma unroll 8
+  for (int kp = 0; kp < EP / 2; ++kp) {
+    const float* row = W2 + (kp * 64 + lane) * 2 * J;
+    float w[2][J];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < J; ++j) w[r][j] = row[r * J + j];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int src = J == 2 ? kp : 2 * kp + r;   // lane holding ctx element k = 2 kp + r
+      constexpr int kZero = 0;
+      const int j2 = J == 2 ? r : kZero;
+#pragma unroll
+      for (int p = 0; p < CN; ++p) {
+        const float c = wave_bcast_f32(j2 == 0 ? ctx[p][0] : ctx[p][J - 1], src);
+#if !defined(JPP_EMU)
+        if (J == 2) {
+          rnn_f2 a = {acc[p][0], acc[p][J - 1]};
+          const rnn_f2 ww = {w[r][0], w[r][J - 1]};
+          const rnn_f2 cc = {c, c};
+          a = __builtin_elementwise_fma(ww, cc, a);
+          acc[p][0] = a.x;
+          acc[p][J - 1] = a.y;
+          continue;
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[p][j] = __builtin_fmaf(w[r][j], c, acc[p][j]);
+      }
+    }
+  }
+}
+
+template <int J, int CN, bool WLDS>
+__device__ __forceinline__ void rnn_matvec_any(const float* __restrict__ Wt, const float (&ctx)[kRnnCN][J],
+                                               float (&acc)[kRnnCN][J], int lane) {
+  if constexpr (WLDS) rnn_matvec_lds<J, CN>(Wt, ctx, acc, lane);
+  else rnn_matvec<J, CN>(Wt, ctx, acc, lane);
+}
+
 // MikolovIndexCalculator::calcIndices + the weight gathers of MikolovScoreCalculator::calcScoresN for one
 // (word, history) pair; the caller adds w[0] + w[1] + ... left to right.  Every history slot holds
 // prev->id (reference quirk, rnn_scorer_gbeam.cc:171-188), so the context hash of order i is
@@ -725,23 +784,28 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
 // MODE 0 (E > 128): one launch does everything, W streamed from L2.
 // MODE 2 (E <= 128, after k_rnn_chain): everything but the recurrence (maxent sums, NCE dot products, score cells,
 // adjustBeamScores, remakeEosBeam) for the sentences k_rnn_chain handled, reading the contexts it left in HBM/L2.
-// MODE 3 (E <= 128): the complete boundary-by-boundary path (W streamed from L2) for the sentences beyond the LDS
-// staging limits, which the other two kernels skip; a launch of its own so that its registers do not set MODE 2's
-// occupancy.
+// MODE 3 (E <= 128): the complete boundary-by-boundary path for the sentences beyond the LDS staging limits, which
+// the other two kernels skip; 16 wavefronts per workgroup share a pair-interleaved copy of W^T in LDS
+// (rnn_matvec_lds).  A launch of its own so that its registers and LDS do not set MODE 2's occupancy.
 // Four wavefronts (sentences) per workgroup and no workgroup barrier after the start: several workgroups per CU
 // hide each other's load latency.
 template <int J, bool SORT, int MODE>
-__global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
+__global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   static_assert(MODE == 0 || ((MODE == 2 || MODE == 3) && J <= 2), "k_rnn_chain covers E <= 128");
-  constexpr int kWaves = 4;
+  constexpr int kWaves = MODE == 3 ? 16 : 4;
+  constexpr bool kWinLds = MODE == 3;
   constexpr int EP = 64 * J;
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   __shared__ u64 s_exptab[kExp2fN];   // 2^(i/32) table of expf_libm: lanes index it divergently
   if (threadIdx.x < (u32)kExp2fN) s_exptab[threadIdx.x] = exp2f_tab((int)threadIdx.x);
+  __shared__ float s_W[kWinLds ? EP * EP : 1];
+  if (kWinLds) {
+    for (u32 q = threadIdx.x; q < (u32)(EP * EP); q += blockDim.x) s_W[rnn_w2_index<(J <= 2 ? J : 1)>(q / EP, q % EP)] = M.rnn_wt[q];
+  }
   __syncthreads();
-  const float* __restrict__ Wt = M.rnn_wt;
+  const float* __restrict__ Wt = kWinLds ? s_W : M.rnn_wt;
   // MODE 3: a fixed, small grid walks the sentences of the last class (the tail of the chain-length order; usually
   // there are none, and a full-size launch of empty workgroups costs more than the other RNN kernels' early exits)
   u32 slot = blockIdx.x * kWaves + wv;
@@ -963,10 +1027,10 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
 #pragma unroll
           for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
           switch (cn) {
-            case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
-            case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
-            case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
-            default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
+            case 1: rnn_matvec_any<J, 1, kWinLds>(Wt, ctx, acc, lane); break;
+            case 2: rnn_matvec_any<J, 2, kWinLds>(Wt, ctx, acc, lane); break;
+            case 3: rnn_matvec_any<J, 3, kWinLds>(Wt, ctx, acc, lane); break;
+            default: rnn_matvec_any<J, 4, kWinLds>(Wt, ctx, acc, lane); break;
           }
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p) {
@@ -1131,10 +1195,10 @@ __global__ void __launch_bounds__(256) k_rnn_score(Batch B, const DevModel* __re
 #pragma unroll
             for (int j = 0; j < J; ++j) acc[p][j] = 0.f;
           switch (cn) {
-            case 1: rnn_matvec<J, 1>(Wt, ctx, acc, lane); break;
-            case 2: rnn_matvec<J, 2>(Wt, ctx, acc, lane); break;
-            case 3: rnn_matvec<J, 3>(Wt, ctx, acc, lane); break;
-            default: rnn_matvec<J, 4>(Wt, ctx, acc, lane); break;
+            case 1: rnn_matvec_any<J, 1, kWinLds>(Wt, ctx, acc, lane); break;
+            case 2: rnn_matvec_any<J, 2, kWinLds>(Wt, ctx, acc, lane); break;
+            case 3: rnn_matvec_any<J, 3, kWinLds>(Wt, ctx, acc, lane); break;
+            default: rnn_matvec_any<J, 4, kWinLds>(Wt, ctx, acc, lane); break;
           }
 #pragma unroll
           for (int p = 0; p < kRnnCN; ++p) {
