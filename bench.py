@@ -296,7 +296,8 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
         cli = ge.build_host()
         out_path = os.path.join(os.path.dirname(corpus), 'cli_out.txt')
         best = None
-        for _ in range(2):   # the output (2 GB) goes to the box's scratch disk, whose write rate varies 2x: best of two runs
+        for _ in range(3):   # a fresh process sometimes stalls for seconds in its first device allocations (seen as 2.5 s in one of
+                             # four runs, tools/gpu_cli_loop.sh), and the 2 GB output goes to the box's scratch disk: best of three runs
             t0 = time.perf_counter()
             p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, corpus],
                                capture_output=True, text=True)
@@ -314,7 +315,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
             size = os.path.getsize(out_path)
             os.remove(out_path)
             r = {'what': 'jumanpp_gpu --model=M.jppmdl corpus -o file: %d lines, file in -> JUMAN text out (%.0f MB), '
-                         'pipeline of read | analyse | format (%d threads) | write; best of 2 runs' % (n_lines, size / 1e6, int(kv.get('threads', 0))),
+                         'pipeline of read | analyse | format (%d threads) | write; best of 3 runs' % (n_lines, size / 1e6, int(kv.get('threads', 0))),
                  'value': round(kv.get('sent_per_s', 0.0), 1), 'unit': 'sentences/s',
                  'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1), 'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
                  'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
@@ -323,9 +324,11 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
             if best is None or r['value'] > best['value']:
                 best = r
         # the same run with the output discarded (what SURVEY section 8(d) prescribes for the reference CLI: -o /dev/null)
-        p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', '/dev/null', corpus],
-                           capture_output=True, text=True)
-        if p.returncode == 0:
+        for _ in range(2):
+            p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', '/dev/null', corpus],
+                               capture_output=True, text=True)
+            if p.returncode != 0:
+                break
             kv = {}
             for tok in (p.stderr.strip().splitlines() or [''])[-1].split():
                 if '=' in tok:
@@ -334,9 +337,10 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                         kv[k] = float(v)
                     except ValueError:
                         pass
-            best['to_dev_null'] = {'value': round(kv.get('sent_per_s', 0.0), 1), 'unit': 'sentences/s',
-                                   'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
-                                   'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')}}
+            r = {'value': round(kv.get('sent_per_s', 0.0), 1), 'unit': 'sentences/s', 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
+                 'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')}}
+            if 'to_dev_null' not in best or r['value'] > best['to_dev_null']['value']:
+                best['to_dev_null'] = r
         return best
     except Exception as e:  # an extra measurement must never take the main line down
         return {'error': str(e)[:200]}

@@ -229,7 +229,8 @@ struct Batch {
   u32* rnn_offs;           // [kRnnOrderBins] next free slot of every length class
   u32* rnn_hist;           // [kRnnOrderBins] sentences per length class (all zero between batches)
   u32* rnn_slow;           // [2] first slot and number of the sentences of the last class (not staged in LDS)
-  float* rnn_ctx;          // [bb][gbeam][EP] hidden state after each rnn node
+  float* rnn_ctx;          // [cpb][gbeam][EP] hidden state after each rnn node; cpb = rnn_cpbase[s] + 3 s + boundary
+  u64* rnn_cpbase;         // [n_sent + 1] codepoints of the sentences before s (the byte-indexed space would triple rnn_ctx)
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]
   // partial annotation (ScorePlugin): CSR constraint arrays and the resulting per-node penalty (null: off)

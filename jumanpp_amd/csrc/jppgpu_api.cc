@@ -280,7 +280,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_cpbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
   void* rnn_ord_zeroed = nullptr;   // the rnn_ord allocation whose histogram has been zeroed
   // workspace
   DevBuf text, offs;
@@ -544,7 +544,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_cpbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
@@ -578,7 +578,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
-              ctx->rnn_ctx.ensure(bbN * G * (size_t)ctx->hmodel.rnn_EP * 4)));
+              ctx->rnn_cpbase.ensure(((size_t)n + 2) * 8)));
   ok = ok && ctx->gstats.ensure(64);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
@@ -636,7 +636,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_offs = B.rnn_hist ? B.rnn_hist + kRnnOrderBins : nullptr;
   B.rnn_slow = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins : nullptr;
   B.rnn_key = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins + 2 : nullptr;
-  B.rnn_ctx = ctx->rnn_ctx.as<float>();
+  B.rnn_ctx = ctx->rnn_ctx.as<float>();   // (sized below, once the codepoint total is known)
+  B.rnn_cpbase = ctx->rnn_cpbase.as<u64>();
   if (n == 0) {
     B.total_nodes = 0;
     *out = Rp;
@@ -654,10 +655,18 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_layout<1>, wblocks, 64 * kLatWaves, st, B);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
-  u64 totals[2] = {0, 0};
+  u64 totals[3] = {0, 0, 0};
+  if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_ncp, B.rnn_cpbase, n, (const u64*)nullptr);
   rt_d2h(&totals[0], B.node_base + n, 8, st);
   rt_d2h(&totals[1], B.node_base2 + n, 8, st);
+  if (ctx->cfg.nscorers == 2) rt_d2h(&totals[2], B.rnn_cpbase + n, 8, st);
   rt_sync(st);
+  if (ctx->cfg.nscorers == 2) {
+    // hidden states: one row of G * EP floats per boundary (codepoints + 3 per sentence)
+    if (!ctx->rnn_ctx.ensure((totals[2] + 3 * (size_t)n + 8) * G * (size_t)ctx->hmodel.rnn_EP * 4))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
+    B.rnn_ctx = ctx->rnn_ctx.as<float>();
+  }
   const u64 total1 = totals[0];
   const u64 seedCap = total1 + totals[1] + 8;
   if (!(ctx->node_info.ensure(seedCap * sizeof(NodeInfo)) && ctx->node_aux.ensure(seedCap * sizeof(NodeAux))))

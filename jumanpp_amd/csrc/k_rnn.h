@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
     const u32 bb0 = B.byte_off[s] + 4 * s;
     const u32 bE = n + 2;
     own = own && n != 0 && B.bnd_ngb[bb0 + bE] != 0;
-    rn_ctx[g] = B.rnn_ctx + (u64)bb0 * G * EP;   // (not own: some sentence's row 0 serves as the parking row)
+    rn_ctx[g] = B.rnn_ctx + (B.rnn_cpbase[s] + 3ull * s) * (u64)G * EP;   // (not own: some sentence's row 0 serves as the parking row)
     nchain[g] = 0;
     const u32 nq = (bE + 1) * (u32)G;
     const u32* rn_cnt = B.rnn_cnt + bb0;
@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
   const u32* conn = B.rnn_conn + (u64)bb0 * G;
   const u32* assign = B.rnn_assign + (u64)bb0 * G;
   const u32* g_len = B.rnn_nlen + (u64)bb0 * G;
-  float* rn_ctx = B.rnn_ctx + (u64)bb0 * G * EP;
+  float* rn_ctx = B.rnn_ctx + (B.rnn_cpbase[s] + 3ull * s) * (u64)G * EP;
 
   // the per-node fields the boundary loop depends on are staged in LDS when they fit
   constexpr u32 kCap = kRnnStageCap, kCapB = kRnnStageCapB;
