@@ -306,6 +306,23 @@ typedef struct {
 } jppgpu_nbest_view;
 
 int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jppgpu_nbest_view* view);
+/* Training hook.  What the reference's trainer reads off an analysed lattice besides the scores
+ * (LossCalculator::addTopNgrams, src/core/training/loss.cc:289-300 -> NgramFeaturesComputer::calculateNgramFeatures,
+ * src/core/impl/feature_computer.cc:13-31): for every connection on the top-1 path of every sentence, from the EOS
+ * side back to the first morpheme, the u32 value of each n-gram feature of the spec for (t2, t1, t0 = that node) --
+ * the weight index before masking by the table size, i.e. where a perceptron update adds its deltas. */
+typedef struct {
+  uint32_t n_sentences;
+  uint32_t n_ngram;                /* features per position, in the spec's feature order (jumandic: 73) */
+  const uint64_t* path_first;      /* [n_sentences + 1] offsets into path_nodes / features (0 positions for failed sentences) */
+  const uint32_t* path_nodes;      /* [path_first[n]] sentence-local node index of t0, EOS first */
+  const uint32_t* features;        /* [path_first[n]][n_ngram] */
+} jppgpu_top1_ngrams_view;
+int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_ngrams_view* view);
+/* Replaces the perceptron weight table of the context (the trainer's update step; HashedFeaturePerceptron /
+ * FloatBufferWeights, src/core/analysis/perceptron.h:76-94, score_api.h:29-42).  n must equal the model's table
+ * size; takes effect for the next jppgpu_analyze_batch* on the context. */
+int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uint64_t n);
 /* Per-batch statistics without copying the lattice: total nodes, sum of path lengths. */
 int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path);
 /* Packed top-1 output written to caller-provided DEVICE buffers (e.g. to be gathered

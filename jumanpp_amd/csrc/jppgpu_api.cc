@@ -22,6 +22,7 @@
 #include "k_sweep.h"
 #include "k_sweep_full.h"
 #include "k_t0.h"
+#include "k_train.h"
 
 using namespace jpp;
 
@@ -271,6 +272,10 @@ struct jppgpu_result {
   HostVec<u64> nb_first;
   HostVec<jppgpu_beam_slot> nb_eos;
   HostVec<jppgpu_nbest_item> nb_items;
+  // jppgpu_result_fetch_top1_ngrams
+  bool ng_have = false;
+  HostVec<u64> ng_first;
+  HostVec<u32> ng_nodes, ng_feat;
   void bind(HostPool* pool);
 };
 
@@ -280,7 +285,7 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_cpbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_cpbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   void* rnn_ord_zeroed = nullptr;   // the rnn_ord allocation whose histogram has been zeroed
   // workspace
   DevBuf text, offs;
@@ -315,6 +320,7 @@ void jppgpu_result::bind(HostPool* pool) {
   beams.pool = pool; kept.pool = pool; byte_off.pool = pool;
   t1_status.pool = pool; t1_ncp.pool = pool; t1_len.pool = pool; t1_idx.pool = pool; t1_base.pool = pool;
   t1_zero.pool = pool; t1_nodes.pool = pool; t1_unk.pool = pool;
+  ng_first.pool = pool; ng_nodes.pool = pool; ng_feat.pool = pool;
   nb_status.pool = pool; nb_ncp.pool = pool; nb_nnodes.pool = pool; nb_first.pool = pool; nb_eos.pool = pool; nb_items.pool = pool;
 }
 
@@ -1175,6 +1181,52 @@ extern "C" int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jpp
   v->eos = res->nb_eos.data();
   v->path_first = res->nb_first.data();
   v->items = res->nb_items.data();
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_ngrams_view* v) {
+  if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jppgpu_ctx* ctx = res->ctx;
+  bind_device(ctx->device);
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  if (!res->ng_have) {
+    if (res->generation != ctx->generation)
+      return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+    jpp_stream_t st = ctx->last_stream;
+    if (!(ctx->nbest_cnt.ensure(((size_t)n + 1) * 4) && ctx->nbest_off.ensure(((size_t)n + 2) * 8)))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (n-gram fetch)");
+    if (n) JPP_LAUNCH(k_path_count, (n + 255) / 256, 256, st, B, ctx->nbest_cnt.as<u32>());
+    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->nbest_cnt.as<u32>(), ctx->nbest_off.as<u64>(), n, (const u64*)nullptr);
+    bool ok = pull(res->ng_first, ctx->nbest_off.p, (size_t)n + 1, st);
+    rt_sync(st);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
+    const u64 M = res->ng_first[n];
+    if (!(ctx->ng_nodes.ensure((M + 1) * 4) && ctx->ng_feat.ensure((M + 1) * kNumNgram * 4)))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (n-gram fetch)");
+    if (n) JPP_LAUNCH(k_path_ngrams, n, 64, st, B, (const u64*)ctx->nbest_off.as<u64>(), ctx->ng_nodes.as<u32>(), ctx->ng_feat.as<u32>());
+    ok = pull(res->ng_nodes, ctx->ng_nodes.p, (size_t)M, st) && pull(res->ng_feat, ctx->ng_feat.p, (size_t)M * kNumNgram, st);
+    rt_sync(st);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
+    res->ng_have = true;
+  }
+  v->n_sentences = n;
+  v->n_ngram = (uint32_t)kNumNgram;
+  v->path_first = res->ng_first.data();
+  v->path_nodes = res->ng_nodes.data();
+  v->features = res->ng_feat.data();
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uint64_t n) {
+  if (!ctx || !weights) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (n != (uint64_t)ctx->hmodel.wmask + 1) return fail(JPPGPU_INVALID_PARAMETER, "weight count does not match the model's table");
+  bind_device(ctx->device);
+  // (ordered behind every batch already enqueued on the context's streams)
+  if (ctx->last_stream) rt_sync(ctx->last_stream);
+  rt_sync(ctx->own_stream);
+  rt_h2d(ctx->weights.p, weights, (size_t)n * 4, nullptr);
+  rt_sync(nullptr);
   return JPPGPU_OK;
 }
 

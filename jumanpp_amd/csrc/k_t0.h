@@ -39,6 +39,74 @@ __host__ __device__ constexpr u64 tri_prefix(int index) {
   return hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)index), kTrigramSeed);
 }
 
+// Primitive features and the kNumPatterns pattern hashes of one node (generated
+// PatternFeatureStaticApply_JumandicStatic::patternsAndUnigramsApply, first half; dynamic equivalent
+// InNodeFeatureComputer + PatternDynamicApplyImpl::apply, innode_features.cc:11-33, feature_impl_pattern.h:59-65)
+// from its entry row, its span and the codepoints / classes of the sentence.
+__device__ __forceinline__ void t0_patterns(const i32 (&entry)[spec::kNumDicFeatures], const NodeInfo& ni, const NodeAux& na,
+                                            bool isUnk, const u32* cps, const i32* cls, u32 n, u64 (&pat)[spec::kNumPatterns]) {
+  // ---- primitive features ----
+  u64 prim[spec::kNumPrims];
+#pragma unroll
+  for (int p = 0; p < spec::kNumPrims; ++p) {
+    const int kind = spec::kPrims[p].kind;
+    const int a = spec::kPrims[p].a;
+    const int bsh = spec::kPrims[p].b;
+    u64 v = 0;
+    if (kind == spec::Copy) {
+      v = (u32)entry[a];
+    } else if (kind == spec::SingleBit) {
+      v = ((u32)entry[a] >> bsh) & 1u;
+    } else if (kind == spec::Provided) {
+      v = isUnk ? (u64)(u32)(a == 0 ? na.ph0 : na.ph1) : 0;
+    } else if (kind == spec::SurfaceCodepointSize) {
+      v = (u64)((i32)ni.end - (i32)ni.start);
+    } else if (kind == spec::Codepoint) {
+      v = ~u64{0};
+      if (a > 0) {
+        u32 pos = (u32)ni.end + (u32)(a - 1);
+        if (pos < n) v = cps[pos];
+      } else {
+        i32 pos = (i32)ni.start + a;
+        if (pos >= 0 && (u32)pos < n) v = cps[pos];
+      }
+    } else if (kind == spec::CodepointType) {
+      v = 0;
+      if (a == 0) {
+        for (u32 q = ni.start; q < ni.end; ++q) v |= (u32)cls[q];
+      } else if (a > 0) {
+        u32 pos = (u32)ni.end + (u32)(a - 1);
+        if (pos < n) v = (u32)cls[pos];
+      } else {
+        i32 pos = (i32)ni.start + a;
+        if (pos >= 0 && (u32)pos < n) v = (u32)cls[pos];
+      }
+    }
+    prim[p] = v;
+  }
+
+  // ---- pattern hashes ----
+#pragma unroll
+  for (int p = 0; p < spec::kNumPatterns; ++p) {
+    u64 h = pattern_prefix(p, spec::kPatterns[p].nargs);
+#pragma unroll
+    for (int q = 0; q < spec::kPatterns[p].nargs; ++q) {
+      const int c = spec::kPatterns[p].args[q];
+      if (spec::kComputes[c].cond < 0) {
+        h = hmix(h, prim[spec::kComputes[c].t[0]]);
+      } else {
+        u64 ht = h, hf = h;
+#pragma unroll
+        for (int z = 0; z < spec::kComputes[c].nt; ++z) ht = hmix(ht, prim[spec::kComputes[c].t[z]]);
+#pragma unroll
+        for (int z = 0; z < spec::kComputes[c].nf; ++z) hf = hmix(hf, prim[spec::kComputes[c].f[z]]);
+        h = prim[spec::kComputes[c].cond] != 0 ? ht : hf;
+      }
+    }
+    pat[p] = h;
+  }
+}
+
 // (more wavefronts per SIMD do not help here: 5 at 94 VGPRs 2.01 ms, 6 at 80 2.05 ms, 8 at 64 with spills 2.68 ms)
 template <bool W24>   // W24: at most 2^24 weights (hmix_index)
 __global__ void __launch_bounds__(64) k_t0(Batch B, const DevModel* __restrict__ Mp) {
@@ -87,67 +155,8 @@ __global__ void __launch_bounds__(64) k_t0(Batch B, const DevModel* __restrict__
 #pragma unroll
     for (int f = 0; f < spec::kNumDicFeatures; ++f) B.node_entry[(nb + k) * spec::kNumDicFeatures + f] = entry[f];
 
-    // ---- primitive features ----
-    u64 prim[spec::kNumPrims];
-#pragma unroll
-    for (int p = 0; p < spec::kNumPrims; ++p) {
-      const int kind = spec::kPrims[p].kind;
-      const int a = spec::kPrims[p].a;
-      const int bsh = spec::kPrims[p].b;
-      u64 v = 0;
-      if (kind == spec::Copy) {
-        v = (u32)entry[a];
-      } else if (kind == spec::SingleBit) {
-        v = ((u32)entry[a] >> bsh) & 1u;
-      } else if (kind == spec::Provided) {
-        v = isUnk ? (u64)(u32)(a == 0 ? na.ph0 : na.ph1) : 0;
-      } else if (kind == spec::SurfaceCodepointSize) {
-        v = (u64)((i32)ni.end - (i32)ni.start);
-      } else if (kind == spec::Codepoint) {
-        v = ~u64{0};
-        if (a > 0) {
-          u32 pos = (u32)ni.end + (u32)(a - 1);
-          if (pos < n) v = cps[pos];
-        } else {
-          i32 pos = (i32)ni.start + a;
-          if (pos >= 0 && (u32)pos < n) v = cps[pos];
-        }
-      } else if (kind == spec::CodepointType) {
-        v = 0;
-        if (a == 0) {
-          for (u32 q = ni.start; q < ni.end; ++q) v |= (u32)cls[q];
-        } else if (a > 0) {
-          u32 pos = (u32)ni.end + (u32)(a - 1);
-          if (pos < n) v = (u32)cls[pos];
-        } else {
-          i32 pos = (i32)ni.start + a;
-          if (pos >= 0 && (u32)pos < n) v = (u32)cls[pos];
-        }
-      }
-      prim[p] = v;
-    }
-
-    // ---- pattern hashes ----
     u64 pat[spec::kNumPatterns];
-#pragma unroll
-    for (int p = 0; p < spec::kNumPatterns; ++p) {
-      u64 h = pattern_prefix(p, spec::kPatterns[p].nargs);
-#pragma unroll
-      for (int q = 0; q < spec::kPatterns[p].nargs; ++q) {
-        const int c = spec::kPatterns[p].args[q];
-        if (spec::kComputes[c].cond < 0) {
-          h = hmix(h, prim[spec::kComputes[c].t[0]]);
-        } else {
-          u64 ht = h, hf = h;
-#pragma unroll
-          for (int z = 0; z < spec::kComputes[c].nt; ++z) ht = hmix(ht, prim[spec::kComputes[c].t[z]]);
-#pragma unroll
-          for (int z = 0; z < spec::kComputes[c].nf; ++z) hf = hmix(hf, prim[spec::kComputes[c].f[z]]);
-          h = prim[spec::kComputes[c].cond] != 0 ? ht : hf;
-        }
-      }
-      pat[p] = h;
-    }
+    t0_patterns(entry, ni, na, isUnk, cps, cls, n, pat);
 #pragma unroll
     for (int p = 0; p < spec::kNumStoredPatterns; ++p) B.node_pat[(nb + k) * kPat + p] = pat[p];
 

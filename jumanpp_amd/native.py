@@ -68,6 +68,11 @@ class NbestView(C.Structure):
                 ('eos', C.c_void_p), ('path_first', C.c_void_p), ('items', C.c_void_p)]
 
 
+class NgramsView(C.Structure):
+    _fields_ = [('n_sentences', C.c_uint32), ('n_ngram', C.c_uint32), ('path_first', C.c_void_p), ('path_nodes', C.c_void_p),
+                ('features', C.c_void_p)]
+
+
 NODE_DT = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
 UNK_DT = np.dtype([('tmpl', '<i4'), ('hash', '<i4'), ('ph0', '<u2'), ('ph1', '<u2'), ('maker', '<u2'), ('pad', '<u2')])
 BEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('total', '<f4'), ('prev_node', '<u4'), ('pad', '<u4')])
@@ -94,6 +99,8 @@ def load_library(path=None):
                                                 C.c_void_p, C.POINTER(C.c_void_p)]
     lib.jppgpu_result_fetch.argtypes = [C.c_void_p, C.c_int, C.POINTER(ResultView)]
     lib.jppgpu_result_fetch_nbest.argtypes = [C.c_void_p, C.c_int32, C.POINTER(NbestView)]
+    lib.jppgpu_result_fetch_top1_ngrams.argtypes = [C.c_void_p, C.POINTER(NgramsView)]
+    lib.jppgpu_ctx_set_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.jppgpu_result_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.jppgpu_result_release.argtypes = [C.c_void_p]
     lib.jppgpu_result_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -185,6 +192,17 @@ class Result:
         return (self._arr(v.eos, BEAM_DT, n * n_best).reshape(n, n_best), first, self._arr(v.items, NBEST_DT, total),
                 self._arr(v.n_nodes, '<u4', n))
 
+    def fetch_top1_ngrams(self):
+        """(path_first [n + 1], path_nodes [M], features [M, n_ngram]) of jppgpu_result_fetch_top1_ngrams"""
+        v = NgramsView()
+        rc = self.ctx.lib.jppgpu_result_fetch_top1_ngrams(self.handle, C.byref(v))
+        if rc != 0:
+            raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
+        n = v.n_sentences
+        first = self._arr(v.path_first, '<u8', n + 1)
+        total = int(first[-1]) if n else 0
+        return first, self._arr(v.path_nodes, '<u4', total), self._arr(v.features, '<u4', total * v.n_ngram).reshape(total, v.n_ngram)
+
     def stats(self):
         a, b = C.c_uint64(), C.c_uint64()
         rc = self.ctx.lib.jppgpu_result_stats(self.handle, C.byref(a), C.byref(b))
@@ -241,6 +259,7 @@ class Context:
             raise JppGpuError('model image has no perceptron weights (untrained model)')
         m.weight_exponent = by[5][0][0]
         m.weights, _ = buf(by[5][0][1])
+        self.weights = np.frombuffer(by[5][0][1], dtype=np.float32).copy()   # (the table as loaded; see set_weights)
         m.num_features = self.num_features
         m.num_placeholders = self.num_placeholders
         ub = by[6][0][1]
@@ -317,6 +336,13 @@ class Context:
             raise JppGpuError('jppgpu_analyze_batch_device failed (%d): %s'
                               % (rc, self.lib.jppgpu_last_error().decode()))
         return Result(self, r)
+
+    def set_weights(self, weights):
+        """jppgpu_ctx_set_weights: a float32 array of the model's table size"""
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        rc = self.lib.jppgpu_ctx_set_weights(self.handle, w.ctypes.data_as(C.c_void_p), w.size)
+        if rc != 0:
+            raise JppGpuError(self.lib.jppgpu_last_error().decode())
 
     def timings(self):
         ms = (C.c_float * 8)()

@@ -49,6 +49,7 @@
 #include "core/dic/dic_builder.h"
 #include "core/dic/dictionary.h"
 #include "core/env.h"
+#include "core/impl/feature_computer.h"
 #include "core/impl/feature_impl_types.h"
 #include "core/impl/model_io.h"
 #include "core/impl/perceptron_io.h"
@@ -1039,9 +1040,64 @@ int doShim(const char* modelFile, const char* libPath, int latticeN, char** extr
 
 }  // namespace
 
+// `ngrams MODEL OUT [beams] < text`: what the trainer's loss computation reads off an analysed lattice
+// (LossCalculator::addTopNgrams, core/training/loss.cc:289-300): for every connection on the top-1 path, from the
+// EOS side back to the first morpheme, the u32 n-gram feature values of NgramFeaturesComputer::calculateNgramFeatures
+// for (t2, t1, t0).  Binary: u32 magic 'NGR1', u32 sentences, u32 features per node; per sentence u32 status
+// (0 ok), u32 positions; per position u16 boundary, u16 position of t0, then the features.
+int doNgrams(const char* modelFile, const char* out, char** extra, int nextra) {
+  Env e;
+  e.init(modelFile, extra, nextra);
+  Analyzer an;
+  CHECK_OK(e.env.makeAnalyzer(&an));
+  an.impl()->setStoreAllPatterns(true);   // the trainer's analyzer keeps the unigram-only patterns too (training_env.h:80)
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(std::cin, line)) lines.push_back(line);
+  std::ofstream os(out, std::ios::binary);
+  auto put32 = [&](u32 v) { os.write(reinterpret_cast<const char*>(&v), 4); };
+  auto put16 = [&](u16 v) { os.write(reinterpret_cast<const char*>(&v), 2); };
+  const u32 nf = (u32)an.impl()->core().spec().features.ngram.size();
+  put32(0x3152474eu);
+  put32((u32)lines.size());
+  put32(nf);
+  std::vector<u32> buf(nf);
+  for (auto& l : lines) {
+    Status st = an.analyze(l);
+    if (!st) {
+      put32(1);
+      put32(0);
+      continue;
+    }
+    auto* lat = an.impl()->lattice();
+    core::features::NgramFeaturesComputer nfc{lat, an.impl()->core().features()};
+    const int last = (int)lat->createdBoundaryCount() - 1;
+    std::vector<const ConnectionPtr*> path;
+    const ConnectionBeamElement& top = lat->boundary(last)->starts()->beamData().row(0).at(0);
+    // (an empty input leaves the previous sentence's beams in place: no path)
+    const ConnectionPtr* p = (last <= 2 || EntryBeam::isFake(top)) ? nullptr : &top.ptr;
+    while (p != nullptr && p->boundary >= 2) {   // boundaries 0 and 1 are the BOS nodes
+      path.push_back(p);
+      p = p->previous;
+    }
+    put32(0);
+    put32((u32)path.size());
+    for (auto* t0 : path) {
+      const ConnectionPtr& t1 = *t0->previous;
+      const ConnectionPtr& t2 = *t1.previous;
+      core::features::NgramFeatureRef nfr{t2.latticeNodePtr(), t1.latticeNodePtr(), t0->latticeNodePtr()};
+      nfc.calculateNgramFeatures(nfr, &buf);
+      put16(t0->boundary);
+      put16(t0->right);
+      os.write(reinterpret_cast<const char*>(buf.data()), nf * 4);
+    }
+  }
+  return os.good() ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::cerr << "usage: ref_dump export|mkmodel|dump|time|shim ...\n";
+    std::cerr << "usage: ref_dump export|mkmodel|dump|time|shim|ngrams ...\n";
     return 2;
   }
   std::string cmd = argv[1];
@@ -1052,6 +1108,7 @@ int main(int argc, char** argv) {
   if (cmd == "dump" && argc >= 4) return doDump(argv[2], argv[3], argv + 4, argc - 4);
   if (cmd == "time" && argc >= 3) return doTime(argv[2], argv + 3, argc - 3);
   if (cmd == "shim" && argc >= 5) return doShim(argv[2], argv[3], atoi(argv[4]), argv + 5, argc - 5);
+  if (cmd == "ngrams" && argc >= 4) return doNgrams(argv[2], argv[3], argv + 4, argc - 4);
   std::cerr << "bad arguments\n";
   return 2;
 }

@@ -597,3 +597,79 @@ def test_emulated_maximum_size_sentences(emu_lib, ref_tools, tmp_path):
     for s in range(len(lines)):
         errs += G.compare_sentence(res, s, gold[s], meta)
     assert not errs, errs[:10]
+
+
+# ---- training hook: top-1 n-gram feature values, weight upload ----
+
+def check_top1_ngrams_against_reference(lib, ref_tools, golden_dir, tmp_path):
+    """jppgpu_result_fetch_top1_ngrams against NgramFeaturesComputer::calculateNgramFeatures on the reference's own
+    lattice (oracle/ref_dump.cc `ngrams`, what LossCalculator::addTopNgrams reads): every u32, bit for bit."""
+    import struct
+    out = str(tmp_path / 'ng.bin')
+    with open(os.path.join(golden_dir, 'mini.txt'), 'rb') as f:
+        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'ngrams', os.path.join(golden_dir, 'mini.jppmdl'), out],
+                              stdin=f, stderr=subprocess.DEVNULL)
+    raw = open(out, 'rb').read()
+    magic, ns, nf = struct.unpack_from('<III', raw, 0)
+    assert magic == 0x3152474e and nf == 73
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    assert ns == len(lines)
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=lib)
+    r = ctx.analyze(lines)
+    full = r.fetch(full=True)
+    first, nodes, feats = r.fetch_top1_ngrams()
+    assert feats.shape[1] == nf and len(first) == ns + 1
+    pos = 12
+    checked = 0
+    for s in range(ns):
+        st, np_ = struct.unpack_from('<II', raw, pos)
+        pos += 8
+        assert (st == 0) == (int(full.status[s]) == 0)
+        lo, hi = int(first[s]), int(first[s + 1])
+        assert hi - lo == np_ == (int(full.path_len[s]) if st == 0 else 0)
+        bb = int(full.bnd_base[s])
+        for j in range(np_):
+            b, rpos = struct.unpack_from('<HH', raw, pos)
+            pos += 4
+            ref = np.frombuffer(raw, dtype='<u4', count=nf, offset=pos)
+            pos += 4 * nf
+            node = int(nodes[lo + j])
+            assert node == int(full.bnd_first[bb + b]) + rpos, (s, j)
+            assert np.array_equal(feats[lo + j], ref), (s, j, np.nonzero(feats[lo + j] != ref)[0][:8])
+            checked += 1
+    assert checked > 300
+    r.release()
+
+
+def test_emulated_top1_ngram_features_match_the_reference_trainer(emu_lib, ref_tools, golden_dir, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_top1_ngrams_against_reference(emu_lib, ref_tools, golden_dir, tmp_path)
+
+
+def check_set_weights(lib, golden_dir):
+    """jppgpu_ctx_set_weights: doubling every weight doubles every perceptron score exactly (powers of two) and
+    keeps every decision; the original table restores the original results bit for bit."""
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=lib)
+    a = ctx.analyze(lines).fetch(full=True)
+    t0, beams, pn = a.t0.copy(), a.beams.copy(), a.path_nodes.copy()
+    real = np.zeros(len(t0), dtype=bool)   # (the two BOS nodes of a sentence have no T0 score, and sentences that
+    for s in range(len(lines)):             # needed stage 2 were relocated: their first region is never written)
+        if int(a.status[s]) == 0:
+            real[int(a.node_base[s]) + 2:int(a.node_base[s]) + int(a.nnodes[s])] = True
+    ctx.set_weights(ctx.weights * np.float32(2.0))
+    b = ctx.analyze(lines).fetch(full=True)
+    assert np.array_equal(b.t0[real], t0[real] * np.float32(2.0)) and np.array_equal(b.path_nodes, pn)
+    live = (beams['left'] != 0xffff) & real[:, None]
+    assert np.array_equal(b.beams['total'][live], beams['total'][live] * np.float32(2.0))
+    assert np.array_equal(b.beams['prev_node'][live], beams['prev_node'][live])
+    ctx.set_weights(ctx.weights)
+    c = ctx.analyze(lines).fetch(full=True)
+    assert np.array_equal(c.t0[real], t0[real]) and np.array_equal(c.beams[real], beams[real])
+    with pytest.raises(J.JppGpuError, match='weight count'):
+        ctx.set_weights(ctx.weights[:-1])
+
+
+def test_emulated_weight_upload(emu_lib, golden_dir):
+    check_set_weights(emu_lib, golden_dir)

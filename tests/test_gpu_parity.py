@@ -335,3 +335,17 @@ def test_gpu_lattice_wider_than_the_lds_staging(gpu_lib, ref_tools, tmp_path, be
     assert list(res.status) == [0, 0, 0] and int(res.bnd_count.max()) > 512
     errs = _compare_all(res, gold, meta, len(lines))
     assert not errs, errs[:10]
+
+
+@pytest.mark.gpu
+def test_gpu_top1_ngram_features_match_the_reference_trainer(gpu_lib, ref_tools, golden_dir, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tc.check_top1_ngrams_against_reference(gpu_lib, ref_tools, golden_dir, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_weight_upload(gpu_lib, golden_dir):
+    import test_cpu_parity as tc
+    tc.check_set_weights(gpu_lib, golden_dir)
