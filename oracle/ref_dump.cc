@@ -24,6 +24,9 @@
 //       host pointers rebuilt from the index form).  The reference's UNMODIFIED
 //       JumanFormat / LatticeFormat then format that analyzer; the bytes must equal those of a plain
 //       Analyzer::analyze run.  Prints one JSON line, exit code 0 iff everything is identical.
+//   ref_dump ngrams  <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
+//       the trainer's read-out: NgramFeaturesComputer::calculateNgramFeatures for every connection of the top-1
+//       path on an analyzer that stores all patterns (what jppgpu_result_fetch_top1_ngrams must reproduce)
 //   ref_dump time    <model.jppmdl> [beam gbeam rcheck rbeam] < corpus
 //       wall-clock of Analyzer::analyze (+JumanFormat) over the corpus, phases split
 //       as BASELINE.md section 3.

@@ -601,20 +601,22 @@ def test_emulated_maximum_size_sentences(emu_lib, ref_tools, tmp_path):
 
 # ---- training hook: top-1 n-gram feature values, weight upload ----
 
-def check_top1_ngrams_against_reference(lib, ref_tools, golden_dir, tmp_path):
+def check_top1_ngrams_against_reference(lib, ref_tools, golden_dir, tmp_path, workload=None, min_checked=300):
     """jppgpu_result_fetch_top1_ngrams against NgramFeaturesComputer::calculateNgramFeatures on the reference's own
-    lattice (oracle/ref_dump.cc `ngrams`, what LossCalculator::addTopNgrams reads): every u32, bit for bit."""
+    lattice (oracle/ref_dump.cc `ngrams`, what LossCalculator::addTopNgrams reads): every u32, bit for bit.
+    workload = (model.jppmdl, image, text file) instead of the golden mini model."""
     import struct
     out = str(tmp_path / 'ng.bin')
-    with open(os.path.join(golden_dir, 'mini.txt'), 'rb') as f:
-        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'ngrams', os.path.join(golden_dir, 'mini.jppmdl'), out],
-                              stdin=f, stderr=subprocess.DEVNULL)
+    model, img, txt = workload or (os.path.join(golden_dir, 'mini.jppmdl'), os.path.join(golden_dir, 'mini.img'),
+                                   os.path.join(golden_dir, 'mini.txt'))
+    with open(txt, 'rb') as f:
+        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'ngrams', model, out], stdin=f, stderr=subprocess.DEVNULL)
     raw = open(out, 'rb').read()
     magic, ns, nf = struct.unpack_from('<III', raw, 0)
     assert magic == 0x3152474e and nf == 73
-    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    lines = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
     assert ns == len(lines)
-    ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=lib)
+    ctx = J.Context(img, lib_path=lib)
     r = ctx.analyze(lines)
     full = r.fetch(full=True)
     first, nodes, feats = r.fetch_top1_ngrams()
@@ -637,7 +639,7 @@ def check_top1_ngrams_against_reference(lib, ref_tools, golden_dir, tmp_path):
             assert node == int(full.bnd_first[bb + b]) + rpos, (s, j)
             assert np.array_equal(feats[lo + j], ref), (s, j, np.nonzero(feats[lo + j] != ref)[0][:8])
             checked += 1
-    assert checked > 300
+    assert checked > min_checked
     r.release()
 
 

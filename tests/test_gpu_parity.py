@@ -346,6 +346,18 @@ def test_gpu_top1_ngram_features_match_the_reference_trainer(gpu_lib, ref_tools,
 
 
 @pytest.mark.gpu
+def test_gpu_top1_ngram_features_on_fresh_workload(gpu_lib, ref_tools, golden_dir, tmp_path):
+    """1500 fresh sentences, 30k-entry dictionary: ~37 000 path positions x 73 features against the reference."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    img, lines, _ = _fresh_workload(ref_tools, str(tmp_path), 30000, 1500, 20, 88)
+    tc.check_top1_ngrams_against_reference(gpu_lib, ref_tools, golden_dir, tmp_path,
+                                           workload=(os.path.join(str(tmp_path), 'w.model'), img, os.path.join(str(tmp_path), 'w.txt')),
+                                           min_checked=20000)
+
+
+@pytest.mark.gpu
 def test_gpu_weight_upload(gpu_lib, golden_dir):
     import test_cpu_parity as tc
     tc.check_set_weights(gpu_lib, golden_dir)
