@@ -675,3 +675,26 @@ def check_set_weights(lib, golden_dir):
 
 def test_emulated_weight_upload(emu_lib, golden_dir):
     check_set_weights(emu_lib, golden_dir)
+
+
+def test_emulated_rnn_tiny_and_degenerate_batches(emu_lib, golden_dir):
+    """the lock-step RNN kernels with almost empty workgroups: batches of 1, 3 and 33 sentences must give what the
+    same sentences give inside the golden batch; a batch of only empty / invalid sentences must not hang or crash."""
+    img = os.path.join(golden_dir, 'mini_rnn.img')
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    ctx = J.Context(img, lib_path=emu_lib)
+    ref = ctx.analyze(lines).fetch(full=True)
+
+    def path_of(res, s):
+        nb, pl = int(res.node_base[s]), int(res.path_len[s])
+        return [tuple(res.nodes[nb + int(k)]) for k in res.path_nodes[nb:nb + pl]], \
+               [float(x) for x in res.beams[nb + int(res.nnodes[s]) - 1]['total']] if int(res.nnodes[s]) > 2 else []
+
+    for pick in ([5], [0, 9, 13], list(range(len(lines))) + [0, 1, 2, 3, 4]):
+        sub = [lines[i] for i in pick]
+        r = ctx.analyze(sub).fetch(full=True)
+        for j, i in enumerate(pick):
+            assert int(r.status[j]) == int(ref.status[i])
+            assert path_of(r, j) == path_of(ref, i), (pick, j)
+    r = ctx.analyze([b'', b'\xff\xfe', b'', b'\xe3\x81']).fetch(full=True)
+    assert list(r.status) == [0, 2, 0, 2] and int(r.path_len.sum()) == 0

@@ -361,3 +361,27 @@ def test_gpu_top1_ngram_features_on_fresh_workload(gpu_lib, ref_tools, golden_di
 def test_gpu_weight_upload(gpu_lib, golden_dir):
     import test_cpu_parity as tc
     tc.check_set_weights(gpu_lib, golden_dir)
+
+
+@pytest.mark.gpu
+def test_gpu_rnn_tiny_and_degenerate_batches(gpu_lib, golden_dir):
+    """same as the emulator test: batches of 1, 3 and 33 sentences through the lock-step RNN kernels, a batch of
+    only empty / invalid sentences"""
+    img = os.path.join(golden_dir, 'mini_rnn.img')
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    ctx = J.Context(img, lib_path=gpu_lib)
+    ref = ctx.analyze(lines).fetch(full=True)
+
+    def path_of(res, s):
+        nb, pl = int(res.node_base[s]), int(res.path_len[s])
+        return [tuple(res.nodes[nb + int(k)]) for k in res.path_nodes[nb:nb + pl]], \
+               [float(x) for x in res.beams[nb + int(res.nnodes[s]) - 1]['total']] if int(res.nnodes[s]) > 2 else []
+
+    for pick in ([5], [0, 9, 13], list(range(len(lines))) + [0, 1, 2, 3, 4]):
+        sub = [lines[i] for i in pick]
+        r = ctx.analyze(sub).fetch(full=True)
+        for j, i in enumerate(pick):
+            assert int(r.status[j]) == int(ref.status[i])
+            assert path_of(r, j) == path_of(ref, i), (pick, j)
+    r = ctx.analyze([b'', b'\xff\xfe', b'', b'\xe3\x81']).fetch(full=True)
+    assert list(r.status) == [0, 2, 0, 2] and int(r.path_len.sum()) == 0
