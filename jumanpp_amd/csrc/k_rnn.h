@@ -271,28 +271,41 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   // ---- B2. RNN lattice: RnnIdContainer::addPath / addPrevChain ----
   // Path p (= lane p) is at boundary t - p in step t: all earlier paths have already published
   // their rnn nodes of that boundary, later ones have not touched it yet.
+  // What a step needs that does not depend on the earlier steps -- is there a connection, does an earlier path
+  // share it (the ptrCache hit) -- is worked out for every (boundary, path) slot at once beforehand, so that the
+  // serial loop reads one byte instead of walking the earlier paths' connections.
+  // (kept in the top byte of the slot's `assign` word, which the step itself overwrites with its result: 0xff no
+  // connection, 0 first path through its connection, else 1 + the earlier path sharing it)
+  for (u32 q = lane; q < nq; q += 64) {
+    const u32 c = conn[q];
+    u32 v = 0xffu;
+    if (c != kNoConn) {
+      const u32 b = q / (u32)G, p = q - b * (u32)G;
+      v = 0;
+      for (u32 pp = 0; pp < p; ++pp) {
+        if (conn[(u64)b * G + pp] == c) {
+          v = pp + 1;
+          break;
+        }
+      }
+    }
+    assign[q] = v << 24;
+  }
+  wave_sync();
   {
     const int p = lane;
     u32 cur = 1u * G;  // handle of the BOS node
     for (u32 t = 2; t < bE + 1 + (u32)ngb; ++t) {
       const u32 b = t - (u32)p;
       if (p < ngb && t >= (u32)p + 2 && b <= bE) {
-        const u32 c = conn[(u64)b * G + p];
-        if (c != kNoConn) {
-          // ptrCache hit: an earlier path went through the same connection
-          int shared = -1;
-          for (int pp = 0; pp < p; ++pp) {
-            if (conn[(u64)b * G + pp] == c) {
-              shared = pp;
-              break;
-            }
-          }
+        const u32 v = assign[(u64)b * G + p] >> 24;
+        const int shared = (int)v - 1;   // ptrCache hit: an earlier path went through the same connection (-1: none)
+        if (v != 0xffu) {
           if (shared >= 0) {
             u32 a = assign[(u64)b * G + shared];
             assign[(u64)b * G + p] = a;
             cur = b * G + a;
           } else {
-            u32 nd = c & 0x03ffffffu;
             i32 id = wid[(u64)b * G + p];
             u32 len = clen ? (u32)clen[(u64)b * G + p] : (g_clen[(u64)b * G + p] >> 16);
             u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
