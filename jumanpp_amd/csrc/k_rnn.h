@@ -310,25 +310,18 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
             u32 len = clen ? (u32)clen[(u64)b * G + p] : (g_clen[(u64)b * G + p] >> 16);
             u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
             u32 cnt = rn_cnt[b];
-            // crdCache_.find(coord): newest published node with the same (boundary, length, id)
+            // crdCache_.find(coord): newest published node with the same (boundary, length, id).  Then nextInBnd is
+            // walked (all older nodes of the boundary) comparing the prefix hash; on a match the connection is
+            // attached to it->second, not to the matching node.  Both searches without early exits: the reads of all
+            // published nodes are then independent of each other (one LDS round trip, not one per node).
             int it = -1;
-            for (int x = (int)cnt - 1; x >= 0; --x) {
-              if (rn_id[(u64)b * G + x] == id && rn_len[(u64)b * G + x] == len) {
-                it = x;
-                break;
-              }
+            u64 hmatch = 0;   // bit x: node x has the prefix hash h
+            for (int x = 0; x < (int)cnt; ++x) {
+              const bool same = rn_id[(u64)b * G + x] == id && rn_len[(u64)b * G + x] == len;
+              it = same ? x : it;
+              hmatch |= (rn_hash[(u64)b * G + x] == h) ? (u64{1} << x) : u64{0};
             }
-            bool merged = false;
-            if (it >= 0) {
-              // walk nextInBnd (all older nodes of the boundary) comparing the prefix hash;
-              // on a match the connection is attached to it->second, not to the matching node
-              for (int x = it; x >= 0; --x) {
-                if (rn_hash[(u64)b * G + x] == h) {
-                  merged = true;
-                  break;
-                }
-              }
-            }
+            const bool merged = it >= 0 && (hmatch & ((u64{2} << it) - 1)) != 0;
             if (merged) {
               assign[(u64)b * G + p] = (u32)it;
               cur = b * G + (u32)it;
