@@ -574,13 +574,38 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     // (Requesting these rows into registers and computing the first-stage hash states of the right nodes while
     // they travel was measured in round 2: 6.92 -> 7.11 ms.  The extra live registers cost more than the
     // overlapped round trip saves at 128 VGPRs.)
-    for (int q = lane; q < U * kPat + ngb * kT2; q += 64) {
-      if (q < U * kPat) {
-        int row = q / kPat, p = q - row * kPat;
-        t1pat[row][p] = pats[(u64)t1node[row] * kPat + p];
-      } else {
-        int r2 = (q - U * kPat) / kT2, p = (q - U * kPat) - r2 * kT2;
-        t2pat[r2][p] = pats[(u64)gb_pnode[r2] * kPat + p];
+    // All row elements of a pass are requested before the first one is stored: written as one loop with a T1 and a
+    // T2 branch this was two divergent halves per iteration, each waiting for its own HBM/L2 round trip (three to
+    // four serial round trips per boundary instead of one).
+    {
+      constexpr int kRowIter = 3;   // elements per lane in flight together (GM = 8: at most 144 elements in all)
+      const int nT1 = U * kPat, total = nT1 + ngb * kT2;
+      for (int q0 = 0; q0 < total; q0 += 64 * kRowIter) {
+        u64 v[kRowIter];
+#pragma unroll
+        for (int z = 0; z < kRowIter; ++z) {
+          // (lanes beyond the last element read element 0 again: a load behind a branch would make the compiler
+          // wait for the previous one before it, see k_rnn_chain)
+          const int q = (q0 + z * 64 + lane) < total ? (q0 + z * 64 + lane) : 0;
+          const bool isT1 = q < nT1;
+          const int qq = isT1 ? q : q - nT1;
+          const int row = isT1 ? qq / kPat : qq / kT2;
+          const int pp = qq - row * (isT1 ? kPat : kT2);
+          const u32 node = isT1 ? t1node[row] : gb_pnode[row];
+          v[z] = pats[(u64)node * kPat + pp];
+        }
+#pragma unroll
+        for (int z = 0; z < kRowIter; ++z) {
+          const int q = q0 + z * 64 + lane;
+          if (q < total) {
+            const bool isT1 = q < nT1;
+            const int qq = isT1 ? q : q - nT1;
+            const int row = isT1 ? qq / kPat : qq / kT2;
+            const int pp = qq - row * (isT1 ? kPat : kT2);
+            if (isT1) t1pat[row][pp] = v[z];
+            else t2pat[row][pp] = v[z];
+          }
+        }
       }
     }
     wave_sync();
