@@ -56,6 +56,19 @@ __device__ __forceinline__ const T JPP_GLOBAL* as_global(const T* p) {
   return (const T JPP_GLOBAL*)p;
 }
 
+// ... and a pointer into LDS typed as such.  Where one branch reads a record from LDS and the other the same field
+// from HBM, the compiler otherwise merges the two loads into one flat_load through a selected pointer: an LDS read
+// through the vector-memory path, with the vmcnt(0) waits that come with it.
+#if defined(JPP_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#define JPP_LDS
+#else
+#define JPP_LDS __attribute__((address_space(3)))
+#endif
+template <typename T>
+__device__ __forceinline__ const T JPP_LDS* as_lds(const T* p) {
+  return (const T JPP_LDS*)p;
+}
+
 // ---- wavefront (64 lanes) helpers -------------------------------------------
 __device__ __forceinline__ int lane_id() {
 #if defined(JPP_EMU)

@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       u32 pnode;
       if (fastCand) {
         lnode = enL[l];
-        pnode = cand[l * (u32)beam + k].prev_node;
+        pnode = as_lds(cand)[l * (u32)beam + k].prev_node;   // (a plain ds_read: see as_lds)
       } else {
         lnode = en[efirst + l];
         pnode = beams[(u64)lnode * beam + k].prev_node;
