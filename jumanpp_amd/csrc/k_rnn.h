@@ -1,19 +1,21 @@
-// Kernels 6a/6b: RNNLM re-ranking of the paths that survive at EOS (Mikolov
-// faster-rnnlm NCE model), then adjustBeamScores + remakeEosBeam.
+// Kernels 6: RNNLM re-ranking of the paths that survive at EOS (Mikolov faster-rnnlm NCE model), then
+// adjustBeamScores + remakeEosBeam.  Launch order for E <= 128 (jppgpu_api.cc):
 //
-// k_rnn_prep (one wavefront per sentence): walks the <= G EOS paths back through the
-// beam pointers, resolves the RNN vocabulary id of every node on them and replays
-// RnnIdContainer::addPath/addPrevChain exactly (including its attach-to-it->second
-// quirk) to obtain the RNN lattice: which rnn node scores which connection, and each
-// rnn node's predecessor.  The replay is a skewed pipeline: lane p handles path p and
-// reaches boundary b at step b + p, i.e. after every earlier path has finished that
-// boundary, which is the only ordering the sequential algorithm depends on.
-//
-// k_rnn_score (one wavefront per sentence, 16 sentences per workgroup sharing the
-// zero-padded transposed recurrent matrix in LDS): boundary by boundary, up to 4 rnn
-// nodes at a time.  The hidden vector is spread over the lanes (J = EP/64 outputs per
-// lane, EP = E rounded up to 64/128/256) and stays in registers; the matvec broadcasts
-// context element k with v_readlane and reads row k of W^T as one J-wide LDS read.
+//   k_rnn_paths    one thread per (sentence, EOS path): walks the beam pointers back from EOS -- the lattice
+//                  connection of every surviving path at every boundary, its global-beam index, its node's length.
+//   k_rnn_prep     one wavefront per sentence: resolves the RNN vocabulary id of every node on the paths and replays
+//                  RnnIdContainer::addPath / addPrevChain exactly (including its attach-to-it->second quirk) to
+//                  obtain the RNN lattice: which rnn node scores which connection, and each rnn node's predecessor.
+//                  The replay is a skewed pipeline: lane p handles path p and reaches boundary b at step b + p, i.e.
+//                  after every earlier path has finished that boundary, which is the only ordering the sequential
+//                  algorithm depends on.
+//   k_rnn_order_*  counting sort of the sentences by the length of their recurrence.
+//   k_rnn_chain    the recurrence (hidden states of all rnn nodes before EOS) on the matrix cores, 32 sentences per
+//                  workgroup in lock step.
+//   k_rnn_score<J, SORT, 2>   maxent sums, NCE scores, score cells, adjustBeamScores, remakeEosBeam.
+//   k_rnn_score<J, SORT, 3>   everything, boundary by boundary, for sentences beyond the LDS staging limits.
+// E > 128 (up to 256): k_rnn_paths, k_rnn_prep, k_rnn_score<4, SORT, 0> (everything in one launch, W from L2).
+// The hidden vector of a node is spread over the lanes of its wavefront (EP = E rounded up to 64 / 128 / 256).
 //
 // Reference behaviour reproduced:
 //   RnnIdResolver::resolveIdsAtGbeam / RnnIdContainer::resolveId / reprOf
@@ -25,8 +27,9 @@
 //   MikolovRnnImplParallel          src/rnn/mikolov_rnn_impl.h:196-256
 //   MikolovIndexCalculator / ScoreCalculator  mikolov_rnn_impl.h:21-131, PRIMES mikolov_rnn.h:18-25
 //   ScoreProcessor::adjustBeamScores / remakeEosBeam  score_processor.cc:521-576
-// Float tolerance: exp() and the lane-tree dot product differ from the CPU in
-// the last ulps (as Eigen itself would from a scalar loop): 1e-4, see DESIGN.md.
+// Float rules: bit-exact to the oracle build of the reference (FMA target, Eigen stand-in of oracle/shim): k-ascending
+// fused chains for the matrix-vector product (vector ALU or v_mfma_f32_16x16x4_f32), sequential rounded-product NCE dot,
+// glibc's expf restated in f64 (expf_libm), fused multiply-adds where GCC contracts them; see DESIGN.md section 3.
 #ifndef JPP_K_RNN_H
 #define JPP_K_RNN_H
 
