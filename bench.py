@@ -2,13 +2,15 @@
 """bench.py -- sentences/sec of the Juman++ analysis hot path on MI355X.
 
 One "step" = one pass of the whole hot path (decode -> seeds -> lattice -> T0
--> global-beam sweep -> top-1 path) over one batch of 65,536 synthetic
-40-codepoint sentences that is already resident in HBM.  Workload =
-BASELINE.json configs[1]: perceptron scorer only, beam 5 (global beam 6,
-right-check 1, right-beam 5 = the CLI defaults), 1M sentences batched 64k.
+-> global-beam sweep -> RNNLM re-ranking -> top-1 path -> packed result) over
+one batch of 65,536 synthetic 40-codepoint sentences that is already resident
+in HBM.  Workload = BASELINE.json configs[2]: perceptron + RNNLM scorer, beam 5
+(global beam 6, right-check 1, right-beam 5 = the CLI defaults), 1M sentences
+batched 64k (`--no-rnn`: configs[1], perceptron only; also reported beside the
+headline as `perceptron_only`).
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the
-definition of the roofline and cpu_baseline objects.
+definition of the roofline, cpu_baseline and parity_sample objects.
 """
 import argparse
 import hashlib
@@ -178,6 +180,91 @@ def _ref_time(ref_dir, model, corpus):
     with open(corpus, 'rb') as f:
         out = subprocess.check_output([os.path.join(ref_dir, 'ref_dump'), 'time', model], stdin=f)
     return json.loads(out.decode())
+
+
+def reference_top1(ref_dir, model, text, offs, np, tmp_dir, procs=None):
+    """CHECKER: the reference's packed top-1 result (oracle/ref_dump.cc `top1`: Analyzer::analyze per sentence, then
+    {EntryPtr, start, end} of the best path in text order) for the sentences text[offs[i]:offs[i+1]], computed by one
+    reference process per usable core.  Returns (status[n], offsets[n+1], items[m] as (eptr i32, start u16, end u16))."""
+    n = len(offs) - 1
+    procs = max(1, min(procs or usable_cores(), (n + 255) // 256))
+    per = (n + procs - 1) // procs
+    os.makedirs(tmp_dir, exist_ok=True)
+    running = []
+    for k in range(procs):
+        lo, hi = k * per, min(n, (k + 1) * per)
+        if lo >= hi:
+            break
+        part = os.path.join(tmp_dir, 'top1_part%d.txt' % k)
+        with open(part, 'wb') as f:
+            for i in range(lo, hi):
+                f.write(text[offs[i]:offs[i + 1]])
+                f.write(b'\n')
+        out = part + '.bin'
+        fin = open(part, 'rb')
+        running.append((subprocess.Popen([os.path.join(ref_dir, 'ref_dump'), 'top1', model, out], stdin=fin,
+                                         stderr=subprocess.DEVNULL), fin, part, out, hi - lo))
+    item_dt = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
+    status, counts, items = [], [], []
+    for pr, fin, part, out, cnt in running:
+        rc = pr.wait()
+        fin.close()
+        if rc != 0:
+            raise RuntimeError('ref_dump top1 failed (rc %d)' % rc)
+        raw = open(out, 'rb').read()
+        os.remove(part)
+        os.remove(out)
+        magic, m = np.frombuffer(raw, dtype='<u4', count=2)
+        assert magic == 0x31504f54 and m == cnt, (hex(int(magic)), m, cnt)
+        pos = 8
+        for _ in range(cnt):
+            st, c = np.frombuffer(raw, dtype='<u4', count=2, offset=pos)
+            pos += 8
+            status.append(int(st))
+            counts.append(int(c))
+            items.append(np.frombuffer(raw, dtype=item_dt, count=int(c), offset=pos))
+            pos += 8 * int(c)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(counts)
+    return np.array(status, dtype=np.int32), offsets, (np.concatenate(items) if items else np.zeros(0, dtype=item_dt))
+
+
+def compare_packed(dev_offs, dev_items, ref_status, ref_offs, ref_items, np):
+    """sentences whose packed top-1 result (EntryPtr raw value incl. the UNK numbering, start, end of every morpheme)
+    differs from the reference's; dev_items is the (m, 2) int32 array of jppgpu_result_pack"""
+    item_dt = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
+    di = np.ascontiguousarray(dev_items).view(item_dt).reshape(-1)
+    do = dev_offs.astype(np.int64)
+    n = len(ref_offs) - 1
+    bad = []
+    same_len = (do[1:n + 1] - do[:n]) == (ref_offs[1:] - ref_offs[:-1])
+    for s in range(n):
+        if ref_status[s] != 0:
+            if do[s + 1] != do[s]:
+                bad.append(s)
+            continue
+        if not same_len[s] or not np.array_equal(di[do[s]:do[s + 1]], ref_items[ref_offs[s]:ref_offs[s + 1]]):
+            bad.append(s)
+    return bad
+
+
+def parity_sample(ref_dir, model, batches, run_packed, np, tmp_dir, n_batches=2):
+    """CHECKER (untimed): the first `n_batches` timed batches once more through the bench path (analyze_device +
+    jppgpu_result_pack), every sentence's packed top-1 result against the reference run on this box's cores."""
+    t = time.time()
+    total, mism, first = 0, 0, []
+    for i in range(min(n_batches, len(batches))):
+        text, offs = batches[i]
+        d_offs, d_items = run_packed(i)
+        rs, ro, ri = reference_top1(ref_dir, model, text, offs, np, tmp_dir)
+        bad = compare_packed(d_offs, d_items, rs, ro, ri, np)
+        total += len(offs) - 1
+        mism += len(bad)
+        first += [(i, int(b)) for b in bad[:4]]
+    return {'sentences': total, 'mismatches': mism, 'first_mismatches': first[:8],
+            'what': 'packed top-1 result (EntryPtr incl. UNK numbering, start, end per morpheme) of the first %d timed '
+                    'batches, bench path (analyze_device + jppgpu_result_pack), vs the reference Analyzer::analyze '
+                    '(oracle/_ref ref_dump top1, %d processes); %.1f s' % (min(n_batches, len(batches)), usable_cores(), time.time() - t)}
 
 
 def cpu_baseline(args, model, mdic, cache_dir):
@@ -400,6 +487,9 @@ def main():
     ap.add_argument('--seed', type=int, default=20260925)
     ap.add_argument('--cpu-sample', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip parity_sample (the reference run on the host cores)')
+    ap.add_argument('--parity-batches', type=int, default=2,
+                    help='timed batches checked sentence by sentence against the reference (parity_sample)')
     ap.add_argument('--no-overlap', action='store_true', help='skip the extra two-batches-in-flight measurement')
     ap.add_argument('--no-config5', action='store_true',
                     help="skip the BASELINE configs[4] leg (beam 32, 220-codepoint sentences, one GPU's share)")
@@ -500,6 +590,25 @@ def main():
         ab = algorithmic_bytes(r, 5, 6, 1, 5, np)
         bad = int((r.status != 0).sum())
         r.release()
+        # self-certification of the line (untimed; the reference is the checker, never the thing measured)
+        parity = None
+        if not args.no_cpu_baseline and not args.no_parity and world == 1:
+            try:
+                def run_packed(i):
+                    rr = step(i)
+                    rr.pack(d_offs.data_ptr(), d_items.data_ptr(), cap_items)
+                    torch.cuda.synchronize()
+                    ho = d_offs.cpu().numpy().view(np.uint32)
+                    hi = d_items[:int(ho[-1])].cpu().numpy()
+                    rr.release()
+                    return ho, hi
+                # (the timed loop starts at batch index `warmup`)
+                order = [(args.warmup + j) % len(batches) for j in range(len(batches))]
+                parity = parity_sample(reference_build()[0], model, [batches[j] for j in order],
+                                       lambda i: run_packed(order[i]), np, os.path.join(cache, 'parity_tmp'),
+                                       n_batches=args.parity_batches)
+            except Exception as e:  # the checker must never take the main line down -- but it must say so
+                parity = {'error': str(e)[:300]}
         avg = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'  # k_rnn has its own line in kernel_ms_per_step
         achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
@@ -624,6 +733,8 @@ def main():
                 'avg_launch_ms': round(avg[dom], 3),
             },
         }
+        if parity is not None:
+            out['parity_sample'] = parity
         if perceptron_only is not None:
             out['perceptron_only'] = perceptron_only
         if overlapped is not None:

@@ -39,9 +39,9 @@ int fail(int code, const std::string& msg) {
 // GPUs (jumanpp_gpu --devices=...) and drive them from several threads, so every entry point that touches
 // the device first binds the thread to its context's GPU.
 #if defined(JPP_EMU)
-inline void bind_device(int) {}
+inline bool bind_device(int) { return true; }
 #else
-inline void bind_device(int device) { (void)hipSetDevice(device); }
+inline bool bind_device(int device) { return hipSetDevice(device) == hipSuccess; }
 #endif
 
 // ---- thin device-memory layer ------------------------------------------------
@@ -284,9 +284,9 @@ struct jppgpu_ctx {
   int device = 0;
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
+  UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
   DevBuf trie, eptrs, edata, weights;
   DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_cpbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
-  void* rnn_ord_zeroed = nullptr;   // the rnn_ord allocation whose histogram has been zeroed
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
@@ -440,6 +440,15 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     H.makers[idx++] = norm[0];
   }
   for (int q = 0; q < idx; ++q) H.maker_of_spec[H.makers[q].spec_index] = q;
+  {
+    // the reference makes its UNK nodes maker by maker: stage 1 in spec order (the normalize maker is its last
+    // member, checked above), then stage 2 (analyzer_impl.cc:100-126, unk_nodes.cc:40-52)
+    u32 r = 0;
+    for (auto& k : st1) ctx->unk_rank.rank[k.spec_index] = (u8)r++;
+    for (auto& k : norm) ctx->unk_rank.rank[k.spec_index] = (u8)r++;
+    for (auto& k : st2) ctx->unk_rank.rank[k.spec_index] = (u8)r++;
+    ctx->unk_rank.n = r;
+  }
   H.has_rnn = 0;
   if (c->use_rnn) {
     // AnalyzerImpl::initScorers: scorer count must match the weights; RNN needs the global beam
@@ -539,7 +548,7 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
 
 extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   if (!ctx) return;
-  bind_device(ctx->device);
+  (void)bind_device(ctx->device);
   DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
                     &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
                     &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_norm,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
@@ -564,7 +573,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
 extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                            uint32_t total_bytes, void* stream_, jppgpu_result** out) {
   if (!ctx || !out || (!d_utf8 && total_bytes) || !d_offsets) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   jpp_stream_t st = static_cast<jpp_stream_t>(stream_);
   *out = nullptr;
   const size_t cpN = (size_t)total_bytes + n + 8;
@@ -711,7 +720,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.node_kept = ctx->node_kept.as<u8>();
   B.path_nodes = ctx->path_nodes.as<u32>();
   T.mark(2, st);
-  JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg);
+  JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg, ctx->unk_rank);
   T.mark(3, st);
   if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
@@ -819,10 +828,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     if (ctx->hmodel.rnn_EP <= 128) {
       // lock-step workgroups take sentences of equal chain length
       B.rnn_order = B.rnn_key + n;
-      if (ctx->rnn_ord_zeroed != ctx->rnn_ord.p) {   // a fresh allocation: the histogram starts at zero, k_rnn_order_scan keeps it there
-        JPP_LAUNCH(k_rnn_order_zero, 1, kRnnOrderBins, st, B.rnn_hist);
-        ctx->rnn_ord_zeroed = ctx->rnn_ord.p;
-      }
+      // zeroed every batch (2 us): inferring "already zero" from the buffer address is wrong when a grown
+      // buffer comes back at the same address
+      JPP_LAUNCH(k_rnn_order_zero, 1, kRnnOrderBins, st, B.rnn_hist);
       JPP_LAUNCH(k_rnn_order_key, (n + 255) / 256, 256, st, B, ctx->cfg);
       JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
@@ -861,7 +869,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
 extern "C" int jppgpu_analyze_batch(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
                                     jppgpu_result** out) {
   if (!ctx || !offsets || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   u32 total = offsets[n];
   if (!(ctx->text.ensure((size_t)total + 64) && ctx->offs.ensure(((size_t)n + 1) * 4)))
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (input)");
@@ -886,7 +894,7 @@ extern "C" int jppgpu_analyze_batch_partial(jppgpu_ctx* ctx, const char* utf8, c
   if (!ctx || !offsets || !out || !p) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   if (!p->nobreak_offsets || !p->boundary_offsets || !p->node_offsets)
     return fail(JPPGPU_INVALID_PARAMETER, "partial annotation offsets are null");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   static_assert(sizeof(jppgpu_node_constraint) == sizeof(PcNode) && sizeof(jppgpu_tag_constraint) == sizeof(PcTag),
                 "ABI and device constraint records must match");
   const size_t nNb = p->nobreak_offsets[n], nB = p->boundary_offsets[n], nNodes = p->node_offsets[n];
@@ -933,7 +941,7 @@ extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
 
 extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
   if (!ctx || !ms) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   if (ctx->timing_pending) {
     rt_sync(ctx->last_stream);
     ctx->timer.collect(ctx->last_ms);
@@ -960,7 +968,7 @@ void pull(std::vector<T>& v, const void* d, size_t count, jpp_stream_t st) {
 extern "C" int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path) {
   if (!res || !res->ctx) return fail(JPPGPU_INVALID_PARAMETER, "null result");
   if (res->generation != res->ctx->generation) return fail(JPPGPU_INVALID_STATE, "result was invalidated");
-  bind_device(res->ctx->device);
+  if (!bind_device(res->ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   jpp_stream_t st = res->ctx->last_stream;
   std::vector<u32> pl;
   pull(pl, res->B.path_len, res->B.n_sent, st);
@@ -976,7 +984,7 @@ extern "C" int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_i
   if (!res || !res->ctx || !d_offsets || (!d_items && cap_items)) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   jppgpu_ctx* ctx = res->ctx;
   if (res->generation != ctx->generation) return fail(JPPGPU_INVALID_STATE, "result was invalidated");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
   if (!(ctx->pack_cnt.ensure(((size_t)n + 1) * 4) && ctx->pack_off.ensure(((size_t)n + 2) * 8)))
@@ -995,7 +1003,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   jppgpu_ctx* ctx = res->ctx;
   if (res->generation != ctx->generation)
     return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   jpp_stream_t st = ctx->last_stream;
   const Batch& B = res->B;
   const u32 n = B.n_sent;
@@ -1131,7 +1139,7 @@ extern "C" int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jpp
   if (n_best <= 0 || n_best > 64) return fail(JPPGPU_INVALID_PARAMETER, "n_best must be in 1..64");
   static_assert(sizeof(jppgpu_nbest_item) == sizeof(NbestItem), "nbest item layout");
   jppgpu_ctx* ctx = res->ctx;
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
   if (res->nb_n != n_best) {
@@ -1187,7 +1195,7 @@ extern "C" int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jpp
 extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_ngrams_view* v) {
   if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   jppgpu_ctx* ctx = res->ctx;
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
   if (!res->ng_have) {
@@ -1221,7 +1229,7 @@ extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_n
 extern "C" int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uint64_t n) {
   if (!ctx || !weights) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   if (n != (uint64_t)ctx->hmodel.wmask + 1) return fail(JPPGPU_INVALID_PARAMETER, "weight count does not match the model's table");
-  bind_device(ctx->device);
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   // (ordered behind every batch already enqueued on the context's streams)
   if (ctx->last_stream) rt_sync(ctx->last_stream);
   rt_sync(ctx->own_stream);

@@ -234,7 +234,19 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_connect(Batch B) {
 // LatticeBuilder::fillEnds).  Sentences with more than kEndsNodeCap nodes run sequentially on lane 0.
 constexpr u32 kEndsNodeCap = 2048;
 
-__global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg) {
+// UNK entry pointers are numbered in CREATION order, like the reference's: ExtraNodesContext::allocateExtra
+// gives every extra node the next index (extra_nodes.cc:41-52), and the nodes are made maker by maker
+// (AnalyzerImpl::makeUnkNodes1/2, analyzer_impl.cc:100-126: stage 1 in spec order, then stage 2), each maker
+// walking the start positions in order, one extra node per seed.  Node order here is (start, seed order)
+// (the stable sort of LatticeBuilder::sortSeeds), so the creation index of an UNK node is
+//   #(UNK nodes of makers created earlier) + #(UNK nodes of its own maker before it in node order).
+// rank[spec index] = position of the maker in that creation sequence.
+struct UnkRank {
+  u8 rank[kMaxUnkMakers];
+  u32 n;
+};
+
+__global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, UnkRank rk) {
   const int lane = (int)(threadIdx.x & 63);
   const int wv = (int)(threadIdx.x >> 6);
   const u32 s = blockIdx.x * kLatWaves + wv;
@@ -259,19 +271,53 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg) {
     na[0] = na[1] = na[N - 1] = NodeAux{0, 0, 0, 0, 0, 0};
   }
   if (N <= kEndsNodeCap) {
-    // UNK entry pointers ~0, ~1, ... in node order; stage the ends
-    u32 unkBase = 0;
+    // UNK entry pointers ~0, ~1, ... in creation order (UnkRank); stage the ends.
+    // First the number of UNK nodes per maker (wave-uniform counters), ...
+    u32 ubase[kMaxUnkMakers];
+#pragma unroll
+    for (int c = 0; c < kMaxUnkMakers; ++c) ubase[c] = 0;
+    for (u32 k0 = 2; k0 + 1 < N; k0 += 64) {
+      const u32 k = k0 + (u32)lane;
+      const bool act = k + 1 < N;
+      const bool isUnk = act && ni[k].eptr < 0;
+      const u32 cls = isUnk ? (u32)rk.rank[na[k].maker & (kMaxUnkMakers - 1)] : 0xffu;
+      if (wave_ballot(isUnk) == 0) continue;
+#pragma unroll
+      for (int c = 0; c < kMaxUnkMakers; ++c)
+        if ((u32)c < rk.n) ubase[c] += (u32)popc64(wave_ballot(cls == (u32)c));
+    }
+    // ... their exclusive prefix = first index of every maker, ...
+    {
+      u32 acc = 0;
+#pragma unroll
+      for (int c = 0; c < kMaxUnkMakers; ++c) {
+        const u32 v = ubase[c];
+        ubase[c] = acc;
+        acc += v;
+      }
+    }
+    // ... then every UNK node takes the next index of its maker in node order
     for (u32 k0 = 2; k0 + 1 < N; k0 += 64) {
       const u32 k = k0 + (u32)lane;
       const bool act = k + 1 < N;
       NodeInfo x = act ? ni[k] : NodeInfo{0, 0, 0};
       const bool isUnk = act && x.eptr < 0;
-      const u64 bal = wave_ballot(isUnk);
-      if (isUnk) {
-        x.eptr = ~(i32)(unkBase + (u32)popc64(bal & ((u64{1} << lane) - 1)));
-        ni[k] = x;
+      if (wave_ballot(isUnk) != 0) {
+        const u32 cls = isUnk ? (u32)rk.rank[na[k].maker & (kMaxUnkMakers - 1)] : 0xffu;
+        u32 mine = 0;
+#pragma unroll
+        for (int c = 0; c < kMaxUnkMakers; ++c) {
+          if ((u32)c < rk.n) {
+            const u64 bal = wave_ballot(cls == (u32)c);
+            if (cls == (u32)c) mine = ubase[c] + (u32)popc64(bal & ((u64{1} << lane) - 1));
+            ubase[c] += (u32)popc64(bal);
+          }
+        }
+        if (isUnk) {
+          x.eptr = ~(i32)mine;
+          ni[k] = x;
+        }
       }
-      unkBase += (u32)popc64(bal);
       if (act) l_end[k] = x.end;
     }
     wave_sync();
@@ -306,12 +352,19 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg) {
     for (u32 b = 0; b <= n + 2; ++b) ecnt[b] = 0;
     ecnt[1] = 1;
     ecnt[2] = 1;
-    i32 unk = 0;
+    u32 ubase[kMaxUnkMakers];
+    for (int c = 0; c < kMaxUnkMakers; ++c) ubase[c] = 0;
+    for (u32 k = 2; k + 1 < N; ++k)
+      if (ni[k].eptr < 0) ubase[rk.rank[na[k].maker & (kMaxUnkMakers - 1)] & (kMaxUnkMakers - 1)] += 1;
+    for (u32 c = 0, acc = 0; c < (u32)kMaxUnkMakers; ++c) {
+      const u32 v = ubase[c];
+      ubase[c] = acc;
+      acc += v;
+    }
     for (u32 k = 2; k + 1 < N; ++k) {
       NodeInfo x = ni[k];
       if (x.eptr < 0) {
-        x.eptr = ~unk;
-        ++unk;
+        x.eptr = ~(i32)(ubase[rk.rank[na[k].maker & (kMaxUnkMakers - 1)] & (kMaxUnkMakers - 1)]++);
         ni[k] = x;
       }
       ecnt[x.end + 2] += 1;

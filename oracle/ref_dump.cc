@@ -27,6 +27,11 @@
 //   ref_dump ngrams  <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the trainer's read-out: NgramFeaturesComputer::calculateNgramFeatures for every connection of the top-1
 //       path on an analyzer that stores all patterns (what jppgpu_result_fetch_top1_ngrams must reproduce)
+//   ref_dump top1    <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
+//       the packed top-1 result of Analyzer::analyze per sentence: u32 status (0 ok / 1 failed), u32 count, then count
+//       records {i32 EntryPtr raw, u16 start, u16 end} in text order (EOS dropped) -- the layout of jppgpu_result_pack.
+//       UNK nodes carry the reference's own EntryPtr (creation-order numbering, extra_nodes.cc:41-52).  Checker of
+//       the at-scale parity tests and of bench.py's parity_sample.
 //   ref_dump time    <model.jppmdl> [beam gbeam rcheck rbeam] < corpus
 //       wall-clock of Analyzer::analyze (+JumanFormat) over the corpus, phases split
 //       as BASELINE.md section 3.
@@ -679,6 +684,48 @@ int doDump(const char* modelFile, const char* out, char** extra, int nextra) {
 }
 
 // ------------------------------------------------------------------ time ---
+int doTop1(const char* modelFile, const char* out, char** extra, int nextra) {
+  Env e;
+  e.init(modelFile, extra, nextra);
+  Analyzer an;
+  CHECK_OK(e.env.makeAnalyzer(&an));
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(std::cin, line)) lines.push_back(line);
+  Writer w;
+  w.put<u32>(0x31504f54u);  // "TOP1"
+  w.put<u32>((u32)lines.size());
+  std::vector<const ConnectionPtr*> path;
+  for (auto& l : lines) {
+    Status st = an.analyze(l);
+    if (!st) {
+      w.put<u32>(1);
+      w.put<u32>(0);
+      continue;
+    }
+    auto* lat = an.impl()->lattice();
+    const int last = (int)lat->createdBoundaryCount() - 1;
+    path.clear();
+    const ConnectionBeamElement& top = lat->boundary(last)->starts()->beamData().row(0).at(0);
+    // the EOS connection itself is dropped; an empty input has no path (analyzer_impl.cc:255-258)
+    const ConnectionPtr* p = (last <= 2 || EntryBeam::isFake(top)) ? nullptr : top.ptr.previous;
+    while (p != nullptr && p->boundary >= 2) {
+      path.push_back(p);
+      p = p->previous;
+    }
+    w.put<u32>(0);
+    w.put<u32>((u32)path.size());
+    for (size_t k = path.size(); k-- > 0;) {
+      auto& ni = lat->boundary(path[k]->boundary)->starts()->nodeInfo().at(path[k]->right);
+      w.put<i32>(ni.entryPtr().rawValue());
+      w.put<u16>(ni.start());
+      w.put<u16>(ni.end());
+    }
+  }
+  w.save(out);
+  return 0;
+}
+
 int doTime(const char* modelFile, char** extra, int nextra) {
   Env e;
   e.init(modelFile, extra, nextra);
@@ -1100,7 +1147,7 @@ int doNgrams(const char* modelFile, const char* out, char** extra, int nextra) {
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::cerr << "usage: ref_dump export|mkmodel|dump|time|shim|ngrams ...\n";
+    std::cerr << "usage: ref_dump export|mkmodel|dump|time|shim|ngrams|top1 ...\n";
     return 2;
   }
   std::string cmd = argv[1];
@@ -1112,6 +1159,7 @@ int main(int argc, char** argv) {
   if (cmd == "time" && argc >= 3) return doTime(argv[2], argv + 3, argc - 3);
   if (cmd == "shim" && argc >= 5) return doShim(argv[2], argv[3], atoi(argv[4]), argv + 5, argc - 5);
   if (cmd == "ngrams" && argc >= 4) return doNgrams(argv[2], argv[3], argv + 4, argc - 4);
+  if (cmd == "top1" && argc >= 4) return doTop1(argv[2], argv[3], argv + 4, argc - 4);
   std::cerr << "bad arguments\n";
   return 2;
 }

@@ -160,8 +160,9 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True, 
                     bad('b%d n%d: eptr %d vs %d' % (b, r, nd['eptr'], ge))
             else:
                 u = res.unk[k]
-                if int(nd['eptr']) >= 0:
-                    bad('b%d n%d: dictionary node where reference has UNK' % (b, r))
+                # UNK entry pointers are numbered in creation order like the reference's (extra_nodes.cc:41-52)
+                if int(nd['eptr']) != ge:
+                    bad('b%d n%d: UNK eptr %d vs %d' % (b, r, nd['eptr'], ge))
                 if (int(u['tmpl']), int(u['hash']), int(u['ph0']), int(u['ph1'])) != tuple(int(x) for x in gn['unk']):
                     bad('b%d n%d: unk (%d,%d,%d,%d) vs %s' % (b, r, u['tmpl'], u['hash'], u['ph0'], u['ph1'], gn['unk']))
             if not scored:

@@ -385,3 +385,50 @@ def test_gpu_rnn_tiny_and_degenerate_batches(gpu_lib, golden_dir):
             assert path_of(r, j) == path_of(ref, i), (pick, j)
     r = ctx.analyze([b'', b'\xff\xfe', b'', b'\xe3\x81']).fetch(full=True)
     assert list(r.status) == [0, 2, 0, 2] and int(r.path_len.sum()) == 0
+
+
+@pytest.mark.parametrize('rnn', [True, False])
+def test_gpu_headline_shape_through_the_bench_path_vs_live_reference(gpu_lib, ref_tools, rnn):
+    """The exact headline shape: 2 x 65 536 sentences of bench.py's own model (300 k dictionary entries, 2^22
+    weights, E = 128 RNN) and corpus generator through the path bench.py times -- jppgpu_analyze_batch_device on
+    device-resident input + jppgpu_result_pack -- and the packed (EntryPtr, start, end) of every morpheme of all
+    131 072 sentences equal to the reference Analyzer::analyze (oracle/_ref `ref_dump top1`, one process per core).
+    65 536-sentence batches are what sizes the workspaces from batch totals and what k_rnn_order_* / k_rnn_chain
+    group by chain length across; smaller batches exercise that code differently."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import argparse
+    import torch
+    import bench
+    args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, rnn=True, rnn_hidden=128,
+                              rnn_vocab=30000, sent_len=40)
+    cache = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'jppgpu_bench_cache')
+    mdic, model, img = bench.make_workload(args, cache)
+    batch = 65536
+    corpus = bench.make_corpus(args, mdic, cache, 2 * batch, args.seed + 1)
+    batches = bench.load_batches(corpus, batch, np)
+    assert len(batches) == 2
+    ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, use_rnn=None if rnn else False, lib_path=gpu_lib)
+    dev = torch.device('cuda', 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    cap = batch * 41
+    d_offs = torch.zeros(batch + 1, dtype=torch.int32, device=dev)
+    d_items = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+    ref_dir, _ = bench.reference_build()
+    ref_model = model if rnn else model + '.perceptron'
+    total_bad = []
+    for bi, (text, offs) in enumerate(batches):
+        t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+        o = torch.from_numpy(offs.astype(np.int32)).to(dev)
+        r = ctx.analyze_device(t.data_ptr(), o.data_ptr(), batch, len(text), stream)
+        r.pack(d_offs.data_ptr(), d_items.data_ptr(), cap)
+        torch.cuda.synchronize()
+        ho = d_offs.cpu().numpy().view(np.uint32)
+        hi = d_items[:int(ho[-1])].cpu().numpy()
+        r.release()
+        rs, ro, ri = bench.reference_top1(ref_dir, ref_model, text, offs, np, os.path.join(cache, 'parity_tmp'))
+        assert int((rs != 0).sum()) == 0 and len(ro) == batch + 1
+        assert int(ro[-1]) > 20 * batch   # ~24 morphemes per sentence: the reference really analysed them
+        bad = bench.compare_packed(ho, hi, rs, ro, ri, np)
+        total_bad += [(bi, s) for s in bad]
+    assert not total_bad, (len(total_bad), total_bad[:8])

@@ -253,38 +253,35 @@ def _ref_cli(ref_tools, model, args, path):
                           capture_output=True).stdout
 
 
-def _lattice_lines_equal_up_to_float_noise(ours, ref, gold, beam_n):
-    """RNN runs: the structure must be identical; printed scores may differ in the last printed digit
-    (1e-4 contract), and a sentence whose N best reference totals contain a near tie may rank differently."""
-    import re
-    bo, br = _sentences(ours), _sentences(ref)
-    assert len(bo) == len(br)
-    num = re.compile('(スコア:|rank\\d+:)(-?[0-9.e+-]+)'.encode('utf-8'))
-    skipped = 0
-    rank = re.compile(rb'rank\d+:(-?[0-9.e+-]+)')
-    for s, (a, b) in enumerate(zip(bo, br)):
-        if a == b:
+def _lattice_blocks_equal_except_reference_unstable(ours, ref_runs):
+    """The criterion of _shim_check for the CLI: every sentence block must be the reference's bytes, except blocks on
+    which runs of the reference itself disagree -- LatticeFormat picks the connection whose scores a line prints with
+    std::max_element over a FlatSet hashed by the HOST ADDRESS of ptr.previous (lattice_config.h:109-124), so among
+    exactly tied connections the printed one changes from run to run.  Such a block must equal one of the reference
+    runs, or agree with them in everything but the last (scores / rank) column of its lines."""
+    bo = ours.split(b'EOS\n')
+    brs = [r.split(b'EOS\n') for r in ref_runs]
+    assert all(len(b) == len(bo) for b in brs), [len(b) for b in brs] + [len(bo)]
+    unstable, via_other_run, via_structure = 0, 0, 0
+    for i, blk in enumerate(bo):
+        refs = [b[i] for b in brs]
+        if blk == refs[0]:
             continue
-        # the N best totals themselves always agree within the float contract, whatever the order among ties
-        ta, tb = [float(x) for x in rank.findall(a[0])], [float(x) for x in rank.findall(b[0])]
-        assert len(ta) == len(tb), s
-        for x, y in zip(ta, tb):
-            assert abs(x - y) <= 2e-4 * max(1.0, abs(y)), (s, a[0], b[0])
-        g = gold[s]
-        eos = g.bnds[len(g.bnds) - 1]['nodes'][0]['beam']
-        tot = [float(x['total']) for x in eos if x['valid']][:beam_n + 1]
-        near_tie = any(abs(tot[i] - tot[i + 1]) <= 1e-4 * max(1.0, abs(tot[i])) for i in range(len(tot) - 1))
-        if near_tie:
-            skipped += 1
+        is_unstable = any(r != refs[0] for r in refs[1:])
+        if blk in refs:
+            via_other_run += 1
             continue
-        assert len(a) == len(b), s
-        for la, lb in zip(a, b):
-            if la == lb:
-                continue
-            assert num.sub(b'\\1#', la) == num.sub(b'\\1#', lb), (s, la, lb)
-            for (_, x), (_, y) in zip(num.findall(la), num.findall(lb)):
-                assert abs(float(x) - float(y)) <= 2e-4 * max(1.0, abs(float(y))), (s, la, lb)
-    return skipped
+        # not the bytes of any run: only acceptable where the reference is unstable itself, and then only in the
+        # column that depends on the tie-break
+        assert is_unstable, (i, blk[:400], refs[0][:400])
+        unstable += 1
+        la, lb = blk.split(b'\n'), refs[0].split(b'\n')
+        assert len(la) == len(lb), i
+        for x, y in zip(la, lb):
+            if x != y:
+                assert x.split(b'\t')[:-1] == y.split(b'\t')[:-1], (i, x, y)
+                via_structure += 1
+    return unstable, via_other_run, via_structure
 
 
 def test_lattice_format_byte_identical_to_reference_cli(cli_emu, ref_tools, tmp_path):
@@ -324,12 +321,11 @@ def test_lattice_format_with_rnn(cli_emu, ref_tools, tmp_path):
     import test_gpu_parity as tg
     tmp = str(tmp_path)
     img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, 12, 14, 29, length=30, rnn=(32, 600))
-    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['-s', '3'], os.path.join(tmp, 'w.txt'))
+    refs = [_ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['-s', '3'], os.path.join(tmp, 'w.txt')) for _ in range(3)]
     rc, out, err = _run(cli_emu, ['--model=' + img, '-s', '3', os.path.join(tmp, 'w.txt')])
     assert rc == 0, err[-300:]
-    meta, gold = G.read_gold(gold_path)
-    skipped = _lattice_lines_equal_up_to_float_noise(out, ref, gold, 3)
-    assert skipped <= len(lines) // 2
+    unstable, _, _ = _lattice_blocks_equal_except_reference_unstable(out, refs)
+    assert unstable <= len(lines) // 2
 
 
 @pytest.mark.gpu
@@ -348,22 +344,24 @@ def test_gpu_config5_lattice_output_beam32_long_sentences(cli_gpu, ref_tools, tm
 
 
 @pytest.mark.gpu
-def test_gpu_config5_lattice_output_with_rnn(cli_gpu, ref_tools, tmp_path):
-    """BASELINE configs[4]: beam 32, long sentences, RNNLM on, lattice-format output."""
+def test_gpu_config5_lattice_output_with_rnn(cli_gpu, gpu_lib, ref_tools, tmp_path):
+    """BASELINE configs[4]: beam 32, long sentences, RNNLM on, lattice-format output.  The lattice (beams, score cells,
+    RNN-adjusted totals) is bit-exact, so the criterion is identity: (a) the reference's UNMODIFIED LatticeFormat on
+    the Lattice re-materialised from our result view prints the bytes of a plain reference analysis (_shim_check),
+    and (b) our own formatter's output equals jumanpp_v2's except on blocks where runs of jumanpp_v2 disagree."""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     import test_gpu_parity as tg
     tmp = str(tmp_path)
     img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 8000, 40, 18, 137, length=210, rnn=(128, 5000),
                                                beams=[32, 32, 1, 32])
+    r = _shim_check(ref_tools, os.path.join(tmp, 'w.model'), gpu_lib, os.path.join(tmp, 'w.txt'), 8, beams=(32, 32, 1, 32))
+    assert r['analysed'] == len(lines)
     flags = ['--beam=32', '--global-beam=32', '--right-check=1', '--right-beam=32', '-s', '8']
-    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt'))
+    refs = [_ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt')) for _ in range(3)]
     rc, out, err = _run(cli_gpu, ['--model=' + img] + flags + [os.path.join(tmp, 'w.txt')])
     assert rc == 0, err[-300:]
-    meta, gold = G.read_gold(gold_path)
-    # long sentences carry many exactly tied paths (UNK makers that yield identical feature rows), so most
-    # sentences only get the N-best-totals check; the structure check runs on the rest
-    _lattice_lines_equal_up_to_float_noise(out, ref, gold, 8)
+    _lattice_blocks_equal_except_reference_unstable(out, refs)
 
 
 # ---- partial annotation (--partial-input): ScorePlugin hooks, src/core/input/partial_example*.cc ----
