@@ -12,11 +12,15 @@
 typedef void* jpp_stream_t;
 #define JPP_LAUNCH(kernel, grid, block, stream, ...) \
   hip_emu::launch(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+#define JPP_LAUNCH_LDS(kernel, grid, block, lds_bytes, stream, ...) JPP_LAUNCH(kernel, grid, block, stream, __VA_ARGS__)
 #else
 #include <hip/hip_runtime.h>
 typedef hipStream_t jpp_stream_t;
 #define JPP_LAUNCH(kernel, grid, block, stream, ...) \
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+// with `lds_bytes` of dynamic LDS on top of the kernel's own (occupancy experiments: tools/gpu_session_r03a.sh)
+#define JPP_LAUNCH_LDS(kernel, grid, block, lds_bytes, stream, ...) \
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds_bytes, stream, __VA_ARGS__)
 #endif
 
 // developer phase timers: real only in a -DJPP_DEV_PROF build of the HIP library (dev/jpp_dev_prof.h)

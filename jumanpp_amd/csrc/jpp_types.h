@@ -252,7 +252,9 @@ struct Batch {
   // result
   u32* path_len;           // [n]
   u32* path_nodes;         // [gn] top-1 path (local node ids, EOS side first), at node_base[s]
-  u32* gstats;             // [4] batch statistics: [0] max right nodes at one boundary
+  u32* gstats;             // [8] batch statistics: [0] max right nodes at one boundary, [1..3] sentences per sweep class
+  u32* sent_maxr;          // [n] widest boundary (right nodes) of the sentence (k_layout)
+  u32* sweep_list;         // [3][n] sentence indices by sweep class (k_sweep_classify)
   u64 total_nodes;
 };
 

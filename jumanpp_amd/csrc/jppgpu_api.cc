@@ -65,7 +65,7 @@ struct Timer {
   void destroy() {}
   void mark(int, jpp_stream_t) {}
   void collect(float* ms) {
-    for (int i = 0; i < 8; ++i) ms[i] = 0;
+    for (int i = 0; i < 11; ++i) ms[i] = 0;
   }
 };
 #else
@@ -100,7 +100,7 @@ void rt_stream_destroy(jpp_stream_t s) {
 void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
 void rt_host_free(void* p) { free(p); }
 struct Timer {
-  hipEvent_t ev[9];
+  hipEvent_t ev[12];
   bool have = false;
   void init() {
     for (auto& e : ev) (void)hipEventCreate(&e);
@@ -128,6 +128,11 @@ struct Timer {
     }
     ms[7] = 0;
     (void)hipEventElapsedTime(&ms[7], ev[0], ev[7]);
+    // the sweep phase by class: ev[8] .. ev[10], ev[5]
+    for (int i = 0; i < 3; ++i) {
+      ms[8 + i] = 0;
+      (void)hipEventElapsedTime(&ms[8 + i], ev[8 + i], i == 2 ? ev[5] : ev[9 + i]);
+    }
   }
 };
 #endif
@@ -291,7 +296,8 @@ struct jppgpu_ctx {
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
   DevBuf sent_ncp, sent_status, sent_flags, sent_nodes, sent_nodes2, node_base, node_base2;
-  DevBuf path_len, bnd_meta, sweep_scratch;
+  DevBuf path_len, bnd_meta, sweep_scratch, sent_maxr, sweep_list;
+  u32 last_class_n[3] = {0, 0, 0};   // sentences per sweep class of the last batch (jppgpu_last_timings)
   DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
   bool partial_pending = false;  // constraints uploaded for the next analyze call
   jppgpu_score_plugin_fn plugin_fn = nullptr;  // host plugin of the next analyze call (jppgpu_analyze_batch_plugin)
@@ -301,7 +307,7 @@ struct jppgpu_ctx {
       path_nodes;
   u64 generation = 0;
   Timer timer;
-  float last_ms[8] = {0};
+  float last_ms[11] = {0};
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
   std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>();
@@ -560,7 +566,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_cpbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
-                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
+                    &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
@@ -569,6 +575,18 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   ctx->timer.destroy();
   delete ctx;
 }
+
+namespace {
+// widest boundary (right nodes) the sweep variants of class 0 / class 1 take: 64 / kMaxRight staged in LDS, with
+// right-check * R prescores inside 2 * the staging
+void sweep_class_thresholds(const Config& cfg, u32* t0, u32* t1) {
+  const u32 rc = cfg.rcheck > 0 ? (u32)cfg.rcheck : 1u;
+  *t0 = rc <= 2 ? 64u : 0u;
+  u32 w = (2u * (u32)kMaxRight) / rc;
+  *t1 = w < (u32)kMaxRight ? w : (u32)kMaxRight;
+  if (*t1 < *t0) *t1 = *t0;
+}
+}  // namespace
 
 extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                            uint32_t total_bytes, void* stream_, jppgpu_result** out) {
@@ -594,7 +612,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
               ctx->rnn_cpbase.ensure(((size_t)n + 2) * 8)));
-  ok = ok && ctx->gstats.ensure(64);
+  ok = ok && ctx->gstats.ensure(64) && ctx->sent_maxr.ensure(((size_t)n + 1) * 4) && ctx->sweep_list.ensure((3 * (size_t)n + 1) * 4);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
   ctx->generation++;
@@ -637,6 +655,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.bnd_ngb = ctx->bnd_ngb.as<u32>();
   B.bnd_gbeam = ctx->bnd_gbeam.as<GbeamEntry>();
   B.gstats = ctx->gstats.as<u32>();
+  B.sent_maxr = ctx->sent_maxr.as<u32>();
+  B.sweep_list = ctx->sweep_list.as<u32>();
   B.rnn_conn = ctx->rnn_conn.as<u32>();
   B.rnn_id = ctx->rnn_id.as<i32>();
   B.rnn_gi = ctx->rnn_gi.as<u32>();
@@ -693,13 +713,18 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_connect<1>, wblocks, 64 * kLatWaves, st, B);
   // stage 2 for disconnected sentences: relocate them behind the stage-1 region
   JPP_LAUNCH(k_layout<2>, wblocks, 64 * kLatWaves, st, B);
+  {
+    u32 t0c, t1c;
+    sweep_class_thresholds(ctx->cfg, &t0c, &t1c);
+    JPP_LAUNCH(k_sweep_classify, sblocks, 256, st, B, t0c, t1c);
+  }
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
   JPP_LAUNCH(k_relocate, sblocks, 256, st, B);
   JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_connect<2>, wblocks, 64 * kLatWaves, st, B);
   u64 totalNodes = 0;
-  u32 gstats[4] = {0, 0, 0, 0};
+  u32 gstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
   rt_d2h(gstats, B.gstats, sizeof(gstats), st);
   rt_sync(st);
@@ -781,42 +806,53 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     B.node_penalty = ctx->node_penalty.as<float>();
   }
   T.mark(4, st);
-  // the <8, *> variants have no makeT0Beam replay (util::partition / introsort): they take the configurations
-  // whose beams are plain stable ranks, i.e. at most 8 candidates and global beam <= beam*4/3
+  // Every sentence runs the sweep variant of its own widest boundary (k_sweep_classify; the class thresholds are
+  // sweep_class_thresholds()).  The <8, *> variants have no makeT0Beam replay (util::partition / introsort): they
+  // take the configurations whose beams are plain stable ranks, i.e. at most 8 candidates and global beam <= beam*4/3.
   const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
-  // wider than the LDS variants stage (or more prescores than they hold): the per-right-node arrays go to HBM
-  const bool unbounded = maxR > (u32)kMaxRight || (u64)ctx->cfg.rcheck * maxR > 2u * (u64)kMaxRight;
+  const u32 nCls[3] = {gstats[1], gstats[2], gstats[3]};
+  const u32* lists[3] = {B.sweep_list, B.sweep_list + n, B.sweep_list + 2 * (size_t)n};
   B.sweep_scratch = nullptr;
   B.sweep_scratch_stride = 0;
   B.sweep_scratch_maxr = 0;
-  if (ctx->cfg.gbeam != 0 && unbounded) {
+  if (ctx->cfg.gbeam != 0 && nCls[2] != 0) {
+    // class 2: the per-right-node arrays (prescores, their sums, cutoff order) in an HBM slice per workgroup
     const u64 rc = ctx->cfg.rcheck > 0 ? (u64)ctx->cfg.rcheck : 1;
     const u64 stride = (((rc + 1) * maxR * 4 + (u64)maxR * 2) + 63) & ~u64{63};
-    if (!ctx->sweep_scratch.ensure((size_t)(stride * n)))
+    if (!ctx->sweep_scratch.ensure((size_t)(stride * nCls[2])))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (wide-lattice scratch)");
     B.sweep_scratch = ctx->sweep_scratch.as<unsigned char>();
     B.sweep_scratch_stride = stride;
     B.sweep_scratch_maxr = maxR;
   }
+  const DevModel* dmS = (const DevModel*)ctx->dmodel;
   if (ctx->cfg.gbeam == 0) {
-    JPP_LAUNCH(k_sweep_full, n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (unbounded && narrow) {
-    JPP_LAUNCH((k_sweep<8, 0>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (unbounded) {
-    JPP_LAUNCH((k_sweep<32, 0>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (narrow && maxR <= 64 && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5) {
-    // the CLI defaults; weight tables of up to 2^24 entries get the 24-bit index arithmetic
-    if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH((k_sweep<8, 64, true, true>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-    else JPP_LAUNCH((k_sweep<8, 64, true, false>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (narrow && maxR <= 64 && ctx->cfg.rcheck <= 2) {
-    JPP_LAUNCH((k_sweep<8, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (narrow) {
-    JPP_LAUNCH((k_sweep<8, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
-  } else if (maxR <= 64 && ctx->cfg.rcheck <= 2) {   // 6 KB less LDS per wavefront than the 512-wide staging
-    JPP_LAUNCH((k_sweep<32, 64>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    JPP_LAUNCH(k_sweep_full, n, 64, st, B, dmS, ctx->cfg);
+    T.mark(8, st); T.mark(9, st); T.mark(10, st);
   } else {
-    JPP_LAUNCH((k_sweep<32, kMaxRight>), n, 64, st, B, (const DevModel*)ctx->dmodel, ctx->cfg);
+    const bool def = narrow && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5;
+    // (developer knob: JPPGPU_DEV_SWEEP_LDS_PAD=bytes of dynamic LDS added to the launch, i.e. fewer wavefronts per
+    // CU -- the occupancy curve of profiles/r03_a_occupancy.txt)
+    static const unsigned devPad = std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD") ? (unsigned)std::atoi(std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD")) : 0u;
+    T.mark(8, st);
+    if (nCls[0]) {   // at most 64 right nodes per boundary, right-check <= 2
+      if (def && ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def) JPP_LAUNCH((k_sweep<8, 64, true, false>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
+      else if (narrow) JPP_LAUNCH((k_sweep<8, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
+      else JPP_LAUNCH((k_sweep<32, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);   // 6 KB less LDS per wavefront than the 512-wide staging
+    }
+    T.mark(9, st);
+    if (nCls[1]) {   // at most kMaxRight right nodes per boundary (and right-check * R prescores within the staging)
+      if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
+      else JPP_LAUNCH((k_sweep<32, kMaxRight>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
+    }
+    T.mark(10, st);
+    if (nCls[2]) {   // any width
+      if (narrow) JPP_LAUNCH((k_sweep<8, 0>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+      else JPP_LAUNCH((k_sweep<32, 0>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+    }
   }
+  ctx->last_class_n[0] = nCls[0]; ctx->last_class_n[1] = nCls[1]; ctx->last_class_n[2] = nCls[2];
   T.mark(5, st);
   if (ctx->cfg.nscorers == 2) {
     JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
@@ -947,7 +983,8 @@ extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
     ctx->timer.collect(ctx->last_ms);
     ctx->timing_pending = false;
   }
-  for (int i = 0; i < n && i < 8; ++i) ms[i] = ctx->last_ms[i];
+  for (int i = 0; i < n && i < 11; ++i) ms[i] = ctx->last_ms[i];
+  for (int i = 11; i < n && i < 14; ++i) ms[i] = (float)ctx->last_class_n[i - 11];
   return JPPGPU_OK;
 }
 

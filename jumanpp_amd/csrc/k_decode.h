@@ -94,7 +94,7 @@ __device__ __forceinline__ bool cl_lower_list(u32 c) {
 __global__ void k_decode(Batch B, Config cfg) {
   u32 s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s == 0) {
-    for (int q = 0; q < 4; ++q) B.gstats[q] = 0;
+    for (int q = 0; q < 8; ++q) B.gstats[q] = 0;
   }
   if (s >= B.n_sent) return;
   u32 off = B.byte_off[s];

@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_layout(Batch B) {
   // one atomic per sentence would serialise 64k updates of one address: skip it when the published
   // maximum (monotonic, possibly stale) already covers this sentence
   if (maxR > B.gstats[0]) atomicMax(&B.gstats[0], maxR);
+  B.sent_maxr[s] = maxR;
   // EOS boundary
   B.bnd_first[bb0 + n + 2] = next;
   B.bnd_cnt[bb0 + n + 2] = 1;
@@ -159,6 +160,36 @@ __global__ void __launch_bounds__(1024) k_scan(const u32* in, u64* out, u32 n, c
     __syncthreads();
   }
   if (t == 0) out[n] = carry;
+}
+
+// Sentences are routed to the sweep variant that fits THEIR widest boundary, not the batch's (one sentence with a
+// 100-homograph boundary must not move the other 65 535 to the generic kernel): class 0 = at most t0 right nodes at
+// every boundary (the variants that stage 64 in LDS), class 1 = at most t1 (LDS staging of kMaxRight), class 2 =
+// wider (per-right-node arrays in an HBM scratch slice; the reference has no limit, lattice_builder.cc:70-93).
+// Counting sort of the sentence indices by class: sweep_list[c * n + k], gstats[1 + c] = sentences of class c.
+// One thread per sentence, one atomic per wavefront and class.  Failed sentences are in no list.
+__global__ void __launch_bounds__(256) k_sweep_classify(Batch B, u32 t0, u32 t1) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = (int)(threadIdx.x & 63);
+  const bool act = s < B.n_sent && B.sent_status[s] == ST_OK;
+  u32 cls = 3;
+  if (act) {
+    const u32 m = B.sent_maxr[s];
+    cls = m <= t0 ? 0u : m <= t1 ? 1u : 2u;
+    if (m > 0xffffu) {   // the cutoff order of the sweep is u16 (node spans are u16 as well: not reachable with real dictionaries)
+      B.sent_status[s] = ST_CAPACITY;
+      cls = 3;
+    }
+  }
+  for (u32 c = 0; c < 3; ++c) {
+    const u64 bal = wave_ballot(cls == c);
+    if (bal == 0) continue;
+    const int leader = __builtin_ctzll(bal);
+    u32 base = 0;
+    if (lane == leader) base = atomicAdd(&B.gstats[1 + c], (u32)popc64(bal));
+    base = wave_shfl_u32(base, leader);
+    if (cls == c) B.sweep_list[(u64)c * B.n_sent + base + (u32)popc64(bal & ((u64{1} << lane) - 1))] = s;
+  }
 }
 
 // relocate flagged sentences: node_base[s] = node_base2[s]

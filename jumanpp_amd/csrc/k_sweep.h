@@ -208,7 +208,8 @@ __global__ void k_penalty(Batch B) {
 
 __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32 q) { return g[q]; }
 
-// RM = capacity of right nodes per boundary staged in LDS (the host picks the variant from the batch maximum)
+// RM = capacity of right nodes per boundary staged in LDS (every sentence runs the variant of its own widest
+// boundary: k_sweep_classify)
 // The workgroup is one wavefront: the phases are separated by wave_sync() (compiler + LDS ordering only).
 // A __syncthreads() would additionally drain the vector-memory counter, i.e. wait for every outstanding
 // global store (beams, cells) ~12 times per boundary.
@@ -217,9 +218,11 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // size, fixed trip counts); any other configuration runs the same code with the values read from `cfg`.
 // W24: the weight table has at most 2^24 entries (hmix_index).
 template <int GM, int RM, bool DEF = false, bool W24 = false>
-__global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
+__global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg,
+                                                           const u32* __restrict__ slist) {
   const DevModel& M = *Mp;
-  const u32 s = blockIdx.x;
+  // workgroup -> sentence through the list of the variant's class (k_sweep_classify)
+  const u32 s = slist[blockIdx.x];
   if (B.sent_status[s] != ST_OK) return;
   const int lane = (int)threadIdx.x;
   const u32 off = B.byte_off[s];
@@ -251,10 +254,9 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   static_assert(spec::kTri[0].t2 < kT2 && spec::kTri[1].t2 < kT2 && spec::kTri[2].t2 < kT2 && spec::kTri[3].t2 < kT2 && spec::kNumTri == 4,
                 "t2pat holds pattern fields 0..3 only");
   __shared__ u64 t2pat[GM][kT2];
-  // the three per-right-node arrays: in LDS (capacity RM), or -- RM == 0, the host picks this variant when a
-  // boundary of the batch has more right nodes than the LDS variants stage -- in an HBM scratch slice of the
-  // sentence sized from the batch maximum, so that no lattice is ever too wide (the reference has no limit,
-  // lattice_builder.cc:70-93)
+  // the three per-right-node arrays: in LDS (capacity RM), or -- RM == 0, the variant of sentences with a boundary
+  // wider than the LDS variants stage -- in an HBM scratch slice of the workgroup sized from the batch maximum, so
+  // that no lattice is ever too wide (the reference has no limit, lattice_builder.cc:70-93)
   constexpr int kRMs = RM > 0 ? RM : 1;
   __shared__ float pres_lds[2 * kRMs];
   __shared__ float csum_lds[kRMs];
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     const u32 rfirst = mb.first;
     const u32 L = mb.ecnt;
     const u32 efirst = mb.efirst;
-    if (RM > 0 && R > (u32)RM) {   // cannot happen: the host chose RM from the batch maximum
+    if (RM > 0 && R > (u32)RM) {   // cannot happen: the sentence was routed here by its widest boundary
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }

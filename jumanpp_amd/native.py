@@ -350,6 +350,13 @@ class Context:
         names = ['decode', 'seeds', 'layout', 't0', 'sweep', 'rnn', 'path', 'total']
         return dict(zip(names, list(ms)[:8]))
 
+    def sweep_classes(self):
+        """the sweep phase of the last batch by sentence class: ms and sentences of the variants staging 64 / 512 / any
+        number of right nodes per boundary"""
+        ms = (C.c_float * 14)()
+        self.lib.jppgpu_last_timings(self.handle, ms, 14)
+        return {'ms': [round(float(x), 4) for x in ms[8:11]], 'sentences': [int(x) for x in ms[11:14]]}
+
     def close(self):
         if self.handle:
             self.lib.jppgpu_ctx_destroy(self.handle)

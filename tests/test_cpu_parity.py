@@ -164,6 +164,37 @@ def test_emulated_lattice_wider_than_the_lds_staging(emu_lib, ref_tools, tmp_pat
     assert not errs, errs[:10]
 
 
+def _mixed_width_workload(ref_tools, tmp, beams, n_lines, rnn=None):
+    """sentences of all three sweep classes in one batch: ordinary generated lines (at most 64 right nodes per
+    boundary), lines through a surface with 100 readings (class 1) and through one with 600 (class 2)"""
+    import test_gpu_parity as tg
+    mdic = os.path.join(tmp, 'w.mdic')
+    extra = ''.join('さけ,0,0,0,名詞,普通名詞,*,*,さけ,よみ%d,さけ/よみ%d,代表表記:さけ/よみ%d\n' % (i, i, i) for i in range(100))
+    extra += ''.join('かき,0,0,0,名詞,普通名詞,*,*,かき,よみ%d,かき/よみ%d,代表表記:かき/よみ%d\n' % (i, i, i) for i in range(600))
+    img, lines, gold = tg._fresh_workload(ref_tools, tmp, 2500, n_lines, 16, 41, length=30, rnn=rnn, beams=beams,
+                                          extra_dict=extra,
+                                          extra_lines=['さけをのむ', 'かきをかきかきとかきく', 'あさけとかきい', 'さけさけ'])
+    return img, lines, gold
+
+
+@pytest.mark.parametrize('beams,rnn', [([5, 6, 1, 5], None), ([5, 6, 1, 5], (32, 600)), ([20, 24, 1, 20], None)])
+def test_emulated_sentences_are_routed_to_sweep_variants_one_by_one(emu_lib, ref_tools, tmp_path, beams, rnn):
+    """one batch holds sentences of every sweep class (widest boundary <= 64 / <= 512 / wider): each runs the variant
+    of its class (k_sweep_classify), and the whole lattice of every sentence is the reference's"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    img, lines, gold_path = _mixed_width_workload(ref_tools, str(tmp_path), beams, 40, rnn=rnn)
+    ctx = J.Context(img, lib_path=emu_lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    cls = ctx.sweep_classes()['sentences']
+    assert cls[0] >= 40 and cls[1] >= 1 and cls[2] >= 2 and sum(cls) == len(lines), cls
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     # reference: invalid UTF-8 -> InvalidParameter (characters.cc:267-269);

@@ -70,11 +70,18 @@ def test_gpu_status_codes(gpu_lib, golden_dir):
     assert list(res.status) == [2, 0, 2, 1, 0]
 
 
-def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None, beams=None, join=0):
+def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rnn=None, beams=None, join=0,
+                    extra_dict='', extra_lines=()):
     mdic = os.path.join(tmp, 'w.mdic')
     with open(mdic, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)],
                               stdout=f)
+        if extra_dict:
+            # the corpus generator draws its words from the dictionary without the extra entries
+            f.flush()
+            import shutil
+            shutil.copyfile(mdic, os.path.join(tmp, 'w.base.mdic'))
+            f.write(extra_dict)
     subprocess.check_call([os.path.join(ref_tools, 'jpp_jumandic_bootstrap'), mdic, os.path.join(tmp, 'w.seed')],
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'mkmodel', os.path.join(tmp, 'w.seed'),
@@ -94,8 +101,12 @@ def _fresh_workload(ref_tools, tmp, n_entries, n_lines, exp, seed, length=40, rn
                            os.path.join(tmp, 'w.img')], stderr=subprocess.DEVNULL)
     txt = os.path.join(tmp, 'w.txt')
     with open(txt, 'w', encoding='utf-8') as f:
-        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines), '--seed',
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'),
+                               os.path.join(tmp, 'w.base.mdic') if extra_dict else mdic, str(n_lines), '--seed',
                                str(seed + 1), '--oov', '0.08', '--len', str(length)], stdout=f)
+    if extra_lines:
+        with open(txt, 'a', encoding='utf-8') as f:
+            f.write('\n'.join(extra_lines) + '\n')
     if join:
         # every other output line is `join` generated sentences glued together
         src = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
@@ -432,3 +443,21 @@ def test_gpu_headline_shape_through_the_bench_path_vs_live_reference(gpu_lib, re
         bad = bench.compare_packed(ho, hi, rs, ro, ri, np)
         total_bad += [(bi, s) for s in bad]
     assert not total_bad, (len(total_bad), total_bad[:8])
+
+
+@pytest.mark.parametrize('rnn', [None, (128, 3000)])
+def test_gpu_sentences_are_routed_to_sweep_variants_one_by_one(gpu_lib, ref_tools, tmp_path, rnn):
+    """3 000 ordinary sentences plus a few through surfaces with 100 and 600 dictionary readings in ONE batch: every
+    sentence runs the sweep variant of its own widest boundary (three launches), all lattices bit-identical to the
+    live reference"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    img, lines, gold_path = tc._mixed_width_workload(ref_tools, str(tmp_path), [5, 6, 1, 5], 3000, rnn=rnn)
+    ctx = J.Context(img, lib_path=gpu_lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    cls = ctx.sweep_classes()['sentences']
+    assert cls[0] >= 3000 and cls[1] >= 1 and cls[2] >= 2 and sum(cls) == len(lines), cls
+    errs = _compare_all(res, gold, meta, len(lines))
+    assert not errs, (len(errs), errs[:10])
