@@ -34,8 +34,9 @@ def make_workload(args, cache_dir):
     """synthetic dictionary + random perceptron + corpus, built with the
     reference's own offline tools (oracle/_ref) -- untimed setup."""
     os.makedirs(cache_dir, exist_ok=True)
-    dkey = 'd%d_s%d' % (args.dict_entries, args.seed)
-    key = 'd%d_w%d_s%d%s' % (args.dict_entries, args.weights_exp, args.seed, '_rnn%d' % args.rnn_hidden if args.rnn else '')
+    hom = int(getattr(args, 'homographs', 0) or 0)
+    dkey = 'd%d_s%d%s' % (args.dict_entries, args.seed, '_h%d' % hom if hom else '')
+    key = '%s_w%d%s' % (dkey, args.weights_exp, '_rnn%d' % args.rnn_hidden if args.rnn else '')
     mdic = os.path.join(cache_dir, dkey + '.mdic')
     seed_model = os.path.join(cache_dir, dkey + '.seed')
     model = os.path.join(cache_dir, key + '.model')
@@ -43,7 +44,7 @@ def make_workload(args, cache_dir):
     if not os.path.exists(seed_model):
         with open(mdic, 'w', encoding='utf-8') as f:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_dict.py'), str(args.dict_entries),
-                                   '--seed', str(args.seed)], stdout=f)
+                                   '--seed', str(args.seed)] + (['--homographs', str(hom)] if hom else []), stdout=f)
         subprocess.check_call([os.path.join(REF, 'jpp_jumandic_bootstrap'), mdic, seed_model + '.tmp'],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         os.rename(seed_model + '.tmp', seed_model)
@@ -372,7 +373,74 @@ def realism_legs(args, cache, local_rank, np, torch, J):
             torch.cuda.empty_cache()
         except Exception as e:  # an extra leg must never take the main line down
             legs[name] = {'error': str(e)[:200]}
+    legs['homographs'] = homograph_leg(args, cache, local_rank, np, torch, J)
     return legs
+
+
+def homograph_leg(args, cache, local_rank, np, torch, J):
+    """jumandic-like fan-out (tools/gen_dict.py --homographs 60: every single hiragana has 8..60 dictionary entries,
+    150 two-kana surfaces 4..30): which sweep variants run and what they cost, (i) on ordinary text of that dictionary,
+    (ii) on a batch without the fan-out surfaces, and (iii) on (ii) with ONE sentence made of the widest surfaces --
+    every sentence runs the variant of its own widest boundary, so (iii) must cost what (ii) costs."""
+    import copy
+    try:
+        a = copy.copy(args)
+        a.homographs = 60
+        mdic, model, img = make_workload(a, cache)
+        # surfaces by number of entries; a dictionary view without the fan-out surfaces for corpus (ii)
+        counts = {}
+        rows = open(mdic, encoding='utf-8').read().split('\n')
+        for r in rows[8:]:
+            if r:
+                counts[r.split(',', 1)[0]] = counts.get(r.split(',', 1)[0], 0) + 1
+        base = os.path.join(cache, os.path.basename(mdic) + '.narrow')
+        if not os.path.exists(base):
+            with open(base, 'w', encoding='utf-8') as f:
+                f.write('\n'.join(rows[:8] + [r for r in rows[8:] if r and counts[r.split(',', 1)[0]] <= 6]) + '\n')
+        wide = sorted(counts, key=lambda k: -counts[k])[:40]
+        corpus_all = make_corpus(a, mdic, cache, args.batch, a.seed + 77)
+        corpus_narrow = make_corpus(a, base, cache, args.batch, a.seed + 78)
+        dev = torch.device('cuda', local_rank)
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank,
+                        use_rnn=None if args.rnn else False)
+
+        def measure(lines):
+            offs = np.zeros(len(lines) + 1, dtype=np.uint32)
+            offs[1:] = np.cumsum([len(l) for l in lines])
+            tx = b''.join(lines)
+            t = torch.frombuffer(bytearray(tx), dtype=torch.uint8).to(dev)
+            o = torch.from_numpy(offs.astype(np.int32)).to(dev)
+            ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(lines), len(tx), stream).release()
+            torch.cuda.synchronize()
+            steps, ms, cls = [], [0.0, 0.0, 0.0], None
+            sweep = 0.0
+            for _ in range(4):
+                t0 = time.perf_counter()
+                r = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(lines), len(tx), stream)
+                torch.cuda.synchronize()
+                steps.append(time.perf_counter() - t0)
+                sc = ctx.sweep_classes()
+                cls = sc['sentences']
+                ms = [m + x / 4 for m, x in zip(ms, sc['ms'])]
+                sweep += ctx.timings()['sweep'] / 4
+                r.release()
+            rr = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(lines), len(tx), stream).fetch()
+            out = {'sentences_per_s': round(len(lines) / sorted(steps)[2], 1), 'sweep_ms': round(sweep, 3),
+                   'sweep_ms_by_class_64_512_any': [round(x, 3) for x in ms], 'sentences_by_class': cls,
+                   'nodes_per_sentence': round(float(rr.nnodes.sum()) / len(lines), 1),
+                   'failed_sentences_in_batch': int((rr.status != 0).sum())}
+            rr.release()
+            return out
+        lines_all = open(corpus_all, 'rb').read().split(b'\n')[:args.batch]
+        lines_narrow = open(corpus_narrow, 'rb').read().split(b'\n')[:args.batch]
+        one_wide = list(lines_narrow)
+        one_wide[len(one_wide) // 2] = ''.join(wide).encode('utf-8')[:3 * args.sent_len]
+        return {'dictionary': '%d entries, --homographs 60 (max %d entries on one surface)' % (a.dict_entries, max(counts.values())),
+                'ordinary_text': measure(lines_all), 'narrow_text': measure(lines_narrow),
+                'narrow_text_plus_one_wide_sentence': measure(one_wide)}
+    except Exception as e:  # an extra leg must never take the main line down
+        return {'error': str(e)[:300]}
 
 
 def cli_end_to_end(args, model, corpus, n_lines, ge):

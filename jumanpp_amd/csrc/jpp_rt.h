@@ -82,6 +82,24 @@ __device__ __forceinline__ int lane_id() {
 #endif
 }
 
+// The lane index recomputed on the spot (v_mbcnt_lo / v_mbcnt_hi, two instructions) and opaque to the optimiser.
+// k_sweep's boundary loop takes its lane index from here at the top of every iteration: whatever is derived from a
+// lane index that lives outside the loop (lane * 16, lane >> 3, LDS addresses per array, ...) is hoisted out of the
+// loop by LLVM and kept in registers across it -- sixty-odd VGPRs in round 2, the difference between four and five
+// wavefronts per SIMD -- and a spilled lane index costs a scratch reload, which on this in-order memory pipeline also
+// waits for every prefetch in flight.
+__device__ __forceinline__ int lane_now() {
+#if defined(JPP_EMU)
+  return hip_emu::lane();
+#elif defined(__HIP_DEVICE_COMPILE__)
+  int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(v));
+  return v;
+#else
+  return 0;
+#endif
+}
+
 // Synchronise the lanes of ONE wavefront around LDS traffic (multi-wave workgroups whose
 // waves work on independent sentences cannot use the workgroup barrier inside ragged loops).
 // LDS operations of a wave complete in order; the fences make the compiler emit the waits.
@@ -137,8 +155,10 @@ __device__ __forceinline__ void vm_wait_all() {
 // occupancy target of a kernel (wavefronts per SIMD): caps its VGPRs accordingly
 #if defined(JPP_EMU)
 #define JPP_WAVES_PER_EU(n)
+#define JPP_WAVES_PER_EU_RANGE(lo, hi)
 #else
 #define JPP_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#define JPP_WAVES_PER_EU_RANGE(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
 
 // workgroup barrier that orders LDS traffic only: outstanding global loads / stores of the wavefront stay in flight

@@ -836,8 +836,19 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     static const unsigned devPad = std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD") ? (unsigned)std::atoi(std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD")) : 0u;
     T.mark(8, st);
     if (nCls[0]) {   // at most 64 right nodes per boundary, right-check <= 2
-      if (def && ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
-      else if (def) JPP_LAUNCH((k_sweep<8, 64, true, false>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
+      // the CLI defaults: the one-row lean LDS layout (6.6 KB), 5 wavefronts per SIMD (96 VGPRs, no scratch); weight
+      // tables of up to 2^24 entries get the 24-bit index arithmetic.  (developer knob JPPGPU_DEV_SWEEP_WAVES: 0 =
+      // the round-2 layout (9.8 KB LDS, 4 waves), 4 / 5 = lean with two row buffers (7.7 KB) compiled for 4 / 5
+      // waves, 15 / 6 = one row buffer compiled for 5 / 6 waves; profiles/r03_f_sweep_layouts.txt)
+      static const int devWaves = std::getenv("JPPGPU_DEV_SWEEP_WAVES") ? std::atoi(std::getenv("JPPGPU_DEV_SWEEP_WAVES")) : 15;
+      const bool w24 = ctx->hmodel.wmask <= 0xffffffu;
+      if (def && w24 && devWaves == 4) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true, 4, 1>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def && w24 && devWaves == 6) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true, 6, 2>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def && w24 && devWaves == 15) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true, 5, 2>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def && w24 && devWaves == 0) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def && w24 && devWaves == 5) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true, 5, 1>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def && w24) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true, 5, 2>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
+      else if (def) JPP_LAUNCH((k_sweep<8, 64, true, false, 5, 2>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
       else if (narrow) JPP_LAUNCH((k_sweep<8, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
       else JPP_LAUNCH((k_sweep<32, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);   // 6 KB less LDS per wavefront than the 512-wide staging
     }

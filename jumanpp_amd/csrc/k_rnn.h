@@ -52,7 +52,8 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 }
 
 // one byte at a time through a double array; returns false once a label mismatches
-__device__ __forceinline__ bool rnn_trie_byte(const u32* units, u32& id, u32& unit, u32 b) {
+template <typename UP>
+__device__ __forceinline__ bool rnn_trie_byte(UP units, u32& id, u32& unit, u32 b) {
   id ^= da_offset(unit) ^ b;
   unit = units[id];
   return da_label(unit) == b;
@@ -62,7 +63,7 @@ __device__ __forceinline__ bool rnn_trie_byte(const u32* units, u32& id, u32& un
 __device__ inline i32 rnn_resolve_id(const DevModel& M, const Batch& B, u32 s, u64 nb, u32 k) {
   NodeInfo ni = B.node_info[nb + k];
   const i32* entry = B.node_entry + (nb + k) * spec::kNumDicFeatures;
-  const u32* units = ni.eptr >= 0 ? M.rnn_known : M.rnn_unk;
+  const u32 JPP_GLOBAL* units = as_global(ni.eptr >= 0 ? M.rnn_known : M.rnn_unk);
   u32 id = 0;
   u32 unit = units[0];
   bool ok = true;
@@ -685,7 +686,7 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int kk = 0; kk < EP / 4; ++kk)
-      wA[t][kk] = role >= 0 ? M.rnn_wt[(u32)(4 * kk + (lane >> 4)) * EP + 16u * (u32)(TPW * role + t) + (u32)(lane & 15)] : 0.f;
+      wA[t][kk] = role >= 0 ? as_global(M.rnn_wt)[(u32)(4 * kk + (lane >> 4)) * EP + 16u * (u32)(TPW * role + t) + (u32)(lane & 15)] : 0.f;
 
   float lastY[NG][J], emb1[NG][J], c1[NG][J], embv[NG][J];
   u32 lastQ[NG], q1[NG], hnd1[NG], qcur[NG];

@@ -49,6 +49,11 @@ struct SeedSink {
     }
     ++n;
   }
+  // count pass: `cnt` dictionary nodes ending at e
+  __device__ __forceinline__ void dic_count(u32 cnt, u32 e) {
+    if (cnt) mark_end(e);
+    n += cnt;
+  }
   __device__ __forceinline__ void unk(i32 tmpl, i32 hash, i32 ph0, i32 ph1, u32 maker, u32 s, u32 e) {
     mark_end(e);
     if (emit) {
@@ -60,7 +65,7 @@ struct SeedSink {
 };
 
 __device__ __forceinline__ int step_cp(const DevModel& M, const SentView& S, TrieCursor& c, u32 j) {
-  return trie_step(M.trie, c, S.txt + S.boff[j], (int)(S.boff[j + 1] - S.boff[j]));
+  return trie_step(as_global(M.trie), c, S.txt + S.boff[j], (int)(S.boff[j + 1] - S.boff[j]));
 }
 
 __device__ __forceinline__ i32 surface_hash(const SentView& S, u32 s, u32 e) {
@@ -84,12 +89,25 @@ __device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, 
 template <typename F>
 __device__ __forceinline__ void for_each_entry(const DevModel& M, i32 v, F&& f) {
   u32 pos = (u32)v;
-  i32 cnt = (i32)read_varint(M.entry_ptrs, pos);
+  VarintWindow<const u8 JPP_GLOBAL*> win(as_global(M.entry_ptrs), pos);
+  i32 cnt = (i32)win.next(pos);
   i32 ptr = 0;
   for (i32 k = 0; k < cnt; ++k) {
-    ptr += (i32)read_varint(M.entry_ptrs, pos);
+    ptr += (i32)win.next(pos);
     f(ptr);
   }
+}
+
+// the length of the entry-pointer list at trie value `v` (all the count pass needs of it)
+__device__ __forceinline__ u32 entry_count(const DevModel& M, i32 v) {
+  u32 pos = (u32)v;
+  return (u32)read_varint(as_global(M.entry_ptrs), pos);
+}
+
+// dictionary nodes of one key: counted (count pass) or emitted
+__device__ __forceinline__ void dic_nodes(const DevModel& M, i32 v, u32 i, u32 e, SeedSink& out) {
+  if (!out.emit) out.dic_count(entry_count(M, v), e);
+  else for_each_entry(M, v, [&](i32 ptr) { out.dic(ptr, i, e); });
 }
 
 // What the dictionary walk from one start learned about the prefixes of the input: the UNK makers ask the
@@ -127,7 +145,7 @@ __device__ __forceinline__ WalkInfo dic_seeds(const DevModel& M, const SentView&
       if (rec && nvals < (u32)kWalkCacheVals) rec->vals[nvals] = c.value;
       ++nvals;
       u32 e = j + 1;
-      for_each_entry(M, c.value, [&](i32 ptr) { out.dic(ptr, i, e); });
+      dic_nodes(M, c.value, i, e, out);
     }
   }
   if (rec) {
@@ -148,7 +166,7 @@ __device__ __forceinline__ WalkInfo dic_seeds_replay(const DevModel& M, const Wa
     const u32 len = (u32)__builtin_ctzll(bits) + 1;
     bits &= bits - 1;
     const u32 e = i + len;
-    for_each_entry(M, wc->vals[k], [&](i32 ptr) { out.dic(ptr, i, e); });
+    dic_nodes(M, wc->vals[k], i, e, out);
     ++k;
   }
   return w;
@@ -274,7 +292,8 @@ __device__ __forceinline__ u32 num_find_longest(const SentView& S, u32 start, i3
 // decode the first `nf` ints of the entry row at EntryPtr `eptr`
 __device__ __forceinline__ void read_entry_row(const DevModel& M, i32 eptr, i32* row, int nf) {
   u32 pos = (u32)(eptr >> 1);
-  for (int k = 0; k < nf; ++k) row[k] = (i32)read_varint(M.entry_data, pos);
+  VarintWindow<const u8 JPP_GLOBAL*> win(as_global(M.entry_data), pos);
+  for (int k = 0; k < nf; ++k) row[k] = (i32)win.next(pos);
 }
 
 __device__ __forceinline__ bool dic_pattern_matches(const DevModel& M, const UnkMaker& mk, i32 value) {
@@ -432,7 +451,7 @@ __device__ inline int norm_lookup(const DevModel& M, const SentView& S, const Cl
           } else {
             u8 bytes[4];
             int nb = utf8_encode3(xn.cp[w], bytes);
-            status = trie_step(M.trie, tc, bytes, nb);
+            status = trie_step(as_global(M.trie), tc, bytes, nb);
             ns.key_pos = (u8)nb;
           }
           // a failed step leaves key_pos at the failing byte in the reference, but such

@@ -63,6 +63,73 @@ constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
 __device__ __forceinline__ bool slot_fake(const BeamSlot& s) { return s.left == kFake16 && s.beam == kFake16; }
 
+// The value itself, but opaque to the optimiser: what is computed from it inside the boundary loop is not hoisted out
+// of the loop into (sixty-odd, in round 2) loop-invariant VGPRs, which is what bounds the wavefronts per SIMD.
+__device__ __forceinline__ int opaque_i32(int v) {
+#if !defined(JPP_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+__device__ __forceinline__ u32 opaque_u32(u32 v) {
+#if !defined(JPP_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
+// cold paths of the sweep as real calls: inlined, their temporaries (six butterfly addresses of the wave-wide maximum,
+// the state of the nth_element replay) are live across the whole boundary loop
+// more candidates than the LDS staging holds (rare): G rounds of a wave-wide maximum over the beam slots in HBM
+__device__ __attribute__((noinline)) int global_beam_from_hbm(const BeamSlot* beams, const u32* ends, u32 ncand, int beam,
+                                                              int G, u64* gb_key) {
+  const int lane = lane_id();
+  u64 last = ~u64{0};
+  int ngb = 0;
+  for (int r = 0; r < G; ++r) {
+    u64 best = 0;
+    for (u32 q = (u32)lane; q < ncand; q += 64) {
+      u32 l = q / (u32)beam, k = q - l * (u32)beam;
+      BeamSlot sl = beams[(u64)ends[l] * beam + k];
+      if (!slot_fake(sl)) {
+        u64 key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
+        if (key < last && key > best) best = key;
+      }
+    }
+    u64 win = wave_max_u64(best);
+    if (win == 0) break;
+    if (lane == 0) gb_key[r] = win;
+    last = win;
+    ++ngb;
+  }
+  return ngb;
+}
+
+__device__ __attribute__((noinline)) void cutoff_replay(u16* order, const float* csum, u32 rbeam, u32 R) {
+  ScoreGreater cmp{csum};
+  nth_element_u16(order, order + rbeam, order + R, cmp);
+}
+
+// q / d for the small runtime divisors of the sweep (beam sizes, global-beam counts: d <= 32) and q < 2048: one
+// multiply by ceil(2^16 / d) and a shift instead of the ~25-instruction reciprocal sequence of a 32-bit division.
+// Exact: q * (d * inv - 2^16) < q * d < 2^16.
+struct SmallDivTab {
+  u32 inv[33];
+  constexpr SmallDivTab() : inv{} {
+    inv[0] = 0;
+    for (u32 d = 1; d <= 32; ++d) inv[d] = (65536u + d - 1) / d;
+  }
+};
+constexpr SmallDivTab kSmallDiv{};
+__device__ __forceinline__ u32 small_div_inv(u32 d) { return kSmallDiv.inv[d]; }   // d wave-uniform: a scalar load
+__device__ __forceinline__ u32 small_div(u32 q, u32 inv) {
+#if defined(JPP_EMU)
+  return (q * inv) >> 16;
+#else
+  return __umul24(q, inv) >> 16;   // both factors below 2^24: the full-rate multiplier
+#endif
+}
+
 // GM = compile-time capacity of the global beam / per-node beam (8 for the CLI defaults, 32 for wide beams)
 
 // ---- 8-lane group helpers -------------------------------------------------------
@@ -76,8 +143,9 @@ constexpr int kBiPerLane = (spec::kNumBi + 7) / 8;
 struct LaneBi {
   const u64* pre;   // [kNumBi] hash prefixes
   const u8* t01;    // [kNumBi] (t0 << 4) | t1
+  u32 t1pack;       // this lane's T1 pattern indices: 4 bits per feature slot m (features gj + 8 m)
 };
-#define JPP_LBI_T1(t, m, j) ((t).t01[((j) + 8 * (m)) < spec::kNumBi ? ((j) + 8 * (m)) : 0] & 15)
+#define JPP_LBI_T1(t, m, j) (((t).t1pack >> (4 * (m))) & 15u)
 
 // weights of this lane's bigram features for one (right node, T1 row) pair, from the cached first-stage
 // states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
@@ -217,9 +285,12 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // jumanpp_args.h:50-54): the four numbers become compile-time constants (no runtime divisions by the beam
 // size, fixed trip counts); any other configuration runs the same code with the values read from `cfg`.
 // W24: the weight table has at most 2^24 entries (hmix_index).
-template <int GM, int RM, bool DEF = false, bool W24 = false>
-__global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg,
-                                                           const u32* __restrict__ slist) {
+// WAVES: wavefronts per SIMD the variant is compiled for (VGPR budget 512 / WAVES); its LDS footprint must allow as many.
+// LEAN: the small-LDS layouts of the default-configuration variants (see kLean below): 0 = off, 1 = lean with the next
+// boundary's pattern rows in a buffer of their own, 2 = the tightest layout (one row buffer).
+template <int GM, int RM, bool DEF = false, bool W24 = false, int WAVES = kSweepWaves, int LEAN = 0>
+__global__ void __launch_bounds__(64) JPP_WAVES_PER_EU_RANGE(WAVES, WAVES)
+k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restrict__ slist) {
   const DevModel& M = *Mp;
   // workgroup -> sentence through the list of the variant's class (k_sweep_classify)
   const u32 s = slist[blockIdx.x];
@@ -249,20 +320,33 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   __shared__ u32 gb_pnode[GM];
   __shared__ u32 gb_t1[GM];
   __shared__ u32 t1node[GM];
-  __shared__ u64 t1pat[GM][kPat];
+  // kLean (the CLI-default variants): the LDS footprint is what bounds the wavefronts per CU, and the kernel is a
+  // chain of dependent round trips that only other wavefronts hide (6.4 / 8.2 / 10.6 ms at 4 / 3 / 2 per SIMD,
+  // profiles/r03_a_occupancy.txt) -- every array is as small as the default configuration allows: rows for the 6
+  // global-beam entries, one prescore per right node that doubles as the cutoff sum, ONE pattern-row buffer (rows
+  // are dead once their first-stage hash states exist), a 16-entry layout ring.  6.5 KB instead of 9.8 KB.
+  static_assert(!LEAN || (DEF && RM > 0), "the lean layout is written for the default configuration");
+  constexpr bool kLean = LEAN != 0;
+  // kOneRow: the tightest layout (6 wavefronts per SIMD: 6.5 KB) has ONE pattern-row buffer and small rings; the
+  // 5-wavefront layout (8 KB) keeps the next boundary's rows apart (requested a whole boundary ahead)
+  constexpr bool kOneRow = LEAN == 2;
+  constexpr int kGR = kLean ? 6 : GM;   // rows of the per-global-beam-entry arrays
+  __shared__ u64 t1pat[kGR][kPat];
   constexpr int kT2 = 4;  // pattern fields of the T2 node the trigrams read (indices 0..3)
   static_assert(spec::kTri[0].t2 < kT2 && spec::kTri[1].t2 < kT2 && spec::kTri[2].t2 < kT2 && spec::kTri[3].t2 < kT2 && spec::kNumTri == 4,
                 "t2pat holds pattern fields 0..3 only");
-  __shared__ u64 t2pat[GM][kT2];
+  __shared__ u64 t2pat[kGR][kT2];
   // the three per-right-node arrays: in LDS (capacity RM), or -- RM == 0, the variant of sentences with a boundary
   // wider than the LDS variants stage -- in an HBM scratch slice of the workgroup sized from the batch maximum, so
   // that no lattice is ever too wide (the reference has no limit, lattice_builder.cc:70-93)
   constexpr int kRMs = RM > 0 ? RM : 1;
-  __shared__ float pres_lds[2 * kRMs];
-  __shared__ float csum_lds[kRMs];
+  // (kLean: right-check 1, so one prescore per right node, and the cutoff sum 0.f + prescore IS the prescore --
+  // except that it turns -0.f into +0.f, which no comparison of the cutoff distinguishes)
+  __shared__ float pres_lds[(kLean ? 1 : 2) * kRMs];
+  __shared__ float csum_lds[kLean ? 1 : kRMs];
   __shared__ u16 order_lds[kRMs];
   float* pres = pres_lds;
-  float* csum = csum_lds;
+  float* csum = kLean ? pres_lds : csum_lds;
   u16* order = order_lds;
   if constexpr (RM == 0) {
     unsigned char* base = B.sweep_scratch + (u64)blockIdx.x * B.sweep_scratch_stride;
@@ -270,7 +354,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     csum = pres + (size_t)(cfg.rcheck > 0 ? cfg.rcheck : 1) * B.sweep_scratch_maxr;   // [maxR]
     order = reinterpret_cast<u16*>(csum + B.sweep_scratch_maxr);           // [maxR]
   }
-  __shared__ float biS[kChunk][GM];
+  __shared__ float biS[kChunk][kGR];
   // default configuration: tail-association bigram sum of (right node t, T1 row 0), formed in the prescore pass
   constexpr bool kHeadShare = DEF && RM > 0;
   __shared__ float biS0[kHeadShare ? RM : 1];
@@ -279,18 +363,24 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   // comparison of the step-by-step sort costs one LDS read per side instead of two dependent ones
   __shared__ u64 skey[GM > 16 ? kChunk : 1][GM];
   __shared__ u8 shave[GM > 16 ? kChunk : 1];   // per node of the pass: length of the sorted range | 0x80 if already in final order
-  __shared__ u64 pR[kChunk][kPat];   // patterns of the right nodes of the current pass (R > kChunk only)
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
   // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
   constexpr int kCandCap = GM <= 8 ? 64 : 512;   // candidate slots (left nodes x beam) staged in LDS per boundary
-  __shared__ __attribute__((aligned(16))) u64 pRn[2][kChunk][kPat];
+  // pattern rows of up to kChunk right nodes: kLean has ONE buffer -- a boundary's rows are dead as soon as their
+  // first-stage states are in s1b / s1t, the next boundary's (or the next pass's) rows are requested right then;
+  // the other variants keep the next boundary's rows (pRn[par ^ 1]) apart from the pass buffer pR
+  __shared__ __attribute__((aligned(16))) u64 pRn[kOneRow ? 1 : 2][kChunk][kPat];
+  __shared__ __attribute__((aligned(16))) u64 pR_lds[kLean ? 1 : kChunk][kPat];
+  // patterns of the right nodes of the current pass (R > kChunk only): kLean re-uses the boundary's own row buffer
+  // (its rows are dead once their first-stage states exist)
+  auto pRbuf = [&](int cur) -> u64(*)[kPat] { return kLean ? pRn[kOneRow ? 0 : cur] : pR_lds; };
   __shared__ __attribute__((aligned(16))) float t0n[2][kChunk];
-  constexpr u32 kEnnCap = GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
+  constexpr u32 kEnnCap = kLean ? 16 : GM <= 8 ? 32 : 64;   // ends-list entries staged per boundary
   __shared__ __attribute__((aligned(16))) u32 enn[2][kEnnCap];
   // first-stage hash states of the right nodes of the current pass: every bigram / trigram index starts with
   // hmix(prefix_k, p0[t0_k]), which depends on the right node only and is shared by all its T1 / T2 partners
-  constexpr int kS1 = 40;  // >= kNumBi, row stride
+  constexpr int kS1 = kOneRow ? spec::kNumBi : 40;  // >= kNumBi, row stride
   static_assert(spec::kNumBi <= kS1, "state row too short");
   // The candidate slots / keys of phase 1 and the bigram states of phases 3-5 are never live together
   // (the states die with the tail of a boundary, the candidates of the next one are requested after it),
@@ -323,6 +413,16 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   lbi.pre = s_bipre;
   lbi.t01 = s_bit01;
   wave_sync();
+  // the T1 pattern indices of the features of group lane j (4 bits per feature slot m), fetched once per boundary
+  __shared__ u32 s_t1pack[8];
+  if (lane < 8) {
+    u32 pk = 0;
+#pragma unroll
+    for (int m = 0; m < kBiPerLane; ++m) pk |= (u32)(s_bit01[(lane + 8 * m) < spec::kNumBi ? (lane + 8 * m) : 0] & 15) << (4 * m);
+    s_t1pack[lane] = pk;
+  }
+  wave_sync();
+  lbi.t1pack = s_t1pack[gj];
 
   if (n == 0) {
     // empty input: the reference returns before scoring anything
@@ -333,7 +433,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   }
   // per-boundary layout records: a kRing-entry LDS ring (slot b mod kRing), filled asynchronously;
   // entries that are not resident (kRing or more boundaries ahead) are read from HBM
-  constexpr u32 kRing = 32;
+  constexpr u32 kRing = kLean ? 16 : 32;
   __shared__ __attribute__((aligned(16))) BndMeta meta[kRing];
   const BndMeta* gmeta = B.bnd_meta + bb0;
   u32 metaEnd = (n + 3) < kRing ? (n + 3) : kRing;  // records below metaEnd have been requested ...
@@ -357,23 +457,42 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     }
     return q;
   };
+  // pattern rows of the first kChunk right nodes of boundary bq into the row buffer `rbuf`
+  auto prefetch_rows = [&](u32 bq, const BndMeta& mq, int rbuf) {
+    if (bq > n + 2) return;
+    const int lane = lane_now();
+    const u32 nxr = mq.cnt < (u32)kChunk ? mq.cnt : (u32)kChunk;
+    static_assert(kPat * 8 % 16 == 0 && kChunk * kPat * 8 / 16 <= 64, "one dwordx4 per lane covers a chunk");
+    lds_async_load<16>(&pRn[rbuf][0][0], reinterpret_cast<const char*>(pats + (u64)mq.first * kPat) + lane * 16,
+                       (u32)lane < nxr * (kPat * 8 / 16));
+  };
   auto prefetch = [&](u32 bq, const BndMeta& mq, int buf) {
     if (bq > n + 2) return;
+    const int lane = lane_now();
     const u32 Rq = mq.cnt, rf = mq.first, Lq = mq.ecnt, ef = mq.efirst;
     const u32 nxr = Rq < (u32)kChunk ? Rq : (u32)kChunk;
-    static_assert(kPat * 8 % 16 == 0 && kChunk * kPat * 8 / 16 <= 64, "one dwordx4 per lane covers a chunk");
-    lds_async_load<16>(&pRn[buf][0][0], reinterpret_cast<const char*>(pats + (u64)rf * kPat) + lane * 16,
-                       (u32)lane < nxr * (kPat * 8 / 16));
+    if constexpr (!kOneRow) prefetch_rows(bq, mq, buf);   // (kOneRow: requested when the single row buffer falls free)
     lds_async_load<4>(&t0n[buf][0], t0s + rf + lane, (u32)lane < nxr);
     lds_async_load<4>(&enn[buf][0], en + ef + lane, (u32)lane < (Lq < kEnnCap ? Lq : kEnnCap));
   };
-  // first-stage states of `nx` right nodes whose pattern rows are rows[0..nx): lane per (node, feature)
+  // first-stage states of `nx` right nodes whose pattern rows are rows[0..nx): lane = feature (37 bigram + 4 trigram
+  // features: one pass of 41 lanes), a loop over the nodes.  The lane's hash prefix and pattern index stay in
+  // registers across the nodes; a lane-per-(node, feature) layout paid a division by 41 and three table reads per
+  // element for nothing.
   auto compute_s1 = [&](const u64(*rows)[kPat], u32 nx) {
     constexpr u32 kF = spec::kNumBi + spec::kNumTri;
-    for (u32 q = lane; q < nx * kF; q += 64) {
-      const u32 x = q / kF, k = q - x * kF;
-      if (k < (u32)spec::kNumBi) s1b[x][k] = hmix(s_bipre[k], rows[x][s_bit01[k] >> 4]);
-      else s1t[x][k - spec::kNumBi] = hmix(s_tripre[k - spec::kNumBi], rows[x][s_trit[k - spec::kNumBi][0]]);
+    static_assert(kF <= 64, "one lane per n-gram feature");
+    const int fl = lane_now();   // (the table reads below stay inside the loop)
+    if ((u32)fl < kF) {
+      const bool bi = fl < spec::kNumBi;
+      const int kt = bi ? 0 : fl - spec::kNumBi;
+      const u64 pre = bi ? s_bipre[fl] : s_tripre[kt];
+      const u32 t0i = bi ? (u32)(s_bit01[fl] >> 4) : (u32)s_trit[kt][0];
+      for (u32 x = 0; x < nx; ++x) {
+        const u64 v = hmix(pre, rows[x][t0i]);
+        if (bi) s1b[x][fl] = v;
+        else s1t[x][kt] = v;
+      }
     }
   };
   JPP_PROF_DECL;
@@ -381,6 +500,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
   u32 bn = next_nonempty(2, mbn);
   int par = 0;
   prefetch(bn, mbn, par);
+  if constexpr (kOneRow) prefetch_rows(bn, mbn, 0);
   lds_async_wait();
   for (u32 b = bn; b <= n + 2; b = bn, par ^= 1) {
     // The records / rows requested during the previous boundary are needed from here on.  They were
@@ -388,6 +508,10 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     // in order, so the waits of phases 1-2 have covered them: no wait here -- it would only drain the beam
     // and cell stores the previous boundary has just issued (every path that skips those phases waits itself).
     wave_sync();
+    // this iteration's own lane index (lane_now): nothing derived from it can be hoisted out of the loop
+    const int lane = lane_now();
+    const int grp = lane >> 3, gj = lane & 7;
+    lbi.t1pack = s_t1pack[gj];
     const BndMeta mb = mbn;
     const u32 R = mb.cnt;
     const u32 rfirst = mb.first;
@@ -412,17 +536,19 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     bn = next_nonempty(b + 1, mbn);
     prefetch(bn, mbn, par ^ 1);
     const u32* enL = enn[par];  // ends list of this boundary (first 64 entries)
+    u64(*const pR)[kPat] = pRbuf(par);
 
     JPP_PROF(0);
     // ---- 1. global beam: top-G of all live (left, slot) by the packed key ----
     int ngb = 0;
     const u32 ncand = L * (u32)beam;
+    const u32 invBeam = small_div_inv((u32)beam);   // (candidate index -> (left, slot); ncand <= 2048 is checked below)
     const bool fastCand = ncand <= (u32)kCandCap && L <= kEnnCap;
     if (fastCand) {
       // the candidates' beam slots go straight to LDS (one dwordx4 per slot); they stay there for the winners
       for (u32 q0 = 0; q0 < ncand; q0 += 64) {
         const u32 q = q0 + (u32)lane;
-        const u32 l = q / (u32)beam, k = q - l * (u32)beam;
+        const u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
         lds_async_load<16>(&cand[q0], &beams[(u64)enL[q < ncand ? l : 0] * beam + k], q < ncand);
       }
       lds_async_wait();
@@ -438,7 +564,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
           u32 q = (u32)lane + 64u * jx;
           u64 key = 0;
           if (q < ncand) {
-            u32 l = q / (u32)beam, k = q - l * (u32)beam;
+            u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
             BeamSlot sl = cand[q];
             if (!slot_fake(sl)) key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
           }
@@ -495,22 +621,8 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         }
       } else {
         lds_async_wait();
-        for (int r = 0; r < G; ++r) {
-          u64 best = 0;
-          for (u32 q = lane; q < ncand; q += 64) {
-            u32 l = q / (u32)beam, k = q - l * (u32)beam;
-            BeamSlot sl = beams[(u64)en[efirst + l] * beam + k];
-            if (!slot_fake(sl)) {
-              u64 key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
-              if (key < last && key > best) best = key;
-            }
-          }
-          u64 win = wave_max_u64(best);
-          if (win == 0) break;
-          if (lane == 0) gb_key[r] = win;
-          last = win;
-          ++ngb;
-        }
+        (void)last;
+        ngb = global_beam_from_hbm(beams, en + efirst, ncand, beam, G, gb_key);
       }
     }
     wave_sync();
@@ -542,6 +654,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         beams[(u64)rfirst * beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
       }
       for (u32 q = lane; q < R; q += 64) B.node_kept[nb + rfirst + q] = 0;
+      if constexpr (kOneRow) prefetch_rows(bn, mbn, 0);   // this boundary's rows are not needed
       lds_async_wait();
       wave_sync();
       continue;
@@ -629,8 +742,13 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         if ((u32)lane < nx) t0R[lane] = t0s[rfirst + tc + lane];
         wave_sync();
       }
-      compute_s1(tc == 0 ? pRn[par] : pR, nx);
+      compute_s1(tc == 0 ? pRn[kOneRow ? 0 : par] : pR, nx);
       wave_sync();
+      // kOneRow: the rows are dead now.  With a single pass per phase the states of phase 3 serve phase 5 as well and
+      // the buffer is free for the next boundary's rows; otherwise the later passes re-stage rows in it first.
+      if constexpr (kOneRow) {
+        if (R <= (u32)kChunk) prefetch_rows(bn, mbn, 0);
+      }
       for (int i = 0; i < c; ++i) {
         const bool act = (u32)grp < nx;
         const u32 t = tc + (u32)grp;
@@ -674,14 +792,18 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     JPP_PROF(3);
     // ---- 4. right-node cutoff (std::nth_element semantics) ----
     const u32 K = (rcheck > 0) ? ((u32)rbeam < R ? (u32)rbeam : R) : R;
-    for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
-    if (rcheck > 0 && R > (u32)rbeam) {
-      for (u32 t = lane; t < R; t += 64) {
-        float sc = 0.f;
-        for (int i = 0; i < c; ++i) sc += pres[i * R + t];
-        csum[t] = sc;
+    if (!(rcheck > 0 && R > (u32)rbeam)) {
+      for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;   // no cutoff: natural order
+    } else {
+      // (the rank pass below writes every entry of `order`: a strict total order gives a permutation)
+      if constexpr (!kLean) {   // (kLean: csum is pres, see the declarations)
+        for (u32 t = lane; t < R; t += 64) {
+          float sc = 0.f;
+          for (int i = 0; i < c; ++i) sc += pres[i * R + t];
+          csum[t] = sc;
+        }
+        wave_sync();
       }
-      wave_sync();
       // Fast path: only the SET of the first rbeam entries matters downstream (kept nodes are scored
       // independently).  If no tie straddles the cut, that set is the unique top-rbeam by score and a
       // parallel stable rank gives it; otherwise replay std::nth_element step by step on one lane.
@@ -700,10 +822,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       if (tieAtCut) {
         for (u32 t = lane; t < R; t += 64) order[t] = (u16)t;
         wave_sync();
-        if (lane == 0) {
-          ScoreGreater cmp{csum};
-          nth_element_u16(order, order + rbeam, order + R, cmp);
-        }
+        if (lane == 0) cutoff_replay(order, csum, (u32)rbeam, R);
       }
     }
     wave_sync();
@@ -711,6 +830,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
     JPP_PROF(4);
     // ---- 5. score + beams, kChunk right nodes at a time in cutoff order ----
     const int ntail = ngb - c;
+    const u32 invNgb = small_div_inv((u32)ngb);   // (ngb <= 32, lane indices < 2048)
     for (u32 op0 = 0; op0 < R; op0 += kChunk) {
       const int nx = (int)((R - op0) < (u32)kChunk ? (R - op0) : (u32)kChunk);
       // patterns / T0 of this pass's right nodes in cutoff order: rows of the prefetched buffer when the
@@ -726,8 +846,13 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       if (!small) {
         compute_s1(pR, (u32)nx);
         wave_sync();
+        // kOneRow: after the last pass the row buffer is free for the next boundary
+        if constexpr (kOneRow) {
+          if (op0 + (u32)kChunk >= R) prefetch_rows(bn, mbn, 0);
+        }
       } else if (c == 0) {
-        compute_s1(pRn[par], (u32)nx);
+        static_assert(!kLean || DEF, "kLean: c >= 1 whenever a boundary is scored, the rows are gone by now");
+        compute_s1(pRn[kOneRow ? 0 : par], (u32)nx);
         wave_sync();
       }
       auto s1Row = [&](int x) -> int { return small ? (int)order[op0 + x] : x; };
@@ -740,7 +865,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
         static_assert(kChunk * GM <= 64 || GM > 8, "one lane per (node, entry) of a pass");
         const int q = lane;
         if (q < nx * ngb) {
-          const int x = q / ngb, i = q - x * ngb;
+          const int x = (int)small_div((u32)q, invNgb), i = q - x * ngb;
           if (i >= c && (op0 + x) < K) {
             const u64* st = s1t[s1Row(x)];
             const u64* t1r = t1pat[gb_t1[i]];
@@ -757,11 +882,12 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       if (ntail > 0) {
         // (kHeadShare: row 0 came out of the prescore pass, the units cover rows 1 .. U-1)
         const int Ur = kHeadShare ? U - 1 : U;
+        const u32 invUr = small_div_inv((u32)Ur);
         const int units = nx * Ur;
         for (int base = 0; base < units; base += 8) {
           int u = base + grp;
           bool act = u < units;
-          int x = act ? u / Ur : 0, tu = act ? u - x * Ur : 0;
+          int x = act ? (int)small_div((u32)u, invUr) : 0, tu = act ? u - x * Ur : 0;
           if (kHeadShare) tu += 1;
           act = act && (op0 + x) < K;
           float w[kBiPerLane];
@@ -775,7 +901,7 @@ __global__ void __launch_bounds__(64, kSweepWaves) k_sweep(Batch B, const DevMod
       JPP_PROF(5);
       // 5b. cells and totals per (node, gbeam entry)
       for (int q = lane; q < nx * ngb; q += 64) {
-        int x = q / ngb, i = q - x * ngb;
+        int x = (int)small_div((u32)q, invNgb), i = q - x * ngb;
         bool kept = (op0 + x) < K;
         u32 t = order[op0 + x];
         float cell, total;

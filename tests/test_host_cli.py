@@ -254,11 +254,16 @@ def _ref_cli(ref_tools, model, args, path):
 
 
 def _lattice_blocks_equal_except_reference_unstable(ours, ref_runs):
-    """The criterion of _shim_check for the CLI: every sentence block must be the reference's bytes, except blocks on
-    which runs of the reference itself disagree -- LatticeFormat picks the connection whose scores a line prints with
-    std::max_element over a FlatSet hashed by the HOST ADDRESS of ptr.previous (lattice_config.h:109-124), so among
-    exactly tied connections the printed one changes from run to run.  Such a block must equal one of the reference
-    runs, or agree with them in everything but the last (scores / rank) column of its lines."""
+    """The criterion of _shim_check for the CLI: every sentence block must be the reference's bytes, except where the
+    reference's own output is not a function of the lattice: LatticeFormat picks the connection whose scores a line
+    prints with std::max_element over a FlatSet hashed by the HOST ADDRESS of ptr.previous (lattice_config.h:109-124),
+    so among exactly tied connections of a node the printed one depends on where the process's pool landed (runs of
+    jumanpp_v2 disagree with each other, and a fixed address layout makes all runs agree on an arbitrary choice).
+    A block that is not the bytes of any reference run must therefore agree with the reference in everything that
+    does not depend on that choice: the N-best totals line, the number of lines, and on every line all columns, the
+    rank list included, except the three scores of the printed connection."""
+    import re
+    scores = re.compile('(特徴量スコア|言語モデルスコア|形態素解析スコア):-?[0-9.e+-]+'.encode('utf-8'))
     bo = ours.split(b'EOS\n')
     brs = [r.split(b'EOS\n') for r in ref_runs]
     assert all(len(b) == len(bo) for b in brs), [len(b) for b in brs] + [len(bo)]
@@ -267,19 +272,16 @@ def _lattice_blocks_equal_except_reference_unstable(ours, ref_runs):
         refs = [b[i] for b in brs]
         if blk == refs[0]:
             continue
-        is_unstable = any(r != refs[0] for r in refs[1:])
         if blk in refs:
             via_other_run += 1
             continue
-        # not the bytes of any run: only acceptable where the reference is unstable itself, and then only in the
-        # column that depends on the tie-break
-        assert is_unstable, (i, blk[:400], refs[0][:400])
         unstable += 1
         la, lb = blk.split(b'\n'), refs[0].split(b'\n')
         assert len(la) == len(lb), i
+        assert la[0] == lb[0] or not la[0].startswith(b'# MA-SCORE'), (i, la[0], lb[0])   # the N-best totals
         for x, y in zip(la, lb):
             if x != y:
-                assert x.split(b'\t')[:-1] == y.split(b'\t')[:-1], (i, x, y)
+                assert scores.sub(b'\\1:#', x) == scores.sub(b'\\1:#', y), (i, x, y)
                 via_structure += 1
     return unstable, via_other_run, via_structure
 

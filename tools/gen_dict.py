@@ -7,7 +7,11 @@ distribution, part-of-speech columns are sampled from a hand-written table of
 JUMAN tag combinations.  Rows 1-8 are the UNK templates the jumandic spec
 points at (jumandic_spec.cc:67-100).
 
-usage: gen_dict.py <n_entries> [--seed 1] > dict.mdic
+usage: gen_dict.py <n_entries> [--seed 1] [--homographs K] > dict.mdic
+
+--homographs K: jumandic-like fan-out of the short, frequent surfaces -- every single hiragana gets 8..K entries
+(particles, verb stems, suffixes, ... of one surface), 150 two-kana surfaces get 4..K/2 -- so that boundaries with
+dozens of right nodes occur in ordinary sentences (the rest of the dictionary keeps at most 6 entries per surface).
 """
 import argparse
 import random
@@ -76,6 +80,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('n', type=int)
     ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--homographs', type=int, default=0)
     a = ap.parse_args()
     rng = random.Random(a.seed)
     kanji = kanji_pool(3000)
@@ -95,6 +100,22 @@ def main():
     weights = [t[3] for t in TAGS]
     seen = set()
     count = len(fixed)
+    if a.homographs > 0:
+        hrng = random.Random(a.seed * 7919 + 13)
+        shorts = [(c, hrng.randint(8, max(8, a.homographs))) for c in HIRA]
+        two = set()
+        while len(two) < 150:
+            two.add(hrng.choice(HIRA) + hrng.choice(HIRA))
+        shorts += [(w, hrng.randint(4, max(4, a.homographs // 2))) for w in sorted(two)]
+        plain = [t for t in TAGS if t[2] == [('*', '*', '')] and t[3] > 0]
+        for surf, k in shorts:
+            for j in range(k):
+                pos, subpos, _, _ = plain[(j * 7 + len(surf)) % len(plain)]
+                rd = ''.join(hrng.choice(HIRA) for _ in range(len(surf)))
+                out.write('%s,0,0,0,%s,%s,*,*,%s,%s,%s,%s\n' % (surf, pos, subpos, surf, rd, surf + '/' + rd,
+                                                                  hrng.choice(FEATURES)))
+                count += 1
+            per_surface[surf] = 1 << 30   # no further entries from the generic generator
     while count < a.n:
         pos, subpos, forms, _ = rng.choices(TAGS, weights=weights)[0]
         style = rng.random()
