@@ -63,6 +63,7 @@ struct UnkMaker {
   u32 replace_mask;     // bit f set: entry feature f is replaced by the surface hash
   u32 pattern_mask;     // features compared by dicPatternMatches (numeric maker)
   i32 spec_index;       // position in spec.unkCreators (= jppgpu_model::unk_makers), reported in jppgpu_unk::maker
+  i32 rank;             // position in the reference's creation sequence of the makers (stage 1 in spec order, then stage 2)
   i32 tmpl[kMaxDicFeatures];  // decoded template entry row
 };
 
@@ -229,8 +230,11 @@ struct Batch {
   u32* rnn_offs;           // [kRnnOrderBins] next free slot of every length class
   u32* rnn_hist;           // [kRnnOrderBins] sentences per length class (all zero between batches)
   u32* rnn_slow;           // [2] first slot and number of the sentences of the last class (not staged in LDS)
-  float* rnn_ctx;          // [cpb][gbeam][EP] hidden state after each rnn node; cpb = rnn_cpbase[s] + 3 s + boundary
-  u64* rnn_cpbase;         // [n_sent + 1] codepoints of the sentences before s (the byte-indexed space would triple rnn_ctx)
+  float* rnn_ctx;          // [row][EP] hidden states: row rnn_rowbase[s] + rnn_noff[b] + idx holds rnn node idx of boundary b
+                           //   (per sentence: row 0 parking, row 1 the BOS state, then its rnn nodes in boundary order)
+  u32* rnn_noff;           // [bb] first row of the boundary's rnn nodes within the sentence's rows (k_rnn_prep)
+  u32* rnn_rows;           // [n_sent] rows of the sentence (k_rnn_prep)
+  u64* rnn_rowbase;        // [n_sent + 1] exclusive scan of rnn_rows
   u8* node_kept;           // [gn]
   GbeamEntry* bnd_gbeam;   // [bb][gbeam]
   // partial annotation (ScorePlugin): CSR constraint arrays and the resulting per-node penalty (null: off)

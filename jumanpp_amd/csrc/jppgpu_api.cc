@@ -6,6 +6,8 @@
 // infrastructure and is never loaded by the product.)
 #include "../../include/jppgpu.h"
 
+#include <sched.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,6 +58,12 @@ void rt_free(void* p) { free(p); }
 void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t) { memcpy(d, h, n); }
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
 void rt_sync(jpp_stream_t) {}
+struct SyncPoint {
+  void init() {}
+  void destroy() {}
+  void mark(jpp_stream_t) {}
+  void wait(jpp_stream_t) {}
+};
 jpp_stream_t rt_stream_create() { return nullptr; }
 void rt_stream_destroy(jpp_stream_t) {}
 void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
@@ -83,7 +91,39 @@ void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t s) {
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
   (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
 }
-void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
+// The pipeline's host syncs sit between short device phases, and the GPU idles from the moment the awaited copy lands
+// until the host has noticed and enqueued the next kernels: poll the stream (yielding the core) instead of sleeping
+// in the driver -- the wake-up latency of a blocking hipStreamSynchronize was ~0.1 ms per sync.
+void rt_sync(jpp_stream_t s) {
+  for (int spin = 0; spin < 200000; ++spin) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e != hipErrorNotReady) return;
+    sched_yield();
+  }
+  (void)hipStreamSynchronize(s);
+}
+// "Everything enqueued before mark() has completed": lets the host wait for a copy while kernels enqueued behind
+// the mark keep the GPU busy.
+struct SyncPoint {
+  hipEvent_t ev = nullptr;
+  void init() { (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming); }
+  void destroy() {
+    if (ev) (void)hipEventDestroy(ev);
+    ev = nullptr;
+  }
+  void mark(jpp_stream_t s) { (void)hipEventRecord(ev, s); }
+  void wait(jpp_stream_t s) {
+    if (!ev) {
+      rt_sync(s);
+      return;
+    }
+    for (int spin = 0; spin < 200000; ++spin) {
+      if (hipEventQuery(ev) != hipErrorNotReady) return;
+      sched_yield();
+    }
+    (void)hipEventSynchronize(ev);
+  }
+};
 // a context's own stream: contexts used from different host threads do not serialise on the null stream
 jpp_stream_t rt_stream_create() {
   hipStream_t s = nullptr;
@@ -291,7 +331,7 @@ struct jppgpu_ctx {
   DevModel* dmodel = nullptr;
   UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
   DevBuf trie, eptrs, edata, weights;
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_cpbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
@@ -307,6 +347,7 @@ struct jppgpu_ctx {
       path_nodes;
   u64 generation = 0;
   Timer timer;
+  SyncPoint rnn_sync;
   float last_ms[11] = {0};
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
@@ -454,6 +495,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     for (auto& k : norm) ctx->unk_rank.rank[k.spec_index] = (u8)r++;
     for (auto& k : st2) ctx->unk_rank.rank[k.spec_index] = (u8)r++;
     ctx->unk_rank.n = r;
+    for (int q = 0; q < idx; ++q) H.makers[q].rank = ctx->unk_rank.rank[H.makers[q].spec_index];
   }
   H.has_rnn = 0;
   if (c->use_rnn) {
@@ -529,6 +571,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   rt_sync(nullptr);
   ctx->own_stream = rt_stream_create();
   ctx->timer.init();
+  ctx->rnn_sync.init();
   *out = ctx;
   return JPPGPU_OK;
 }
@@ -565,7 +608,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
                     &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_cpbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
   for (auto* b : bufs) b->release();
@@ -573,6 +616,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   rt_stream_destroy(ctx->own_stream);
   ctx->host_pool->clear();
   ctx->timer.destroy();
+  ctx->rnn_sync.destroy();
   delete ctx;
 }
 
@@ -611,7 +655,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
-              ctx->rnn_cpbase.ensure(((size_t)n + 2) * 8)));
+              ctx->rnn_noff.ensure(bbN * 4) && ctx->rnn_rows.ensure(((size_t)n + 1) * 4) && ctx->rnn_rowbase.ensure(((size_t)n + 2) * 8)));
   ok = ok && ctx->gstats.ensure(64) && ctx->sent_maxr.ensure(((size_t)n + 1) * 4) && ctx->sweep_list.ensure((3 * (size_t)n + 1) * 4);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
@@ -671,8 +715,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_offs = B.rnn_hist ? B.rnn_hist + kRnnOrderBins : nullptr;
   B.rnn_slow = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins : nullptr;
   B.rnn_key = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins + 2 : nullptr;
-  B.rnn_ctx = ctx->rnn_ctx.as<float>();   // (sized below, once the codepoint total is known)
-  B.rnn_cpbase = ctx->rnn_cpbase.as<u64>();
+  B.rnn_ctx = ctx->rnn_ctx.as<float>();   // (sized after k_rnn_prep, once the number of rnn nodes is known)
+  B.rnn_noff = ctx->rnn_noff.as<u32>();
+  B.rnn_rows = ctx->rnn_rows.as<u32>();
+  B.rnn_rowbase = ctx->rnn_rowbase.as<u64>();
   if (n == 0) {
     B.total_nodes = 0;
     *out = Rp;
@@ -683,32 +729,28 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const u32 wblocks = (n + kLatWaves - 1) / kLatWaves;
   Timer& T = ctx->timer;
   T.mark(0, st);
-  JPP_LAUNCH(k_decode, sblocks, 256, st, B, ctx->cfg);
+  JPP_LAUNCH(k_decode, (n + kDecWaves - 1) / kDecWaves, 64 * kDecWaves, st, B, ctx->cfg);
   T.mark(1, st);
-  JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  // (developer knob JPPGPU_DEV_SEEDS_WAVES=6: the count / emit passes compiled for 6 instead of 8 wavefronts per SIMD)
+  static const int devSeedsWaves = std::getenv("JPPGPU_DEV_SEEDS_WAVES") ? std::atoi(std::getenv("JPPGPU_DEV_SEEDS_WAVES")) : 8;
+  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<0, 6>), n, 64, st, B, (const DevModel*)ctx->dmodel);
+  else JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_norm<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_layout<1>, wblocks, 64 * kLatWaves, st, B);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
-  u64 totals[3] = {0, 0, 0};
-  if (ctx->cfg.nscorers == 2) JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_ncp, B.rnn_cpbase, n, (const u64*)nullptr);
+  u64 totals[2] = {0, 0};
   rt_d2h(&totals[0], B.node_base + n, 8, st);
   rt_d2h(&totals[1], B.node_base2 + n, 8, st);
-  if (ctx->cfg.nscorers == 2) rt_d2h(&totals[2], B.rnn_cpbase + n, 8, st);
   rt_sync(st);
-  if (ctx->cfg.nscorers == 2) {
-    // hidden states: one row of G * EP floats per boundary (codepoints + 3 per sentence)
-    if (!ctx->rnn_ctx.ensure((totals[2] + 3 * (size_t)n + 8) * G * (size_t)ctx->hmodel.rnn_EP * 4))
-      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
-    B.rnn_ctx = ctx->rnn_ctx.as<float>();
-  }
   const u64 total1 = totals[0];
   const u64 seedCap = total1 + totals[1] + 8;
   if (!(ctx->node_info.ensure(seedCap * sizeof(NodeInfo)) && ctx->node_aux.ensure(seedCap * sizeof(NodeAux))))
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (node table)");
   B.node_info = ctx->node_info.as<NodeInfo>();
   B.node_aux = ctx->node_aux.as<NodeAux>();
-  JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<1, 6>), n, 64, st, B, (const DevModel*)ctx->dmodel);
+  else JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_norm<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   JPP_LAUNCH(k_connect<1>, wblocks, 64 * kLatWaves, st, B);
   // stage 2 for disconnected sentences: relocate them behind the stage-1 region
@@ -872,6 +914,14 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
     const DevModel* dm = (const DevModel*)ctx->dmodel;
+    // hidden states: one row of EP floats per rnn node (+ parking and BOS rows per sentence), i.e. ~31 rows per
+    // 40-codepoint sentence instead of the (codepoints + 3) * G = 258 of a boundary-indexed table (1.0 GB instead of
+    // 8.6 GB per 65 536 sentences).  The row total is only known here: a third host sync; the sentence ordering of
+    // the lock-step recurrence (which does not need the table) is enqueued before the host waits.
+    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.rnn_rows, B.rnn_rowbase, n, (const u64*)nullptr);
+    u64 rnnRows = 0;
+    rt_d2h(&rnnRows, B.rnn_rowbase + n, 8, st);
+    ctx->rnn_sync.mark(st);
     if (ctx->hmodel.rnn_EP <= 128) {
       // lock-step workgroups take sentences of equal chain length
       B.rnn_order = B.rnn_key + n;
@@ -882,6 +932,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
+    ctx->rnn_sync.wait(st);
+    if (!ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
+    B.rnn_ctx = ctx->rnn_ctx.as<float>();
     const u32 slowGrid = (n + 15) / 16 < 512u ? (n + 15) / 16 : 512u;   // k_rnn_score<.., 3> (16 sentences per workgroup) loops over its list
     if (ctx->hmodel.rnn_EP == 64) {
       JPP_LAUNCH((k_rnn_chain<1>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);

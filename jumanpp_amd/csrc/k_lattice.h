@@ -302,17 +302,17 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
     na[0] = na[1] = na[N - 1] = NodeAux{0, 0, 0, 0, 0, 0};
   }
   if (N <= kEndsNodeCap) {
-    // UNK entry pointers ~0, ~1, ... in creation order (UnkRank); stage the ends.
-    // First the number of UNK nodes per maker (wave-uniform counters), ...
+    // UNK entry pointers ~0, ~1, ... in creation order; stage the ends.  k_seeds left -(1 + rank of the maker) in the
+    // entry pointer of every UNK node.  First the number of UNK nodes per maker (wave-uniform counters), ...
     u32 ubase[kMaxUnkMakers];
 #pragma unroll
     for (int c = 0; c < kMaxUnkMakers; ++c) ubase[c] = 0;
     for (u32 k0 = 2; k0 + 1 < N; k0 += 64) {
       const u32 k = k0 + (u32)lane;
       const bool act = k + 1 < N;
-      const bool isUnk = act && ni[k].eptr < 0;
-      const u32 cls = isUnk ? (u32)rk.rank[na[k].maker & (kMaxUnkMakers - 1)] : 0xffu;
-      if (wave_ballot(isUnk) == 0) continue;
+      const i32 ep = act ? ni[k].eptr : 0;
+      const u32 cls = ep < 0 ? (u32)(-1 - ep) : 0xffu;
+      if (wave_ballot(ep < 0) == 0) continue;
 #pragma unroll
       for (int c = 0; c < kMaxUnkMakers; ++c)
         if ((u32)c < rk.n) ubase[c] += (u32)popc64(wave_ballot(cls == (u32)c));
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
       NodeInfo x = act ? ni[k] : NodeInfo{0, 0, 0};
       const bool isUnk = act && x.eptr < 0;
       if (wave_ballot(isUnk) != 0) {
-        const u32 cls = isUnk ? (u32)rk.rank[na[k].maker & (kMaxUnkMakers - 1)] : 0xffu;
+        const u32 cls = isUnk ? (u32)(-1 - x.eptr) : 0xffu;
         u32 mine = 0;
 #pragma unroll
         for (int c = 0; c < kMaxUnkMakers; ++c) {
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
     u32 ubase[kMaxUnkMakers];
     for (int c = 0; c < kMaxUnkMakers; ++c) ubase[c] = 0;
     for (u32 k = 2; k + 1 < N; ++k)
-      if (ni[k].eptr < 0) ubase[rk.rank[na[k].maker & (kMaxUnkMakers - 1)] & (kMaxUnkMakers - 1)] += 1;
+      if (ni[k].eptr < 0) ubase[(u32)(-1 - ni[k].eptr) & (kMaxUnkMakers - 1)] += 1;
     for (u32 c = 0, acc = 0; c < (u32)kMaxUnkMakers; ++c) {
       const u32 v = ubase[c];
       ubase[c] = acc;
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
     for (u32 k = 2; k + 1 < N; ++k) {
       NodeInfo x = ni[k];
       if (x.eptr < 0) {
-        x.eptr = ~(i32)(ubase[rk.rank[na[k].maker & (kMaxUnkMakers - 1)] & (kMaxUnkMakers - 1)]++);
+        x.eptr = ~(i32)(ubase[(u32)(-1 - x.eptr) & (kMaxUnkMakers - 1)]++);
         ni[k] = x;
       }
       ecnt[x.end + 2] += 1;

@@ -163,6 +163,9 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   const int lane = (int)(threadIdx.x & 63);
   const u32 s = blockIdx.x * kRnnPrepWaves + wv;
   if (s >= B.n_sent) return;
+  // hidden-state rows of the sentence (rnn_rows, scanned into rnn_rowbase): every sentence owns at least its
+  // parking row, sentences with an RNN lattice get parking + BOS + one row per rnn node (end of this kernel)
+  if (lane == 0) B.rnn_rows[s] = 1;
   if (B.sent_status[s] != ST_OK) return;
   const u32 off = B.byte_off[s];
   const u32 bb0 = off + 4 * s;
@@ -354,6 +357,19 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       g_len[q] = rn_len[q];
     }
     for (u32 q = lane; q <= bE; q += 64) g_cnt[q] = rn_cnt[q];
+  }
+  // dense hidden-state rows: node idx of boundary b lives in row rnn_noff[b] + idx of the sentence's slice of
+  // rnn_ctx; row 0 = parking row (boundary 0), row 1 = BOS state (boundary 1), then the rnn nodes in boundary order
+  {
+    u32 carry = 0;
+    for (u32 b0 = 0; b0 <= bE; b0 += 64) {
+      const u32 b = b0 + (u32)lane;
+      const u32 c = b > bE ? 0u : b < 2 ? 1u : rn_cnt[b];
+      const u32 incl = wave_scan_incl_u32(c, lane);
+      if (b <= bE) B.rnn_noff[bb0 + b] = carry + incl - c;
+      carry += wave_shfl_u32(incl, 63);
+    }
+    if (lane == 0) B.rnn_rows[s] = carry;
   }
 }
 
@@ -637,15 +653,20 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
     const u32 bb0 = B.byte_off[s] + 4 * s;
     const u32 bE = n + 2;
     own = own && n != 0 && B.bnd_ngb[bb0 + bE] != 0;
-    rn_ctx[g] = B.rnn_ctx + (B.rnn_cpbase[s] + 3ull * s) * (u64)G * EP;   // (not own: some sentence's row 0 serves as the parking row)
+    rn_ctx[g] = B.rnn_ctx + B.rnn_rowbase[s] * (u64)EP;   // (not own: some sentence's row 0 serves as the parking row)
     nchain[g] = 0;
     const u32 nq = (bE + 1) * (u32)G;
     const u32* rn_cnt = B.rnn_cnt + bb0;
     if (own && rnn_stageable(bE, G, cfg.beam, B.sent_nodes[s])) {
       const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
       const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
+      // predecessors as hidden-state ROWS (rnn_noff): handle pb * G + pidx -> rnn_noff[pb] + pidx
+      const u32* rn_noff = B.rnn_noff + bb0;
+      const u32 invG = small_div_inv((u32)G);
       for (u32 q = lane; q < nq; q += 64) {
-        l_prev_all[g][wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
+        const u32 hp = rn_prev[q];   // (a handle < nq for every rnn node; anything for the unused slots, the BOS node's "none")
+        const u32 pb = hp < nq ? small_div(hp, invG) : 0u;
+        l_prev_all[g][wv][q] = hp < nq ? (u16)(rn_noff[pb] + (hp - pb * (u32)G)) : (u16)0;
         l_id_all[g][wv][q] = rn_id[q];
       }
       // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
@@ -657,7 +678,7 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
           const float x = 0.f + embT[i];
           v = sigmoid_ref(x, s_exptab);
         }
-        rn_ctx[g][(u64)1 * G * EP + i] = v;
+        rn_ctx[g][(u64)1 * EP + i] = v;   // row 1
       }
       // lane b lists the rnn nodes of boundary b at the offset an exclusive scan gives it
       const u32 bq = (u32)lane;
@@ -702,11 +723,12 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
   // loads of group g's round r: predecessor's context (this lane owns elements lane and lane + 64) and embedding row
   auto fetch = [&](int g, u32 r) {
     u32 eid = 0;
-    q1[g] = hnd1[g] = 0;
+    q1[g] = hnd1[g] = 0;   // (rows: the node of round r is row 2 + r, hnd1 the row of its predecessor; row 0 parks)
     if (r < nchain[g]) {
-      q1[g] = l_node_all[g][wv][r];
-      hnd1[g] = l_prev_all[g][wv][q1[g]];
-      const i32 id = l_id_all[g][wv][q1[g]];
+      const u32 qh = l_node_all[g][wv][r];
+      q1[g] = 2 + r;
+      hnd1[g] = l_prev_all[g][wv][qh];
+      const i32 id = l_id_all[g][wv][qh];
       eid = id == -1 ? 0u : (u32)id;
     }
 #pragma unroll
@@ -853,13 +875,14 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
   const u32* conn = B.rnn_conn + (u64)bb0 * G;
   const u32* assign = B.rnn_assign + (u64)bb0 * G;
   const u32* g_len = B.rnn_nlen + (u64)bb0 * G;
-  float* rn_ctx = B.rnn_ctx + (B.rnn_cpbase[s] + 3ull * s) * (u64)G * EP;
+  float* rn_ctx = B.rnn_ctx + B.rnn_rowbase[s] * (u64)EP;   // the sentence's hidden-state rows (rnn_noff)
 
   // the per-node fields the boundary loop depends on are staged in LDS when they fit
   constexpr u32 kCap = kRnnStageCap, kCapB = kRnnStageCapB;
   __shared__ u16 l_prev_all[kWaves][kCap];
   __shared__ i32 l_id_all[kWaves][kCap];
   __shared__ u8 l_cnt_all[kWaves][kCapB];
+  __shared__ u16 l_noff_all[kWaves][kCapB];
   // per connection (boundary, path): lattice node | slot << 16 | rnn node << 22 | gbeam index << 27, perceptron score cell
   __shared__ u32 l_conn_all[kWaves][kCap];
   __shared__ float l_cell0_all[kWaves][kCap];
@@ -888,7 +911,10 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
       l_prev_all[wv][q] = (u16)rn_prev[q];   // handles are < nq; the BOS node's "none" is never followed
       l_id_all[wv][q] = rn_id[q];
     }
-    for (u32 q = lane; q <= bE; q += 64) l_cnt_all[wv][q] = (u8)rn_cnt[q];
+    for (u32 q = lane; q <= bE; q += 64) {
+      l_cnt_all[wv][q] = (u8)rn_cnt[q];
+      l_noff_all[wv][q] = (u16)B.rnn_noff[bb0 + q];
+    }
     rn_id = l_id_all[wv];
     // connections: every load below is independent, so they are all in flight together
     const u32* g_gi = B.rnn_gi + (u64)bb0 * G;
@@ -901,6 +927,17 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
   }
   const u32* l_conn = l_conn_all[wv];
   const float* l_cell0 = l_cell0_all[wv];
+  // hidden-state row of rnn-node handle h = b * G + idx
+  const u32 invG = small_div_inv((u32)G);
+  const u32* g_noff = B.rnn_noff + bb0;
+  auto ctx_row = [&](u32 h) -> u32 {
+    if (inLds) {
+      const u32 hb = small_div(h, invG);   // (staged: h < kRnnStageCap)
+      return (u32)l_noff_all[wv][hb] + (h - hb * (u32)G);
+    }
+    const u32 hb = h / (u32)G;
+    return g_noff[hb] + (h - hb * (u32)G);
+  };
   float prevT = 0.f;  // running total of this lane's path (adjustBeamScores), BOS element total = 0
   JPP_RPROF_DECL;
   JPP_RPROF(0);
@@ -914,7 +951,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
       float x = 0.f + embT[i];
       v = sigmoid_ref(x, s_exptab);
     }
-    if (MODE != 2) rn_ctx[(u64)1 * G * EP + i] = v;   // (k_rnn_chain made the staged sentences' BOS state)
+    if (MODE != 2) rn_ctx[(u64)1 * EP + i] = v;   // row 1 (k_rnn_chain made the staged sentences' BOS state)
   }
   wave_sync();
   float* l_mx = l_mx_all[wv];
@@ -1021,7 +1058,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
             for (int j = 0; j < J; ++j)
               ctx[p][j] = rel == 0 ? lastOut[0][j] : rel == 1 ? lastOut[1][j] : rel == 2 ? lastOut[2][j] : lastOut[3][j];
           } else {
-            const float* cp = rn_ctx + (u64)hnd * EP + (u32)lane * J;
+            const float* cp = rn_ctx + (u64)ctx_row(hnd) * EP + (u32)lane * J;
 #pragma unroll
             for (int j = 0; j < J; ++j) ctx[p][j] = cp[j];
           }
@@ -1045,7 +1082,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
 #pragma unroll
         for (int p = 0; p < kRnnCN; ++p) {
           if (p < cn) {
-            float* op = rn_ctx + ((u64)b * G + c0 + p) * EP + (u32)lane * J;
+            float* op = rn_ctx + (u64)ctx_row(b * (u32)G + c0 + (u32)p) * EP + (u32)lane * J;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
               const u32 i = (u32)lane * J + j;
@@ -1081,7 +1118,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
           score = 0.f - nceConst;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
         } else {
           const u32 eid = id == -1 ? 0u : (u32)id;
-          score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)l_prev[q] * EP, E);
+          score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)ctx_row(l_prev[q]) * EP, E);
           score += l_mx[q];
           score -= nceConst;
         }
@@ -1163,7 +1200,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
             const u32 hnd = rn_prev[(u64)b * G + c0 + p];
             const i32 id = rn_id[(u64)b * G + c0 + p];
             const u32 eid = id == -1 ? 0u : (u32)id;
-            const float* cp = rn_ctx + (u64)hnd * EP + (u32)lane * J;
+            const float* cp = rn_ctx + (u64)ctx_row(hnd) * EP + (u32)lane * J;
 #pragma unroll
             for (int j = 0; j < J; ++j) ctx[p][j] = cp[j];
 #pragma unroll
@@ -1186,7 +1223,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
             score = 0.f - nceConst;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
           } else {
             const u32 eid = id == -1 ? 0u : (u32)id;
-            score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)rn_prev[(u64)b * G + c0 + x] * EP, E);
+            score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)ctx_row(rn_prev[(u64)b * G + c0 + x]) * EP, E);
             float me = mw[0];
 #pragma unroll
             for (u32 i = 1; i < 4; ++i)
@@ -1213,7 +1250,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
 #pragma unroll
           for (int p = 0; p < kRnnCN; ++p) {
             if (p < cn) {
-              float* op = rn_ctx + ((u64)b * G + c0 + p) * EP + (u32)lane * J;
+              float* op = rn_ctx + (u64)ctx_row(b * (u32)G + c0 + (u32)p) * EP + (u32)lane * J;
 #pragma unroll
               for (int j = 0; j < J; ++j) {
                 u32 i = (u32)lane * J + j;

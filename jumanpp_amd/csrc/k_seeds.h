@@ -26,13 +26,43 @@
 
 namespace jpp {
 
-struct SentView {
+// The decoded sentence as the makers see it (`V` below): in HBM, or -- ordinary sentences -- a copy in LDS made once per
+// workgroup.  The emit pass alone issued ~175 dependent vector-memory reads per wavefront, most of them one lane
+// looking at the class / codepoint / bytes of a neighbouring position; from LDS they cost a tenth of an L2 round trip.
+struct SentViewG {
   const u8* txt;     // sentence bytes
   const u32* cp;     // codepoints
   const i32* cls;    // classes
   const u16* boff;   // byte offsets (n+1 entries)
   u32 n;
 };
+struct SentViewL {
+  const u8 JPP_LDS* txt;
+  const u32 JPP_LDS* cp;
+  const i32 JPP_LDS* cls;
+  const u16 JPP_LDS* boff;
+  u32 n;
+};
+constexpr u32 kSentLdsCp = 128, kSentLdsBytes = 512;   // sentences up to this size are staged in LDS
+struct SentLds {
+  u32 cp[kSentLdsCp];
+  i32 cls[kSentLdsCp];
+  u16 boff[kSentLdsCp + 2];
+  u8 txt[kSentLdsBytes + 8];
+};
+// (all lanes of the workgroup call; `bytes` = byte length of the sentence)
+__device__ __forceinline__ void stage_sentence(SentLds& L, const SentViewG& S, u32 bytes) {
+  for (u32 i = threadIdx.x; i < S.n; i += blockDim.x) {
+    L.cp[i] = S.cp[i];
+    L.cls[i] = S.cls[i];
+  }
+  for (u32 i = threadIdx.x; i <= S.n; i += blockDim.x) L.boff[i] = S.boff[i];
+  for (u32 i = threadIdx.x; i < bytes; i += blockDim.x) L.txt[i] = S.txt[i];
+  __syncthreads();
+}
+__device__ __forceinline__ SentViewL lds_view(const SentLds& L, u32 n) {
+  return SentViewL{as_lds(L.txt), as_lds(L.cp), as_lds(L.cls), as_lds(L.boff), n};
+}
 
 struct SeedSink {
   bool emit;
@@ -54,26 +84,31 @@ struct SeedSink {
     if (cnt) mark_end(e);
     n += cnt;
   }
-  __device__ __forceinline__ void unk(i32 tmpl, i32 hash, i32 ph0, i32 ph1, u32 maker, u32 s, u32 e) {
+  // `rank`: the maker's position in the creation sequence; the provisional entry pointer -(1 + rank) carries it to
+  // k_ends, which numbers the UNK nodes maker by maker
+  __device__ __forceinline__ void unk(i32 tmpl, i32 hash, i32 ph0, i32 ph1, u32 maker, i32 rank, u32 s, u32 e) {
     mark_end(e);
     if (emit) {
-      ni[n] = NodeInfo{-1, (u16)s, (u16)e};  // final ~index is assigned by k_ends
+      ni[n] = NodeInfo{-(1 + rank), (u16)s, (u16)e};  // final ~index is assigned by k_ends
       na[n] = NodeAux{tmpl, hash, (u16)ph0, (u16)ph1, (u16)maker, 0};
     }
     ++n;
   }
 };
 
-__device__ __forceinline__ int step_cp(const DevModel& M, const SentView& S, TrieCursor& c, u32 j) {
+template <typename V>
+__device__ __forceinline__ int step_cp(const DevModel& M, const V& S, TrieCursor& c, u32 j) {
   return trie_step(as_global(M.trie), c, S.txt + S.boff[j], (int)(S.boff[j + 1] - S.boff[j]));
 }
 
-__device__ __forceinline__ i32 surface_hash(const SentView& S, u32 s, u32 e) {
+template <typename V>
+__device__ __forceinline__ i32 surface_hash(const V& S, u32 s, u32 e) {
   return unk_string_hash(S.txt + S.boff[s], (u32)(S.boff[e] - S.boff[s]));
 }
 
 // makePtr(surface, conf, notPrefix)
-__device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, const SentView& S,
+template <typename V>
+__device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, const V& S,
                                          SeedSink& out, u32 s, u32 e, bool notPrefix) {
   if (!out.emit) {
     out.mark_end(e);
@@ -82,7 +117,7 @@ __device__ __forceinline__ void emit_unk(const DevModel& M, const UnkMaker& mk, 
   }
   i32 ph[2] = {0, 0};
   if (mk.placeholder >= 0 && mk.placeholder < 2) ph[mk.placeholder] = notPrefix ? 1 : 0;
-  out.unk(mk.pattern_ptr, surface_hash(S, s, e), ph[0], ph[1], (u32)mk.spec_index, s, e);
+  out.unk(mk.pattern_ptr, surface_hash(S, s, e), ph[0], ph[1], (u32)mk.spec_index, mk.rank, s, e);
 }
 
 // expand the entry-pointer list at trie value `v`
@@ -126,7 +161,8 @@ __device__ __forceinline__ int walk_status(const WalkInfo& w, u32 len) {
 
 // `rec` (count pass): where to record the walk for the emit passes.  The record is written straight to
 // memory: a local WalkCache indexed by the running key count would live in scratch.
-__device__ __forceinline__ WalkInfo dic_seeds(const DevModel& M, const SentView& S, u32 i, SeedSink& out,
+template <typename V>
+__device__ __forceinline__ WalkInfo dic_seeds(const DevModel& M, const V& S, u32 i, SeedSink& out,
                                               WalkCache* rec = nullptr) {
   TrieCursor c{0, 0};
   WalkInfo w{0, 0, true};
@@ -172,7 +208,8 @@ __device__ __forceinline__ WalkInfo dic_seeds_replay(const DevModel& M, const Wa
   return w;
 }
 
-__device__ __forceinline__ void single_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+template <typename V>
+__device__ __forceinline__ void single_maker(const DevModel& M, const UnkMaker& mk, const V& S,
                                              u32 i, const WalkInfo& w, SeedSink& out) {
   if ((S.cls[i] & mk.char_class) == 0) return;
   int st;
@@ -186,7 +223,8 @@ __device__ __forceinline__ void single_maker(const DevModel& M, const UnkMaker& 
   emit_unk(M, mk, S, out, i, i + 1, st == TRIE_NONODE);
 }
 
-__device__ __forceinline__ void chunking_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+template <typename V>
+__device__ __forceinline__ void chunking_maker(const DevModel& M, const UnkMaker& mk, const V& S,
                                                u32 i, const WalkInfo& w, SeedSink& out) {
   if ((S.cls[i] & mk.char_class) == 0) return;
   TrieCursor c{0, 0};
@@ -206,9 +244,11 @@ __device__ __forceinline__ void chunking_maker(const DevModel& M, const UnkMaker
 }
 
 // ---- numeric ---------------------------------------------------------------
-__device__ __forceinline__ bool cls_has(const SentView& S, u32 k, i32 mask) { return (S.cls[k] & mask) != 0; }
+template <typename V>
+__device__ __forceinline__ bool cls_has(const V& S, u32 k, i32 mask) { return (S.cls[k] & mask) != 0; }
 
-__device__ __forceinline__ u32 num_check_suffix(const SentView& S, u32 start, u32 pos) {
+template <typename V>
+__device__ __forceinline__ u32 num_check_suffix(const V& S, u32 start, u32 pos) {
   // suffixPatterns キロ メガ ギガ テラ ミリ
   const u32 pats[5][2] = {{U'キ', U'ロ'}, {U'メ', U'ガ'}, {U'ギ', U'ガ'}, {U'テ', U'ラ'}, {U'ミ', U'リ'}};
   pos &= 0xffff;
@@ -224,7 +264,8 @@ __device__ __forceinline__ u32 num_check_suffix(const SentView& S, u32 start, u3
   return 0;
 }
 
-__device__ __forceinline__ u32 num_check_prefix(const SentView& S, u32 start, u32 pos) {
+template <typename V>
+__device__ __forceinline__ u32 num_check_prefix(const V& S, u32 start, u32 pos) {
   const u32 pats[3] = {U'数', U'何', U'幾'};
   for (int p = 0; p < 3; ++p) {
     u32 suffixLength = num_check_suffix(S, start, pos + 1) & 0xffff;
@@ -235,7 +276,8 @@ __device__ __forceinline__ u32 num_check_prefix(const SentView& S, u32 start, u3
   return 0;
 }
 
-__device__ __forceinline__ u32 num_check_interfix(const SentView& S, u32 start, u32 pos, i32 cc) {
+template <typename V>
+__device__ __forceinline__ u32 num_check_interfix(const V& S, u32 start, u32 pos, i32 cc) {
   u32 rest = S.n - (start + pos);
   if (pos > 0) {
     // ぶんの
@@ -250,7 +292,8 @@ __device__ __forceinline__ u32 num_check_interfix(const SentView& S, u32 start, 
   return 0;
 }
 
-__device__ __forceinline__ u32 num_check_comma(const SentView& S, u32 start, u32 pos) {
+template <typename V>
+__device__ __forceinline__ u32 num_check_comma(const V& S, u32 start, u32 pos) {
   u32 posComma = (start + pos) & 0xffff;
   if (pos == 0) return 0;
   if (!cls_has(S, posComma, CC_COMMA)) return 0;
@@ -261,7 +304,8 @@ __device__ __forceinline__ u32 num_check_comma(const SentView& S, u32 start, u32
   return k == 3 ? 1 : 0;
 }
 
-__device__ __forceinline__ u32 num_check_period(const SentView& S, u32 start, u32 pos, i32 cc) {
+template <typename V>
+__device__ __forceinline__ u32 num_check_period(const V& S, u32 start, u32 pos, i32 cc) {
   u32 pp = start + pos;
   if (pos == 0) return 0;
   if (!cls_has(S, pp, CC_FAMILY_NUM_PERIOD)) return 0;
@@ -270,7 +314,8 @@ __device__ __forceinline__ u32 num_check_period(const SentView& S, u32 start, u3
   return 0;
 }
 
-__device__ __forceinline__ u32 num_find_longest(const SentView& S, u32 start, i32 cc) {
+template <typename V>
+__device__ __forceinline__ u32 num_find_longest(const V& S, u32 start, i32 cc) {
   u32 pos = 0;
   for (pos = 0; pos <= 64 && start + pos < S.n; pos = (pos + 1) & 0xffff) {
     if (!cls_has(S, start + pos, cc)) {
@@ -313,7 +358,8 @@ __device__ __forceinline__ bool dic_pattern_matches(const DevModel& M, const Unk
   return match;
 }
 
-__device__ __forceinline__ void numeric_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+template <typename V>
+__device__ __forceinline__ void numeric_maker(const DevModel& M, const UnkMaker& mk, const V& S,
                                               u32 i, const WalkInfo& w, SeedSink& out) {
   u32 length = num_find_longest(S, i, mk.char_class);
   if (length == 0) return;
@@ -345,7 +391,8 @@ __device__ __forceinline__ void numeric_maker(const DevModel& M, const UnkMaker&
 }
 
 // ---- onomatopoeia ----------------------------------------------------------
-__device__ __forceinline__ u32 onoma_find(const SentView& S, u32 start, i32 cc) {
+template <typename V>
+__device__ __forceinline__ u32 onoma_find(const V& S, u32 start, i32 cc) {
   if (start + 4 >= S.n) return 0;
   if ((S.cls[start] & cc) == 0) return 0;
   i32 c1 = S.cls[start];
@@ -366,7 +413,8 @@ __device__ __forceinline__ u32 onoma_find(const SentView& S, u32 start, i32 cc) 
   return pattern;
 }
 
-__device__ __forceinline__ void onoma_maker(const DevModel& M, const UnkMaker& mk, const SentView& S,
+template <typename V>
+__device__ __forceinline__ void onoma_maker(const DevModel& M, const UnkMaker& mk, const V& S,
                                             u32 i, SeedSink& out) {
   u32 pattern = onoma_find(S, i, mk.char_class);
   if (pattern == 0) return;
@@ -382,7 +430,8 @@ __device__ __forceinline__ void onoma_maker(const DevModel& M, const UnkMaker& m
   }
 }
 
-__device__ __forceinline__ void run_maker(const DevModel& M, const UnkMaker& mk, const SentView& S, u32 i,
+template <typename V>
+__device__ __forceinline__ void run_maker(const DevModel& M, const UnkMaker& mk, const V& S, u32 i,
                                           const WalkInfo& w, SeedSink& out) {
   switch (mk.type) {
     case UNK_SINGLE: single_maker(M, mk, S, i, w, out); break;
@@ -417,7 +466,8 @@ __device__ __forceinline__ int utf8_encode3(u32 cp, u8* b) {
 }
 
 // returns number of results or -1 on capacity overflow; results are sorted and uniqued
-__device__ inline int norm_lookup(const DevModel& M, const SentView& S, const ClNodes* cl, u32 start,
+template <typename V>
+__device__ inline int norm_lookup(const DevModel& M, const V& S, const ClNodes* cl, u32 start,
                                   NormResult* res) {
   NormState a[kMaxNormStates], b[kMaxNormStates];
   NormState* s1 = a;
@@ -509,7 +559,8 @@ __device__ inline int norm_lookup(const DevModel& M, const SentView& S, const Cl
 
 // makePtr(surface, conf, eptr, feature): entry row of `eptr` with the replace
 // fields overwritten by the hash of the *input* surface, placeholder = flags
-__device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk, const SentView& S,
+template <typename V>
+__device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk, const V& S,
                                           SeedSink& out, u32 s, const NormResult& r) {
   if (!out.emit) {
     ++out.n;
@@ -517,24 +568,16 @@ __device__ __forceinline__ void norm_emit(const DevModel& M, const UnkMaker& mk,
   }
   i32 ph[2] = {0, 0};
   if (mk.placeholder >= 0 && mk.placeholder < 2) ph[mk.placeholder] = (i32)r.flags;
-  out.unk(r.ptr, surface_hash(S, s, r.end), ph[0], ph[1], (u32)M.makers[M.norm_maker].spec_index, s, r.end);
+  out.unk(r.ptr, surface_hash(S, s, r.end), ph[0], ph[1], (u32)M.makers[M.norm_maker].spec_index, M.makers[M.norm_maker].rank, s, r.end);
 }
 
 // MODE 0: count (writes pos_cntA / pos_cnt2); MODE 1: emit stage 1; MODE 2: emit stage 1+2
 // for sentences with the stage-2 flag (into their relocated region).
 // (the trie walk is a chain of dependent loads: 8 wavefronts per SIMD at 64 VGPRs and a few spilled registers beat
 // 4 at 97 -- count pass 642 -> 491 us, emit pass 722 -> 668 us; the rarely taken stage-2 pass gains nothing)
-template <int MODE>
-__global__ void __launch_bounds__(64) JPP_WAVES_PER_EU(MODE == 2 ? 4 : 8) k_seeds(Batch B, const DevModel* __restrict__ Mp) {
-  const DevModel& M = *Mp;
-  u32 s = blockIdx.x;
-  if (B.sent_status[s] != ST_OK) return;
-  if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
-  if (MODE == 1 && (B.sent_flags[s] & 2) != 0) return;  // known from the count pass to need stage 2: emitted once, by MODE 2
-  u32 off = B.byte_off[s];
-  u32 g0 = off + s;
-  u32 bb0 = off + 4 * s;
-  SentView S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, B.sent_ncp[s]};
+// the seeds of one sentence (see k_seeds), on either view of it
+template <int MODE, typename V>
+__device__ __forceinline__ void seeds_of_sentence(const Batch& B, const DevModel& M, const V& S, u32 s, u32 g0, u32 bb0) {
   u64 nbase = MODE == 0 ? 0 : B.node_base[s];
   for (u32 i = threadIdx.x; i < S.n; i += blockDim.x) {
     SeedSink out;
@@ -572,33 +615,50 @@ __global__ void __launch_bounds__(64) JPP_WAVES_PER_EU(MODE == 2 ? 4 : 8) k_seed
   }
 }
 
-// normalize maker: same modes.  Its nodes are the last stage-1 nodes of a start.
-template <int MODE>
-__global__ void k_norm(Batch B, const DevModel* __restrict__ Mp) {
+template <int MODE, int WAVES = (MODE == 2 ? 4 : 8)>
+__global__ void __launch_bounds__(64) JPP_WAVES_PER_EU(WAVES) k_seeds(Batch B, const DevModel* __restrict__ Mp) {
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
+  if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
+  if (MODE == 1 && (B.sent_flags[s] & 2) != 0) return;  // known from the count pass to need stage 2: emitted once, by MODE 2
   u32 off = B.byte_off[s];
   u32 g0 = off + s;
   u32 bb0 = off + 4 * s;
-  u32 n = B.sent_ncp[s];
-  bool applicable = M.norm_maker >= 0 && (B.sent_flags[s] & 1);
-  if (MODE == 0 && !applicable) {
-    for (u32 i = threadIdx.x; i < n; i += blockDim.x) B.pos_cntN[g0 + i] = 0;
-    return;
+  const u32 bytes = B.byte_off[s + 1] - off;
+  SentViewG S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, B.sent_ncp[s]};
+  __shared__ SentLds L;
+  if (S.n <= kSentLdsCp && bytes <= kSentLdsBytes) {
+    stage_sentence(L, S, bytes);
+    seeds_of_sentence<MODE>(B, M, lds_view(L, S.n), s, g0, bb0);
+  } else {
+    seeds_of_sentence<MODE>(B, M, S, s, g0, bb0);
   }
-  if (!applicable) return;
-  if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
-  if (MODE == 1 && (B.sent_flags[s] & 2) != 0) return;
-  SentView S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, n};
+}
+
+// normalize maker: same modes.  Its nodes are the last stage-1 nodes of a start.
+template <int MODE, typename V>
+__device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel& M, const V& S, u32 s, u32 g0, u32 bb0, u32 n) {
   const UnkMaker& mk = M.makers[M.norm_maker];
   u64 nbase = MODE == 0 ? 0 : B.node_base[s];
   static_assert(sizeof(NormResult) == 8, "cached as one 64-bit word");
   NormResult* cache = reinterpret_cast<NormResult*>(B.pos_norm) + (u64)g0 * kNormCache;
+  // Count pass: a traversal from start i only ever looks at the charlattice nodes of the positions i + 1 .. i + d, d
+  // = the depth of the plain dictionary walk from i (the un-normalised state dies with the trie path, and a state
+  // can only leave that path THROUGH a charlattice node).  k_seeds<0> recorded d; sentences of up to 64 codepoints
+  // keep the positions that have charlattice nodes in one ballot, and most starts are dismissed without a walk.
+  u64 clmask = ~u64{0};
+  if (MODE == 0 && n <= 64) clmask = wave_ballot(threadIdx.x < n && B.cl_nodes[g0 + threadIdx.x].n != 0);
   for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
     NormResult res[kMaxNormResults];
     int nr;
     if (MODE == 0) {
+      const u32 depth = B.pos_walk[g0 + i].ok_len;
+      const bool reachable = depth >= 63 || i >= 63 || ((clmask >> (i + 1)) & ((u64{1} << depth) - 1)) != 0;
+      if (!reachable) {
+        B.pos_cntN[g0 + i] = 0;
+        continue;
+      }
       nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
       if (nr < 0) {
         atomicMax(&B.sent_status[s], (i32)ST_CAPACITY);
@@ -631,6 +691,34 @@ __global__ void k_norm(Batch B, const DevModel* __restrict__ Mp) {
       out.n = 0;
       for (int k = 0; k < nr; ++k) norm_emit(M, mk, S, out, i, res[k]);
     }
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) k_norm(Batch B, const DevModel* __restrict__ Mp) {
+  const DevModel& M = *Mp;
+  u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  u32 off = B.byte_off[s];
+  u32 g0 = off + s;
+  u32 bb0 = off + 4 * s;
+  u32 n = B.sent_ncp[s];
+  bool applicable = M.norm_maker >= 0 && (B.sent_flags[s] & 1);
+  if (MODE == 0 && !applicable) {
+    for (u32 i = threadIdx.x; i < n; i += blockDim.x) B.pos_cntN[g0 + i] = 0;
+    return;
+  }
+  if (!applicable) return;
+  if (MODE == 2 && (B.sent_flags[s] & 2) == 0) return;
+  if (MODE == 1 && (B.sent_flags[s] & 2) != 0) return;
+  const u32 bytes = B.byte_off[s + 1] - off;
+  SentViewG S{B.text + off, B.cp_code + g0, B.cp_class + g0, B.cp_boff + g0, n};
+  __shared__ SentLds L;
+  if (n <= kSentLdsCp && bytes <= kSentLdsBytes) {
+    stage_sentence(L, S, bytes);
+    norm_of_sentence<MODE>(B, M, lds_view(L, n), s, g0, bb0, n);
+  } else {
+    norm_of_sentence<MODE>(B, M, S, s, g0, bb0, n);
   }
 }
 
