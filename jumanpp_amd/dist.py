@@ -48,6 +48,33 @@ def gather_packed(offsets, items, dst=0):
     return out
 
 
+def gather_packed_fixed(offsets, items, dst=0):
+    """The same gather without a host sync: every rank contributes its WHOLE packed buffer -- offsets int32 [n+1] and
+    the items array at its fixed capacity int32 [cap, 2], both the same shape on every rank (the bench's case: equal
+    batch sizes) -- so no size has to cross to the host first.  What is sent beyond the used prefix is padding
+    (~1.6x the payload at 24 morphemes per 40-codepoint sentence: 21 MB per rank and step, nothing for xGMI).
+    Returns on `dst` a list of (offsets, items) per rank; items[:offsets[-1]] is the valid part."""
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    dev = offsets.device
+    n1 = offsets.numel()
+    flat = items.reshape(-1)
+    length = n1 + flat.numel()
+    key = ('fixed', str(dev), world, length)
+    state = _bufs.get(key)
+    if state is None:
+        state = _bufs[key] = {'send': torch.empty(length, dtype=torch.int32, device=dev),
+                              'recv': [torch.empty(length, dtype=torch.int32, device=dev) for _ in range(world)]
+                              if rank == dst else None}
+    send = state['send']
+    send[:n1].copy_(offsets)
+    send[n1:].copy_(flat)
+    dist.gather(send, state['recv'], dst=dst)
+    if rank != dst:
+        return None
+    return [(b[:n1], b[n1:].reshape(-1, 2)) for b in state['recv']]
+
+
 def shard_range(n, rank, world):
     """contiguous block partition by sentence index"""
     per = (n + world - 1) // world

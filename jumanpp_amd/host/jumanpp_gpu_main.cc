@@ -15,6 +15,18 @@
 // (jumanpp.cc:156-179) by one analysis thread per GPU: batches are dealt to the devices in turn, every
 // device has its own pair of analyzers, and the formatter consumes the batches in input order, so the
 // output is the same byte string for any device list.  Sentences are independent: no collective.
+//
+// Files in, file out (INPUT... and -o OUT, the bulk case) takes the SHARDED pipeline: no stage is shared between
+// devices.  The inputs are mapped; one scanner cuts them into batches of whole examples at newline boundaries
+// (memchr, ~10 GB/s) and deals them to the devices; every device has its own thread that splits its batch into
+// lines and analyses it, its own format workers, and its own writer, which pwrite()s the batch at the offset a
+// tiny sequencer hands out in input order (the prefix sum of the formatted sizes).  Everything else (stdin,
+// stdout, --partial-input, --no-pipeline) keeps the general four-stage pipeline below.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -24,6 +36,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <memory>
 #include <mutex>
@@ -104,6 +117,98 @@ struct Job {
 // the text of one formatted batch, in chunks of consecutive sentences
 struct Formatted {
   std::vector<std::string> text, errors;
+};
+
+// SHARDED pipeline: one batch = a run of whole examples of a mapped input file
+struct ShardJob {
+  size_t seq = 0;              // position in input order
+  const char* data = nullptr;  // the batch's lines, each with its newline (the last one of a file maybe without)
+  size_t bytes = 0;
+  std::vector<StringPiece> inputs, comments;   // per example, pointing into the mapping
+  std::vector<std::pair<size_t, Status>> readErrors;   // (example, status): over-long inputs / comments, sorted
+  int device = 0, analyzer = 0;
+  Status batchStatus;
+  double gpuMs = 0;
+  bool lastReadOk = true;
+  std::vector<std::string> text, errors;   // formatted chunks of consecutive sentences
+  size_t outBytes = 0;
+  uint64_t outOffset = 0;
+};
+
+struct MappedFile {
+  const char* data = nullptr;
+  size_t size = 0;
+  bool open(const std::string& path) {
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+      ::close(fd);
+      return false;
+    }
+    size = (size_t)st.st_size;
+    if (size) {
+      void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (p == MAP_FAILED) {
+        ::close(fd);
+        return false;
+      }
+      madvise(p, size, MADV_SEQUENTIAL);
+      data = static_cast<const char*>(p);
+    }
+    ::close(fd);
+    return true;
+  }
+  ~MappedFile() {
+    if (data) munmap(const_cast<char*>(data), size);
+  }
+};
+
+// a fixed set of workers that run `fn(worker)` together, once per call of run()
+class WorkerPool {
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)> fn_;
+  size_t generation_ = 0, running_ = 0;
+  bool stop_ = false;
+
+ public:
+  explicit WorkerPool(int n) {
+    for (int t = 0; t < n; ++t)
+      threads_.emplace_back([this, t]() {
+        size_t seen = 0;
+        for (;;) {
+          std::function<void(int)> fn;
+          {
+            std::unique_lock<std::mutex> l(mu_);
+            cv_.wait(l, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            fn = fn_;
+          }
+          fn(t);
+          std::lock_guard<std::mutex> l(mu_);
+          if (--running_ == 0) done_.notify_all();
+        }
+      });
+  }
+  void run(std::function<void(int)> fn) {
+    std::unique_lock<std::mutex> l(mu_);
+    fn_ = std::move(fn);
+    running_ = threads_.size();
+    ++generation_;
+    cv_.notify_all();
+    done_.wait(l, [&] { return running_ == 0; });
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+      cv_.notify_all();
+    }
+    for (auto& t : threads_) t.join();
+  }
 };
 
 std::string statusText(const Status& s) {
@@ -414,9 +519,12 @@ int main(int argc, const char** argv) {
     return f;
   };
 
+  // files in, file out: the sharded pipeline (see the head of this file)
+  const bool sharded = conf.pipeline && !conf.partialInput && !conf.inputs.empty() && !conf.output.empty() &&
+                       conf.output != "-" && std::getenv("JUMANPP_GPU_NO_SHARDED") == nullptr;
   std::unique_ptr<std::ofstream> ofile;
   std::ostream* out = &std::cout;
-  if (!conf.output.empty() && conf.output != "-") {
+  if (!sharded && !conf.output.empty() && conf.output != "-") {
     ofile.reset(new std::ofstream(conf.output, std::ios::binary));
     out = ofile.get();
   }
@@ -485,6 +593,260 @@ int main(int argc, const char** argv) {
       std::cerr << "Failed to initialize I/O: " << s << "\n";
       return 1;
     }
+  }
+
+  if (sharded) {
+    Clock clock;
+    // every device's format workers have OutputFormat objects of their own
+    while ((int)formats.size() < nDev * std::max(1, conf.threads / nDev)) {
+      formats.emplace_back(makeFormat(&s));
+      if (!s) {
+        std::cerr << "Failed to initialize I/O: " << s << "\n";
+        return 1;
+      }
+    }
+    std::vector<std::unique_ptr<MappedFile>> maps;
+    for (auto& path : conf.inputs) {
+      maps.emplace_back(new MappedFile());
+      if (!maps.back()->open(path)) {
+        std::cerr << "could not map the input file " << path << "\n";
+        return 1;
+      }
+    }
+    const int ofd = ::open(conf.output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    if (ofd < 0) {
+      std::cerr << "could not open the output file " << conf.output << "\n";
+      return 1;
+    }
+    std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<ShardJob>>>> readQ, fmtQ, writeQ;
+    std::vector<std::unique_ptr<Semaphore>> freeAnalyzers;
+    for (int d = 0; d < nDev; ++d) {
+      readQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(2));
+      fmtQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(1));
+      writeQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(2));
+      freeAnalyzers.emplace_back(new Semaphore(nAnalyzers));
+    }
+    std::atomic<long long> scanUs(0), prepUs(0), formatUs(0), writeUs(0), gpuUs(0);
+    std::vector<double> analyzeMsDev((size_t)nDev, 0.0);
+    auto us = [&]() { return (long long)(clock.ms() * 1000.0); };
+
+    // scanner: batches of conf.batch examples (an example = its "# " comment lines + one other line,
+    // PlainStreamReader::readExample, stream_reader.cc:12-38), dealt to the devices in turn
+    std::thread scanner([&]() {
+      size_t seq = 0;
+      for (auto& mf : maps) {
+        const char* p = mf->data;
+        const char* const end = mf->data + mf->size;
+        while (p < end) {
+          const long long t0 = us();
+          const char* q = p;
+          size_t examples = 0;
+          while (q < end && examples < conf.batch) {
+            const char* nl = static_cast<const char*>(memchr(q, '\n', (size_t)(end - q)));
+            const char* lineEnd = nl ? nl : end;
+            const bool comment = lineEnd - q > 2 && q[0] == '#' && q[1] == ' ';
+            q = nl ? nl + 1 : end;
+            if (!comment || q >= end) ++examples;   // (comment lines at the end of a file: an example with an empty input)
+          }
+          std::unique_ptr<ShardJob> job(new ShardJob());
+          job->seq = seq;
+          job->data = p;
+          job->bytes = (size_t)(q - p);
+          job->device = (int)(seq % (size_t)nDev);
+          ++seq;
+          p = q;
+          scanUs += us() - t0;
+          readQ[job->device]->push(std::move(job));
+        }
+      }
+      for (auto& qd : readQ) qd->close();
+    });
+
+    // per device: split the batch into examples, analyse
+    std::vector<std::thread> gpus;
+    for (int d = 0; d < nDev; ++d) {
+      gpus.emplace_back([&, d]() {
+        std::unique_ptr<ShardJob> job;
+        int next = 0, live = nAnalyzers;
+        while (readQ[d]->pop(&job)) {
+          long long t0 = us();
+          {
+            const char* q = job->data;
+            const char* const end = job->data + job->bytes;
+            StringPiece comment("", 0);
+            while (q < end) {
+              const char* nl = static_cast<const char*>(memchr(q, '\n', (size_t)(end - q)));
+              const char* lineEnd = nl ? nl : end;
+              const StringPiece line(q, (size_t)(lineEnd - q));
+              q = nl ? nl + 1 : end;
+              if (line.size() > 2 && line[0] == '#' && line[1] == ' ') {
+                comment = line;
+                if (q < end) continue;
+                job->inputs.push_back(StringPiece("", 0));   // comment lines at the end of the file
+              } else {
+                job->inputs.push_back(line);
+              }
+              job->comments.push_back(comment);
+              const size_t i = job->inputs.size() - 1;
+              if (comment.size() > maxComment)
+                job->readErrors.emplace_back(i, Status::InvalidParameter() << "Comment size was: " << comment.size() << " which is more than max: " << maxComment);
+              else if (job->inputs[i].size() > maxInput)
+                job->readErrors.emplace_back(i, Status::InvalidParameter() << "Input size was: " << job->inputs[i].size() << " which is more than max: " << maxInput);
+              comment = StringPiece("", 0);
+            }
+            job->lastReadOk = job->readErrors.empty() || job->readErrors.back().first + 1 != job->inputs.size();
+          }
+          prepUs += us() - t0;
+          freeAnalyzers[d]->acquire();
+          job->analyzer = next;
+          const double a0 = clock.ms();
+          if (!analyzers[d][job->analyzer]) {
+            Status made = makeAnalyzer(d, job->analyzer);
+            if (!made) {   // (no HBM for a second copy of the model) carry on with the first analyzer alone
+              analyzers[d][job->analyzer].reset();
+              freeAnalyzers[d]->acquire();
+              live = 1;
+              job->analyzer = 0;
+            }
+          }
+          next = (job->analyzer + 1) % live;
+          {
+            std::vector<StringPiece> pieces(job->inputs);
+            for (auto& e : job->readErrors) pieces[e.first] = StringPiece("", 0);
+            GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
+            job->batchStatus = analyzer.analyzeBatch(pieces, useLattice);
+            float ms[8];
+            analyzer.lastTimings(ms);
+            job->gpuMs = ms[7];
+          }
+          analyzeMsDev[d] += clock.ms() - a0;
+          fmtQ[d]->push(std::move(job));
+        }
+        fmtQ[d]->close();
+      });
+    }
+
+    // sequencer state: batches take their output offset in input order
+    std::mutex seqMu;
+    std::condition_variable seqCv;
+    size_t seqNext = 0;
+    uint64_t outTotal = 0;
+    size_t sentences = 0;
+    int result = 0;
+
+    // per device: format with the device's own workers, take the offset, hand the batch to the device's writer
+    const int perDev = std::max(1, conf.threads / nDev);
+    std::vector<std::thread> formatters;
+    for (int d = 0; d < nDev; ++d) {
+      formatters.emplace_back([&, d]() {
+        WorkerPool pool(perDev);
+        std::unique_ptr<ShardJob> job;
+        const size_t kChunk = 64;
+        while (fmtQ[d]->pop(&job)) {
+          const long long t0 = us();
+          const GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
+          const size_t n = job->inputs.size();
+          const size_t nChunks = (n + kChunk - 1) / kChunk;
+          job->text.assign(nChunks, std::string());
+          job->errors.assign(nChunks, std::string());
+          std::atomic<size_t> nextChunk(0);
+          ShardJob* jp = job.get();
+          pool.run([&, jp](int t) {
+            OutputFormat* format = formats[(size_t)(d * perDev + t) % formats.size()].get();
+            for (size_t c; (c = nextChunk.fetch_add(1)) < nChunks;) {
+              std::string& text = jp->text[c];
+              std::string& errors = jp->errors[c];
+              auto bad = jp->readErrors.begin();
+              while (bad != jp->readErrors.end() && bad->first < c * kChunk) ++bad;
+              for (size_t i = c * kChunk; i < std::min(n, (c + 1) * kChunk); ++i) {
+                if (bad != jp->readErrors.end() && bad->first == i) {
+                  errors += "failed to read an example: " + statusText(bad->second);
+                  ++bad;
+                  continue;
+                }
+                Status st = jp->batchStatus.isOk() ? analyzer.sentenceStatus(i) : jp->batchStatus;
+                if (!st) {
+                  errors += statusText(st);
+                  text.append(emptyResult.data(), emptyResult.size());
+                  continue;
+                }
+                const StringPiece& cm = jp->comments[i];
+                const StringPiece comment = cm.size() < 2 ? StringPiece("") : StringPiece(cm.data() + 2, cm.size() - 2);
+                st = format->format(analyzer, i, comment);
+                if (!st) errors += statusText(st);
+                else {
+                  StringPiece r = format->result();
+                  text.append(r.data(), r.size());
+                }
+              }
+            }
+          });
+          job->outBytes = 0;
+          for (auto& t : job->text) job->outBytes += t.size();
+          freeAnalyzers[d]->release();   // the analyzer's results are no longer needed
+          formatUs += us() - t0;
+          {
+            std::unique_lock<std::mutex> l(seqMu);
+            seqCv.wait(l, [&] { return seqNext == job->seq; });
+            job->outOffset = outTotal;
+            outTotal += job->outBytes;
+            sentences += n;
+            gpuUs += (long long)(job->gpuMs * 1000.0);
+            result = job->lastReadOk ? 0 : 1;   // the reference's exit code is that of the last example read
+            for (auto& e : job->errors)
+              if (!e.empty()) std::cerr << e;   // (in input order)
+            ++seqNext;
+            seqCv.notify_all();
+          }
+          writeQ[d]->push(std::move(job));
+        }
+        writeQ[d]->close();
+      });
+    }
+
+    std::atomic<bool> writeFailed(false);
+    std::vector<std::thread> writers;
+    for (int d = 0; d < nDev; ++d) {
+      writers.emplace_back([&, d]() {
+        std::unique_ptr<ShardJob> job;
+        while (writeQ[d]->pop(&job)) {
+          const long long t0 = us();
+          uint64_t off = job->outOffset;
+          for (auto& t : job->text) {
+            size_t done = 0;
+            while (done < t.size()) {
+              ssize_t w = pwrite(ofd, t.data() + done, t.size() - done, (off_t)(off + done));
+              if (w <= 0) {
+                writeFailed = true;
+                break;
+              }
+              done += (size_t)w;
+            }
+            off += t.size();
+          }
+          writeUs += us() - t0;
+        }
+      });
+    }
+    scanner.join();
+    for (auto& t : gpus) t.join();
+    for (auto& t : formatters) t.join();
+    for (auto& t : writers) t.join();
+    ::close(ofd);
+    if (writeFailed) {
+      std::cerr << "write to " << conf.output << " failed\n";
+      return 1;
+    }
+    if (conf.timing) {
+      const double wall = clock.ms();
+      double analyzeMs = 0;
+      for (double v : analyzeMsDev) analyzeMs = std::max(analyzeMs, v);
+      std::cerr << "devices=" << nDev << " sentences=" << sentences << " gpu_ms=" << gpuUs / 1000.0 << " wall_ms=" << wall
+                << " read_ms=" << (scanUs + prepUs) / 1000.0 << " analyze_ms=" << analyzeMs << " format_ms=" << formatUs / 1000.0
+                << " write_ms=" << writeUs / 1000.0 << " threads=" << conf.threads << " pipeline=1 sharded=1 sent_per_s="
+                << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
+    }
+    return result;
   }
 
   // batch j goes to device j mod nDev and comes back through that device's queue: popping the done queues

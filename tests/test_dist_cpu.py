@@ -16,7 +16,7 @@ import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
 import jumanpp_amd as J
-from jumanpp_amd.dist import gather_packed, shard_range
+from jumanpp_amd.dist import gather_packed, gather_packed_fixed, shard_range
 dist.init_process_group('gloo')
 rank, world = dist.get_rank(), dist.get_world_size()
 lines = [l.rstrip('\n') for l in open(%(txt)r, encoding='utf-8')]
@@ -42,6 +42,15 @@ if rank == 0:
     assert torch.equal(cat_items, full_items[:m]), 'gathered morphemes differ'
     assert m > 100
     print('DIST_OK', m)
+# the sync-free variant (equal shapes on every rank: the shards are padded to the same number of sentences)
+per = (len(lines) + world - 1) // world
+sub = lines[lo:hi] + [''] * (per - (hi - lo))
+offs2, items2 = packed(sub)
+got2 = gather_packed_fixed(offs2, items2, dst=0)
+if rank == 0:
+    cat2 = torch.cat([g[1][:int(g[0][-1])] for g in got2])
+    assert torch.equal(cat2, full_items[:m]), 'fixed-capacity gather differs'
+    print('DIST_FIXED_OK')
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -63,4 +72,4 @@ def test_two_rank_sharded_gather_matches_single_process(emu_lib, golden_dir, tmp
                                       stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert 'DIST_OK' in outs[0], outs
+    assert 'DIST_OK' in outs[0] and 'DIST_FIXED_OK' in outs[0], outs

@@ -201,6 +201,57 @@ def test_gpu_cli_devices_list(cli_gpu, ref_tools, tmp_path):
     assert out == ref.stdout
 
 
+def _sharded_input(golden_dir, tmp, copies):
+    """mini.txt a few times over plus comment lines (one at the very end), an empty line and a line that fails"""
+    src = open(os.path.join(golden_dir, 'mini.txt'), 'rb').read()
+    path = os.path.join(tmp, 'sharded_in.txt')
+    with open(path, 'wb') as f:
+        f.write(src * copies)
+        f.write('# S-ID:1 comment\nすごーーい〜かぁっこいいねぇっッ！\n\nx\ty\n'.encode('utf-8') + b'\xe3\x81\n' + b'# trailing comment')
+    return path
+
+
+@pytest.mark.parametrize('model', ['mini.jppmdl', 'mini_rnn.jppmdl'])
+def test_sharded_pipeline_files_in_file_out(cli_emu, ref_tools, golden_dir, tmp_path, model):
+    """INPUT... -o OUT takes the sharded pipeline (mapped input cut at newline boundaries, per-device line splitting,
+    analysis, format workers and pwrite at sequenced offsets): the output file is the reference's stdout for one
+    and for three devices, small and large batches, one and two input files"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    tmp = str(tmp_path)
+    path = _sharded_input(golden_dir, tmp, 2)
+    m = os.path.join(golden_dir, model)
+    ref = _ref_cli(ref_tools, m, [], path)
+    out = os.path.join(tmp, 'o.txt')
+    for dev, batch in (('0', 1000), ('0,1,2', 9)):
+        rc, so, err = _run(cli_emu, ['--model=' + m, '--devices=' + dev, '--batch=%d' % batch, '--timing', '-o', out, path])
+        assert rc == 0 and so == b'', err[-300:]
+        assert b'sharded=1' in err and b'devices=%d ' % len(dev.split(',')) in err
+        assert open(out, 'rb').read() == ref, (dev, batch)
+    two = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + m, path, os.path.join(golden_dir, 'mini.txt')],
+                         capture_output=True).stdout
+    rc, so, err = _run(cli_emu, ['--model=' + m, '--batch=40', '-o', out, path, os.path.join(golden_dir, 'mini.txt')])
+    assert rc == 0 and open(out, 'rb').read() == two
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_pipeline(cli_gpu, ref_tools, tmp_path):
+    """the sharded pipeline on the MI355X box (one GPU: the device list names it twice), RNN model"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_gpu_parity as tg
+    tmp = str(tmp_path)
+    img, lines, _ = tg._fresh_workload(ref_tools, tmp, 30000, 3000, 20, 29, rnn=(128, 8000))
+    path = os.path.join(tmp, 'w.txt')
+    ref = subprocess.run([os.path.join(ref_tools, 'jumanpp_v2'), '--model=' + os.path.join(tmp, 'w.model'), path],
+                         capture_output=True).stdout
+    out = os.path.join(tmp, 'o.txt')
+    for dev, batch in (('0', 1024), ('0,0', 300)):
+        rc, so, err = _run(cli_gpu, ['--model=' + img, '--devices=' + dev, '--batch=%d' % batch, '--timing', '-o', out, path])
+        assert rc == 0 and b'sharded=1' in err, err[-300:]
+        assert open(out, 'rb').read() == ref, dev
+
+
 # ---- the drop-in boundary itself: the reference's UNMODIFIED formatters on a re-materialised Lattice ----
 
 def _shim_check(ref_tools, model, lib, text_path, lattice_n, beams=()):
