@@ -67,7 +67,26 @@ struct UnkMaker {
   i32 tmpl[kMaxDicFeatures];  // decoded template entry row
 };
 
+// Feature descriptors of a spec other than the compiled-in jumandic tables: what the
+// reference's DYNAMIC feature objects are built from when the spec hash does not match its generated code
+// (features_api.cc:20-60).  Table-driven k_t0_dyn / k_sweep<.., DYN> read them; the limits are those of the
+// device layout (entry rows of at most 8 columns, at most kPat patterns referenced by bigrams / trigrams, ...).
+constexpr int kDynMaxPrims = 32, kDynMaxComputes = 32, kDynMaxPatterns = 64, kDynMaxArgs = 8, kDynMaxBranch = 8;
+constexpr int kDynMaxUni = 64, kDynMaxBi = 40, kDynMaxTri = 4;
+struct DevSpec {
+  i32 nprims, ncomputes, npatterns, nstored, nuni, nbi, ntri, pad0;
+  struct Prim { i32 kind, a, b; } prims[kDynMaxPrims];
+  struct Compute { i32 cond, nt, nf; i32 t[kDynMaxBranch]; i32 f[kDynMaxBranch]; } computes[kDynMaxComputes];
+  struct Pattern { i32 nargs; i32 slot; u64 prefix; i32 args[kDynMaxArgs]; } patterns[kDynMaxPatterns];   // slot: stored position or -1
+  struct Uni { u64 prefix; i32 t0; i32 pad; } uni[kDynMaxUni];      // t0: pattern index
+  u64 bi_prefix[kDynMaxBi];
+  u8 bi_t01[kDynMaxBi];        // (t0 slot << 4) | t1 slot
+  u64 tri_prefix[kDynMaxTri];
+  u8 tri_t[kDynMaxTri][4];     // t0, t1, t2 slots
+};
+
 struct DevModel {
+  const DevSpec* spec;       // null: the built-in jumandic tables
   const u32* trie;
   const u8* entry_ptrs;
   const u8* entry_data;

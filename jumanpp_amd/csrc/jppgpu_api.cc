@@ -330,7 +330,8 @@ struct jppgpu_ctx {
   DevModel hmodel{};
   DevModel* dmodel = nullptr;
   UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
-  DevBuf trie, eptrs, edata, weights;
+  DevBuf trie, eptrs, edata, weights, dyn_spec;
+  bool dynamic_spec = false;   // a spec other than the built-in jumandic tables: table-driven kernels
   DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
   DevBuf text, offs;
@@ -371,6 +372,144 @@ void jppgpu_result::bind(HostPool* pool) {
   nb_status.pool = pool; nb_ncp.pool = pool; nb_nnodes.pool = pool; nb_first.pool = pool; nb_eos.pool = pool; nb_items.pool = pool;
 }
 
+namespace {
+// The flattened FeaturesSpec descriptors of a model (jppgpu_model::feature_spec; i32 counts and lists, see
+// include/jppgpu.h) into the device tables of the table-driven kernels.  Returns an empty string or why the spec is
+// outside what those kernels hold.
+std::string parse_feature_spec(const void* blob, size_t bytes, int numFeatures, DevSpec* out) {
+  const i32* p = static_cast<const i32*>(blob);
+  const size_t n = bytes / 4;
+  size_t pos = 0;
+  bool ok = true;
+  auto rd = [&]() -> i32 {
+    if (pos >= n) {
+      ok = false;
+      return 0;
+    }
+    return p[pos++];
+  };
+  auto rdList = [&](std::vector<i32>* v) {
+    const i32 c = rd();
+    v->clear();
+    for (i32 i = 0; ok && i < c; ++i) v->push_back(rd());
+  };
+  std::memset(out, 0, sizeof(*out));
+  std::vector<i32> a, b;
+  const i32 nprims = rd();
+  if (!ok || nprims < 0 || nprims > kDynMaxPrims) return "too many primitive features";
+  out->nprims = nprims;
+  for (i32 i = 0; i < nprims; ++i) {
+    const i32 kind = rd();
+    rdList(&a);
+    if (!ok) return "truncated spec";
+    // spec::PrimitiveFeatureKind: Copy 1, SingleBit 2, Provided 3, ByteLength 4, CodepointSize 5,
+    // SurfaceCodepointSize 6, CodepointType 7, Codepoint 8
+    if (kind < 1 || kind > 8 || kind == 4 || kind == 5)
+      return "primitive feature kind " + std::to_string(kind) + " (length / match features need the dictionary's string storages)";
+    out->prims[i].kind = kind;
+    out->prims[i].a = a.size() > 0 ? a[0] : 0;
+    out->prims[i].b = a.size() > 1 ? a[1] : 0;
+    if ((kind == 1 || kind == 2) && (out->prims[i].a < 0 || out->prims[i].a >= numFeatures)) return "primitive feature reads a column outside the entry row";
+    if (kind == 3 && (out->prims[i].a < 0 || out->prims[i].a > 1)) return "more than two placeholders";
+  }
+  const i32 ncomp = rd();
+  if (!ok || ncomp < 0 || ncomp > kDynMaxComputes) return "too many computed features";
+  out->ncomputes = ncomp;
+  for (i32 i = 0; i < ncomp; ++i) {
+    const i32 prim = rd();
+    rdList(&a);
+    rdList(&b);
+    if (!ok) return "truncated spec";
+    auto& c = out->computes[i];
+    if (a.empty() && b.empty()) {   // plain primitive
+      c.cond = -1;
+      c.nt = 1;
+      c.t[0] = prim;
+      c.nf = 0;
+    } else {
+      if (a.size() > (size_t)kDynMaxBranch || b.size() > (size_t)kDynMaxBranch) return "computed feature with too many branch members";
+      c.cond = prim;
+      c.nt = (i32)a.size();
+      c.nf = (i32)b.size();
+      for (size_t q = 0; q < a.size(); ++q) c.t[q] = a[q];
+      for (size_t q = 0; q < b.size(); ++q) c.f[q] = b[q];
+    }
+    if (prim < 0 || prim >= nprims) return "computed feature refers to an unknown primitive";
+    for (i32 q = 0; q < c.nt; ++q)
+      if (c.t[q] < 0 || c.t[q] >= nprims) return "computed feature refers to an unknown primitive";
+    for (i32 q = 0; q < c.nf; ++q)
+      if (c.f[q] < 0 || c.f[q] >= nprims) return "computed feature refers to an unknown primitive";
+  }
+  const i32 npat = rd();
+  if (!ok || npat < 0 || npat > kDynMaxPatterns) return "too many pattern features";
+  out->npatterns = npat;
+  for (i32 i = 0; i < npat; ++i) {
+    const i32 idx = rd();
+    rdList(&a);
+    if (!ok) return "truncated spec";
+    if (idx != i) return "pattern features out of order";
+    if (a.size() > (size_t)kDynMaxArgs) return "pattern feature with too many arguments";
+    auto& pt = out->patterns[i];
+    pt.nargs = (i32)a.size();
+    pt.slot = -1;
+    pt.prefix = hmix(hmix(hmix(kHashSeed0, (u64)(u32)idx), (u64)a.size()), kPatternSeed);   // feature_impl_pattern.h:28-41
+    for (size_t q = 0; q < a.size(); ++q) {
+      if (a[q] < 0 || a[q] >= ncomp) return "pattern feature refers to an unknown feature";
+      pt.args[q] = a[q];
+    }
+  }
+  struct Ng {
+    i32 index;
+    std::vector<i32> refs;
+  };
+  std::vector<Ng> uni, bi, tri;
+  const i32 nng = rd();
+  for (i32 i = 0; ok && i < nng; ++i) {
+    Ng g;
+    g.index = rd();
+    rdList(&g.refs);
+    if (!ok) break;
+    for (i32 r : g.refs)
+      if (r < 0 || r >= npat) return "n-gram feature refers to an unknown pattern";
+    if (g.refs.size() == 1) uni.push_back(g);
+    else if (g.refs.size() == 2) bi.push_back(g);
+    else if (g.refs.size() == 3) tri.push_back(g);
+    else return "n-gram feature of order " + std::to_string(g.refs.size());
+  }
+  if (!ok) return "truncated spec";
+  if (uni.size() > (size_t)kDynMaxUni || bi.size() > (size_t)kDynMaxBi || tri.size() > (size_t)kDynMaxTri)
+    return "more n-gram features than the sweep's lane layout holds (64 unigrams, 40 bigrams, 4 trigrams)";
+  // stored patterns: those a bigram or trigram reads (the unigram-only ones are consumed where they are computed),
+  // in pattern order
+  for (auto& g : bi)
+    for (i32 r : g.refs) out->patterns[r].slot = 0;
+  for (auto& g : tri)
+    for (i32 r : g.refs) out->patterns[r].slot = 0;
+  i32 slot = 0;
+  for (i32 i = 0; i < npat; ++i)
+    if (out->patterns[i].slot == 0) out->patterns[i].slot = slot++;
+  if (slot > kPat) return "more than " + std::to_string(kPat) + " patterns are read by bigram / trigram features";
+  out->nstored = slot;
+  out->nuni = (i32)uni.size();
+  out->nbi = (i32)bi.size();
+  out->ntri = (i32)tri.size();
+  // hash prefixes: Hasher{}.mix(order + 2).mix(index).mix(seed) (feature_impl_ngram_partial.h:23-31,52-60,98-106)
+  for (size_t i = 0; i < uni.size(); ++i) {
+    out->uni[i].prefix = hmix(hmix(hmix(kHashSeed0, 3), (u64)(u32)uni[i].index), kUnigramSeed);
+    out->uni[i].t0 = uni[i].refs[0];
+  }
+  for (size_t i = 0; i < bi.size(); ++i) {
+    out->bi_prefix[i] = hmix(hmix(hmix(kHashSeed0, 4), (u64)(u32)bi[i].index), kBigramSeed);
+    out->bi_t01[i] = (u8)((out->patterns[bi[i].refs[0]].slot << 4) | out->patterns[bi[i].refs[1]].slot);
+  }
+  for (size_t i = 0; i < tri.size(); ++i) {
+    out->tri_prefix[i] = hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)tri[i].index), kTrigramSeed);
+    for (int q = 0; q < 3; ++q) out->tri_t[i][q] = (u8)out->patterns[tri[i].refs[q]].slot;
+  }
+  return std::string();
+}
+}  // namespace
+
 extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
 
 extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, jppgpu_ctx** out) {
@@ -394,15 +533,25 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED,
                 "jppgpu: beam / global beam > 32 is not supported");
-  if (m->num_features != spec::kNumDicFeatures || m->num_placeholders != spec::kNumPlaceholders)
-    return fail(JPPGPU_INVALID_PARAMETER, "model does not have the jumandic entry layout");
-  // the reference only accepts static feature code whose spec hash matches
-  // (features_api.cc:38-47); we compare the flattened descriptors themselves.
-  if (m->feature_spec_bytes != spec::kSpecBlobSize ||
-      memcmp(m->feature_spec, spec::kSpecBlob, spec::kSpecBlobSize) != 0)
-    return fail(JPPGPU_INVALID_PARAMETER,
-                "model feature spec differs from the built-in jumandic feature tables "
-                "(regenerate jumandic_spec.inc with tools/gen_spec_tables.py)");
+  // The reference runs its generated static feature code when the spec hash matches it and its table-driven dynamic
+  // feature objects otherwise (features_api.cc:20-60); here: the compiled-in jumandic tables when the flattened
+  // descriptors equal them, the table-driven kernels (k_t0_dyn, k_sweep<.., DYN>: the dynamic code's summation
+  // orders) for any other spec that fits the device layout.
+  const bool builtinSpec = m->num_features == spec::kNumDicFeatures && m->num_placeholders == spec::kNumPlaceholders &&
+                           m->feature_spec_bytes == spec::kSpecBlobSize &&
+                           memcmp(m->feature_spec, spec::kSpecBlob, spec::kSpecBlobSize) == 0;
+  std::unique_ptr<DevSpec> dynSpec;
+  if (!builtinSpec) {
+    if (m->num_features < 1 || m->num_features > spec::kNumDicFeatures || m->num_placeholders < 0 ||
+        m->num_placeholders > spec::kNumPlaceholders)
+      return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: entry rows of more than 8 columns / more than 2 placeholders are not supported");
+    if (!m->feature_spec || m->feature_spec_bytes < 16) return fail(JPPGPU_INVALID_PARAMETER, "model has no feature spec");
+    dynSpec.reset(new DevSpec());
+    const std::string why = parse_feature_spec(m->feature_spec, m->feature_spec_bytes, m->num_features, dynSpec.get());
+    if (!why.empty()) return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: feature spec outside the table-driven kernels: " + why);
+    if (c->global_beam <= 0)
+      return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the full-beam path (--global-beam 0) exists for the built-in jumandic spec only");
+  }
   if (m->weight_exponent >= 32 || !m->weights) return fail(JPPGPU_INVALID_PARAMETER, "bad perceptron weights");
   if (m->num_unk_makers > kMaxUnkMakers - 1) return fail(JPPGPU_NOT_IMPLEMENTED, "too many UNK makers");
   if (m->trie_bytes % 4 != 0 || m->trie_bytes == 0) return fail(JPPGPU_INVALID_PARAMETER, "bad trie blob");
@@ -425,6 +574,17 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   rt_h2d(ctx->eptrs.p, m->entry_ptrs, m->entry_ptrs_bytes, nullptr);
   rt_h2d(ctx->edata.p, m->entry_data, m->entry_data_bytes, nullptr);
   rt_h2d(ctx->weights.p, m->weights, wbytes, nullptr);
+  H.spec = nullptr;
+  if (dynSpec) {
+    if (!ctx->dyn_spec.ensure(sizeof(DevSpec))) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (feature tables)");
+    }
+    rt_h2d(ctx->dyn_spec.p, dynSpec.get(), sizeof(DevSpec), nullptr);
+    rt_sync(nullptr);
+    H.spec = ctx->dyn_spec.as<DevSpec>();
+    ctx->dynamic_spec = true;
+  }
   H.trie = ctx->trie.as<u32>();
   H.entry_ptrs = ctx->eptrs.as<u8>();
   H.entry_data = ctx->edata.as<u8>();
@@ -588,6 +748,8 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
   if (right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
   if (beam > kMaxBeam || global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: beam / global beam > 32 is not supported");
+  if (ctx->dynamic_spec && global_beam <= 0)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the full-beam path (--global-beam 0) exists for the built-in jumandic spec only");
   ctx->cfg.beam = beam;
   ctx->cfg.gbeam = global_beam > 0 ? global_beam : 0;
   ctx->cfg.rcheck = right_check;
@@ -598,7 +760,7 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
 extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   if (!ctx) return;
   (void)bind_device(ctx->device);
-  DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->text,
+  DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->dyn_spec, &ctx->text,
                     &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
                     &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_norm,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
                     &ctx->sent_status, &ctx->sent_flags, &ctx->sent_nodes, &ctx->sent_nodes2, &ctx->node_base,
@@ -789,7 +951,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(2, st);
   JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg, ctx->unk_rank);
   T.mark(3, st);
-  if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  if (ctx->dynamic_spec) JPP_LAUNCH(k_t0_dyn, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   B.node_penalty = nullptr;
   if (ctx->partial_pending) {
@@ -877,6 +1040,23 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     // CU -- the occupancy curve of profiles/r03_a_occupancy.txt)
     static const unsigned devPad = std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD") ? (unsigned)std::atoi(std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD")) : 0u;
     T.mark(8, st);
+    if (ctx->dynamic_spec) {
+      // table-driven variants (a spec other than the built-in jumandic tables)
+      if (nCls[0]) {
+        if (narrow) JPP_LAUNCH((k_sweep<8, 64, false, false, kSweepWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
+        else JPP_LAUNCH((k_sweep<32, 64, false, false, kSweepWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
+      }
+      T.mark(9, st);
+      if (nCls[1]) {
+        if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
+        else JPP_LAUNCH((k_sweep<32, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
+      }
+      T.mark(10, st);
+      if (nCls[2]) {
+        if (narrow) JPP_LAUNCH((k_sweep<8, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+        else JPP_LAUNCH((k_sweep<32, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+      }
+    } else {
     if (nCls[0]) {   // at most 64 right nodes per boundary, right-check <= 2
       // the CLI defaults: the one-row lean LDS layout (6.6 KB), 5 wavefronts per SIMD (96 VGPRs, no scratch); weight
       // tables of up to 2^24 entries get the 24-bit index arithmetic.  (developer knob JPPGPU_DEV_SWEEP_WAVES: 0 =
@@ -903,6 +1083,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     if (nCls[2]) {   // any width
       if (narrow) JPP_LAUNCH((k_sweep<8, 0>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
       else JPP_LAUNCH((k_sweep<32, 0>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+    }
     }
   }
   ctx->last_class_n[0] = nCls[0]; ctx->last_class_n[1] = nCls[1]; ctx->last_class_n[2] = nCls[2];
@@ -1300,6 +1481,8 @@ extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_n
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
+  if (ctx->dynamic_spec)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the trainer read-out exists for the built-in jumandic spec only");
   if (!res->ng_have) {
     if (res->generation != ctx->generation)
       return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");

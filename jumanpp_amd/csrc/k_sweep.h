@@ -137,7 +137,8 @@ __device__ __forceinline__ u32 small_div(u32 q, u32 inv) {
 // lane j of the group owns features k = j + 8m (m < 5), its table entries live in
 // registers (loaded once per kernel), so all weight gathers of a group are issued
 // together.  The reference's summation orders are then rebuilt with shuffles.
-constexpr int kBiPerLane = (spec::kNumBi + 7) / 8;
+constexpr int kBiPerLane = (kDynMaxBi + 7) / 8;   // feature slots per lane of an 8-lane group (kDynMaxBi >= spec::kNumBi)
+static_assert(spec::kNumBi <= kDynMaxBi && spec::kNumTri <= kDynMaxTri, "lane layout of the bigram / trigram features");
 
 // tables in LDS (filled once per kernel)
 struct LaneBi {
@@ -150,26 +151,27 @@ struct LaneBi {
 // weights of this lane's bigram features for one (right node, T1 row) pair, from the cached first-stage
 // states of the right node: s1[k] = hmix(prefix_k, p0[t0_k])
 template <bool W24>
+// (nBi: the number of bigram features -- spec::kNumBi, a constant after inlining, or the count of a table-driven spec)
 __device__ __forceinline__ void bi_gather_s1(const LaneBi& t, int j, const u64* s1, const u64* t1r,
-                                             const float JPP_GLOBAL* __restrict__ W, u32 wmask, bool act, float* w) {
+                                             const float JPP_GLOBAL* __restrict__ W, u32 wmask, bool act, float* w, int nBi) {
   u32 idx[kBiPerLane];
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
-    const int k = (j + 8 * m) < spec::kNumBi ? (j + 8 * m) : 0;
+    const int k = (j + 8 * m) < nBi ? (j + 8 * m) : 0;
     idx[m] = hmix_index<W24>(s1[k], t1r[JPP_LBI_T1(t, m, j)], wmask);
   }
 #pragma unroll
-  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < spec::kNumBi) ? W[idx[m]] : 0.f;
+  for (int m = 0; m < kBiPerLane; ++m) w[m] = (act && (j + 8 * m) < nBi) ? W[idx[m]] : 0.f;
 }
 
 // generated applyBiStep2: f_j = 0 + w_j + w_{j+8} + ..., then f_0 + f_1 + ... + f_7.
 // The three sums below are valid on the group leader (gj == 0) only: it reads its members through
 // row_shl DPP modifiers in exactly the order of the scalar code.
-__device__ __forceinline__ float bi_sum8(const float* w, int lane, int j) {
+__device__ __forceinline__ float bi_sum8(const float* w, int lane, int j, int nBi) {
   float f = 0.f;
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m)
-    if (j + 8 * m < spec::kNumBi) f += w[m];
+    if (j + 8 * m < nBi) f += w[m];
   float total = f;
   total += row_shl_f32<1>(f);
   total += row_shl_f32<2>(f);
@@ -183,13 +185,13 @@ __device__ __forceinline__ float bi_sum8(const float* w, int lane, int j) {
 
 // computeUnrolled4RawPerceptron: r_q = 0 + w_q + w_{q+4} + ... (q < 4), then ((r0 + r1) + r2) + r3.
 // Feature q + 4n sits in lane q (n even) or lane q + 4 (n odd) of the group.
-__device__ __forceinline__ float bi_sum4(const float* w, int lane, int j) {
+__device__ __forceinline__ float bi_sum4(const float* w, int lane, int j, int nBi) {
   float r = 0.f;
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
     float other = row_shl_f32<4>(w[m]);  // lanes 0..3 of the group read lanes 4..7
-    if (j + 8 * m < spec::kNumBi) r += w[m];
-    if (j + 4 + 8 * m < spec::kNumBi) r += other;
+    if (j + 8 * m < nBi) r += w[m];
+    if (j + 4 + 8 * m < nBi) r += other;
   }
   float total = r;
   total += row_shl_f32<1>(r);
@@ -200,16 +202,16 @@ __device__ __forceinline__ float bi_sum4(const float* w, int lane, int j) {
 
 // applyBiTriFullKernel: r1 = 0 + w_0 + w_2 + ..., r2 = 0 + w_1 + w_3 + ..., result r1 + r2
 // (lane 0 of the group accumulates the even features, lane 1 the odd ones)
-__device__ __forceinline__ float bi_sum2(const float* w, int lane, int j) {
+__device__ __forceinline__ float bi_sum2(const float* w, int lane, int j, int nBi) {
   const int par = j & 1;
   float r = 0.f;
 #pragma unroll
   for (int m = 0; m < kBiPerLane; ++m) {
     float v0 = w[m], v2 = row_shl_f32<2>(w[m]), v4 = row_shl_f32<4>(w[m]), v6 = row_shl_f32<6>(w[m]);
-    if (0 + par + 8 * m < spec::kNumBi) r += v0;
-    if (2 + par + 8 * m < spec::kNumBi) r += v2;
-    if (4 + par + 8 * m < spec::kNumBi) r += v4;
-    if (6 + par + 8 * m < spec::kNumBi) r += v6;
+    if (0 + par + 8 * m < nBi) r += v0;
+    if (2 + par + 8 * m < nBi) r += v2;
+    if (4 + par + 8 * m < nBi) r += v4;
+    if (6 + par + 8 * m < nBi) r += v6;
   }
   return r + row_shl_f32<1>(r);
 }
@@ -288,7 +290,10 @@ __device__ __attribute__((noinline)) BndMeta load_bnd_meta(const BndMeta* g, u32
 // WAVES: wavefronts per SIMD the variant is compiled for (VGPR budget 512 / WAVES); its LDS footprint must allow as many.
 // LEAN: the small-LDS layouts of the default-configuration variants (see kLean below): 0 = off, 1 = lean with the next
 // boundary's pattern rows in a buffer of their own, 2 = the tightest layout (one row buffer).
-template <int GM, int RM, bool DEF = false, bool W24 = false, int WAVES = kSweepWaves, int LEAN = 0>
+// DYN: a spec other than the built-in jumandic tables: the n-gram descriptors come from DevModel::spec, and every
+// sum takes the association of the reference's DYNAMIC feature code (PartialNgramFeatureApplyImpl,
+// feature_impl_ngram_partial.h:188-357): computeUnrolled4RawPerceptron for every row of every n-gram order.
+template <int GM, int RM, bool DEF = false, bool W24 = false, int WAVES = kSweepWaves, int LEAN = 0, bool DYN = false>
 __global__ void __launch_bounds__(64) JPP_WAVES_PER_EU_RANGE(WAVES, WAVES)
 k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restrict__ slist) {
   const DevModel& M = *Mp;
@@ -326,14 +331,17 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   // global-beam entries, one prescore per right node that doubles as the cutoff sum, ONE pattern-row buffer (rows
   // are dead once their first-stage hash states exist), a 16-entry layout ring.  6.5 KB instead of 9.8 KB.
   static_assert(!LEAN || (DEF && RM > 0), "the lean layout is written for the default configuration");
+  static_assert(!DYN || (!DEF && !W24), "the table-driven variant is the generic one");
+  const int nBi = DYN ? M.spec->nbi : spec::kNumBi;
+  const int nTri = DYN ? M.spec->ntri : spec::kNumTri;
   constexpr bool kLean = LEAN != 0;
   // kOneRow: the tightest layout (6 wavefronts per SIMD: 6.5 KB) has ONE pattern-row buffer and small rings; the
   // 5-wavefront layout (8 KB) keeps the next boundary's rows apart (requested a whole boundary ahead)
   constexpr bool kOneRow = LEAN == 2;
   constexpr int kGR = kLean ? 6 : GM;   // rows of the per-global-beam-entry arrays
   __shared__ u64 t1pat[kGR][kPat];
-  constexpr int kT2 = 4;  // pattern fields of the T2 node the trigrams read (indices 0..3)
-  static_assert(spec::kTri[0].t2 < kT2 && spec::kTri[1].t2 < kT2 && spec::kTri[2].t2 < kT2 && spec::kTri[3].t2 < kT2 && spec::kNumTri == 4,
+  constexpr int kT2 = DYN ? kPat : 4;  // pattern fields of the T2 node the trigrams read (built-in spec: indices 0..3)
+  static_assert(spec::kTri[0].t2 < 4 && spec::kTri[1].t2 < 4 && spec::kTri[2].t2 < 4 && spec::kTri[3].t2 < 4 && spec::kNumTri == 4,
                 "t2pat holds pattern fields 0..3 only");
   __shared__ u64 t2pat[kGR][kT2];
   // the three per-right-node arrays: in LDS (capacity RM), or -- RM == 0, the variant of sentences with a boundary
@@ -391,24 +399,35 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   BeamSlot* const cand = reinterpret_cast<BeamSlot*>(u_buf);                    // live beam slots of the left nodes
   u64* const ckey = reinterpret_cast<u64*>(u_buf + kCandCap * sizeof(BeamSlot));  // their keys (rank selection)
   u64(*const s1b)[kS1] = reinterpret_cast<u64(*)[kS1]>(u_buf);
-  __shared__ u64 s1t[kChunk][spec::kNumTri];
-  __shared__ u64 s_tripre[spec::kNumTri];
-  __shared__ u8 s_trit[spec::kNumTri][4];
+  __shared__ u64 s1t[kChunk][kDynMaxTri];
+  __shared__ u64 s_tripre[kDynMaxTri];
+  __shared__ u8 s_trit[kDynMaxTri][4];
 
   const int grp = lane >> 3, gj = lane & 7;
   LaneBi lbi;
-  __shared__ u64 s_bipre[spec::kNumBi];
-  __shared__ u8 s_bit01[spec::kNumBi];
+  __shared__ u64 s_bipre[DYN ? kDynMaxBi : spec::kNumBi];
+  __shared__ u8 s_bit01[DYN ? kDynMaxBi : spec::kNumBi];
   static_assert(kPat <= 16, "pattern indices are packed in 4 bits");
-  if (lane < spec::kNumBi) {
-    s_bipre[lane] = kNg.bi_pre[lane];
-    s_bit01[lane] = (u8)((kNg.bi_t0[lane] << 4) | kNg.bi_t1[lane]);
-  }
-  if (lane < spec::kNumTri) {
-    s_tripre[lane] = kNg.tri_pre[lane];
-    s_trit[lane][0] = (u8)kNg.tri_t0[lane];
-    s_trit[lane][1] = (u8)kNg.tri_t1[lane];
-    s_trit[lane][2] = (u8)kNg.tri_t2[lane];
+  if constexpr (DYN) {
+    if (lane < nBi) {
+      s_bipre[lane] = M.spec->bi_prefix[lane];
+      s_bit01[lane] = M.spec->bi_t01[lane];
+    }
+    if (lane < kDynMaxTri) {
+      s_tripre[lane] = lane < nTri ? M.spec->tri_prefix[lane] : 0;
+      for (int q = 0; q < 3; ++q) s_trit[lane][q] = lane < nTri ? M.spec->tri_t[lane][q] : (u8)0;
+    }
+  } else {
+    if (lane < spec::kNumBi) {
+      s_bipre[lane] = kNg.bi_pre[lane];
+      s_bit01[lane] = (u8)((kNg.bi_t0[lane] << 4) | kNg.bi_t1[lane]);
+    }
+    if (lane < spec::kNumTri) {
+      s_tripre[lane] = kNg.tri_pre[lane];
+      s_trit[lane][0] = (u8)kNg.tri_t0[lane];
+      s_trit[lane][1] = (u8)kNg.tri_t1[lane];
+      s_trit[lane][2] = (u8)kNg.tri_t2[lane];
+    }
   }
   lbi.pre = s_bipre;
   lbi.t01 = s_bit01;
@@ -418,7 +437,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   if (lane < 8) {
     u32 pk = 0;
 #pragma unroll
-    for (int m = 0; m < kBiPerLane; ++m) pk |= (u32)(s_bit01[(lane + 8 * m) < spec::kNumBi ? (lane + 8 * m) : 0] & 15) << (4 * m);
+    for (int m = 0; m < kBiPerLane; ++m) pk |= (u32)(s_bit01[(lane + 8 * m) < nBi ? (lane + 8 * m) : 0] & 15) << (4 * m);
     s_t1pack[lane] = pk;
   }
   wave_sync();
@@ -480,12 +499,12 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   // registers across the nodes; a lane-per-(node, feature) layout paid a division by 41 and three table reads per
   // element for nothing.
   auto compute_s1 = [&](const u64(*rows)[kPat], u32 nx) {
-    constexpr u32 kF = spec::kNumBi + spec::kNumTri;
-    static_assert(kF <= 64, "one lane per n-gram feature");
+    const u32 kF = (u32)(nBi + nTri);
+    static_assert(kDynMaxBi + kDynMaxTri <= 64, "one lane per n-gram feature");
     const int fl = lane_now();   // (the table reads below stay inside the loop)
     if ((u32)fl < kF) {
-      const bool bi = fl < spec::kNumBi;
-      const int kt = bi ? 0 : fl - spec::kNumBi;
+      const bool bi = fl < nBi;
+      const int kt = bi ? 0 : fl - nBi;
       const u64 pre = bi ? s_bipre[fl] : s_tripre[kt];
       const u32 t0i = bi ? (u32)(s_bit01[fl] >> 4) : (u32)s_trit[kt][0];
       for (u32 x = 0; x < nx; ++x) {
@@ -756,20 +775,20 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         const u64* t1r = t1pat[gb_t1[i]];
         const u64* t2r = t2pat[i];
         float w[kBiPerLane];
-        bi_gather_s1<W24>(lbi, gj, s1b[xr], t1r, W, wmask, act, w);
+        bi_gather_s1<W24>(lbi, gj, s1b[xr], t1r, W, wmask, act, w, nBi);
         float g = 0.f;
-        if (act && gj < spec::kNumTri) {
+        if (act && gj < nTri) {
           u32 idx = hmix_index<W24>(hmix(s1t[xr][gj], t1r[s_trit[gj][1]]), t2r[s_trit[gj][2]], wmask);
           g += W[idx];
         }
         // generated applyBiStep2 (8 round-robin sums; last right node: unrolled-4) and applyTriStep3
-        const float b8 = bi_sum8(w, lane, gj);
-        const float b4 = bi_sum4(w, lane, gj);
+        const float b8 = DYN ? 0.f : bi_sum8(w, lane, gj, nBi);
+        const float b4 = bi_sum4(w, lane, gj, nBi);
         if constexpr (kHeadShare) {
           // The tail (5a) adds up the same 37 weights of (right node, T1 row 0) again, only in the
           // association of applyBiTriFullKernel: form that sum here, from the weights already gathered,
           // and 5a skips row 0 (with one head entry, c == 1, its row is always row 0).
-          const float tailS = (U == 1) ? b4 : bi_sum2(w, lane, gj);   // row 0 is the last T1 row iff U == 1
+          const float tailS = (U == 1) ? b4 : bi_sum2(w, lane, gj, nBi);   // row 0 is the last T1 row iff U == 1
           if (act && gj == 0) biS0[t] = tailS;
         }
         static_assert(spec::kNumTri == 4, "the trigram sum below reads group members 1..3");
@@ -779,7 +798,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         tsum += row_shl_f32<3>(g);
         if (act && gj == 0) {
           float sc = t0c[grp];
-          sc += (t == R - 1) ? b4 : b8;
+          sc += (DYN || t == R - 1) ? b4 : b8;   // (DYN: computeUnrolled4RawPerceptron for every row)
           sc += tsum;
           // applyPluginToPrescores (score_processor.cc:578-596)
           if (B.node_penalty) sc -= B.node_penalty[nb + rfirst + t];
@@ -872,7 +891,9 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
             const u64* t2r = t2pat[i];
 #pragma unroll
             for (int f = 0; f < spec::kNumTri; ++f) {
-              u32 idx = hmix_index<W24>(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]], wmask);
+              if (DYN && f >= nTri) continue;
+              const int i1 = DYN ? (int)s_trit[f][1] : kNg.tri_t1[f], i2 = DYN ? (int)s_trit[f][2] : kNg.tri_t2[f];
+              u32 idx = hmix_index<W24>(hmix(st[f], t1r[i1]), t2r[i2], wmask);
               wtri[f] = W[idx];
             }
           }
@@ -891,10 +912,10 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           if (kHeadShare) tu += 1;
           act = act && (op0 + x) < K;
           float w[kBiPerLane];
-          bi_gather_s1<W24>(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w);
-          const float s2 = bi_sum2(w, lane, gj);
-          const float s4 = bi_sum4(w, lane, gj);
-          if (act && gj == 0) biS[x][tu] = (tu == U - 1) ? s4 : s2;
+          bi_gather_s1<W24>(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w, nBi);
+          const float s2 = DYN ? 0.f : bi_sum2(w, lane, gj, nBi);
+          const float s4 = bi_sum4(w, lane, gj, nBi);
+          if (act && gj == 0) biS[x][tu] = (DYN || tu == U - 1) ? s4 : s2;
         }
       }
       wave_sync();
@@ -925,7 +946,10 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           } else {
 #pragma unroll
             for (int f = 0; f < spec::kNumTri; ++f) {
-              u32 idx = hmix_index<W24>(hmix(st[f], t1r[kNg.tri_t1[f]]), t2r[kNg.tri_t2[f]], wmask);
+              w[f] = 0.f;
+              if (DYN && f >= nTri) continue;
+              const int i1 = DYN ? (int)s_trit[f][1] : kNg.tri_t1[f], i2 = DYN ? (int)s_trit[f][2] : kNg.tri_t2[f];
+              u32 idx = hmix_index<W24>(hmix(st[f], t1r[i1]), t2r[i2], wmask);
               w[f] = W[idx];
             }
           }
@@ -934,7 +958,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           if (kHeadShare && gb_t1[i] == 0) S = biS0[t];
           else S = biS[x][gb_t1[i]];
           float res;
-          if (i < ngb - 1) {
+          if (!DYN && i < ngb - 1) {   // (DYN: every row through computeUnrolled4RawPerceptron)
             float r1 = 0.f, r2 = 0.f;
             r1 += w[0];
             r2 += w[1];

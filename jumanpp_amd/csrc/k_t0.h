@@ -184,6 +184,133 @@ __global__ void __launch_bounds__(64) k_t0(Batch B, const DevModel* __restrict__
   }
 }
 
+// The same kernel for a spec other than the built-in jumandic tables: every descriptor is read from the DevSpec
+// tables (staged in LDS), and the unigram weights are summed the way the reference's DYNAMIC feature code sums
+// them -- PartialNgramFeatureApplyImpl::applyUni, feature_impl_ngram_partial.h:188-214: every row through
+// computeUnrolled4RawPerceptron (perceptron.h:46-72), four partial sums from 0.f in feature order, ((r1+r2)+r3)+r4.
+// Patterns: PatternDynamicApplyImpl (feature_impl_pattern.h:28-65); only those a bigram / trigram reads are stored
+// (DevSpec::Pattern::slot), the reference's dynamic lattice stores all of them.
+__global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restrict__ Mp) {
+  const DevModel& M = *Mp;
+  __shared__ DevSpec S;
+  {
+    const u32* src = reinterpret_cast<const u32*>(M.spec);
+    u32* dst = reinterpret_cast<u32*>(&S);
+    for (u32 i = threadIdx.x; i < sizeof(DevSpec) / 4; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  u32 off = B.byte_off[s];
+  u32 g0 = off + s;
+  u32 n = B.sent_ncp[s];
+  u32 N = B.sent_nodes[s];
+  u64 nb = B.node_base[s];
+  const u32* cps = B.cp_code + g0;
+  const i32* cls = B.cp_class + g0;
+  const int nf = M.num_features;
+  const float JPP_GLOBAL* W = as_global(M.weights);
+
+  for (u32 k = 2 + threadIdx.x; k < N; k += blockDim.x) {
+    NodeInfo ni = B.node_info[nb + k];
+    NodeAux na = B.node_aux[nb + k];
+    // ---- entry row ----
+    i32 entry[spec::kNumDicFeatures];
+#pragma unroll
+    for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = 0;
+    bool isUnk = false;
+    if (ni.eptr == kEptrEOS) {
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? kEptrEOS : 0;
+    } else if (ni.eptr >= 0) {
+      read_entry_row(M, ni.eptr, entry, nf);
+    } else {
+      isUnk = true;
+      const UnkMaker& mk = M.makers[M.maker_of_spec[na.maker]];
+      if (mk.type == UNK_NORMALIZE) {
+        read_entry_row(M, na.tmpl, entry, nf);
+      } else {
+#pragma unroll
+        for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? mk.tmpl[f] : 0;
+      }
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) {
+        if (f < nf && ((mk.replace_mask >> f) & 1)) entry[f] = na.hash;
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < spec::kNumDicFeatures; ++f) B.node_entry[(nb + k) * spec::kNumDicFeatures + f] = entry[f];
+
+    // ---- primitive features (feature_impl_prim.h:62-236) ----
+    auto primitive = [&](int p) -> u64 {
+      const int kind = S.prims[p].kind, a = S.prims[p].a, bsh = S.prims[p].b;
+      u32 col = 0;
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) col = f == a ? (u32)entry[f] : col;   // (no dynamic register index)
+      if (kind == spec::Copy) return col;
+      if (kind == spec::SingleBit) return (col >> bsh) & 1u;
+      if (kind == spec::Provided) return isUnk ? (u64)(u32)(a == 0 ? na.ph0 : na.ph1) : 0;
+      if (kind == spec::SurfaceCodepointSize) return (u64)((i32)ni.end - (i32)ni.start);
+      if (kind == spec::Codepoint) {
+        if (a > 0) {
+          const u32 pos = (u32)ni.end + (u32)(a - 1);
+          return pos < n ? (u64)cps[pos] : ~u64{0};
+        }
+        const i32 pos = (i32)ni.start + a;
+        return (pos >= 0 && (u32)pos < n) ? (u64)cps[pos] : ~u64{0};
+      }
+      // CodepointType
+      if (a == 0) {
+        u64 v = 0;
+        for (u32 q = ni.start; q < ni.end; ++q) v |= (u32)cls[q];
+        return v;
+      }
+      if (a > 0) {
+        const u32 pos = (u32)ni.end + (u32)(a - 1);
+        return pos < n ? (u64)(u32)cls[pos] : 0;
+      }
+      const i32 pos = (i32)ni.start + a;
+      return (pos >= 0 && (u32)pos < n) ? (u64)(u32)cls[pos] : 0;
+    };
+    // ---- patterns, unigram weights ----
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    // (pattern by pattern: a pattern's hash feeds the unigram features over it and, if stored, its slot; unigram
+    // features are summed in FEATURE order, so their weights are gathered first and added afterwards)
+    float wu[kDynMaxUni];
+    for (int p = 0; p < S.npatterns; ++p) {
+      u64 h = S.patterns[p].prefix;
+      for (int q = 0; q < S.patterns[p].nargs; ++q) {
+        const DevSpec::Compute& c = S.computes[S.patterns[p].args[q]];
+        if (c.cond < 0) {
+          h = hmix(h, primitive(c.t[0]));
+        } else if (primitive(c.cond) != 0) {
+          for (int z = 0; z < c.nt; ++z) h = hmix(h, primitive(c.t[z]));
+        } else {
+          for (int z = 0; z < c.nf; ++z) h = hmix(h, primitive(c.f[z]));
+        }
+      }
+      if (S.patterns[p].slot >= 0) B.node_pat[(nb + k) * kPat + S.patterns[p].slot] = h;
+      for (int u = 0; u < S.nuni; ++u)
+        if (S.uni[u].t0 == p) wu[u] = W[(u32)hmix(S.uni[u].prefix, h) & M.wmask];
+    }
+    for (int q = S.nstored; q < kPat; ++q) B.node_pat[(nb + k) * kPat + q] = 0;
+    {
+      int u = 0;
+      for (; u + 4 <= S.nuni; u += 4) {
+        r[0] += wu[u];
+        r[1] += wu[u + 1];
+        r[2] += wu[u + 2];
+        r[3] += wu[u + 3];
+      }
+      const int rest = S.nuni - u;
+      if (rest >= 3) r[2] += wu[u + 2];
+      if (rest >= 2) r[1] += wu[u + 1];
+      if (rest >= 1) r[0] += wu[u];
+    }
+    B.node_t0[nb + k] = r[0] + r[1] + r[2] + r[3];
+  }
+}
+
 }  // namespace jpp
 
 #endif  // JPP_K_T0_H

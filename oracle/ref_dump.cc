@@ -27,6 +27,11 @@
 //   ref_dump ngrams  <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the trainer's read-out: NgramFeaturesComputer::calculateNgramFeatures for every connection of the top-1
 //       path on an analyzer that stores all patterns (what jppgpu_result_fetch_top1_ngrams must reproduce)
+//   ref_dump bootstrapv <dict.mdic> <out.jppmdl> <drop|add>
+//       jpp_jumandic_bootstrap with a VARIANT of the jumandic spec, so that the spec hash no longer matches the
+//       reference's generated static feature code and the reference runs its dynamic feature objects
+//       (features_api.cc:20-60): `drop` removes the last n-gram feature of the spec, `add` appends a unigram, a
+//       bigram and swaps two bigrams.  The checker of the table-driven kernels.
 //   ref_dump top1    <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the packed top-1 result of Analyzer::analyze per sentence: u32 status (0 ok / 1 failed), u32 count, then count
 //       records {i32 EntryPtr raw, u16 start, u16 end} in text order (EOS dropped) -- the layout of jppgpu_result_pack.
@@ -62,6 +67,8 @@
 #include "core/impl/model_io.h"
 #include "core/impl/perceptron_io.h"
 #include "jpp_jumandic_cg.h"
+#include "jumandic/shared/jumandic_spec.h"
+#include "util/mmap.h"
 #include "jumandic/shared/juman_format.h"
 #include "jumandic/shared/lattice_format.h"
 #include "../include/jppgpu.h"
@@ -547,7 +554,10 @@ int doDump(const char* modelFile, const char* out, char** extra, int nextra) {
         auto R = bnd->localNodeCount();
         if (R == 0) continue;
         proc.startBoundary(R);
-        proc.computeT0All(b, sconf->feature, &pfc);
+        // (analyzer_impl.cc:270-280: static pattern code computes patterns + T0 here; with a spec whose hash does not
+        // match the generated code the patterns were made while the lattice was built and T0 comes from applyT0)
+        if (proc.patternIsStatic()) proc.computeT0All(b, sconf->feature, &pfc);
+        else proc.applyT0(b, sconf->feature);
         auto t0buf = proc.scores_.bufferT0();
         t0[b].assign(t0buf.begin(), t0buf.begin() + R);
         auto gb = proc.makeGlobalBeam(b, lat->config().globalBeamSize);
@@ -684,6 +694,53 @@ int doDump(const char* modelFile, const char* out, char** extra, int nextra) {
 }
 
 // ------------------------------------------------------------------ time ---
+int doBootstrapVariant(const char* mdic, const char* out, const char* variant) {
+  core::spec::AnalysisSpec spec;
+  CHECK_OK(jumandic::SpecFactory::makeSpec(&spec));
+  auto& ng = spec.features.ngram;
+  const std::string v{variant};
+  if (v == "drop") {
+    ng.pop_back();
+  } else if (v == "add") {
+    i32 maxIdx = 0;
+    for (auto& f : ng) maxIdx = std::max(maxIdx, f.index);
+    // patterns 0 and 1 are read by bigrams already, i.e. they are stored ones
+    core::spec::NgramFeatureDescriptor uni, bi;
+    uni.index = maxIdx + 1;
+    uni.references = {1};
+    bi.index = maxIdx + 2;
+    bi.references = {1, 0};
+    ng.push_back(uni);
+    ng.push_back(bi);
+    // and a different order of two existing bigram features
+    i32 a = -1, b = -1;
+    for (i32 i = 0; i < (i32)ng.size(); ++i)
+      if (ng[i].references.size() == 2) {
+        if (a < 0) a = i;
+        else if (b < 0) b = i;
+      }
+    std::swap(ng[a], ng[b]);
+  } else {
+    std::cerr << "unknown variant " << v << "\n";
+    return 2;
+  }
+  const std::string mdicS{mdic}, outS{out};
+  util::FullyMappedFile file;
+  CHECK_OK(file.open(StringPiece{mdicS}, util::MMapType::ReadOnly));
+  core::dic::DictionaryBuilder builder;
+  CHECK_OK(builder.importSpec(&spec));
+  CHECK_OK(builder.importCsv(StringPiece{mdicS}, file.contents()));
+  core::dic::DictionaryHolder holder;
+  CHECK_OK(holder.load(builder.result()));
+  core::model::ModelInfo minfo{};
+  minfo.parts.emplace_back();
+  CHECK_OK(builder.fillModelPart(&minfo.parts.back(), "variant"));
+  core::model::ModelSaver saver;
+  CHECK_OK(saver.open(StringPiece{outS}));
+  CHECK_OK(saver.save(minfo));
+  return 0;
+}
+
 int doTop1(const char* modelFile, const char* out, char** extra, int nextra) {
   Env e;
   e.init(modelFile, extra, nextra);
@@ -1160,6 +1217,7 @@ int main(int argc, char** argv) {
   if (cmd == "shim" && argc >= 5) return doShim(argv[2], argv[3], atoi(argv[4]), argv + 5, argc - 5);
   if (cmd == "ngrams" && argc >= 4) return doNgrams(argv[2], argv[3], argv + 4, argc - 4);
   if (cmd == "top1" && argc >= 4) return doTop1(argv[2], argv[3], argv + 4, argc - 4);
+  if (cmd == "bootstrapv" && argc == 5) return doBootstrapVariant(argv[2], argv[3], argv[4]);
   std::cerr << "bad arguments\n";
   return 2;
 }

@@ -195,6 +195,67 @@ def test_emulated_sentences_are_routed_to_sweep_variants_one_by_one(emu_lib, ref
     assert not errs, errs[:10]
 
 
+def _variant_spec_workload(ref_tools, tmp, variant, n_lines, beams=None, rnn=None, n_entries=2500, exp=14, length=30, seed=21):
+    """a model whose spec is NOT the built-in jumandic one (oracle/ref_dump.cc `bootstrapv`: the jumandic spec with its
+    last n-gram feature dropped / with a unigram and a bigram added and two bigrams swapped): the reference's spec hash
+    no longer matches its generated code and it runs its dynamic feature objects (features_api.cc:20-60)"""
+    mdic = os.path.join(tmp, 'v.mdic')
+    with open(mdic, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)], stdout=f)
+    rd = os.path.join(ref_tools, 'ref_dump')
+    subprocess.check_call([rd, 'bootstrapv', mdic, os.path.join(tmp, 'v.seed'), variant], stderr=subprocess.DEVNULL)
+    subprocess.check_call([rd, 'mkmodel', os.path.join(tmp, 'v.seed'), os.path.join(tmp, 'v.model'), str(exp), '3', '0.1'],
+                          stderr=subprocess.DEVNULL)
+    if rnn is not None:
+        hidden, vocab = rnn
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_rnn.py'), mdic, os.path.join(tmp, 'rnn'),
+                               '--vocab', str(vocab), '--hidden', str(hidden), '--maxent-size', str(1 << 18),
+                               '--seed', str(seed)], stdout=subprocess.DEVNULL)
+        os.rename(os.path.join(tmp, 'v.model'), os.path.join(tmp, 'p.model'))
+        subprocess.check_call([os.path.join(ref_tools, 'jumanpp_v2_train'), '--model-input=' + os.path.join(tmp, 'p.model'),
+                               '--model-output=' + os.path.join(tmp, 'v.model'), '--rnn-model=' + os.path.join(tmp, 'rnn'),
+                               '--rnn-fields=surface,pos', '--rnn-nce-bias=5.6', '--rnn-unk-constant=-3.47',
+                               '--rnn-unk-length=-2.93', '--feature-weight-perceptron=1', '--feature-weight-rnn=0.0176'],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([rd, 'export', os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.img')], stderr=subprocess.DEVNULL)
+    txt = os.path.join(tmp, 'v.txt')
+    with open(txt, 'w', encoding='utf-8') as f:
+        subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines), '--seed', str(seed + 1),
+                               '--oov', '0.08', '--len', str(length)], stdout=f)
+    with open(txt, 'rb') as f:
+        subprocess.check_call([rd, 'dump', os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.gold')] + [str(x) for x in (beams or [])],
+                              stdin=f, stderr=subprocess.DEVNULL)
+    lines = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
+    return os.path.join(tmp, 'v.img'), lines, os.path.join(tmp, 'v.gold')
+
+
+def check_variant_spec(lib, ref_tools, tmp, variant, n_lines, beams, rnn, **kw):
+    img, lines, gold_path = _variant_spec_workload(ref_tools, tmp, variant, n_lines, beams=beams, rnn=rnn, **kw)
+    b = beams or [5, 6, 1, 5]
+    ctx = J.Context(img, lib_path=lib, beam=b[0], global_beam=b[1], right_check=b[2], right_beam=b[3])
+    meta, gold = G.read_gold(gold_path)
+    assert meta['npat'] > 14   # the reference's dynamic lattice keeps every pattern: it did run its dynamic code
+    slots = G.stored_pattern_slots(img)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta, pat_slots=slots, verbose=False)
+    assert not errs, (len(errs), errs[:8])
+    return ctx
+
+
+@pytest.mark.parametrize('variant,beams,rnn', [('drop', None, None), ('add', None, (32, 600)), ('add', [20, 24, 1, 20], None)])
+def test_emulated_table_driven_kernels_on_a_non_jumandic_spec(emu_lib, ref_tools, tmp_path, variant, beams, rnn):
+    """a spec other than the compiled-in tables is analysed by the table-driven kernels (k_t0_dyn,
+    k_sweep<.., DYN>) with the summation orders of the reference's DYNAMIC feature code: whole lattice bit-identical"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    ctx = check_variant_spec(emu_lib, ref_tools, str(tmp_path), variant, 40, beams, rnn)
+    # what the table-driven path does not have says so
+    with pytest.raises(J.JppGpuError):
+        J.Context(os.path.join(str(tmp_path), 'v.img'), lib_path=emu_lib, beam=5, global_beam=0, right_check=0, right_beam=0, use_rnn=False)
+
+
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):
     ctx = J.Context(os.path.join(golden_dir, 'mini.img'), lib_path=emu_lib)
     # reference: invalid UTF-8 -> InvalidParameter (characters.cc:267-269);

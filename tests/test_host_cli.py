@@ -201,6 +201,21 @@ def test_gpu_cli_devices_list(cli_gpu, ref_tools, tmp_path):
     assert out == ref.stdout
 
 
+def test_cli_on_a_non_jumandic_spec(cli_emu, ref_tools, tmp_path):
+    """jumanpp_gpu reads a .jppmdl whose spec is not the built-in one (native reader -> table-driven kernels) and
+    prints jumanpp_v2's bytes, Juman and lattice format"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tmp = str(tmp_path)
+    tc._variant_spec_workload(ref_tools, tmp, 'add', 25)
+    model, txt = os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.txt')
+    for flags in ([], ['-s', '3']):
+        ref = _ref_cli(ref_tools, model, flags, txt)
+        rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
+        assert rc == 0 and out == ref, (flags, err[-300:])
+
+
 def _sharded_input(golden_dir, tmp, copies):
     """mini.txt a few times over plus comment lines (one at the very end), an empty line and a line that fails"""
     src = open(os.path.join(golden_dir, 'mini.txt'), 'rb').read()
