@@ -71,11 +71,12 @@ def make_workload(args, cache_dir):
 
 
 def make_corpus(args, mdic, cache_dir, n_lines, seed):
-    path = os.path.join(cache_dir, 'corpus_%d_%d_%d.txt' % (n_lines, args.sent_len, seed))
+    oov = float(getattr(args, 'oov', 0.05))
+    path = os.path.join(cache_dir, 'corpus_%d_%d_%d%s.txt' % (n_lines, args.sent_len, seed, '' if oov == 0.05 else '_oov%g' % oov))
     if not os.path.exists(path):
         with open(path, 'w', encoding='utf-8') as f:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines),
-                                   '--seed', str(seed), '--len', str(args.sent_len), '--oov', '0.05'], stdout=f)
+                                   '--seed', str(seed), '--len', str(args.sent_len), '--oov', str(oov)], stdout=f)
     return path
 
 
@@ -129,7 +130,95 @@ def algorithmic_bytes(res, cfg_beam, cfg_gbeam, rcheck, rbeam, np):
              + 4 * (c * Rs * 41 + K * (U * 37 + np.maximum(Gs - c, 0) * 4))  # bi/tri weight gathers
              + Rs * cfg_beam * slot                     # beams written
              + (K * Gs + (Rs - K) * c) * 4)             # score cells written
-    return dict(t0=int(t0_bytes), sweep=int(sweep.sum()), nodes=N)
+    # gathers actually issued: the bigram weights of (kept right node, T1 row 0) serve prescore and tail
+    issued = sweep - 4 * K * 37 * (c > 0)
+    return dict(t0=int(t0_bytes), sweep=int(sweep.sum()), sweep_issued=int(issued.sum()), nodes=N)
+
+
+def kernel_source_id():
+    """sha256 over the kernel sources: profiles/traffic.json carries the id of the sources its counters were collected
+    with, and roofline.traffic is only reported when it equals the running library's (a counter profile must not
+    survive a kernel change silently)"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'jumanpp_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        fp = os.path.join(d, name)
+        if os.path.isfile(fp):
+            h.update(name.encode())
+            h.update(open(fp, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def front_end_bytes(img, res, lines, np):
+    """Algorithmic bytes of the front end (decode -> seeds -> lattice layout) per SURVEY 8(d): 4 B per double-array
+    unit touched (B_t) + entry-pointer list bytes (P), counted by walking the model image's trie on the host for a
+    sample of sentences, + the sentence bytes + what the front end writes per codepoint / boundary / node.  Returns
+    bytes per sentence (mean over the sample)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import model_image as mi
+    secs = mi.read_sections(img)
+    units = np.frombuffer([p for t, a, p in secs if t == mi.SEC_TRIE][0], dtype='<u4')
+    eptrs = [p for t, a, p in secs if t == mi.SEC_ENTRY_PTRS][0]
+
+    def varint_len(pos):
+        n = 1
+        while eptrs[pos + n - 1] & 0x80:
+            n += 1
+        return n
+
+    def list_bytes(pos):
+        v, shift, q = 0, 0, pos
+        while True:
+            b = eptrs[q]
+            q += 1
+            v |= (b & 0x7f) << shift
+            shift += 7
+            if b < 0x80:
+                break
+        for _ in range(v):
+            q += varint_len(q)
+        return q - pos
+
+    bt = p_bytes = 0
+    for line in lines:
+        raw = line
+        cps = raw.decode('utf-8', errors='ignore')
+        starts, off = [], 0
+        for ch in cps:
+            starts.append(off)
+            off += len(ch.encode('utf-8'))
+        starts.append(off)
+        for i in range(len(cps)):
+            idn = 0
+            unit = int(units[0])
+            bt += 1
+            ok = True
+            for j in range(i, len(cps)):
+                for b in raw[starts[j]:starts[j + 1]]:
+                    offs = (unit >> 10) << ((unit & (1 << 9)) >> 6)
+                    idn ^= offs ^ b
+                    unit = int(units[idn])
+                    bt += 1
+                    if (unit & ((1 << 31) | 0xff)) != b:
+                        ok = False
+                        break
+                if not ok:
+                    break
+                if (unit >> 8) & 1:
+                    offs = (unit >> 10) << ((unit & (1 << 9)) >> 6)
+                    leaf = int(units[idn ^ offs])
+                    bt += 1
+                    p_bytes += list_bytes(leaf & 0x7fffffff)
+    n = max(1, len(lines))
+    ok = res.status == 0
+    nodes = float(res.nnodes[ok].sum()) / max(1, int(ok.sum()))
+    ncp = float(res.ncp[ok].sum()) / max(1, int(ok.sum()))
+    nbytes = sum(len(l) for l in lines) / n
+    per_cp = 4 + 4 + 2 + 20 + 48 + 6 + 8          # codepoint, class, byte offset, charlattice nodes, walk record, counts, end mask
+    per_bnd = 16 + 16 + 16                        # first / count arrays, ends first / count, the packed boundary record
+    per_node = 8 + 16 + 4                         # node record, UNK record, ends-list entry
+    return {'trie_units': bt / n, 'entry_pointer_bytes': p_bytes / n,
+            'bytes_per_sentence': 4 * bt / n + p_bytes / n + nbytes + ncp * per_cp + (ncp + 3) * per_bnd + nodes * per_node}
 
 
 def _cpu_flags():
@@ -393,13 +482,19 @@ def homograph_leg(args, cache, local_rank, np, torch, J):
         for r in rows[8:]:
             if r:
                 counts[r.split(',', 1)[0]] = counts.get(r.split(',', 1)[0], 0) + 1
-        base = os.path.join(cache, os.path.basename(mdic) + '.narrow')
+        # a dictionary view for corpus (ii): no fan-out surfaces, and no hiragana at all (every single hiragana is a
+        # fan-out surface, so any hiragana in the text makes a wide boundary)
+        def plain(surface):
+            return counts[surface] <= 6 and not any('\u3041' <= ch <= '\u309f' for ch in surface)
+        base = os.path.join(cache, os.path.basename(mdic) + '.narrow2')
         if not os.path.exists(base):
             with open(base, 'w', encoding='utf-8') as f:
-                f.write('\n'.join(rows[:8] + [r for r in rows[8:] if r and counts[r.split(',', 1)[0]] <= 6]) + '\n')
+                f.write('\n'.join(rows[:8] + [r for r in rows[8:] if r and plain(r.split(',', 1)[0])]) + '\n')
         wide = sorted(counts, key=lambda k: -counts[k])[:40]
         corpus_all = make_corpus(a, mdic, cache, args.batch, a.seed + 77)
-        corpus_narrow = make_corpus(a, base, cache, args.batch, a.seed + 78)
+        a_narrow = copy.copy(a)
+        a_narrow.oov = 0.0   # (the OOV runs of the generator contain hiragana)
+        corpus_narrow = make_corpus(a_narrow, base, cache, args.batch, a.seed + 79)
         dev = torch.device('cuda', local_rank)
         stream = torch.cuda.current_stream().cuda_stream
         ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank,
@@ -676,10 +771,10 @@ def main():
     out = None
     if rank == 0:
         # algorithmic bytes of one representative batch (untimed)
-        r = step(0).fetch(full=True)
+        r = step(args.warmup).fetch(full=True)
         ab = algorithmic_bytes(r, 5, 6, 1, 5, np)
         bad = int((r.status != 0).sum())
-        r.release()
+        r_front = r
         # self-certification of the line (untimed; the reference is the checker, never the thing measured)
         parity = None
         if not args.no_cpu_baseline and not args.no_parity and world == 1:
@@ -702,19 +797,56 @@ def main():
         avg = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'  # k_rnn has its own line in kernel_ms_per_step
         achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
-        # HBM traffic of the dominant kernel: measured offline by tools/gpu_profile.sh (separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), committed under profiles/
+        # HBM traffic of the dominant kernel: measured offline (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        # of this same command, tools/gpu_session_*.sh), committed under profiles/ -- reported only when it was
+        # collected with the kernel sources that are running now
         traffic, traffic_note = None, None
+        src_id = kernel_source_id()
         try:
             tp = json.load(open(args.traffic_profile))
             if (tp.get('batch') == args.batch and tp.get('rnn') == bool(args.rnn) and tp.get('sent_len') == args.sent_len
                     and tp.get('dict_entries') == args.dict_entries and world == 1):
-                ent = tp['kernels'].get('k_' + dom)
-                if ent:
-                    traffic = ent['hbm_bytes_per_launch']
-                    traffic_note = tp.get('note')
+                if tp.get('kernel_source_id') != src_id:
+                    traffic_note = ('profiles/traffic.json was collected with other kernel sources (%s, running %s): not reported'
+                                    % (tp.get('kernel_source_id'), src_id))
+                else:
+                    ent = tp['kernels'].get('k_' + dom)
+                    if ent:
+                        traffic = ent['hbm_bytes_per_launch']
+                        traffic_note = tp.get('note')
         except (OSError, ValueError, KeyError):
             pass
+        # the contract's byte count charges the 37 bigram gathers of (kept right node, T1 row 0) twice, as the reference
+        # performs them (prescore + tail); the kernel gathers them once and forms both sums from them
+        issued = ab.get('sweep_issued', ab['sweep'])
+        # front end (decode + seeds + normalize + layout: everything before T0)
+        front = None
+        try:
+            sample = [batches[args.warmup % len(batches)][0][int(o0):int(o1)] for o0, o1 in
+                      zip(batches[args.warmup % len(batches)][1][:384], batches[args.warmup % len(batches)][1][1:385])]
+            fb = front_end_bytes(img, r_front, sample, np)
+            front_ms = avg['decode'] + avg['seeds'] + avg['layout']
+            fbytes = fb['bytes_per_sentence'] * args.batch
+            front = {'bound': 'hbm', 'kernels': 'k_decode + k_seeds<0/1/2> + k_norm<0/1/2> + k_layout / k_scan / k_connect / k_relocate / k_ends',
+                     'achieved': round(fbytes / (front_ms * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                     'frac': round(fbytes / (front_ms * 1e-3) / 1e9 / 8000.0, 5), 'traffic': None,
+                     'algorithmic_bytes_per_step': int(fbytes), 'ms_per_step': round(front_ms, 3),
+                     'trie_units_per_sentence': round(fb['trie_units'], 1),
+                     'entry_pointer_bytes_per_sentence': round(fb['entry_pointer_bytes'], 1),
+                     'what': 'SURVEY 8(d): 4 B per double-array unit touched + entry-pointer list bytes (host walk of the '
+                             "model's trie over 384 sentences of the timed batch) + sentence bytes + the arrays the front end "
+                             'writes; includes the two host syncs of the phase'}
+            try:
+                if traffic is not None or True:
+                    tpk = tp['kernels'] if tp.get('kernel_source_id') == src_id else {}
+                    fk = [k for k in tpk if k.startswith(('k_decode', 'k_seeds', 'k_norm', 'k_layout', 'k_connect', 'k_ends', 'k_relocate'))]
+                    if fk:
+                        front['traffic'] = int(sum(tpk[k]['hbm_bytes_per_launch'] for k in fk))
+            except Exception:
+                pass
+        except Exception as e:
+            front = {'error': str(e)[:200]}
+        r_front.release()
         # configs[1] (perceptron only) on the same model and batches, outside the timed region
         perceptron_only = None
         ctx2 = None
@@ -821,7 +953,12 @@ def main():
                 'traffic_source': traffic_note,
                 'algorithmic_bytes_per_launch': ab[dom],
                 'avg_launch_ms': round(avg[dom], 3),
+                'kernel_source_id': src_id,
+                # the same with the gathers the kernel actually issues
+                'frac_gathers_issued': round(issued / (avg['sweep'] * 1e-3) / 1e9 / 8000.0, 5) if dom == 'sweep' and avg['sweep'] > 0 else None,
+                'algorithmic_bytes_gathers_issued': issued if dom == 'sweep' else None,
             },
+            'roofline_front': front,
         }
         if parity is not None:
             out['parity_sample'] = parity

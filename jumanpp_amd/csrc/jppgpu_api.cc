@@ -6,8 +6,6 @@
 // infrastructure and is never loaded by the product.)
 #include "../../include/jppgpu.h"
 
-#include <sched.h>
-
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,17 +89,10 @@ void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t s) {
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
   (void)hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s);
 }
-// The pipeline's host syncs sit between short device phases, and the GPU idles from the moment the awaited copy lands
-// until the host has noticed and enqueued the next kernels: poll the stream (yielding the core) instead of sleeping
-// in the driver -- the wake-up latency of a blocking hipStreamSynchronize was ~0.1 ms per sync.
-void rt_sync(jpp_stream_t s) {
-  for (int spin = 0; spin < 200000; ++spin) {
-    const hipError_t e = hipStreamQuery(s);
-    if (e != hipErrorNotReady) return;
-    sched_yield();
-  }
-  (void)hipStreamSynchronize(s);
-}
+// (Polling the stream with sched_yield() instead of sleeping in the driver was measured in round 3: it buys ~0.02 ms per
+// sync when the host is idle, and it DOUBLED the batch time inside jumanpp_gpu, whose 32 format workers own the cores
+// the polling thread yields to.  The driver's blocking wait it is.)
+void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
 // "Everything enqueued before mark() has completed": lets the host wait for a copy while kernels enqueued behind
 // the mark keep the GPU busy.
 struct SyncPoint {
@@ -116,10 +107,6 @@ struct SyncPoint {
     if (!ev) {
       rt_sync(s);
       return;
-    }
-    for (int spin = 0; spin < 200000; ++spin) {
-      if (hipEventQuery(ev) != hipErrorNotReady) return;
-      sched_yield();
     }
     (void)hipEventSynchronize(ev);
   }

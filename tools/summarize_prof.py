@@ -42,8 +42,10 @@ def main():
             # HBM section), so the fetch side is doubled; narrow requests are then over-estimated, i.e. this is an
             # upper bound of the bytes that crossed the L2 <-> fabric interface
             e['hbm_bytes_per_launch'] = int(2 * e['FETCH_SIZE_KB'] * 1024 + e['WRITE_SIZE_KB'] * 1024)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+        import bench
         tj = {'batch': int(sys.argv[2]), 'sent_len': int(sys.argv[3]), 'dict_entries': int(sys.argv[4]),
-              'rnn': sys.argv[5] == '1', 'kernels': per_kernel,
+              'rnn': sys.argv[5] == '1', 'kernels': per_kernel, 'kernel_source_id': bench.kernel_source_id(),
               'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py`, '
                       'avg per launch; bytes = 2 x FETCH_SIZE KB (gfx950 tallies a 128-B request at 64 B; calibrated for streaming reads by the guide and for random 4-byte gathers by tools/micro/gather_calib.hip, profiles/r02_f_gather_calib.txt) + WRITE_SIZE KB'}
         with open(os.path.join(out, 'traffic.json'), 'w') as f:
