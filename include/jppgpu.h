@@ -84,7 +84,12 @@ typedef struct {
   int32_t num_placeholders;    /* spec.features.numPlaceholders */
   const jppgpu_unk_maker* unk_makers; /* spec.unkCreators, in spec order */
   int32_t num_unk_makers;
-  const void* feature_spec;    /* flattened FeaturesSpec descriptors; must equal the built-in jumandic tables */
+  const void* feature_spec;    /* flattened FeaturesSpec descriptors (i32 lists: primitive, computed, pattern and n-gram
+                                * features in spec order).  Equal to the built-in jumandic tables: the compiled-in
+                                * kernels run (the reference's generated static code, features_api.cc:38-47); any
+                                * other spec within the device layout: the table-driven kernels with the summation
+                                * orders of the reference's dynamic feature objects; outside it: JPPGPU_NOT_IMPLEMENTED
+                                * with the reason in jppgpu_last_error() */
   size_t feature_spec_bytes;
   /* optional RNN re-ranker = blocks of the model's Rnn part
    * (src/core/analysis/rnn_scorer_gbeam.cc:375-398): data[1..6] + decoded header */
