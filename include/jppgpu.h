@@ -126,6 +126,10 @@ typedef struct {
   int32_t use_rnn;          /* 1: run the RNN scorer (ScorerDef::others), needs model.has_rnn */
   float weight_perceptron;  /* ScorerDef::scoreWeights[0] (used only with use_rnn) */
   float weight_rnn;         /* ScorerDef::scoreWeights[1] */
+  int32_t dynamic_features; /* 1: score with the summation orders of the reference's table-driven (dynamic) feature
+                             * objects even when the spec is the compiled-in one -- what its trainer runs
+                             * (TrainingEnv::initFeatures(nullptr), src/jumandic/main/jumanpp_train.cc:206,
+                             * src/core/features_api.cc:20-60).  0: static code when the spec matches (the analyser). */
 } jppgpu_config;
 
 /* EntryPtr::BOS() / EntryPtr::EOS() raw values (src/core/core_types.h:44-58) */
@@ -267,6 +271,40 @@ typedef void (*jppgpu_score_plugin_fn)(void* user, const jppgpu_lattice_nodes* l
 int jppgpu_analyze_batch_plugin(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
                                 jppgpu_score_plugin_fn plugin, void* user, jppgpu_result** out);
 
+/* Trainer hook-up, first half: gold nodes.  The reference's trainer looks at the node seeds of a sentence after the
+ * dictionary and UNK makers ran and before the lattice is built, and appends a seed for every node of the gold
+ * analysis that is not among them (Trainer::prepare, src/core/training/trainer.cc:13-47;
+ * TrainingExampleAdapter::ensureNodes / makeUnkTrainingNode, src/core/training/gold_example.h:88-109,
+ * gold_example.cc:118-136).  The batched form: once the seeds of the whole batch exist on the device, `hook` sees them
+ * on the host (in their final order: by start, then creation) and returns the seeds to add; they are inserted behind the
+ * makers' seeds of their start position, sentences that received seeds are checked for connectivity again (a sentence the
+ * makers left disconnected becomes analysable; one that stays disconnected gets JPPGPU_SENT_NO_LATTICE), and the
+ * analysis continues.  An added node is an UNK node with template_ptr 0, the given content hash and entry row, zero
+ * placeholders and maker == JPPGPU_GOLD_MAKER; its EntryPtr follows those of the makers' UNK nodes. */
+#define JPPGPU_GOLD_MAKER 0xffff
+typedef struct {
+  uint32_t n_sentences;
+  const int32_t* status;         /* [n] JPPGPU_SENT_OK or JPPGPU_SENT_NO_LATTICE: seeds present; anything else: none */
+  const uint32_t* n_codepoints;  /* [n] */
+  const uint32_t* n_seeds;       /* [n] */
+  const uint64_t* seed_base;     /* [n] */
+  const jppgpu_node* seeds;      /* entry_ptr < 0: an UNK node (not yet numbered), described by unk[] */
+  const jppgpu_unk* unk;
+} jppgpu_seed_view;
+typedef struct {
+  uint16_t start, end;           /* codepoint span */
+  int32_t content_hash;          /* hashUnkString(surface) */
+  int32_t row[8];                /* entry row, model.num_features values */
+} jppgpu_extra_seed;
+typedef struct {
+  const uint32_t* offsets;       /* [n + 1] CSR over the sentences; NULL: nothing to add */
+  const jppgpu_extra_seed* seeds;/* ascending start within a sentence */
+} jppgpu_extra_seeds;
+/* fills *out with arrays that stay valid until jppgpu_analyze_batch_seeds returns; non-zero return aborts the batch */
+typedef int (*jppgpu_seed_hook_fn)(void* user, const jppgpu_seed_view* seeds, jppgpu_extra_seeds* out);
+int jppgpu_analyze_batch_seeds(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                               jppgpu_seed_hook_fn hook, void* user, jppgpu_result** out);
+
 int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                 uint32_t total_bytes, void* stream, jppgpu_result** out);
 /* Copy results to the host.  full=0 (JPPGPU_FETCH_BASIC): status, node table, UNK table, top-1 paths.
@@ -324,6 +362,12 @@ typedef struct {
   const uint32_t* features;        /* [path_first[n]][n_ngram] */
 } jppgpu_top1_ngrams_view;
 int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_ngrams_view* view);
+/* The same values along caller-given paths (the gold path: LossCalculator::resolveGold, loss.cc:366-389):
+ * path_first[n + 1] offsets into path_nodes, which lists sentence-local node indices in TEXT order; the first two
+ * positions of a path see the BOS nodes as t1 / t2 (NgramFeatureRef::init).  In the returned view path_first /
+ * path_nodes repeat the input and features[k] belongs to position k.  Paths of failed sentences must be empty. */
+int jppgpu_result_fetch_path_ngrams(jppgpu_result* res, const uint64_t* path_first, const uint32_t* path_nodes,
+                                    jppgpu_top1_ngrams_view* view);
 /* Replaces the perceptron weight table of the context (the trainer's update step; HashedFeaturePerceptron /
  * FloatBufferWeights, src/core/analysis/perceptron.h:76-94, score_api.h:29-42).  n must equal the model's table
  * size; takes effect for the next jppgpu_analyze_batch* on the context. */

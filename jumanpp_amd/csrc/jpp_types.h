@@ -152,6 +152,16 @@ struct NodeAux {
   u16 pad;
 };
 
+// A node the trainer adds to the seeds of a sentence (TrainingExampleAdapter::makeUnkTrainingNode,
+// src/core/training/gold_example.cc:118-136): an UNK node with template EntryPtr 0 whose entry row is given.
+// NodeAux of such a node: maker == kGoldMaker, pad = its index among the sentence's extra seeds.
+struct ExtraSeed {
+  u16 start, end;
+  i32 hash;
+  i32 row[8];
+};
+constexpr u16 kGoldMaker = 0xffff;
+
 // One beam slot: the index form of ConnectionBeamElement
 // (src/core/analysis/lattice_config.h:37-79).  `prev_node` (sentence-local
 // node id of the left node) replaces the host pointer `previous`.
@@ -278,6 +288,9 @@ struct Batch {
   u32* gstats;             // [8] batch statistics: [0] max right nodes at one boundary, [1..3] sentences per sweep class
   u32* sent_maxr;          // [n] widest boundary (right nodes) of the sentence (k_layout)
   u32* sweep_list;         // [3][n] sentence indices by sweep class (k_sweep_classify)
+  // gold nodes injected by the trainer (jppgpu_analyze_batch_seeds): CSR over the sentences; null otherwise
+  const u32* gold_off;     // [n + 1]
+  const ExtraSeed* gold;   // [gold_off[n]]
   u64 total_nodes;
 };
 

@@ -16,6 +16,7 @@
 #include "jpp_rt.h"
 #include "jpp_types.h"
 #include "k_decode.h"
+#include "k_gold.h"
 #include "k_lattice.h"
 #include "k_rnn.h"
 #include "k_seeds.h"
@@ -308,6 +309,9 @@ struct jppgpu_result {
   bool ng_have = false;
   HostVec<u64> ng_first;
   HostVec<u32> ng_nodes, ng_feat;
+  // jppgpu_result_fetch_path_ngrams
+  HostVec<u64> gp_first;
+  HostVec<u32> gp_nodes, gp_feat;
   void bind(HostPool* pool);
 };
 
@@ -319,6 +323,7 @@ struct jppgpu_ctx {
   UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
   DevBuf trie, eptrs, edata, weights, dyn_spec;
   bool dynamic_spec = false;   // a spec other than the built-in jumandic tables: table-driven kernels
+  bool builtin_spec = false;   // the spec equals the compiled-in tables (k_path_ngrams reads them), also when dynamic_spec is forced
   DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
   DevBuf text, offs;
@@ -330,6 +335,9 @@ struct jppgpu_ctx {
   bool partial_pending = false;  // constraints uploaded for the next analyze call
   jppgpu_score_plugin_fn plugin_fn = nullptr;  // host plugin of the next analyze call (jppgpu_analyze_batch_plugin)
   void* plugin_user = nullptr;
+  jppgpu_seed_hook_fn seed_hook = nullptr;     // gold-seed hook of the next analyze call (jppgpu_analyze_batch_seeds)
+  void* seed_user = nullptr;
+  DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
   DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
       path_nodes;
@@ -356,6 +364,7 @@ void jppgpu_result::bind(HostPool* pool) {
   t1_status.pool = pool; t1_ncp.pool = pool; t1_len.pool = pool; t1_idx.pool = pool; t1_base.pool = pool;
   t1_zero.pool = pool; t1_nodes.pool = pool; t1_unk.pool = pool;
   ng_first.pool = pool; ng_nodes.pool = pool; ng_feat.pool = pool;
+  gp_first.pool = pool; gp_nodes.pool = pool; gp_feat.pool = pool;
   nb_status.pool = pool; nb_ncp.pool = pool; nb_nnodes.pool = pool; nb_first.pool = pool; nb_eos.pool = pool; nb_items.pool = pool;
 }
 
@@ -528,7 +537,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
                            m->feature_spec_bytes == spec::kSpecBlobSize &&
                            memcmp(m->feature_spec, spec::kSpecBlob, spec::kSpecBlobSize) == 0;
   std::unique_ptr<DevSpec> dynSpec;
-  if (!builtinSpec) {
+  if (!builtinSpec || c->dynamic_features) {
     if (m->num_features < 1 || m->num_features > spec::kNumDicFeatures || m->num_placeholders < 0 ||
         m->num_placeholders > spec::kNumPlaceholders)
       return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: entry rows of more than 8 columns / more than 2 placeholders are not supported");
@@ -571,6 +580,15 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     rt_sync(nullptr);
     H.spec = ctx->dyn_spec.as<DevSpec>();
     ctx->dynamic_spec = true;
+    // (k_path_ngrams addresses the stored patterns by the compiled-in numbering)
+    if (builtinSpec) {
+      bool same = dynSpec->nstored == spec::kNumStoredPatterns;
+      for (int i = 0; i < dynSpec->npatterns; ++i)
+        same = same && dynSpec->patterns[i].slot == (i < spec::kNumStoredPatterns ? i : -1);
+      ctx->builtin_spec = same;
+    }
+  } else {
+    ctx->builtin_spec = true;
   }
   H.trie = ctx->trie.as<u32>();
   H.entry_ptrs = ctx->eptrs.as<u8>();
@@ -759,7 +777,8 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
-                    &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty};
+                    &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
+                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
@@ -919,6 +938,91 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
   rt_d2h(gstats, B.gstats, sizeof(gstats), st);
   rt_sync(st);
+  B.gold_off = nullptr;
+  B.gold = nullptr;
+  bool goldInserted = false;
+  if (ctx->seed_hook) {
+    // the trainer's gold nodes (jppgpu_analyze_batch_seeds): the hook sees the seeds of the batch and returns the ones to add
+    jppgpu_seed_hook_fn hook = ctx->seed_hook;
+    ctx->seed_hook = nullptr;
+    const size_t N = (size_t)totalNodes;
+    std::vector<i32> h_status(n);
+    std::vector<u32> h_ncp(n), h_nn(n), h_ns(n);
+    std::vector<u64> h_base(n + 1), h_sbase(n);
+    std::vector<NodeInfo> h_nodes(N);
+    std::vector<NodeAux> h_aux(N);
+    rt_d2h(h_status.data(), B.sent_status, n * 4, st);
+    rt_d2h(h_ncp.data(), B.sent_ncp, n * 4, st);
+    rt_d2h(h_nn.data(), B.sent_nodes, n * 4, st);
+    rt_d2h(h_base.data(), B.node_base, (n + 1) * 8, st);
+    if (N) {
+      rt_d2h(h_nodes.data(), B.node_info, N * sizeof(NodeInfo), st);
+      rt_d2h(h_aux.data(), B.node_aux, N * sizeof(NodeAux), st);
+    }
+    rt_sync(st);
+    auto live = [&](u32 q) { return h_status[q] == ST_OK || h_status[q] == ST_NO_LATTICE; };
+    for (u32 q = 0; q < n; ++q) {
+      h_ns[q] = live(q) && h_nn[q] >= 3 ? h_nn[q] - 3 : 0;   // without the two BOS nodes and EOS
+      h_sbase[q] = h_base[q] + 2;
+    }
+    static_assert(sizeof(jppgpu_node) == sizeof(NodeInfo) && sizeof(jppgpu_unk) == sizeof(NodeAux), "ABI node records");
+    static_assert(sizeof(jppgpu_extra_seed) == sizeof(ExtraSeed), "ABI extra seed record");
+    jppgpu_seed_view view{};
+    view.n_sentences = n;
+    view.status = h_status.data();
+    view.n_codepoints = h_ncp.data();
+    view.n_seeds = h_ns.data();
+    view.seed_base = h_sbase.data();
+    view.seeds = reinterpret_cast<const jppgpu_node*>(h_nodes.data());
+    view.unk = reinterpret_cast<const jppgpu_unk*>(h_aux.data());
+    jppgpu_extra_seeds extra{nullptr, nullptr};
+    if (hook(ctx->seed_user, &view, &extra) != 0) return fail(JPPGPU_INVALID_STATE, "the seed hook reported an error");
+    const u64 totalExtra = extra.offsets ? extra.offsets[n] : 0;
+    if (totalExtra) {
+      if (!extra.seeds || extra.offsets[0] != 0) return fail(JPPGPU_INVALID_PARAMETER, "extra seeds: bad offsets");
+      std::vector<u64> nbase(n + 1);
+      u64 acc = 0;
+      for (u32 q = 0; q < n; ++q) {
+        const u32 a = extra.offsets[q], b = extra.offsets[q + 1];
+        if (b < a || b - a > 0xffffu) return fail(JPPGPU_INVALID_PARAMETER, "extra seeds: bad offsets");
+        if (b > a && !live(q)) return fail(JPPGPU_INVALID_PARAMETER, "extra seeds for a sentence that has no seed table");
+        for (u32 k = a; k < b; ++k) {
+          const jppgpu_extra_seed& e = extra.seeds[k];
+          if (!(e.start < e.end && e.end <= h_ncp[q]) || (k > a && extra.seeds[k - 1].start > e.start))
+            return fail(JPPGPU_INVALID_PARAMETER, "extra seeds: span outside the sentence or starts not ascending");
+        }
+        nbase[q] = acc;
+        acc += h_nn[q] + (b - a);
+      }
+      nbase[n] = acc;
+      if (!(ctx->node_info2.ensure((acc + 8) * sizeof(NodeInfo)) && ctx->node_aux2.ensure((acc + 8) * sizeof(NodeAux)) &&
+            ctx->gold_off.ensure(((size_t)n + 1) * 4) && ctx->gold.ensure((size_t)totalExtra * sizeof(ExtraSeed)) &&
+            ctx->gold_base.ensure(((size_t)n + 1) * 8)))
+        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (gold seeds)");
+      rt_h2d(ctx->gold_off.p, extra.offsets, ((size_t)n + 1) * 4, st);
+      rt_h2d(ctx->gold.p, extra.seeds, (size_t)totalExtra * sizeof(ExtraSeed), st);
+      rt_h2d(ctx->gold_base.p, nbase.data(), ((size_t)n + 1) * 8, st);
+      B.gold_off = ctx->gold_off.as<u32>();
+      B.gold = ctx->gold.as<ExtraSeed>();
+      JPP_LAUNCH(k_gold_insert, wblocks, 64 * kLatWaves, st, B, (const u64*)ctx->gold_base.as<u64>(), ctx->node_info2.as<NodeInfo>(),
+                 ctx->node_aux2.as<NodeAux>(), ctx->unk_rank.n);
+      JPP_LAUNCH(k_gold_bounds, wblocks, 64 * kLatWaves, st, B, (const u64*)ctx->gold_base.as<u64>(),
+                 (const NodeInfo*)ctx->node_info2.as<NodeInfo>());
+      std::swap(ctx->node_info, ctx->node_info2);
+      std::swap(ctx->node_aux, ctx->node_aux2);
+      B.node_info = ctx->node_info.as<NodeInfo>();
+      B.node_aux = ctx->node_aux.as<NodeAux>();
+      {
+        u32 t0c, t1c;
+        sweep_class_thresholds(ctx->cfg, &t0c, &t1c);
+        JPP_LAUNCH(k_sweep_classify, sblocks, 256, st, B, t0c, t1c);
+      }
+      rt_d2h(gstats, B.gstats, sizeof(gstats), st);
+      rt_sync(st);   // (also: the hook's arrays are no longer read after this point)
+      totalNodes = acc;
+      goldInserted = true;
+    }
+  }
   const u32 maxR = gstats[0];
   B.total_nodes = totalNodes;
   const u64 cap = totalNodes + 8;
@@ -936,7 +1040,11 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.node_kept = ctx->node_kept.as<u8>();
   B.path_nodes = ctx->path_nodes.as<u32>();
   T.mark(2, st);
-  JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg, ctx->unk_rank);
+  {
+    UnkRank rk = ctx->unk_rank;
+    if (goldInserted) rk.n += 1;   // the gold nodes are created after every maker's (Trainer::prepare)
+    JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg, rk);
+  }
   T.mark(3, st);
   if (ctx->dynamic_spec) JPP_LAUNCH(k_t0_dyn, n, 64, st, B, (const DevModel*)ctx->dmodel);
   else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
@@ -1155,6 +1263,19 @@ extern "C" int jppgpu_analyze_batch_plugin(jppgpu_ctx* ctx, const char* utf8, co
   ctx->plugin_user = user;
   int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
   ctx->plugin_fn = nullptr;
+  return rc;
+}
+
+extern "C" int jppgpu_analyze_batch_seeds(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                          jppgpu_seed_hook_fn hook, void* user, jppgpu_result** out) {
+  if (!ctx || !offsets || !out || !hook) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (!ctx->dynamic_spec)
+    return fail(JPPGPU_INVALID_STATE, "jppgpu: gold seeds need a context created with dynamic_features = 1 (the trainer's feature code)");
+  if (ctx->cfg.nscorers > 1) return fail(JPPGPU_INVALID_STATE, "jppgpu: gold seeds are not scored by the RNN (the trainer runs the perceptron only)");
+  ctx->seed_hook = hook;
+  ctx->seed_user = user;
+  int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
+  ctx->seed_hook = nullptr;
   return rc;
 }
 
@@ -1468,7 +1589,7 @@ extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_n
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
-  if (ctx->dynamic_spec)
+  if (!ctx->builtin_spec)
     return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the trainer read-out exists for the built-in jumandic spec only");
   if (!res->ng_have) {
     if (res->generation != ctx->generation)
@@ -1495,6 +1616,40 @@ extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_n
   v->path_first = res->ng_first.data();
   v->path_nodes = res->ng_nodes.data();
   v->features = res->ng_feat.data();
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_fetch_path_ngrams(jppgpu_result* res, const uint64_t* path_first, const uint32_t* path_nodes,
+                                               jppgpu_top1_ngrams_view* v) {
+  if (!res || !res->ctx || !v || !path_first) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jppgpu_ctx* ctx = res->ctx;
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  if (!ctx->builtin_spec)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the trainer read-out exists for the built-in jumandic spec only");
+  if (res->generation != ctx->generation)
+    return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+  const u64 M = path_first[n];
+  if (path_first[0] != 0 || (M && !path_nodes)) return fail(JPPGPU_INVALID_PARAMETER, "bad path offsets");
+  for (u32 q = 0; q < n; ++q)
+    if (path_first[q + 1] < path_first[q]) return fail(JPPGPU_INVALID_PARAMETER, "bad path offsets");
+  jpp_stream_t st = ctx->last_stream;
+  if (!(ctx->nbest_off.ensure(((size_t)n + 2) * 8) && ctx->ng_nodes.ensure((M + 1) * 4) && ctx->ng_feat.ensure((M + 1) * kNumNgram * 4)))
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (n-gram fetch)");
+  rt_h2d(ctx->nbest_off.p, path_first, ((size_t)n + 1) * 8, st);
+  if (M) rt_h2d(ctx->ng_nodes.p, path_nodes, (size_t)M * 4, st);
+  if (n) JPP_LAUNCH(k_given_path_ngrams, n, 64, st, B, (const u64*)ctx->nbest_off.as<u64>(), (const u32*)ctx->ng_nodes.as<u32>(), ctx->ng_feat.as<u32>());
+  bool ok = res->gp_first.resize((size_t)n + 1) && res->gp_nodes.resize((size_t)M) && pull(res->gp_feat, ctx->ng_feat.p, (size_t)M * kNumNgram, st);
+  rt_sync(st);
+  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
+  memcpy(res->gp_first.data(), path_first, ((size_t)n + 1) * 8);
+  if (M) memcpy(res->gp_nodes.data(), path_nodes, (size_t)M * 4);
+  v->n_sentences = n;
+  v->n_ngram = (uint32_t)kNumNgram;
+  v->path_first = res->gp_first.data();
+  v->path_nodes = res->gp_nodes.data();
+  v->features = res->gp_feat.data();
   return JPPGPU_OK;
 }
 

@@ -224,6 +224,12 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
       for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? kEptrEOS : 0;
     } else if (ni.eptr >= 0) {
       read_entry_row(M, ni.eptr, entry, nf);
+    } else if (na.maker == kGoldMaker) {
+      // a gold node of the trainer: the row is given (gold_example.cc:118-136)
+      isUnk = true;
+      const ExtraSeed* g = B.gold + B.gold_off[s] + na.pad;
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? g->row[f] : 0;
     } else {
       isUnk = true;
       const UnkMaker& mk = M.makers[M.maker_of_spec[na.maker]];

@@ -12,6 +12,7 @@
 // and produces what `oracle/ref_dump export` writes into a model image; tests/test_host_cli.py runs the same
 // analyses from both and against the reference CLI.
 #include <cstring>
+#include <fstream>
 #include <map>
 
 #include "model_image.h"
@@ -93,6 +94,11 @@ struct UnkDesc {  // spec::UnkProcessorDescriptor
 };
 struct TrainDesc {
   int32_t number, fieldIdx, dicIdx;
+  float weight;
+};
+struct AllowedDesc {
+  int32_t target, source;
+  std::string key;
 };
 struct BuiltFieldDesc {
   int32_t dicIndex, specIndex, uniqueValues;
@@ -128,19 +134,24 @@ Status ModelImage::loadJppmdl(const std::string& fn) {
   };
   std::vector<Part> parts;
   uint64_t nparts = l.varint();
+  rawParts_.clear();
   for (uint64_t i = 0; i < nparts && l.ok; ++i) {
     Part pt;
+    RawPart rp;
     pt.kind = l.i32();
-    (void)l.str();  // comment
+    rp.kind = pt.kind;
+    rp.comment = l.str();
     uint64_t nb = l.varint();
     for (uint64_t b = 0; b < nb && l.ok; ++b) {
       uint64_t off = l.varint(), size = l.varint();
       if (off + size > sz) return Status::InvalidState() << "model file " << fn << " has a block outside the file";
       pt.data.push_back(StringPiece(base + off, (size_t)size));
+      rp.blocks.emplace_back((size_t)off, (size_t)size);
     }
     (void)l.varint();  // start
     (void)l.varint();  // end
     parts.push_back(std::move(pt));
+    rawParts_.push_back(std::move(rp));
   }
   if (!l.ok || !l.atEnd()) return Status::InvalidState() << "model file " << fn << " has corrupted model header";
   auto firstPartOf = [&](int32_t kind) -> const Part* {
@@ -270,18 +281,23 @@ Status ModelImage::loadJppmdl(const std::string& fn) {
     unks.push_back(std::move(u));
   }
   // training spec
-  (void)d.i32();  // surfaceIdx
+  const int32_t trainSurfaceIdx = d.i32();
   std::vector<TrainDesc> trains;
   for (uint64_t i = 0, n = d.varint(); i < n && d.ok; ++i) {
     TrainDesc t;
     t.number = d.i32();
     t.fieldIdx = d.i32();
     t.dicIdx = d.i32();
-    (void)d.f32();
+    t.weight = d.f32();
     trains.push_back(t);
   }
+  std::vector<AllowedDesc> allowed;
   for (uint64_t i = 0, n = d.varint(); i < n && d.ok; ++i) {  // allowedUnk
-    (void)d.i32(); (void)d.i32(); (void)d.str();
+    AllowedDesc a;
+    a.target = d.i32();
+    a.source = d.i32();
+    a.key = d.str();
+    allowed.push_back(std::move(a));
   }
   const uint32_t magic2 = (uint32_t)d.varint();
   if (!d.ok || !d.atEnd()) return Status::InvalidParameter("failed to load dictionary metadata from model file");
@@ -351,11 +367,35 @@ Status ModelImage::loadJppmdl(const std::string& fn) {
     if (t.fieldIdx < 0 || (size_t)t.fieldIdx >= fdesc.size()) return Status::InvalidParameter("bad training field in the model");
     trainFields_.push_back(TrainField{fdesc[t.fieldIdx].name, t.dicIdx});
   }
+  trainingSpec_ = TrainingSpecInfo();
+  trainingSpec_.surfaceIdx = trainSurfaceIdx;
+  for (auto& t : trains) {
+    TrainingFieldSpec f;
+    f.number = t.number;
+    f.fieldIdx = t.fieldIdx;
+    f.dicIdx = t.dicIdx;
+    f.weight = t.weight;
+    f.name = fdesc[t.fieldIdx].name;
+    trainingSpec_.fields.push_back(std::move(f));
+  }
+  for (auto& a : allowed) {
+    if (a.target < 0 || (size_t)a.target >= fdesc.size() || a.source < 0 || (size_t)a.source >= fdesc.size())
+      return Status::InvalidParameter("bad allowed-unk field in the model");
+    AllowedUnkFieldSpec f;
+    f.targetField = a.target;
+    f.sourceField = a.source;
+    f.targetName = fdesc[a.target].name;
+    f.sourceName = fdesc[a.source].name;
+    f.sourceKey = a.key;
+    f.sourceDicIndex = fdesc[a.source].dicIndex;
+    trainingSpec_.allowedUnk.push_back(std::move(f));
+  }
 
   // ---- perceptron ----
   const Part* perc = firstPartOf(1);
-  if (perc == nullptr || perc->data.size() < 2) return Status::InvalidParameter("model image has no perceptron weights (untrained model)");
-  {
+  if ((perc == nullptr || perc->data.size() < 2) && !allowUntrained_)
+    return Status::InvalidParameter("model image has no perceptron weights (untrained model)");
+  if (perc != nullptr && perc->data.size() >= 2) {
     Loader pl(perc->data[0]);
     int32_t exponent = pl.i32();
     if (!pl.ok || exponent < 0 || exponent > 40 || perc->data[1].size() != ((size_t)4 << exponent)) {
@@ -532,6 +572,81 @@ Status ModelImage::applyRnnConfig(const RnnConfigOverride& o, bool* useRnn, RnnS
   *useRnn = true;
   weights->perceptron = o.perceptronWeight;  // scoreWeights come from the override itself, not from the merge
   weights->rnn = o.rnnWeight;
+  return Status::Ok();
+}
+
+namespace {
+void putVarint(std::string* o, uint64_t v) {
+  while (v >= 0x80) {
+    o->push_back((char)(v | 0x80));
+    v >>= 7;
+  }
+  o->push_back((char)v);
+}
+}  // namespace
+
+Status ModelImage::saveWithPerceptron(const std::string& path, const float* weights, uint32_t exponent, const std::string& comment) const {
+  if (rawParts_.empty()) return Status::InvalidState() << "only a natively loaded .jppmdl can be saved";
+  struct OutPart {
+    int32_t kind;
+    std::string comment;
+    std::vector<StringPiece> data;
+  };
+  std::vector<OutPart> parts;
+  for (const auto& rp : rawParts_) {
+    OutPart o{rp.kind, rp.comment, {}};
+    for (const auto& b : rp.blocks) o.data.push_back(StringPiece(data_.data() + b.first, b.second));
+    parts.push_back(std::move(o));
+  }
+  std::string percHeader;
+  putVarint(&percHeader, exponent);   // PerceptronInfo::modelSizeExponent (perceptron_io.h)
+  {
+    OutPart o{1, comment, {}};
+    o.data.push_back(StringPiece(percHeader));
+    o.data.push_back(StringPiece(reinterpret_cast<const char*>(weights), (size_t)4 << exponent));
+    parts.push_back(std::move(o));
+  }
+  // layout: every block on its own 4096-byte boundary, the header in the first page
+  auto align4k = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+  std::string hdr;
+  putVarint(&hdr, parts.size());
+  size_t offset = 4096;
+  std::vector<std::pair<size_t, StringPiece>> placed;
+  for (const auto& pt : parts) {
+    putVarint(&hdr, (uint32_t)pt.kind);
+    putVarint(&hdr, pt.comment.size());
+    hdr += pt.comment;
+    putVarint(&hdr, pt.data.size());
+    const size_t start = offset;
+    for (const auto& b : pt.data) {
+      putVarint(&hdr, offset);
+      putVarint(&hdr, b.size());
+      placed.emplace_back(offset, b);
+      offset = align4k(offset + b.size());
+    }
+    putVarint(&hdr, start);
+    putVarint(&hdr, offset);
+  }
+  if (hdr.size() > 4080) return Status::NotImplemented() << "model header size >4080 bytes is not implemented";
+  std::ofstream out(path, std::ios::binary | std::ios::trunc);
+  if (!out) return Status::InvalidParameter() << "could not open " << path << " for writing";
+  std::string page(4096, '\0');
+  std::memcpy(&page[0], "jp2Mdl!", 8);
+  std::string sz;
+  putVarint(&sz, hdr.size());
+  std::memcpy(&page[8], sz.data(), sz.size());
+  std::memcpy(&page[8 + sz.size()], hdr.data(), hdr.size());
+  out.write(page.data(), (std::streamsize)page.size());
+  size_t at = 4096;
+  const std::string zeros(4096, '\0');
+  for (const auto& pb : placed) {
+    if (pb.first > at) out.write(zeros.data(), (std::streamsize)(pb.first - at));
+    out.write(pb.second.data(), (std::streamsize)pb.second.size());
+    at = pb.first + pb.second.size();
+  }
+  if (offset > at) out.write(zeros.data(), (std::streamsize)(offset - at));
+  out.flush();
+  if (!out) return Status::InvalidState() << "failed to write " << path;
   return Status::Ok();
 }
 

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <string>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "jpp_status.h"
@@ -40,6 +41,25 @@ struct DictionaryField {
 struct TrainField {
   std::string name;   // dictionary field name
   int32_t dicIdx = 0; // entry-row column
+};
+
+// spec::TrainingSpec (src/core/spec/spec_types.h:181-198), what the trainer reads
+struct TrainingFieldSpec {
+  int32_t number = 0;    // column in the training example
+  int32_t fieldIdx = 0;  // index of the field in the dictionary spec
+  int32_t dicIdx = 0;    // entry-row column
+  float weight = 0;
+  std::string name;      // dictionary field name
+};
+struct AllowedUnkFieldSpec {
+  int32_t targetField = 0, sourceField = 0;   // spec indices
+  std::string targetName, sourceName, sourceKey;
+  int32_t sourceDicIndex = 0;                 // FieldDescriptor::dicIndex of the source field (< 0: data column)
+};
+struct TrainingSpecInfo {
+  int32_t surfaceIdx = 0;
+  std::vector<TrainingFieldSpec> fields;
+  std::vector<AllowedUnkFieldSpec> allowedUnk;
 };
 
 struct RnnScoreWeights {
@@ -74,6 +94,15 @@ class ModelImage {
   std::unordered_map<uint64_t, uint64_t> posMap_, conjMap_;
   bool hasIdMap_ = false;
   std::vector<TrainField> trainFields_;
+  TrainingSpecInfo trainingSpec_;
+  // the container's parts as loaded (jppmdl only): what saveWithPerceptron re-emits
+  struct RawPart {
+    int32_t kind = 0;
+    std::string comment;
+    std::vector<std::pair<size_t, size_t>> blocks;   // (offset, size) in data_
+  };
+  std::vector<RawPart> rawParts_;
+  bool allowUntrained_ = false;
   std::vector<char> ownedFeatureSpec_;
   size_t fileSize_ = 0;
   Status loadImage(const std::string& fn);
@@ -85,6 +114,16 @@ class ModelImage {
   ModelImage& operator=(const ModelImage&) = delete;
 
   Status loadModel(StringPiece filename);
+  // the trainer starts from a model without a perceptron part (jpp_jumandic_bootstrap output): weights stay null
+  Status loadModelForTraining(StringPiece filename) {
+    allowUntrained_ = true;
+    return loadModel(filename);
+  }
+  const TrainingSpecInfo& trainingSpec() const { return trainingSpec_; }
+  // the trainer's output: the loaded .jppmdl with a perceptron part appended (jumanpp_train.cc doTrainJpp:
+  // env.modelInfoCopy() + SoftConfidenceWeighted::exportModel, scw.cc:128-151; container: ModelSaver::save,
+  // src/core/impl/model_io.cc:47-99).  Readable by the reference and by loadModel.
+  Status saveWithPerceptron(const std::string& path, const float* weights, uint32_t exponent, const std::string& comment) const;
 
   const jppgpu_model& cmodel() const { return model_; }
   bool hasRnn() const { return hasRnn_; }
