@@ -43,7 +43,8 @@ class Model(C.Structure):
 class Config(C.Structure):
     _fields_ = [('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
                 ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32),
-                ('use_rnn', C.c_int32), ('weight_perceptron', C.c_float), ('weight_rnn', C.c_float)]
+                ('use_rnn', C.c_int32), ('weight_perceptron', C.c_float), ('weight_rnn', C.c_float),
+                ('dynamic_features', C.c_int32)]
 
 
 class ResultView(C.Structure):
@@ -73,6 +74,18 @@ class NgramsView(C.Structure):
                 ('features', C.c_void_p)]
 
 
+class SeedView(C.Structure):
+    _fields_ = [('n_sentences', C.c_uint32), ('status', C.c_void_p), ('n_codepoints', C.c_void_p), ('n_seeds', C.c_void_p),
+                ('seed_base', C.c_void_p), ('seeds', C.c_void_p), ('unk', C.c_void_p)]
+
+
+class ExtraSeeds(C.Structure):
+    _fields_ = [('offsets', C.c_void_p), ('seeds', C.c_void_p)]
+
+
+SEED_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SeedView), C.POINTER(ExtraSeeds))
+EXTRA_SEED_DT = np.dtype([('start', '<u2'), ('end', '<u2'), ('hash', '<i4'), ('row', '<i4', (8,))])
+
 NODE_DT = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
 UNK_DT = np.dtype([('tmpl', '<i4'), ('hash', '<i4'), ('ph0', '<u2'), ('ph1', '<u2'), ('maker', '<u2'), ('pad', '<u2')])
 BEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('total', '<f4'), ('prev_node', '<u4'), ('pad', '<u4')])
@@ -101,6 +114,9 @@ def load_library(path=None):
     lib.jppgpu_result_fetch_nbest.argtypes = [C.c_void_p, C.c_int32, C.POINTER(NbestView)]
     lib.jppgpu_result_fetch_top1_ngrams.argtypes = [C.c_void_p, C.POINTER(NgramsView)]
     lib.jppgpu_ctx_set_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.jppgpu_analyze_batch_seeds.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, SEED_HOOK, C.c_void_p,
+                                               C.POINTER(C.c_void_p)]
+    lib.jppgpu_result_fetch_path_ngrams.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NgramsView)]
     lib.jppgpu_result_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.jppgpu_result_release.argtypes = [C.c_void_p]
     lib.jppgpu_result_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
@@ -203,6 +219,17 @@ class Result:
         total = int(first[-1]) if n else 0
         return first, self._arr(v.path_nodes, '<u4', total), self._arr(v.features, '<u4', total * v.n_ngram).reshape(total, v.n_ngram)
 
+    def fetch_path_ngrams(self, path_first, path_nodes):
+        """features [M, n_ngram] of jppgpu_result_fetch_path_ngrams for paths given in text order"""
+        pf = np.ascontiguousarray(path_first, dtype=np.uint64)
+        pn = np.ascontiguousarray(path_nodes, dtype=np.uint32)
+        v = NgramsView()
+        rc = self.ctx.lib.jppgpu_result_fetch_path_ngrams(self.handle, pf.ctypes.data, pn.ctypes.data, C.byref(v))
+        if rc != 0:
+            raise JppGpuError(self.ctx.lib.jppgpu_last_error().decode())
+        total = int(pf[-1])
+        return self._arr(v.features, '<u4', total * v.n_ngram).reshape(total, v.n_ngram)
+
     def stats(self):
         a, b = C.c_uint64(), C.c_uint64()
         rc = self.ctx.lib.jppgpu_result_stats(self.handle, C.byref(a), C.byref(b))
@@ -233,7 +260,7 @@ class Context:
 
     def __init__(self, image_path, beam=5, global_beam=6, right_check=1, right_beam=5,
                  max_input_bytes=4096, device=0, lib_path=None, use_rnn=None,
-                 weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None):
+                 weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None, dynamic_features=False, max_unk_makers=None):
         """use_rnn=None: run the RNN scorer iff the model image has an RNN part (what
         JumanppEnv::loadModel does); the score weights default to the model's saved
         RnnInferenceConfig (env.cc:86-100)."""
@@ -278,7 +305,7 @@ class Context:
             makers[i] = UnkMaker(t, cc, pp, pr, ph, mask)
         self._keep.append(makers)
         m.unk_makers = makers
-        m.num_unk_makers = n_unk
+        m.num_unk_makers = n_unk if max_unk_makers is None else min(n_unk, max_unk_makers)   # (tests: a model whose makers cannot connect every input)
         m.feature_spec, m.feature_spec_bytes = buf(by[7][0][1])
         self.has_rnn = 11 in by and any(a == 100 for a, _ in by[11])
         wp, wr = 1.0, 0.0
@@ -307,7 +334,7 @@ class Context:
         if weight_rnn is not None:
             wr = weight_rnn
         cfg = Config(beam, global_beam, right_check, right_beam, max_input_bytes, device,
-                     1 if use_rnn else 0, wp, wr)
+                     1 if use_rnn else 0, wp, wr, 1 if dynamic_features else 0)
         h = C.c_void_p()
         rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -326,6 +353,55 @@ class Context:
         rc = self.lib.jppgpu_analyze_batch(self.handle, text, offs.ctypes.data, len(enc), C.byref(r))
         if rc != 0:
             raise JppGpuError('jppgpu_analyze_batch failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+        return Result(self, r)
+
+    def analyze_with_seeds(self, sentences, hook):
+        """jppgpu_analyze_batch_seeds.  hook(seeds) -> list (one per sentence) of lists of (start, end, hash, row[<=8]);
+        `seeds` is a dict of numpy arrays: status, n_codepoints, n_seeds, seed_base, seeds (NODE_DT), unk (UNK_DT)"""
+        enc = [s.encode('utf-8') if isinstance(s, str) else bytes(s) for s in sentences]
+        n = len(enc)
+        offs = np.zeros(n + 1, dtype=np.uint32)
+        if enc:
+            offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64).astype(np.uint32)
+        keep = {}
+
+        def c_hook(_user, view_p, out_p):
+            try:
+                v = view_p.contents
+
+                def arr(ptr, dt, cnt):
+                    if not ptr or cnt == 0:
+                        return np.zeros(0, dtype=dt)
+                    return np.frombuffer((C.c_char * (np.dtype(dt).itemsize * cnt)).from_address(ptr), dtype=dt).copy()
+                ns = arr(v.n_seeds, '<u4', n)
+                sb = arr(v.seed_base, '<u8', n)
+                total = int((sb + ns).max()) if n else 0
+                view = {'status': arr(v.status, '<i4', n), 'n_codepoints': arr(v.n_codepoints, '<u4', n), 'n_seeds': ns,
+                        'seed_base': sb, 'seeds': arr(v.seeds, NODE_DT, total), 'unk': arr(v.unk, UNK_DT, total)}
+                extra = hook(view)
+                eo = np.zeros(n + 1, dtype=np.uint32)
+                flat = []
+                for q in range(n):
+                    flat.extend(extra[q] if extra else [])
+                    eo[q + 1] = len(flat)
+                es = np.zeros(len(flat), dtype=EXTRA_SEED_DT)
+                for k, (st, en, h, row) in enumerate(flat):
+                    es[k]['start'], es[k]['end'], es[k]['hash'] = st, en, h
+                    es[k]['row'][:len(row)] = row
+                keep['eo'], keep['es'] = eo, es
+                out_p.contents.offsets = eo.ctypes.data
+                out_p.contents.seeds = es.ctypes.data if len(flat) else None
+                return 0
+            except Exception as e:   # an exception must not cross the C frame
+                keep['error'] = e
+                return 1
+        cb = SEED_HOOK(c_hook)
+        r = C.c_void_p()
+        rc = self.lib.jppgpu_analyze_batch_seeds(self.handle, b''.join(enc), offs.ctypes.data, n, cb, None, C.byref(r))
+        if 'error' in keep:
+            raise keep['error']
+        if rc != 0:
+            raise JppGpuError('jppgpu_analyze_batch_seeds failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
         return Result(self, r)
 
     def analyze_device(self, d_text_ptr, d_offsets_ptr, n, total_bytes, stream=None):
