@@ -8,9 +8,11 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "jpp_rt.h"
@@ -338,6 +340,14 @@ struct jppgpu_ctx {
   jppgpu_seed_hook_fn seed_hook = nullptr;     // gold-seed hook of the next analyze call (jppgpu_analyze_batch_seeds)
   void* seed_user = nullptr;
   DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
+  // per-entry T0 memo (k_t0_memo): device table + what its weight-dependent half is rebuilt from
+  DevBuf t0_memo;
+  u32 t0_memo_slots = 0;
+  struct MemoSeed {
+    u32 slot, len;
+    i32 row[spec::kNumDicFeatures];
+  };
+  std::vector<MemoSeed> t0_memo_seeds;
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
   DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
       path_nodes;
@@ -503,6 +513,176 @@ std::string parse_feature_spec(const void* blob, size_t bytes, int numFeatures, 
     for (int q = 0; q < 3; ++q) out->tri_t[i][q] = (u8)out->patterns[tri[i].refs[q]].slot;
   }
   return std::string();
+}
+}  // namespace
+
+namespace {
+// ---- per-entry T0 memo (k_t0.h: T0Memo) ------------------------------------------------------------------------------
+// Every key of the double array with the codepoint length of its surface: depth-first over the units (darts-clone
+// layout as in jpp_device.h: trie_step).
+struct TrieKey {
+  i32 value;
+  u32 len;
+};
+unsigned memo_threads() {
+  unsigned hc = std::thread::hardware_concurrency();
+  return hc == 0 ? 1u : hc > 16 ? 16u : hc;
+}
+
+// the subtree below `start` (inclusive)
+void trie_subtree(const u32* units, size_t nunits, u32 start_id, u32 start_len, std::vector<TrieKey>* out) {
+  auto offset_of = [](u32 unit) { return (unit >> 10) << ((unit & (1u << 9)) >> 6); };
+  struct Item {
+    u32 id, len;
+  };
+  std::vector<Item> stack;
+  stack.push_back(Item{start_id, start_len});
+  size_t visited = 0;
+  while (!stack.empty() && visited <= nunits) {
+    const Item it = stack.back();
+    stack.pop_back();
+    ++visited;
+    const u32 unit = units[it.id];
+    const u32 base = it.id ^ offset_of(unit);
+    if ((unit >> 8) & 1) {
+      if (base < nunits) out->push_back(TrieKey{(i32)(units[base] & 0x7fffffffu), it.len});
+    }
+    for (u32 b = 1; b < 256; ++b) {
+      const u32 child = base ^ b;
+      if (child >= nunits || child == it.id) continue;
+      if ((units[child] & ((1u << 31) | 0xFFu)) != b) continue;
+      stack.push_back(Item{child, it.len + ((b & 0xC0u) != 0x80u ? 1u : 0u)});
+    }
+  }
+}
+
+void trie_keys(const u32* units, size_t nunits, std::vector<TrieKey>* out) {
+  if (nunits == 0) return;
+  // the first two byte levels by hand, their subtrees on worker threads
+  auto offset_of = [](u32 unit) { return (unit >> 10) << ((unit & (1u << 9)) >> 6); };
+  struct Start {
+    u32 id, len;
+  };
+  std::vector<Start> level{Start{0, 0}}, starts;
+  for (int depth = 0; depth < 2; ++depth) {
+    std::vector<Start> next;
+    for (const Start& st : level) {
+      const u32 unit = units[st.id];
+      const u32 base = st.id ^ offset_of(unit);
+      if (((unit >> 8) & 1) && base < nunits) out->push_back(TrieKey{(i32)(units[base] & 0x7fffffffu), st.len});
+      for (u32 b = 1; b < 256; ++b) {
+        const u32 child = base ^ b;
+        if (child >= nunits || child == st.id) continue;
+        if ((units[child] & ((1u << 31) | 0xFFu)) != b) continue;
+        next.push_back(Start{child, st.len + ((b & 0xC0u) != 0x80u ? 1u : 0u)});
+      }
+    }
+    level.swap(next);
+  }
+  starts.swap(level);
+  const unsigned nt = memo_threads();
+  std::vector<std::vector<TrieKey>> parts(nt);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt; ++t)
+    pool.emplace_back([&, t]() {
+      for (size_t i = t; i < starts.size(); i += nt) trie_subtree(units, nunits, starts[i].id, starts[i].len, &parts[t]);
+    });
+  for (auto& th : pool) th.join();
+  for (auto& pt : parts) out->insert(out->end(), pt.begin(), pt.end());
+}
+
+// the seeds of the memo: (slot, surface length, entry row) of every dictionary entry reachable through the trie
+void collect_memo_seeds(const jppgpu_model* m, std::vector<jppgpu_ctx::MemoSeed>* seeds, u32* nslots) {
+  std::vector<TrieKey> keys;
+  trie_keys(static_cast<const u32*>(m->trie), m->trie_bytes / 4, &keys);
+  const u8* eptrs = static_cast<const u8*>(m->entry_ptrs);
+  const u8* edata = static_cast<const u8*>(m->entry_data);
+  const u32 slots = (u32)(m->entry_data_bytes / 8 + 1);
+  std::vector<u32> seen(slots, 0);   // 0: free, otherwise 1 + index into seeds, ~0u: ambiguous
+  for (const TrieKey& k : keys) {
+    size_t pos = (size_t)(u32)k.value;
+    if (pos >= m->entry_ptrs_bytes) continue;
+    const u64 cnt = host_varint(eptrs, pos);
+    i32 ptr = 0;
+    for (u64 q = 0; q < cnt && pos < m->entry_ptrs_bytes; ++q) {
+      ptr += (i32)host_varint(eptrs, pos);
+      if (ptr < 0) break;
+      const size_t at = (size_t)((u32)ptr >> 1);
+      const u32 slot = (u32)(at >> 3);
+      if (slot >= slots || at + 8 * 10 > m->entry_data_bytes) continue;   // (entries at the very end of the blob take the full path)
+      jppgpu_ctx::MemoSeed sd{};
+      sd.slot = slot;
+      sd.len = k.len;
+      size_t rp = at;
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) sd.row[f] = (i32)host_varint(edata, rp);
+      if (seen[slot] == 0) {
+        seeds->push_back(sd);
+        seen[slot] = (u32)seeds->size();
+      } else if (seen[slot] != ~0u) {
+        const jppgpu_ctx::MemoSeed& o = (*seeds)[seen[slot] - 1];
+        if (o.len != sd.len || memcmp(o.row, sd.row, sizeof(sd.row)) != 0) {   // one record cannot serve two different nodes
+          (*seeds)[seen[slot] - 1].len = 0;
+          seen[slot] = ~0u;
+        }
+      }
+    }
+  }
+  *nslots = slots;
+}
+
+// records from the seeds and a weight table (host pointers)
+void fill_memo_range(const std::vector<jppgpu_ctx::MemoSeed>& seeds, size_t from, size_t to, const float* weights, u32 wmask, T0Memo* table) {
+  for (size_t i = from; i < to; ++i) {
+    const auto& sd = seeds[i];
+    if (sd.len == 0) continue;
+    T0Memo& r = table[sd.slot];
+    u64 prim[spec::kNumPrims];
+    u64 pat[spec::kNumPatterns];
+    t0_entry_prims(sd.row, sd.len, prim);
+    t0_pattern_hashes(prim, pat);
+    float w[spec::kNumUni];
+    for (int u = 0; u < spec::kNumUni; ++u)
+      w[u] = weights[(u32)hmix(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0]) & wmask];
+    bool ok = true;
+    for (int j = 0; j < 4; ++j) {
+      u32 bits;
+      memcpy(&bits, &w[j], 4);
+      ok = ok && bits != 0x80000000u;   // (0.f + -0.f differs from -0.f: the last node of a boundary starts its sums from 0.f)
+    }
+    if (!ok) continue;
+    for (int f = 0; f < spec::kNumDicFeatures; ++f) r.row[f] = sd.row[f];
+    for (int p = 0; p < spec::kNumStoredPatterns; ++p) r.pat[p] = pat[p];
+    for (int j = 0; j < 4; ++j) {
+      float acc = w[j];
+      for (int u = j + 4; u < kT0CtxFirst; u += 4) acc += w[u];
+      r.pre[j] = acc;
+    }
+    for (int u = kT0CtxLast + 1; u < spec::kNumUni; ++u) r.raw[u - kT0CtxLast - 1] = w[u];
+    r.len = sd.len;
+  }
+}
+
+// records from the seeds and a weight table (host pointers); the weight gathers miss the host caches, hence the threads
+void fill_memo(const std::vector<jppgpu_ctx::MemoSeed>& seeds, const float* weights, u32 wmask, std::vector<T0Memo>* table) {
+  const unsigned nt = memo_threads();
+  std::vector<std::thread> pool;
+  const size_t per = (seeds.size() + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t a = (size_t)t * per, b = a + per < seeds.size() ? a + per : seeds.size();
+    if (a >= b) break;
+    pool.emplace_back([&, a, b]() { fill_memo_range(seeds, a, b, weights, wmask, table->data()); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+bool upload_memo(jppgpu_ctx* ctx, const float* weights) {
+  std::vector<T0Memo> table((size_t)ctx->t0_memo_slots);
+  memset(static_cast<void*>(table.data()), 0, table.size() * sizeof(T0Memo));
+  fill_memo(ctx->t0_memo_seeds, weights, ctx->hmodel.wmask, &table);
+  if (!ctx->t0_memo.ensure(table.size() * sizeof(T0Memo))) return false;
+  rt_h2d(ctx->t0_memo.p, table.data(), table.size() * sizeof(T0Memo), nullptr);
+  rt_sync(nullptr);
+  return true;
 }
 }  // namespace
 
@@ -734,6 +914,25 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
   }
   rt_h2d(ctx->dmodel, &H, sizeof(DevModel), nullptr);
   rt_sync(nullptr);
+  // (developer knob JPPGPU_DEV_T0_MEMO=0: k_t0 without the per-entry memo)
+  static const bool devT0Memo = !(std::getenv("JPPGPU_DEV_T0_MEMO") && std::atoi(std::getenv("JPPGPU_DEV_T0_MEMO")) == 0);
+  if (!ctx->dynamic_spec && devT0Memo) {
+    const auto t_a = std::chrono::steady_clock::now();
+    collect_memo_seeds(m, &ctx->t0_memo_seeds, &ctx->t0_memo_slots);
+    const auto t_b = std::chrono::steady_clock::now();
+    if (!upload_memo(ctx, m->weights)) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
+    }
+    if (std::getenv("JPPGPU_DEV_T0_MEMO")) {   // =1 / =2: report
+      size_t valid = 0;
+      for (const auto& sd : ctx->t0_memo_seeds) valid += sd.len != 0;
+      std::fprintf(stderr, "[jppgpu] T0 memo: %zu entries (%zu with a record) in %u slots, trie walk %.1f ms, records + upload %.1f ms\n",
+                   ctx->t0_memo_seeds.size(), valid, ctx->t0_memo_slots,
+                   std::chrono::duration<double, std::milli>(t_b - t_a).count(),
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
+    }
+  }
   ctx->own_stream = rt_stream_create();
   ctx->timer.init();
   ctx->rnn_sync.init();
@@ -778,7 +977,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
-                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base};
+                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
@@ -1047,6 +1246,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   T.mark(3, st);
   if (ctx->dynamic_spec) JPP_LAUNCH(k_t0_dyn, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  else if (ctx->t0_memo_slots && ctx->hmodel.wmask <= 0xffffffu)
+    JPP_LAUNCH(k_t0_memo<true>, n, 64, st, B, (const DevModel*)ctx->dmodel, (const T0Memo*)ctx->t0_memo.as<T0Memo>(), ctx->t0_memo_slots);
+  else if (ctx->t0_memo_slots)
+    JPP_LAUNCH(k_t0_memo<false>, n, 64, st, B, (const DevModel*)ctx->dmodel, (const T0Memo*)ctx->t0_memo.as<T0Memo>(), ctx->t0_memo_slots);
   else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   B.node_penalty = nullptr;
@@ -1662,6 +1865,7 @@ extern "C" int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uin
   rt_sync(ctx->own_stream);
   rt_h2d(ctx->weights.p, weights, (size_t)n * 4, nullptr);
   rt_sync(nullptr);
+  if (ctx->t0_memo_slots && !upload_memo(ctx, weights)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
   return JPPGPU_OK;
 }
 

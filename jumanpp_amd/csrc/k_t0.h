@@ -39,14 +39,59 @@ __host__ __device__ constexpr u64 tri_prefix(int index) {
   return hmix(hmix(hmix(kHashSeed0, 5), (u64)(u32)index), kTrigramSeed);
 }
 
+// hash of pattern P over the primitive values (PatternFeatureStaticApply / feature_impl_pattern.h:28-41, compute features
+// feature_impl_compute.cc:12-26)
+template <int P>
+__host__ __device__ inline u64 t0_pattern_one(const u64 (&prim)[spec::kNumPrims]) {
+  u64 h = pattern_prefix(P, spec::kPatterns[P].nargs);
+#pragma unroll
+  for (int q = 0; q < spec::kPatterns[P].nargs; ++q) {
+    const int c = spec::kPatterns[P].args[q];
+    if (spec::kComputes[c].cond < 0) {
+      h = hmix(h, prim[spec::kComputes[c].t[0]]);
+    } else {
+      u64 ht = h, hf = h;
+#pragma unroll
+      for (int z = 0; z < spec::kComputes[c].nt; ++z) ht = hmix(ht, prim[spec::kComputes[c].t[z]]);
+#pragma unroll
+      for (int z = 0; z < spec::kComputes[c].nf; ++z) hf = hmix(hf, prim[spec::kComputes[c].f[z]]);
+      h = prim[spec::kComputes[c].cond] != 0 ? ht : hf;
+    }
+  }
+  return h;
+}
+template <int P = 0>
+__host__ __device__ inline void t0_pattern_hashes(const u64 (&prim)[spec::kNumPrims], u64 (&pat)[spec::kNumPatterns]) {
+  if constexpr (P < spec::kNumPatterns) {
+    pat[P] = t0_pattern_one<P>(prim);
+    t0_pattern_hashes<P + 1>(prim, pat);
+  }
+}
+
+// Which patterns look at the sentence around / under the node (codepoints, character classes) and which are a function
+// of the dictionary entry and the length of its surface alone: the latter are the same for every lattice node of one
+// dictionary entry, which is what the per-entry memo of k_t0_memo stores.
+constexpr bool t0_prim_is_context(int p) { return spec::kPrims[p].kind == spec::Codepoint || spec::kPrims[p].kind == spec::CodepointType; }
+constexpr bool t0_compute_is_context(int c) {
+  bool r = false;
+  if (spec::kComputes[c].cond < 0) return t0_prim_is_context(spec::kComputes[c].t[0]);
+  r = t0_prim_is_context(spec::kComputes[c].cond);
+  for (int z = 0; z < spec::kComputes[c].nt; ++z) r = r || t0_prim_is_context(spec::kComputes[c].t[z]);
+  for (int z = 0; z < spec::kComputes[c].nf; ++z) r = r || t0_prim_is_context(spec::kComputes[c].f[z]);
+  return r;
+}
+constexpr bool t0_pattern_is_context(int p) {
+  bool r = false;
+  for (int q = 0; q < spec::kPatterns[p].nargs; ++q) r = r || t0_compute_is_context(spec::kPatterns[p].args[q]);
+  return r;
+}
+
 // Primitive features and the kNumPatterns pattern hashes of one node (generated
 // PatternFeatureStaticApply_JumandicStatic::patternsAndUnigramsApply, first half; dynamic equivalent
 // InNodeFeatureComputer + PatternDynamicApplyImpl::apply, innode_features.cc:11-33, feature_impl_pattern.h:59-65)
 // from its entry row, its span and the codepoints / classes of the sentence.
-__device__ __forceinline__ void t0_patterns(const i32 (&entry)[spec::kNumDicFeatures], const NodeInfo& ni, const NodeAux& na,
-                                            bool isUnk, const u32* cps, const i32* cls, u32 n, u64 (&pat)[spec::kNumPatterns]) {
-  // ---- primitive features ----
-  u64 prim[spec::kNumPrims];
+__device__ __forceinline__ void t0_prims(const i32 (&entry)[spec::kNumDicFeatures], const NodeInfo& ni, const NodeAux& na,
+                                         bool isUnk, const u32* cps, const i32* cls, u32 n, u64 (&prim)[spec::kNumPrims]) {
 #pragma unroll
   for (int p = 0; p < spec::kNumPrims; ++p) {
     const int kind = spec::kPrims[p].kind;
@@ -84,27 +129,147 @@ __device__ __forceinline__ void t0_patterns(const i32 (&entry)[spec::kNumDicFeat
     }
     prim[p] = v;
   }
+}
 
-  // ---- pattern hashes ----
-#pragma unroll
-  for (int p = 0; p < spec::kNumPatterns; ++p) {
-    u64 h = pattern_prefix(p, spec::kPatterns[p].nargs);
-#pragma unroll
-    for (int q = 0; q < spec::kPatterns[p].nargs; ++q) {
-      const int c = spec::kPatterns[p].args[q];
-      if (spec::kComputes[c].cond < 0) {
-        h = hmix(h, prim[spec::kComputes[c].t[0]]);
-      } else {
-        u64 ht = h, hf = h;
-#pragma unroll
-        for (int z = 0; z < spec::kComputes[c].nt; ++z) ht = hmix(ht, prim[spec::kComputes[c].t[z]]);
-#pragma unroll
-        for (int z = 0; z < spec::kComputes[c].nf; ++z) hf = hmix(hf, prim[spec::kComputes[c].f[z]]);
-        h = prim[spec::kComputes[c].cond] != 0 ? ht : hf;
-      }
-    }
-    pat[p] = h;
+__device__ __forceinline__ void t0_patterns(const i32 (&entry)[spec::kNumDicFeatures], const NodeInfo& ni, const NodeAux& na,
+                                            bool isUnk, const u32* cps, const i32* cls, u32 n, u64 (&pat)[spec::kNumPatterns]) {
+  u64 prim[spec::kNumPrims];
+  t0_prims(entry, ni, na, isUnk, cps, cls, n, prim);
+  t0_pattern_hashes(prim, pat);
+}
+
+// ---- per-entry memo ------------------------------------------------------------------------------------------------
+// A dictionary node's entry row, its 14 stored patterns and 26 of its 32 unigram weights depend on the dictionary entry
+// only (placeholders are 0 for dictionary nodes, the surface length is the key's): one 176-byte record per entry, built
+// on the host when the model (or a new weight table) is loaded, replaces the varint decode, 32 pattern hashes and 26
+// scattered weight gathers -- the gathers are what bound k_t0 (3.2x line amplification at the fabric ceiling).
+// Record of the entry at EntryPtr e: slot (e >> 1) >> 3 (an entry row is at least 8 bytes long, so slots are unique).
+//   pre[j]: the weights of the features u = j, j + 4, ... < 23 summed in that order -- the four accumulators of
+//           computeUnrolled4RawPerceptron up to the first feature that looks at the context;
+//   raw[]:  the weights of the three features behind the context block (u = 29, 30, 31);
+//   len:    codepoints of the key (0: no record -- the node takes the full path).
+// The context features (u = 23..28) are hashed and gathered per node and added between the two, in the reference's order.
+struct alignas(16) U4 {
+  u32 x, y, z, w;
+};
+__host__ __device__ inline float bits_f32(u32 v) { return __builtin_bit_cast(float, v); }
+
+struct T0Memo {
+  i32 row[spec::kNumDicFeatures];
+  u64 pat[spec::kNumStoredPatterns];
+  float pre[4];
+  float raw[3];
+  u32 len;
+};
+static_assert(sizeof(T0Memo) == 176 && spec::kNumDicFeatures == 8 && spec::kNumStoredPatterns == 14, "memo record layout");
+constexpr int kT0CtxFirst = 23, kT0CtxLast = 28;   // unigram positions (summation order) that read the context
+constexpr bool t0_memo_layout_ok() {
+  if (spec::kNumUni != 32) return false;
+  for (int u = 0; u < spec::kNumUni; ++u)
+    if (t0_pattern_is_context(spec::kUni[u].t0) != (u >= kT0CtxFirst && u <= kT0CtxLast)) return false;
+  for (int p = 0; p < spec::kNumStoredPatterns; ++p)
+    if (t0_pattern_is_context(p)) return false;
+  return true;
+}
+static_assert(t0_memo_layout_ok(), "the memo assumes which unigram features read the context");
+
+// entry-only primitives (host: building the memo; placeholders 0, context primitives unused)
+__host__ __device__ inline void t0_entry_prims(const i32 (&entry)[spec::kNumDicFeatures], u32 len, u64 (&prim)[spec::kNumPrims]) {
+  for (int p = 0; p < spec::kNumPrims; ++p) {
+    const int kind = spec::kPrims[p].kind, a = spec::kPrims[p].a, bsh = spec::kPrims[p].b;
+    u64 v = 0;
+    if (kind == spec::Copy) v = (u32)entry[a];
+    else if (kind == spec::SingleBit) v = ((u32)entry[a] >> bsh) & 1u;
+    else if (kind == spec::SurfaceCodepointSize) v = len;
+    prim[p] = v;
   }
+}
+
+// the weights of the context features (summation positions kT0CtxFirst..kT0CtxLast) of one node
+template <bool W24, int U = kT0CtxFirst, typename WP>
+__device__ __forceinline__ void t0_context_weights(const u64 (&prim)[spec::kNumPrims], WP weights, u32 wmask, float (&wc)[kT0CtxLast - kT0CtxFirst + 1]) {
+  if constexpr (U <= kT0CtxLast) {
+    const u32 idx = hmix_index<W24>(uni_prefix(spec::kUni[U].index), t0_pattern_one<spec::kUni[U].t0>(prim), wmask);
+    wc[U - kT0CtxFirst] = weights[idx];
+    t0_context_weights<W24, U + 1>(prim, weights, wmask, wc);
+  }
+}
+
+// what a sentence's T0 pass needs of its sentence
+struct T0Sent {
+  u32 n, N, bb0;
+  u64 nb;
+  const u32* cps;
+  const i32* cls;
+};
+
+// one node, everything computed from scratch
+template <bool W24>
+__device__ __forceinline__ void t0_node_full(const Batch& B, const DevModel& M, const T0Sent& S, u32 k) {
+  NodeInfo ni = B.node_info[S.nb + k];
+  NodeAux na = B.node_aux[S.nb + k];
+  u32 b = (k == S.N - 1) ? S.n + 2 : (u32)ni.start + 2;
+  u32 first = B.bnd_first[S.bb0 + b];
+  u32 R = B.bnd_cnt[S.bb0 + b];
+  bool isLast = (k - first) == R - 1;
+
+  // ---- entry row ----
+  i32 entry[spec::kNumDicFeatures];
+  bool isUnk = false;
+  if (ni.eptr == kEptrEOS) {
+#pragma unroll
+    for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = kEptrEOS;
+  } else if (ni.eptr >= 0) {
+    read_entry_row(M, ni.eptr, entry, spec::kNumDicFeatures);
+  } else {
+    isUnk = true;
+    const UnkMaker& mk = M.makers[M.maker_of_spec[na.maker]];
+    if (mk.type == UNK_NORMALIZE) {
+      read_entry_row(M, na.tmpl, entry, spec::kNumDicFeatures);
+    } else {
+#pragma unroll
+      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = mk.tmpl[f];
+    }
+#pragma unroll
+    for (int f = 0; f < spec::kNumDicFeatures; ++f) {
+      if ((mk.replace_mask >> f) & 1) entry[f] = na.hash;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < spec::kNumDicFeatures; ++f) B.node_entry[(S.nb + k) * spec::kNumDicFeatures + f] = entry[f];
+
+  u64 pat[spec::kNumPatterns];
+  t0_patterns(entry, ni, na, isUnk, S.cps, S.cls, S.n, pat);
+#pragma unroll
+  for (int p = 0; p < spec::kNumStoredPatterns; ++p) B.node_pat[(S.nb + k) * kPat + p] = pat[p];
+
+  // ---- unigram perceptron ----
+  static_assert(spec::kNumUni >= 4, "unigram count");
+  float w[spec::kNumUni];
+#pragma unroll
+  for (int u = 0; u < spec::kNumUni; ++u) {
+    u32 idx = hmix_index<W24>(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0], M.wmask);
+    w[u] = as_global(M.weights)[idx];
+  }
+  float part[4];
+  if (isLast) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[j] = 0.f;
+#pragma unroll
+    for (int u = 0; u < spec::kNumUni; ++u) part[u & 3] += w[u];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[j] = w[j];
+#pragma unroll
+    for (int u = 4; u < spec::kNumUni; ++u) part[u & 3] += w[u];
+  }
+  B.node_t0[S.nb + k] = part[0] + part[1] + part[2] + part[3];
+}
+
+__device__ __forceinline__ T0Sent t0_sentence(const Batch& B, u32 s) {
+  const u32 off = B.byte_off[s];
+  const u32 g0 = off + s;
+  return T0Sent{B.sent_ncp[s], B.sent_nodes[s], off + 4 * s, B.node_base[s], B.cp_code + g0, B.cp_class + g0};
 }
 
 // (more wavefronts per SIMD do not help here: 5 at 94 VGPRs 2.01 ms, 6 at 80 2.05 ms, 8 at 64 with spills 2.68 ms)
@@ -113,75 +278,74 @@ __global__ void __launch_bounds__(64) k_t0(Batch B, const DevModel* __restrict__
   const DevModel& M = *Mp;
   u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
-  u32 off = B.byte_off[s];
-  u32 g0 = off + s;
-  u32 bb0 = off + 4 * s;
-  u32 n = B.sent_ncp[s];
-  u32 N = B.sent_nodes[s];
-  u64 nb = B.node_base[s];
-  const u32* cps = B.cp_code + g0;
-  const i32* cls = B.cp_class + g0;
+  const T0Sent S = t0_sentence(B, s);
+  for (u32 k = 2 + threadIdx.x; k < S.N; k += blockDim.x) t0_node_full<W24>(B, M, S, k);
+}
 
-  for (u32 k = 2 + threadIdx.x; k < N; k += blockDim.x) {
-    NodeInfo ni = B.node_info[nb + k];
-    NodeAux na = B.node_aux[nb + k];
-    u32 b = (k == N - 1) ? n + 2 : (u32)ni.start + 2;
-    u32 first = B.bnd_first[bb0 + b];
-    u32 R = B.bnd_cnt[bb0 + b];
-    bool isLast = (k - first) == R - 1;
-
-    // ---- entry row ----
-    i32 entry[spec::kNumDicFeatures];
-    bool isUnk = false;
-    if (ni.eptr == kEptrEOS) {
+// The same with the per-entry memo (T0Memo above).  Pass A: every lane takes one node; a dictionary node whose record is
+// valid copies its row and stored patterns from it, hashes the six context patterns, gathers their six weights and
+// finishes the four accumulators; every other node (UNK makers' nodes, EOS, entries without a record) is put on a list
+// in LDS.  Pass B: the listed nodes, one per lane again, from scratch -- so that the long path runs with full wavefronts
+// instead of on the few lanes of pass A that missed.
+constexpr u32 kT0MissCap = 512;
+template <bool W24>
+__global__ void __launch_bounds__(64) k_t0_memo(Batch B, const DevModel* __restrict__ Mp, const T0Memo* __restrict__ memo, u32 nslots) {
+  const DevModel& M = *Mp;
+  const u32 s = blockIdx.x;
+  if (B.sent_status[s] != ST_OK) return;
+  const T0Sent S = t0_sentence(B, s);
+  const int lane = (int)threadIdx.x;
+  __shared__ u32 miss[kT0MissCap];
+  u32 nmiss = 0;   // wave-uniform
+  auto drain = [&]() {
+    wave_sync();
+    for (u32 q = (u32)lane; q < nmiss; q += 64) t0_node_full<W24>(B, M, S, miss[q]);
+    wave_sync();
+    nmiss = 0;
+  };
+  for (u32 k0 = 2; k0 < S.N; k0 += 64) {
+    const u32 k = k0 + (u32)lane;
+    bool hit = false;
+    if (k < S.N) {
+      const NodeInfo ni = B.node_info[S.nb + k];
+      const u32 len = (u32)ni.end - (u32)ni.start;
+      const u32 slot = ni.eptr >= 0 ? (u32)ni.eptr >> 4 : nslots;
+      if (slot < nslots) {
+        const U4 JPP_GLOBAL* rec = reinterpret_cast<const U4 JPP_GLOBAL*>(as_global(memo + slot));
+        const U4 tail = rec[10];   // raw[0..2], len
+        if (tail.w == len) {
+          hit = true;
+          U4 q[10];
 #pragma unroll
-      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = kEptrEOS;
-    } else if (ni.eptr >= 0) {
-      read_entry_row(M, ni.eptr, entry, spec::kNumDicFeatures);
-    } else {
-      isUnk = true;
-      const UnkMaker& mk = M.makers[M.maker_of_spec[na.maker]];
-      if (mk.type == UNK_NORMALIZE) {
-        read_entry_row(M, na.tmpl, entry, spec::kNumDicFeatures);
-      } else {
+          for (int z = 0; z < 10; ++z) q[z] = rec[z];
+          // entry row and stored patterns, as read
+          U4* orow = reinterpret_cast<U4*>(B.node_entry + (S.nb + k) * spec::kNumDicFeatures);
+          orow[0] = q[0];
+          orow[1] = q[1];
+          U4* opat = reinterpret_cast<U4*>(B.node_pat + (S.nb + k) * kPat);
 #pragma unroll
-        for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = mk.tmpl[f];
+          for (int z = 0; z < 7; ++z) opat[z] = q[2 + z];
+          i32 entry[spec::kNumDicFeatures] = {(i32)q[0].x, (i32)q[0].y, (i32)q[0].z, (i32)q[0].w, (i32)q[1].x, (i32)q[1].y, (i32)q[1].z, (i32)q[1].w};
+          u64 prim[spec::kNumPrims];
+          t0_prims(entry, ni, NodeAux{0, 0, 0, 0, 0, 0}, false, S.cps, S.cls, S.n, prim);
+          float wc[kT0CtxLast - kT0CtxFirst + 1];
+          t0_context_weights<W24>(prim, as_global(M.weights), M.wmask, wc);
+          float part[4] = {bits_f32(q[9].x), bits_f32(q[9].y), bits_f32(q[9].z), bits_f32(q[9].w)};
+          const float raw[3] = {bits_f32(tail.x), bits_f32(tail.y), bits_f32(tail.z)};
+#pragma unroll
+          for (int u = kT0CtxFirst; u < spec::kNumUni; ++u) part[u & 3] += u <= kT0CtxLast ? wc[u - kT0CtxFirst] : raw[u - kT0CtxLast - 1];
+          B.node_t0[S.nb + k] = part[0] + part[1] + part[2] + part[3];
+        }
       }
-#pragma unroll
-      for (int f = 0; f < spec::kNumDicFeatures; ++f) {
-        if ((mk.replace_mask >> f) & 1) entry[f] = na.hash;
-      }
     }
-#pragma unroll
-    for (int f = 0; f < spec::kNumDicFeatures; ++f) B.node_entry[(nb + k) * spec::kNumDicFeatures + f] = entry[f];
-
-    u64 pat[spec::kNumPatterns];
-    t0_patterns(entry, ni, na, isUnk, cps, cls, n, pat);
-#pragma unroll
-    for (int p = 0; p < spec::kNumStoredPatterns; ++p) B.node_pat[(nb + k) * kPat + p] = pat[p];
-
-    // ---- unigram perceptron ----
-    static_assert(spec::kNumUni >= 4, "unigram count");
-    float w[spec::kNumUni];
-#pragma unroll
-    for (int u = 0; u < spec::kNumUni; ++u) {
-      u32 idx = hmix_index<W24>(uni_prefix(spec::kUni[u].index), pat[spec::kUni[u].t0], M.wmask);
-      w[u] = as_global(M.weights)[idx];
+    const u64 bal = wave_ballot(k < S.N && !hit);
+    if (bal != 0) {
+      if (k < S.N && !hit) miss[nmiss + (u32)popc64(bal & ((u64{1} << lane) - 1))] = k;
+      nmiss += (u32)popc64(bal);
+      if (nmiss + 64 > kT0MissCap) drain();
     }
-    float part[4];
-    if (isLast) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) part[j] = 0.f;
-#pragma unroll
-      for (int u = 0; u < spec::kNumUni; ++u) part[u & 3] += w[u];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) part[j] = w[j];
-#pragma unroll
-      for (int u = 4; u < spec::kNumUni; ++u) part[u & 3] += w[u];
-    }
-    B.node_t0[nb + k] = part[0] + part[1] + part[2] + part[3];
   }
+  if (nmiss) drain();
 }
 
 // The same kernel for a spec other than the built-in jumandic tables: every descriptor is read from the DevSpec
