@@ -245,7 +245,7 @@ struct Batch {
   float* node_t0;          // [gn]
   BeamSlot* node_beam;     // [gn][beam]
   float* node_cells;       // [gn][gbeam][nscorers]
-  u32* rnn_conn;           // [bb][gbeam] connection of EOS path p at boundary b: node | slot<<28, or ~0
+  u32* rnn_conn;           // [bb][gbeam] connection of EOS path p at boundary b: node (26 bits) | slot<<26, or ~0
   i32* rnn_id;             // [bb][gbeam] RNN vocabulary id of that node
   u32* rnn_gi;             // [bb][gbeam] global-beam index of the connection (= which score cell of its node it owns) | codepoints of its lattice node << 16
   u32* rnn_assign;         // [bb][gbeam] rnn node (index within boundary) a connection is scored with

@@ -540,8 +540,14 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
       return;
     }
-    // the previous requests have landed (wait above); boundaries below b are done: recycle their ring
-    // slots for the records up to 63 ahead
+    // The ring records requested during the previous boundary have landed -- INVARIANT (nothing checks it; the emulator
+    // copies synchronously): every path through an iteration ends with a vmcnt(0) behind its prefetch() and ring refill:
+    //   (1) fastCand: the lds_async_wait() behind the candidate-slot copy of phase 1,
+    //   (2) !fastCand: the lds_async_wait() in front of global_beam_from_hbm(),
+    //   (3) no global beam entry (ngb == 0): the lds_async_wait() before `continue`,
+    // and the first iteration starts behind the lds_async_wait() in front of the loop.  A new path through the loop body
+    // needs its own wait before the next iteration reads `meta` / the prefetched rows.
+    // Boundaries below b are done: recycle their ring slots for the records up to kRing - 1 ahead.
     metaReady = metaEnd;
     if (metaEnd < n + 3 && metaEnd <= b + kRing / 2) {   // refill when half of the window is used up
       const u32 lo = metaEnd, hi = (b + kRing) < (n + 3) ? (b + kRing) : (n + 3);
@@ -570,7 +576,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         const u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
         lds_async_load<16>(&cand[q0], &beams[(u64)enL[q < ncand ? l : 0] * beam + k], q < ncand);
       }
-      lds_async_wait();
+      lds_async_wait();   // invariant (1) above: also covers this boundary's prefetch() and ring refill
       wave_sync();
     }
     {
@@ -639,7 +645,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           }
         }
       } else {
-        lds_async_wait();
+        lds_async_wait();   // invariant (2) above
         (void)last;
         ngb = global_beam_from_hbm(beams, en + efirst, ncand, beam, G, gb_key);
       }
@@ -674,7 +680,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
       }
       for (u32 q = lane; q < R; q += 64) B.node_kept[nb + rfirst + q] = 0;
       if constexpr (kOneRow) prefetch_rows(bn, mbn, 0);   // this boundary's rows are not needed
-      lds_async_wait();
+      lds_async_wait();   // invariant (3) above
       wave_sync();
       continue;
     }
