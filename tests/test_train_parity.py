@@ -30,9 +30,13 @@ def _training_set(ref, tmp, n_lines, dict_entries=20000, seed=7):
     teacher = os.path.join(tmp, 'teacher.model')
     subprocess.check_call([os.path.join(ref, 'ref_dump'), 'mkmodel', seed_model, teacher, '18', '11', '0.1'])
     raw = os.path.join(tmp, 'raw.txt')
+    gen = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines + n_lines // 20 + 8), '--seed', '5',
+                          '--len', '24', '--oov', '0.08'], stdout=subprocess.PIPE, check=True).stdout.decode('utf-8')
+    # (the Morph corpus format cannot express words that contain its separators: jumanpp_v2 --full-morph does not quote)
+    keep = [l for l in gen.split('\n') if l and not any(c in l for c in ' _"#,')][:n_lines]
+    assert len(keep) == n_lines
     with open(raw, 'w', encoding='utf-8') as f:
-        subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines), '--seed', '5', '--len', '24',
-                               '--oov', '0.08'], stdout=f)
+        f.write('\n'.join(keep) + '\n')
     out = subprocess.run([os.path.join(ref, 'jumanpp_v2'), '--model=' + teacher, '--full-morph', raw], stdout=subprocess.PIPE,
                          stderr=subprocess.DEVNULL, check=True).stdout.decode('utf-8')
     corpus = os.path.join(tmp, 'train.txt')
