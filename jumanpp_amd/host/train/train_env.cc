@@ -1,6 +1,7 @@
 #include "train_env.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <random>
@@ -143,6 +144,9 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
     offsets.push_back((uint32_t)text.size());
   }
   hookStatus_ = Status::Ok();
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+  auto t0 = now();
   jppgpu_result* res = nullptr;
   if (jppgpu_analyze_batch_seeds(ctx_, text.data(), offsets.data(), n, &TrainingEnv::seedHook, this, &res) != JPPGPU_OK) {
     if (!hookStatus_) return hookStatus_;
@@ -153,6 +157,8 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
     ~Release() { jppgpu_result_release(r); }
   } release{res};
   goldNodesAdded_ += extraSeeds_.size();
+  stageMs_[0] += since(t0);
+  t0 = now();
   jppgpu_result_view view{};
   if (jppgpu_result_fetch(res, JPPGPU_FETCH_FULL, &view) != JPPGPU_OK) return abiError("jppgpu_result_fetch");
   for (uint32_t q = 0; q < n; ++q) {
@@ -163,6 +169,8 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
                                     << " on line " << ex.line();
     }
   }
+  stageMs_[1] += since(t0);
+  t0 = now();
   jppgpu_top1_ngrams_view top{};
   if (jppgpu_result_fetch_top1_ngrams(res, &top) != JPPGPU_OK) return abiError("jppgpu_result_fetch_top1_ngrams");
   // gold paths as node indices, EOS last (LossCalculator::resolveGold)
@@ -175,6 +183,8 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
   }
   jppgpu_top1_ngrams_view gold{};
   if (jppgpu_result_fetch_path_ngrams(res, gfirst.data(), gnodes.data(), &gold) != JPPGPU_OK) return abiError("jppgpu_result_fetch_path_ngrams");
+  stageMs_[2] += since(t0);
+  t0 = now();
   const uint32_t mask = scw_->mask();
   // every example of the batch is judged with the weights it was analysed with
   std::vector<LossCalculator> loss(n);
@@ -190,6 +200,8 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
     Status s = lc.compare(L, goldPaths_[q], top.features + top.path_first[q] * top.n_ngram, (size_t)(top.path_first[q + 1] - top.path_first[q]));
     if (!s) return Status(s.code(), s.message() + " [example on line " + std::to_string(batch_[(size_t)order_[q]].line()) + "]");
   }
+  stageMs_[3] += since(t0);
+  t0 = now();
   double curLoss = 0;
   for (uint32_t q = 0; q < n; ++q) {
     LossCalculator& lc = loss[q];
@@ -203,7 +215,10 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
     examplesSeen_ += 1;
   }
   batchLoss_ = curLoss;
+  stageMs_[4] += since(t0);
+  t0 = now();
   if (jppgpu_ctx_set_weights(ctx_, scw_->weights().data(), (uint64_t)scw_->weights().size()) != JPPGPU_OK) return abiError("jppgpu_ctx_set_weights");
+  stageMs_[5] += since(t0);
   return Status::Ok();
 }
 

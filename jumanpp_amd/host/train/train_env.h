@@ -70,6 +70,7 @@ class TrainingEnv {
   double batchLoss_ = 0, totalLoss_ = 0;
   int32_t leftBeam_ = 0, rightBeam_ = 0, rightCheck_ = 0;
   uint64_t examplesSeen_ = 0, goldNodesAdded_ = 0;
+  double stageMs_[6] = {0, 0, 0, 0, 0, 0};   // analyse (incl. the seed hook), fetch, n-gram read-outs, loss, SCW, weights upload
 
   // hook state of the batch in flight
   std::vector<std::vector<GoldPosition>> goldPaths_;
@@ -101,6 +102,7 @@ class TrainingEnv {
   uint64_t examplesSeen() const { return examplesSeen_; }
   uint64_t goldNodesAdded() const { return goldNodesAdded_; }
   int32_t leftBeam() const { return leftBeam_; }
+  const double* stageMs() const { return stageMs_; }
 };
 
 // doTrain (jumanpp_train.cc:168-198)
