@@ -110,8 +110,8 @@ int main(int argc, char** argv) {
   std::cerr << "trained on " << env.examplesSeen() << " example passes, " << env.goldNodesAdded() << " gold nodes added, last epoch loss="
             << env.epochLoss() << "\n";
   const double* ms = env.stageMs();
-  std::cerr << "stage ms: analyse+seed hook " << ms[0] << ", lattice fetch " << ms[1] << ", n-gram read-outs " << ms[2] << ", loss " << ms[3]
-            << ", feature diff + SCW " << ms[4] << ", weights upload " << ms[5] << "\n";
+  std::cerr << "stage ms: analyse+seed hook " << ms[0] << ", lattice fetch " << ms[1] << ", n-gram read-outs " << ms[2] << ", gold scores + loss + feature diff " << ms[3]
+            << ", SCW updates " << ms[4] << ", weights upload " << ms[5] << "\n";
   s = model.saveWithPerceptron(a.outputFilename, env.scw().weights().data(), env.scw().exponent(), a.comment);
   if (!s) {
     std::cerr << "failed to save model: " << s << "\n";

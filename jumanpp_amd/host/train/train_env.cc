@@ -6,6 +6,7 @@
 #include <fstream>
 #include <random>
 #include <sstream>
+#include <thread>
 
 namespace jumanpp_amd {
 namespace train {
@@ -186,9 +187,13 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
   stageMs_[2] += since(t0);
   t0 = now();
   const uint32_t mask = scw_->mask();
-  // every example of the batch is judged with the weights it was analysed with
+  // Every example of the batch is judged with the weights it was analysed with.  Gold scores, comparison, loss and
+  // feature difference of an example depend on nothing but its own lattice (the reference computes them on its worker
+  // threads, OwningFullTrainer::compute): one slice of the batch per host thread.  The SCW updates follow in batch order.
   std::vector<LossCalculator> loss(n);
-  for (uint32_t q = 0; q < n; ++q) {
+  std::vector<float> lossValue(n, 0.f);
+  std::vector<Status> st(n);
+  auto judge = [&](uint32_t q) {
     LossCalculator& lc = loss[q];
     lc.initialize(&model_->trainingSpec());
     lc.computeGoldScores(scw_->weights().data(), mask, gold.features + gold.path_first[q] * gold.n_ngram, gold.n_ngram,
@@ -197,21 +202,34 @@ Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
     L.view = &view;
     L.s = q;
     L.numFeatures = model_->numFeatures();
-    Status s = lc.compare(L, goldPaths_[q], top.features + top.path_first[q] * top.n_ngram, (size_t)(top.path_first[q + 1] - top.path_first[q]));
-    if (!s) return Status(s.code(), s.message() + " [example on line " + std::to_string(batch_[(size_t)order_[q]].line()) + "]");
+    st[q] = lc.compare(L, goldPaths_[q], top.features + top.path_first[q] * top.n_ngram, (size_t)(top.path_first[q + 1] - top.path_first[q]));
+    if (!st[q]) return;
+    int32_t used = lc.fullSize();   // Trainer::computeTrainingLoss (trainer.cc:49-67)
+    if (args_.mode == TrainingMode::FalloffBeam) used = lc.fallOffBeam();
+    else if (args_.mode == TrainingMode::MaxViolation) used = lc.maxViolation();
+    lossValue[q] = lc.computeLoss(used);
+    lc.computeFeatureDiff(mask);
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 1u : nt > 16 ? 16u : nt;
+  if (n < 16 || nt == 1) {
+    for (uint32_t q = 0; q < n; ++q) judge(q);
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+      pool.emplace_back([&, t]() {
+        for (uint32_t q = t; q < n; q += nt) judge(q);
+      });
+    for (auto& th : pool) th.join();
   }
+  for (uint32_t q = 0; q < n; ++q)
+    if (!st[q]) return Status(st[q].code(), st[q].message() + " [example on line " + std::to_string(batch_[(size_t)order_[q]].line()) + "]");
   stageMs_[3] += since(t0);
   t0 = now();
   double curLoss = 0;
   for (uint32_t q = 0; q < n; ++q) {
-    LossCalculator& lc = loss[q];
-    int32_t used = lc.fullSize();   // Trainer::computeTrainingLoss (trainer.cc:49-67)
-    if (args_.mode == TrainingMode::FalloffBeam) used = lc.fallOffBeam();
-    else if (args_.mode == TrainingMode::MaxViolation) used = lc.maxViolation();
-    const float l = lc.computeLoss(used);
-    lc.computeFeatureDiff(mask);
-    curLoss += l;
-    scw_->update(l, lc.featureDiff());   // handleProcessedTrainer (training_env.cc:91-106)
+    curLoss += lossValue[q];
+    scw_->update(lossValue[q], loss[q].featureDiff());   // handleProcessedTrainer (training_env.cc:91-106)
     examplesSeen_ += 1;
   }
   batchLoss_ = curLoss;
