@@ -605,7 +605,7 @@ def config5_leg(args, cache, local_rank, np, torch, J):
     try:
         a = copy.copy(args)
         a.sent_len = 220
-        batch = 4096
+        batch = int(getattr(args, 'config5_batch', 4096))
         mdic, model, img = make_workload(a, cache)
         corpus = make_corpus(a, mdic, cache, batch * 2, 31)
         batches = load_batches(corpus, batch, np)
@@ -673,6 +673,7 @@ def main():
                     help='timed batches checked sentence by sentence against the reference (parity_sample)')
     ap.add_argument('--no-overlap', action='store_true', help='skip the extra two-batches-in-flight measurement')
     ap.add_argument('--no-config5', action='store_true',
+    ap.add_argument('--config5-batch', type=int, default=4096, help='sentences per step of the configs[4]-shape leg')
                     help="skip the BASELINE configs[4] leg (beam 32, 220-codepoint sentences, one GPU's share)")
     ap.add_argument('--no-cli', action='store_true', help='skip the end-to-end jumanpp_gpu run (file in, JUMAN text out)')
     ap.add_argument('--no-realism', action='store_true',
