@@ -673,8 +673,8 @@ def main():
                     help='timed batches checked sentence by sentence against the reference (parity_sample)')
     ap.add_argument('--no-overlap', action='store_true', help='skip the extra two-batches-in-flight measurement')
     ap.add_argument('--no-config5', action='store_true',
-    ap.add_argument('--config5-batch', type=int, default=4096, help='sentences per step of the configs[4]-shape leg')
                     help="skip the BASELINE configs[4] leg (beam 32, 220-codepoint sentences, one GPU's share)")
+    ap.add_argument('--config5-batch', type=int, default=4096, help='sentences per step of the configs[4]-shape leg')
     ap.add_argument('--no-cli', action='store_true', help='skip the end-to-end jumanpp_gpu run (file in, JUMAN text out)')
     ap.add_argument('--no-realism', action='store_true',
                     help='skip the extra workload legs (1M-entry dictionary, 2^24 and 2^26 weights; SURVEY 8(d))')
