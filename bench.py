@@ -598,14 +598,15 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
 
 def config5_leg(args, cache, local_rank, np, torch, J):
     """BASELINE configs[4] on one GPU (never `value`): beam = global beam = right beam = 32, right-check 1,
-    220-codepoint sentences, RNNLM on, 4,096 sentences per batch, same model as the headline.  Reports the
+    220-codepoint sentences, RNNLM on, 16,384 sentences per batch (4,096 until round 3: one wavefront per 1 100-node
+    sentence needs more sentences than that to fill the chip, profiles/r03_n_config5_batches.txt), same model as the headline.  Reports the
     device-resident rate and the roofline of its dominant kernel (k_sweep<32, *>); the algorithmic bytes come
     from the fully fetched lattice of the first 256 sentences, scaled by the node count."""
     import copy
     try:
         a = copy.copy(args)
         a.sent_len = 220
-        batch = int(getattr(args, 'config5_batch', 4096))
+        batch = int(getattr(args, 'config5_batch', 16384))
         mdic, model, img = make_workload(a, cache)
         corpus = make_corpus(a, mdic, cache, batch * 2, 31)
         batches = load_batches(corpus, batch, np)
@@ -674,7 +675,7 @@ def main():
     ap.add_argument('--no-overlap', action='store_true', help='skip the extra two-batches-in-flight measurement')
     ap.add_argument('--no-config5', action='store_true',
                     help="skip the BASELINE configs[4] leg (beam 32, 220-codepoint sentences, one GPU's share)")
-    ap.add_argument('--config5-batch', type=int, default=4096, help='sentences per step of the configs[4]-shape leg')
+    ap.add_argument('--config5-batch', type=int, default=16384, help='sentences per step of the configs[4]-shape leg')
     ap.add_argument('--no-cli', action='store_true', help='skip the end-to-end jumanpp_gpu run (file in, JUMAN text out)')
     ap.add_argument('--no-realism', action='store_true',
                     help='skip the extra workload legs (1M-entry dictionary, 2^24 and 2^26 weights; SURVEY 8(d))')
