@@ -374,7 +374,9 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
   // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
-  constexpr int kCandCap = GM <= 8 ? 64 : 512;   // candidate slots (left nodes x beam) staged in LDS per boundary
+  // candidate slots (left nodes x beam) staged in LDS per boundary; more take global_beam_from_hbm (wide variant: 8 left
+  // nodes x 32 -- at 512 the buffer alone held the kernel at 6 wavefronts per CU)
+  constexpr int kCandCap = GM <= 8 ? 64 : 256;
   // pattern rows of up to kChunk right nodes: kLean has ONE buffer -- a boundary's rows are dead as soon as their
   // first-stage states are in s1b / s1t, the next boundary's (or the next pass's) rows are requested right then;
   // the other variants keep the next boundary's rows (pRn[par ^ 1]) apart from the pass buffer pR
