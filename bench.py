@@ -466,6 +466,92 @@ def realism_legs(args, cache, local_rank, np, torch, J):
     return legs
 
 
+def trainer_leg(args, mdic, cache, ge):
+    """SURVEY 8 row f4 (trainer hook-up), never `value`: one epoch of `jumanpp_gpu_train` (examples analysed by the device in
+    batches, gold nodes injected through the seed hook, loss + SCW update on the host) next to the reference's own
+    `jumanpp_v2_train`, and -- the parity half -- the model FILE both write for --batch 1 on a prefix of the corpus.
+    Corpus: sentences of the headline generator annotated by the reference with the headline dictionary and a
+    random-weight teacher model (`jumanpp_v2 --full-morph` = the trainer's input format)."""
+    try:
+        train_cli = ge.TRAIN_CLI
+        ge.build_host()
+        dkey = os.path.basename(mdic)[:-5]
+        seed_model = os.path.join(cache, dkey + '.seed')
+        teacher = os.path.join(cache, dkey + '.teacher')
+        if not os.path.exists(teacher):
+            subprocess.check_call([os.path.join(REF, 'ref_dump'), 'mkmodel', seed_model, teacher + '.tmp', '20', '11', '0.1'])
+            os.rename(teacher + '.tmp', teacher)
+        n_ex = 8192
+        corpus = os.path.join(cache, dkey + '_train%d.txt' % n_ex)
+        if not os.path.exists(corpus):
+            gen = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_ex + n_ex // 16), '--seed', '77',
+                                  '--len', str(args.sent_len), '--oov', '0.05'], stdout=subprocess.PIPE, check=True).stdout.decode('utf-8')
+            # (the Morph corpus format has no quoting: sentences with its separator characters cannot be written in it)
+            lines = [l for l in gen.split('\n') if l and not any(c in l for c in ' _"#,')][:n_ex]
+            nproc = max(1, min(16, len(os.sched_getaffinity(0))))
+            parts = [lines[i::nproc] for i in range(nproc)]
+            procs = []
+            for i, part in enumerate(parts):
+                pth = corpus + '.raw%d' % i
+                with open(pth, 'w', encoding='utf-8') as f:
+                    f.write('\n'.join(part) + '\n')
+                procs.append((pth, subprocess.Popen([os.path.join(REF, 'jumanpp_v2'), '--model=' + teacher, '--full-morph', pth],
+                                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)))
+            with open(corpus + '.tmp', 'w', encoding='utf-8') as f:
+                for pth, pr in procs:
+                    o = pr.communicate()[0].decode('utf-8')
+                    os.remove(pth)
+                    for l in o.split('\n'):
+                        if l.strip():
+                            f.write(l.rstrip(' ') + '\n')
+            os.rename(corpus + '.tmp', corpus)
+        gb = ['--gb-left-min=6', '--gb-left-max=6', '--gb-rcheck-min=1', '--gb-rcheck-max=1', '--gb-right-min=5', '--gb-right-max=5',
+              '--size=%d' % args.weights_exp]
+        tmp = tempfile.mkdtemp(prefix='jpptrain_')
+
+        def run(cmd):
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            return time.perf_counter() - t0, p
+        batch = 512
+        wall, p = run([train_cli, '--model-input=' + seed_model, '--model-output=' + os.path.join(tmp, 'g.model'), '--corpus=' + corpus,
+                       '--batch=%d' % batch] + gb)
+        if p.returncode != 0:
+            return {'error': p.stderr.decode()[-300:]}
+        err = p.stderr.decode().strip().splitlines()
+        stages = {}
+        for part in err[-1].replace('stage ms: ', '').split(', '):
+            k, v = part.rsplit(' ', 1)
+            stages[k] = round(float(v), 1)
+        epoch_ms = sum(stages.values())
+        nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
+        ref_wall, _ = run([os.path.join(REF, 'jumanpp_v2_train'), '--model-input=' + seed_model, '--model-output=' + os.path.join(tmp, 'r.model'),
+                           '--corpus=' + corpus, '--batch=%d' % (4 * nthreads), '--threads=%d' % nthreads] + gb)
+        ref1_wall, _ = run([os.path.join(REF, 'jumanpp_v2_train'), '--model-input=' + seed_model, '--model-output=' + os.path.join(tmp, 'r1.model'),
+                            '--corpus=' + corpus, '--batch=1', '--threads=1'] + gb)
+        # parity: --batch 1 on the first 256 examples, both trainers, same bytes
+        head = os.path.join(tmp, 'head.txt')
+        with open(head, 'w', encoding='utf-8') as f:
+            f.writelines(open(corpus, encoding='utf-8').readlines()[:256])
+        run([os.path.join(REF, 'jumanpp_v2_train'), '--model-input=' + seed_model, '--model-output=' + os.path.join(tmp, 'rp.model'),
+             '--corpus=' + head, '--batch=1', '--threads=1'] + gb)
+        _, pg = run([train_cli, '--model-input=' + seed_model, '--model-output=' + os.path.join(tmp, 'gp.model'), '--corpus=' + head, '--batch=1'] + gb)
+        same = pg.returncode == 0 and open(os.path.join(tmp, 'rp.model'), 'rb').read() == open(os.path.join(tmp, 'gp.model'), 'rb').read()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+        return {'what': 'jumanpp_gpu_train, one epoch over %d annotated %d-codepoint sentences, --batch %d (one device pass per batch, '
+                        'weights frozen inside a batch), global beam 6/1/5, 2^%d weights; examples/s over the epoch loop (stage sum), '
+                        'process wall time apart' % (n_ex, args.sent_len, batch, args.weights_exp),
+                'value': round(n_ex / (epoch_ms * 1e-3), 1), 'unit': 'examples/s', 'epoch_ms': round(epoch_ms, 1), 'stage_ms': stages,
+                'device_share_ms': round(sum(v for k, v in stages.items() if k.startswith(('analyse', 'lattice', 'n-gram', 'weights'))), 1),
+                'process_wall_s': round(wall, 2),
+                'reference': {'what': 'jumanpp_v2_train, same corpus, whole process', 'threads_%d_wall_s' % nthreads: round(ref_wall, 2),
+                              'threads_1_batch_1_wall_s': round(ref1_wall, 2)},
+                'parity_batch1': {'examples': 256, 'model_files_identical': bool(same)}}
+    except Exception as e:  # noqa: BLE001
+        return {'error': repr(e)[:300]}
+
+
 def homograph_leg(args, cache, local_rank, np, torch, J):
     """jumandic-like fan-out (tools/gen_dict.py --homographs 60: every single hiragana has 8..60 dictionary entries,
     150 two-kana surfaces 4..30): which sweep variants run and what they cost, (i) on ordinary text of that dictionary,
@@ -676,6 +762,7 @@ def main():
     ap.add_argument('--no-config5', action='store_true',
                     help="skip the BASELINE configs[4] leg (beam 32, 220-codepoint sentences, one GPU's share)")
     ap.add_argument('--config5-batch', type=int, default=16384, help='sentences per step of the configs[4]-shape leg')
+    ap.add_argument('--no-trainer', action='store_true', help='skip the trainer leg (jumanpp_gpu_train vs jumanpp_v2_train)')
     ap.add_argument('--no-cli', action='store_true', help='skip the end-to-end jumanpp_gpu run (file in, JUMAN text out)')
     ap.add_argument('--no-realism', action='store_true',
                     help='skip the extra workload legs (1M-entry dictionary, 2^24 and 2^26 weights; SURVEY 8(d))')
@@ -980,6 +1067,8 @@ def main():
             out['config5'] = config5_leg(args, cache, local_rank, np, torch, J)
         if not args.no_realism and world == 1:
             out['realism'] = realism_legs(args, cache, local_rank, np, torch, J)
+        if not args.no_trainer and world == 1:
+            out['trainer'] = trainer_leg(args, mdic, cache, ge)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
         print(json.dumps(out, ensure_ascii=False), flush=True)
