@@ -370,7 +370,8 @@ int jppgpu_result_fetch_path_ngrams(jppgpu_result* res, const uint64_t* path_fir
                                     jppgpu_top1_ngrams_view* view);
 /* Replaces the perceptron weight table of the context (the trainer's update step; HashedFeaturePerceptron /
  * FloatBufferWeights, src/core/analysis/perceptron.h:76-94, score_api.h:29-42).  n must equal the model's table
- * size; takes effect for the next jppgpu_analyze_batch* on the context. */
+ * size; takes effect for the next jppgpu_analyze_batch* on the context.  (A context that runs the static feature code
+ * also rebuilds its per-dictionary-entry T0 records from the new table: ~0.1 s for a 300 k-entry dictionary.) */
 int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uint64_t n);
 /* Per-batch statistics without copying the lattice: total nodes, sum of path lengths. */
 int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* total_path);
