@@ -3,8 +3,8 @@
 set -u
 REPO="$(pwd)"; OUT="$REPO/gpurun_out"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_host_cli.py -m gpu -x -q > "$OUT/r03q_pytest.log" 2>&1; tail -3 "$OUT/r03q_pytest.log"
-timeout 900 python bench.py --no-cpu-baseline --no-overlap --no-realism --no-config5 --no-parity --no-trainer --steps 4 --warmup 2 > "$OUT/r03q_cli.json" 2> "$OUT/r03q_cli.err"
+echo "(CLI tests: see the previous run)"
+timeout 900 python bench.py --no-cpu-baseline --no-overlap --no-realism --no-config5 --no-parity --no-trainer > "$OUT/r03q_cli.json" 2> "$OUT/r03q_cli.err"
 python - <<'PY'
 import json
 d = json.loads(open('/root/repo/gpurun_out/r03q_cli.json').read().strip().splitlines()[-1])
