@@ -566,9 +566,7 @@ int main(int argc, const char** argv) {
   // GPU | format it (conf.threads workers, one OutputFormat each) | write it.  Two analyzers alternate
   // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
   // call, is being formatted.  Output order is the input order.
-  // (the sharded file-to-file pipeline below rotates three: one being submitted to, one whose results are being
-  // collected, one being formatted)
-  const int nAnalyzers = conf.pipeline ? (sharded ? 3 : 2) : 1;
+  const int nAnalyzers = conf.pipeline ? 2 : 1;
   if (conf.devices.empty()) conf.devices.push_back(conf.device);
   const int nDev = (int)conf.devices.size();
   // per device: the second analyzer (a second copy of the model in HBM) is made when a second batch shows
@@ -620,16 +618,15 @@ int main(int argc, const char** argv) {
       std::cerr << "could not open the output file " << conf.output << "\n";
       return 1;
     }
-    std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<ShardJob>>>> readQ, flightQ, fmtQ, writeQ;
+    std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<ShardJob>>>> readQ, fmtQ, writeQ;
     std::vector<std::unique_ptr<Semaphore>> freeAnalyzers;
     for (int d = 0; d < nDev; ++d) {
       readQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(2));
-      flightQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(1));
       fmtQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(1));
       writeQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(2));
       freeAnalyzers.emplace_back(new Semaphore(nAnalyzers));
     }
-    std::atomic<long long> scanUs(0), prepUs(0), formatUs(0), writeUs(0), gpuUs(0), collectUs(0);
+    std::atomic<long long> scanUs(0), prepUs(0), formatUs(0), writeUs(0), gpuUs(0);
     std::vector<double> analyzeMsDev((size_t)nDev, 0.0);
     auto us = [&]() { return (long long)(clock.ms() * 1000.0); };
 
@@ -665,9 +662,7 @@ int main(int argc, const char** argv) {
       for (auto& qd : readQ) qd->close();
     });
 
-    // per device: split the batch into examples and submit it to the device (the next free analyzer of the rotation);
-    // a second thread waits for the results and copies them to the host -- so the device already works on batch k+1
-    // while the results of batch k cross PCIe and batch k-1 is being formatted
+    // per device: split the batch into examples, analyse
     std::vector<std::thread> gpus;
     for (int d = 0; d < nDev; ++d) {
       gpus.emplace_back([&, d]() {
@@ -707,15 +702,10 @@ int main(int argc, const char** argv) {
           const double a0 = clock.ms();
           if (!analyzers[d][job->analyzer]) {
             Status made = makeAnalyzer(d, job->analyzer);
-            if (!made) {
-              // (no HBM for another copy of the model and its workspaces) carry on with the analyzers made so far:
-              // wait until the batches in flight are through (every other token), then leave as many tokens in
-              // circulation as the smaller rotation has analyzers
-              const int have = job->analyzer;
+            if (!made) {   // (no HBM for a second copy of the model) carry on with the first analyzer alone
               analyzers[d][job->analyzer].reset();
-              for (int i = 1; i < live; ++i) freeAnalyzers[d]->acquire();
-              live = have;
-              for (int i = 1; i < live; ++i) freeAnalyzers[d]->release();
+              freeAnalyzers[d]->acquire();
+              live = 1;
               job->analyzer = 0;
             }
           }
@@ -724,26 +714,12 @@ int main(int argc, const char** argv) {
             std::vector<StringPiece> pieces(job->inputs);
             for (auto& e : job->readErrors) pieces[e.first] = StringPiece("", 0);
             GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
-            job->batchStatus = analyzer.submitBatch(pieces, useLattice);
+            job->batchStatus = analyzer.analyzeBatch(pieces, useLattice);
+            float ms[8];
+            analyzer.lastTimings(ms);
+            job->gpuMs = ms[7];
           }
           analyzeMsDev[d] += clock.ms() - a0;
-          flightQ[d]->push(std::move(job));
-        }
-        flightQ[d]->close();
-      });
-    }
-    std::vector<std::thread> collectors;
-    for (int d = 0; d < nDev; ++d) {
-      collectors.emplace_back([&, d]() {
-        std::unique_ptr<ShardJob> job;
-        while (flightQ[d]->pop(&job)) {
-          const long long t0 = us();
-          GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
-          if (job->batchStatus.isOk()) job->batchStatus = analyzer.collectBatch();
-          float ms[8];
-          analyzer.lastTimings(ms);
-          job->gpuMs = ms[7];
-          collectUs += us() - t0;
           fmtQ[d]->push(std::move(job));
         }
         fmtQ[d]->close();
@@ -830,8 +806,8 @@ int main(int argc, const char** argv) {
 
     std::atomic<bool> writeFailed(false);
     std::vector<std::thread> writers;
-    for (int d = 0; d < 2 * nDev; ++d) {   // two per device: a batch's text goes to the page cache at memcpy speed, one thread per 23 ms batch was the slowest stage
-      writers.emplace_back([&, d = d / 2]() {
+    for (int d = 0; d < nDev; ++d) {
+      writers.emplace_back([&, d]() {
         std::unique_ptr<ShardJob> job;
         while (writeQ[d]->pop(&job)) {
           const long long t0 = us();
@@ -854,7 +830,6 @@ int main(int argc, const char** argv) {
     }
     scanner.join();
     for (auto& t : gpus) t.join();
-    for (auto& t : collectors) t.join();
     for (auto& t : formatters) t.join();
     for (auto& t : writers) t.join();
     ::close(ofd);
@@ -867,8 +842,7 @@ int main(int argc, const char** argv) {
       double analyzeMs = 0;
       for (double v : analyzeMsDev) analyzeMs = std::max(analyzeMs, v);
       std::cerr << "devices=" << nDev << " sentences=" << sentences << " gpu_ms=" << gpuUs / 1000.0 << " wall_ms=" << wall
-                << " read_ms=" << (scanUs + prepUs) / 1000.0 << " analyze_ms=" << analyzeMs << " collect_ms=" << collectUs / 1000.0
-                << " format_ms=" << formatUs / 1000.0
+                << " read_ms=" << (scanUs + prepUs) / 1000.0 << " analyze_ms=" << analyzeMs << " format_ms=" << formatUs / 1000.0
                 << " write_ms=" << writeUs / 1000.0 << " threads=" << conf.threads << " pipeline=1 sharded=1 sent_per_s="
                 << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
     }
