@@ -19,6 +19,12 @@ SoftConfidenceWeighted::SoftConfidenceWeighted(const ScwConfig& cfg, uint32_t ex
 
 void SoftConfidenceWeighted::update(float loss, const std::vector<ScoredFeature>& features) {
   if (loss < 1e-5) return;
+  // (the two tables are 2^k floats each and the features of an example are scattered over them: ask for every line
+  // before the four passes below walk them in order -- same arithmetic, the cache misses overlap instead of queueing)
+  for (const auto& v : features) {
+    __builtin_prefetch(&weights_[v.feature], 1, 1);
+    __builtin_prefetch(&diagonal_[v.feature], 1, 1);
+  }
   // calcScore / calcVt (scw.cc:47-63): double accumulators over float products
   double score = 0, vt = 0;
   for (const auto& v : features) score += weights_[v.feature] * v.score;

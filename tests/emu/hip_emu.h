@@ -39,9 +39,14 @@ namespace hip_emu {
 
 constexpr int kWave = 64;
 
+// Fibers switch with __builtin_setjmp / __builtin_longjmp: swapcontext saves and restores the signal mask, two system
+// calls per switch, and a kernel like k_sweep switches at every wave_sync() of every lane.  A fiber is created once
+// (makecontext, entered with setcontext) and then lives in a loop that runs the launch body once per block it is part of.
 struct Fiber {
   ucontext_t ctx;
+  void* jb[5];
   char* stack = nullptr;
+  bool started = false;
   bool done = false;
   int wait = 0;  // 0 runnable, 1 block barrier, 2 wave barrier
 };
@@ -51,7 +56,7 @@ struct State {
   dim3 bidx, tidx;
   int cur = 0;
   std::vector<Fiber> fibers;
-  ucontext_t sched;
+  void* sched_jb[5];
   std::function<void()> body;
   // per-wave exchange slots for shuffles / ballots
   std::vector<uint64_t> xchg;
@@ -62,9 +67,10 @@ inline State& st() {
   return s;
 }
 
-inline void yield_to_sched() {
+__attribute__((noinline)) inline void yield_to_sched() {
   State& s = st();
-  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  Fiber& f = s.fibers[s.cur];
+  if (__builtin_setjmp(f.jb) == 0) __builtin_longjmp(s.sched_jb, 1);
 }
 
 inline void block_barrier() {
@@ -80,27 +86,53 @@ inline void wave_barrier() {
 }
 
 inline void fiber_main() {
+  for (;;) {
+    st().body();
+    State& s = st();
+    s.fibers[s.cur].done = true;
+    yield_to_sched();
+  }
+}
+
+// scheduler side: run fiber f until it yields
+__attribute__((noinline)) inline void resume(Fiber& f) {
   State& s = st();
-  s.body();
-  s.fibers[s.cur].done = true;
-  yield_to_sched();
+  if (__builtin_setjmp(s.sched_jb) == 0) {
+    if (!f.started) {
+      f.started = true;
+      setcontext(&f.ctx);
+    } else {
+      __builtin_longjmp(f.jb, 1);
+    }
+  }
 }
 
 inline void run_block(unsigned nthreads) {
   State& s = st();
   constexpr size_t kStack = 256 * 1024;
-  if (s.fibers.size() < nthreads) s.fibers.resize(nthreads);
+  if (s.fibers.size() < nthreads) {
+    // (the vector may not move fibers that are parked inside it: reserve once for the largest block there is)
+    if (s.fibers.capacity() < 1024) s.fibers.reserve(1024);
+    if (nthreads > 1024) {
+      fprintf(stderr, "hip_emu: blocks of more than 1024 threads are not supported\n");
+      abort();
+    }
+    s.fibers.resize(nthreads);
+  }
   s.xchg.assign(nthreads, 0);
   for (unsigned t = 0; t < nthreads; ++t) {
     Fiber& f = s.fibers[t];
-    if (!f.stack) f.stack = static_cast<char*>(malloc(kStack));
+    if (!f.stack) {
+      f.stack = static_cast<char*>(malloc(kStack));
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack;
+      f.ctx.uc_stack.ss_size = kStack;
+      f.ctx.uc_link = nullptr;
+      makecontext(&f.ctx, (void (*)())fiber_main, 0);
+      f.started = false;
+    }
     f.done = false;
     f.wait = 0;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = kStack;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, (void (*)())fiber_main, 0);
   }
   for (;;) {
     bool progress = false;
@@ -112,7 +144,7 @@ inline void run_block(unsigned nthreads) {
       if (f.wait != 0) continue;
       s.cur = (int)t;
       s.tidx = dim3(t % s.block.x, 0, 0);
-      swapcontext(&s.sched, &f.ctx);
+      resume(f);
       progress = true;
     }
     if (alldone) break;
