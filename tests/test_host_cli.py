@@ -796,3 +796,19 @@ def test_double_array_builder_on_random_keys(emu_lib, tmp_path):
                           ['-o', exe, '-L' + os.path.dirname(emu_lib), '-l:libjppgpu_emu.so', '-Wl,-rpath,' + os.path.dirname(emu_lib)])
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-500:]
+
+
+def test_cli_without_the_t0_memo_equals_the_reference(cli_emu, ref_tools, golden_dir):
+    """the plain k_t0 (every node from scratch), which the per-entry memo normally replaces for the built-in spec, behind
+    its developer switch: same bytes as the reference, with and without the memo"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    m = os.path.join(golden_dir, 'mini_rnn.jppmdl')
+    path = os.path.join(golden_dir, 'mini.txt')
+    ref = _ref_cli(ref_tools, m, [], path)
+    for memo in ('0', '1'):
+        env = dict(os.environ, JPPGPU_DEV_T0_MEMO=memo)
+        p = subprocess.run([cli_emu, '--model=' + m, path], capture_output=True, env=env)
+        assert p.returncode == 0, p.stderr[-300:]
+        assert p.stdout == ref, memo
+        assert (b'T0 memo:' in p.stderr) == (memo == '1')

@@ -78,14 +78,14 @@ def small_set(ref_tools, tmp_path_factory):
         pytest.skip('oracle/_ref not built')
     if not os.path.exists(os.path.join(ref_tools, 'jumanpp_v2_train')):
         pytest.skip('oracle/_ref has no trainer binary')
-    return _training_set(ref_tools, str(tmp_path_factory.mktemp('train')), 60)
+    return _training_set(ref_tools, str(tmp_path_factory.mktemp('train')), 300)
 
 
 def test_trained_model_file_identical_to_reference_trainer(emu_trainer, ref_tools, small_set, tmp_path):
-    """one epoch, the reference's defaults (full mode, beam 5) with a global beam: same bytes in the output model"""
+    """two epochs over 300 examples, the reference's defaults (full mode, beam 5) with a global beam: same bytes in the output model"""
     seed_model, corpus, _ = small_set
-    r, g, log = _train_both(ref_tools, emu_trainer, str(tmp_path), seed_model, corpus, ['--size=15'] + GB, 'a')
-    assert _gold_added(log) > 20
+    r, g, log = _train_both(ref_tools, emu_trainer, str(tmp_path), seed_model, corpus, ['--size=15', '--max-epochs=2', '--epsilon=0'] + GB, 'a')
+    assert _gold_added(log) > 200
     assert open(r, 'rb').read() == open(g, 'rb').read()
 
 
@@ -102,7 +102,7 @@ def test_training_modes_epochs_and_batch_iterations(emu_trainer, ref_tools, smal
     seed_model, corpus, _ = small_set
     short = os.path.join(str(tmp_path), 'short.txt')
     with open(short, 'w', encoding='utf-8') as f:
-        f.writelines(open(corpus, encoding='utf-8').readlines()[:30])
+        f.writelines(open(corpus, encoding='utf-8').readlines()[:100])
     r, g, _ = _train_both(ref_tools, emu_trainer, str(tmp_path), seed_model, short, flags, 'b')
     assert open(r, 'rb').read() == open(g, 'rb').read()
 
