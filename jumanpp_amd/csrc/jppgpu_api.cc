@@ -64,6 +64,7 @@ struct SyncPoint {
   void destroy() {}
   void mark(jpp_stream_t) {}
   void wait(jpp_stream_t) {}
+  void make_stream_wait(jpp_stream_t) {}
 };
 jpp_stream_t rt_stream_create() { return nullptr; }
 void rt_stream_destroy(jpp_stream_t) {}
@@ -113,6 +114,10 @@ struct SyncPoint {
     }
     (void)hipEventSynchronize(ev);
   }
+  // device-side: work enqueued on `s` after this call starts once everything before mark() has completed
+  void make_stream_wait(jpp_stream_t s) {
+    if (ev) (void)hipStreamWaitEvent(s, ev, 0);
+  }
 };
 // a context's own stream: contexts used from different host threads do not serialise on the null stream
 jpp_stream_t rt_stream_create() {
@@ -130,7 +135,7 @@ void rt_stream_destroy(jpp_stream_t s) {
 void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
 void rt_host_free(void* p) { free(p); }
 struct Timer {
-  hipEvent_t ev[12];
+  hipEvent_t ev[13];
   bool have = false;
   void init() {
     for (auto& e : ev) (void)hipEventCreate(&e);
@@ -158,10 +163,12 @@ struct Timer {
     }
     ms[7] = 0;
     (void)hipEventElapsedTime(&ms[7], ev[0], ev[7]);
-    // the sweep phase by class: ev[8] .. ev[10], ev[5]
+    // the sweep phase by class (classes 1 and 2 may run on the context's second stream, beside class 0):
+    // class 0 ev[8] .. ev[11], class 1 ev[9] .. ev[10], class 2 ev[10] .. ev[12]
+    static const int from[3] = {8, 9, 10}, to[3] = {11, 10, 12};
     for (int i = 0; i < 3; ++i) {
       ms[8 + i] = 0;
-      (void)hipEventElapsedTime(&ms[8 + i], ev[8 + i], i == 2 ? ev[5] : ev[9 + i]);
+      (void)hipEventElapsedTime(&ms[8 + i], ev[from[i]], ev[to[i]]);
     }
   }
 };
@@ -337,6 +344,8 @@ struct jppgpu_ctx {
   bool partial_pending = false;  // constraints uploaded for the next analyze call
   jppgpu_score_plugin_fn plugin_fn = nullptr;  // host plugin of the next analyze call (jppgpu_analyze_batch_plugin)
   void* plugin_user = nullptr;
+  jpp_stream_t aux_stream = nullptr;   // the sweep variants of the rare wide sentences run here, beside the main variant
+  SyncPoint sweep_fork, sweep_join;
   jppgpu_seed_hook_fn seed_hook = nullptr;     // gold-seed hook of the next analyze call (jppgpu_analyze_batch_seeds)
   void* seed_user = nullptr;
   DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
@@ -934,6 +943,9 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     }
   }
   ctx->own_stream = rt_stream_create();
+  ctx->aux_stream = rt_stream_create();
+  ctx->sweep_fork.init();
+  ctx->sweep_join.init();
   ctx->timer.init();
   ctx->rnn_sync.init();
   *out = ctx;
@@ -981,6 +993,9 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
+  rt_stream_destroy(ctx->aux_stream);
+  ctx->sweep_fork.destroy();
+  ctx->sweep_join.destroy();
   ctx->host_pool->clear();
   ctx->timer.destroy();
   ctx->rnn_sync.destroy();
@@ -1331,12 +1346,21 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const DevModel* dmS = (const DevModel*)ctx->dmodel;
   if (ctx->cfg.gbeam == 0) {
     JPP_LAUNCH(k_sweep_full, n, 64, st, B, dmS, ctx->cfg);
-    T.mark(8, st); T.mark(9, st); T.mark(10, st);
+    T.mark(8, st); T.mark(11, st); T.mark(9, st); T.mark(10, st); T.mark(12, st);
   } else {
     const bool def = narrow && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5;
     // (developer knob: JPPGPU_DEV_SWEEP_LDS_PAD=bytes of dynamic LDS added to the launch, i.e. fewer wavefronts per
     // CU -- the occupancy curve of profiles/r03_a_occupancy.txt)
     static const unsigned devPad = std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD") ? (unsigned)std::atoi(std::getenv("JPPGPU_DEV_SWEEP_LDS_PAD")) : 0u;
+    // The wider classes hold few sentences on ordinary text, and a kernel of a handful of wavefronts lasts as long as its
+    // longest sentence (one 300-node-per-boundary sentence: 1.9 ms): they run on the context's second stream, beside
+    // the main class instead of behind it (profiles/r03_r_bench.json realism.homographs: 10.4 + 1.9 ms in sequence).
+    jpp_stream_t s12 = st;
+    if (nCls[0] != 0 && (nCls[1] != 0 || nCls[2] != 0) && ctx->aux_stream) {
+      ctx->sweep_fork.mark(st);
+      ctx->sweep_fork.make_stream_wait(ctx->aux_stream);
+      s12 = ctx->aux_stream;
+    }
     T.mark(8, st);
     if (ctx->dynamic_spec) {
       // table-driven variants (a spec other than the built-in jumandic tables)
@@ -1344,15 +1368,16 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
         if (narrow) JPP_LAUNCH((k_sweep<8, 64, false, false, kSweepWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
         else JPP_LAUNCH((k_sweep<32, 64, false, false, kSweepWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
       }
-      T.mark(9, st);
+      T.mark(11, st);
+      T.mark(9, s12);
       if (nCls[1]) {
-        if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
-        else JPP_LAUNCH((k_sweep<32, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
+        if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
+        else JPP_LAUNCH((k_sweep<32, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
       }
-      T.mark(10, st);
+      T.mark(10, s12);
       if (nCls[2]) {
-        if (narrow) JPP_LAUNCH((k_sweep<8, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
-        else JPP_LAUNCH((k_sweep<32, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+        if (narrow) JPP_LAUNCH((k_sweep<8, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
+        else JPP_LAUNCH((k_sweep<32, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
       }
     } else {
     if (nCls[0]) {   // at most 64 right nodes per boundary, right-check <= 2
@@ -1372,16 +1397,22 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       else if (narrow) JPP_LAUNCH((k_sweep<8, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
       else JPP_LAUNCH((k_sweep<32, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);   // 6 KB less LDS per wavefront than the 512-wide staging
     }
-    T.mark(9, st);
+    T.mark(11, st);
+    T.mark(9, s12);
     if (nCls[1]) {   // at most kMaxRight right nodes per boundary (and right-check * R prescores within the staging)
-      if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
-      else JPP_LAUNCH((k_sweep<32, kMaxRight>), nCls[1], 64, st, B, dmS, ctx->cfg, lists[1]);
+      if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
+      else JPP_LAUNCH((k_sweep<32, kMaxRight>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
     }
-    T.mark(10, st);
+    T.mark(10, s12);
     if (nCls[2]) {   // any width
-      if (narrow) JPP_LAUNCH((k_sweep<8, 0>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
-      else JPP_LAUNCH((k_sweep<32, 0>), nCls[2], 64, st, B, dmS, ctx->cfg, lists[2]);
+      if (narrow) JPP_LAUNCH((k_sweep<8, 0>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
+      else JPP_LAUNCH((k_sweep<32, 0>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
     }
+    }
+    T.mark(12, s12);
+    if (s12 != st) {   // the main stream continues when both are done
+      ctx->sweep_join.mark(s12);
+      ctx->sweep_join.make_stream_wait(st);
     }
   }
   ctx->last_class_n[0] = nCls[0]; ctx->last_class_n[1] = nCls[1]; ctx->last_class_n[2] = nCls[2];
