@@ -1254,19 +1254,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.node_kept = ctx->node_kept.as<u8>();
   B.path_nodes = ctx->path_nodes.as<u32>();
   T.mark(2, st);
-  // k_ends (UNK entry pointers, ends lists, BOS / EOS records, BOS beams: latency bound) and the T0 kernel (fabric
-  // bound) touch disjoint data -- T0 reads of a node record only the sign of its entry pointer, and knows EOS by
-  // position -- so k_ends runs on the context's second stream beside it; the streams join before anything reads either
-  jpp_stream_t sEnds = st;
-  if (ctx->aux_stream) {
-    ctx->sweep_fork.mark(st);
-    ctx->sweep_fork.make_stream_wait(ctx->aux_stream);
-    sEnds = ctx->aux_stream;
-  }
   {
     UnkRank rk = ctx->unk_rank;
     if (goldInserted) rk.n += 1;   // the gold nodes are created after every maker's (Trainer::prepare)
-    JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, sEnds, B, ctx->cfg, rk);
+    JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg, rk);
   }
   T.mark(3, st);
   if (ctx->dynamic_spec) JPP_LAUNCH(k_t0_dyn, n, 64, st, B, (const DevModel*)ctx->dmodel);
@@ -1276,10 +1267,6 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     JPP_LAUNCH(k_t0_memo<false>, n, 64, st, B, (const DevModel*)ctx->dmodel, (const T0Memo*)ctx->t0_memo.as<T0Memo>(), ctx->t0_memo_slots);
   else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  if (sEnds != st) {
-    ctx->sweep_join.mark(sEnds);
-    ctx->sweep_join.make_stream_wait(st);
-  }
   B.node_penalty = nullptr;
   if (ctx->partial_pending) {
     ctx->partial_pending = false;

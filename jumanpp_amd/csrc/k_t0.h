@@ -206,11 +206,9 @@ struct T0Sent {
 // one node, everything computed from scratch
 template <bool W24>
 __device__ __forceinline__ void t0_node_full(const Batch& B, const DevModel& M, const T0Sent& S, u32 k) {
-  // (the EOS record is k_ends' to write, and k_ends runs beside this kernel: EOS is the last node, by position)
-  const bool eos = k == S.N - 1;
-  NodeInfo ni = eos ? NodeInfo{kEptrEOS, (u16)S.n, (u16)S.n} : B.node_info[S.nb + k];
-  NodeAux na = eos ? NodeAux{0, 0, 0, 0, 0, 0} : B.node_aux[S.nb + k];
-  u32 b = eos ? S.n + 2 : (u32)ni.start + 2;
+  NodeInfo ni = B.node_info[S.nb + k];
+  NodeAux na = B.node_aux[S.nb + k];
+  u32 b = (k == S.N - 1) ? S.n + 2 : (u32)ni.start + 2;
   u32 first = B.bnd_first[S.bb0 + b];
   u32 R = B.bnd_cnt[S.bb0 + b];
   bool isLast = (k - first) == R - 1;
@@ -218,7 +216,7 @@ __device__ __forceinline__ void t0_node_full(const Batch& B, const DevModel& M, 
   // ---- entry row ----
   i32 entry[spec::kNumDicFeatures];
   bool isUnk = false;
-  if (eos) {
+  if (ni.eptr == kEptrEOS) {
 #pragma unroll
     for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = kEptrEOS;
   } else if (ni.eptr >= 0) {
@@ -308,7 +306,7 @@ __global__ void __launch_bounds__(64) k_t0_memo(Batch B, const DevModel* __restr
   for (u32 k0 = 2; k0 < S.N; k0 += 64) {
     const u32 k = k0 + (u32)lane;
     bool hit = false;
-    if (k + 1 < S.N) {   // (EOS, the last node, takes the full path: its record is written by k_ends, which runs beside this kernel)
+    if (k < S.N) {
       const NodeInfo ni = B.node_info[S.nb + k];
       const u32 len = (u32)ni.end - (u32)ni.start;
       const u32 slot = ni.eptr >= 0 ? (u32)ni.eptr >> 4 : nslots;
@@ -378,15 +376,14 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
   const float JPP_GLOBAL* W = as_global(M.weights);
 
   for (u32 k = 2 + threadIdx.x; k < N; k += blockDim.x) {
-    const bool eos = k == N - 1;   // (by position: the EOS record is written by k_ends, which runs beside this kernel)
-    NodeInfo ni = eos ? NodeInfo{kEptrEOS, (u16)n, (u16)n} : B.node_info[nb + k];
-    NodeAux na = eos ? NodeAux{0, 0, 0, 0, 0, 0} : B.node_aux[nb + k];
+    NodeInfo ni = B.node_info[nb + k];
+    NodeAux na = B.node_aux[nb + k];
     // ---- entry row ----
     i32 entry[spec::kNumDicFeatures];
 #pragma unroll
     for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = 0;
     bool isUnk = false;
-    if (eos) {
+    if (ni.eptr == kEptrEOS) {
 #pragma unroll
       for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? kEptrEOS : 0;
     } else if (ni.eptr >= 0) {
