@@ -734,8 +734,6 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, 
     dynSpec.reset(new DevSpec());
     const std::string why = parse_feature_spec(m->feature_spec, m->feature_spec_bytes, m->num_features, dynSpec.get());
     if (!why.empty()) return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: feature spec outside the table-driven kernels: " + why);
-    if (c->global_beam <= 0)
-      return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the full-beam path (--global-beam 0) exists for the built-in jumandic spec only");
   }
   if (m->weight_exponent >= 32 || !m->weights) return fail(JPPGPU_INVALID_PARAMETER, "bad perceptron weights");
   if (m->num_unk_makers > kMaxUnkMakers - 1) return fail(JPPGPU_NOT_IMPLEMENTED, "too many UNK makers");
@@ -964,8 +962,6 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
   if (right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
   if (beam > kMaxBeam || global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: beam / global beam > 32 is not supported");
-  if (ctx->dynamic_spec && global_beam <= 0)
-    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: the full-beam path (--global-beam 0) exists for the built-in jumandic spec only");
   ctx->cfg.beam = beam;
   ctx->cfg.gbeam = global_beam > 0 ? global_beam : 0;
   ctx->cfg.rcheck = right_check;
@@ -1345,7 +1341,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   const DevModel* dmS = (const DevModel*)ctx->dmodel;
   if (ctx->cfg.gbeam == 0) {
-    JPP_LAUNCH(k_sweep_full, n, 64, st, B, dmS, ctx->cfg);
+    if (ctx->dynamic_spec) JPP_LAUNCH(k_sweep_full<true>, n, 64, st, B, dmS, ctx->cfg);
+    else JPP_LAUNCH(k_sweep_full<false>, n, 64, st, B, dmS, ctx->cfg);
     T.mark(8, st); T.mark(11, st); T.mark(9, st); T.mark(10, st); T.mark(12, st);
   } else {
     const bool def = narrow && ctx->cfg.beam == 5 && ctx->cfg.gbeam == 6 && ctx->cfg.rcheck == 1 && ctx->cfg.rbeam == 5;

@@ -9,6 +9,9 @@
 //   AnalyzerImpl::computeScoresFull          src/core/analysis/analyzer_impl.cc:197-248
 //   ScoreProcessor::applyT1 / applyT2        src/core/analysis/score_processor.cc:136-156
 //     (generated applyBiStep2: 8 round-robin sums, last row unrolled-4; applyTriStep3: 4)
+//   DYN: the reference's table-driven feature objects (a spec other than the compiled-in one, and its trainer):
+//     PartialNgramDynamicFeatureApply::applyBiStep2 / applyTriStep3, feature_impl_ngram_partial.h:216-273 -- every row
+//     through computeUnrolled4RawPerceptron (four round-robin sums), descriptors from DevSpec
 //   fillBeamCandidates / processBeamCandidates / makeBeams   score_processor.cc:165-244
 #ifndef JPP_K_SWEEP_FULL_H
 #define JPP_K_SWEEP_FULL_H
@@ -20,8 +23,11 @@ namespace jpp {
 constexpr int kFullCand = 512;   // live (left, slot) candidates per boundary staged in LDS
 constexpr int kFullChunk = 4;    // right nodes per pass
 
+template <bool DYN = false>
 __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
+  const int nBi = DYN ? M.spec->nbi : spec::kNumBi;
+  const int nTri = DYN ? M.spec->ntri : spec::kNumTri;
   const u32 s = blockIdx.x;
   if (B.sent_status[s] != ST_OK) return;
   const int lane = (int)threadIdx.x;
@@ -90,21 +96,27 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
         u32 x = act ? u / nc : 0, i = act ? u - x * nc : 0;
         u32 t = t0 + x;
         bool lastRow = (t == R - 1);
-        int Wd = lastRow ? 4 : 8;
+        int Wd = (DYN || lastRow) ? 4 : 8;
         const u64* p0 = pats + (u64)(rfirst + t) * kPat;
         const u64* t1r = pats + (u64)c_lnode[i] * kPat;
         const u64* t2r = pats + (u64)c_pnode[i] * kPat;
         float f = 0.f;
         if (act && j < Wd) {
-          for (int k = j; k < spec::kNumBi; k += Wd) {
-            u32 idx = (u32)hmix(hmix(kNg.bi_pre[k], p0[kNg.bi_t0[k]]), t1r[kNg.bi_t1[k]]) & wmask;
+          for (int k = j; k < nBi; k += Wd) {
+            const u64 pre = DYN ? M.spec->bi_prefix[k] : kNg.bi_pre[k];
+            const int i0 = DYN ? (int)(M.spec->bi_t01[k] >> 4) : (int)kNg.bi_t0[k];
+            const int i1 = DYN ? (int)(M.spec->bi_t01[k] & 15) : (int)kNg.bi_t1[k];
+            u32 idx = (u32)hmix(hmix(pre, p0[i0]), t1r[i1]) & wmask;
             f += W[idx];
           }
         }
         float g = 0.f;
-        if (act && j < spec::kNumTri) {
-          u32 idx = (u32)hmix(hmix(hmix(kNg.tri_pre[j], p0[kNg.tri_t0[j]]), t1r[kNg.tri_t1[j]]),
-                              t2r[kNg.tri_t2[j]]) & wmask;
+        if (act && j < nTri) {
+          const u64 pre = DYN ? M.spec->tri_prefix[j] : kNg.tri_pre[j];
+          const int i0 = DYN ? (int)M.spec->tri_t[j][0] : (int)kNg.tri_t0[j];
+          const int i1 = DYN ? (int)M.spec->tri_t[j][1] : (int)kNg.tri_t1[j];
+          const int i2 = DYN ? (int)M.spec->tri_t[j][2] : (int)kNg.tri_t2[j];
+          u32 idx = (u32)hmix(hmix(hmix(pre, p0[i0]), t1r[i1]), t2r[i2]) & wmask;
           g += W[idx];
         }
         float bsum = wave_shfl_f32(f, (grp << 3));
@@ -114,7 +126,7 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
           float v = wave_shfl_f32(f, (grp << 3) + jj);
           float w = wave_shfl_f32(g, (grp << 3) + jj);
           if (jj < Wd) bsum += v;
-          if (jj < spec::kNumTri) tsum += w;
+          if (jj < nTri) tsum += w;
         }
         if (act && j == 0) {
           float cell = t0s[rfirst + t];

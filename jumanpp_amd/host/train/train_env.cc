@@ -43,10 +43,6 @@ Status TrainingEnv::initialize(const TrainingArguments& args, const ModelImage* 
   model_ = model;
   if (args.sizeExponent > 31) return Status::InvalidState() << "size exponent was too large: " << args.sizeExponent << ", maximum allowed is 31";
   JPPA_RETURN_IF_ERROR(args.globalBeam.validate());
-  if (!args.globalBeam.leftEnabled()) {
-    return Status::NotImplemented() << "the device trainer scores with the global beam; give --gb-left-min / --gb-left-max "
-                                       "(the full-beam path has no table-driven variant)";
-  }
   JPPA_RETURN_IF_ERROR(tio_.initialize(*model));
   JPPA_RETURN_IF_ERROR(resolver_.initialize(*model));
   reader_.initialize(&tio_, resolver_.surfaceColumn());

@@ -531,7 +531,9 @@ int doDump(const char* modelFile, const char* out, char** extra, int nextra) {
         EntryBeam::initializeBlock(bnd->starts()->beamData().data());
         proc.startBoundary(R);
         if (R > 0) {
-          proc.computeT0All(b, sconf->feature, &pfc);
+          // (AnalyzerImpl::computeScoresFull, analyzer_impl.cc:215-219: generated code when the spec matches it, else applyT0)
+          if (proc.patternIsStatic()) proc.computeT0All(b, sconf->feature, &pfc);
+          else proc.applyT0(b, sconf->feature);
           auto t0buf = proc.scores_.bufferT0();
           t0[b].assign(t0buf.begin(), t0buf.begin() + R);
         }

@@ -244,16 +244,15 @@ def check_variant_spec(lib, ref_tools, tmp, variant, n_lines, beams, rnn, **kw):
     return ctx
 
 
-@pytest.mark.parametrize('variant,beams,rnn', [('drop', None, None), ('add', None, (32, 600)), ('add', [20, 24, 1, 20], None)])
+@pytest.mark.parametrize('variant,beams,rnn', [('drop', None, None), ('add', None, (32, 600)), ('add', [20, 24, 1, 20], None),
+                                               ('drop', [5, 0, 0, 0], None)])
 def test_emulated_table_driven_kernels_on_a_non_jumandic_spec(emu_lib, ref_tools, tmp_path, variant, beams, rnn):
     """a spec other than the compiled-in tables is analysed by the table-driven kernels (k_t0_dyn,
-    k_sweep<.., DYN>) with the summation orders of the reference's DYNAMIC feature code: whole lattice bit-identical"""
+    k_sweep<.., DYN>, k_sweep_full<DYN> without a global beam) with the summation orders of the reference's DYNAMIC
+    feature code: whole lattice bit-identical"""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
-    ctx = check_variant_spec(emu_lib, ref_tools, str(tmp_path), variant, 40, beams, rnn)
-    # what the table-driven path does not have says so
-    with pytest.raises(J.JppGpuError):
-        J.Context(os.path.join(str(tmp_path), 'v.img'), lib_path=emu_lib, beam=5, global_beam=0, right_check=0, right_beam=0, use_rnn=False)
+    check_variant_spec(emu_lib, ref_tools, str(tmp_path), variant, 40, beams, rnn)
 
 
 def test_status_codes_bad_utf8_and_too_long(emu_lib, golden_dir):

@@ -97,6 +97,9 @@ def test_trained_model_file_identical_to_reference_trainer(emu_trainer, ref_tool
     ['--training-mode=falloff', '--beam=3', '--gb-left-min=5', '--gb-left-max=5', '--size=16', '--scw-c=0.5', '--scw-phi=2'],
     # several passes over every batch
     ['--max-batch-iters=3', '--epsilon=0'] + GB,
+    # the reference trainer's own defaults: no global beam at all (full-beam scoring, k_sweep_full<DYN>)
+    ['--size=15'],
+    ['--beam=3', '--training-mode=violation', '--max-epochs=2', '--epsilon=0'],
 ])
 def test_training_modes_epochs_and_batch_iterations(emu_trainer, ref_tools, small_set, tmp_path, flags):
     seed_model, corpus, _ = small_set
