@@ -2,7 +2,7 @@
 // training examples on the device.  Same flags where the function exists here; the output is a .jppmdl with the
 // trained perceptron part appended, loadable by the reference's analyser and by jumanpp_gpu.
 //   not here: --rnn-model (embedding an RNN into a model is an offline repack, not the analysis path),
-//   --partial-corpus, --scw-dump-dir, --gb-first-full (full beam on the first batch iteration only), --threads (accepted and
+//   --partial-corpus, --scw-dump-dir, --threads (accepted and
 //   ignored: the device analyses the whole batch at once).
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +25,7 @@ void usage() {
   std::cout << "jumanpp_gpu_train --model-input=FILE --model-output=FILE --corpus=FILE [--size=15] [--seed=N]\n"
                "  [--training-mode=full|falloff|violation] [--scw-c=1] [--scw-phi=5] [--beam=5] [--batch=1]\n"
                "  [--max-batch-iters=1] [--max-epochs=1] [--epsilon=1e-3] [--corpus-format=morph|csv]\n"
-               "  [--gb-left-min=N --gb-left-max=N [--gb-right-min=N --gb-right-max=N --gb-rcheck-min=N --gb-rcheck-max=N]]\n"
+               "  [--gb-left-min=N --gb-left-max=N [--gb-right-min=N --gb-right-max=N --gb-rcheck-min=N --gb-rcheck-max=N] [--gb-first-full]]\n"
                "  [--corpus-comment=TEXT] [--device=0]\n";
 }
 }  // namespace
@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
     else if (flagValue(arg, "gb-right-max", &v)) a.globalBeam.maxRightBeam = std::atoi(v.c_str());
     else if (flagValue(arg, "gb-rcheck-min", &v)) a.globalBeam.minRightCheck = std::atoi(v.c_str());
     else if (flagValue(arg, "gb-rcheck-max", &v)) a.globalBeam.maxRightCheck = std::atoi(v.c_str());
+    else if (arg == "--gb-first-full") a.globalBeam.fullFirstIter = true;
     else if (flagValue(arg, "device", &v)) a.device = std::atoi(v.c_str());
     else if (arg == "-h" || arg == "--help") {
       usage();

@@ -132,8 +132,13 @@ int TrainingEnv::seedHook(void* user, const jppgpu_seed_view* view, jppgpu_extra
 
 // TrainingEnv::trainOneBatch (training_env.cc:55-89): Trainer::prepare + compute for every example of the batch (one
 // device pass), then handleProcessedTrainer per example in submission order
-Status TrainingEnv::trainOneBatch(int32_t /*iter*/) {
+Status TrainingEnv::trainOneBatch(int32_t iter) {
   const uint32_t n = (uint32_t)order_.size();
+  if (leftBeam_ > 0) {   // TrainingEnv::trainOneBatch (training_env.cc:64-71): ITrainer::setGlobalBeam per submitted trainer
+    const bool full = args_.globalBeam.fullFirstIter && iter == 0;
+    if (jppgpu_ctx_set_beams(ctx_, args_.beamSize, full ? 0 : leftBeam_, full ? 0 : rightCheck_, full ? 0 : rightBeam_) != JPPGPU_OK)
+      return abiError("jppgpu_ctx_set_beams");
+  }
   std::string text;
   std::vector<uint32_t> offsets(1, 0);
   for (uint32_t q = 0; q < n; ++q) {

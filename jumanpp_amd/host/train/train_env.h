@@ -32,6 +32,7 @@ struct GlobalBeamParams {
   int32_t minLeftBeam = -1, maxLeftBeam = -1;
   int32_t minRightBeam = -1, maxRightBeam = -1;
   int32_t minRightCheck = -1, maxRightCheck = -1;
+  bool fullFirstIter = false;   // --gb-first-full: full-beam scoring on the first iteration over every batch
   bool leftEnabled() const { return minLeftBeam > 0; }
   bool rightEnabled() const { return minRightBeam > 0; }
   Status validate() const;

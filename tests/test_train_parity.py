@@ -100,6 +100,8 @@ def test_trained_model_file_identical_to_reference_trainer(emu_trainer, ref_tool
     # the reference trainer's own defaults: no global beam at all (full-beam scoring, k_sweep_full<DYN>)
     ['--size=15'],
     ['--beam=3', '--training-mode=violation', '--max-epochs=2', '--epsilon=0'],
+    # full beam on the first pass over every batch, the global beam on the second
+    ['--gb-first-full', '--max-batch-iters=2', '--epsilon=0'] + GB,
 ])
 def test_training_modes_epochs_and_batch_iterations(emu_trainer, ref_tools, small_set, tmp_path, flags):
     seed_model, corpus, _ = small_set
