@@ -463,11 +463,12 @@ def test_gpu_sentences_are_routed_to_sweep_variants_one_by_one(gpu_lib, ref_tool
     assert not errs, (len(errs), errs[:10])
 
 
-@pytest.mark.parametrize('variant,rnn', [('drop', None), ('add', (128, 3000))])
-def test_gpu_table_driven_kernels_on_a_non_jumandic_spec(gpu_lib, ref_tools, tmp_path, variant, rnn):
+@pytest.mark.parametrize('variant,rnn,beams', [('drop', None, None), ('add', (128, 3000), None), ('drop', None, [5, 0, 0, 0])])
+def test_gpu_table_driven_kernels_on_a_non_jumandic_spec(gpu_lib, ref_tools, tmp_path, variant, rnn, beams):
     """SURVEY 8 f3 on the MI355X: 1 500 sentences of a 30 k-entry dictionary under a spec whose hash does not match the
-    reference's generated code -- table-driven kernels against the reference's dynamic feature path, bit for bit"""
+    reference's generated code -- table-driven kernels (global-beam and full-beam sweeps) against the reference's dynamic
+    feature path, bit for bit"""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     import test_cpu_parity as tc
-    tc.check_variant_spec(gpu_lib, ref_tools, str(tmp_path), variant, 1500, None, rnn, n_entries=30000, exp=20, length=40, seed=37)
+    tc.check_variant_spec(gpu_lib, ref_tools, str(tmp_path), variant, 1500, beams, rnn, n_entries=30000, exp=20, length=40, seed=37)

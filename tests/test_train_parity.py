@@ -274,6 +274,12 @@ def test_gpu_trained_model_identical_and_batched_training(gpu_lib, ref_tools, tm
     r, g, log = _train_both(ref_tools, ge.TRAIN_CLI, str(tmp_path), seed_model, corpus, ['--size=18', '--max-epochs=2', '--epsilon=0'] + GB, 'gpu')
     assert _gold_added(log) > 200
     assert open(r, 'rb').read() == open(g, 'rb').read()
+    # the reference trainer's default configuration: no global beam (full-beam scoring, k_sweep_full<DYN>)
+    head = os.path.join(str(tmp_path), 'head.txt')
+    with open(head, 'w', encoding='utf-8') as f:
+        f.writelines(open(corpus, encoding='utf-8').readlines()[:150])
+    r2, g2, _ = _train_both(ref_tools, ge.TRAIN_CLI, str(tmp_path), seed_model, head, ['--size=16'], 'gpu_full')
+    assert open(r2, 'rb').read() == open(g2, 'rb').read()
     o = os.path.join(str(tmp_path), 'batched.model')
     p = subprocess.run([ge.TRAIN_CLI, '--model-input=' + seed_model, '--model-output=' + o, '--corpus=' + corpus, '--batch=128',
                         '--size=18', '--max-epochs=3', '--epsilon=0'] + GB, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
