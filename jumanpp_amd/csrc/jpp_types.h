@@ -277,6 +277,12 @@ struct Batch {
   float* node_penalty;     // [node] 0, 1000 or 10000
   // k_sweep<*, 0> only (a boundary with more right nodes than the LDS variants stage): per-sentence slice
   // for the prescores, their sums and the cutoff order
+  // full-beam sweep: boundaries with more live candidates than its LDS staging holds take one of `full_slots` HBM
+  // slices of `full_cap` candidates each (full_locks[slot]: 0 free / 1 taken)
+  unsigned char* full_scratch;
+  u32* full_locks;
+  u32 full_slots;
+  u32 full_cap;
   unsigned char* sweep_scratch;
   u64 sweep_scratch_stride;
   u32 sweep_scratch_maxr;

@@ -349,6 +349,7 @@ struct jppgpu_ctx {
   jppgpu_seed_hook_fn seed_hook = nullptr;     // gold-seed hook of the next analyze call (jppgpu_analyze_batch_seeds)
   void* seed_user = nullptr;
   DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
+  DevBuf full_scratch, full_locks;   // k_sweep_full's HBM slices for boundaries beyond its LDS staging
   // per-entry T0 memo (k_t0_memo): device table + what its weight-dependent half is rebuilt from
   DevBuf t0_memo;
   u32 t0_memo_slots = 0;
@@ -985,7 +986,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
-                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo};
+                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
@@ -1340,6 +1341,23 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     B.sweep_scratch_maxr = maxR;
   }
   const DevModel* dmS = (const DevModel*)ctx->dmodel;
+  B.full_scratch = nullptr;
+  B.full_locks = nullptr;
+  B.full_slots = 0;
+  B.full_cap = 0;
+  if (ctx->cfg.gbeam == 0) {
+    if (!ctx->full_locks.p) {
+      const std::vector<u32> zeros(kFullSlots, 0u);
+      if (!(ctx->full_scratch.ensure((size_t)kFullSlots * full_slot_bytes(kFullSlotCand)) && ctx->full_locks.ensure(kFullSlots * 4)))
+        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (full-beam scratch)");
+      rt_h2d(ctx->full_locks.p, zeros.data(), kFullSlots * 4, st);
+      rt_sync(st);
+    }
+    B.full_scratch = ctx->full_scratch.as<unsigned char>();
+    B.full_locks = ctx->full_locks.as<u32>();
+    B.full_slots = kFullSlots;
+    B.full_cap = kFullSlotCand;
+  }
   if (ctx->cfg.gbeam == 0) {
     if (ctx->dynamic_spec) JPP_LAUNCH(k_sweep_full<true>, n, 64, st, B, dmS, ctx->cfg);
     else JPP_LAUNCH(k_sweep_full<false>, n, 64, st, B, dmS, ctx->cfg);

@@ -20,8 +20,14 @@
 
 namespace jpp {
 
-constexpr int kFullCand = 512;   // live (left, slot) candidates per boundary staged in LDS
+constexpr int kFullCand = 512;   // live (left, slot) candidates per boundary staged in LDS; beyond: an HBM slice (below)
 constexpr int kFullChunk = 4;    // right nodes per pass
+// The reference has no limit on the candidates of a boundary (score_processor.cc:165-191).  A boundary with more than
+// kFullCand takes a slice of the batch's scratch pool: slot = workgroup index mod pool size, held under a spin lock for
+// the rest of the sentence (a holder always runs to completion, so waiting for a slot cannot deadlock).
+constexpr u32 kFullSlots = 128;
+constexpr u32 kFullSlotCand = 16384;   // 128 left nodes x beam 128, or 512 x 32
+__host__ __device__ constexpr size_t full_slot_bytes(u32 cap) { return (size_t)cap * (4 * 4 + kFullChunk * 8); }
 
 template <bool DYN = false>
 __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
@@ -43,12 +49,26 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
   const u64* pats = B.node_pat + nb * kPat;
   const float* t0s = B.node_t0 + nb;
 
-  __shared__ u32 c_lnode[kFullCand];   // left node of candidate
-  __shared__ u32 c_pnode[kFullCand];   // its previous node (T2)
-  __shared__ u32 c_lk[kFullCand];      // (left << 16) | slot
-  __shared__ float c_total[kFullCand]; // left element total
-  __shared__ u64 keys[kFullChunk][kFullCand];
+  __shared__ u32 l_c_lnode[kFullCand];   // left node of candidate
+  __shared__ u32 l_c_pnode[kFullCand];   // its previous node (T2)
+  __shared__ u32 l_c_lk[kFullCand];      // (left << 16) | slot
+  __shared__ float l_c_total[kFullCand]; // left element total
+  __shared__ u64 l_keys[kFullChunk * kFullCand];
   __shared__ u32 sh_nc;
+  u32* c_lnode = l_c_lnode;
+  u32* c_pnode = l_c_pnode;
+  u32* c_lk = l_c_lk;
+  float* c_total = l_c_total;
+  u64* keys = l_keys;        // keys[x * cap + i]
+  u32 cap = (u32)kFullCand;
+  bool haveSlot = false;
+  u32 slot = 0;
+  auto releaseSlot = [&]() {
+    if (haveSlot && lane == 0) {
+      __threadfence();
+      atomicExch(&B.full_locks[slot], 0u);
+    }
+  };
 
   if (n == 0) {
     for (int q = lane; q < beam; q += 64) beams[(u64)2 * beam + q] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
@@ -61,28 +81,55 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
     const u32 L = B.end_cnt[bb0 + b];
     const u32 efirst = B.end_first[bb0 + b];
     // candidates in (left asc, slot asc) order = fillBeamCandidates order
-    if (lane == 0) {
-      u32 nc = 0;
-      for (u32 l = 0; l < L; ++l) {
-        u32 lnode = en[efirst + l];
-        for (int k = 0; k < beam; ++k) {
-          BeamSlot sl = beams[(u64)lnode * beam + k];
-          if (slot_fake(sl)) break;
-          if (nc < (u32)kFullCand) {
-            c_lnode[nc] = lnode;
-            c_pnode[nc] = sl.prev_node;
-            c_lk[nc] = (l << 16) | (u32)k;
-            c_total[nc] = sl.total;
+    auto collect = [&]() {
+      if (lane == 0) {
+        u32 nc = 0;
+        for (u32 l = 0; l < L; ++l) {
+          u32 lnode = en[efirst + l];
+          for (int k = 0; k < beam; ++k) {
+            BeamSlot sl = beams[(u64)lnode * beam + k];
+            if (slot_fake(sl)) break;
+            if (nc < cap) {
+              c_lnode[nc] = lnode;
+              c_pnode[nc] = sl.prev_node;
+              c_lk[nc] = (l << 16) | (u32)k;
+              c_total[nc] = sl.total;
+            }
+            ++nc;
           }
-          ++nc;
         }
+        sh_nc = nc;
       }
-      sh_nc = nc;
+      __syncthreads();
+    };
+    collect();
+    u32 nc = sh_nc;
+    if (nc > cap && !haveSlot && B.full_slots != 0) {
+      // more candidates than the LDS staging holds: the rest of this sentence works in an HBM slice
+      slot = blockIdx.x % B.full_slots;
+      if (lane == 0) {
+        while (atomicCAS(&B.full_locks[slot], 0u, 1u) != 0u) {
+#if !defined(JPP_EMU)
+          __builtin_amdgcn_s_sleep(32);
+#endif
+        }
+        __threadfence();
+      }
+      __syncthreads();
+      haveSlot = true;
+      cap = B.full_cap;
+      unsigned char* base = B.full_scratch + (size_t)slot * full_slot_bytes(cap);
+      c_lnode = reinterpret_cast<u32*>(base);
+      c_pnode = c_lnode + cap;
+      c_lk = c_pnode + cap;
+      c_total = reinterpret_cast<float*>(c_lk + cap);
+      keys = reinterpret_cast<u64*>(c_total + cap);
+      collect();
+      nc = sh_nc;
     }
-    __syncthreads();
-    const u32 nc = sh_nc;
-    if (nc > (u32)kFullCand) {
+    if (nc > cap) {
       if (lane == 0) B.sent_status[s] = ST_CAPACITY;
+      releaseSlot();
       return;
     }
     for (u32 t0 = 0; t0 < R; t0 += kFullChunk) {
@@ -133,16 +180,16 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
           cell += bsum;
           cell += tsum;
           float score = c_total[i] + cell;  // leftElm.totalScore + localScore
-          keys[x][i] = ((u64)f32_sortable(score) << 32) | c_lk[i];
+          keys[(size_t)x * cap + i] = ((u64)f32_sortable(score) << 32) | c_lk[i];
         }
       }
       __syncthreads();
       // top `beam` of the unique keys per right node (processBeamCandidates): rank by counting
       for (u32 q = lane; q < nx * nc; q += 64) {
         u32 x = q / nc, i = q - x * nc;
-        u64 me = keys[x][i];
+        u64 me = keys[(size_t)x * cap + i];
         u32 rank = 0;
-        for (u32 z = 0; z < nc; ++z) rank += keys[x][z] > me;
+        for (u32 z = 0; z < nc; ++z) rank += keys[(size_t)x * cap + z] > me;
         if (rank < (u32)beam) {
           u32 hi = (u32)(me >> 32);
           beams[(u64)(rfirst + t0 + x) * beam + rank] =
@@ -158,6 +205,7 @@ __global__ void __launch_bounds__(64) k_sweep_full(Batch B, const DevModel* __re
     if (lane == 0) B.bnd_ngb[bb0 + b] = 0;
     __syncthreads();
   }
+  releaseSlot();
 }
 
 }  // namespace jpp

@@ -277,6 +277,17 @@ inline T atomicMax(T* p, T v) {
   if (v > o) *p = v;
   return o;
 }
+inline unsigned atomicCAS(unsigned* p, unsigned expect, unsigned v) {
+  const unsigned old = *p;
+  if (old == expect) *p = v;
+  return old;
+}
+inline unsigned atomicExch(unsigned* p, unsigned v) {
+  const unsigned old = *p;
+  *p = v;
+  return old;
+}
+inline void __threadfence() {}
 inline unsigned atomicOr(unsigned* p, unsigned v) {
   unsigned o = *p;
   *p = o | v;

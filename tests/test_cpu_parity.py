@@ -123,6 +123,33 @@ def test_emulated_full_beam_matches_live_reference(emu_lib, golden_dir, ref_tool
     assert not errs, errs[:10]
 
 
+def check_full_beam_beyond_the_lds_staging(lib, ref_tools, tmp, n_lines, wide_copies=1):
+    """full-beam scoring where a boundary has more live (left node, slot) candidates than k_sweep_full stages in LDS
+    (512): 80 readings of one surface x beam 32 = up to 2 752 candidates -- the kernel takes an HBM slice of its scratch
+    pool; the reference has no limit (score_processor.cc:165-191)"""
+    import test_gpu_parity as tg
+    extra = ''.join('かき,0,0,0,名詞,普通名詞,*,*,かき,よみ%d,かき/よみ%d,代表表記:かき/よみ%d\n' % (i, i, i) for i in range(80))
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, n_lines, 14, 7, length=30, beams=[32, 0, 0, 0], extra_dict=extra,
+                                               extra_lines=['かきかきかきの', 'あかきかきい'] * wide_copies)
+    ctx = J.Context(img, lib_path=lib, beam=32, global_beam=0, right_check=0, right_beam=0)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs, widest = [], 0
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+        bb = int(res.bnd_base[s])
+        widest = max(widest, int(res.end_count[bb + 2:bb + int(res.ncp[s]) + 3].max()))
+    assert widest * 32 > 2048, widest
+    assert (res.status == 0).all()
+    assert not errs, errs[:10]
+
+
+def test_emulated_full_beam_beyond_the_lds_staging(emu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_full_beam_beyond_the_lds_staging(emu_lib, ref_tools, str(tmp_path), 10)
+
+
 def _wide_boundary_workload(ref_tools, tmp, beams, n_homographs=600):
     """a dictionary that puts more right nodes on one boundary than the LDS variants of k_sweep stage
     (kMaxRight = 512): `n_homographs` distinct readings of one surface"""

@@ -463,6 +463,15 @@ def test_gpu_sentences_are_routed_to_sweep_variants_one_by_one(gpu_lib, ref_tool
     assert not errs, (len(errs), errs[:10])
 
 
+def test_gpu_full_beam_beyond_the_lds_staging(gpu_lib, ref_tools, tmp_path):
+    """the HBM-slice path of k_sweep_full with its slot locks contended (128 slots): 300 random sentences + 500 with
+    boundaries of up to 2 752 candidates"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tc.check_full_beam_beyond_the_lds_staging(gpu_lib, ref_tools, str(tmp_path), 300, wide_copies=250)
+
+
 @pytest.mark.parametrize('variant,rnn,beams', [('drop', None, None), ('add', (128, 3000), None), ('drop', None, [5, 0, 0, 0])])
 def test_gpu_table_driven_kernels_on_a_non_jumandic_spec(gpu_lib, ref_tools, tmp_path, variant, rnn, beams):
     """SURVEY 8 f3 on the MI355X: 1 500 sentences of a 30 k-entry dictionary under a spec whose hash does not match the
