@@ -277,6 +277,12 @@ struct Batch {
   float* node_penalty;     // [node] 0, 1000 or 10000
   // k_sweep<*, 0> only (a boundary with more right nodes than the LDS variants stage): per-sentence slice
   // for the prescores, their sums and the cutoff order
+  // normalize maker: a start with more results / traversal states than the per-lane arrays hold (kMaxNormResults /
+  // kMaxNormStates) repeats its traversal in an HBM slice: norm_slots groups of 64 (one slice per lane of a wavefront,
+  // group = workgroup index mod norm_slots), norm_locks[group * 64 + lane]
+  unsigned char* norm_scratch;
+  u32* norm_locks;
+  u32 norm_slots;
   // full-beam sweep: boundaries with more live candidates than its LDS staging holds take one of `full_slots` HBM
   // slices of `full_cap` candidates each (full_locks[slot]: 0 free / 1 taken)
   unsigned char* full_scratch;

@@ -350,6 +350,7 @@ struct jppgpu_ctx {
   void* seed_user = nullptr;
   DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
   DevBuf full_scratch, full_locks;   // k_sweep_full's HBM slices for boundaries beyond its LDS staging
+  DevBuf norm_scratch, norm_locks;   // k_norm's HBM slices for starts beyond the per-lane result / state arrays
   // per-entry T0 memo (k_t0_memo): device table + what its weight-dependent half is rebuilt from
   DevBuf t0_memo;
   u32 t0_memo_slots = 0;
@@ -986,7 +987,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
-                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks};
+                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
@@ -1098,6 +1099,22 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_noff = ctx->rnn_noff.as<u32>();
   B.rnn_rows = ctx->rnn_rows.as<u32>();
   B.rnn_rowbase = ctx->rnn_rowbase.as<u64>();
+  B.norm_scratch = nullptr;
+  B.norm_locks = nullptr;
+  B.norm_slots = 0;
+  if (ctx->hmodel.norm_maker >= 0) {
+    if (!ctx->norm_locks.p) {
+      static_assert(sizeof(NormState) == 16 && sizeof(NormResult) == 8, "slice layout");
+      const std::vector<u32> zeros(kNormSlotGroups * 64, 0u);
+      if (!(ctx->norm_scratch.ensure((size_t)kNormSlotGroups * 64 * norm_slice_bytes()) && ctx->norm_locks.ensure(zeros.size() * 4)))
+        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (normalize scratch)");
+      rt_h2d(ctx->norm_locks.p, zeros.data(), zeros.size() * 4, st);
+      rt_sync(st);
+    }
+    B.norm_scratch = ctx->norm_scratch.as<unsigned char>();
+    B.norm_locks = ctx->norm_locks.as<u32>();
+    B.norm_slots = kNormSlotGroups;
+  }
   if (n == 0) {
     B.total_nodes = 0;
     *out = Rp;

@@ -465,11 +465,18 @@ __device__ __forceinline__ int utf8_encode3(u32 cp, u8* b) {
   return 3;
 }
 
-// returns number of results or -1 on capacity overflow; results are sorted and uniqued
+// The reference's traversal has no bound on its state and result lists (charlattice.cc:266-353).  The per-lane arrays
+// hold kMaxNormStates / kMaxNormResults; a start that needs more repeats the traversal in an HBM slice of these sizes:
+constexpr int kBigNormStates = 2048;
+constexpr int kBigNormResults = 8192;
+constexpr u32 kNormSlotGroups = 16;   // x 64 lanes x 128 KB = 128 MB, allocated when the first batch needs it ... (see jppgpu_api.cc)
+__host__ __device__ constexpr size_t norm_slice_bytes() { return (size_t)kBigNormResults * 8 + 2 * (size_t)kBigNormStates * 16; }
+
+// returns number of results or -1 on capacity overflow; results are sorted and uniqued.
+// a, b: two state lists of maxs entries; res: maxr entries
 template <typename V>
-__device__ inline int norm_lookup(const DevModel& M, const V& S, const ClNodes* cl, u32 start,
-                                  NormResult* res) {
-  NormState a[kMaxNormStates], b[kMaxNormStates];
+__device__ inline int norm_lookup_into(const DevModel& M, const V& S, const ClNodes* cl, u32 start, NormResult* res, int maxr,
+                                       NormState* a, NormState* b, int maxs) {
   NormState* s1 = a;
   NormState* s2 = b;
   int n1 = 0, n2 = 0, nres = 0;
@@ -517,11 +524,11 @@ __device__ inline int norm_lookup(const DevModel& M, const V& S, const ClNodes* 
           u16 flags = ns.flags;
           if (newFlag & CL_DELETE) flags |= CL_DELETE_LAST;
           for_each_entry(M, ns.value, [&](i32 ptr) {
-            if (nres < kMaxNormResults) res[nres++] = NormResult{ptr, flags, ns.end};
+            if (nres < maxr) res[nres++] = NormResult{ptr, flags, ns.end};
             else overflow = true;
           });
         }
-        if (n2 < kMaxNormStates) s2[n2++] = ns;
+        if (n2 < maxs) s2[n2++] = ns;
         else overflow = true;
       }
     }
@@ -555,6 +562,40 @@ __device__ inline int norm_lookup(const DevModel& M, const V& S, const ClNodes* 
     res[m++] = res[x];
   }
   return m;
+}
+
+template <typename V>
+__device__ inline int norm_lookup(const DevModel& M, const V& S, const ClNodes* cl, u32 start, NormResult* res) {
+  NormState a[kMaxNormStates], b[kMaxNormStates];
+  return norm_lookup_into(M, S, cl, start, res, kMaxNormResults, a, b, kMaxNormStates);
+}
+
+// The same in this lane's HBM slice (taken under its lock; the caller releases it with norm_big_release once it is done
+// with the results, which stay in the slice).  Lanes of one wavefront own different slices, so a lane never waits for
+// a lane of its own wavefront; other wavefronts run on independently, so the wait cannot deadlock.
+// Returns the results through *out; -1: no pool, or beyond the slice as well.
+template <typename V>
+__device__ inline int norm_lookup_big(const Batch& B, const DevModel& M, const V& S, const ClNodes* cl, u32 start, u32* lock_out,
+                                      const NormResult** out) {
+  if (B.norm_slots == 0) return -1;
+  const u32 li = (blockIdx.x % B.norm_slots) * 64u + (threadIdx.x & 63u);
+  while (atomicCAS(&B.norm_locks[li], 0u, 1u) != 0u) {
+#if !defined(JPP_EMU)
+    __builtin_amdgcn_s_sleep(32);
+#endif
+  }
+  __threadfence();
+  unsigned char* base = B.norm_scratch + (size_t)li * norm_slice_bytes();
+  NormResult* res = reinterpret_cast<NormResult*>(base);
+  NormState* a = reinterpret_cast<NormState*>(base + (size_t)kBigNormResults * 8);
+  NormState* b = a + kBigNormStates;
+  *lock_out = li;
+  *out = res;
+  return norm_lookup_into(M, S, cl, start, res, kBigNormResults, a, b, kBigNormStates);
+}
+__device__ inline void norm_big_release(const Batch& B, u32 li) {
+  __threadfence();
+  atomicExch(&B.norm_locks[li], 0u);
 }
 
 // makePtr(surface, conf, eptr, feature): entry row of `eptr` with the replace
@@ -650,7 +691,10 @@ __device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel&
   u64 clmask = ~u64{0};
   if (MODE == 0 && n <= 64) clmask = wave_ballot(threadIdx.x < n && B.cl_nodes[g0 + threadIdx.x].n != 0);
   for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
-    NormResult res[kMaxNormResults];
+    NormResult res_local[kMaxNormResults];
+    const NormResult* res = res_local;
+    bool big = false;
+    u32 bigLock = 0;
     int nr;
     if (MODE == 0) {
       const u32 depth = B.pos_walk[g0 + i].ok_len;
@@ -659,8 +703,12 @@ __device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel&
         B.pos_cntN[g0 + i] = 0;
         continue;
       }
-      nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
-      if (nr < 0) {
+      nr = norm_lookup(M, S, B.cl_nodes + g0, i, res_local);
+      if (nr < 0) {   // beyond the per-lane arrays: once more in this lane's HBM slice
+        nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, &bigLock, &res);
+        big = B.norm_slots != 0;
+      }
+      if (nr < 0 || nr > 0xffff) {
         atomicMax(&B.sent_status[s], (i32)ST_CAPACITY);
         nr = 0;
       }
@@ -669,10 +717,18 @@ __device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel&
       nr = (int)B.pos_cntN[g0 + i];
       if (nr == 0) continue;
       if (nr <= kNormCache) {
-        for (int k = 0; k < nr; ++k) res[k] = cache[(u64)i * kNormCache + k];
+        for (int k = 0; k < nr; ++k) res_local[k] = cache[(u64)i * kNormCache + k];
+      } else if (nr <= kMaxNormResults) {
+        nr = norm_lookup(M, S, B.cl_nodes + g0, i, res_local);
+        if (nr < 0) {   // (more states than the per-lane lists hold, though the results fit)
+          nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, &bigLock, &res);
+          big = B.norm_slots != 0;
+        }
       } else {
-        nr = norm_lookup(M, S, B.cl_nodes + g0, i, res);
+        nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, &bigLock, &res);
+        big = B.norm_slots != 0;
       }
+      if (nr < 0) nr = 0;   // (cannot happen: the count pass went through the same traversal)
     }
     if (MODE == 0) {
       B.pos_cntN[g0 + i] = (u16)nr;
@@ -691,6 +747,7 @@ __device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel&
       out.n = 0;
       for (int k = 0; k < nr; ++k) norm_emit(M, mk, S, out, i, res[k]);
     }
+    if (big) norm_big_release(B, bigLock);
   }
 }
 

@@ -144,6 +144,33 @@ def check_full_beam_beyond_the_lds_staging(lib, ref_tools, tmp, n_lines, wide_co
     assert not errs, errs[:10]
 
 
+def check_normalize_beyond_the_lane_arrays(lib, ref_tools, tmp, n_lines, copies=1):
+    """the normalize maker with more results from one start than a lane's arrays hold (160): 300 readings of one surface,
+    reached through prolongation / small-kana variants of it -- the traversal is repeated in the lane's HBM slice; the
+    reference's lists are unbounded (charlattice.cc:266-353)"""
+    import test_gpu_parity as tg
+    extra = ''.join('すごい,0,0,0,名詞,普通名詞,*,*,すごい,よみ%d,すごい/よみ%d,代表表記:すごい/よみ%d\n' % (i, i, i) for i in range(300))
+    wide = ['すごーい', 'あすごーーいね', 'すっごーい', 'すごーいすごーい']
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, n_lines, 14, 7, length=30, extra_dict=extra, extra_lines=wide * copies)
+    ctx = J.Context(img, lib_path=lib)
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    assert (res.status == 0).all(), [int(x) for x in res.status if x != 0][:5]
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+    s = len(lines) - 4
+    bb = int(res.bnd_base[s])
+    assert int(res.bnd_count[bb:bb + int(res.ncp[s]) + 3].max()) >= 300
+
+
+def test_emulated_normalize_beyond_the_lane_arrays(emu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_normalize_beyond_the_lane_arrays(emu_lib, ref_tools, str(tmp_path), 6)
+
+
 def test_emulated_full_beam_beyond_the_lds_staging(emu_lib, ref_tools, tmp_path):
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')

@@ -463,6 +463,15 @@ def test_gpu_sentences_are_routed_to_sweep_variants_one_by_one(gpu_lib, ref_tool
     assert not errs, (len(errs), errs[:10])
 
 
+def test_gpu_normalize_beyond_the_lane_arrays(gpu_lib, ref_tools, tmp_path):
+    """the HBM-slice path of the normalize maker with its locks contended (16 slot groups): 200 random sentences + 1 200
+    with 300 normalised candidates from one start"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tc.check_normalize_beyond_the_lane_arrays(gpu_lib, ref_tools, str(tmp_path), 200, copies=300)
+
+
 def test_gpu_full_beam_beyond_the_lds_staging(gpu_lib, ref_tools, tmp_path):
     """the HBM-slice path of k_sweep_full with its slot locks contended (128 slots): 300 random sentences + 500 with
     boundaries of up to 2 752 candidates"""
