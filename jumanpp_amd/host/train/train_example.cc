@@ -140,9 +140,13 @@ Status GoldExampleReader::readExample(GoldExample* result) {
   StringPiece line;
   if (format_ == CorpusFormat::Morph) {
     // FullExampleReader::readFullExampleDblCsv (full_example.cc:76-112)
-    if (!nextLine(&line) || !outer_.parse(line, ' ')) {
+    if (!nextLine(&line)) {
       finished_ = true;
       return Status::Ok();
+    }
+    if (!outer_.parse(line, ' ')) {
+      // (an empty line is one empty word to the reference's reader, which then fails on it; so does a malformed quote)
+      return Status::InvalidParameter() << "failed to read word #0 from the line #" << lineNo_;
     }
     result->line_ = lineNo_;
     for (size_t i = 0; i < outer_.fields.size(); ++i) {
