@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -132,8 +134,35 @@ void rt_stream_destroy(jpp_stream_t s) {
 // copies got faster but pinning tens of megabytes per batch made the analysis stage 2-3x slower and
 // erratic; ordinary memory, recycled through HostPool so that it is neither re-allocated nor re-zeroed
 // per batch, is what is used.
-void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
-void rt_host_free(void* p) { free(p); }
+// (developer knob JPPGPU_DEV_PINNED=1: blocks of at least 1 MB page-locked -- they are recycled through HostPool, so a
+// steady-state batch pins nothing; profiles/r03_u_pinned_results.txt)
+std::mutex g_pinned_mu;
+std::set<void*> g_pinned;
+void* rt_host_alloc(size_t n) {
+  static const bool pinned = std::getenv("JPPGPU_DEV_PINNED") && std::atoi(std::getenv("JPPGPU_DEV_PINNED")) != 0;
+  if (pinned && n >= (size_t{1} << 20)) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n, hipHostMallocDefault) == hipSuccess && p) {
+      std::lock_guard<std::mutex> l(g_pinned_mu);
+      g_pinned.insert(p);
+      return p;
+    }
+  }
+  return malloc(n ? n : 1);
+}
+void rt_host_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> l(g_pinned_mu);
+    auto it = g_pinned.find(p);
+    if (it != g_pinned.end()) {
+      g_pinned.erase(it);
+      (void)hipHostFree(p);
+      return;
+    }
+  }
+  free(p);
+}
 struct Timer {
   hipEvent_t ev[13];
   bool have = false;
