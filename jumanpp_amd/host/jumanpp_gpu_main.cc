@@ -42,6 +42,7 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -629,6 +630,15 @@ int main(int argc, const char** argv) {
     std::atomic<long long> scanUs(0), prepUs(0), formatUs(0), writeUs(0), gpuUs(0);
     std::vector<double> analyzeMsDev((size_t)nDev, 0.0);
     auto us = [&]() { return (long long)(clock.ms() * 1000.0); };
+    // The second analyzer of a device (a second copy of the model and its per-entry tables in HBM: ~0.15 s) is made on
+    // a thread of its own while the first batch is read and analysed, when the input is large enough to need it; made
+    // lazily on the analysis thread it cost a quarter of a 1 M-line run (profiles/r03_v_cli_batches.txt).
+    size_t inputBytes = 0;
+    for (auto& mf : maps) inputBytes += mf->size;
+    std::vector<std::future<Status>> secondAnalyzer((size_t)nDev);
+    if (nAnalyzers > 1 && inputBytes > (size_t)conf.batch * 16 * (size_t)nDev) {
+      for (int d = 0; d < nDev; ++d) secondAnalyzer[(size_t)d] = std::async(std::launch::async, [&, d]() { return makeAnalyzer(d, 1); });
+    }
 
     // scanner: batches of conf.batch examples (an example = its "# " comment lines + one other line,
     // PlainStreamReader::readExample, stream_reader.cc:12-38), dealt to the devices in turn
@@ -700,8 +710,9 @@ int main(int argc, const char** argv) {
           freeAnalyzers[d]->acquire();
           job->analyzer = next;
           const double a0 = clock.ms();
-          if (!analyzers[d][job->analyzer]) {
-            Status made = makeAnalyzer(d, job->analyzer);
+          const bool pendingSecond = job->analyzer == 1 && secondAnalyzer[(size_t)d].valid();
+          if (pendingSecond || !analyzers[d][job->analyzer]) {
+            Status made = pendingSecond ? secondAnalyzer[(size_t)d].get() : makeAnalyzer(d, job->analyzer);
             if (!made) {   // (no HBM for a second copy of the model) carry on with the first analyzer alone
               analyzers[d][job->analyzer].reset();
               freeAnalyzers[d]->acquire();
