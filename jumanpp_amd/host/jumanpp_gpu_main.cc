@@ -44,6 +44,8 @@
 #include <string>
 #include <future>
 #include <thread>
+
+#include <sched.h>
 #include <vector>
 
 #include "gpu_analyzer.h"
@@ -216,6 +218,34 @@ std::string statusText(const Status& s) {
   std::ostringstream o;
   o << s;
   return o.str();
+}
+
+// Hardware threads this process may really use: the affinity mask and the cgroup CPU quota, not what is visible (a
+// container that sees 256 CPUs and is granted 16 is throttled for the rest of the scheduler period once its threads
+// have used the quota up: 32 format workers there stalled the analysis thread for tens of milliseconds at a time).
+unsigned usableCores() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int c = CPU_COUNT(&set);
+    if (c > 0) n = std::min(n, (unsigned)c);
+  }
+  {
+    std::ifstream f("/sys/fs/cgroup/cpu.max");   // cgroup v2: "<quota|max> <period>"
+    std::string quota;
+    long long period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0) {
+      const long long q = std::atoll(quota.c_str());
+      if (q > 0) n = std::min(n, (unsigned)std::max(1LL, q / period));
+    }
+  }
+  {
+    std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");   // cgroup v1
+    long long q = -1, per = 0;
+    if (fq >> q && fp >> per && q > 0 && per > 0) n = std::min(n, (unsigned)std::max(1LL, q / per));
+  }
+  return n;
 }
 
 template <typename T>
@@ -487,7 +517,7 @@ int main(int argc, const char** argv) {
     sconf.numScorers = 1;
     def.scoreWeights = {1.0f};
   }
-  if (conf.threads <= 0) conf.threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (conf.threads <= 0) conf.threads = (int)std::min(32u, usableCores());
   // JumanppExec::initOutput (jumandic_env.cc:55-150) and emptyResult (:211-222); one instance per format worker
   StringPiece emptyResult = "# ERROR\nEOS\n";
   const bool latticeFormat = conf.lattice != 0;
