@@ -1,5 +1,10 @@
 #include "juman_format.h"
 
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
 namespace jumanpp_amd {
 
 Status JumandicFields::initialize(const OutputManager& om) {
@@ -55,16 +60,63 @@ void formatNormalizedFeature(std::string& p, int32_t v) {
   if (has(M_DELETE_LAST)) p += 'L';
 }
 
+NodeTextCache::NodeTextCache(size_t entryDataBytes) : nslots_(entryDataBytes / 8 + 1) {
+  slots_.reset(new std::atomic<const Record*>[nslots_]);
+  for (size_t i = 0; i < nslots_; ++i) slots_[i].store(nullptr, std::memory_order_relaxed);
+}
+
+NodeTextCache::~NodeTextCache() {
+  for (size_t i = 0; i < nslots_; ++i) std::free(const_cast<Record*>(slots_[i].load(std::memory_order_relaxed)));
+}
+
+void NodeTextCache::publish(int32_t eptr, StringPiece text) {
+  const size_t slot = (size_t)((uint32_t)eptr >> 4);
+  if (eptr < 0 || slot >= nslots_ || text.size() > 0xffffffu) return;
+  if (slots_[slot].load(std::memory_order_relaxed) != nullptr) return;
+  Record* r = static_cast<Record*>(std::malloc(sizeof(Record) + text.size()));
+  if (r == nullptr) return;
+  r->eptr = eptr;
+  r->len = (uint32_t)text.size();
+  std::memcpy(r + 1, text.data(), text.size());
+  const Record* expected = nullptr;
+  if (!slots_[slot].compare_exchange_strong(expected, r, std::memory_order_release, std::memory_order_relaxed)) std::free(r);
+}
+
+std::shared_ptr<NodeTextCache> NodeTextCache::forModel(const ModelImage* model) {
+  static std::mutex mu;
+  static std::map<const ModelImage*, std::weak_ptr<NodeTextCache>> caches;
+  std::lock_guard<std::mutex> l(mu);
+  std::shared_ptr<NodeTextCache> c = caches[model].lock();
+  if (!c) {
+    c = std::make_shared<NodeTextCache>(model->entryData().size());
+    caches[model] = c;
+  }
+  return c;
+}
+
 Status JumanFormat::initialize(const ModelImage* model) {
   model_ = model;
   if (!model->hasIdMap()) {
     return Status::InvalidState("model image has no JUMAN id tables (re-export it with the current ref_dump)");
   }
+  cache_ = NodeTextCache::forModel(model);
   OutputManager om(model);
   return flds_.initialize(om);
 }
 
 bool JumanFormat::formatOne(const OutputManager& om, const SentenceResult& s, uint32_t node, bool first) {
+  // a dictionary node as the first alternative of its position: its text is cached per entry
+  if (node >= s.numNodes || s.nodes == nullptr) return false;
+  const int32_t eptr = s.nodes[node].entry_ptr;
+  const bool cacheable = first && eptr >= 0 && cache_ != nullptr;
+  if (cacheable) {
+    const StringPiece hit = cache_->find(eptr);
+    if (!hit.empty()) {
+      printer_.append(hit.data(), hit.size());
+      return true;
+    }
+  }
+  const size_t startOfNode = printer_.size();
   if (!om.locate(s, node, &walker_)) return false;
   std::string& printer = printer_;
   while (walker_.next()) {
@@ -131,6 +183,7 @@ bool JumanFormat::formatOne(const OutputManager& om, const SentenceResult& s, ui
     printer += '\n';
     first = false;
   }
+  if (cacheable) cache_->publish(eptr, StringPiece(printer_.data() + startOfNode, printer_.size() - startOfNode));
   return true;
 }
 

@@ -4,6 +4,8 @@
 #ifndef JUMANPP_AMD_HOST_JUMAN_FORMAT_H
 #define JUMANPP_AMD_HOST_JUMAN_FORMAT_H
 
+#include <atomic>
+#include <memory>
 #include <string>
 
 #include "gpu_analyzer.h"
@@ -28,11 +30,43 @@ class OutputFormat {
   virtual StringPiece result() const = 0;
 };
 
+// The text JumanFormat prints for a DICTIONARY node is a function of its entry alone (all rows of an alias entry
+// included): formatted once, by whichever format worker meets the entry first, and copied from then on.  One slot per
+// entry ((EntryPtr >> 1) >> 3, unique because an entry row is at least 8 bytes long), published with a compare-and-swap;
+// a record carries its entry pointer, so a slot that ever served two pointers would simply never hit for the second.
+class NodeTextCache {
+  struct Record {
+    int32_t eptr;
+    uint32_t len;
+    // text follows
+  };
+  std::unique_ptr<std::atomic<const Record*>[]> slots_;
+  size_t nslots_ = 0;
+
+ public:
+  explicit NodeTextCache(size_t entryDataBytes);
+  ~NodeTextCache();
+  NodeTextCache(const NodeTextCache&) = delete;
+  NodeTextCache& operator=(const NodeTextCache&) = delete;
+  // the cached text of the dictionary node `eptr`, or an empty piece
+  StringPiece find(int32_t eptr) const {
+    const size_t slot = (size_t)((uint32_t)eptr >> 4);
+    if (eptr < 0 || slot >= nslots_) return StringPiece();
+    const Record* r = slots_[slot].load(std::memory_order_acquire);
+    if (r == nullptr || r->eptr != eptr) return StringPiece();
+    return StringPiece(reinterpret_cast<const char*>(r + 1), r->len);
+  }
+  void publish(int32_t eptr, StringPiece text);
+  // one cache per model, shared by the format objects of all workers
+  static std::shared_ptr<NodeTextCache> forModel(const ModelImage* model);
+};
+
 class JumanFormat : public OutputFormat {
   const ModelImage* model_ = nullptr;
   JumandicFields flds_;
   std::string printer_;
   NodeWalker walker_;
+  std::shared_ptr<NodeTextCache> cache_;
   bool formatOne(const OutputManager& om, const SentenceResult& s, uint32_t node, bool first);
 
  public:
