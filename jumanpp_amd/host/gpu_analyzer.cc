@@ -36,7 +36,6 @@ void GpuAnalyzer::releaseResult() {
   groups_.clear();
   groupOf_.clear();
   localIdx_.clear();
-  pendingFetch_ = false;
 }
 
 Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cfg, const ScoringConfig& sconf,
@@ -247,64 +246,26 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
     double t1 = now();
     tAnalyze += t1 - t0;
     // host copies are taken right away: the next group's batch invalidates the device side of this result
-    // (submitBatch of a one-group batch leaves them to collectBatch)
-    if (deferFetch_ && beams.size() == 1) {
-      pendingFetch_ = true;
-      pendingFull_ = fullLattice;
-      return Status::Ok();
+    if (fullLattice && latticeNBest_ > 0) {
+      const int32_t nBest = std::min<int32_t>(64, cfg_.autoBeamStep > 0 ? G.beam : latticeNBest_);
+      rc = jppgpu_result_fetch_nbest(G.result, nBest, &G.nbest);
+      if (rc != JPPGPU_OK) return fromCode(rc);
+      G.hasNbest = true;
+      G.view = jppgpu_result_view{};
+      G.view.n_sentences = G.nbest.n_sentences;
+      G.view.status = G.nbest.status;
+      G.view.n_codepoints = G.nbest.n_codepoints;
+      G.view.n_nodes = G.nbest.n_nodes;
+      G.view.beam = G.nbest.beam;
+      G.view.global_beam = G.nbest.global_beam;
+      G.view.num_scorers = G.nbest.num_scorers;
+    } else {
+      rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
+      if (rc != JPPGPU_OK) return fromCode(rc);
     }
-    Status fs = fetchGroup(groups_.size() - 1, fullLattice);
-    if (!fs) return fs;
     tFetch += now() - t1;
   }
   double tGroups = now();
-  Status fin = finishBatch();
-  if (hostTiming)
-    std::fprintf(stderr, "runBatch n=%zu total=%.2f ms: prepare %.2f analyze %.2f fetch %.2f offsets %.2f\n", n, now() - tStart,
-                 tGroups - tStart - tAnalyze - tFetch, tAnalyze, tFetch, now() - tGroups);
-  return fin;
-}
-
-Status GpuAnalyzer::submitBatch(const std::vector<StringPiece>& inputs, bool fullLattice) {
-  deferFetch_ = true;
-  Status s = runBatch(inputs, fullLattice, nullptr);
-  deferFetch_ = false;
-  return s;
-}
-
-Status GpuAnalyzer::collectBatch() {
-  if (!pendingFetch_) return Status::Ok();
-  pendingFetch_ = false;
-  Status fs = fetchGroup(0, pendingFull_);
-  if (!fs) return fs;
-  return finishBatch();
-}
-
-Status GpuAnalyzer::fetchGroup(size_t g, bool fullLattice) {
-  Group& G = groups_[g];
-  int rc;
-  if (fullLattice && latticeNBest_ > 0) {
-    const int32_t nBest = std::min<int32_t>(64, cfg_.autoBeamStep > 0 ? G.beam : latticeNBest_);
-    rc = jppgpu_result_fetch_nbest(G.result, nBest, &G.nbest);
-    if (rc != JPPGPU_OK) return fromCode(rc);
-    G.hasNbest = true;
-    G.view = jppgpu_result_view{};
-    G.view.n_sentences = G.nbest.n_sentences;
-    G.view.status = G.nbest.status;
-    G.view.n_codepoints = G.nbest.n_codepoints;
-    G.view.n_nodes = G.nbest.n_nodes;
-    G.view.beam = G.nbest.beam;
-    G.view.global_beam = G.nbest.global_beam;
-    G.view.num_scorers = G.nbest.num_scorers;
-  } else {
-    rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
-    if (rc != JPPGPU_OK) return fromCode(rc);
-  }
-  return Status::Ok();
-}
-
-Status GpuAnalyzer::finishBatch() {
-  const size_t n = inputs_.size();
   // codepoint -> byte offset tables (for surfaces): sized here, filled by the first sentence(i) call,
   // which may come from any format worker (distinct sentences write distinct ranges)
   cpOffsetsBase_.assign(n + 1, 0);
@@ -317,6 +278,9 @@ Status GpuAnalyzer::finishBatch() {
   cpOffsets_.assign(cpTotal, 0);
   cpOffsetsReady_.assign(n, 0);
   cpOffsetsBase_[n] = cpTotal;
+  if (hostTiming)
+    std::fprintf(stderr, "runBatch n=%zu total=%.2f ms: prepare %.2f analyze %.2f fetch %.2f offsets %.2f\n", n, now() - tStart,
+                 tGroups - tStart - tAnalyze - tFetch, tAnalyze, tFetch, now() - tGroups);
   return Status::Ok();
 }
 

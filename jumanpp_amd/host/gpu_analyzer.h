@@ -113,9 +113,6 @@ class GpuAnalyzer {
                   ScorePlugin* plugin = nullptr);
 
   void releaseResult();
-  Status fetchGroup(size_t g, bool fullLattice);
-  Status finishBatch();
-  bool deferFetch_ = false, pendingFetch_ = false, pendingFull_ = false;
 
  public:
   GpuAnalyzer() = default;
@@ -129,11 +126,6 @@ class GpuAnalyzer {
   Status analyze(StringPiece input);
   // n sentences, one launch sequence; a failing sentence does not fail the batch (see sentenceStatus)
   Status analyzeBatch(const std::vector<StringPiece>& inputs, bool fullLattice = false);
-  // The same in two halves, for a caller that keeps several analyzers of one GPU busy: submitBatch uploads the text and
-  // enqueues the analysis (it returns once the device work is queued, after the lattice-size round trips), collectBatch
-  // waits for it and copies the results to the host.  Between the two the object may be handed to another thread.
-  Status submitBatch(const std::vector<StringPiece>& inputs, bool fullLattice = false);
-  Status collectBatch();
 
   // Analyzer::analyze(input, plugin) for a batch, with any plugin of the batched form above
   Status analyzeBatch(const std::vector<StringPiece>& inputs, ScorePlugin* plugin, bool fullLattice = false);

@@ -597,9 +597,7 @@ int main(int argc, const char** argv) {
   // GPU | format it (conf.threads workers, one OutputFormat each) | write it.  Two analyzers alternate
   // so that batch k+1 is analysed while batch k, whose results stay valid until its analyzer's next
   // call, is being formatted.  Output order is the input order.
-  // (the sharded file-to-file pipeline rotates three: one being submitted to, one whose results are being collected or
-  // formatted, one being formatted)
-  const int nAnalyzers = conf.pipeline ? (sharded ? 3 : 2) : 1;
+  const int nAnalyzers = conf.pipeline ? 2 : 1;
   if (conf.devices.empty()) conf.devices.push_back(conf.device);
   const int nDev = (int)conf.devices.size();
   // per device: the second analyzer (a second copy of the model in HBM) is made when a second batch shows
@@ -667,12 +665,9 @@ int main(int argc, const char** argv) {
     // lazily on the analysis thread it cost a quarter of a 1 M-line run (profiles/r03_v_cli_batches.txt).
     size_t inputBytes = 0;
     for (auto& mf : maps) inputBytes += mf->size;
-    std::vector<std::vector<std::future<Status>>> laterAnalyzers((size_t)nDev);
-    for (auto& v : laterAnalyzers) v.resize((size_t)nAnalyzers);
+    std::vector<std::future<Status>> secondAnalyzer((size_t)nDev);
     if (nAnalyzers > 1 && inputBytes > (size_t)conf.batch * 16 * (size_t)nDev) {
-      for (int d = 0; d < nDev; ++d)
-        for (int a = 1; a < nAnalyzers; ++a)
-          laterAnalyzers[(size_t)d][(size_t)a] = std::async(std::launch::async, [&, d, a]() { return makeAnalyzer(d, a); });
+      for (int d = 0; d < nDev; ++d) secondAnalyzer[(size_t)d] = std::async(std::launch::async, [&, d]() { return makeAnalyzer(d, 1); });
     }
 
     // scanner: batches of conf.batch examples (an example = its "# " comment lines + one other line,
@@ -707,30 +702,13 @@ int main(int argc, const char** argv) {
       for (auto& qd : readQ) qd->close();
     });
 
-    // per device: split the batch into examples and submit it to the next analyzer of the rotation, THEN collect the
-    // results of the batch submitted before it: the device works on batch k+1 while the results of batch k cross PCIe
-    // and batch k-1 is being formatted
+    // per device: split the batch into examples, analyse
     std::vector<std::thread> gpus;
     for (int d = 0; d < nDev; ++d) {
       gpus.emplace_back([&, d]() {
-        std::unique_ptr<ShardJob> job, prev;
+        std::unique_ptr<ShardJob> job;
         int next = 0, live = nAnalyzers;
-        auto collect = [&](std::unique_ptr<ShardJob>& j) {
-          const double c0 = clock.ms();
-          GpuAnalyzer& analyzer = *analyzers[d][j->analyzer];
-          if (j->batchStatus.isOk()) j->batchStatus = analyzer.collectBatch();
-          float ms[8];
-          analyzer.lastTimings(ms);
-          j->gpuMs = ms[7];
-          analyzeMsDev[d] += clock.ms() - c0;
-          fmtQ[d]->push(std::move(j));
-        };
-        for (;;) {
-          const bool have = readQ[d]->pop(&job);
-          if (!have) {
-            if (prev) collect(prev);
-            break;
-          }
+        while (readQ[d]->pop(&job)) {
           long long t0 = us();
           {
             const char* q = job->data;
@@ -762,19 +740,13 @@ int main(int argc, const char** argv) {
           freeAnalyzers[d]->acquire();
           job->analyzer = next;
           const double a0 = clock.ms();
-          std::future<Status>& pending = laterAnalyzers[(size_t)d][(size_t)job->analyzer];
-          if (pending.valid() || !analyzers[d][job->analyzer]) {
-            Status made = pending.valid() ? pending.get() : makeAnalyzer(d, job->analyzer);
-            if (!made) {
-              // (no HBM for another copy of the model and its workspaces) carry on with the analyzers made so far: let
-              // everything in flight run through (collect the submitted batch, take every other token), then leave as
-              // many tokens in circulation as the smaller rotation has analyzers
-              const int haveN = job->analyzer;
+          const bool pendingSecond = job->analyzer == 1 && secondAnalyzer[(size_t)d].valid();
+          if (pendingSecond || !analyzers[d][job->analyzer]) {
+            Status made = pendingSecond ? secondAnalyzer[(size_t)d].get() : makeAnalyzer(d, job->analyzer);
+            if (!made) {   // (no HBM for a second copy of the model) carry on with the first analyzer alone
               analyzers[d][job->analyzer].reset();
-              if (prev) collect(prev);
-              for (int i = 1; i < live; ++i) freeAnalyzers[d]->acquire();
-              live = haveN;
-              for (int i = 1; i < live; ++i) freeAnalyzers[d]->release();
+              freeAnalyzers[d]->acquire();
+              live = 1;
               job->analyzer = 0;
             }
           }
@@ -783,11 +755,13 @@ int main(int argc, const char** argv) {
             std::vector<StringPiece> pieces(job->inputs);
             for (auto& e : job->readErrors) pieces[e.first] = StringPiece("", 0);
             GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
-            job->batchStatus = analyzer.submitBatch(pieces, useLattice);
+            job->batchStatus = analyzer.analyzeBatch(pieces, useLattice);
+            float ms[8];
+            analyzer.lastTimings(ms);
+            job->gpuMs = ms[7];
           }
           analyzeMsDev[d] += clock.ms() - a0;
-          if (prev) collect(prev);
-          prev = std::move(job);
+          fmtQ[d]->push(std::move(job));
         }
         fmtQ[d]->close();
       });
