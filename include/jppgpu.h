@@ -117,6 +117,12 @@ typedef struct {
 /* AnalyzerConfig + ScoringConfig subset (src/core/analysis/analyzer.h:15-27,
  * defaults of the CLI: src/jumandic/shared/jumanpp_args.h:50-54) */
 typedef struct {
+  uint32_t struct_size;     /* = sizeof(jppgpu_config) of the header the CALLER was compiled against (JPPGPU_CONFIG_INIT sets
+                             * it).  The struct only ever grows at its end: the library reads the first struct_size bytes
+                             * and takes the defaults (0) for fields the caller's header did not have; a size it never
+                             * shipped (smaller than JPPGPU_CONFIG_MIN_SIZE, larger than its own with non-zero unknown
+                             * tail, not a multiple of 4) is JPPGPU_INVALID_PARAMETER.  ABI break of round 4: up to
+                             * round 3 the struct started with `beam` and had no size field. */
   int32_t beam;             /* 5 */
   int32_t global_beam;      /* 6 */
   int32_t right_check;      /* 1 */
@@ -131,6 +137,8 @@ typedef struct {
                              * (TrainingEnv::initFeatures(nullptr), src/jumandic/main/jumanpp_train.cc:206,
                              * src/core/features_api.cc:20-60).  0: static code when the spec matches (the analyser). */
 } jppgpu_config;
+#define JPPGPU_CONFIG_MIN_SIZE 44u   /* struct_size .. dynamic_features: the first layout that carried a size */
+#define JPPGPU_CONFIG_INIT {(uint32_t)sizeof(jppgpu_config)}
 
 /* EntryPtr::BOS() / EntryPtr::EOS() raw values (src/core/core_types.h:44-58) */
 #define JPPGPU_ENTRY_BOS ((int32_t)0x80000000)

@@ -728,9 +728,23 @@ bool upload_memo(jppgpu_ctx* ctx, const float* weights) {
 
 extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
 
-extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c, jppgpu_ctx** out) {
-  if (!m || !c || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_in, jppgpu_ctx** out) {
+  if (!m || !c_in || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   *out = nullptr;
+  // the caller's struct may be older (shorter) or newer (longer) than ours: read what both sides know
+  jppgpu_config c_local;
+  memset(&c_local, 0, sizeof(c_local));
+  {
+    const uint32_t sz = c_in->struct_size;
+    if (sz < JPPGPU_CONFIG_MIN_SIZE || sz % 4 != 0 || sz > 4096)
+      return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_config::struct_size is not a size this library knows (set it to sizeof(jppgpu_config))");
+    memcpy(&c_local, c_in, sz < sizeof(c_local) ? sz : sizeof(c_local));
+    const unsigned char* tail = reinterpret_cast<const unsigned char*>(c_in);
+    for (uint32_t i = (uint32_t)sizeof(c_local); i < sz; ++i)
+      if (tail[i] != 0) return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu_config carries a non-zero field this library does not know");
+    c_local.struct_size = (uint32_t)sizeof(c_local);
+  }
+  const jppgpu_config* c = &c_local;
 #if !defined(JPP_EMU)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

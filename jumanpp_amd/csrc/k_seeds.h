@@ -570,32 +570,43 @@ __device__ inline int norm_lookup(const DevModel& M, const V& S, const ClNodes* 
   return norm_lookup_into(M, S, cl, start, res, kMaxNormResults, a, b, kMaxNormStates);
 }
 
-// The same in this lane's HBM slice (taken under its lock; the caller releases it with norm_big_release once it is done
-// with the results, which stay in the slice).  Lanes of one wavefront own different slices, so a lane never waits for
-// a lane of its own wavefront; other wavefronts run on independently, so the wait cannot deadlock.
+// The same in this lane's HBM slice.  A pool slot is 64 slices, one per lane, and is owned by ONE WAVEFRONT at a time
+// (norm_slot_acquire / norm_slot_release, wave-uniform): the lock is taken by lane 0 while no lane of the wavefront is
+// inside a critical section, a wavefront holds at most one slot and never waits while it holds one, so the waits cannot
+// form a cycle.  (Until round 3 every lane took a lock of its own inside divergent code: a lane that had its lock stayed
+// masked off until its siblings left their spin loops, so two wavefronts of the same slot could take their lanes' locks
+// crosswise and hang -- ADVICE r03.)  The results stay in the slice until the caller releases the slot.
 // Returns the results through *out; -1: no pool, or beyond the slice as well.
 template <typename V>
-__device__ inline int norm_lookup_big(const Batch& B, const DevModel& M, const V& S, const ClNodes* cl, u32 start, u32* lock_out,
+__device__ inline int norm_lookup_big(const Batch& B, const DevModel& M, const V& S, const ClNodes* cl, u32 start, u32 slot,
                                       const NormResult** out) {
   if (B.norm_slots == 0) return -1;
-  const u32 li = (blockIdx.x % B.norm_slots) * 64u + (threadIdx.x & 63u);
-  while (atomicCAS(&B.norm_locks[li], 0u, 1u) != 0u) {
-#if !defined(JPP_EMU)
-    __builtin_amdgcn_s_sleep(32);
-#endif
-  }
-  __threadfence();
+  const u32 li = slot * 64u + (threadIdx.x & 63u);
   unsigned char* base = B.norm_scratch + (size_t)li * norm_slice_bytes();
   NormResult* res = reinterpret_cast<NormResult*>(base);
   NormState* a = reinterpret_cast<NormState*>(base + (size_t)kBigNormResults * 8);
   NormState* b = a + kBigNormStates;
-  *lock_out = li;
   *out = res;
   return norm_lookup_into(M, S, cl, start, res, kBigNormResults, a, b, kBigNormStates);
 }
-__device__ inline void norm_big_release(const Batch& B, u32 li) {
+// wave-uniform: every lane of the (single-wavefront) workgroup calls these together
+__device__ inline u32 norm_slot_acquire(const Batch& B) {
+  const u32 slot = B.norm_slots ? blockIdx.x % B.norm_slots : 0u;
+  if (B.norm_slots != 0 && (threadIdx.x & 63u) == 0) {
+    while (atomicCAS(&B.norm_locks[slot * 64u], 0u, 1u) != 0u) {
+#if !defined(JPP_EMU)
+      __builtin_amdgcn_s_sleep(32);
+#endif
+    }
+    __threadfence();
+  }
+  __syncthreads();
+  return slot;
+}
+__device__ inline void norm_slot_release(const Batch& B, u32 slot) {
   __threadfence();
-  atomicExch(&B.norm_locks[li], 0u);
+  __syncthreads();
+  if (B.norm_slots != 0 && (threadIdx.x & 63u) == 0) atomicExch(&B.norm_locks[slot * 64u], 0u);
 }
 
 // makePtr(surface, conf, eptr, feature): entry row of `eptr` with the replace
@@ -690,54 +701,58 @@ __device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel&
   // keep the positions that have charlattice nodes in one ballot, and most starts are dismissed without a walk.
   u64 clmask = ~u64{0};
   if (MODE == 0 && n <= 64) clmask = wave_ballot(threadIdx.x < n && B.cl_nodes[g0 + threadIdx.x].n != 0);
-  for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+  // The trip count is uniform over the wavefront (lanes beyond n idle along): whether any lane of a round needs the HBM
+  // slice is decided with one ballot, and the slot is taken and released by the wavefront as a whole.
+  for (u32 i0 = 0; i0 < n; i0 += blockDim.x) {
+    const u32 i = i0 + threadIdx.x;
     NormResult res_local[kMaxNormResults];
     const NormResult* res = res_local;
-    bool big = false;
-    u32 bigLock = 0;
-    int nr;
-    if (MODE == 0) {
+    int nr = 0;
+    bool act = i < n;
+    bool needBig = false;
+    if (act && MODE == 0) {
       const u32 depth = B.pos_walk[g0 + i].ok_len;
       const bool reachable = depth >= 63 || i >= 63 || ((clmask >> (i + 1)) & ((u64{1} << depth) - 1)) != 0;
       if (!reachable) {
         B.pos_cntN[g0 + i] = 0;
-        continue;
+        act = false;
+      } else {
+        nr = norm_lookup(M, S, B.cl_nodes + g0, i, res_local);
+        needBig = nr < 0;   // beyond the per-lane arrays: once more in this lane's HBM slice
       }
-      nr = norm_lookup(M, S, B.cl_nodes + g0, i, res_local);
-      if (nr < 0) {   // beyond the per-lane arrays: once more in this lane's HBM slice
-        nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, &bigLock, &res);
-        big = B.norm_slots != 0;
+    } else if (act) {
+      // the count pass left the number of results and, for short lists, the results themselves
+      nr = (int)B.pos_cntN[g0 + i];
+      if (nr == 0) {
+        act = false;
+      } else if (nr <= kNormCache) {
+        for (int k = 0; k < nr; ++k) res_local[k] = cache[(u64)i * kNormCache + k];
+      } else if (nr <= kMaxNormResults) {
+        nr = norm_lookup(M, S, B.cl_nodes + g0, i, res_local);
+        needBig = nr < 0;   // (more states than the per-lane lists hold, though the results fit)
+      } else {
+        needBig = true;
       }
+    }
+    const bool anyBig = wave_ballot(needBig) != 0;   // uniform
+    u32 slot = 0;
+    if (anyBig) {
+      slot = norm_slot_acquire(B);
+      if (needBig) nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, slot, &res);
+    }
+    if (act && MODE == 0) {
       if (nr < 0 || nr > 0xffff) {
         atomicMax(&B.sent_status[s], (i32)ST_CAPACITY);
         nr = 0;
       }
-    } else {
-      // the count pass left the number of results and, for short lists, the results themselves
-      nr = (int)B.pos_cntN[g0 + i];
-      if (nr == 0) continue;
-      if (nr <= kNormCache) {
-        for (int k = 0; k < nr; ++k) res_local[k] = cache[(u64)i * kNormCache + k];
-      } else if (nr <= kMaxNormResults) {
-        nr = norm_lookup(M, S, B.cl_nodes + g0, i, res_local);
-        if (nr < 0) {   // (more states than the per-lane lists hold, though the results fit)
-          nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, &bigLock, &res);
-          big = B.norm_slots != 0;
-        }
-      } else {
-        nr = norm_lookup_big(B, M, S, B.cl_nodes + g0, i, &bigLock, &res);
-        big = B.norm_slots != 0;
-      }
-      if (nr < 0) nr = 0;   // (cannot happen: the count pass went through the same traversal)
-    }
-    if (MODE == 0) {
       B.pos_cntN[g0 + i] = (u16)nr;
       u64 ends = 0;
       for (int k = 0; k < nr; ++k) ends |= res[k].end < 64 ? (u64{1} << res[k].end) : u64{0};
       if (ends) B.pos_ends[g0 + i] |= ends;   // k_seeds<0> of this launch sequence wrote the word already
       if (nr <= kNormCache)
         for (int k = 0; k < nr; ++k) cache[(u64)i * kNormCache + k] = res[k];
-    } else {
+    } else if (act) {
+      if (nr < 0) nr = 0;   // (cannot happen: the count pass went through the same traversal)
       SeedSink out;
       out.emit = true;
       out.ends = 0;
@@ -747,7 +762,7 @@ __device__ __forceinline__ void norm_of_sentence(const Batch& B, const DevModel&
       out.n = 0;
       for (int k = 0; k < nr; ++k) norm_emit(M, mk, S, out, i, res[k]);
     }
-    if (big) norm_big_release(B, bigLock);
+    if (anyBig) norm_slot_release(B, slot);
   }
 }
 

@@ -55,7 +55,7 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
   if (cfg.autoBeamStep < 0 || (cfg.autoBeamStep > 0 && (cfg.autoBeamBase <= 0 || cfg.autoBeamMax < cfg.autoBeamBase))) {
     return Status::InvalidParameter("auto beam: step must be positive and base <= max");
   }
-  jppgpu_config c{};
+  jppgpu_config c = JPPGPU_CONFIG_INIT;
   c.beam = sconf.beamSize;
   c.global_beam = cfg.globalBeamSize;
   c.right_check = cfg.rightGbeamCheck;

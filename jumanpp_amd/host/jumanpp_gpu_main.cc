@@ -551,8 +551,21 @@ int main(int argc, const char** argv) {
   };
 
   // files in, file out: the sharded pipeline (see the head of this file)
-  const bool sharded = conf.pipeline && !conf.partialInput && !conf.inputs.empty() && !conf.output.empty() &&
-                       conf.output != "-" && std::getenv("JUMANPP_GPU_NO_SHARDED") == nullptr;
+  bool sharded = conf.pipeline && !conf.partialInput && !conf.inputs.empty() && !conf.output.empty() &&
+                 conf.output != "-" && std::getenv("JUMANPP_GPU_NO_SHARDED") == nullptr;
+  if (sharded) {
+    // it maps its inputs and pwrite()s its output: every input must be a regular file, and the output a regular (or
+    // new) file that is none of the inputs (O_TRUNC on a mapped input would end in SIGBUS).  FIFOs, /dev/stdin,
+    // /dev/stdout, process substitutions and an output that names an input take the general stream pipeline.
+    struct stat so;
+    const bool haveOut = ::stat(conf.output.c_str(), &so) == 0;
+    if (haveOut && !S_ISREG(so.st_mode)) sharded = false;
+    for (auto& path : conf.inputs) {
+      struct stat si;
+      if (::stat(path.c_str(), &si) != 0 || !S_ISREG(si.st_mode)) sharded = false;
+      else if (haveOut && si.st_dev == so.st_dev && si.st_ino == so.st_ino) sharded = false;
+    }
+  }
   std::unique_ptr<std::ofstream> ofile;
   std::ostream* out = &std::cout;
   if (!sharded && !conf.output.empty() && conf.output != "-") {

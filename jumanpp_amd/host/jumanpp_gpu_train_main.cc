@@ -26,7 +26,12 @@ void usage() {
                "  [--training-mode=full|falloff|violation] [--scw-c=1] [--scw-phi=5] [--beam=5] [--batch=1]\n"
                "  [--max-batch-iters=1] [--max-epochs=1] [--epsilon=1e-3] [--corpus-format=morph|csv]\n"
                "  [--gb-left-min=N --gb-left-max=N [--gb-right-min=N --gb-right-max=N --gb-rcheck-min=N --gb-rcheck-max=N] [--gb-first-full]]\n"
-               "  [--corpus-comment=TEXT] [--device=0]\n";
+               "  [--corpus-comment=TEXT] [--device=0]\n"
+               "\n"
+               "--batch=1 writes the model file jumanpp_v2_train writes (byte for byte).  With --batch=N > 1 all N examples of\n"
+               "a batch are analysed with the weights the batch started with and the N SCW updates are applied afterwards;\n"
+               "the reference interleaves each example's analysis with the updates of the examples before it\n"
+               "(trainOneBatch / handleProcessedTrainer), so the two trainers' models DIFFER for any batch above 1.\n";
 }
 }  // namespace
 

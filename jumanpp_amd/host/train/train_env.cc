@@ -52,7 +52,7 @@ Status TrainingEnv::initialize(const TrainingArguments& args, const ModelImage* 
   m.weights = scw_->weights().data();
   m.weight_exponent = args.sizeExponent;
   m.has_rnn = 0;
-  jppgpu_config c{};
+  jppgpu_config c = JPPGPU_CONFIG_INIT;
   c.beam = args.beamSize;
   c.global_beam = leftBeam_;
   c.right_check = rightCheck_;

@@ -41,7 +41,7 @@ class Model(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
+    _fields_ = [('struct_size', C.c_uint32), ('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
                 ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32),
                 ('use_rnn', C.c_int32), ('weight_perceptron', C.c_float), ('weight_rnn', C.c_float),
                 ('dynamic_features', C.c_int32)]
@@ -333,7 +333,7 @@ class Context:
             wp = weight_perceptron
         if weight_rnn is not None:
             wr = weight_rnn
-        cfg = Config(beam, global_beam, right_check, right_beam, max_input_bytes, device,
+        cfg = Config(C.sizeof(Config), beam, global_beam, right_check, right_beam, max_input_bytes, device,
                      1 if use_rnn else 0, wp, wr, 1 if dynamic_features else 0)
         h = C.c_void_p()
         rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))

@@ -953,7 +953,7 @@ int doShim(const char* modelFile, const char* libPath, int latticeN, char** extr
     m.rnn_num_fields = (u32)rh.fields.size();
     for (size_t i = 0; i < rh.fields.size() && i < 8; ++i) m.rnn_fields[i] = rh.fields[i];
   }
-  jppgpu_config c{};
+  jppgpu_config c = JPPGPU_CONFIG_INIT;
   c.beam = e.beam;
   c.global_beam = e.gbeam;
   c.right_check = e.rcheck;

@@ -464,12 +464,13 @@ def test_gpu_sentences_are_routed_to_sweep_variants_one_by_one(gpu_lib, ref_tool
 
 
 def test_gpu_normalize_beyond_the_lane_arrays(gpu_lib, ref_tools, tmp_path):
-    """the HBM-slice path of the normalize maker with its locks contended (16 slot groups): 200 random sentences + 1 200
-    with 300 normalised candidates from one start"""
+    """the HBM-slice path of the normalize maker with its slot locks contended (16 pool slots, one owner wavefront at a
+    time): 200 random sentences + 3 000 with 300 normalised candidates from one start, 1 200 of them with two to four such
+    starts in the same wavefront (the case that could hang the per-lane locks of round 3)"""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     import test_cpu_parity as tc
-    tc.check_normalize_beyond_the_lane_arrays(gpu_lib, ref_tools, str(tmp_path), 200, copies=300)
+    tc.check_normalize_beyond_the_lane_arrays(gpu_lib, ref_tools, str(tmp_path), 200, copies=600)
 
 
 def test_gpu_full_beam_beyond_the_lds_staging(gpu_lib, ref_tools, tmp_path):

@@ -249,6 +249,25 @@ def test_sharded_pipeline_files_in_file_out(cli_emu, ref_tools, golden_dir, tmp_
     assert rc == 0 and open(out, 'rb').read() == two
 
 
+def test_sharded_pipeline_only_for_regular_files(cli_emu, golden_dir, tmp_path):
+    """-o /dev/stdout (a pipe), a FIFO as input and an output that names the input must not take the mmap / pwrite
+    pipeline: same bytes as the plain run, no ESPIPE failure, no SIGBUS"""
+    m = os.path.join(golden_dir, 'mini.jppmdl')
+    src = os.path.join(golden_dir, 'mini.txt')
+    ref = open(os.path.join(golden_dir, 'mini.juman.txt'), 'rb').read()
+    p = subprocess.run('%s --model=%s --timing -o /dev/stdout %s | cat' % (cli_emu, m, src), shell=True, capture_output=True)
+    assert p.returncode == 0 and p.stdout == ref and b'sharded=1' not in p.stderr, p.stderr[-300:]
+    p = subprocess.run(['bash', '-c', '%s --model=%s -o %s <(cat %s)' % (cli_emu, m, tmp_path / 'o1.txt', src)], capture_output=True)
+    assert p.returncode == 0 and open(tmp_path / 'o1.txt', 'rb').read() == ref, p.stderr[-300:]
+    same = tmp_path / 'same.txt'
+    same.write_bytes(open(src, 'rb').read())
+    p = subprocess.run([cli_emu, '--model=' + m, '-o', str(same), str(same)], capture_output=True)
+    assert p.returncode in (0, 1), p.returncode          # (the reference truncates its own input as well) -- but no signal
+    # regular files still take it
+    rc, so, err = _run(cli_emu, ['--model=' + m, '--timing', '-o', str(tmp_path / 'o2.txt'), src])
+    assert rc == 0 and b'sharded=1' in err and open(tmp_path / 'o2.txt', 'rb').read() == ref
+
+
 @pytest.mark.gpu
 def test_gpu_sharded_pipeline(cli_gpu, ref_tools, tmp_path):
     """the sharded pipeline on the MI355X box (one GPU: the device list names it twice), RNN model"""
