@@ -272,7 +272,7 @@ def _ref_time(ref_dir, model, corpus):
     return json.loads(out.decode())
 
 
-def reference_top1(ref_dir, model, text, offs, np, tmp_dir, procs=None):
+def reference_top1(ref_dir, model, text, offs, np, tmp_dir, procs=None, beams=None):
     """CHECKER: the reference's packed top-1 result (oracle/ref_dump.cc `top1`: Analyzer::analyze per sentence, then
     {EntryPtr, start, end} of the best path in text order) for the sentences text[offs[i]:offs[i+1]], computed by one
     reference process per usable core.  Returns (status[n], offsets[n+1], items[m] as (eptr i32, start u16, end u16))."""
@@ -292,7 +292,8 @@ def reference_top1(ref_dir, model, text, offs, np, tmp_dir, procs=None):
                 f.write(b'\n')
         out = part + '.bin'
         fin = open(part, 'rb')
-        running.append((subprocess.Popen([os.path.join(ref_dir, 'ref_dump'), 'top1', model, out], stdin=fin,
+        running.append((subprocess.Popen([os.path.join(ref_dir, 'ref_dump'), 'top1', model, out] +
+                                         [str(int(x)) for x in (beams or [])], stdin=fin,
                                          stderr=subprocess.DEVNULL), fin, part, out, hi - lo))
     item_dt = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
     status, counts, items = [], [], []
@@ -357,6 +358,30 @@ def parity_sample(ref_dir, model, batches, run_packed, np, tmp_dir, n_batches=2)
                     '(oracle/_ref ref_dump top1, %d processes); %.1f s' % (min(n_batches, len(batches)), usable_cores(), time.time() - t)}
 
 
+def leg_parity(model, result, n_batch, text, offs, n_check, beams, np, torch, dev, tmp_dir, max_len):
+    """CHECKER (untimed) of an extra leg: `result` is the leg's OWN full-size batch as the timed loop analysed it; its
+    packed top-1 result is compared, for the first `n_check` sentences, with the reference run on this box's cores
+    under the leg's beam configuration (ref_dump top1 <beam gbeam rcheck rbeam>).  The device work is the benchmarked
+    shape; only the number of sentences the reference re-analyses is bounded."""
+    try:
+        t = time.time()
+        cap = n_batch * (max_len + 1)
+        d_offs = torch.zeros(n_batch + 1, dtype=torch.int32, device=dev)
+        d_items = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+        result.pack(d_offs.data_ptr(), d_items.data_ptr(), cap)
+        torch.cuda.synchronize()
+        ho = d_offs.cpu().numpy().view(np.uint32)
+        n_check = min(n_check, n_batch)
+        hi = d_items[:int(ho[n_check])].cpu().numpy()
+        rs, ro, ri = reference_top1(reference_build()[0], model, text, offs[:n_check + 1], np, tmp_dir, beams=beams)
+        bad = compare_packed(ho[:n_check + 1], hi, rs, ro, ri, np)
+        return {'sentences': n_check, 'mismatches': len(bad), 'first_mismatches': [int(b) for b in bad[:8]],
+                'what': 'packed top-1 result of the first %d sentences of the leg\'s own %d-sentence batch vs the reference '
+                        '(ref_dump top1, beams %s, %d processes); %.1f s' % (n_check, n_batch, list(beams), usable_cores(), time.time() - t)}
+    except Exception as e:  # the checker must never take the line down -- but it must say so
+        return {'error': str(e)[:300]}
+
+
 def cpu_baseline(args, model, mdic, cache_dir):
     """The real reference (Analyzer::analyze in a loop, oracle/ref_dump.cc `time`) on this box's host cores:
     one thread on the timed workload (with the RNN), one thread perceptron-only, and every core at once
@@ -407,15 +432,14 @@ def cpu_baseline(args, model, mdic, cache_dir):
 
 
 def realism_legs(args, cache, local_rank, np, torch, J):
-    """Extra legs beside the headline (never `value`): the same step on (i) a 1M-entry dictionary, (ii) weight
-    tables of 2^24 (64 MB: beyond the aggregate L2) and 2^26 floats (256 MB: the size of the Infinity Cache),
-    so the gathers of k_t0 / k_sweep leave the caches the headline's 16 MB table lives in."""
+    """Extra legs beside the headline (never `value`): the same step on (i) the headline workload of rounds 1-3 (300 k
+    entries, 2^22 weights = 16 MB, cache resident: the friendly end), (ii) a weight table of 2^26 floats (256 MB: the
+    size of the Infinity Cache), (iii) a homograph-heavy dictionary.  Every leg carries its own parity_sample."""
     import copy
     legs = {}
     dev = torch.device('cuda', local_rank)
     stream = torch.cuda.current_stream().cuda_stream
-    for name, over in (('dict_1m', {'dict_entries': 1000000}), ('weights_2e24', {'weights_exp': 24}),
-                       ('weights_2e26', {'weights_exp': 26})):
+    for name, over in (('dict_300k_weights_2e22', {'dict_entries': 300000, 'weights_exp': 22}), ('weights_2e26', {'weights_exp': 26})):
         try:
             a = copy.copy(args)
             for k, v in over.items():
@@ -450,13 +474,20 @@ def realism_legs(args, cache, local_rank, np, torch, J):
             # median step: a fresh context stalls once for ~60 ms between two of its first calls (seen in the kernel
             # trace as one idle gap, profiles/r02_p_realism_gaps.txt), which a 5-step mean would carry as +12 ms per step
             el = sorted(per_step)[k // 2]
-            r = run(0).fetch()
+            r = run(0)
+            par = None
+            if not args.no_parity and not args.no_cpu_baseline:
+                par = leg_parity(model, r, args.batch, batches[0][0], batches[0][1], 16384, [5, 6, 1, 5], np, torch, dev,
+                                 os.path.join(cache, 'parity_tmp'), args.sent_len)
+            r = r.fetch()
             legs[name] = {'value': round(args.batch / el, 1), 'unit': 'sentences/s', 'steps': k, 'timing': 'median step',
                           'ms_per_step': round(el * 1e3, 3),
                           'nodes_per_sentence': round(float(r.nnodes.sum()) / args.batch, 1),
                           'failed_sentences_in_batch': int((r.status != 0).sum()),
                           'kernel_ms_per_step': {kk: round(v / k, 3) for kk, v in km.items()},
                           'dict_entries': a.dict_entries, 'weights_exp': a.weights_exp, 'setup_s': round(setup_s, 1)}
+            if par is not None:
+                legs[name]['parity_sample'] = par
             r.release()
             del ctx, d
             torch.cuda.empty_cache()
@@ -586,7 +617,7 @@ def homograph_leg(args, cache, local_rank, np, torch, J):
         ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank,
                         use_rnn=None if args.rnn else False)
 
-        def measure(lines):
+        def measure(lines, check=0):
             offs = np.zeros(len(lines) + 1, dtype=np.uint32)
             offs[1:] = np.cumsum([len(l) for l in lines])
             tx = b''.join(lines)
@@ -606,20 +637,27 @@ def homograph_leg(args, cache, local_rank, np, torch, J):
                 ms = [m + x / 4 for m, x in zip(ms, sc['ms'])]
                 sweep += ctx.timings()['sweep'] / 4
                 r.release()
-            rr = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(lines), len(tx), stream).fetch()
+            rr = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(lines), len(tx), stream)
+            par = None
+            if check and not args.no_parity and not args.no_cpu_baseline:
+                par = leg_parity(model, rr, len(lines), tx, offs, check, [5, 6, 1, 5], np, torch, dev,
+                                 os.path.join(cache, 'parity_tmp'), max(len(l) for l in lines))
+            rr = rr.fetch()
             out = {'sentences_per_s': round(len(lines) / sorted(steps)[2], 1), 'sweep_ms': round(sweep, 3),
                    'sweep_ms_by_class_64_512_any': [round(x, 3) for x in ms], 'sentences_by_class': cls,
                    'nodes_per_sentence': round(float(rr.nnodes.sum()) / len(lines), 1),
                    'failed_sentences_in_batch': int((rr.status != 0).sum())}
             rr.release()
+            if par is not None:
+                out['parity_sample'] = par
             return out
         lines_all = open(corpus_all, 'rb').read().split(b'\n')[:args.batch]
         lines_narrow = open(corpus_narrow, 'rb').read().split(b'\n')[:args.batch]
         one_wide = list(lines_narrow)
         one_wide[len(one_wide) // 2] = ''.join(wide).encode('utf-8')[:3 * args.sent_len]
         return {'dictionary': '%d entries, --homographs 60 (max %d entries on one surface)' % (a.dict_entries, max(counts.values())),
-                'ordinary_text': measure(lines_all), 'narrow_text': measure(lines_narrow),
-                'narrow_text_plus_one_wide_sentence': measure(one_wide)}
+                'ordinary_text': measure(lines_all, 8192), 'narrow_text': measure(lines_narrow),
+                'narrow_text_plus_one_wide_sentence': measure(one_wide, len(one_wide) // 2 + 64)}
     except Exception as e:  # an extra leg must never take the main line down
         return {'error': str(e)[:300]}
 
@@ -755,7 +793,12 @@ def config5_leg(args, cache, local_rank, np, torch, J):
                 km[kk] = km.get(kk, 0.0) + v / k
             r.release()
         el = time.perf_counter() - t0
-        r = run(0).fetch()
+        r = run(0)
+        par = None
+        if not args.no_parity and not args.no_cpu_baseline:
+            par = leg_parity(model, r, batch, batches[0][0], batches[0][1], 2048, [32, 32, 1, 32], np, torch, dev,
+                             os.path.join(cache, 'parity_tmp'), 220)
+        r = r.fetch()
         nodes = float(r.nnodes.sum())
         bad = int((r.status != 0).sum())
         r.release()
@@ -774,20 +817,23 @@ def config5_leg(args, cache, local_rank, np, torch, J):
                 'kernel_ms_per_step': {kk: round(v, 3) for kk, v in km.items()},
                 'roofline': {'bound': 'hbm', 'kernel': 'k_sweep<32,*>', 'achieved': round(ach, 2), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(ach / 8000.0, 5), 'algorithmic_bytes_per_launch': int(sweep_bytes),
-                             'avg_launch_ms': round(km['sweep'], 3)}}
+                             'avg_launch_ms': round(km['sweep'], 3)},
+                'parity_sample': par}
     except Exception as e:  # an extra leg must never take the main line down
         return {'error': str(e)[:200]}
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=16)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=65536)
     ap.add_argument('--sent-len', type=int, default=40)
-    ap.add_argument('--dict-entries', type=int, default=300000)
-    ap.add_argument('--weights-exp', type=int, default=22)
+    ap.add_argument('--dict-entries', type=int, default=1000000,
+                    help='rows of the synthetic jumandic-layout dictionary (SURVEY 8(d): 5e5..1e6; 300000 = the headline of rounds 1-3, now the realism leg dict_300k_weights_2e22)')
+    ap.add_argument('--weights-exp', type=int, default=24,
+                    help='log2 of the perceptron table (24 = 64 MB: beyond the aggregate L2; 22 until round 3)')
     ap.add_argument('--seed', type=int, default=20260925)
     ap.add_argument('--cpu-sample', type=int, default=20000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -810,7 +856,11 @@ def main():
     ap.add_argument('--rnn-hidden', type=int, default=128)
     ap.add_argument('--rnn-vocab', type=int, default=30000)
     ap.add_argument('--cache', default=os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache'))
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
 
     import numpy as np
     import torch
@@ -902,7 +952,7 @@ def main():
         r_front = r
         # self-certification of the line (untimed; the reference is the checker, never the thing measured)
         parity = None
-        if not args.no_cpu_baseline and not args.no_parity and world == 1:
+        if not args.no_cpu_baseline and not args.no_parity:   # (world > 1: rank 0 certifies its own shard)
             try:
                 def run_packed(i):
                     rr = step(i)
@@ -930,7 +980,7 @@ def main():
         try:
             tp = json.load(open(args.traffic_profile))
             if (tp.get('batch') == args.batch and tp.get('rnn') == bool(args.rnn) and tp.get('sent_len') == args.sent_len
-                    and tp.get('dict_entries') == args.dict_entries and world == 1):
+                    and tp.get('dict_entries') == args.dict_entries and tp.get('weights_exp', 22) == args.weights_exp):
                 if tp.get('kernel_source_id') != src_id:
                     traffic_note = ('profiles/traffic.json was collected with other kernel sources (%s, running %s): not reported'
                                     % (tp.get('kernel_source_id'), src_id))
@@ -1105,7 +1155,7 @@ def main():
             out['realism'] = realism_legs(args, cache, local_rank, np, torch, J)
         if not args.no_trainer and world == 1:
             out['trainer'] = trainer_leg(args, mdic, cache, ge)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:   # rank 0 only, at every world size (the other ranks wait at the final barrier)
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if dist is not None:

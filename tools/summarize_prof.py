@@ -2,7 +2,7 @@
 """Condense rocprofv3 rocpd databases (kernel trace + PMC passes) into a small
 text summary that is committed under profiles/, plus traffic.json (HBM bytes per
 launch and kernel) that bench.py reports as roofline.traffic.
-usage: summarize_prof.py <dir with prof_trace/ prof_fetch/ prof_write/> [batch sent_len dict_entries rnn]"""
+usage: summarize_prof.py <dir with prof_trace/ prof_fetch/ prof_write/> [the bench.py arguments of the profiled command]"""
 import glob
 import json
 import re
@@ -36,7 +36,7 @@ def main():
                     e = per_kernel.setdefault(m.group(1), {'FETCH_SIZE_KB': 0.0, 'WRITE_SIZE_KB': 0.0})
                     # template variants of one kernel (k_seeds<0/1/2>...) add up: they run once per batch each
                     e[cn + '_KB'] = e.get(cn + '_KB', 0.0) + v
-    if per_kernel and len(sys.argv) >= 6:
+    if per_kernel:
         for e in per_kernel.values():
             # FETCH_SIZE/WRITE_SIZE are in KB; gfx950 tallies 128-B read requests at 64 B (MI355X_MICROARCH.md,
             # HBM section), so the fetch side is doubled; narrow requests are then over-estimated, i.e. this is an
@@ -44,8 +44,9 @@ def main():
             e['hbm_bytes_per_launch'] = int(2 * e['FETCH_SIZE_KB'] * 1024 + e['WRITE_SIZE_KB'] * 1024)
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
         import bench
-        tj = {'batch': int(sys.argv[2]), 'sent_len': int(sys.argv[3]), 'dict_entries': int(sys.argv[4]),
-              'rnn': sys.argv[5] == '1', 'kernels': per_kernel, 'kernel_source_id': bench.kernel_source_id(),
+        a = bench.build_parser().parse_known_args(sys.argv[2:])[0]   # the workload the passes ran (bench.py's defaults otherwise)
+        tj = {'batch': a.batch, 'sent_len': a.sent_len, 'dict_entries': a.dict_entries, 'weights_exp': a.weights_exp,
+              'rnn': bool(a.rnn), 'kernels': per_kernel, 'kernel_source_id': bench.kernel_source_id(),
               'note': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python bench.py`, '
                       'avg per launch; bytes = 2 x FETCH_SIZE KB (gfx950 tallies a 128-B request at 64 B; calibrated for streaming reads by the guide and for random 4-byte gathers by tools/micro/gather_calib.hip, profiles/r02_f_gather_calib.txt) + WRITE_SIZE KB'}
         with open(os.path.join(out, 'traffic.json'), 'w') as f:
