@@ -132,7 +132,8 @@ def algorithmic_bytes(res, cfg_beam, cfg_gbeam, rcheck, rbeam, np):
              + (K * Gs + (Rs - K) * c) * 4)             # score cells written
     # gathers actually issued: the bigram weights of (kept right node, T1 row 0) serve prescore and tail
     issued = sweep - 4 * K * 37 * (c > 0)
-    return dict(t0=int(t0_bytes), sweep=int(sweep.sum()), sweep_issued=int(issued.sum()), nodes=N)
+    gathers = c * Rs * 41 + K * (U * 37 + np.maximum(Gs - c, 0) * 4) - K * 37 * (c > 0)
+    return dict(t0=int(t0_bytes), sweep=int(sweep.sum()), sweep_issued=int(issued.sum()), nodes=N, sweep_gathers=int(gathers.sum()))
 
 
 def kernel_source_id():
@@ -356,6 +357,55 @@ def parity_sample(ref_dir, model, batches, run_packed, np, tmp_dir, n_batches=2)
             'what': 'packed top-1 result (EntryPtr incl. UNK numbering, start, end per morpheme) of the first %d timed '
                     'batches, bench path (analyze_device + jppgpu_result_pack), vs the reference Analyzer::analyze '
                     '(oracle/_ref ref_dump top1, %d processes); %.1f s' % (min(n_batches, len(batches)), usable_cores(), time.time() - t)}
+
+
+# measured ceilings of the chip this bench runs on (profiles/r04_b_gather_policy.txt, r04_c_gather_policy.txt: random 4-byte
+# gathers from 64 MB .. 1 GB tables, every cache policy and allocation flavour): an L2 miss is ONE 128-byte request to the
+# fabric (TCC_EA0_RDREQ_128B == TCC_MISS), and the chip serves 59-63 G of them per second = 7.5-8.1 TB/s
+GATHER_MISS_PEAK = 63.0e9      # lines/s, 64 MB table (the headline's weight table)
+SCLK_HZ = 2.4e9                # MI355X peak engine clock; SIMD-cycles available = duration x SCLK x 1024 SIMDs
+F32_MFMA_PEAK = 157.3e12       # dense f32 MFMA, MI355X_MICROARCH.md
+
+
+def load_profile(path, args, src_id):
+    """a committed counter profile (traffic.json / counters.json) -- only if it was collected on THIS workload with THESE
+    kernel sources; otherwise (None, why)"""
+    try:
+        tp = json.load(open(path))
+    except (OSError, ValueError):
+        return None, 'no profile at %s' % os.path.relpath(path, ROOT)
+    same = (tp.get('batch') == args.batch and tp.get('rnn') == bool(args.rnn) and tp.get('sent_len') == args.sent_len
+            and tp.get('dict_entries') == args.dict_entries and tp.get('weights_exp', 22) == args.weights_exp)
+    if not same:
+        return None, '%s was collected on another workload' % os.path.basename(path)
+    if tp.get('kernel_source_id') != src_id:
+        return None, ('%s was collected with other kernel sources (%s, running %s): not reported'
+                      % (os.path.basename(path), tp.get('kernel_source_id'), src_id))
+    return tp, tp.get('note')
+
+
+def valu_roofline(counters, kernel_prefix, launch_ms, gathers):
+    """the vector-ALU yard-stick of a kernel that is not a stream.  achieved = wave-instructions x 4
+    cycles (SQ_INSTS_VALU; the quarter-rate share -- 32-bit multiplies of the hash -- is not counted separately by the
+    hardware and is left out, so this is a LOWER bound of the busy cycles), peak = SIMD-cycles of the launch."""
+    ent = None
+    for k, v in counters.items():
+        if k.startswith(kernel_prefix) and 'SQ_INSTS_VALU' in v and (ent is None or v['SQ_INSTS_VALU'] > ent['SQ_INSTS_VALU']):
+            ent, name = v, k
+    if ent is None:
+        return None
+    insts = ent['SQ_INSTS_VALU']
+    peak = launch_ms * 1e-3 * SCLK_HZ * 1024
+    lanes = ent.get('SQ_THREAD_CYCLES_VALU', 0.0) / max(1.0, ent.get('SQ_ACTIVE_INST_VALU', insts))
+    out = {'bound': 'valu', 'kernel': name, 'achieved': round(insts * 4 / 1e9, 3), 'peak': round(peak / 1e9, 3),
+           'unit': 'G SIMD-cycles per launch', 'frac': round(insts * 4 / peak, 4),
+           'wave_instructions_valu': int(insts), 'wave_instructions_salu': int(ent.get('SQ_INSTS_SALU', 0)),
+           'active_lanes_per_valu_instruction': round(lanes, 1),
+           'what': 'SQ_INSTS_VALU x 4 cycles / (launch duration x %.1f GHz x 1024 SIMDs); quarter-rate multiplies counted '
+                   'as full-rate (lower bound)' % (SCLK_HZ / 1e9)}
+    if gathers:
+        out['lane_instructions_per_gathered_weight'] = round(insts * lanes / gathers, 1)
+    return out
 
 
 def leg_parity(model, result, n_batch, text, offs, n_check, beams, np, torch, dev, tmp_dir, max_len):
@@ -853,6 +903,8 @@ def build_parser():
     ap.add_argument('--no-rnn', dest='rnn', action='store_false', help='BASELINE configs[1]: perceptron only')
     ap.add_argument('--traffic-profile', default=os.path.join(ROOT, 'profiles', 'traffic.json'),
                     help='per-kernel HBM bytes per launch from the committed rocprofv3 --pmc passes of this command')
+    ap.add_argument('--counters-profile', default=os.path.join(ROOT, 'profiles', 'counters.json'),
+                    help='per-kernel SQ counters per launch from the committed rocprofv3 --pmc passes (tools/gpu_session.sh valu)')
     ap.add_argument('--rnn-hidden', type=int, default=128)
     ap.add_argument('--rnn-vocab', type=int, default=30000)
     ap.add_argument('--cache', default=os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache'))
@@ -977,20 +1029,48 @@ def main():
         # collected with the kernel sources that are running now
         traffic, traffic_note = None, None
         src_id = kernel_source_id()
-        try:
-            tp = json.load(open(args.traffic_profile))
-            if (tp.get('batch') == args.batch and tp.get('rnn') == bool(args.rnn) and tp.get('sent_len') == args.sent_len
-                    and tp.get('dict_entries') == args.dict_entries and tp.get('weights_exp', 22) == args.weights_exp):
-                if tp.get('kernel_source_id') != src_id:
-                    traffic_note = ('profiles/traffic.json was collected with other kernel sources (%s, running %s): not reported'
-                                    % (tp.get('kernel_source_id'), src_id))
-                else:
-                    ent = tp['kernels'].get('k_' + dom)
-                    if ent:
-                        traffic = ent['hbm_bytes_per_launch']
-                        traffic_note = tp.get('note')
-        except (OSError, ValueError, KeyError):
-            pass
+        tp, traffic_note = load_profile(args.traffic_profile, args, src_id)
+        if tp is not None:
+            ent = tp['kernels'].get('k_' + dom) or tp['kernels'].get('k_' + dom + '_memo')
+            if ent:
+                traffic = ent['hbm_bytes_per_launch']
+        else:
+            tp = {}
+        # what actually bounds k_sweep on this workload: the rate of L2 MISSES (every one a 128-byte request to the fabric)
+        gather_roof = None
+        ent = tp.get('kernels', {}).get('k_sweep')
+        if ent and avg['sweep'] > 0:
+            lines = 2 * ent['FETCH_SIZE_KB'] * 1024 / 128.0
+            rate = lines / (avg['sweep'] * 1e-3)
+            gather_roof = {'bound': 'l2-miss', 'kernel': 'k_sweep', 'achieved': round(rate / 1e9, 2), 'peak': GATHER_MISS_PEAK / 1e9,
+                           'unit': 'G 128-byte lines/s', 'frac': round(rate / GATHER_MISS_PEAK, 4), 'lines_per_launch': int(lines),
+                           'read_bytes_per_launch': int(lines * 128), 'read_tb_per_s': round(lines * 128 / (avg['sweep'] * 1e-3) / 1e12, 2),
+                           'what': 'L2 misses of the launch (FETCH_SIZE: TCC_EA0_RDREQ, all of them 128-byte requests) / launch time; '
+                                   'peak = the chip\'s measured rate of random 4-byte gather misses from a 64 MB table, '
+                                   'profiles/r04_c_gather_policy.txt (no cache policy or allocation flavour changes it)'}
+        cp, counters_note = load_profile(args.counters_profile, args, src_id)
+        valu_roof = valu_roofline(cp['kernels'], 'k_sweep<8, 64', avg['sweep'], ab.get('sweep_gathers')) if cp else None
+        if valu_roof is None:
+            valu_roof = {'note': counters_note}
+        # RNN block: bytes by SURVEY 8(d) (n_rnn (2 E 4 + 12) embedding rows and ids + n_ctx E 4 x 2 hidden states written and
+        # read), flops of the recurrence (2 E^2 per rnn node) against the dense f32 MFMA peak for k_rnn_chain alone
+        rnn_roof = None
+        if args.rnn and avg.get('rnn', 0) > 0:
+            st = ctx.rnn_stats()
+            n_rnn = max(0, st['rows'] - 2 * args.batch)
+            E = args.rnn_hidden
+            rbytes = n_rnn * (2 * E * 4 + 12) + n_rnn * E * 4 * 2
+            rnn_roof = {'bound': 'hbm', 'kernels': 'k_rnn_paths + k_rnn_prep + k_rnn_order_* + k_rnn_chain + k_rnn_score',
+                        'achieved': round(rbytes / (avg['rnn'] * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': round(rbytes / (avg['rnn'] * 1e-3) / 1e9 / 8000.0, 5), 'algorithmic_bytes_per_step': int(rbytes),
+                        'ms_per_step': round(avg['rnn'], 3), 'rnn_nodes_per_sentence': round(n_rnn / args.batch, 2)}
+            if st['chain_ms'] > 0:
+                fl = n_rnn * 2.0 * E * E
+                rnn_roof['chain_mfma'] = {'bound': 'mfma', 'kernel': 'k_rnn_chain', 'achieved': round(fl / (st['chain_ms'] * 1e-3) / 1e12, 2),
+                                          'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                                          'frac': round(fl / (st['chain_ms'] * 1e-3) / F32_MFMA_PEAK, 4), 'ms': round(st['chain_ms'], 3),
+                                          'what': 'v_mfma_f32_16x16x4_f32, 2 E^2 flops per rnn node; 16 of the 16 columns of a tile are '
+                                                  'sentences in lock step'}
         # the contract's byte count charges the 37 bigram gathers of (kept right node, T1 row 0) twice, as the reference
         # performs them (prescore + tail); the kernel gathers them once and forms both sums from them
         issued = ab.get('sweep_issued', ab['sweep'])
@@ -1134,6 +1214,9 @@ def main():
                 'algorithmic_bytes_gathers_issued': issued if dom == 'sweep' else None,
             },
             'roofline_front': front,
+            'roofline_gather': gather_roof,
+            'roofline_valu': valu_roof,
+            'roofline_rnn': rnn_roof,
         }
         if parity is not None:
             out['parity_sample'] = parity

@@ -392,7 +392,9 @@ void jppgpu_result_release(jppgpu_result* res);
 /* device timing of the last batch's kernels in milliseconds (HIP events on the launch stream):
  * [0] decode [1] seeds [2] layout [3] t0 [4] sweep [5] rnn [6] path, [7] whole pipeline; and, for n > 8, the sweep by
  * sentence class (every sentence runs the kernel variant of its own widest boundary): [8] [9] [10] ms of the variants
- * for at most 64 / at most 512 / any number of nodes starting at one boundary, [11] [12] [13] sentences in each class */
+ * for at most 64 / at most 512 / any number of nodes starting at one boundary, [11] [12] [13] sentences in each class,
+ * [14] rows of the RNN hidden-state table of the batch (rnn nodes + 2 per sentence; 0 without the RNN), [15] ms of
+ * k_rnn_chain alone (0 when it did not run) */
 int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n);
 
 #ifdef __cplusplus

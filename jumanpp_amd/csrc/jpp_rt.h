@@ -251,6 +251,19 @@ __device__ __forceinline__ float row_shl_f32(float v) {
 #endif
 }
 
+// A value that IS the same in every lane (a boundary record read from LDS at a uniform address, a count derived from
+// one), moved to a scalar register: loops over it become scalar loops (s_cmp / s_cbranch instead of an exec-mask
+// dance per iteration), comparisons take an SGPR operand, address arithmetic goes to the scalar unit and the VGPR is
+// free.  The caller guarantees the uniformity; the emulator returns the value as it is.
+__device__ __forceinline__ u32 uni(u32 v) {
+#if defined(JPP_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+  return v;
+#else
+  return (u32)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+__device__ __forceinline__ int uni(int v) { return (int)uni((u32)v); }
+
 // broadcast lane `src` (wave-uniform) of v to every lane: v_readlane_b32
 __device__ __forceinline__ float wave_bcast_f32(float v, int src) {
 #if defined(JPP_EMU)

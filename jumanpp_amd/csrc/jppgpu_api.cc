@@ -77,7 +77,7 @@ struct Timer {
   void destroy() {}
   void mark(int, jpp_stream_t) {}
   void collect(float* ms) {
-    for (int i = 0; i < 11; ++i) ms[i] = 0;
+    for (int i = 0; i < 12; ++i) ms[i] = 0;
   }
 };
 #else
@@ -164,8 +164,9 @@ void rt_host_free(void* p) {
   free(p);
 }
 struct Timer {
-  hipEvent_t ev[13];
+  hipEvent_t ev[15];
   bool have = false;
+  bool chain = false;   // ev[13] .. ev[14] bracket k_rnn_chain (recorded only when it ran)
   void init() {
     for (auto& e : ev) (void)hipEventCreate(&e);
     have = true;
@@ -183,6 +184,8 @@ struct Timer {
       std::fprintf(stderr, "[jppgpu] phase mark %d reached: %s\n", i, hipGetErrorString(e));
     }
     (void)hipEventRecord(ev[i], s);
+    if (i == 14) chain = true;
+    if (i == 0) chain = false;
   }
   void collect(float* ms) {
     // ev[0]..ev[7] bracket the seven phases
@@ -199,6 +202,8 @@ struct Timer {
       ms[8 + i] = 0;
       (void)hipEventElapsedTime(&ms[8 + i], ev[from[i]], ev[to[i]]);
     }
+    ms[11] = 0;
+    if (chain) (void)hipEventElapsedTime(&ms[11], ev[13], ev[14]);
   }
 };
 #endif
@@ -394,7 +399,8 @@ struct jppgpu_ctx {
   u64 generation = 0;
   Timer timer;
   SyncPoint rnn_sync;
-  float last_ms[11] = {0};
+  float last_ms[12] = {0};   // [11] = k_rnn_chain
+  u64 last_rnn_rows = 0;     // hidden-state rows of the last batch (rnn nodes + 2 per sentence)
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
   std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>();
@@ -1518,18 +1524,23 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
     ctx->rnn_sync.wait(st);
+    ctx->last_rnn_rows = rnnRows;
     if (!ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
     B.rnn_ctx = ctx->rnn_ctx.as<float>();
     const u32 slowGrid = (n + 15) / 16 < 512u ? (n + 15) / 16 : 512u;   // k_rnn_score<.., 3> (16 sentences per workgroup) loops over its list
     if (ctx->hmodel.rnn_EP == 64) {
+      T.mark(13, st);
       JPP_LAUNCH((k_rnn_chain<1>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
+      T.mark(14, st);
       if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<1, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<1, false, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
     } else if (ctx->hmodel.rnn_EP == 128) {
+      T.mark(13, st);
       JPP_LAUNCH((k_rnn_chain<2>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
+      T.mark(14, st);
       if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<2, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
@@ -1648,6 +1659,8 @@ extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
   }
   for (int i = 0; i < n && i < 11; ++i) ms[i] = ctx->last_ms[i];
   for (int i = 11; i < n && i < 14; ++i) ms[i] = (float)ctx->last_class_n[i - 11];
+  if (n > 14) ms[14] = (float)ctx->last_rnn_rows;
+  if (n > 15) ms[15] = ctx->last_ms[11];
   return JPPGPU_OK;
 }
 

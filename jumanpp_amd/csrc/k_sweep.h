@@ -519,6 +519,15 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   JPP_PROF_DECL;
   BndMeta mbn{0, 0, 0, 0};
   u32 bn = next_nonempty(2, mbn);
+  // (records and everything counted from them are wave-uniform: keep them in scalar registers, see uni())
+  auto uni_meta = [](BndMeta& m) {
+    m.first = uni(m.first);
+    m.cnt = uni(m.cnt);
+    m.efirst = uni(m.efirst);
+    m.ecnt = uni(m.ecnt);
+  };
+  bn = uni(bn);
+  uni_meta(mbn);
   int par = 0;
   prefetch(bn, mbn, par);
   if constexpr (kOneRow) prefetch_rows(bn, mbn, 0);
@@ -560,7 +569,8 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
       lds_async_load<16>(&meta[0], gmeta + lo + c0 + lane, (u32)lane < cntAll - c0);
       metaEnd = hi;
     }
-    bn = next_nonempty(b + 1, mbn);
+    bn = uni(next_nonempty(b + 1, mbn));
+    uni_meta(mbn);
     prefetch(bn, mbn, par ^ 1);
     const u32* enL = enn[par];  // ends list of this boundary (first 64 entries)
     u64(*const pR)[kPat] = pRbuf(par);
@@ -653,6 +663,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
       }
     }
     wave_sync();
+    ngb = uni(ngb);
     if (lane < ngb) {
       u64 key = gb_key[lane];
       u32 l = (u32)(key >> 16) & 0xffff, k = (u32)key & 0xffff;
@@ -720,32 +731,42 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
     // T2 branch this was two divergent halves per iteration, each waiting for its own HBM/L2 round trip (three to
     // four serial round trips per boundary instead of one).
     {
-      constexpr int kRowIter = 3;   // elements per lane in flight together (GM = 8: at most 144 elements in all)
-      const int nT1 = U * kPat, total = nT1 + ngb * kT2;
-      for (int q0 = 0; q0 < total; q0 += 64 * kRowIter) {
+      // Row elements by SLOT, a slot = one load per lane: a T1 slot covers four rows with 16 lanes each (kPat = 14 of them
+      // busy), a T2 slot 64 / kT2w rows with kT2w lanes each -- the (row, field) of a lane is a shift and a mask.  (Until
+      // round 3 the elements were numbered consecutively: two divisions by 14 and by 4 per element and load, a tenth of the
+      // boundary's vector instructions.)  Up to kRowIter slots are in flight together.
+      constexpr int kRowIter = 3;                 // GM = 8: two T1 slots + one T2 slot = one round
+      constexpr int kT2w = kT2 <= 4 ? 4 : 16;     // lanes per T2 row
+      constexpr int kT2rows = 64 / kT2w;          // T2 rows per slot
+      static_assert(kPat <= 16 && kT2 <= kT2w, "a row fits its lane group");
+      const int nT1s = (U + 3) >> 2;
+      const int nSlots = nT1s + (ngb + kT2rows - 1) / kT2rows;
+      for (int s0 = 0; s0 < nSlots; s0 += kRowIter) {
         u64 v[kRowIter];
 #pragma unroll
         for (int z = 0; z < kRowIter; ++z) {
-          // (lanes beyond the last element read element 0 again: a load behind a branch would make the compiler
-          // wait for the previous one before it, see k_rnn_chain)
-          const int q = (q0 + z * 64 + lane) < total ? (q0 + z * 64 + lane) : 0;
-          const bool isT1 = q < nT1;
-          const int qq = isT1 ? q : q - nT1;
-          const int row = isT1 ? qq / kPat : qq / kT2;
-          const int pp = qq - row * (isT1 ? kPat : kT2);
-          const u32 node = isT1 ? t1node[row] : gb_pnode[row];
-          v[z] = pats[(u64)node * kPat + pp];
+          const int sl = s0 + z;
+          const bool isT1 = sl < nT1s;
+          const int row = isT1 ? sl * 4 + (lane >> 4) : (sl - nT1s) * kT2rows + lane / kT2w;
+          const int pp = isT1 ? (lane & 15) : (lane & (kT2w - 1));
+          const bool ok = sl < nSlots && (isT1 ? (row < U && pp < kPat) : (row < ngb && pp < kT2));
+          // (lanes without an element read element 0 again: a load behind a branch would make the compiler wait for the
+          // previous one before it, see k_rnn_chain)
+          const u32 node = ok ? (isT1 ? t1node[row] : gb_pnode[row]) : t1node[0];
+          v[z] = pats[(u64)node * kPat + (ok ? pp : 0)];
         }
 #pragma unroll
         for (int z = 0; z < kRowIter; ++z) {
-          const int q = q0 + z * 64 + lane;
-          if (q < total) {
-            const bool isT1 = q < nT1;
-            const int qq = isT1 ? q : q - nT1;
-            const int row = isT1 ? qq / kPat : qq / kT2;
-            const int pp = qq - row * (isT1 ? kPat : kT2);
-            if (isT1) t1pat[row][pp] = v[z];
-            else t2pat[row][pp] = v[z];
+          const int sl = s0 + z;
+          const bool isT1 = sl < nT1s;
+          const int row = isT1 ? sl * 4 + (lane >> 4) : (sl - nT1s) * kT2rows + lane / kT2w;
+          const int pp = isT1 ? (lane & 15) : (lane & (kT2w - 1));
+          if (sl < nSlots) {
+            if (isT1) {
+              if (row < U && pp < kPat) t1pat[row][pp] = v[z];
+            } else {
+              if (row < ngb && pp < kT2) t2pat[row][pp] = v[z];
+            }
           }
         }
       }

@@ -426,6 +426,12 @@ class Context:
         names = ['decode', 'seeds', 'layout', 't0', 'sweep', 'rnn', 'path', 'total']
         return dict(zip(names, list(ms)[:8]))
 
+    def rnn_stats(self):
+        """rows of the RNN hidden-state table of the last batch (rnn nodes + 2 per sentence) and ms of k_rnn_chain"""
+        ms = (C.c_float * 16)()
+        self.lib.jppgpu_last_timings(self.handle, ms, 16)
+        return {'rows': int(ms[14]), 'chain_ms': float(ms[15])}
+
     def sweep_classes(self):
         """the sweep phase of the last batch by sentence class: ms and sentences of the variants staging 64 / 512 / any
         number of right nodes per boundary"""

@@ -67,10 +67,12 @@ for step in "$@"; do
         i=$((i+1)); rm -rf "$OUT/pmc_$i"
         timeout 400 rocprofv3 --pmc $grp -d "$OUT/pmc_$i" -o pmc -- python "$REPO/bench.py" --steps 2 --warmup 1 $LEAN --no-parity $BA > "$OUT/pmc_$i.log" 2>&1 || echo "pmc group $i failed: $grp"
       done
-      python - "$OUT" > "$OUT/${TAG}_pmc_summary.txt" 2>&1 <<'PY'
-import glob, os, sqlite3, sys
+      python - "$OUT" "$REPO" $BA > "$OUT/${TAG}_pmc_summary.txt" 2>&1 <<'PY'
+import glob, json, os, re, sqlite3, sys
+out, repo = sys.argv[1], sys.argv[2]
 print('== rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1` (one pass per counter group): kernel, counter, dispatches, avg per launch')
-for db in sorted(glob.glob(os.path.join(sys.argv[1], 'pmc_*', '**', '*.db'), recursive=True)):
+per = {}
+for db in sorted(glob.glob(os.path.join(out, 'pmc_*', '**', '*.db'), recursive=True)):
     con = sqlite3.connect(db)
     q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
          "where kernel_name like '%k_sweep%' or kernel_name like '%k_rnn%' or kernel_name like '%k_t0%' or kernel_name like '%k_seeds%' "
@@ -78,8 +80,19 @@ for db in sorted(glob.glob(os.path.join(sys.argv[1], 'pmc_*', '**', '*.db'), rec
     try:
         for kn, cn, n, v in con.execute(q):
             print('%-64s %-30s n=%d avg=%.6g' % (kn[:64], cn, n, v))
+            m = re.search(r'(k_[a-z0-9_]+(<[^>]*>)?)', kn)
+            if m:
+                per.setdefault(m.group(1), {})[cn] = v
     except Exception as e:
         print('db', db, 'error', e)
+# counters.json: what bench.py's roofline_valu reads (profiles/counters.json), stamped like traffic.json
+sys.path.insert(0, repo)
+import bench
+a = bench.build_parser().parse_known_args(sys.argv[3:])[0]
+json.dump({'batch': a.batch, 'sent_len': a.sent_len, 'dict_entries': a.dict_entries, 'weights_exp': a.weights_exp, 'rnn': bool(a.rnn),
+           'kernel_source_id': bench.kernel_source_id(), 'kernels': per,
+           'note': 'rocprofv3 --pmc, one pass per counter group, of `python bench.py --steps 2 --warmup 1` (lean legs); avg per launch'},
+          open(os.path.join(out, 'counters.json'), 'w'), indent=1, sort_keys=True)
 PY
       grep "k_sweep" "$OUT/${TAG}_pmc_summary.txt" | head -40
       for j in 1 2 3 4; do rm -rf "$OUT/pmc_$j"; done ;;

@@ -16,8 +16,9 @@ import jumanpp_amd as J
 
 lib_path = os.path.join(ROOT, 'build', 'libjppgpu_prof.so')
 C5 = '--config5' in sys.argv   # BASELINE configs[4] shape: beam 32, 220-codepoint sentences, 4096 per batch
-args = argparse.Namespace(dict_entries=300000, weights_exp=22, seed=20260925, sent_len=220 if C5 else 40,
-                          batch=4096 if C5 else 65536, rnn=True, rnn_hidden=128, rnn_vocab=30000)
+args = bench.build_parser().parse_args([])   # bench.py's default workload
+if C5:
+    args.sent_len, args.batch = 220, 4096
 cache = os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache')
 mdic, model, img = bench.make_workload(args, cache)
 corpus = bench.make_corpus(args, mdic, cache, args.batch * 2, 31 if C5 else args.seed + 1)

@@ -66,24 +66,25 @@ int run(const char* name, const float* tab, uint64_t n, int k, float* out) {
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* out;
   CK(hipMalloc(&out, 64));
-  const int ks[] = {20, 24, 26, 28};
-  for (int k : ks) {
-    const uint64_t n = 1ull << k;
-    float* tab;
-    CK(hipMalloc(&tab, n * 4));
-    CK(hipMemset(tab, 0, n * 4));
-    run<0>("plain", tab, n, k, out);
-    run<1>("nt", tab, n, k, out);
-    run<2>("sc1", tab, n, k, out);
-    run<3>("sc0 sc1", tab, n, k, out);
-    run<4>("sc0 sc1 nt", tab, n, k, out);
-    run<5>("sc0", tab, n, k, out);
-    run<6>("sc0 nt", tab, n, k, out);
-    run<7>("sc1 nt", tab, n, k, out);
-    CK(hipFree(tab));
+  // allocation flavours: 0 = hipMalloc (cached in L2), 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained
+  const int ks[] = {24, 26};
+  for (int flavour = 0; flavour < 3; ++flavour) {
+    for (int k : ks) {
+      const uint64_t n = 1ull << k;
+      float* tab = nullptr;
+      if (flavour == 0) CK(hipMalloc(&tab, n * 4));
+      if (flavour == 1) CK(hipExtMallocWithFlags((void**)&tab, n * 4, hipDeviceMallocUncached));
+      if (flavour == 2) CK(hipExtMallocWithFlags((void**)&tab, n * 4, hipDeviceMallocFinegrained));
+      CK(hipMemset(tab, 0, n * 4));
+      printf("-- allocation: %s\n", flavour == 0 ? "hipMalloc" : flavour == 1 ? "hipDeviceMallocUncached" : "hipDeviceMallocFinegrained");
+      run<0>("plain", tab, n, k, out);
+      run<1>("nt", tab, n, k, out);
+      run<3>("sc0 sc1", tab, n, k, out);
+      CK(hipFree(tab));
+    }
   }
   return 0;
 }
