@@ -331,6 +331,76 @@ int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void*
  * side -- further fetches, jppgpu_result_pack -- is invalidated by the next batch). */
 int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_view* view);
 
+/* ---- output text on the device (replaces OutputFormat::format for the top-1 formats) ----------------------
+ * The reference formats one sentence at a time on the host: JumanFormat::format walks the top-1 path, and for every node
+ * prints strings of the dictionary entry (src/jumandic/shared/juman_format.cc:94-168, src/core/analysis/output.cc:65-130).
+ * What it prints for a DICTIONARY node is a function of the entry alone, and for an UNK node the same text with the
+ * surface-bearing fields replaced by the node's input bytes and a flag feature appended.  The host layer therefore
+ * renders every entry row ONCE per model into a table of text pieces (host/format_table.cc), the library keeps it in
+ * HBM, and two kernels per batch (k_fmt_count / k_fmt_write, csrc/k_format.h) assemble the text of all sentences; only
+ * bytes and one offset per sentence cross PCIe.  The library knows nothing of JUMAN: every literal comes from the table.
+ *
+ * One row = one output line of a node (an alias entry has several: rows after the first start with their own prefix,
+ * "@ " in JUMAN).  Its text lies in the blob exactly as a dictionary node prints it:
+ *     PRE S ' ' R ' ' B MID TAIL      TAIL = '"' FEAT '"' '\n'  (has_features)  or  "NIL" '\n'
+ * S, R, B are the three fields an UNK maker may replace by the input surface (jumandic: surface, reading, baseform);
+ * an UNK node prints  PRE S' ' ' R' ' ' B' MID '"' FEAT [sep flag_label flags] '"' '\n'  where X' is the escaped input
+ * surface when the node's maker replaces X, and the bracket appears when the node's flag placeholder is non-zero
+ * (JumanFormat: formatNormalizedFeature, juman_format.cc:57-92; sep = ' ' iff FEAT is not empty). */
+typedef struct {
+  uint32_t blob_off;       /* first byte of the row text in `blob` */
+  uint16_t len_pre, len_s, len_r, len_b;
+  uint16_t len_mid;        /* from the byte after B to the byte before TAIL */
+  uint16_t flags;          /* bit 0: has_features (TAIL is the quoted form), bit 1: last row of its entry */
+  uint32_t len_feat;       /* FEAT bytes (inside the quotes; 0 when TAIL is "NIL") */
+  uint32_t len_total;      /* whole row text incl. the newline */
+} jppgpu_format_row;       /* 24 bytes */
+
+typedef struct {
+  uint32_t struct_size;    /* sizeof(jppgpu_format_table) */
+  /* entry -> rows: slot = (EntryPtr raw >> 1) >> 3 (an entry row is at least 8 bytes long, so slots are unique);
+   * value 0 = no entry starts in that slot, otherwise 1 + index of the entry's first row */
+  const uint32_t* slot_first_row;
+  uint64_t n_slots;
+  const jppgpu_format_row* rows;
+  uint64_t n_rows;
+  const char* blob;
+  uint64_t blob_bytes;
+  /* per UNK maker (index as in jppgpu_model::unk_makers): bit 0 / 1 / 2 = S / R / B print the input surface */
+  uint8_t maker_replaces[16];
+  /* escapeForJumanOutput (juman_format.cc:42-54): an input surface of exactly one byte equal to escape_from[i] prints
+   * as escape_to[i][0 .. escape_len[i]) */
+  uint8_t n_escapes;
+  char escape_from[4];
+  uint8_t escape_len[4];
+  char escape_to[4][8];
+  /* flag feature of UNK nodes: placeholder index (0/1; < 0: none), label bytes, and per bit of the value one letter,
+   * printed in table order when (value & flag_mask[i]) != 0 */
+  int32_t flag_placeholder;
+  uint8_t flag_label_len;
+  char flag_label[32];
+  uint8_t n_flags;
+  uint32_t flag_mask[16];
+  char flag_char[16];
+  /* sentence frame: text after the last node ("EOS\n"), and the whole text of a sentence that failed ("# ERROR\nEOS\n") */
+  uint8_t eos_len, error_len;
+  char eos_text[16];
+  char error_text[32];
+} jppgpu_format_table;
+
+/* copies the table to the device (once per model and context); JPPGPU_NOT_IMPLEMENTED for sizes it cannot index */
+int jppgpu_ctx_set_format_table(jppgpu_ctx* ctx, const jppgpu_format_table* table);
+
+typedef struct {
+  uint32_t n_sentences;
+  const uint64_t* offsets;   /* [n + 1] byte offsets into text: sentence i is text[offsets[i] .. offsets[i + 1]) */
+  const char* text;          /* host copy, owned by the result (valid until jppgpu_result_release) */
+  const int32_t* status;     /* [n] JPPGPU_SENT_* */
+} jppgpu_text_view;
+/* the formatted top-1 analyses of the batch; needs jppgpu_ctx_set_format_table.  The device side of the result must
+ * still be valid (no later batch on the context). */
+int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* view);
+
 /* The n best analyses, as jumandic::output::LatticeFormat consumes them (LatticeFormatInfo::fillInfo,
  * src/jumandic/shared/lattice_format.cc:13-43; score lookup :129-141): for every EOS beam slot i < n_best
  * the connections of its path from the EOS side back to BOS, each with the beam slot, the node and UNK

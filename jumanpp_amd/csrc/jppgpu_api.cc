@@ -20,6 +20,7 @@
 #include "jpp_rt.h"
 #include "jpp_types.h"
 #include "k_decode.h"
+#include "k_format.h"
 #include "k_gold.h"
 #include "k_lattice.h"
 #include "k_rnn.h"
@@ -71,6 +72,7 @@ struct SyncPoint {
 jpp_stream_t rt_stream_create() { return nullptr; }
 void rt_stream_destroy(jpp_stream_t) {}
 void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
+void* rt_host_alloc_pinned(size_t n) { return malloc(n ? n : 1); }
 void rt_host_free(void* p) { free(p); }
 struct Timer {
   void init() {}
@@ -147,6 +149,18 @@ void* rt_host_alloc(size_t n) {
       g_pinned.insert(p);
       return p;
     }
+  }
+  return malloc(n ? n : 1);
+}
+// page-locked blocks for the formatted output text (150 MB per 65 536-sentence batch: pageable memory crosses PCIe at
+// ~8 GB/s through the runtime's staging buffer, pinned memory at the link rate); recycled through a HostPool of their
+// own, so a steady-state batch pins nothing
+void* rt_host_alloc_pinned(size_t n) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault) == hipSuccess && p) {
+    std::lock_guard<std::mutex> l(g_pinned_mu);
+    g_pinned.insert(p);
+    return p;
   }
   return malloc(n ? n : 1);
 }
@@ -252,6 +266,7 @@ struct HostPool {
     void* p;
     size_t cap;
   };
+  bool pinned = false;   // blocks come from rt_host_alloc_pinned
   std::vector<Block> free_blocks;
   Block take(size_t bytes) {
     int best = -1;
@@ -263,7 +278,7 @@ struct HostPool {
       return b;
     }
     size_t want = bytes + bytes / 8 + 256;
-    return Block{rt_host_alloc(want), want};
+    return Block{pinned ? rt_host_alloc_pinned(want) : rt_host_alloc(want), want};
   }
   void give(Block b) {
     if (b.p) free_blocks.push_back(b);
@@ -317,6 +332,7 @@ struct jppgpu_result {
   // declared first = destroyed last: a result released after its context keeps the pool alive until its
   // own blocks are back in it
   std::shared_ptr<HostPool> pool_ref;
+  std::shared_ptr<HostPool> text_pool_ref;
   jppgpu_ctx* ctx = nullptr;
   Batch B{};
   u64 generation = 0;
@@ -341,6 +357,11 @@ struct jppgpu_result {
   HostVec<u64> t1_base, t1_zero;
   HostVec<jppgpu_node> t1_nodes;
   HostVec<jppgpu_unk> t1_unk;
+  // jppgpu_result_format_top1
+  bool fm_have = false;
+  HostVec<i32> fm_status;
+  HostVec<u64> fm_off;
+  HostVec<char> fm_text;   // (page-locked: text_pool_ref)
   // jppgpu_result_fetch_nbest
   int nb_n = 0;
   HostVec<i32> nb_status;
@@ -404,6 +425,10 @@ struct jppgpu_ctx {
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
   std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>();
+  std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
+  // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
+  bool fmt_have = false;
+  DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table, fmt_len, fmt_cnt, fmt_off, fmt_text;
   bool timing_pending = false;
 };
 
@@ -421,6 +446,7 @@ void jppgpu_result::bind(HostPool* pool) {
   t1_zero.pool = pool; t1_nodes.pool = pool; t1_unk.pool = pool;
   ng_first.pool = pool; ng_nodes.pool = pool; ng_feat.pool = pool;
   gp_first.pool = pool; gp_nodes.pool = pool; gp_feat.pool = pool;
+  fm_status.pool = pool; fm_off.pool = pool;
   nb_status.pool = pool; nb_ncp.pool = pool; nb_nnodes.pool = pool; nb_first.pool = pool; nb_eos.pool = pool; nb_items.pool = pool;
 }
 
@@ -1036,7 +1062,8 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
-                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks};
+                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
+                    &ctx->fmt_slots, &ctx->fmt_rows, &ctx->fmt_blob, &ctx->fmt_table, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
@@ -1044,6 +1071,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   ctx->sweep_fork.destroy();
   ctx->sweep_join.destroy();
   ctx->host_pool->clear();
+  ctx->text_pool->clear();
   ctx->timer.destroy();
   ctx->rnn_sync.destroy();
   delete ctx;
@@ -1091,7 +1119,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   ctx->generation++;
   jppgpu_result* Rp = new jppgpu_result();
   Rp->pool_ref = ctx->host_pool;
+  Rp->text_pool_ref = ctx->text_pool;
   Rp->bind(ctx->host_pool.get());
+  Rp->fm_text.pool = ctx->text_pool.get();
   jppgpu_result& R = *Rp;
   R.ctx = ctx;
   R.generation = ctx->generation;
@@ -1708,6 +1738,90 @@ extern "C" int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_i
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
   JPP_LAUNCH(k_pack_write, sblocks, 256, st, B, (const u64*)ctx->pack_off.as<u64>(), static_cast<u32*>(d_offsets),
              static_cast<NodeInfo*>(d_items), (u64)cap_items);
+  return JPPGPU_OK;
+}
+
+// ---- output text on the device (k_format.h) -----------------------------------------------------------------------------
+extern "C" int jppgpu_ctx_set_format_table(jppgpu_ctx* ctx, const jppgpu_format_table* t) {
+  if (!ctx || !t) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (t->struct_size != sizeof(jppgpu_format_table))
+    return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_format_table::struct_size is not the size this library was built with");
+  if (!t->slot_first_row || !t->rows || !t->blob || t->n_rows == 0)
+    return fail(JPPGPU_INVALID_PARAMETER, "format table: empty");
+  if (t->n_rows >= 0xffffffffull || t->blob_bytes >= 0xffffffffull || t->n_slots >= 0xffffffffull)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "format table: more than 2^32 rows / blob bytes / slots");
+  if (t->n_escapes > 4 || t->n_flags > 16 || t->flag_label_len > 32 || t->eos_len > 16 || t->error_len > 32 || t->flag_placeholder > 1)
+    return fail(JPPGPU_INVALID_PARAMETER, "format table: literal beyond its field");
+  static_assert(sizeof(FmtRow) == sizeof(jppgpu_format_row), "row layout");
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  if (!(ctx->fmt_slots.ensure(t->n_slots * 4) && ctx->fmt_rows.ensure(t->n_rows * sizeof(FmtRow)) &&
+        ctx->fmt_blob.ensure(t->blob_bytes + 64) && ctx->fmt_table.ensure(sizeof(FmtTable))))
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format table)");
+  jpp_stream_t st = ctx->own_stream;
+  rt_h2d(ctx->fmt_slots.p, t->slot_first_row, t->n_slots * 4, st);
+  rt_h2d(ctx->fmt_rows.p, t->rows, t->n_rows * sizeof(FmtRow), st);
+  rt_h2d(ctx->fmt_blob.p, t->blob, t->blob_bytes, st);
+  FmtTable T;
+  memset(&T, 0, sizeof(T));
+  T.slot_first_row = ctx->fmt_slots.as<u32>();
+  T.n_slots = t->n_slots;
+  T.rows = ctx->fmt_rows.as<FmtRow>();
+  T.n_rows = t->n_rows;
+  T.blob = ctx->fmt_blob.as<u8>();
+  memcpy(T.maker_replaces, t->maker_replaces, 16);
+  T.n_escapes = t->n_escapes;
+  memcpy(T.escape_from, t->escape_from, 4);
+  memcpy(T.escape_len, t->escape_len, 4);
+  memcpy(T.escape_to, t->escape_to, 32);
+  T.flag_placeholder = t->flag_placeholder;
+  T.flag_label_len = t->flag_label_len;
+  memcpy(T.flag_label, t->flag_label, 32);
+  T.n_flags = t->n_flags;
+  memcpy(T.flag_mask, t->flag_mask, sizeof(T.flag_mask));
+  memcpy(T.flag_char, t->flag_char, 16);
+  T.eos_len = t->eos_len;
+  T.error_len = t->error_len;
+  memcpy(T.eos_text, t->eos_text, 16);
+  memcpy(T.error_text, t->error_text, 32);
+  rt_h2d(ctx->fmt_table.p, &T, sizeof(T), st);
+  rt_sync(st);   // (T and the caller's arrays may go away)
+  ctx->fmt_have = true;
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v) {
+  if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jppgpu_ctx* ctx = res->ctx;
+  if (!ctx->fmt_have) return fail(JPPGPU_INVALID_STATE, "jppgpu_result_format_top1 needs jppgpu_ctx_set_format_table");
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  if (!res->fm_have) {
+    if (res->generation != ctx->generation)
+      return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+    jpp_stream_t st = ctx->last_stream;
+    if (!(ctx->fmt_len.ensure((B.total_nodes + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8)))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format)");
+    const FmtTable* T = ctx->fmt_table.as<FmtTable>();
+    if (n) JPP_LAUNCH(k_fmt_count, (n + 3) / 4, 256, st, B, T, ctx->fmt_len.as<u32>(), ctx->fmt_cnt.as<u32>());
+    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
+    bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
+    rt_sync(st);   // the byte total sizes the text buffers
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format offsets)");
+    const u64 total = res->fm_off.data()[n];
+    if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
+    if (n) JPP_LAUNCH(k_fmt_write, (n + 3) / 4, 256, st, B, T, (const u32*)ctx->fmt_len.as<u32>(), (const u64*)ctx->fmt_off.as<u64>(),
+                      ctx->fmt_text.as<u8>());
+    ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
+    ok &= pull(res->fm_status, B.sent_status, n, st);   // (k_fmt_count may have failed a sentence the table cannot render)
+    rt_sync(st);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format text)");
+    res->fm_have = true;
+  }
+  v->n_sentences = n;
+  v->offsets = res->fm_off.data();
+  v->text = res->fm_text.data();
+  v->status = res->fm_status.data();
   return JPPGPU_OK;
 }
 

@@ -1,0 +1,38 @@
+// The per-model table behind the device-side JUMAN formatter (include/jppgpu.h: jppgpu_format_table,
+// csrc/k_format.h): every entry row of the dictionary rendered ONCE, by the same code JumanFormat prints a node with
+// (formatJumanRow), plus the few literals of the format.  Replaces, for the top-1 JUMAN output, the per-sentence
+// JumanFormat::format of the reference (src/jumandic/shared/juman_format.cc:94-168) and its per-entry text cache here.
+#ifndef JUMANPP_AMD_HOST_FORMAT_TABLE_H
+#define JUMANPP_AMD_HOST_FORMAT_TABLE_H
+
+#include <string>
+#include <vector>
+
+#include "jppgpu.h"
+#include "model_image.h"
+
+namespace jumanpp_amd {
+
+class JumanFormatTable {
+  std::vector<uint32_t> slots_;
+  std::vector<jppgpu_format_row> rows_;
+  std::string blob_;
+  jppgpu_format_table view_{};
+  size_t entries_ = 0;
+  double buildMs_ = 0;
+
+ public:
+  // InvalidState / NotImplemented when the model cannot be rendered by the table (an UNK maker that replaces a field
+  // the table has no slot for, no JUMAN id map, entry pointers that are not the builder's consecutive lists):
+  // the caller keeps formatting on the host
+  Status build(const ModelImage* model, unsigned threads);
+  const jppgpu_format_table& view() const { return view_; }
+  size_t numEntries() const { return entries_; }
+  size_t numRows() const { return rows_.size(); }
+  size_t blobBytes() const { return blob_.size(); }
+  double buildMs() const { return buildMs_; }
+};
+
+}  // namespace jumanpp_amd
+
+#endif  // JUMANPP_AMD_HOST_FORMAT_TABLE_H

@@ -69,6 +69,8 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
     releaseResult();
     jppgpu_ctx_destroy(ctx_);
     ctx_ = nullptr;
+    haveFormatTable_ = false;
+    textMode_ = false;
   }
   int rc = jppgpu_ctx_create(&model->cmodel(), &c, &ctx_);
   if (rc != JPPGPU_OK) return fromCode(rc);
@@ -259,6 +261,11 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
       G.view.beam = G.nbest.beam;
       G.view.global_beam = G.nbest.global_beam;
       G.view.num_scorers = G.nbest.num_scorers;
+    } else if (textMode_ && !fullLattice) {
+      textFetched_ = false;
+      text_ = jppgpu_text_view{};
+      G.view = jppgpu_result_view{};
+      if (!deferText_) JPPA_RETURN_IF_ERROR(fetchText());
     } else {
       rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
       if (rc != JPPGPU_OK) return fromCode(rc);
@@ -270,7 +277,7 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
   // which may come from any format worker (distinct sentences write distinct ranges)
   cpOffsetsBase_.assign(n + 1, 0);
   uint64_t cpTotal = 0;
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = 0; i < n && !(textMode_ && !fullLattice); ++i) {
     cpOffsetsBase_[i] = cpTotal;
     const jppgpu_result_view& v = groups_[groupOf_[i]].view;
     if (v.status[localIdx_[i]] == JPPGPU_SENT_OK) cpTotal += (uint64_t)v.n_codepoints[localIdx_[i]] + 1;
@@ -286,6 +293,7 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
 
 Status GpuAnalyzer::sentenceStatus(size_t i) const {
   if (groups_.empty() || i >= inputs_.size()) return Status::InvalidState("no result for this sentence");
+  if (groups_[groupOf_.empty() ? 0 : groupOf_[i]].view.status == nullptr) return Status::InvalidState("the batch's text was not fetched");
   switch (groups_[groupOf_[i]].view.status[localIdx_[i]]) {
     case JPPGPU_SENT_OK: return Status::Ok();
     case JPPGPU_SENT_TOO_LONG:
@@ -302,6 +310,7 @@ SentenceResult GpuAnalyzer::sentence(size_t i) const {
   const jppgpu_result_view& v = groups_[groupOf_[i]].view;
   const uint32_t k = localIdx_[i];
   r.input = inputs_[i];
+  if (v.n_codepoints == nullptr) return r;   // text mode: no node tables were fetched
   r.numCodepoints = v.n_codepoints[k];
   r.numNodes = v.n_nodes[k];
   if (v.node_base != nullptr) {  // (n-best mode carries no node table: the paths' node records are in the n-best items)
@@ -325,6 +334,39 @@ SentenceResult GpuAnalyzer::sentence(size_t i) const {
   }
   r.cpByteOffsets = offs;
   return r;
+}
+
+Status GpuAnalyzer::fetchText() {
+  if (!textMode_ || groups_.size() != 1 || groups_[0].result == nullptr) return Status::InvalidState("no text-mode batch to fetch");
+  if (textFetched_) return Status::Ok();
+  Group& G = groups_[0];
+  int rc = jppgpu_result_format_top1(G.result, &text_);
+  if (rc != JPPGPU_OK) return fromCode(rc);
+  G.view.n_sentences = text_.n_sentences;
+  G.view.status = text_.status;
+  textFetched_ = true;
+  return Status::Ok();
+}
+
+TextBatch GpuAnalyzer::takeText() {
+  TextBatch tb;
+  if (textFetched_ && groups_.size() == 1) {
+    tb.result = groups_[0].result;
+    tb.view = text_;
+    groups_[0].result = nullptr;
+    groups_.clear();
+    textFetched_ = false;
+    text_ = jppgpu_text_view{};
+  }
+  return tb;
+}
+
+Status GpuAnalyzer::setFormatTable(const jppgpu_format_table& table) {
+  if (!ctx_) return Status::InvalidState("GpuAnalyzer::setFormatTable before initialize");
+  int rc = jppgpu_ctx_set_format_table(ctx_, &table);
+  if (rc != JPPGPU_OK) return fromCode(rc);
+  haveFormatTable_ = true;
+  return Status::Ok();
 }
 
 void GpuAnalyzer::lastTimings(float ms[8]) const {

@@ -69,6 +69,32 @@ class ScorePlugin {
                              float* penalty) = 0;
 };
 
+// the formatted text of one batch, detached from the analyzer that produced it (host copies of a result stay valid
+// until it is released, also across later batches of the context): lets a writer keep the bytes while the analyzer
+// takes its next batch
+struct TextBatch {
+  jppgpu_result* result = nullptr;
+  jppgpu_text_view view{};
+  TextBatch() = default;
+  TextBatch(const TextBatch&) = delete;
+  TextBatch& operator=(const TextBatch&) = delete;
+  TextBatch(TextBatch&& o) noexcept : result(o.result), view(o.view) { o.result = nullptr; }
+  TextBatch& operator=(TextBatch&& o) noexcept {
+    if (this != &o) {
+      reset();
+      result = o.result;
+      view = o.view;
+      o.result = nullptr;
+    }
+    return *this;
+  }
+  ~TextBatch() { reset(); }
+  void reset() {
+    if (result) jppgpu_result_release(result);
+    result = nullptr;
+  }
+};
+
 struct SentenceResult {
   StringPiece input;
   uint32_t numCodepoints = 0;
@@ -98,6 +124,10 @@ class GpuAnalyzer {
     int32_t beam = 0;
   };
   int32_t latticeNBest_ = 0;
+  bool textMode_ = false;          // results are fetched as formatted text (jppgpu_result_format_top1)
+  bool haveFormatTable_ = false;
+  bool deferText_ = false, textFetched_ = false;
+  jppgpu_text_view text_{};
   std::vector<Group> groups_;
   std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
   AnalyzerConfig cfg_;
@@ -138,6 +168,28 @@ class GpuAnalyzer {
   // -- the n best paths' beam slots, nodes and score cells, gathered on the device
   // (jppgpu_result_fetch_nbest) -- instead of the whole lattice; with auto-beam n is the sentence's beam.
   void setLatticeNBest(int32_t n) { latticeNBest_ = n; }
+  // OutputFormat::format on the device (include/jppgpu.h: jppgpu_format_table): after setFormatTable, text mode makes
+  // analyzeBatch(inputs) fetch the formatted top-1 analyses of the batch -- bytes and one offset per sentence -- instead
+  // of node tables.  Not with auto-beam (several groups per batch) or a full-lattice fetch; sentence(i) is not
+  // available in text mode, sentenceStatus(i) and sentenceText(i) are.
+  Status setFormatTable(const jppgpu_format_table& table);
+  bool setTextMode(bool on) {
+    textMode_ = on && haveFormatTable_ && cfg_.autoBeamStep <= 0;
+    return textMode_ == on;
+  }
+  bool textMode() const { return textMode_; }
+  // deferred: analyzeBatch only analyses; fetchText() -- from any thread, before the analyzer's next batch -- runs the
+  // format kernels and copies the text (so that the copy of batch k overlaps the analysis of batch k + 1 on the
+  // device's other analyzer)
+  void setDeferredText(bool on) { deferText_ = on; }
+  Status fetchText();
+  // hands the batch's text (and the result that owns it) to the caller; sentenceStatus / sentenceText are gone with it
+  TextBatch takeText();
+  StringPiece sentenceText(size_t i) const {
+    return StringPiece(text_.text + text_.offsets[i], (size_t)(text_.offsets[i + 1] - text_.offsets[i]));
+  }
+  // the whole batch: sentence i is text[offsets[i] .. offsets[i + 1])
+  const jppgpu_text_view& batchText() const { return text_; }
   // the n-best view holding sentence i (nullptr unless the batch was fetched in n-best mode)
   const jppgpu_nbest_view* nbestOf(size_t i, uint32_t* local) const {
     *local = localIdx_[i];

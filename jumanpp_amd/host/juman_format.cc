@@ -104,6 +104,92 @@ Status JumanFormat::initialize(const ModelImage* model) {
   return flds_.initialize(om);
 }
 
+// one output line of a node: the row the walker stands on (juman_format.cc:100-165).  `pieces`, when given, receives the
+// byte lengths of the parts the device-side formatter replaces or appends to (format_table.cc)
+void formatJumanRow(const ModelImage& model, const JumandicFields& flds, const NodeWalker& walker, bool first, std::string& printer,
+                    JumanRowPieces* pieces) {
+  const size_t at0 = printer.size();
+  if (!first) put(printer, "@ ");
+  const size_t atS = printer.size();
+  const int32_t* fb = walker.features();
+  int32_t ids[4];
+  // conjForm and conjType are reversed in the entry row (juman_format.cc:104-106)
+  model.dicToJuman(fb[1], fb[2], fb[4], fb[3], ids);
+  put(printer, escapeForJumanOutput(flds.surface[walker]));
+  const size_t endS = printer.size();
+  printer += ' ';
+  put(printer, escapeForJumanOutput(flds.reading[walker]));
+  const size_t endR = printer.size();
+  printer += ' ';
+  put(printer, escapeForJumanOutput(flds.baseform[walker]));
+  const size_t endB = printer.size();
+  printer += ' ';
+  put(printer, ifEmpty(flds.pos[walker], "*"));
+  printer += ' ';
+  printer += std::to_string(ids[0]);
+  printer += ' ';
+  put(printer, ifEmpty(flds.subpos[walker], "*"));
+  printer += ' ';
+  printer += std::to_string(ids[1]);
+  printer += ' ';
+  put(printer, ifEmpty(flds.conjType[walker], "*"));
+  printer += ' ';
+  printer += std::to_string(ids[2]);
+  printer += ' ';
+  put(printer, ifEmpty(flds.conjForm[walker], "*"));
+  printer += ' ';
+  printer += std::to_string(ids[3]);
+  printer += ' ';
+  const size_t endMid = printer.size();
+  KVListIterator res = flds.features[walker];
+  StringPiece canonic = flds.canonicForm[walker];
+  const bool special = walker.isSpecial();
+  const bool hasFeatures = special || res.hasNext() || !canonic.empty();
+  size_t featBytes = 0;
+  if (!hasFeatures) {
+    put(printer, "NIL");
+  } else {
+    bool output = false;
+    printer += '"';
+    const size_t featAt = printer.size();
+    if (!canonic.empty()) {
+      put(printer, "代表表記:");
+      put(printer, canonic);
+      if (res.hasNext()) printer += ' ';
+      output = true;
+    }
+    while (res.next()) {
+      output = true;
+      put(printer, res.key());
+      if (res.hasValue()) {
+        printer += ':';
+        put(printer, res.value());
+      }
+      if (res.hasNext()) printer += ' ';
+    }
+    featBytes = printer.size() - featAt;
+    if (special) {
+      int32_t ufld = walker.placeholder(NormalizedPlaceholderIdx);
+      if (ufld != 0) {
+        if (output) printer += ' ';
+        formatNormalizedFeature(printer, ufld);
+      }
+    }
+    printer += '"';
+  }
+  printer += '\n';
+  if (pieces != nullptr) {
+    pieces->pre = (uint32_t)(atS - at0);
+    pieces->s = (uint32_t)(endS - atS);
+    pieces->r = (uint32_t)(endR - endS - 1);
+    pieces->b = (uint32_t)(endB - endR - 1);
+    pieces->mid = (uint32_t)(endMid - endB);
+    pieces->feat = (uint32_t)featBytes;
+    pieces->hasFeatures = hasFeatures;
+    pieces->total = (uint32_t)(printer.size() - at0);
+  }
+}
+
 bool JumanFormat::formatOne(const OutputManager& om, const SentenceResult& s, uint32_t node, bool first) {
   // a dictionary node as the first alternative of its position: its text is cached per entry
   if (node >= s.numNodes || s.nodes == nullptr) return false;
@@ -118,69 +204,8 @@ bool JumanFormat::formatOne(const OutputManager& om, const SentenceResult& s, ui
   }
   const size_t startOfNode = printer_.size();
   if (!om.locate(s, node, &walker_)) return false;
-  std::string& printer = printer_;
   while (walker_.next()) {
-    if (!first) put(printer, "@ ");
-    const int32_t* fb = walker_.features();
-    int32_t ids[4];
-    // conjForm and conjType are reversed in the entry row (juman_format.cc:104-106)
-    model_->dicToJuman(fb[1], fb[2], fb[4], fb[3], ids);
-    put(printer, escapeForJumanOutput(flds_.surface[walker_]));
-    printer += ' ';
-    put(printer, escapeForJumanOutput(flds_.reading[walker_]));
-    printer += ' ';
-    put(printer, escapeForJumanOutput(flds_.baseform[walker_]));
-    printer += ' ';
-    put(printer, ifEmpty(flds_.pos[walker_], "*"));
-    printer += ' ';
-    printer += std::to_string(ids[0]);
-    printer += ' ';
-    put(printer, ifEmpty(flds_.subpos[walker_], "*"));
-    printer += ' ';
-    printer += std::to_string(ids[1]);
-    printer += ' ';
-    put(printer, ifEmpty(flds_.conjType[walker_], "*"));
-    printer += ' ';
-    printer += std::to_string(ids[2]);
-    printer += ' ';
-    put(printer, ifEmpty(flds_.conjForm[walker_], "*"));
-    printer += ' ';
-    printer += std::to_string(ids[3]);
-    printer += ' ';
-    KVListIterator res = flds_.features[walker_];
-    StringPiece canonic = flds_.canonicForm[walker_];
-    const bool special = walker_.isSpecial();
-    const bool hasFeatures = special || res.hasNext() || !canonic.empty();
-    if (!hasFeatures) {
-      put(printer, "NIL");
-    } else {
-      bool output = false;
-      printer += '"';
-      if (!canonic.empty()) {
-        put(printer, "代表表記:");
-        put(printer, canonic);
-        if (res.hasNext()) printer += ' ';
-        output = true;
-      }
-      while (res.next()) {
-        output = true;
-        put(printer, res.key());
-        if (res.hasValue()) {
-          printer += ':';
-          put(printer, res.value());
-        }
-        if (res.hasNext()) printer += ' ';
-      }
-      if (special) {
-        int32_t ufld = walker_.placeholder(NormalizedPlaceholderIdx);
-        if (ufld != 0) {
-          if (output) printer += ' ';
-          formatNormalizedFeature(printer, ufld);
-        }
-      }
-      printer += '"';
-    }
-    printer += '\n';
+    formatJumanRow(*model_, flds_, walker_, first, printer_, nullptr);
     first = false;
   }
   if (cacheable) cache_->publish(eptr, StringPiece(printer_.data() + startOfNode, printer_.size() - startOfNode));

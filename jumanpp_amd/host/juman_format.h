@@ -22,6 +22,16 @@ struct JumandicFields {
 
 constexpr int NormalizedPlaceholderIdx = 0;  // src/jumandic/shared/jumandic_spec.h:14
 
+// byte lengths of the parts of one JUMAN output line (see include/jppgpu.h: jppgpu_format_row)
+struct JumanRowPieces {
+  uint32_t pre = 0, s = 0, r = 0, b = 0, mid = 0, feat = 0, total = 0;
+  bool hasFeatures = false;
+};
+// the line JumanFormat prints for the entry row the walker stands on, appended to `printer`
+void formatJumanRow(const ModelImage& model, const JumandicFields& flds, const NodeWalker& walker, bool first, std::string& printer,
+                    JumanRowPieces* pieces);
+void formatNormalizedFeature(std::string& p, int32_t v);
+
 // core::OutputFormat (src/core/env.h:73-79), per sentence of the last batch
 class OutputFormat {
  public:

@@ -25,6 +25,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -48,6 +49,7 @@
 #include <sched.h>
 #include <vector>
 
+#include "format_table.h"
 #include "gpu_analyzer.h"
 #include "juman_format.h"
 #include "lattice_format.h"
@@ -80,6 +82,7 @@ struct Conf {
   RnnConfigOverride rnn;  // --rnn-nce-bias, --rnn-unk-constant, --rnn-unk-length, --feature-weight-*
   int threads = 0;            // --threads=N format workers (0: one per hardware thread, at most 32)
   bool pipeline = true;       // --no-pipeline: one analyzer, read/analyse/format strictly in turn per batch
+  bool hostFormat = false;    // --host-format: JUMAN text from the host formatters even where the device can print it
 };
 
 bool argValue(int argc, const char** argv, int& i, const char* name, std::string* out) {
@@ -134,6 +137,9 @@ struct ShardJob {
   double gpuMs = 0;
   bool lastReadOk = true;
   std::vector<std::string> text, errors;   // formatted chunks of consecutive sentences
+  // device text: the batch's bytes stay in the result's (page-locked) host copy; the writer gets them as segments
+  TextBatch deviceText;
+  std::vector<struct iovec> segments;
   size_t outBytes = 0;
   uint64_t outOffset = 0;
 };
@@ -394,6 +400,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--feature-weight-rnn", &v)) { conf.rnn.rnnWeight = std::strtof(v.c_str(), nullptr); conf.rnn.hasRnnWeight = true; }
     else if (argValue(argc, argv, i, "--threads", &v)) conf.threads = std::atoi(v.c_str());
     else if (std::strcmp(argv[i], "--no-pipeline") == 0) conf.pipeline = false;
+    else if (std::strcmp(argv[i], "--host-format") == 0) conf.hostFormat = true;
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
@@ -460,7 +467,8 @@ int main(int argc, const char** argv) {
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
-                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing\n";
+                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing,\n"
+                 "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format)\n";
     return 1;
   }
   if (conf.model.empty()) {
@@ -617,11 +625,33 @@ int main(int argc, const char** argv) {
   // up there: a short input pays for one
   std::vector<std::vector<std::unique_ptr<GpuAnalyzer>>> analyzers((size_t)nDev);
   for (auto& v : analyzers) v.resize((size_t)nAnalyzers);
+  // The top-1 JUMAN format is printed by the device when the model allows it (format_table.h): every entry row of the
+  // dictionary rendered once, here, by the host formatter's own row printer; the analyzers then fetch text instead of
+  // node tables and the format workers below have nothing to do.  Lattice / morph / segmented / subset formats,
+  // --auto-nbest (several beam groups per batch) and --host-format keep the host formatters.
+  JumanFormatTable formatTable;
+  bool deviceText = !conf.hostFormat && !latticeFormat && !useLattice && conf.kind == Conf::Juman && acfg.autoBeamStep <= 0 &&
+                    std::getenv("JUMANPP_GPU_HOST_FORMAT") == nullptr;
+  if (deviceText) {
+    Status built = formatTable.build(&model, (unsigned)std::max(1, conf.threads));
+    if (!built) deviceText = false;   // (e.g. an UNK maker that rewrites a field the table renders: host formatters)
+    if (conf.timing)
+      std::cerr << "device_format=" << (deviceText ? 1 : 0) << " table_entries=" << formatTable.numEntries() << " rows=" << formatTable.numRows()
+                << " blob_bytes=" << formatTable.blobBytes() << " build_ms=" << formatTable.buildMs() << (built ? "" : " (" + statusText(built) + ")") << "\n";
+  }
   auto makeAnalyzer = [&](int d, int a) -> Status {
     analyzers[d][a].reset(new GpuAnalyzer());
     // the lattice format reads the N best paths only: they are gathered on the device (N = what it prints)
     if (latticeFormat) analyzers[d][a]->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
-    return analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d]);
+    Status made = analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d]);
+    if (made && deviceText) {
+      made = analyzers[d][a]->setFormatTable(formatTable.view());
+      if (made) {
+        analyzers[d][a]->setTextMode(true);
+        analyzers[d][a]->setDeferredText(sharded);
+      }
+    }
+    return made;
   };
   for (int d = 0; d < nDev; ++d) {
     s = makeAnalyzer(d, 0);
@@ -798,8 +828,73 @@ int main(int argc, const char** argv) {
         const size_t kChunk = 64;
         while (fmtQ[d]->pop(&job)) {
           const long long t0 = us();
-          const GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
           const size_t n = job->inputs.size();
+          if (deviceText && job->batchStatus.isOk()) {
+            // the device formats: this thread runs the format kernels and copies the text (while the analysis thread is
+            // on the device's other analyzer), then cuts the batch's bytes into the segments the writer puts out --
+            // one run per stretch of sentences without a comment line, a failed read or an error message
+            GpuAnalyzer& an = *analyzers[d][job->analyzer];
+            Status fs = an.fetchText();
+            job->errors.assign(1, std::string());
+            std::string& errors = job->errors[0];
+            job->outBytes = 0;
+            if (!fs) {
+              job->batchStatus = fs;
+            } else {
+              const jppgpu_text_view& tv = an.batchText();
+              auto seg = [&](const char* p, size_t len) {
+                if (len == 0) return;
+                if (!job->segments.empty()) {
+                  struct iovec& last = job->segments.back();
+                  if (static_cast<const char*>(last.iov_base) + last.iov_len == p) {
+                    last.iov_len += len;
+                    job->outBytes += len;
+                    return;
+                  }
+                }
+                struct iovec v;
+                v.iov_base = const_cast<char*>(p);
+                v.iov_len = len;
+                job->segments.push_back(v);
+                job->outBytes += len;
+              };
+              auto bad = job->readErrors.begin();
+              for (size_t i = 0; i < n; ++i) {
+                if (bad != job->readErrors.end() && bad->first == i) {
+                  errors += "failed to read an example: " + statusText(bad->second);
+                  ++bad;
+                  continue;   // (analysed as an empty line; nothing of it is printed)
+                }
+                if (tv.status[i] != JPPGPU_SENT_OK) errors += statusText(an.sentenceStatus(i));   // (its text is the error result)
+                const StringPiece& cm = job->comments[i];
+                if (cm.size() >= 2 && tv.status[i] == JPPGPU_SENT_OK) {
+                  seg(cm.data(), cm.size());   // "# comment", as it stands in the mapped input
+                  seg("\n", 1);
+                }
+                seg(tv.text + tv.offsets[i], (size_t)(tv.offsets[i + 1] - tv.offsets[i]));
+              }
+              job->deviceText = an.takeText();
+            }
+          }
+          if (deviceText && job->batchStatus.isOk()) {
+            freeAnalyzers[d]->release();
+            formatUs += us() - t0;
+            std::unique_lock<std::mutex> l(seqMu);
+            seqCv.wait(l, [&] { return seqNext == job->seq; });
+            job->outOffset = outTotal;
+            outTotal += job->outBytes;
+            sentences += n;
+            gpuUs += (long long)(job->gpuMs * 1000.0);
+            result = job->lastReadOk ? 0 : 1;
+            for (auto& e : job->errors)
+              if (!e.empty()) std::cerr << e;
+            ++seqNext;
+            seqCv.notify_all();
+            l.unlock();
+            writeQ[d]->push(std::move(job));
+            continue;
+          }
+          const GpuAnalyzer& analyzer = *analyzers[d][job->analyzer];
           const size_t nChunks = (n + kChunk - 1) / kChunk;
           job->text.assign(nChunks, std::string());
           job->errors.assign(nChunks, std::string());
@@ -866,6 +961,23 @@ int main(int argc, const char** argv) {
         while (writeQ[d]->pop(&job)) {
           const long long t0 = us();
           uint64_t off = job->outOffset;
+          for (size_t k = 0; k < job->segments.size() && !writeFailed;) {
+            // pwritev takes at most IOV_MAX segments and may write less than it was given
+            const size_t cnt = std::min<size_t>(job->segments.size() - k, 1024);
+            ssize_t w = pwritev(ofd, job->segments.data() + k, (int)cnt, (off_t)off);
+            if (w <= 0) {
+              writeFailed = true;
+              break;
+            }
+            off += (uint64_t)w;
+            size_t left = (size_t)w;
+            while (k < job->segments.size() && left >= job->segments[k].iov_len) left -= job->segments[k++].iov_len;
+            if (left > 0) {
+              job->segments[k].iov_base = static_cast<char*>(job->segments[k].iov_base) + left;
+              job->segments[k].iov_len -= left;
+            }
+          }
+          job->deviceText.reset();   // the text block goes back to its analyzer's pool
           for (auto& t : job->text) {
             size_t done = 0;
             while (done < t.size()) {
@@ -976,6 +1088,16 @@ int main(int argc, const char** argv) {
       }
       StringPiece comment = e.comment.size() < 2 ? StringPiece("") : StringPiece(e.comment.data() + 2, e.comment.size() - 2);
       if (conf.partialInput) comment = StringPiece(e.partial->comment);
+      if (analyzer.textMode()) {   // the device printed the sentence; the comment line goes in front of it
+        if (!comment.empty()) {
+          text->append("# ");
+          text->append(comment.data(), comment.size());
+          *text += '\n';
+        }
+        const StringPiece r = analyzer.sentenceText(i);
+        text->append(r.data(), r.size());
+        continue;
+      }
       st = format->format(analyzer, i, comment);
       if (!st) *errors += statusText(st);
       else {

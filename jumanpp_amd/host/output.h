@@ -80,6 +80,7 @@ class StringField {
  public:
   // StringField::operator[] (output.cc:112-130): negative value = surface of the UNK node
   StringPiece operator[](const NodeWalker& w) const;
+  int32_t index() const { return index_; }   // >= 0: feature column of the entry row, < 0: ~data column
 };
 
 class KVListIterator {

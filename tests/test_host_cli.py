@@ -71,6 +71,50 @@ def test_juman_format_with_rnn(cli_emu, golden_dir):
     assert rc == 0 and out2 == open(os.path.join(golden_dir, 'mini.juman.txt'), 'rb').read()
 
 
+def _device_format_case(cli, golden_dir, tmp_path):
+    """the top-1 JUMAN format is printed by the DEVICE by default (k_fmt_count / k_fmt_write over the per-model table of
+    rendered entry rows, host/format_table.cc): it must say so, and its bytes must be those of the host formatters
+    (--host-format) and of the reference -- stream and file pipelines, comments, failing lines, tiny batches, alias
+    entries ("@ " rows) and every UNK maker (tests/golden/ref: the reference's own dictionaries)"""
+    fix = os.path.join(golden_dir, 'ref')
+    cases = [(os.path.join(golden_dir, 'mini.jppmdl'), os.path.join(golden_dir, 'mini.txt'), os.path.join(golden_dir, 'mini.juman.txt')),
+             (os.path.join(golden_dir, 'mini_rnn.jppmdl'), os.path.join(golden_dir, 'mini.txt'), os.path.join(golden_dir, 'mini_rnn.juman.txt'))]
+    for m in ('minimal', 'minimal_trained', 'codegen', 'bug28', 'bug950111'):
+        cases.append((os.path.join(fix, m + '.jppmdl'), os.path.join(fix, m + '.txt'), os.path.join(fix, m + '.juman.out')))
+    for model, txt, ref_path in cases:
+        ref = open(ref_path, 'rb').read()
+        rc, dev, err = _run(cli, ['--model=' + model, '--timing', txt])
+        assert rc == 0 and b'device_format=1' in err, err[-300:]
+        rc, host, err2 = _run(cli, ['--model=' + model, '--timing', '--host-format', txt])
+        assert rc == 0 and b'device_format' not in err2
+        assert dev == ref and host == ref, model
+        out = str(tmp_path / 'o.txt')
+        rc, _, err = _run(cli, ['--model=' + model, '--timing', '--batch=5', '-o', out, txt])
+        assert rc == 0 and b'device_format=1' in err and b'sharded=1' in err and open(out, 'rb').read() == ref, model
+    # comment lines, an empty line, invalid UTF-8, an over-long line, a tab as a one-byte surface: both formatters, both pipelines
+    model = cases[0][0]
+    data = ('# S-ID:1 first\n' + open(cases[0][1], encoding='utf-8').read() + '# c2\n\n# c3\nすごーーい\n').encode('utf-8') \
+        + b'\xe3\x81\n' + ('あ' * 1400).encode('utf-8') + b'\n\t\n \n# last comment'
+    src = tmp_path / 'in.txt'
+    src.write_bytes(data)
+    rc, host, eh = _run(cli, ['--model=' + model, '--host-format', str(src)])
+    rc2, dev, ed = _run(cli, ['--model=' + model, str(src)])
+    assert dev == host and rc == rc2 and ed == eh
+    for batch in ('3', '1000'):
+        out = str(tmp_path / 'o2.txt')
+        rc3, _, e3 = _run(cli, ['--model=' + model, '--batch=' + batch, '-o', out, str(src)])
+        assert open(out, 'rb').read() == host and rc3 == rc and e3 == eh, batch
+
+
+def test_device_side_juman_format(cli_emu, golden_dir, tmp_path):
+    _device_format_case(cli_emu, golden_dir, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_device_side_juman_format(cli_gpu, golden_dir, tmp_path):
+    _device_format_case(cli_gpu, golden_dir, tmp_path)
+
+
 def test_cli_comments_errors_and_batching_like_reference(cli_emu, golden_dir, ref_tools, tmp_path):
     """comment lines, an over-long line, invalid UTF-8, empty lines, stdin input, tiny batches:
     stdout must equal the reference CLI's on the same bytes (the model comes from the goldens' recipe)."""
