@@ -136,6 +136,11 @@ typedef struct {
                              * objects even when the spec is the compiled-in one -- what its trainer runs
                              * (TrainingEnv::initFeatures(nullptr), src/jumandic/main/jumanpp_train.cc:206,
                              * src/core/features_api.cc:20-60).  0: static code when the spec matches (the analyser). */
+  /* ScorerDef::others beyond the model's RNN (score_api.h:44-72): scorers that live on the HOST and fill their slot of
+   * the score cells through jppgpu_analyze_batch_scored.  Scorer slots: 0 perceptron, 1 RNN (when use_rnn), then the
+   * host scorers in order; at most 4 in all.  Needs a global beam, like every extra scorer (analyzer_impl.cc:81-86). */
+  int32_t num_host_scorers; /* 0 .. 2 */
+  float weight_host[2];     /* ScorerDef::scoreWeights of the host scorers */
 } jppgpu_config;
 #define JPPGPU_CONFIG_MIN_SIZE 44u   /* struct_size .. dynamic_features: the first layout that carried a size */
 #define JPPGPU_CONFIG_INIT {(uint32_t)sizeof(jppgpu_config)}
@@ -312,6 +317,19 @@ typedef struct {
 typedef int (*jppgpu_seed_hook_fn)(void* user, const jppgpu_seed_view* seeds, jppgpu_extra_seeds* out);
 int jppgpu_analyze_batch_seeds(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
                                jppgpu_seed_hook_fn hook, void* user, jppgpu_result** out);
+
+/* ScoreComputer::scoreLattice (score_api.h:54-59) for a scorer on the host: called once per batch when the lattice is
+ * built, the perceptron cells are written and the beams hold the perceptron totals (with use_rnn: the RNN cells too).
+ * `lattice` is the full view of the batch (jppgpu_result_fetch(JPPGPU_FETCH_FULL)): nodes, ends lists, global beams,
+ * beams, cells.  The scorer writes ITS slot of the connections it scores:
+ *     cells[((node_base[i] + node) * global_beam + gbeam_index) * num_scorers + scorer_idx]
+ * (what the reference's scorer writes through scores->nodeScores(right).beamLeft(beam, left).at(scorerIdx));
+ * cells it leaves alone read 0.  A non-zero return aborts the batch with JPPGPU_INVALID_STATE.  Afterwards the device
+ * re-makes the beam totals and the EOS beam from the weighted cells (adjustBeamScores / remakeEosBeam, k_adjust.h). */
+typedef int (*jppgpu_score_lattice_fn)(void* user, const jppgpu_result_view* lattice, uint32_t scorer_idx, float* cells);
+int jppgpu_analyze_batch_scored(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                const jppgpu_score_lattice_fn* scorers, void* const* users, uint32_t n_scorers,
+                                jppgpu_result** out);
 
 int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
                                 uint32_t total_bytes, void* stream, jppgpu_result** out);

@@ -19,6 +19,7 @@
 
 #include "jpp_rt.h"
 #include "jpp_types.h"
+#include "k_adjust.h"
 #include "k_decode.h"
 #include "k_format.h"
 #include "k_gold.h"
@@ -74,6 +75,13 @@ void rt_stream_destroy(jpp_stream_t) {}
 void* rt_host_alloc(size_t n) { return malloc(n ? n : 1); }
 void* rt_host_alloc_pinned(size_t n) { return malloc(n ? n : 1); }
 void rt_host_free(void* p) { free(p); }
+// (emulator: "device" pointers are host pointers)
+void* rt_mailbox_alloc(size_t n, void** dev) {
+  void* p = calloc(1, n);
+  *dev = p;
+  return p;
+}
+void rt_mailbox_free(void* p) { free(p); }
 struct Timer {
   void init() {}
   void destroy() {}
@@ -163,6 +171,24 @@ void* rt_host_alloc_pinned(size_t n) {
     return p;
   }
   return malloc(n ? n : 1);
+}
+// a few words of page-locked host memory the device writes directly (hipHostMallocMapped): the batch totals that size
+// the next allocations reach the host without a copy engine -- a 16-byte hipMemcpyAsync queues behind whatever the
+// engine is doing, e.g. the 150 MB text copy of the previous batch on the context next door (3-4 ms per sync in
+// jumanpp_gpu, profiles/r04_f_cli_stages.txt)
+void* rt_mailbox_alloc(size_t n, void** dev) {
+  void* p = nullptr;
+  *dev = nullptr;
+  if (hipHostMalloc(&p, n, hipHostMallocMapped) != hipSuccess || !p) return nullptr;
+  if (hipHostGetDevicePointer(dev, p, 0) != hipSuccess) {
+    (void)hipHostFree(p);
+    return nullptr;
+  }
+  memset(p, 0, n);
+  return p;
+}
+void rt_mailbox_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 void rt_host_free(void* p) {
   if (!p) return;
@@ -401,6 +427,13 @@ struct jppgpu_ctx {
   void* plugin_user = nullptr;
   jpp_stream_t aux_stream = nullptr;   // the sweep variants of the rare wide sentences run here, beside the main variant
   SyncPoint sweep_fork, sweep_join;
+  // scorers: slot 0 perceptron, slot 1 the RNN when use_rnn, then the host scorers (jppgpu_analyze_batch_scored)
+  bool use_rnn = false;
+  int n_host_scorers = 0;
+  ScoreWeights score_weights{};
+  const jppgpu_score_lattice_fn* scored_fns = nullptr;   // of the next analyze call
+  void* const* scored_users = nullptr;
+  DevBuf adj_stack;
   jppgpu_seed_hook_fn seed_hook = nullptr;     // gold-seed hook of the next analyze call (jppgpu_analyze_batch_seeds)
   void* seed_user = nullptr;
   DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
@@ -425,6 +458,8 @@ struct jppgpu_ctx {
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
   std::shared_ptr<HostPool> host_pool = std::make_shared<HostPool>();
+  volatile u64* mail_host = nullptr;   // [16] written by k_mail
+  u64* mail_dev = nullptr;
   std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
   bool fmt_have = false;
@@ -787,7 +822,9 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
 #endif
   // --- configuration checks (AnalyzerImpl::initScorers, analyzer_impl.cc:43-89) ---
   if (c->beam <= 0) return fail(JPPGPU_INVALID_PARAMETER, "AnalyzerImpl: beam size can not be zero for scoring");
-  if (c->global_beam <= 0 && c->use_rnn)
+  if (c->num_host_scorers < 0 || c->num_host_scorers > 2 || 1 + (c->use_rnn ? 1 : 0) + c->num_host_scorers > kMaxScorers)
+    return fail(JPPGPU_INVALID_PARAMETER, "jppgpu: num_host_scorers outside 0 .. 2");
+  if (c->global_beam <= 0 && (c->use_rnn || c->num_host_scorers > 0))
     return fail(JPPGPU_INVALID_STATE, "additional scorers are supported only with global beam enabled");
   if (c->global_beam > 0 && c->right_check > 0 && c->right_beam <= 0)
     return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
@@ -819,8 +856,17 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   auto* ctx = new jppgpu_ctx();
   ctx->device = c->device;
   ctx->cfg = Config{c->beam, c->global_beam > 0 ? c->global_beam : 0, c->right_check, c->right_beam,
-                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096, c->use_rnn ? 2 : 1,
-                    c->use_rnn ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
+                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096, 1 + (c->use_rnn ? 1 : 0) + c->num_host_scorers,
+                    (c->use_rnn || c->num_host_scorers > 0) ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
+  ctx->use_rnn = c->use_rnn != 0;
+  ctx->n_host_scorers = c->num_host_scorers;
+  {
+    int k = 0;
+    ctx->score_weights.w[k++] = ctx->cfg.w_perceptron;
+    if (ctx->use_rnn) ctx->score_weights.w[k++] = ctx->cfg.w_rnn;
+    for (int h = 0; h < c->num_host_scorers; ++h) ctx->score_weights.w[k++] = c->weight_host[h];
+    for (; k < kMaxScorers; ++k) ctx->score_weights.w[k] = 0.f;
+  }
   if (ctx->cfg.max_input_bytes > 65535) ctx->cfg.max_input_bytes = 65535;
   DevModel& H = ctx->hmodel;
   size_t wbytes = (size_t{1} << m->weight_exponent) * sizeof(float);
@@ -1023,6 +1069,12 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   ctx->sweep_join.init();
   ctx->timer.init();
   ctx->rnn_sync.init();
+  {
+    void* dev = nullptr;
+    ctx->mail_host = static_cast<volatile u64*>(rt_mailbox_alloc(16 * 8, &dev));
+    ctx->mail_dev = static_cast<u64*>(dev);
+    ctx->text_pool->pinned = true;
+  }
   *out = ctx;
   return JPPGPU_OK;
 }
@@ -1032,7 +1084,7 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
   if (!ctx) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   // the same checks as at construction (AnalyzerImpl::initScorers, analyzer_impl.cc:43-89)
   if (beam <= 0) return fail(JPPGPU_INVALID_PARAMETER, "AnalyzerImpl: beam size can not be zero for scoring");
-  if (global_beam <= 0 && ctx->cfg.nscorers == 2)
+  if (global_beam <= 0 && ctx->cfg.nscorers > 1)
     return fail(JPPGPU_INVALID_STATE, "additional scorers are supported only with global beam enabled");
   if (global_beam > 0 && right_check > 0 && right_beam <= 0)
     return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
@@ -1063,13 +1115,14 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
                     &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
-                    &ctx->fmt_slots, &ctx->fmt_rows, &ctx->fmt_blob, &ctx->fmt_table, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
+                    &ctx->adj_stack, &ctx->fmt_slots, &ctx->fmt_rows, &ctx->fmt_blob, &ctx->fmt_table, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
   rt_stream_destroy(ctx->aux_stream);
   ctx->sweep_fork.destroy();
   ctx->sweep_join.destroy();
+  rt_mailbox_free((void*)ctx->mail_host);
   ctx->host_pool->clear();
   ctx->text_pool->clear();
   ctx->timer.destroy();
@@ -1108,7 +1161,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
             ctx->bnd_first.ensure(bbN * 4) && ctx->bnd_cnt.ensure(bbN * 4) && ctx->end_first.ensure(bbN * 4) &&
             ctx->end_cnt.ensure(bbN * 4) && ctx->bnd_ngb.ensure(bbN * 4) && ctx->bnd_meta.ensure(bbN * sizeof(BndMeta)) &&
             ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry)) &&
-            (ctx->cfg.nscorers < 2 || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) && ctx->rnn_gi.ensure(bbN * G * 4) &&
+            (!ctx->use_rnn || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) && ctx->rnn_gi.ensure(bbN * G * 4) &&
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
               ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
@@ -1215,9 +1268,16 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
   u64 totals[2] = {0, 0};
-  rt_d2h(&totals[0], B.node_base + n, 8, st);
-  rt_d2h(&totals[1], B.node_base2 + n, 8, st);
-  rt_sync(st);
+  if (ctx->mail_host) {
+    JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.node_base + n), (const u64*)(B.node_base2 + n), (const u32*)nullptr, ctx->mail_dev);
+    rt_sync(st);
+    totals[0] = ctx->mail_host[0];
+    totals[1] = ctx->mail_host[1];
+  } else {
+    rt_d2h(&totals[0], B.node_base + n, 8, st);
+    rt_d2h(&totals[1], B.node_base2 + n, 8, st);
+    rt_sync(st);
+  }
   const u64 total1 = totals[0];
   const u64 seedCap = total1 + totals[1] + 8;
   if (!(ctx->node_info.ensure(seedCap * sizeof(NodeInfo)) && ctx->node_aux.ensure(seedCap * sizeof(NodeAux))))
@@ -1242,9 +1302,16 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   JPP_LAUNCH(k_connect<2>, wblocks, 64 * kLatWaves, st, B);
   u64 totalNodes = 0;
   u32 gstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
-  rt_d2h(gstats, B.gstats, sizeof(gstats), st);
-  rt_sync(st);
+  if (ctx->mail_host) {
+    JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.node_base2 + n), (const u64*)nullptr, (const u32*)B.gstats, ctx->mail_dev);
+    rt_sync(st);
+    totalNodes = ctx->mail_host[0];
+    for (int q = 0; q < 8; ++q) gstats[q] = (u32)ctx->mail_host[2 + q];
+  } else {
+    rt_d2h(&totalNodes, B.node_base2 + n, 8, st);
+    rt_d2h(gstats, B.gstats, sizeof(gstats), st);
+    rt_sync(st);
+  }
   B.gold_off = nullptr;
   B.gold = nullptr;
   bool goldInserted = false;
@@ -1528,7 +1595,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   ctx->last_class_n[0] = nCls[0]; ctx->last_class_n[1] = nCls[1]; ctx->last_class_n[2] = nCls[2];
   T.mark(5, st);
-  if (ctx->cfg.nscorers == 2) {
+  if (ctx->use_rnn) {
     JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
     JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
                (const DevModel*)ctx->dmodel, ctx->cfg);
@@ -1541,7 +1608,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     // the lock-step recurrence (which does not need the table) is enqueued before the host waits.
     JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.rnn_rows, B.rnn_rowbase, n, (const u64*)nullptr);
     u64 rnnRows = 0;
-    rt_d2h(&rnnRows, B.rnn_rowbase + n, 8, st);
+    if (ctx->mail_host) JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr, (const u32*)nullptr, ctx->mail_dev + 12);
+    else rt_d2h(&rnnRows, B.rnn_rowbase + n, 8, st);
     ctx->rnn_sync.mark(st);
     if (ctx->hmodel.rnn_EP <= 128) {
       // lock-step workgroups take sentences of equal chain length
@@ -1554,6 +1622,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
     ctx->rnn_sync.wait(st);
+    if (ctx->mail_host) rnnRows = ctx->mail_host[12];
     ctx->last_rnn_rows = rnnRows;
     if (!ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
@@ -1585,6 +1654,36 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(7, st);
   ctx->last_stream = st;
   ctx->timing_pending = true;
+  if (ctx->scored_fns != nullptr) {
+    // ScorerDef::others on the host (AnalyzerImpl::computeScoresGbeam, analyzer_impl.cc:286-294): every host scorer sees
+    // the scored lattice and fills its slot of the cells; the device then re-makes the totals and the EOS beam from the
+    // weighted cells (k_adjust.h) and the top-1 paths are traced again
+    const jppgpu_score_lattice_fn* fns = ctx->scored_fns;
+    void* const* users = ctx->scored_users;
+    ctx->scored_fns = nullptr;
+    jppgpu_result_view view;
+    int frc = jppgpu_result_fetch(Rp, JPPGPU_FETCH_FULL, &view);
+    if (frc != JPPGPU_OK) return frc;
+    const int S = ctx->cfg.nscorers, G = ctx->cfg.gbeam;
+    const int firstHost = 1 + (ctx->use_rnn ? 1 : 0);
+    const size_t ncell = (size_t)B.total_nodes * (size_t)G;
+    float* cells = Rp->cells.data();
+    for (int slot = firstHost; slot < S; ++slot)
+      for (size_t q = 0; q < ncell; ++q) cells[q * S + slot] = 0.f;
+    for (int h = 0; h < ctx->n_host_scorers; ++h) {
+      if (fns[h] == nullptr || fns[h](users ? users[h] : nullptr, &view, (uint32_t)(firstHost + h), cells) != 0)
+        return fail(JPPGPU_INVALID_STATE, "jppgpu: a host scorer failed (ScoreComputer::scoreLattice)");
+    }
+    if (ncell) rt_h2d(B.node_cells, cells, ncell * S * 4, st);
+    if (!ctx->adj_stack.ensure(bbN * (size_t)G * 4 + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (score adjustment)");
+    const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
+    if (sortE) JPP_LAUNCH((k_adjust<true>), (n + 3) / 4, 256, st, B, ctx->cfg, ctx->score_weights, ctx->adj_stack.as<u32>());
+    else JPP_LAUNCH((k_adjust<false>), (n + 3) / 4, 256, st, B, ctx->cfg, ctx->score_weights, ctx->adj_stack.as<u32>());
+    JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
+    rt_sync(st);   // (the host copy of the cells may be recycled by the next fetch)
+    // beam totals, the EOS beam and the paths have changed: later fetches copy them again
+    Rp->fetched_basic = Rp->fetched_full = Rp->fetched_top1 = false;
+  }
 #if !defined(JPP_EMU)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(JPPGPU_INVALID_STATE, std::string("kernel launch failed: ") + hipGetErrorString(e));
@@ -1613,6 +1712,19 @@ extern "C" int jppgpu_analyze_batch_plugin(jppgpu_ctx* ctx, const char* utf8, co
   ctx->plugin_user = user;
   int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
   ctx->plugin_fn = nullptr;
+  return rc;
+}
+
+extern "C" int jppgpu_analyze_batch_scored(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                           const jppgpu_score_lattice_fn* scorers, void* const* users, uint32_t n_scorers,
+                                           jppgpu_result** out) {
+  if (!ctx || !offsets || !out || !scorers) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if ((int)n_scorers != ctx->n_host_scorers || n_scorers == 0)
+    return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_analyze_batch_scored: as many scorers as jppgpu_config::num_host_scorers, at least one");
+  ctx->scored_fns = scorers;
+  ctx->scored_users = users;
+  int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
+  ctx->scored_fns = nullptr;
   return rc;
 }
 

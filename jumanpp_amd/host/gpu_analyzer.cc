@@ -340,8 +340,13 @@ Status GpuAnalyzer::fetchText() {
   if (!textMode_ || groups_.size() != 1 || groups_[0].result == nullptr) return Status::InvalidState("no text-mode batch to fetch");
   if (textFetched_) return Status::Ok();
   Group& G = groups_[0];
+  static const bool hostTiming = std::getenv("JPPGPU_HOST_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   int rc = jppgpu_result_format_top1(G.result, &text_);
   if (rc != JPPGPU_OK) return fromCode(rc);
+  if (hostTiming)
+    std::fprintf(stderr, "fetchText n=%u bytes=%llu total=%.2f ms\n", text_.n_sentences, (unsigned long long)text_.offsets[text_.n_sentences],
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   G.view.n_sentences = text_.n_sentences;
   G.view.status = text_.status;
   textFetched_ = true;
