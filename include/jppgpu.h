@@ -284,6 +284,38 @@ typedef void (*jppgpu_score_plugin_fn)(void* user, const jppgpu_lattice_nodes* l
 int jppgpu_analyze_batch_plugin(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
                                 jppgpu_score_plugin_fn plugin, void* user, jppgpu_result** out);
 
+/* ScorePlugin::updateScore(lattice, ConnectionPtr, &score) (score_plugin.h:14-19; call sites score_processor.cc:578-613)
+ * per CONNECTION, batched: the plugin sees the built lattice of the batch -- nodes, the right nodes of every boundary and
+ * its ends list (the left nodes) -- and says for every (left node, right node) pair of every boundary what the score of
+ * a connection between the two loses:  penalty[pair_base[bb] + left * bnd_count[bb] + right], left = index into the
+ * boundary's ends list, right = index among the nodes starting there (ConnectionPtr::left / ::right), bb = bnd_base[i] + b.
+ * Applied where applyPluginToPrescores / applyPluginToGbeam act, as ONE subtraction per connection.  What the batched
+ * form cannot express: an amount that depends on the beam slot or the history (ConnectionPtr::beam / ::previous). */
+typedef struct {
+  uint32_t n_sentences;
+  int32_t num_features;
+  const int32_t* status;
+  const uint32_t* n_codepoints;
+  const uint32_t* n_nodes;
+  const uint64_t* node_base;
+  uint64_t total_nodes;
+  const jppgpu_node* nodes;
+  const jppgpu_unk* unk;
+  const int32_t* entry_rows;      /* [total_nodes][num_features] */
+  const uint64_t* bnd_base;       /* [n]; sentence i has n_codepoints[i] + 3 boundaries */
+  uint64_t total_boundaries;
+  const uint32_t* bnd_first;      /* [total_boundaries] first node starting at the boundary (sentence-local) */
+  const uint32_t* bnd_count;      /* right nodes */
+  const uint32_t* end_first;      /* [total_boundaries] offset of the boundary's ends list in end_nodes (sentence-local) */
+  const uint32_t* end_count;      /* left nodes */
+  const uint32_t* end_nodes;      /* [total_nodes] at node_base[i]: sentence-local node ids */
+  const uint64_t* pair_base;      /* [total_boundaries + 1] */
+  uint64_t total_pairs;
+} jppgpu_lattice_pairs;
+typedef void (*jppgpu_connection_plugin_fn)(void* user, const jppgpu_lattice_pairs* lattice, float* penalty /* [total_pairs], zeroed */);
+int jppgpu_analyze_batch_pairs(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                               jppgpu_connection_plugin_fn plugin, void* user, jppgpu_result** out);
+
 /* Trainer hook-up, first half: gold nodes.  The reference's trainer looks at the node seeds of a sentence after the
  * dictionary and UNK makers ran and before the lattice is built, and appends a seed for every node of the gold
  * analysis that is not among them (Trainer::prepare, src/core/training/trainer.cc:13-47;

@@ -275,6 +275,8 @@ struct Batch {
   const PcNode* pc_nodes;
   const PcTag* pc_tags;
   float* node_penalty;     // [node] 0, 1000 or 10000
+  const float* pair_penalty;   // per (boundary, left, right) amount of a per-connection ScorePlugin, or null
+  const u64* pair_base;        // [bb] start of the boundary's L x R matrix in pair_penalty
   // k_sweep<*, 0> only (a boundary with more right nodes than the LDS variants stage): per-sentence slice
   // for the prescores, their sums and the cutoff order
   // normalize maker: a start with more results / traversal states than the per-lane arrays hold (kMaxNormResults /

@@ -424,6 +424,8 @@ struct jppgpu_ctx {
   DevBuf pc_nb_off, pc_nb, pc_b_off, pc_b, pc_node_off, pc_nodes, pc_tags, node_penalty;
   bool partial_pending = false;  // constraints uploaded for the next analyze call
   jppgpu_score_plugin_fn plugin_fn = nullptr;  // host plugin of the next analyze call (jppgpu_analyze_batch_plugin)
+  jppgpu_connection_plugin_fn pair_fn = nullptr;   // per-connection plugin of the next analyze call (jppgpu_analyze_batch_pairs)
+  DevBuf pair_penalty, pair_base;
   void* plugin_user = nullptr;
   jpp_stream_t aux_stream = nullptr;   // the sweep variants of the rare wide sentences run here, beside the main variant
   SyncPoint sweep_fork, sweep_join;
@@ -1115,7 +1117,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
                     &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
-                    &ctx->adj_stack, &ctx->fmt_slots, &ctx->fmt_rows, &ctx->fmt_blob, &ctx->fmt_table, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
+                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_slots, &ctx->fmt_rows, &ctx->fmt_blob, &ctx->fmt_table, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
   for (auto* b : bufs) b->release();
   rt_free(ctx->dmodel);
   rt_stream_destroy(ctx->own_stream);
@@ -1428,6 +1430,86 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
   B.node_penalty = nullptr;
+  B.pair_penalty = nullptr;
+  B.pair_base = nullptr;
+  if (ctx->pair_fn) {
+    // the per-connection ScorePlugin, batched: the plugin sees nodes, right-node ranges and ends lists of every boundary
+    // and fills an L x R matrix of amounts per boundary (k_ends, launched above, wrote the ends lists)
+    jppgpu_connection_plugin_fn fn = ctx->pair_fn;
+    ctx->pair_fn = nullptr;
+    const size_t N = (size_t)B.total_nodes;
+    const size_t NB = bbN;
+    std::vector<i32> h_status(n);
+    std::vector<u32> h_ncp(n), h_nn(n), h_off(n + 1);
+    std::vector<u64> h_base(n + 1), h_bbase(n);
+    std::vector<NodeInfo> h_nodes(N);
+    std::vector<NodeAux> h_aux(N);
+    std::vector<i32> h_rows(N * spec::kNumDicFeatures);
+    std::vector<u32> h_bf(NB), h_bc(NB), h_ef(NB), h_ec(NB), h_en(N);
+    rt_d2h(h_status.data(), B.sent_status, n * 4, st);
+    rt_d2h(h_ncp.data(), B.sent_ncp, n * 4, st);
+    rt_d2h(h_nn.data(), B.sent_nodes, n * 4, st);
+    rt_d2h(h_base.data(), B.node_base, (n + 1) * 8, st);
+    rt_d2h(h_off.data(), B.byte_off, (n + 1) * 4, st);
+    rt_d2h(h_bf.data(), B.bnd_first, NB * 4, st);
+    rt_d2h(h_bc.data(), B.bnd_cnt, NB * 4, st);
+    rt_d2h(h_ef.data(), B.end_first, NB * 4, st);
+    rt_d2h(h_ec.data(), B.end_cnt, NB * 4, st);
+    if (N) {
+      rt_d2h(h_nodes.data(), B.node_info, N * sizeof(NodeInfo), st);
+      rt_d2h(h_aux.data(), B.node_aux, N * sizeof(NodeAux), st);
+      rt_d2h(h_rows.data(), B.node_entry, N * spec::kNumDicFeatures * 4, st);
+      rt_d2h(h_en.data(), B.end_nodes, N * 4, st);
+    }
+    rt_sync(st);
+    std::vector<u64> h_pair(NB + 1, 0);
+    u64 acc = 0;
+    for (u32 q = 0; q < n; ++q) {
+      h_bbase[q] = (u64)h_off[q] + 4ull * q;
+      if (h_status[q] != ST_OK) h_nn[q] = 0;
+    }
+    {
+      // only boundaries of live sentences carry a matrix; the rest of the boundary index space stays empty
+      std::vector<u8> liveB(NB, 0);
+      for (u32 q = 0; q < n; ++q)
+        if (h_status[q] == ST_OK)
+          for (u32 b = 0; b < h_ncp[q] + 3 && h_bbase[q] + b < NB; ++b) liveB[h_bbase[q] + b] = 1;
+      for (size_t bb = 0; bb < NB; ++bb) {
+        h_pair[bb] = acc;
+        if (liveB[bb]) acc += (u64)h_bc[bb] * h_ec[bb];
+      }
+      h_pair[NB] = acc;
+    }
+    jppgpu_lattice_pairs view{};
+    view.n_sentences = n;
+    view.num_features = spec::kNumDicFeatures;
+    view.status = h_status.data();
+    view.n_codepoints = h_ncp.data();
+    view.n_nodes = h_nn.data();
+    view.node_base = h_base.data();
+    view.total_nodes = N;
+    view.nodes = reinterpret_cast<const jppgpu_node*>(h_nodes.data());
+    view.unk = reinterpret_cast<const jppgpu_unk*>(h_aux.data());
+    view.entry_rows = h_rows.data();
+    view.bnd_base = h_bbase.data();
+    view.total_boundaries = NB;
+    view.bnd_first = h_bf.data();
+    view.bnd_count = h_bc.data();
+    view.end_first = h_ef.data();
+    view.end_count = h_ec.data();
+    view.end_nodes = h_en.data();
+    view.pair_base = h_pair.data();
+    view.total_pairs = acc;
+    std::vector<float> pen((size_t)acc, 0.f);
+    fn(ctx->plugin_user, &view, pen.data());
+    if (!(ctx->pair_penalty.ensure((size_t)acc * 4 + 4) && ctx->pair_base.ensure((NB + 1) * 8)))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (connection plugin)");
+    if (acc) rt_h2d(ctx->pair_penalty.p, pen.data(), (size_t)acc * 4, st);
+    rt_h2d(ctx->pair_base.p, h_pair.data(), (NB + 1) * 8, st);
+    rt_sync(st);
+    B.pair_penalty = ctx->pair_penalty.as<float>();
+    B.pair_base = ctx->pair_base.as<u64>();
+  }
   if (ctx->partial_pending) {
     ctx->partial_pending = false;
     if (!ctx->node_penalty.ensure((size_t)B.total_nodes * 4)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (partial)");
@@ -1712,6 +1794,18 @@ extern "C" int jppgpu_analyze_batch_plugin(jppgpu_ctx* ctx, const char* utf8, co
   ctx->plugin_user = user;
   int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
   ctx->plugin_fn = nullptr;
+  return rc;
+}
+
+extern "C" int jppgpu_analyze_batch_pairs(jppgpu_ctx* ctx, const char* utf8, const uint32_t* offsets, uint32_t n,
+                                          jppgpu_connection_plugin_fn plugin, void* user, jppgpu_result** out) {
+  if (!ctx || !offsets || !out || !plugin) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (ctx->cfg.gbeam <= 0)
+    return fail(JPPGPU_INVALID_STATE, "jppgpu: the score plugin acts on global-beam scoring only (as in the reference, analyzer_impl.cc:236-238)");
+  ctx->pair_fn = plugin;
+  ctx->plugin_user = user;
+  int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
+  ctx->pair_fn = nullptr;
   return rc;
 }
 

@@ -831,6 +831,8 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           sc += tsum;
           // applyPluginToPrescores (score_processor.cc:578-596)
           if (B.node_penalty) sc -= B.node_penalty[nb + rfirst + t];
+          // a per-connection plugin: the amount of (left node of head entry i, right node t)
+          if (B.pair_penalty) sc -= B.pair_penalty[B.pair_base[bb0 + b] + (u64)gb_left[i] * R + t];
           pres[(u32)i * R + t] = sc;
         }
       }
@@ -1005,6 +1007,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           // applyPluginToGbeam (score_processor.cc:598-613), then copyT0Scores(tail, resultTail, t0Score)
           float v = res;
           if (B.node_penalty) v -= B.node_penalty[nb + rfirst + t];
+          if (B.pair_penalty) v -= B.pair_penalty[B.pair_base[bb0 + b] + (u64)gb_left[i] * R + t];
           v += t0Of(x);
           cell = v;
           v += gb_score[i];

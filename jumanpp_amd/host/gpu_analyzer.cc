@@ -43,7 +43,21 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
   if (model == nullptr) return Status::InvalidParameter("model was null");
   if (scorer == nullptr) return Status::InvalidParameter("scorer was null");
   // Analyzer::initialize / AnalyzerImpl::initScorers (analyzer.cc:16-36, analyzer_impl.cc:43-89)
-  const int32_t nScorers = scorer->useRnn ? 2 : 1;
+  // ScorerDef::others: the model's RNN (device kernels) first when it is used, then host scorers
+  bool useRnn = scorer->useRnn;
+  std::vector<ScorerFactory*> hostFactories;
+  for (size_t k = 0; k < scorer->others.size(); ++k) {
+    ScorerFactory* f = scorer->others[k];
+    if (f == nullptr) return Status::InvalidParameter("ScorerDef::others holds a null factory");
+    if (f->isModelRnn()) {
+      if (useRnn || k != 0) return Status::NotImplemented("the model's RNN must be the first (and only RNN) entry of ScorerDef::others");
+      useRnn = true;
+    } else {
+      hostFactories.push_back(f);
+    }
+  }
+  if (hostFactories.size() > 2) return Status::NotImplemented("at most two host scorers in ScorerDef::others");
+  const int32_t nScorers = (int32_t)(1 + (useRnn ? 1 : 0) + hostFactories.size());
   if (sconf.numScorers != nScorers) {
     return Status::InvalidParameter() << "number of scorers in ScoringConfig (" << sconf.numScorers
                                       << ") does not match the ScorerDef (" << nScorers << ")";
@@ -62,9 +76,19 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
   c.right_beam = cfg.rightGbeamSize;
   c.max_input_bytes = (int32_t)cfg.maxInputBytes;
   c.device = device;
-  c.use_rnn = scorer->useRnn ? 1 : 0;
+  c.use_rnn = useRnn ? 1 : 0;
   c.weight_perceptron = scorer->scoreWeights[0];
-  c.weight_rnn = scorer->useRnn ? scorer->scoreWeights[1] : 0.f;
+  c.weight_rnn = useRnn ? scorer->scoreWeights[1] : 0.f;
+  c.num_host_scorers = (int32_t)hostFactories.size();
+  for (size_t k = 0; k < hostFactories.size(); ++k) c.weight_host[k] = scorer->scoreWeights[1 + (useRnn ? 1 : 0) + k];
+  // AnalyzerImpl::initScorers: one ScoreComputer instance per factory (analyzer_impl.cc:64-70)
+  hostScorers_.clear();
+  for (ScorerFactory* f : hostFactories) {
+    std::unique_ptr<ScoreComputer> comp;
+    JPPA_RETURN_IF_ERROR(f->makeInstance(&comp));
+    if (!comp) return Status::InvalidState("a ScorerFactory made no ScoreComputer");
+    hostScorers_.push_back(std::move(comp));
+  }
   if (ctx_) {
     releaseResult();
     jppgpu_ctx_destroy(ctx_);
@@ -77,6 +101,11 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
   model_ = model;
   cfg_ = cfg;
   sconf_ = sconf;
+  // ScorerDef::feature: another weight table for the same hashed perceptron (HashedFeaturePerceptron, perceptron.h:75-111)
+  if (scorer->feature != nullptr && scorer->feature->weights != nullptr) {
+    rc = jppgpu_ctx_set_weights(ctx_, scorer->feature->weights, scorer->feature->size);
+    if (rc != JPPGPU_OK) return fromCode(rc);
+  }
   return Status::Ok();
 }
 
@@ -152,6 +181,15 @@ struct PluginCall {
 void pluginTrampoline(void* user, const jppgpu_lattice_nodes* lattice, float* penalty) {
   auto* c = static_cast<PluginCall*>(user);
   c->plugin->nodePenalties(*lattice, *c->ids, penalty);
+}
+
+void pairTrampoline(void* user, const jppgpu_lattice_pairs* lattice, float* penalty) {
+  auto* c = static_cast<PluginCall*>(user);
+  c->plugin->connectionPenalties(*lattice, *c->ids, penalty);
+}
+
+int scorerTrampoline(void* user, const jppgpu_result_view* lattice, uint32_t scorerIdx, float* cells) {
+  return static_cast<ScoreComputer*>(user)->scoreLattice(*lattice, scorerIdx, cells).isOk() ? 0 : 1;
 }
 
 }  // namespace
@@ -241,9 +279,21 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
     const uint32_t ng = (uint32_t)members[g].size();
     double t0 = now();
     PluginCall call{plugin, &members[g]};
-    int rc = pg       ? jppgpu_analyze_batch_partial(ctx_, text.data(), offsets.data(), ng, pg, &G.result)
-             : plugin ? jppgpu_analyze_batch_plugin(ctx_, text.data(), offsets.data(), ng, pluginTrampoline, &call, &G.result)
-                      : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
+    int rc;
+    if (!hostScorers_.empty()) {
+      // ScorerDef::others on the host (no plugin on this path: the reference's plugin acts inside the sweep, the host
+      // scorers after it -- both at once would need the pair matrix AND the scored lattice; not built)
+      if (pg || plugin) return Status::NotImplemented("host scorers together with a score plugin");
+      jppgpu_score_lattice_fn fns[2] = {scorerTrampoline, scorerTrampoline};
+      void* users[2] = {hostScorers_[0].get(), hostScorers_.size() > 1 ? hostScorers_[1].get() : nullptr};
+      rc = jppgpu_analyze_batch_scored(ctx_, text.data(), offsets.data(), ng, fns, users, (uint32_t)hostScorers_.size(), &G.result);
+    } else {
+      rc = pg       ? jppgpu_analyze_batch_partial(ctx_, text.data(), offsets.data(), ng, pg, &G.result)
+           : plugin ? (plugin->perConnection()
+                           ? jppgpu_analyze_batch_pairs(ctx_, text.data(), offsets.data(), ng, pairTrampoline, &call, &G.result)
+                           : jppgpu_analyze_batch_plugin(ctx_, text.data(), offsets.data(), ng, pluginTrampoline, &call, &G.result))
+                    : jppgpu_analyze_batch(ctx_, text.data(), offsets.data(), ng, &G.result);
+    }
     if (rc != JPPGPU_OK) return fromCode(rc);
     double t1 = now();
     tAnalyze += t1 - t0;

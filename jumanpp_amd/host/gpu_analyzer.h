@@ -18,6 +18,7 @@
 #define JUMANPP_AMD_HOST_GPU_ANALYZER_H
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -50,23 +51,73 @@ struct ScoringConfig {
   int32_t numScorers = 1;
 };
 
-// core::analysis::ScorerDef (score_api.h:66-72).  The feature scorer is the model's perceptron;
-// `others` can only hold the model's RNN (useRnn), weighted by scoreWeights like the reference.
-struct ScorerDef {
-  bool useRnn = false;
-  std::vector<float> scoreWeights;
+// core::analysis::ScoreComputer (score_api.h:54-59): a scorer beyond the perceptron.  The reference hands it the
+// pointer-linked Lattice of ONE sentence; here it sees the index-form lattice of a whole batch (the full result view:
+// nodes, ends lists, global beams, beams, cells) and writes its slot of the score cells,
+//     cells[((node_base[i] + node) * global_beam + gbeamIndex) * num_scorers + scorerIdx],
+// for the connections it scores -- what the reference's scorer does through
+// scores->nodeScores(right).beamLeft(beam, left).at(scorerIdx).
+class ScoreComputer {
+ public:
+  virtual ~ScoreComputer() = default;
+  virtual Status scoreLattice(const jppgpu_result_view& lattice, uint32_t scorerIdx, float* cells) = 0;
 };
 
-// core::analysis::ScorePlugin (score_plugin.h:14-19) in its batched form: the reference asks the plugin for
-// every scored connection (updateScore(lattice, connection, &score)); here the plugin sees the built lattice
-// of a batch once and says per node what every connection INTO that node loses (jppgpu_analyze_batch_plugin).
+// core::analysis::ScorerFactory (score_api.h:61-64)
+class ScorerFactory {
+ public:
+  virtual ~ScorerFactory() = default;
+  virtual Status makeInstance(std::unique_ptr<ScoreComputer>* result) = 0;
+  // the model's own RNN (RnnScorerGbeamFactory): scored by the device kernels, no ScoreComputer instance is made
+  virtual bool isModelRnn() const { return false; }
+};
+
+// the RnnHolder's scorer factory (src/core/analysis/rnn_scorer_gbeam.h): stands for the RNN part of the loaded model
+class ModelRnnScorerFactory : public ScorerFactory {
+ public:
+  Status makeInstance(std::unique_ptr<ScoreComputer>*) override { return Status::Ok(); }
+  bool isModelRnn() const override { return true; }
+};
+
+// core::analysis::FeatureScorer as far as a device can honour it (score_api.h:44-52): the hashed perceptron IS its weight
+// table (HashedFeaturePerceptron, perceptron.h:75-111); a table given here replaces the model's (same size).
+struct FeatureScorer {
+  const float* weights = nullptr;   // null: the model's own table
+  size_t size = 0;
+};
+
+// core::analysis::ScorerDef (score_api.h:66-72): `feature` (null = the model's perceptron), the other scorers in order,
+// one weight per scorer.  The model's RNN, when used, must be others[0] (its cells are slot 1 on the device); any other
+// factory makes a host ScoreComputer that is called once per batch (jppgpu_analyze_batch_scored), after which the device
+// re-makes the beam totals and the EOS beam from the weighted cells like adjustBeamScores / remakeEosBeam.
+// `useRnn = true` is shorthand for "others starts with the model's RNN" (the CLI's only case).
+struct ScorerDef {
+  bool useRnn = false;
+  const FeatureScorer* feature = nullptr;
+  std::vector<ScorerFactory*> others;
+  std::vector<float> scoreWeights;
+  int32_t numScorers() const { return (int32_t)(1 + (useRnn ? 1 : 0) + others.size()); }
+};
+
+// core::analysis::ScorePlugin (score_plugin.h:14-19) in its batched forms.  The reference asks the plugin for every scored
+// connection (updateScore(lattice, connection, &score)); here the plugin sees the built lattice of a batch once and says
+//   nodePenalties:        per node, what every connection INTO that node loses (jppgpu_analyze_batch_plugin), or
+//   connectionPenalties:  per (left node, right node) pair of every boundary, what a connection between the two loses
+//                         (jppgpu_analyze_batch_pairs; perConnection() must return true).
+// One subtraction per connection; an amount that depends on the beam slot or the path history cannot be expressed.
 class ScorePlugin {
  public:
   virtual ~ScorePlugin() = default;
+  virtual bool perConnection() const { return false; }
   // lattice.n_sentences sentences in the order of the batch (or of one beam group of it, see groupSentences);
   // penalty[lattice.node_base[i] + k] belongs to node k of sentence i and arrives zeroed
-  virtual void nodePenalties(const jppgpu_lattice_nodes& lattice, const std::vector<uint32_t>& sentenceIds,
-                             float* penalty) = 0;
+  virtual void nodePenalties(const jppgpu_lattice_nodes& lattice, const std::vector<uint32_t>& sentenceIds, float* penalty) {
+    (void)lattice; (void)sentenceIds; (void)penalty;
+  }
+  // penalty[lattice.pair_base[bb] + left * lattice.bnd_count[bb] + right], zeroed
+  virtual void connectionPenalties(const jppgpu_lattice_pairs& lattice, const std::vector<uint32_t>& sentenceIds, float* penalty) {
+    (void)lattice; (void)sentenceIds; (void)penalty;
+  }
 };
 
 // the formatted text of one batch, detached from the analyzer that produced it (host copies of a result stay valid
@@ -132,6 +183,7 @@ class GpuAnalyzer {
   std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
   AnalyzerConfig cfg_;
   ScoringConfig sconf_;
+  std::vector<std::unique_ptr<ScoreComputer>> hostScorers_;   // ScorerDef::others that are not the model's RNN
   std::vector<StringPiece> inputs_;
   mutable std::vector<uint32_t> cpOffsets_;  // concatenated per-sentence codepoint -> byte offset tables
   mutable std::vector<uint8_t> cpOffsetsReady_;

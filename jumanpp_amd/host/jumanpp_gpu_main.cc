@@ -739,14 +739,34 @@ int main(int argc, const char** argv) {
           const long long t0 = us();
           const char* q = p;
           size_t examples = 0;
+          std::unique_ptr<ShardJob> job(new ShardJob());
+          job->inputs.reserve(conf.batch);
+          job->comments.reserve(conf.batch);
+          StringPiece comment("", 0);
+          // one pass over the lines: the batch is cut here AND split into its examples (the device threads used to walk
+          // the same bytes a second time, 1.1 ms per batch on the thread that feeds the GPU)
           while (q < end && examples < conf.batch) {
             const char* nl = static_cast<const char*>(memchr(q, '\n', (size_t)(end - q)));
             const char* lineEnd = nl ? nl : end;
-            const bool comment = lineEnd - q > 2 && q[0] == '#' && q[1] == ' ';
+            const StringPiece line(q, (size_t)(lineEnd - q));
             q = nl ? nl + 1 : end;
-            if (!comment || q >= end) ++examples;   // (comment lines at the end of a file: an example with an empty input)
+            if (line.size() > 2 && line[0] == '#' && line[1] == ' ') {
+              comment = line;
+              if (q < end) continue;
+              job->inputs.push_back(StringPiece("", 0));   // comment lines at the end of a file: an example with an empty input
+            } else {
+              job->inputs.push_back(line);
+            }
+            job->comments.push_back(comment);
+            const size_t i = job->inputs.size() - 1;
+            if (comment.size() > maxComment)
+              job->readErrors.emplace_back(i, Status::InvalidParameter() << "Comment size was: " << comment.size() << " which is more than max: " << maxComment);
+            else if (job->inputs[i].size() > maxInput)
+              job->readErrors.emplace_back(i, Status::InvalidParameter() << "Input size was: " << job->inputs[i].size() << " which is more than max: " << maxInput);
+            comment = StringPiece("", 0);
+            ++examples;
           }
-          std::unique_ptr<ShardJob> job(new ShardJob());
+          job->lastReadOk = job->readErrors.empty() || job->readErrors.back().first + 1 != job->inputs.size();
           job->seq = seq;
           job->data = p;
           job->bytes = (size_t)(q - p);
@@ -768,32 +788,6 @@ int main(int argc, const char** argv) {
         int next = 0, live = nAnalyzers;
         while (readQ[d]->pop(&job)) {
           long long t0 = us();
-          {
-            const char* q = job->data;
-            const char* const end = job->data + job->bytes;
-            StringPiece comment("", 0);
-            while (q < end) {
-              const char* nl = static_cast<const char*>(memchr(q, '\n', (size_t)(end - q)));
-              const char* lineEnd = nl ? nl : end;
-              const StringPiece line(q, (size_t)(lineEnd - q));
-              q = nl ? nl + 1 : end;
-              if (line.size() > 2 && line[0] == '#' && line[1] == ' ') {
-                comment = line;
-                if (q < end) continue;
-                job->inputs.push_back(StringPiece("", 0));   // comment lines at the end of the file
-              } else {
-                job->inputs.push_back(line);
-              }
-              job->comments.push_back(comment);
-              const size_t i = job->inputs.size() - 1;
-              if (comment.size() > maxComment)
-                job->readErrors.emplace_back(i, Status::InvalidParameter() << "Comment size was: " << comment.size() << " which is more than max: " << maxComment);
-              else if (job->inputs[i].size() > maxInput)
-                job->readErrors.emplace_back(i, Status::InvalidParameter() << "Input size was: " << job->inputs[i].size() << " which is more than max: " << maxInput);
-              comment = StringPiece("", 0);
-            }
-            job->lastReadOk = job->readErrors.empty() || job->readErrors.back().first + 1 != job->inputs.size();
-          }
           prepUs += us() - t0;
           freeAnalyzers[d]->acquire();
           job->analyzer = next;
@@ -970,41 +964,60 @@ int main(int argc, const char** argv) {
 
     std::atomic<bool> writeFailed(false);
     std::vector<std::thread> writers;
+    // A batch is 150 MB of text: one thread copies that into the page cache in ~20 ms -- longer than the GPU needs for the
+    // batch (profiles/r04_g_cli_stages.txt: the writer was the slowest stage at 3.1 M sentences/s).  The writer of a device
+    // hands out byte ranges of the batch to a few helpers; every range is written at its own file offset.
+    const int writeHelpers = std::max(1, std::min(4, conf.threads / std::max(1, nDev)));
     for (int d = 0; d < nDev; ++d) {
       writers.emplace_back([&, d]() {
+        WorkerPool pool(writeHelpers);
         std::unique_ptr<ShardJob> job;
         while (writeQ[d]->pop(&job)) {
           const long long t0 = us();
-          uint64_t off = job->outOffset;
-          for (size_t k = 0; k < job->segments.size() && !writeFailed;) {
-            // pwritev takes at most IOV_MAX segments and may write less than it was given
-            const size_t cnt = std::min<size_t>(job->segments.size() - k, 1024);
-            ssize_t w = pwritev(ofd, job->segments.data() + k, (int)cnt, (off_t)off);
-            if (w <= 0) {
-              writeFailed = true;
-              break;
-            }
-            off += (uint64_t)w;
-            size_t left = (size_t)w;
-            while (k < job->segments.size() && left >= job->segments[k].iov_len) left -= job->segments[k++].iov_len;
-            if (left > 0) {
-              job->segments[k].iov_base = static_cast<char*>(job->segments[k].iov_base) + left;
-              job->segments[k].iov_len -= left;
-            }
-          }
-          job->deviceText.reset();   // the text block goes back to its analyzer's pool
-          for (auto& t : job->text) {
-            size_t done = 0;
-            while (done < t.size()) {
-              ssize_t w = pwrite(ofd, t.data() + done, t.size() - done, (off_t)(off + done));
+          // the host formatters' chunks are segments like the device text's
+          if (job->segments.empty())
+            for (auto& t : job->text)
+              if (!t.empty()) {
+                struct iovec v;
+                v.iov_base = const_cast<char*>(t.data());
+                v.iov_len = t.size();
+                job->segments.push_back(v);
+              }
+          const std::vector<struct iovec>& segs = job->segments;
+          std::vector<uint64_t> start(segs.size() + 1, 0);
+          for (size_t k = 0; k < segs.size(); ++k) start[k + 1] = start[k] + segs[k].iov_len;
+          const uint64_t total = start[segs.size()];
+          const uint64_t base = job->outOffset;
+          pool.run([&](int t) {
+            const uint64_t lo = total * (uint64_t)t / (uint64_t)writeHelpers, hi = total * (uint64_t)(t + 1) / (uint64_t)writeHelpers;
+            if (lo >= hi) return;
+            size_t k = (size_t)(std::upper_bound(start.begin(), start.end(), lo) - start.begin()) - 1;
+            uint64_t pos = lo;
+            while (pos < hi && !writeFailed) {
+              // pwritev takes at most IOV_MAX segments and may write less than it was given
+              struct iovec part[256];
+              int cnt = 0;
+              uint64_t p2 = pos;
+              size_t k2 = k;
+              while (cnt < 256 && p2 < hi && k2 < segs.size()) {
+                const uint64_t inSeg = p2 - start[k2];
+                const uint64_t len = std::min<uint64_t>(segs[k2].iov_len - inSeg, hi - p2);
+                part[cnt].iov_base = static_cast<char*>(segs[k2].iov_base) + inSeg;
+                part[cnt].iov_len = (size_t)len;
+                ++cnt;
+                p2 += len;
+                ++k2;
+              }
+              const ssize_t w = pwritev(ofd, part, cnt, (off_t)(base + pos));
               if (w <= 0) {
                 writeFailed = true;
-                break;
+                return;
               }
-              done += (size_t)w;
+              pos += (uint64_t)w;
+              while (k < segs.size() && start[k + 1] <= pos) ++k;
             }
-            off += t.size();
-          }
+          });
+          job->deviceText.reset();   // the text block goes back to its analyzer's pool
           writeUs += us() - t0;
         }
       });

@@ -44,7 +44,7 @@ class Config(C.Structure):
     _fields_ = [('struct_size', C.c_uint32), ('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
                 ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32),
                 ('use_rnn', C.c_int32), ('weight_perceptron', C.c_float), ('weight_rnn', C.c_float),
-                ('dynamic_features', C.c_int32)]
+                ('dynamic_features', C.c_int32), ('num_host_scorers', C.c_int32), ('weight_host', C.c_float * 2)]
 
 
 class ResultView(C.Structure):
@@ -84,6 +84,18 @@ class ExtraSeeds(C.Structure):
 
 
 SEED_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(SeedView), C.POINTER(ExtraSeeds))
+
+
+class LatticePairs(C.Structure):
+    _fields_ = [('n_sentences', C.c_uint32), ('num_features', C.c_int32), ('status', C.c_void_p), ('n_codepoints', C.c_void_p),
+                ('n_nodes', C.c_void_p), ('node_base', C.c_void_p), ('total_nodes', C.c_uint64), ('nodes', C.c_void_p),
+                ('unk', C.c_void_p), ('entry_rows', C.c_void_p), ('bnd_base', C.c_void_p), ('total_boundaries', C.c_uint64),
+                ('bnd_first', C.c_void_p), ('bnd_count', C.c_void_p), ('end_first', C.c_void_p), ('end_count', C.c_void_p),
+                ('end_nodes', C.c_void_p), ('pair_base', C.c_void_p), ('total_pairs', C.c_uint64)]
+
+
+SCORE_LATTICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(ResultView), C.c_uint32, C.c_void_p)
+CONNECTION_PLUGIN_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(LatticePairs), C.c_void_p)
 EXTRA_SEED_DT = np.dtype([('start', '<u2'), ('end', '<u2'), ('hash', '<i4'), ('row', '<i4', (8,))])
 
 NODE_DT = np.dtype([('eptr', '<i4'), ('start', '<u2'), ('end', '<u2')])
@@ -115,6 +127,10 @@ def load_library(path=None):
     lib.jppgpu_result_fetch_top1_ngrams.argtypes = [C.c_void_p, C.POINTER(NgramsView)]
     lib.jppgpu_ctx_set_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.jppgpu_analyze_batch_seeds.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, SEED_HOOK, C.c_void_p,
+                                               C.POINTER(C.c_void_p)]
+    lib.jppgpu_analyze_batch_scored.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(SCORE_LATTICE_FN), C.c_void_p,
+                                                C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.jppgpu_analyze_batch_pairs.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, CONNECTION_PLUGIN_FN, C.c_void_p,
                                                C.POINTER(C.c_void_p)]
     lib.jppgpu_result_fetch_path_ngrams.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NgramsView)]
     lib.jppgpu_result_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -260,7 +276,8 @@ class Context:
 
     def __init__(self, image_path, beam=5, global_beam=6, right_check=1, right_beam=5,
                  max_input_bytes=4096, device=0, lib_path=None, use_rnn=None,
-                 weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None, dynamic_features=False, max_unk_makers=None):
+                 weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None, dynamic_features=False, max_unk_makers=None,
+                 host_scorer_weights=()):
         """use_rnn=None: run the RNN scorer iff the model image has an RNN part (what
         JumanppEnv::loadModel does); the score weights default to the model's saved
         RnnInferenceConfig (env.cc:86-100)."""
@@ -334,7 +351,8 @@ class Context:
         if weight_rnn is not None:
             wr = weight_rnn
         cfg = Config(C.sizeof(Config), beam, global_beam, right_check, right_beam, max_input_bytes, device,
-                     1 if use_rnn else 0, wp, wr, 1 if dynamic_features else 0)
+                     1 if use_rnn else 0, wp, wr, 1 if dynamic_features else 0, len(host_scorer_weights),
+                     (C.c_float * 2)(*(list(host_scorer_weights) + [0.0, 0.0])[:2]))
         h = C.c_void_p()
         rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -402,6 +420,79 @@ class Context:
             raise keep['error']
         if rc != 0:
             raise JppGpuError('jppgpu_analyze_batch_seeds failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+        return Result(self, r)
+
+    def _pack(self, sentences):
+        enc = [s.encode('utf-8') if isinstance(s, str) else bytes(s) for s in sentences]
+        offs = np.zeros(len(enc) + 1, dtype=np.uint32)
+        if enc:
+            offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64).astype(np.uint32)
+        return b''.join(enc), offs, len(enc)
+
+    def analyze_scored(self, sentences, scorers):
+        """jppgpu_analyze_batch_scored: `scorers` = one callable per host scorer of the context (host_scorer_weights),
+        called as f(lattice, scorer_idx, cells) with `lattice` a dict of numpy views of the full result view and `cells`
+        the writable [total_nodes, global_beam, num_scorers] float32 array"""
+        text, offs, n = self._pack(sentences)
+        keep = []
+
+        def wrap(f):
+            def c_fn(_user, view_p, idx, cells_p):
+                v = view_p.contents
+                N, NB, G, S = v.total_nodes, v.total_boundaries, v.global_beam, v.num_scorers
+
+                def arr(ptr, dt, cnt):
+                    if not ptr or cnt == 0:
+                        return np.zeros(0, dtype=dt)
+                    return np.frombuffer((C.c_char * (np.dtype(dt).itemsize * cnt)).from_address(ptr), dtype=dt, count=cnt)
+                lat = dict(n=v.n_sentences, beam=v.beam, gbeam=G, nscorers=S, status=arr(v.status, '<i4', v.n_sentences),
+                           ncp=arr(v.n_codepoints, '<u4', v.n_sentences), nnodes=arr(v.n_nodes, '<u4', v.n_sentences),
+                           node_base=arr(v.node_base, '<u8', v.n_sentences), bnd_base=arr(v.bnd_base, '<u8', v.n_sentences),
+                           nodes=arr(v.nodes, NODE_DT, N), bnd_first=arr(v.bnd_first, '<u4', NB), bnd_count=arr(v.bnd_count, '<u4', NB),
+                           end_first=arr(v.end_first, '<u4', NB), end_count=arr(v.end_count, '<u4', NB), end_nodes=arr(v.end_nodes, '<u4', N),
+                           gbeam_count=arr(v.gbeam_count, '<u4', NB), gbeam_entries=arr(v.gbeam, GBEAM_DT, NB * G).reshape(-1, G),
+                           beams=arr(v.beams, BEAM_DT, N * v.beam).reshape(-1, v.beam))
+                cells = np.frombuffer((C.c_char * (4 * N * G * S)).from_address(cells_p), dtype='<f4', count=N * G * S).reshape(N, G, S)
+                try:
+                    f(lat, int(idx), cells)
+                    return 0
+                except Exception:   # noqa: BLE001 -- reported through the ABI's error path
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return SCORE_LATTICE_FN(c_fn)
+        fns = (SCORE_LATTICE_FN * len(scorers))(*[wrap(f) for f in scorers])
+        keep.append(fns)
+        r = C.c_void_p()
+        rc = self.lib.jppgpu_analyze_batch_scored(self.handle, text, offs.ctypes.data, n, fns, None, len(scorers), C.byref(r))
+        if rc != 0:
+            raise JppGpuError('jppgpu_analyze_batch_scored failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+        return Result(self, r)
+
+    def analyze_pairs(self, sentences, plugin):
+        """jppgpu_analyze_batch_pairs: plugin(lattice, penalty) fills the float32 array `penalty` [total_pairs]"""
+        text, offs, n = self._pack(sentences)
+
+        def c_fn(_user, view_p, pen_p):
+            v = view_p.contents
+            N, NB = v.total_nodes, v.total_boundaries
+
+            def arr(ptr, dt, cnt):
+                if not ptr or cnt == 0:
+                    return np.zeros(0, dtype=dt)
+                return np.frombuffer((C.c_char * (np.dtype(dt).itemsize * cnt)).from_address(ptr), dtype=dt, count=cnt)
+            lat = dict(n=v.n_sentences, status=arr(v.status, '<i4', v.n_sentences), ncp=arr(v.n_codepoints, '<u4', v.n_sentences),
+                       nnodes=arr(v.n_nodes, '<u4', v.n_sentences), node_base=arr(v.node_base, '<u8', v.n_sentences),
+                       bnd_base=arr(v.bnd_base, '<u8', v.n_sentences), nodes=arr(v.nodes, NODE_DT, N),
+                       bnd_first=arr(v.bnd_first, '<u4', NB), bnd_count=arr(v.bnd_count, '<u4', NB), end_first=arr(v.end_first, '<u4', NB),
+                       end_count=arr(v.end_count, '<u4', NB), end_nodes=arr(v.end_nodes, '<u4', N), pair_base=arr(v.pair_base, '<u8', NB + 1))
+            pen = arr(pen_p, '<f4', v.total_pairs)
+            plugin(lat, pen)
+        cb = CONNECTION_PLUGIN_FN(c_fn)
+        r = C.c_void_p()
+        rc = self.lib.jppgpu_analyze_batch_pairs(self.handle, text, offs.ctypes.data, n, cb, None, C.byref(r))
+        if rc != 0:
+            raise JppGpuError('jppgpu_analyze_batch_pairs failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
         return Result(self, r)
 
     def analyze_device(self, d_text_ptr, d_offsets_ptr, n, total_bytes, stream=None):

@@ -37,6 +37,10 @@
 //       records {i32 EntryPtr raw, u16 start, u16 end} in text order (EOS dropped) -- the layout of jppgpu_result_pack.
 //       UNK nodes carry the reference's own EntryPtr (creation-order numbering, extra_nodes.cc:41-52).  Checker of
 //       the at-scale parity tests and of bench.py's parity_sample.
+//   ref_dump top1x   <model.jppmdl> <out.bin> <scorer-weight|none> <plugin 0|1> [beam gbeam rcheck rbeam] < corpus
+//       `top1` with a TEST ScoreComputer appended to ScorerDef::others (weight given) and / or a TEST per-connection
+//       ScorePlugin passed to Analyzer::analyze; also writes <out.bin>.totals (EOS beam totals).  Checker of
+//       jppgpu_analyze_batch_scored / jppgpu_analyze_batch_pairs.
 //   ref_dump time    <model.jppmdl> [beam gbeam rcheck rbeam] < corpus
 //       wall-clock of Analyzer::analyze (+JumanFormat) over the corpus, phases split
 //       as BASELINE.md section 3.
@@ -785,6 +789,146 @@ int doTop1(const char* modelFile, const char* out, char** extra, int nextra) {
   return 0;
 }
 
+// ---- top1x: the reference with a TEST scorer in ScorerDef::others and / or a TEST ScorePlugin ---------------------------
+// The checker of jppgpu_analyze_batch_scored and jppgpu_analyze_batch_pairs.
+//
+// Test scorer (a ScoreComputer, score_api.h:54-59): for every boundary b >= 2 with nodes, every right node r and every
+// element i of the boundary's global beam, the cell of (r, i) gets
+//     -0.25 * [left node is special] - 0.0625 * (codepoints of the left node) + 0.125 * [right node is special]
+// (dyadic values: exact in float).  Test plugin (score_plugin.h:14-19): every connection whose LEFT node is special
+// loses 1, every connection into a node of more than two codepoints whose left node starts at an odd position loses 0.5.
+namespace {
+struct TestScorer : public ScoreComputer {
+  Status scoreLattice(Lattice* l, const ExtraNodesContext*, u32 scorerIdx) override {
+    const u32 nb = l->createdBoundaryCount();
+    for (u32 b = 2; b < nb; ++b) {
+      auto bnd = l->boundary(b);
+      const u32 R = bnd->localNodeCount();
+      if (R == 0) continue;
+      auto ends = bnd->ends()->nodePtrs();
+      auto gbeam = bnd->ends()->globalBeam();
+      for (auto el : gbeam) {
+        // (left, beam) of the element: its node's place in this boundary's ends list, its slot in that node's beam
+        i32 left = -1;
+        for (u32 q = 0; q < ends.size(); ++q)
+          if (ends.at(q).boundary == el->ptr.boundary && ends.at(q).position == el->ptr.right) left = (i32)q;
+        if (left < 0) return JPPS_INVALID_STATE << "test scorer: gbeam element outside the ends list";
+        auto lstarts = l->boundary(el->ptr.boundary)->starts();
+        auto row = lstarts->beamData().row(el->ptr.right);
+        const i32 beam = (i32)(el - row.begin());
+        auto& lni = lstarts->nodeInfo().at(el->ptr.right);
+        for (u32 r = 0; r < R; ++r) {
+          auto& rni = bnd->starts()->nodeInfo().at(r);
+          float v = 0.f;
+          if (lni.entryPtr().isSpecial()) v -= 0.25f;
+          v -= 0.0625f * (float)(lni.end() - lni.start());
+          if (rni.entryPtr().isSpecial()) v += 0.125f;
+          bnd->scores()->nodeScores((i32)r).beamLeft(beam, left).at(scorerIdx) = v;
+        }
+      }
+    }
+    return Status::Ok();
+  }
+};
+struct TestScorerFactory : public ScorerFactory {
+  Status load(const model::ModelInfo&) override { return Status::Ok(); }
+  Status makeInstance(std::unique_ptr<ScoreComputer>* result) override {
+    result->reset(new TestScorer());
+    return Status::Ok();
+  }
+};
+struct TestPlugin : public ScorePlugin {
+  bool updateScore(const Lattice* l, const ConnectionPtr& ptr, float* score) const override {
+    auto bnd = l->boundary(ptr.boundary);
+    auto& lp = bnd->ends()->nodePtrs().at(ptr.left);
+    auto& lni = l->boundary(lp.boundary)->starts()->nodeInfo().at(lp.position);
+    auto& rni = bnd->starts()->nodeInfo().at(ptr.right);
+    // ONE subtraction per connection: the batched form of the hook hands the device an amount per connection
+    float amount = 0.f;
+    if (lni.entryPtr().isSpecial()) amount += 1.0f;
+    if (rni.end() - rni.start() > 2 && (lni.start() & 1) != 0) amount += 0.5f;
+    if (amount == 0.f) return false;
+    *score -= amount;
+    return true;
+  }
+};
+}  // namespace
+
+// ref_dump top1x <model> <out.bin> <scorer-weight|none> <plugin 0|1> [beam gbeam rcheck rbeam] < corpus
+int doTop1x(const char* modelFile, const char* out, const char* scorerW, const char* usePlugin, char** extra, int nextra) {
+  Env e;
+  e.init(modelFile, extra, nextra);
+  ScorerDef def = *e.env.scorers();
+  TestScorerFactory factory;
+  if (std::string(scorerW) != "none") {
+    def.others.push_back(&factory);
+    def.scoreWeights.push_back((float)atof(scorerW));
+  }
+  AnalyzerConfig ac;
+  ac.globalBeamSize = e.gbeam;
+  ac.rightGbeamCheck = e.rcheck;
+  ac.rightGbeamSize = e.rbeam;
+  ScoringConfig sc{e.beam, (i32)def.scoreWeights.size()};
+  Analyzer an;
+  CHECK_OK(an.initialize(e.env.coreHolder(), ac, sc, &def));
+  TestPlugin plugin;
+  const bool withPlugin = atoi(usePlugin) != 0;
+  std::vector<std::string> lines;
+  std::string line;
+  while (std::getline(std::cin, line)) lines.push_back(line);
+  Writer w;
+  w.put<u32>(0x31504f54u);  // "TOP1": the layout of `top1`, plus the EOS beam totals (float bits) behind every path
+  w.put<u32>((u32)lines.size());
+  std::vector<const ConnectionPtr*> path;
+  for (auto& l : lines) {
+    Status st = an.analyze(l, withPlugin ? &plugin : nullptr);
+    if (!st) {
+      w.put<u32>(1);
+      w.put<u32>(0);
+      continue;
+    }
+    auto* lat = an.impl()->lattice();
+    const int last = (int)lat->createdBoundaryCount() - 1;
+    path.clear();
+    const ConnectionBeamElement& top = lat->boundary(last)->starts()->beamData().row(0).at(0);
+    const ConnectionPtr* p = (last <= 2 || EntryBeam::isFake(top)) ? nullptr : top.ptr.previous;
+    while (p != nullptr && p->boundary >= 2) {
+      path.push_back(p);
+      p = p->previous;
+    }
+    w.put<u32>(0);
+    w.put<u32>((u32)path.size());
+    for (size_t k = path.size(); k-- > 0;) {
+      auto& ni = lat->boundary(path[k]->boundary)->starts()->nodeInfo().at(path[k]->right);
+      w.put<i32>(ni.entryPtr().rawValue());
+      w.put<u16>(ni.start());
+      w.put<u16>(ni.end());
+    }
+  }
+  w.save(out);
+  // second file: the EOS beam totals of every sentence (beam floats, fake slots as 0)
+  {
+    Writer t;
+    t.put<u32>((u32)lines.size());
+    t.put<u32>((u32)e.beam);
+    for (auto& l : lines) {
+      Status st = an.analyze(l, withPlugin ? &plugin : nullptr);
+      auto* lat = an.impl()->lattice();
+      const int last = (int)lat->createdBoundaryCount() - 1;
+      for (int k = 0; k < e.beam; ++k) {
+        float v = 0.f;
+        if (st && last > 2) {
+          auto& el = lat->boundary(last)->starts()->beamData().row(0).at(k);
+          if (!EntryBeam::isFake(el)) v = el.totalScore;
+        }
+        t.put<float>(v);
+      }
+    }
+    t.save((std::string(out) + ".totals").c_str());
+  }
+  return 0;
+}
+
 int doTime(const char* modelFile, char** extra, int nextra) {
   Env e;
   e.init(modelFile, extra, nextra);
@@ -1219,6 +1363,7 @@ int main(int argc, char** argv) {
   if (cmd == "shim" && argc >= 5) return doShim(argv[2], argv[3], atoi(argv[4]), argv + 5, argc - 5);
   if (cmd == "ngrams" && argc >= 4) return doNgrams(argv[2], argv[3], argv + 4, argc - 4);
   if (cmd == "top1" && argc >= 4) return doTop1(argv[2], argv[3], argv + 4, argc - 4);
+  if (cmd == "top1x" && argc >= 6) return doTop1x(argv[2], argv[3], argv[4], argv[5], argv + 6, argc - 6);
   if (cmd == "bootstrapv" && argc == 5) return doBootstrapVariant(argv[2], argv[3], argv[4]);
   std::cerr << "bad arguments\n";
   return 2;
