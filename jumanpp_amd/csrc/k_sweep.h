@@ -371,6 +371,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   // comparison of the step-by-step sort costs one LDS read per side instead of two dependent ones
   __shared__ u64 skey[GM > 16 ? kChunk : 1][GM];
   __shared__ u8 shave[GM > 16 ? kChunk : 1];   // per node of the pass: length of the sorted range | 0x80 if already in final order
+  __shared__ u8 sreplay[GM > 16 ? kChunk : 1];  // per node of the pass: its totals tie, the sort is replayed
   __shared__ float t0R[kChunk];
   // static data of a boundary, fetched asynchronously (global_load_lds) while the previous boundary is
   // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
@@ -1034,6 +1035,10 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         // order is the unique descending one, so the parallel rank below IS makeT0Beam's result.  Only a
         // node that holds two equal totals replays the two algorithms step by step on one lane.
         static_assert(GM == 32, "one half-wave per right node");
+        // Three passes over the nodes of the chunk (round 4; until then the replay ran inside the rank loop, two nodes
+        // per iteration, i.e. up to four serial replays one after the other per chunk): A ranks and ties, nodes without
+        // a tie write their beams; B every node that needs the replay runs it at once, ONE LANE PER NODE; C the parallel
+        // stable rank of the partitioned keys.
         for (int q0 = 0; q0 < nx * GM; q0 += 64) {
           const int q = q0 + lane;
           const bool in = q < nx * GM;
@@ -1056,74 +1061,88 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           }
           const u64 tb = wave_ballot(wide && tie);
           const bool replay = wide && ((tb >> (lane & 32)) & 0xffffffffull) != 0;
-          // Ties: one lane replays the partitioning steps of the reference's sort (util::partition beyond
-          // beam*4/3, then the Hoare partitions of introsort while a range is longer than 16).  What follows
-          // in std::sort is libstdc++'s final insertion pass, a STABLE sort of the array as partitioned -- i.e.
-          // a rank again: greater totals first, equal totals in their order after partitioning -- taken in
-          // parallel by the node's 32 lanes below (std_sort_partition_only, jpp_select.h).
-          if (replay && i == 0) {
-            u64* keys = skey[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
-            const float* tr = tot[x];
-            // the reference sorts indices with `scores[i1] > scores[i2]`: the same predicate on the packed totals
-            auto comp = [](u64 a, u64 bb) {
-              const u32 xa = (u32)(a >> 32), xb = (u32)(bb >> 32);
-              float fa, fb;
-              __builtin_memcpy(&fa, &xa, 4);
-              __builtin_memcpy(&fb, &xb, 4);
-              return fa > fb;
-            };
-            auto fill = [&]() {
-              for (int z = 0; z < cnt; ++z) {
-                u32 bits;
-                __builtin_memcpy(&bits, &tr[z], 4);
-                keys[z] = ((u64)bits << 32) | (u32)z;
-              }
-            };
-            fill();
-            u64* itr = keys + cnt;
-            if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
-            bool sorted = false;
-            static_assert(GM <= 32, "stackless partition replay covers at most 32 candidates");
-            if (!std_sort_partition_only_le32(keys, itr, comp)) {
-              // depth limit of introsort hit (heap-sort fallback, not stable): replay all of it from the start
-              fill();
-              itr = keys + cnt;
-              if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
-              std_sort(keys, itr, comp);
-              sorted = true;
+          if (in && i == 0) sreplay[x] = replay ? 1 : 0;
+          if (!replay) {
+            if (i < cnt) {
+              if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
+            } else if (i < beam) {
+              row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
             }
-            shave[x] = (u8)((itr - keys) | (sorted ? 0x80 : 0));
-          }
-          wave_sync();
-          if (replay) {
-            const int have = shave[x] & 0x7f;
-            const bool sorted = (shave[x] & 0x80) != 0;
-            if (i < have) {
-              const u64 mine = skey[x][i];
-              const u32 vb = (u32)(mine >> 32);
-              float mv;
-              __builtin_memcpy(&mv, &vb, 4);
-              int pos = i;
-              if (!sorted) {
-                pos = 0;
-                for (int p2 = 0; p2 < have; ++p2) {
-                  const u32 ob = (u32)(skey[x][p2] >> 32);
-                  float ov;
-                  __builtin_memcpy(&ov, &ob, 4);
-                  if (ov > mv || (ov == mv && p2 < i)) ++pos;
-                }
-              }
-              const u32 iz = (u32)mine & 0xffu;
-              if (pos < beam) row[pos] = BeamSlot{gb_left[iz], gb_slot[iz], mv, gb_lnode[iz], iz};
-            }
-            // slots beyond the sorted range stay fake (have >= beam whenever util::partition ran)
-            if (i >= have && i < beam) row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
-          } else if (i < cnt) {
-            if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
-          } else if (i < beam) {
-            row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
           }
           if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
+        }
+        wave_sync();
+        // B. Ties: the partitioning steps of the reference's sort (util::partition beyond beam*4/3, then the Hoare
+        // partitions of introsort while a range is longer than 16), replayed step by step.  What follows in std::sort is
+        // libstdc++'s final insertion pass, a STABLE sort of the array as partitioned -- i.e. a rank again: greater
+        // totals first, equal totals in their order after partitioning (std_sort_partition_only, jpp_select.h).
+        if (lane < nx && sreplay[lane] != 0) {
+          const int x = lane;
+          const bool kept = (op0 + x) < K;
+          const int cnt = kept ? ngb : c;
+          u64* keys = skey[x];   // in LDS: as a private array it would live in scratch (HBM latency per access)
+          const float* tr = tot[x];
+          // the reference sorts indices with `scores[i1] > scores[i2]`: the same predicate on the packed totals
+          auto comp = [](u64 a, u64 bb) {
+            const u32 xa = (u32)(a >> 32), xb = (u32)(bb >> 32);
+            float fa, fb;
+            __builtin_memcpy(&fa, &xa, 4);
+            __builtin_memcpy(&fb, &xb, 4);
+            return fa > fb;
+          };
+          auto fill = [&]() {
+            for (int z = 0; z < cnt; ++z) {
+              u32 bits;
+              __builtin_memcpy(&bits, &tr[z], 4);
+              keys[z] = ((u64)bits << 32) | (u32)z;
+            }
+          };
+          fill();
+          u64* itr = keys + cnt;
+          if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
+          bool sorted = false;
+          static_assert(GM <= 32, "stackless partition replay covers at most 32 candidates");
+          if (!std_sort_partition_only_le32(keys, itr, comp)) {
+            // depth limit of introsort hit (heap-sort fallback, not stable): replay all of it from the start
+            fill();
+            itr = keys + cnt;
+            if (cnt > partB) itr = jpp_partition(keys, itr, comp, (long)beam, (long)partB);
+            std_sort(keys, itr, comp);
+            sorted = true;
+          }
+          shave[x] = (u8)((itr - keys) | (sorted ? 0x80 : 0));
+        }
+        wave_sync();
+        // C. the replayed nodes' beams
+        for (int q0 = 0; q0 < nx * GM; q0 += 64) {
+          const int q = q0 + lane;
+          const bool in = q < nx * GM;
+          const int x = in ? q / GM : 0, i = in ? q - x * GM : GM;
+          if (!in || sreplay[x] == 0) continue;
+          const u32 t = order[op0 + x];
+          BeamSlot* row = beams + (u64)(rfirst + t) * beam;
+          const int have = shave[x] & 0x7f;
+          const bool sorted = (shave[x] & 0x80) != 0;
+          if (i < have) {
+            const u64 mine = skey[x][i];
+            const u32 vb = (u32)(mine >> 32);
+            float mv;
+            __builtin_memcpy(&mv, &vb, 4);
+            int pos = i;
+            if (!sorted) {
+              pos = 0;
+              for (int p2 = 0; p2 < have; ++p2) {
+                const u32 ob = (u32)(skey[x][p2] >> 32);
+                float ov;
+                __builtin_memcpy(&ov, &ob, 4);
+                if (ov > mv || (ov == mv && p2 < i)) ++pos;
+              }
+            }
+            const u32 iz = (u32)mine & 0xffu;
+            if (pos < beam) row[pos] = BeamSlot{gb_left[iz], gb_slot[iz], mv, gb_lnode[iz], iz};
+          }
+          // slots beyond the sorted range stay fake (have >= beam whenever util::partition ran)
+          if (i >= have && i < beam) row[i] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
         }
       } else {
         for (int q = lane; q < nx * GM; q += 64) {

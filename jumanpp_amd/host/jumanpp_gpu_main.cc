@@ -82,6 +82,7 @@ struct Conf {
   RnnConfigOverride rnn;  // --rnn-nce-bias, --rnn-unk-constant, --rnn-unk-length, --feature-weight-*
   int threads = 0;            // --threads=N format workers (0: one per hardware thread, at most 32)
   bool pipeline = true;       // --no-pipeline: one analyzer, read/analyse/format strictly in turn per batch
+  int pipelinesPerDevice = 2;  // --pipelines-per-device=N (bulk runs)
   bool hostFormat = false;    // --host-format: JUMAN text from the host formatters even where the device can print it
 };
 
@@ -401,6 +402,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--threads", &v)) conf.threads = std::atoi(v.c_str());
     else if (std::strcmp(argv[i], "--no-pipeline") == 0) conf.pipeline = false;
     else if (std::strcmp(argv[i], "--host-format") == 0) conf.hostFormat = true;
+    else if (argValue(argc, argv, i, "--pipelines-per-device", &v)) conf.pipelinesPerDevice = std::max(1, std::min(4, std::atoi(v.c_str())));
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
@@ -468,7 +470,8 @@ int main(int argc, const char** argv) {
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
                  "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing,\n"
-                 "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format)\n";
+                 "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format),\n"
+                 "           --pipelines-per-device=2 (bulk runs: analysis threads, each with its analyzer pair, per GPU)\n";
     return 1;
   }
   if (conf.model.empty()) {
@@ -620,6 +623,25 @@ int main(int argc, const char** argv) {
   // call, is being formatted.  Output order is the input order.
   const int nAnalyzers = conf.pipeline ? 2 : 1;
   if (conf.devices.empty()) conf.devices.push_back(conf.device);
+  // Bulk runs (files in, file out, input of more than eight batches): two pipelines per GPU unless the list was given
+  // with repetitions already.  One analysis thread spends 17.9 ms of host time per 65 536-sentence batch inside the
+  // library (three waits on the device among them) plus 3 ms of its own around it, for 16 ms of GPU time; a second
+  // thread with its own analyzer pair fills those gaps: 3.11 -> 3.69 M sentences/s on one MI355X
+  // (profiles/r04_h_cli_stages.txt).  --pipelines-per-device=1 restores one.
+  if (sharded && conf.pipelinesPerDevice > 1) {
+    size_t inputBytes0 = 0;
+    for (auto& path : conf.inputs) {
+      struct stat si;
+      if (::stat(path.c_str(), &si) == 0) inputBytes0 += (size_t)si.st_size;
+    }
+    bool repeats = false;
+    for (size_t a = 0; a < conf.devices.size(); ++a)
+      for (size_t b = a + 1; b < conf.devices.size(); ++b) repeats = repeats || conf.devices[a] == conf.devices[b];
+    if (!repeats && inputBytes0 > (size_t)conf.batch * 40 * 8) {
+      const std::vector<int> once = conf.devices;
+      for (int k = 1; k < conf.pipelinesPerDevice; ++k) conf.devices.insert(conf.devices.end(), once.begin(), once.end());
+    }
+  }
   const int nDev = (int)conf.devices.size();
   // per device: the second analyzer (a second copy of the model in HBM) is made when a second batch shows
   // up there: a short input pays for one
