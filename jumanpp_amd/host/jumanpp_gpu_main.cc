@@ -637,7 +637,7 @@ int main(int argc, const char** argv) {
     bool repeats = false;
     for (size_t a = 0; a < conf.devices.size(); ++a)
       for (size_t b = a + 1; b < conf.devices.size(); ++b) repeats = repeats || conf.devices[a] == conf.devices[b];
-    if (!repeats && inputBytes0 > (size_t)conf.batch * 40 * 8) {
+    if (!repeats && inputBytes0 > (size_t)conf.batch * 40 * 8 && inputBytes0 > (size_t{16} << 20)) {
       const std::vector<int> once = conf.devices;
       for (int k = 1; k < conf.pipelinesPerDevice; ++k) conf.devices.insert(conf.devices.end(), once.begin(), once.end());
     }
