@@ -1154,7 +1154,7 @@ def main():
         if world == 1 and not args.no_overlap:
             try:
                 ctxB = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank,
-                                 use_rnn=None if args.rnn else False)
+                                 use_rnn=None if args.rnn else False, share_with=ctx)   # (one copy of the model in HBM)
                 ctxs = [ctx, ctxB]
                 streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
                 offsB = [torch.zeros(args.batch + 1, dtype=torch.int32, device=dev) for _ in range(2)]

@@ -217,6 +217,12 @@ void jppgpu_ctx_destroy(jppgpu_ctx* ctx);
 /* Changes the beam configuration of the following batches; the model stays resident.
  * AnalyzerImpl::setGlobalBeam + the per-sentence beam of auto-beam mode
  * (src/core/analysis/analyzer_impl.cc:311-331,350-361).  Same validation as jppgpu_ctx_create. */
+/* A further context on the same device that shares the base context's copy of the model in HBM (dictionary blobs, weight
+ * table, RNN tables, per-entry T0 records, format table); workspaces, streams and configuration are its own.  What a
+ * second Analyzer over the same CoreHolder is in the reference (src/core/env.cc:109-121: makeAnalyzer).  The shared
+ * tables are freed with the last context using them; jppgpu_ctx_set_weights / jppgpu_ctx_set_format_table on either
+ * context acts on the shared copy. */
+int jppgpu_ctx_create_shared(jppgpu_ctx* base, const jppgpu_config* config, jppgpu_ctx** out);
 int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t global_beam, int32_t right_check,
                          int32_t right_beam);
 const char* jppgpu_last_error(void);

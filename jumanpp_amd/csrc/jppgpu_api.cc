@@ -405,16 +405,37 @@ struct jppgpu_result {
   void bind(HostPool* pool);
 };
 
+// What a context holds of the MODEL in HBM: the dictionary blobs, the weight table, the RNN tables, the per-entry T0
+// records and the format table -- read-only for the kernels, so every context of a device can use the same copy
+// (jppgpu_ctx_create_shared).  Freed with its last context.
+struct ModelBufs {
+  DevBuf trie, eptrs, edata, weights, dyn_spec;
+  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent;
+  DevModel* dmodel = nullptr;
+  // per-entry T0 memo (k_t0_memo): device table + what its weight-dependent half is rebuilt from
+  DevBuf t0_memo;
+  u32 t0_memo_slots = 0;
+  struct MemoSeed {
+    u32 slot, len;
+    i32 row[spec::kNumDicFeatures];
+  };
+  std::vector<MemoSeed> t0_memo_seeds;
+  // output text on the device (jppgpu_ctx_set_format_table)
+  bool fmt_have = false;
+  DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table;
+  int device = 0;
+  ~ModelBufs();
+};
+
 struct jppgpu_ctx {
   Config cfg{};
   int device = 0;
   DevModel hmodel{};
-  DevModel* dmodel = nullptr;
+  std::shared_ptr<ModelBufs> mb = std::make_shared<ModelBufs>();
   UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
-  DevBuf trie, eptrs, edata, weights, dyn_spec;
   bool dynamic_spec = false;   // a spec other than the built-in jumandic tables: table-driven kernels
   bool builtin_spec = false;   // the spec equals the compiled-in tables (k_path_ngrams reads them), also when dynamic_spec is forced
-  DevBuf rnn_known, rnn_unk, rnn_wt, rnn_emb, rnn_nce, rnn_maxent, rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
+  DevBuf rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
@@ -441,14 +462,6 @@ struct jppgpu_ctx {
   DevBuf node_info2, node_aux2, gold_off, gold, gold_base;
   DevBuf full_scratch, full_locks;   // k_sweep_full's HBM slices for boundaries beyond its LDS staging
   DevBuf norm_scratch, norm_locks;   // k_norm's HBM slices for starts beyond the per-lane result / state arrays
-  // per-entry T0 memo (k_t0_memo): device table + what its weight-dependent half is rebuilt from
-  DevBuf t0_memo;
-  u32 t0_memo_slots = 0;
-  struct MemoSeed {
-    u32 slot, len;
-    i32 row[spec::kNumDicFeatures];
-  };
-  std::vector<MemoSeed> t0_memo_seeds;
   DevBuf bnd_first, bnd_cnt, end_first, end_cnt, bnd_ngb, bnd_gbeam;
   DevBuf node_info, node_aux, end_nodes, node_entry, node_pat, node_t0, node_beam, node_cells, node_kept,
       path_nodes;
@@ -464,8 +477,7 @@ struct jppgpu_ctx {
   u64* mail_dev = nullptr;
   std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
-  bool fmt_have = false;
-  DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table, fmt_len, fmt_cnt, fmt_off, fmt_text;
+  DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text;
   bool timing_pending = false;
 };
 
@@ -701,7 +713,7 @@ void trie_keys(const u32* units, size_t nunits, std::vector<TrieKey>* out) {
 }
 
 // the seeds of the memo: (slot, surface length, entry row) of every dictionary entry reachable through the trie
-void collect_memo_seeds(const jppgpu_model* m, std::vector<jppgpu_ctx::MemoSeed>* seeds, u32* nslots) {
+void collect_memo_seeds(const jppgpu_model* m, std::vector<ModelBufs::MemoSeed>* seeds, u32* nslots) {
   std::vector<TrieKey> keys;
   trie_keys(static_cast<const u32*>(m->trie), m->trie_bytes / 4, &keys);
   const u8* eptrs = static_cast<const u8*>(m->entry_ptrs);
@@ -719,7 +731,7 @@ void collect_memo_seeds(const jppgpu_model* m, std::vector<jppgpu_ctx::MemoSeed>
       const size_t at = (size_t)((u32)ptr >> 1);
       const u32 slot = (u32)(at >> 3);
       if (slot >= slots || at + 8 * 10 > m->entry_data_bytes) continue;   // (entries at the very end of the blob take the full path)
-      jppgpu_ctx::MemoSeed sd{};
+      ModelBufs::MemoSeed sd{};
       sd.slot = slot;
       sd.len = k.len;
       size_t rp = at;
@@ -728,7 +740,7 @@ void collect_memo_seeds(const jppgpu_model* m, std::vector<jppgpu_ctx::MemoSeed>
         seeds->push_back(sd);
         seen[slot] = (u32)seeds->size();
       } else if (seen[slot] != ~0u) {
-        const jppgpu_ctx::MemoSeed& o = (*seeds)[seen[slot] - 1];
+        const ModelBufs::MemoSeed& o = (*seeds)[seen[slot] - 1];
         if (o.len != sd.len || memcmp(o.row, sd.row, sizeof(sd.row)) != 0) {   // one record cannot serve two different nodes
           (*seeds)[seen[slot] - 1].len = 0;
           seen[slot] = ~0u;
@@ -740,7 +752,7 @@ void collect_memo_seeds(const jppgpu_model* m, std::vector<jppgpu_ctx::MemoSeed>
 }
 
 // records from the seeds and a weight table (host pointers)
-void fill_memo_range(const std::vector<jppgpu_ctx::MemoSeed>& seeds, size_t from, size_t to, const float* weights, u32 wmask, T0Memo* table) {
+void fill_memo_range(const std::vector<ModelBufs::MemoSeed>& seeds, size_t from, size_t to, const float* weights, u32 wmask, T0Memo* table) {
   for (size_t i = from; i < to; ++i) {
     const auto& sd = seeds[i];
     if (sd.len == 0) continue;
@@ -772,7 +784,7 @@ void fill_memo_range(const std::vector<jppgpu_ctx::MemoSeed>& seeds, size_t from
 }
 
 // records from the seeds and a weight table (host pointers); the weight gathers miss the host caches, hence the threads
-void fill_memo(const std::vector<jppgpu_ctx::MemoSeed>& seeds, const float* weights, u32 wmask, std::vector<T0Memo>* table) {
+void fill_memo(const std::vector<ModelBufs::MemoSeed>& seeds, const float* weights, u32 wmask, std::vector<T0Memo>* table) {
   const unsigned nt = memo_threads();
   std::vector<std::thread> pool;
   const size_t per = (seeds.size() + nt - 1) / nt;
@@ -785,23 +797,31 @@ void fill_memo(const std::vector<jppgpu_ctx::MemoSeed>& seeds, const float* weig
 }
 
 bool upload_memo(jppgpu_ctx* ctx, const float* weights) {
-  std::vector<T0Memo> table((size_t)ctx->t0_memo_slots);
+  std::vector<T0Memo> table((size_t)ctx->mb->t0_memo_slots);
   memset(static_cast<void*>(table.data()), 0, table.size() * sizeof(T0Memo));
-  fill_memo(ctx->t0_memo_seeds, weights, ctx->hmodel.wmask, &table);
-  if (!ctx->t0_memo.ensure(table.size() * sizeof(T0Memo))) return false;
-  rt_h2d(ctx->t0_memo.p, table.data(), table.size() * sizeof(T0Memo), nullptr);
+  fill_memo(ctx->mb->t0_memo_seeds, weights, ctx->hmodel.wmask, &table);
+  if (!ctx->mb->t0_memo.ensure(table.size() * sizeof(T0Memo))) return false;
+  rt_h2d(ctx->mb->t0_memo.p, table.data(), table.size() * sizeof(T0Memo), nullptr);
   rt_sync(nullptr);
   return true;
 }
 }  // namespace
 
+ModelBufs::~ModelBufs() {
+  (void)bind_device(device);
+  DevBuf* bufs[] = {&trie, &eptrs, &edata, &weights, &dyn_spec, &rnn_known, &rnn_unk, &rnn_wt, &rnn_emb, &rnn_nce, &rnn_maxent,
+                    &t0_memo, &fmt_slots, &fmt_rows, &fmt_blob, &fmt_table};
+  for (auto* b : bufs) b->release();
+  rt_free(dmodel);
+}
+
 extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
 
-extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_in, jppgpu_ctx** out) {
-  if (!m || !c_in || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
-  *out = nullptr;
-  // the caller's struct may be older (shorter) or newer (longer) than ours: read what both sides know
-  jppgpu_config c_local;
+namespace {
+// the caller's struct may be older (shorter) or newer (longer) than ours: read what both sides know; then the
+// configuration checks of AnalyzerImpl::initScorers (analyzer_impl.cc:43-89)
+int read_config(const jppgpu_config* c_in, jppgpu_config* outc) {
+  jppgpu_config& c_local = *outc;
   memset(&c_local, 0, sizeof(c_local));
   {
     const uint32_t sz = c_in->struct_size;
@@ -822,7 +842,6 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   if (c->device < 0 || c->device >= ndev) return fail(JPPGPU_INVALID_PARAMETER, "bad device ordinal");
   if (hipSetDevice(c->device) != hipSuccess) return fail(JPPGPU_NO_DEVICE, "hipSetDevice failed");
 #endif
-  // --- configuration checks (AnalyzerImpl::initScorers, analyzer_impl.cc:43-89) ---
   if (c->beam <= 0) return fail(JPPGPU_INVALID_PARAMETER, "AnalyzerImpl: beam size can not be zero for scoring");
   if (c->num_host_scorers < 0 || c->num_host_scorers > 2 || 1 + (c->use_rnn ? 1 : 0) + c->num_host_scorers > kMaxScorers)
     return fail(JPPGPU_INVALID_PARAMETER, "jppgpu: num_host_scorers outside 0 .. 2");
@@ -834,6 +853,46 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
     return fail(JPPGPU_NOT_IMPLEMENTED,
                 "jppgpu: beam / global beam > 32 is not supported");
+  return JPPGPU_OK;
+}
+
+// Config, scorer weights of a new context
+void apply_config(jppgpu_ctx* ctx, const jppgpu_config* c) {
+  ctx->device = c->device;
+  ctx->cfg = Config{c->beam, c->global_beam > 0 ? c->global_beam : 0, c->right_check, c->right_beam,
+                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096, 1 + (c->use_rnn ? 1 : 0) + c->num_host_scorers,
+                    (c->use_rnn || c->num_host_scorers > 0) ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
+  ctx->use_rnn = c->use_rnn != 0;
+  ctx->n_host_scorers = c->num_host_scorers;
+  int k = 0;
+  ctx->score_weights.w[k++] = ctx->cfg.w_perceptron;
+  if (ctx->use_rnn) ctx->score_weights.w[k++] = ctx->cfg.w_rnn;
+  for (int h = 0; h < c->num_host_scorers; ++h) ctx->score_weights.w[k++] = c->weight_host[h];
+  for (; k < kMaxScorers; ++k) ctx->score_weights.w[k] = 0.f;
+  if (ctx->cfg.max_input_bytes > 65535) ctx->cfg.max_input_bytes = 65535;
+}
+
+// streams, events, mailbox: what every context has of its own
+void finish_context(jppgpu_ctx* ctx) {
+  ctx->own_stream = rt_stream_create();
+  ctx->aux_stream = rt_stream_create();
+  ctx->sweep_fork.init();
+  ctx->sweep_join.init();
+  ctx->timer.init();
+  ctx->rnn_sync.init();
+  void* dev = nullptr;
+  ctx->mail_host = static_cast<volatile u64*>(rt_mailbox_alloc(16 * 8, &dev));
+  ctx->mail_dev = static_cast<u64*>(dev);
+  ctx->text_pool->pinned = true;
+}
+}  // namespace
+
+extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_in, jppgpu_ctx** out) {
+  if (!m || !c_in || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  *out = nullptr;
+  jppgpu_config c_local;
+  if (int rc = read_config(c_in, &c_local)) return rc;
+  const jppgpu_config* c = &c_local;
   // The reference runs its generated static feature code when the spec hash matches it and its table-driven dynamic
   // feature objects otherwise (features_api.cc:20-60); here: the compiled-in jumandic tables when the flattened
   // descriptors equal them, the table-driven kernels (k_t0_dyn, k_sweep<.., DYN>: the dynamic code's summation
@@ -856,41 +915,29 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   if (m->trie_bytes % 4 != 0 || m->trie_bytes == 0) return fail(JPPGPU_INVALID_PARAMETER, "bad trie blob");
 
   auto* ctx = new jppgpu_ctx();
-  ctx->device = c->device;
-  ctx->cfg = Config{c->beam, c->global_beam > 0 ? c->global_beam : 0, c->right_check, c->right_beam,
-                    c->max_input_bytes > 0 ? c->max_input_bytes : 4096, 1 + (c->use_rnn ? 1 : 0) + c->num_host_scorers,
-                    (c->use_rnn || c->num_host_scorers > 0) ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
-  ctx->use_rnn = c->use_rnn != 0;
-  ctx->n_host_scorers = c->num_host_scorers;
-  {
-    int k = 0;
-    ctx->score_weights.w[k++] = ctx->cfg.w_perceptron;
-    if (ctx->use_rnn) ctx->score_weights.w[k++] = ctx->cfg.w_rnn;
-    for (int h = 0; h < c->num_host_scorers; ++h) ctx->score_weights.w[k++] = c->weight_host[h];
-    for (; k < kMaxScorers; ++k) ctx->score_weights.w[k] = 0.f;
-  }
-  if (ctx->cfg.max_input_bytes > 65535) ctx->cfg.max_input_bytes = 65535;
+  apply_config(ctx, c);
+  ctx->mb->device = c->device;
   DevModel& H = ctx->hmodel;
   size_t wbytes = (size_t{1} << m->weight_exponent) * sizeof(float);
-  bool ok = ctx->trie.ensure(m->trie_bytes) && ctx->eptrs.ensure(m->entry_ptrs_bytes + 16) &&
-            ctx->edata.ensure(m->entry_data_bytes + 16) && ctx->weights.ensure(wbytes);
+  bool ok = ctx->mb->trie.ensure(m->trie_bytes) && ctx->mb->eptrs.ensure(m->entry_ptrs_bytes + 16) &&
+            ctx->mb->edata.ensure(m->entry_data_bytes + 16) && ctx->mb->weights.ensure(wbytes);
   if (!ok) {
     jppgpu_ctx_destroy(ctx);
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (model)");
   }
-  rt_h2d(ctx->trie.p, m->trie, m->trie_bytes, nullptr);
-  rt_h2d(ctx->eptrs.p, m->entry_ptrs, m->entry_ptrs_bytes, nullptr);
-  rt_h2d(ctx->edata.p, m->entry_data, m->entry_data_bytes, nullptr);
-  rt_h2d(ctx->weights.p, m->weights, wbytes, nullptr);
+  rt_h2d(ctx->mb->trie.p, m->trie, m->trie_bytes, nullptr);
+  rt_h2d(ctx->mb->eptrs.p, m->entry_ptrs, m->entry_ptrs_bytes, nullptr);
+  rt_h2d(ctx->mb->edata.p, m->entry_data, m->entry_data_bytes, nullptr);
+  rt_h2d(ctx->mb->weights.p, m->weights, wbytes, nullptr);
   H.spec = nullptr;
   if (dynSpec) {
-    if (!ctx->dyn_spec.ensure(sizeof(DevSpec))) {
+    if (!ctx->mb->dyn_spec.ensure(sizeof(DevSpec))) {
       jppgpu_ctx_destroy(ctx);
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (feature tables)");
     }
-    rt_h2d(ctx->dyn_spec.p, dynSpec.get(), sizeof(DevSpec), nullptr);
+    rt_h2d(ctx->mb->dyn_spec.p, dynSpec.get(), sizeof(DevSpec), nullptr);
     rt_sync(nullptr);
-    H.spec = ctx->dyn_spec.as<DevSpec>();
+    H.spec = ctx->mb->dyn_spec.as<DevSpec>();
     ctx->dynamic_spec = true;
     // (k_path_ngrams addresses the stored patterns by the compiled-in numbering)
     if (builtinSpec) {
@@ -902,10 +949,10 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   } else {
     ctx->builtin_spec = true;
   }
-  H.trie = ctx->trie.as<u32>();
-  H.entry_ptrs = ctx->eptrs.as<u8>();
-  H.entry_data = ctx->edata.as<u8>();
-  H.weights = ctx->weights.as<float>();
+  H.trie = ctx->mb->trie.as<u32>();
+  H.entry_ptrs = ctx->mb->eptrs.as<u8>();
+  H.entry_data = ctx->mb->edata.as<u8>();
+  H.weights = ctx->mb->weights.as<float>();
   H.trie_units = (u32)(m->trie_bytes / 4);
   H.entry_ptrs_bytes = (u32)m->entry_ptrs_bytes;
   H.entry_data_bytes = (u32)m->entry_data_bytes;
@@ -991,27 +1038,27 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
     std::vector<float> wt(EP * EP, 0.f);
     for (u64 i = 0; i < E; ++i)
       for (u64 k = 0; k < E; ++k) wt[k * EP + i] = m->rnn_matrix[i * E + k];
-    bool ok2 = ctx->rnn_known.ensure(m->rnn_known_index_bytes) && ctx->rnn_unk.ensure(m->rnn_unk_index_bytes) &&
-               ctx->rnn_wt.ensure(EP * EP * 4) && ctx->rnn_emb.ensure(V * E * 4) && ctx->rnn_nce.ensure(V * E * 4) &&
-               ctx->rnn_maxent.ensure(m->rnn_maxent_size * 4);
+    bool ok2 = ctx->mb->rnn_known.ensure(m->rnn_known_index_bytes) && ctx->mb->rnn_unk.ensure(m->rnn_unk_index_bytes) &&
+               ctx->mb->rnn_wt.ensure(EP * EP * 4) && ctx->mb->rnn_emb.ensure(V * E * 4) && ctx->mb->rnn_nce.ensure(V * E * 4) &&
+               ctx->mb->rnn_maxent.ensure(m->rnn_maxent_size * 4);
     if (!ok2) {
       jppgpu_ctx_destroy(ctx);
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (rnn)");
     }
-    rt_h2d(ctx->rnn_known.p, m->rnn_known_index, m->rnn_known_index_bytes, nullptr);
-    rt_h2d(ctx->rnn_unk.p, m->rnn_unk_index, m->rnn_unk_index_bytes, nullptr);
-    rt_h2d(ctx->rnn_wt.p, wt.data(), EP * EP * 4, nullptr);
-    rt_h2d(ctx->rnn_emb.p, m->rnn_embeddings, V * E * 4, nullptr);
-    rt_h2d(ctx->rnn_nce.p, m->rnn_nce_embeddings, V * E * 4, nullptr);
-    rt_h2d(ctx->rnn_maxent.p, m->rnn_maxent, m->rnn_maxent_size * 4, nullptr);
+    rt_h2d(ctx->mb->rnn_known.p, m->rnn_known_index, m->rnn_known_index_bytes, nullptr);
+    rt_h2d(ctx->mb->rnn_unk.p, m->rnn_unk_index, m->rnn_unk_index_bytes, nullptr);
+    rt_h2d(ctx->mb->rnn_wt.p, wt.data(), EP * EP * 4, nullptr);
+    rt_h2d(ctx->mb->rnn_emb.p, m->rnn_embeddings, V * E * 4, nullptr);
+    rt_h2d(ctx->mb->rnn_nce.p, m->rnn_nce_embeddings, V * E * 4, nullptr);
+    rt_h2d(ctx->mb->rnn_maxent.p, m->rnn_maxent, m->rnn_maxent_size * 4, nullptr);
     rt_sync(nullptr);
     H.has_rnn = 1;
-    H.rnn_known = ctx->rnn_known.as<u32>();
-    H.rnn_unk = ctx->rnn_unk.as<u32>();
-    H.rnn_wt = ctx->rnn_wt.as<float>();
-    H.rnn_emb = ctx->rnn_emb.as<float>();
-    H.rnn_nce = ctx->rnn_nce.as<float>();
-    H.rnn_maxent = ctx->rnn_maxent.as<float>();
+    H.rnn_known = ctx->mb->rnn_known.as<u32>();
+    H.rnn_unk = ctx->mb->rnn_unk.as<u32>();
+    H.rnn_wt = ctx->mb->rnn_wt.as<float>();
+    H.rnn_emb = ctx->mb->rnn_emb.as<float>();
+    H.rnn_nce = ctx->mb->rnn_nce.as<float>();
+    H.rnn_maxent = ctx->mb->rnn_maxent.as<float>();
     H.rnn_E = (u32)E;
     H.rnn_EP = (u32)EP;
     H.rnn_order = m->rnn_maxent_order;
@@ -1039,18 +1086,18 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
     H.rnn_nfields = m->rnn_num_fields;
     for (u32 f = 0; f < m->rnn_num_fields; ++f) H.rnn_fields[f] = m->rnn_fields[f];
   }
-  ctx->dmodel = static_cast<DevModel*>(rt_malloc(sizeof(DevModel)));
-  if (!ctx->dmodel) {
+  ctx->mb->dmodel = static_cast<DevModel*>(rt_malloc(sizeof(DevModel)));
+  if (!ctx->mb->dmodel) {
     jppgpu_ctx_destroy(ctx);
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (model header)");
   }
-  rt_h2d(ctx->dmodel, &H, sizeof(DevModel), nullptr);
+  rt_h2d(ctx->mb->dmodel, &H, sizeof(DevModel), nullptr);
   rt_sync(nullptr);
   // (developer knob JPPGPU_DEV_T0_MEMO=0: k_t0 without the per-entry memo)
   static const bool devT0Memo = !(std::getenv("JPPGPU_DEV_T0_MEMO") && std::atoi(std::getenv("JPPGPU_DEV_T0_MEMO")) == 0);
   if (!ctx->dynamic_spec && devT0Memo) {
     const auto t_a = std::chrono::steady_clock::now();
-    collect_memo_seeds(m, &ctx->t0_memo_seeds, &ctx->t0_memo_slots);
+    collect_memo_seeds(m, &ctx->mb->t0_memo_seeds, &ctx->mb->t0_memo_slots);
     const auto t_b = std::chrono::steady_clock::now();
     if (!upload_memo(ctx, m->weights)) {
       jppgpu_ctx_destroy(ctx);
@@ -1058,25 +1105,41 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
     }
     if (std::getenv("JPPGPU_DEV_T0_MEMO")) {   // =1 / =2: report
       size_t valid = 0;
-      for (const auto& sd : ctx->t0_memo_seeds) valid += sd.len != 0;
+      for (const auto& sd : ctx->mb->t0_memo_seeds) valid += sd.len != 0;
       std::fprintf(stderr, "[jppgpu] T0 memo: %zu entries (%zu with a record) in %u slots, trie walk %.1f ms, records + upload %.1f ms\n",
-                   ctx->t0_memo_seeds.size(), valid, ctx->t0_memo_slots,
+                   ctx->mb->t0_memo_seeds.size(), valid, ctx->mb->t0_memo_slots,
                    std::chrono::duration<double, std::milli>(t_b - t_a).count(),
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_b).count());
     }
   }
-  ctx->own_stream = rt_stream_create();
-  ctx->aux_stream = rt_stream_create();
-  ctx->sweep_fork.init();
-  ctx->sweep_join.init();
-  ctx->timer.init();
-  ctx->rnn_sync.init();
-  {
-    void* dev = nullptr;
-    ctx->mail_host = static_cast<volatile u64*>(rt_mailbox_alloc(16 * 8, &dev));
-    ctx->mail_dev = static_cast<u64*>(dev);
-    ctx->text_pool->pinned = true;
-  }
+  finish_context(ctx);
+  *out = ctx;
+  return JPPGPU_OK;
+}
+
+// A second context on the device of `base` that uses base's copy of the model in HBM (dictionary, weights, RNN tables,
+// per-entry T0 records, format table): only workspaces, streams and the configuration are its own.  The model tables
+// live until the last context that uses them is destroyed, in any order.  jppgpu_ctx_set_weights on either context
+// changes the table both read.
+extern "C" int jppgpu_ctx_create_shared(jppgpu_ctx* base, const jppgpu_config* c_in, jppgpu_ctx** out) {
+  if (!base || !c_in || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  *out = nullptr;
+  jppgpu_config c_local;
+  if (int rc = read_config(c_in, &c_local)) return rc;
+  const jppgpu_config* c = &c_local;
+  if (c->device != base->device) return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_ctx_create_shared: the model copy lives on another device");
+  if (c->use_rnn && !base->hmodel.has_rnn)
+    return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_ctx_create_shared: use_rnn set but the shared model copy has no RNN tables");
+  if (base->builtin_spec && ((c->dynamic_features != 0) != base->dynamic_spec))
+    return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_ctx_create_shared: dynamic_features differs from the base context");
+  auto* ctx = new jppgpu_ctx();
+  apply_config(ctx, c);
+  ctx->mb = base->mb;
+  ctx->hmodel = base->hmodel;
+  ctx->unk_rank = base->unk_rank;
+  ctx->dynamic_spec = base->dynamic_spec;
+  ctx->builtin_spec = base->builtin_spec;
+  finish_context(ctx);
   *out = ctx;
   return JPPGPU_OK;
 }
@@ -1103,23 +1166,22 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
 extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   if (!ctx) return;
   (void)bind_device(ctx->device);
-  DevBuf* bufs[] = {&ctx->trie,       &ctx->eptrs,     &ctx->edata,      &ctx->weights,   &ctx->dyn_spec, &ctx->text,
+  DevBuf* bufs[] = {&ctx->text,
                     &ctx->offs,       &ctx->cp_code,   &ctx->cp_class,   &ctx->cp_boff,   &ctx->cl_nodes,
                     &ctx->pos_cnt1,   &ctx->pos_cntN,  &ctx->pos_norm,  &ctx->pos_cnt2,   &ctx->pos_ends,  &ctx->pos_walk,  &ctx->reach,     &ctx->sent_ncp,
                     &ctx->sent_status, &ctx->sent_flags, &ctx->sent_nodes, &ctx->sent_nodes2, &ctx->node_base,
                     &ctx->node_base2, &ctx->path_len,  &ctx->bnd_first,  &ctx->bnd_cnt,   &ctx->end_first,
                     &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
                     &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
-                    &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_known, &ctx->rnn_unk, &ctx->rnn_wt,
-                    &ctx->rnn_emb,    &ctx->rnn_nce,   &ctx->rnn_maxent, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
+                    &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
-                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->t0_memo, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
-                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_slots, &ctx->fmt_rows, &ctx->fmt_blob, &ctx->fmt_table, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
+                    &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
+                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
   for (auto* b : bufs) b->release();
-  rt_free(ctx->dmodel);
+  ctx->mb.reset();   // (the model tables go with their last context)
   rt_stream_destroy(ctx->own_stream);
   rt_stream_destroy(ctx->aux_stream);
   ctx->sweep_fork.destroy();
@@ -1263,9 +1325,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(1, st);
   // (developer knob JPPGPU_DEV_SEEDS_WAVES=6: the count / emit passes compiled for 6 instead of 8 wavefronts per SIMD)
   static const int devSeedsWaves = std::getenv("JPPGPU_DEV_SEEDS_WAVES") ? std::atoi(std::getenv("JPPGPU_DEV_SEEDS_WAVES")) : 8;
-  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<0, 6>), n, 64, st, B, (const DevModel*)ctx->dmodel);
-  else JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  JPP_LAUNCH(k_norm<0>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<0, 6>), n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  else JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  JPP_LAUNCH(k_norm<0>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_layout<1>, wblocks, 64 * kLatWaves, st, B);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
@@ -1286,9 +1348,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (node table)");
   B.node_info = ctx->node_info.as<NodeInfo>();
   B.node_aux = ctx->node_aux.as<NodeAux>();
-  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<1, 6>), n, 64, st, B, (const DevModel*)ctx->dmodel);
-  else JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  JPP_LAUNCH(k_norm<1>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<1, 6>), n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  else JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  JPP_LAUNCH(k_norm<1>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_connect<1>, wblocks, 64 * kLatWaves, st, B);
   // stage 2 for disconnected sentences: relocate them behind the stage-1 region
   JPP_LAUNCH(k_layout<2>, wblocks, 64 * kLatWaves, st, B);
@@ -1299,8 +1361,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
   JPP_LAUNCH(k_relocate, sblocks, 256, st, B);
-  JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_connect<2>, wblocks, 64 * kLatWaves, st, B);
   u64 totalNodes = 0;
   u32 gstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1422,13 +1484,13 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     JPP_LAUNCH(k_ends, wblocks, 64 * kLatWaves, st, B, ctx->cfg, rk);
   }
   T.mark(3, st);
-  if (ctx->dynamic_spec) JPP_LAUNCH(k_t0_dyn, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  else if (ctx->t0_memo_slots && ctx->hmodel.wmask <= 0xffffffu)
-    JPP_LAUNCH(k_t0_memo<true>, n, 64, st, B, (const DevModel*)ctx->dmodel, (const T0Memo*)ctx->t0_memo.as<T0Memo>(), ctx->t0_memo_slots);
-  else if (ctx->t0_memo_slots)
-    JPP_LAUNCH(k_t0_memo<false>, n, 64, st, B, (const DevModel*)ctx->dmodel, (const T0Memo*)ctx->t0_memo.as<T0Memo>(), ctx->t0_memo_slots);
-  else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->dmodel);
-  else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->dmodel);
+  if (ctx->dynamic_spec) JPP_LAUNCH(k_t0_dyn, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  else if (ctx->mb->t0_memo_slots && ctx->hmodel.wmask <= 0xffffffu)
+    JPP_LAUNCH(k_t0_memo<true>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel, (const T0Memo*)ctx->mb->t0_memo.as<T0Memo>(), ctx->mb->t0_memo_slots);
+  else if (ctx->mb->t0_memo_slots)
+    JPP_LAUNCH(k_t0_memo<false>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel, (const T0Memo*)ctx->mb->t0_memo.as<T0Memo>(), ctx->mb->t0_memo_slots);
+  else if (ctx->hmodel.wmask <= 0xffffffu) JPP_LAUNCH(k_t0<true>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  else JPP_LAUNCH(k_t0<false>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   B.node_penalty = nullptr;
   B.pair_penalty = nullptr;
   B.pair_base = nullptr;
@@ -1585,7 +1647,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     B.sweep_scratch_stride = stride;
     B.sweep_scratch_maxr = maxR;
   }
-  const DevModel* dmS = (const DevModel*)ctx->dmodel;
+  const DevModel* dmS = (const DevModel*)ctx->mb->dmodel;
   B.full_scratch = nullptr;
   B.full_locks = nullptr;
   B.full_slots = 0;
@@ -1680,10 +1742,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   if (ctx->use_rnn) {
     JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
     JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
-               (const DevModel*)ctx->dmodel, ctx->cfg);
+               (const DevModel*)ctx->mb->dmodel, ctx->cfg);
     // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
-    const DevModel* dm = (const DevModel*)ctx->dmodel;
+    const DevModel* dm = (const DevModel*)ctx->mb->dmodel;
     // hidden states: one row of EP floats per rnn node (+ parking and BOS rows per sentence), i.e. ~31 rows per
     // 40-codepoint sentence instead of the (codepoints + 3) * G = 258 of a boundary-indexed table (1.0 GB instead of
     // 8.6 GB per 65 536 sentences).  The row total is only known here: a third host sync; the sentence ordering of
@@ -1960,20 +2022,20 @@ extern "C" int jppgpu_ctx_set_format_table(jppgpu_ctx* ctx, const jppgpu_format_
     return fail(JPPGPU_INVALID_PARAMETER, "format table: literal beyond its field");
   static_assert(sizeof(FmtRow) == sizeof(jppgpu_format_row), "row layout");
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
-  if (!(ctx->fmt_slots.ensure(t->n_slots * 4) && ctx->fmt_rows.ensure(t->n_rows * sizeof(FmtRow)) &&
-        ctx->fmt_blob.ensure(t->blob_bytes + 64) && ctx->fmt_table.ensure(sizeof(FmtTable))))
+  if (!(ctx->mb->fmt_slots.ensure(t->n_slots * 4) && ctx->mb->fmt_rows.ensure(t->n_rows * sizeof(FmtRow)) &&
+        ctx->mb->fmt_blob.ensure(t->blob_bytes + 64) && ctx->mb->fmt_table.ensure(sizeof(FmtTable))))
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format table)");
   jpp_stream_t st = ctx->own_stream;
-  rt_h2d(ctx->fmt_slots.p, t->slot_first_row, t->n_slots * 4, st);
-  rt_h2d(ctx->fmt_rows.p, t->rows, t->n_rows * sizeof(FmtRow), st);
-  rt_h2d(ctx->fmt_blob.p, t->blob, t->blob_bytes, st);
+  rt_h2d(ctx->mb->fmt_slots.p, t->slot_first_row, t->n_slots * 4, st);
+  rt_h2d(ctx->mb->fmt_rows.p, t->rows, t->n_rows * sizeof(FmtRow), st);
+  rt_h2d(ctx->mb->fmt_blob.p, t->blob, t->blob_bytes, st);
   FmtTable T;
   memset(&T, 0, sizeof(T));
-  T.slot_first_row = ctx->fmt_slots.as<u32>();
+  T.slot_first_row = ctx->mb->fmt_slots.as<u32>();
   T.n_slots = t->n_slots;
-  T.rows = ctx->fmt_rows.as<FmtRow>();
+  T.rows = ctx->mb->fmt_rows.as<FmtRow>();
   T.n_rows = t->n_rows;
-  T.blob = ctx->fmt_blob.as<u8>();
+  T.blob = ctx->mb->fmt_blob.as<u8>();
   memcpy(T.maker_replaces, t->maker_replaces, 16);
   T.n_escapes = t->n_escapes;
   memcpy(T.escape_from, t->escape_from, 4);
@@ -1989,16 +2051,16 @@ extern "C" int jppgpu_ctx_set_format_table(jppgpu_ctx* ctx, const jppgpu_format_
   T.error_len = t->error_len;
   memcpy(T.eos_text, t->eos_text, 16);
   memcpy(T.error_text, t->error_text, 32);
-  rt_h2d(ctx->fmt_table.p, &T, sizeof(T), st);
+  rt_h2d(ctx->mb->fmt_table.p, &T, sizeof(T), st);
   rt_sync(st);   // (T and the caller's arrays may go away)
-  ctx->fmt_have = true;
+  ctx->mb->fmt_have = true;
   return JPPGPU_OK;
 }
 
 extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v) {
   if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   jppgpu_ctx* ctx = res->ctx;
-  if (!ctx->fmt_have) return fail(JPPGPU_INVALID_STATE, "jppgpu_result_format_top1 needs jppgpu_ctx_set_format_table");
+  if (!ctx->mb->fmt_have) return fail(JPPGPU_INVALID_STATE, "jppgpu_result_format_top1 needs jppgpu_ctx_set_format_table");
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
@@ -2008,7 +2070,7 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
     jpp_stream_t st = ctx->last_stream;
     if (!(ctx->fmt_len.ensure((B.total_nodes + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format)");
-    const FmtTable* T = ctx->fmt_table.as<FmtTable>();
+    const FmtTable* T = ctx->mb->fmt_table.as<FmtTable>();
     if (n) JPP_LAUNCH(k_fmt_count, (n + 3) / 4, 256, st, B, T, ctx->fmt_len.as<u32>(), ctx->fmt_cnt.as<u32>());
     JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
@@ -2302,9 +2364,9 @@ extern "C" int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uin
   // (ordered behind every batch already enqueued on the context's streams)
   if (ctx->last_stream) rt_sync(ctx->last_stream);
   rt_sync(ctx->own_stream);
-  rt_h2d(ctx->weights.p, weights, (size_t)n * 4, nullptr);
+  rt_h2d(ctx->mb->weights.p, weights, (size_t)n * 4, nullptr);
   rt_sync(nullptr);
-  if (ctx->t0_memo_slots && !upload_memo(ctx, weights)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
+  if (ctx->mb->t0_memo_slots && !upload_memo(ctx, weights)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
   return JPPGPU_OK;
 }
 

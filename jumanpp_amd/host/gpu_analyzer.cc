@@ -39,7 +39,7 @@ void GpuAnalyzer::releaseResult() {
 }
 
 Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cfg, const ScoringConfig& sconf,
-                               const ScorerDef* scorer, int device) {
+                               const ScorerDef* scorer, int device, const GpuAnalyzer* shareModelWith) {
   if (model == nullptr) return Status::InvalidParameter("model was null");
   if (scorer == nullptr) return Status::InvalidParameter("scorer was null");
   // Analyzer::initialize / AnalyzerImpl::initScorers (analyzer.cc:16-36, analyzer_impl.cc:43-89)
@@ -96,7 +96,13 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
     haveFormatTable_ = false;
     textMode_ = false;
   }
-  int rc = jppgpu_ctx_create(&model->cmodel(), &c, &ctx_);
+  int rc;
+  if (shareModelWith != nullptr && shareModelWith->ctx_ != nullptr && shareModelWith->model_ == model) {
+    rc = jppgpu_ctx_create_shared(shareModelWith->ctx_, &c, &ctx_);
+    if (rc == JPPGPU_OK) haveFormatTable_ = shareModelWith->haveFormatTable_;   // (the table is part of the shared copy)
+  } else {
+    rc = jppgpu_ctx_create(&model->cmodel(), &c, &ctx_);
+  }
   if (rc != JPPGPU_OK) return fromCode(rc);
   model_ = model;
   cfg_ = cfg;

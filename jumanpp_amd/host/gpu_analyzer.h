@@ -202,8 +202,11 @@ class GpuAnalyzer {
   GpuAnalyzer& operator=(const GpuAnalyzer&) = delete;
   ~GpuAnalyzer();
 
+  // shareModelWith: an initialised analyzer of the same model on the same device whose copy of the model in HBM
+  // (dictionary, weights, RNN tables, T0 records, format table) this one uses instead of uploading its own -- the
+  // second Analyzer over one CoreHolder (JumanppEnv::makeAnalyzer, src/core/env.cc:109-121)
   Status initialize(const ModelImage* model, const AnalyzerConfig& cfg, const ScoringConfig& sconf,
-                    const ScorerDef* scorer, int device = 0);
+                    const ScorerDef* scorer, int device = 0, const GpuAnalyzer* shareModelWith = nullptr);
   // one sentence; the Status is the sentence's own status
   Status analyze(StringPiece input);
   // n sentences, one launch sequence; a failing sentence does not fail the batch (see sentenceStatus)
@@ -249,6 +252,7 @@ class GpuAnalyzer {
     return g.hasNbest ? &g.nbest : nullptr;
   }
 
+  bool ready() const { return ctx_ != nullptr; }   // initialize succeeded
   size_t numSentences() const { return inputs_.size(); }
   Status sentenceStatus(size_t i) const;
   SentenceResult sentence(size_t i) const;

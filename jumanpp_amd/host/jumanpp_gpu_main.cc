@@ -665,9 +665,15 @@ int main(int argc, const char** argv) {
     analyzers[d][a].reset(new GpuAnalyzer());
     // the lattice format reads the N best paths only: they are gathered on the device (N = what it prints)
     if (latticeFormat) analyzers[d][a]->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
-    Status made = analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d]);
+    // one copy of the model per GPU: a later analyzer of the same physical device uses the first one's
+    const GpuAnalyzer* donor = nullptr;
+    for (int d2 = 0; d2 < nDev && donor == nullptr; ++d2)
+      if (conf.devices[d2] == conf.devices[d] && analyzers[d2][0] && analyzers[d2][0].get() != analyzers[d][a].get() &&
+          analyzers[d2][0]->ready())
+        donor = analyzers[d2][0].get();
+    Status made = analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d], donor);
     if (made && deviceText) {
-      made = analyzers[d][a]->setFormatTable(formatTable.view());
+      if (donor == nullptr) made = analyzers[d][a]->setFormatTable(formatTable.view());
       if (made) {
         analyzers[d][a]->setTextMode(true);
         analyzers[d][a]->setDeferredText(sharded);

@@ -118,6 +118,7 @@ def load_library(path=None):
     lib = C.CDLL(path)
     lib.jppgpu_last_error.restype = C.c_char_p
     lib.jppgpu_ctx_create.argtypes = [C.POINTER(Model), C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.jppgpu_ctx_create_shared.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(C.c_void_p)]
     lib.jppgpu_ctx_destroy.argtypes = [C.c_void_p]
     lib.jppgpu_analyze_batch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     lib.jppgpu_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
@@ -277,7 +278,7 @@ class Context:
     def __init__(self, image_path, beam=5, global_beam=6, right_check=1, right_beam=5,
                  max_input_bytes=4096, device=0, lib_path=None, use_rnn=None,
                  weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None, dynamic_features=False, max_unk_makers=None,
-                 host_scorer_weights=()):
+                 host_scorer_weights=(), share_with=None):
         """use_rnn=None: run the RNN scorer iff the model image has an RNN part (what
         JumanppEnv::loadModel does); the score weights default to the model's saved
         RnnInferenceConfig (env.cc:86-100)."""
@@ -354,7 +355,10 @@ class Context:
                      1 if use_rnn else 0, wp, wr, 1 if dynamic_features else 0, len(host_scorer_weights),
                      (C.c_float * 2)(*(list(host_scorer_weights) + [0.0, 0.0])[:2]))
         h = C.c_void_p()
-        rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))
+        if share_with is not None:   # the other context's copy of the model in HBM (jppgpu_ctx_create_shared)
+            rc = self.lib.jppgpu_ctx_create_shared(share_with.handle, C.byref(cfg), C.byref(h))
+        else:
+            rc = self.lib.jppgpu_ctx_create(C.byref(m), C.byref(cfg), C.byref(h))
         if rc != 0:
             raise JppGpuError('jppgpu_ctx_create failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
         self.handle = h

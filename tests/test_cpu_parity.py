@@ -844,3 +844,28 @@ def test_emulated_rnn_tiny_and_degenerate_batches(emu_lib, golden_dir):
             assert path_of(r, j) == path_of(ref, i), (pick, j)
     r = ctx.analyze([b'', b'\xff\xfe', b'', b'\xe3\x81']).fetch(full=True)
     assert list(r.status) == [0, 2, 0, 2] and int(r.path_len.sum()) == 0
+
+
+def test_shared_model_contexts(emu_lib, golden_dir):
+    """jppgpu_ctx_create_shared: a second context on the first one's copy of the model -- own configuration, same
+    results as a context of its own; the tables outlive the base context"""
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    for image, gold_a, gold_b in (('mini.img', 'mini.gold', 'mini_b3.gold'), ('mini_rnn.img', 'mini_rnn.gold', None)):
+        base = J.Context(os.path.join(golden_dir, image), lib_path=emu_lib)
+        cfg_b = dict(beam=3, global_beam=4, right_check=2, right_beam=3) if gold_b else {}
+        other = J.Context(os.path.join(golden_dir, image), lib_path=emu_lib, share_with=base, **cfg_b)
+        for ctx, gold_name in ((base, gold_a), (other, gold_b or gold_a)):
+            meta, gold = G.read_gold(os.path.join(golden_dir, gold_name))
+            res = ctx.analyze(lines).fetch(full=True)
+            errs = []
+            for s_ in range(len(lines)):
+                errs += G.compare_sentence(res, s_, gold[s_], meta)
+            assert not errs, (image, gold_name, errs[:5])
+            res.release()
+        base.close()   # the shared tables must survive their first owner
+        meta, gold = G.read_gold(os.path.join(golden_dir, gold_b or gold_a))
+        res = other.analyze(lines).fetch(full=True)
+        errs = []
+        for s_ in range(len(lines)):
+            errs += G.compare_sentence(res, s_, gold[s_], meta)
+        assert not errs, errs[:5]

@@ -105,7 +105,7 @@ PY
       timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-overlap --no-realism --no-cli --no-trainer $BA > "$OUT/${TAG}_config5.json" 2> "$OUT/${TAG}_config5.err"
       python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(json.dumps(d.get('config5'))[:1500])" "$OUT/${TAG}_config5.json" ;;
     cli)
-      timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-overlap --no-realism --no-config5 --no-trainer $BA > "$OUT/${TAG}_cli.json" 2> "$OUT/${TAG}_cli.err"
+      timeout 900 python bench.py --no-cpu-baseline --no-parity --no-overlap --no-realism --no-config5 --no-trainer $BA > "$OUT/${TAG}_cli.json" 2> "$OUT/${TAG}_cli.err"
       python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(json.dumps(d.get('cli_end_to_end'), ensure_ascii=False)[:3000])" "$OUT/${TAG}_cli.json" ;;
     run)
       base="$(basename "$arg" | cut -d. -f1)"
