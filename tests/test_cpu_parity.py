@@ -846,7 +846,7 @@ def test_emulated_rnn_tiny_and_degenerate_batches(emu_lib, golden_dir):
     assert list(r.status) == [0, 2, 0, 2] and int(r.path_len.sum()) == 0
 
 
-def test_shared_model_contexts(emu_lib, golden_dir):
+def check_shared_model_contexts(emu_lib, golden_dir):
     """jppgpu_ctx_create_shared: a second context on the first one's copy of the model -- own configuration, same
     results as a context of its own; the tables outlive the base context"""
     lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
@@ -869,3 +869,7 @@ def test_shared_model_contexts(emu_lib, golden_dir):
         for s_ in range(len(lines)):
             errs += G.compare_sentence(res, s_, gold[s_], meta)
         assert not errs, errs[:5]
+
+
+def test_shared_model_contexts(emu_lib, golden_dir):
+    check_shared_model_contexts(emu_lib, golden_dir)

@@ -491,3 +491,10 @@ def test_gpu_table_driven_kernels_on_a_non_jumandic_spec(gpu_lib, ref_tools, tmp
         pytest.skip('oracle/_ref not built')
     import test_cpu_parity as tc
     tc.check_variant_spec(gpu_lib, ref_tools, str(tmp_path), variant, 1500, beams, rnn, n_entries=30000, exp=20, length=40, seed=37)
+
+
+def test_gpu_shared_model_contexts(gpu_lib, golden_dir):
+    """two contexts on one copy of the model in HBM (jppgpu_ctx_create_shared), different beam configurations, the base
+    destroyed first"""
+    import test_cpu_parity as tc
+    tc.check_shared_model_contexts(gpu_lib, golden_dir)
