@@ -1186,7 +1186,7 @@ def main():
                 overlapped = {'what': 'two batches in flight on two HIP streams (two contexts), same workload',
                               'value': round(args.batch * k3 / e3, 1), 'unit': 'sentences/s', 'steps': k3,
                               'ms_per_step': round(e3 / k3 * 1e3, 3)}
-                del ctxB
+                del ctxs, ctxB, pending, pr, r, offsB, itemsB   # (the list kept both contexts alive into the CLI leg)
             except Exception as e:  # the extra measurement must never take the main line down
                 overlapped = {'error': str(e)[:200]}
         out = {
