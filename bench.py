@@ -1243,14 +1243,12 @@ def main():
             out['perceptron_only'] = perceptron_only
         if overlapped is not None:
             out['overlapped_two_streams'] = overlapped
-        if not args.no_cli and world == 1:
-            # the child process gets the device to itself as far as this process can arrange it
-            del ctx
-            ctx2 = None
-            import gc
-            gc.collect()
-            torch.cuda.empty_cache()
-            out['cli_end_to_end'] = cli_end_to_end(args, model, corpus, args.batch * len(batches), ge)
+        # (this process' contexts go before the legs that run child processes or make contexts of their own)
+        del ctx
+        ctx2 = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         if not args.no_config5 and world == 1:
             out['config5'] = config5_leg(args, cache, local_rank, np, torch, J)
         if not args.no_realism and world == 1:
@@ -1259,6 +1257,11 @@ def main():
             out['trainer'] = trainer_leg(args, mdic, cache, ge)
         if not args.no_cpu_baseline:   # rank 0 only, at every world size (the other ranks wait at the final barrier)
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
+        if not args.no_cli and world == 1:
+            # Last of the legs: on a box that has just started, the first child processes run at a third of their speed
+            # (profiles/r04_l_cli_probe.txt: five identical bench runs in a row, the CLI leg 0.85 / 1.45 / 2.71 / 2.56 / 2.28 M
+            # sentences/s in that order, whatever legs ran before it); a minute of the other legs later the box is warm.
+            out['cli_end_to_end'] = cli_end_to_end(args, model, corpus, args.batch * len(batches), ge)
         print(json.dumps(out, ensure_ascii=False), flush=True)
     if dist is not None:
         dist.barrier()
