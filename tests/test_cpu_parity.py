@@ -873,3 +873,34 @@ def check_shared_model_contexts(emu_lib, golden_dir):
 
 def test_shared_model_contexts(emu_lib, golden_dir):
     check_shared_model_contexts(emu_lib, golden_dir)
+
+
+def check_wide_global_beam_candidates(lib, ref_tools, tmp, beams, nhom=(3, 9, 14, 20), n_lines=6):
+    """the wide sweep variant's global beam by candidate count: surfaces with 3 / 9 / 14 / 20 homographs put 96, 288, 448
+    and 640 (left node, slot) candidates on a boundary at beam 32 -- one key per lane, the per-lane-maxima prefilter
+    with one and with several keys per lane, and beyond 512 the G rounds over HBM; ties among homographs everywhere"""
+    import test_gpu_parity as tg
+    surf = ['かき', 'さけ', 'くも', 'はし']
+    extra = ''
+    for sf, k in zip(surf, nhom):
+        extra += ''.join('%s,0,0,0,名詞,普通名詞,*,*,%s,よみ%d,%s/よみ%d,代表表記:%s/よみ%d\n' % (sf, sf, i, sf, i, sf, i) for i in range(k))
+    lines_x = ['かきをさけとくもにはしで', 'かきかきさけさけくもくもはしはし', 'はしのくものさけのかき', 'くもくもくもさけ', 'はしはしかき']
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, n_lines, 15, 53, length=40, beams=beams, extra_dict=extra,
+                                               extra_lines=lines_x)
+    ctx = J.Context(img, lib_path=lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+    meta, gold = G.read_gold(gold_path)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs, most = [], 0
+    for s_ in range(len(lines)):
+        errs += G.compare_sentence(res, s_, gold[s_], meta)
+        bb = int(res.bnd_base[s_])
+        most = max(most, int(res.end_count[bb + 2:bb + int(res.ncp[s_]) + 3].max()))
+    assert most >= max(nhom), most
+    assert not errs, (len(errs), errs[:10])
+
+
+@pytest.mark.parametrize('beams', [[32, 32, 1, 32], [24, 32, 2, 16], [32, 20, 1, 32]])
+def test_emulated_wide_global_beam_candidates(emu_lib, ref_tools, tmp_path, beams):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_wide_global_beam_candidates(emu_lib, ref_tools, str(tmp_path), beams)

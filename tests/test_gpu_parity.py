@@ -498,3 +498,12 @@ def test_gpu_shared_model_contexts(gpu_lib, golden_dir):
     destroyed first"""
     import test_cpu_parity as tc
     tc.check_shared_model_contexts(gpu_lib, golden_dir)
+
+
+@pytest.mark.parametrize('beams', [[32, 32, 1, 32], [24, 32, 2, 16]])
+def test_gpu_wide_global_beam_candidates(gpu_lib, ref_tools, tmp_path, beams):
+    """96 .. 640 global-beam candidates per boundary at beam 32 (keys in registers, prefilter, HBM rounds), 200 sentences"""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tc.check_wide_global_beam_candidates(gpu_lib, ref_tools, str(tmp_path), beams, n_lines=200)
