@@ -377,7 +377,8 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   // being scored: patterns / T0 of its first kChunk right nodes and its ends list; double buffered
   // candidate slots (left nodes x beam) staged in LDS per boundary; more take global_beam_from_hbm (wide variant: 8 left
   // nodes x 32 -- at 512 the buffer alone held the kernel at 6 wavefronts per CU)
-  constexpr int kCandCap = GM <= 8 ? 64 : 256;
+  constexpr int kCandCap = GM <= 8 ? 64 : 256;   // (wide variant: KEYS in registers, 4 per lane and chunk -- no slots staged in LDS)
+  constexpr int kCandSlots = GM <= 8 ? 64 : 0;   // beam slots of the candidates staged in LDS (narrow variant only)
   // pattern rows of up to kChunk right nodes: kLean has ONE buffer -- a boundary's rows are dead as soon as their
   // first-stage states are in s1b / s1t, the next boundary's (or the next pass's) rows are requested right then;
   // the other variants keep the next boundary's rows (pRn[par ^ 1]) apart from the pass buffer pR
@@ -396,11 +397,11 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   // The candidate slots / keys of phase 1 and the bigram states of phases 3-5 are never live together
   // (the states die with the tail of a boundary, the candidates of the next one are requested after it),
   // so they share one buffer.
-  constexpr u32 kCandBytes = kCandCap * sizeof(BeamSlot) + 64 * sizeof(u64);
+  constexpr u32 kCandBytes = kCandSlots * sizeof(BeamSlot) + 64 * sizeof(u64);
   constexpr u32 kS1Bytes = kChunk * kS1 * sizeof(u64);
   __shared__ __attribute__((aligned(16))) unsigned char u_buf[kCandBytes > kS1Bytes ? kCandBytes : kS1Bytes];
   BeamSlot* const cand = reinterpret_cast<BeamSlot*>(u_buf);                    // live beam slots of the left nodes
-  u64* const ckey = reinterpret_cast<u64*>(u_buf + kCandCap * sizeof(BeamSlot));  // their keys (rank selection)
+  u64* const ckey = reinterpret_cast<u64*>(u_buf + kCandSlots * sizeof(BeamSlot));  // their keys (rank selection)
   u64(*const s1b)[kS1] = reinterpret_cast<u64(*)[kS1]>(u_buf);
   __shared__ u64 s1t[kChunk][kDynMaxTri];
   __shared__ u64 s_tripre[kDynMaxTri];
@@ -581,87 +582,195 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
     int ngb = 0;
     const u32 ncand = L * (u32)beam;
     const u32 invBeam = small_div_inv((u32)beam);   // (candidate index -> (left, slot); ncand <= 2048 is checked below)
-    const bool fastCand = ncand <= (u32)kCandCap && L <= kEnnCap;
-    if (fastCand) {
-      // the candidates' beam slots go straight to LDS (one dwordx4 per slot); they stay there for the winners
-      for (u32 q0 = 0; q0 < ncand; q0 += 64) {
-        const u32 q = q0 + (u32)lane;
-        const u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
-        lds_async_load<16>(&cand[q0], &beams[(u64)enL[q < ncand ? l : 0] * beam + k], q < ncand);
-      }
-      lds_async_wait();   // invariant (1) above: also covers this boundary's prefetch() and ring refill
-      wave_sync();
-    }
-    {
-      u64 last = ~u64{0};
+    // (wide variant: chunks of kCandCap keys, any number of them up to the staged ends list)
+    const bool fastCand = (GM > 8 ? ncand <= 2048u : ncand <= (u32)kCandCap) && L <= kEnnCap;
+    if constexpr (GM > 8) {
+      // WIDE VARIANT (round 4).  Up to 512 candidates = 16 left nodes at beam 32: every lane reads the 8 bytes of its
+      // candidates' slots that make the key (left | beam | total) straight into registers, eight loads in flight; nothing
+      // is staged in LDS.  (Until round 4: 256 slots of 16 bytes in LDS, and anything beyond that -- every boundary with
+      // more than 8 left nodes -- took G rounds of a wave-wide maximum over HBM: 42 % of the kernel on the configs[4]
+      // shape, profiles/r04_m_phases5.txt.)
       if (fastCand) {
-        // every lane keeps its <= 4 candidate keys in registers
-        u64 mykey[kCandCap / 64];
-#pragma unroll
-        for (int jx = 0; jx < kCandCap / 64; ++jx) {
-          u32 q = (u32)lane + 64u * jx;
-          u64 key = 0;
-          if (q < ncand) {
-            u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
-            BeamSlot sl = cand[q];
-            if (!slot_fake(sl)) key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
-          }
-          mykey[jx] = key;
-        }
-        if (ncand <= 64u) {
-          // the keys are unique, so the global beam is "every key with fewer than G larger ones":
-          // each lane ranks its own key against the others (LDS broadcast reads)
-          ckey[lane] = mykey[0];
-          wave_sync();
-          const u64 me = mykey[0];
-          u32 rank = 0;
-          for (u32 z = 0; z < ncand; ++z) rank += ckey[z] > me ? 1u : 0u;
-          const int live = popc64(wave_ballot(me != 0));
-          ngb = live < G ? live : G;
-          if (me != 0 && rank < (u32)G) gb_key[rank] = me;
-        } else {
-          // More than 64 candidates (wide beams): the G-th largest key by a bitwise threshold search -- per
-          // bit one compare per register-resident key and a ballot count, no cross-lane reduction chain --
-          // then the selected keys are compacted and ranked among themselves (the keys are unique).
+        // Chunks of 256 candidates (4 keys per lane): the G best keys of every chunk go to a pool in LDS, the G best of
+        // the pool are the global beam (the top G of a union lie in the union of the parts' top G).  One chunk is the
+        // common case; 2 048 candidates = 64 left nodes at beam 32 make eight chunks and one pool pass.
+        u64* const pool = ckey + 64;   // [256]: u_buf holds 64 scratch keys + the pool (2 560 bytes)
+        static_assert(kCandCap == 256 && sizeof(u_buf) >= (64 + 256) * sizeof(u64), "pool of the chunked global beam");
+        // the bits a key can have: 63..32 total, 16 + log2(kEnnCap) .. 16 left index, 4..0 (beam <= 32) slot
+        auto key_bit = [](int bit) { return bit >= 32 || (bit >= 16 && bit <= 22) || bit <= 5; };
+        // top G of the (<= 256) keys in `k4`, ranked, written to dst[0 .. return value)
+        auto select4 = [&](u64 (&k4)[4], u64* dst) -> int {
           int live = 0;
 #pragma unroll
-          for (int jx = 0; jx < kCandCap / 64; ++jx) live += popc64(wave_ballot(mykey[jx] != 0));
-          ngb = live < G ? live : G;
-          u64 thr = 1;   // every live key is >= 1
+          for (int jx = 0; jx < 4; ++jx) live += popc64(wave_ballot(k4[jx] != 0));
+          const int want = live < G ? live : G;
+          u64 lo = 1;   // every live key is >= 1
           if (live > G) {
-            thr = 0;
-            // bits that can be set in a key: 63..32 total, 16 + log2(kEnnCap).. 16 left index, 4..0 (beam <= 32) slot
-            for (int bit = 63; bit >= 0; --bit) {
-              if (bit < 32 && !((bit >= 16 && bit <= 22) || bit <= 5)) continue;
-              const u64 c2 = thr | (u64{1} << bit);
-              int cntGe = 0;
+            // the G-th largest of the 64 per-lane maxima is a lower bound of the G-th largest key
+            u64 mx = 0;
 #pragma unroll
-              for (int jx = 0; jx < kCandCap / 64; ++jx) cntGe += popc64(wave_ballot(mykey[jx] >= c2));
-              if (cntGe >= G) thr = c2;
+            for (int jx = 0; jx < 4; ++jx) mx = k4[jx] > mx ? k4[jx] : mx;
+            if (popc64(wave_ballot(mx != 0)) > G) {
+              lo = 0;
+              for (int bit = 63; bit >= 0; --bit) {
+                if (!key_bit(bit)) continue;
+                const u64 c2 = lo | (u64{1} << bit);
+                if (popc64(wave_ballot(mx >= c2)) >= G) lo = c2;
+              }
+            }
+            int c0 = 0;
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) c0 += popc64(wave_ballot(k4[jx] >= lo));
+            if (c0 > 64) {
+              // (a few lanes hold most of the large keys) the exact threshold, bit by bit over all registers
+              lo = 0;
+              for (int bit = 63; bit >= 0; --bit) {
+                if (!key_bit(bit)) continue;
+                const u64 c2 = lo | (u64{1} << bit);
+                int cntGe = 0;
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) cntGe += popc64(wave_ballot(k4[jx] >= c2));
+                if (cntGe >= G) lo = c2;
+              }
             }
           }
-          // compaction: position = number of selected keys in earlier registers / lower lanes
+          // the survivors (at most 64), one per lane, ranked among themselves (the keys are unique)
           int base = 0;
 #pragma unroll
-          for (int jx = 0; jx < kCandCap / 64; ++jx) {
-            const bool sel = mykey[jx] != 0 && mykey[jx] >= thr;
+          for (int jx = 0; jx < 4; ++jx) {
+            const bool sel = k4[jx] != 0 && k4[jx] >= lo;
             const u64 m = wave_ballot(sel);
-            if (sel) ckey[base + popc64(m & ((u64{1} << lane) - 1))] = mykey[jx];
+            if (sel) ckey[base + popc64(m & ((u64{1} << lane) - 1))] = k4[jx];
             base += popc64(m);
           }
           wave_sync();
-          if (lane < ngb) {
+          if (lane < base) {
             const u64 me = ckey[lane];
             u32 rank = 0;
-            for (int z = 0; z < ngb; ++z) rank += ckey[z] > me ? 1u : 0u;
-            gb_key[rank] = me;
+            for (int z = 0; z < base; ++z) rank += ckey[z] > me ? 1u : 0u;
+            if (rank < (u32)want) dst[rank] = me;
           }
+          wave_sync();
+          return want;
+        };
+        const bool oneChunk = ncand <= 256u;
+        int npool = 0;
+        for (u32 c0 = 0; c0 < ncand; c0 += 256u) {
+          u64 raw[4];
+          u64 k4[4];
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) {
+            const u32 q = c0 + (u32)lane + 64u * jx;
+            const u32 qq = q < ncand ? q : 0;
+            const u32 l = small_div(qq, invBeam), k = qq - l * (u32)beam;
+            raw[jx] = *reinterpret_cast<const u64*>(&beams[(u64)as_lds(enL)[l] * beam + k]);   // {u16 left, u16 beam, f32 total}
+          }
+          if (c0 == 0) lds_async_wait();   // invariant (1): this boundary's prefetch() and ring refill were issued before these loads
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) {
+            const u32 q = c0 + (u32)lane + 64u * jx;
+            const u32 l = small_div(q < ncand ? q : 0, invBeam), k = q - l * (u32)beam;
+            const bool fake = (u32)raw[jx] == 0xffffffffu;   // left == beam == 0xffff
+            k4[jx] = (q < ncand && !fake) ? (((u64)f32_sortable(__builtin_bit_cast(float, (u32)(raw[jx] >> 32))) << 32) | ((u64)l << 16) | k) : 0;
+          }
+          npool += select4(k4, oneChunk ? gb_key : pool + npool);
+        }
+        if (oneChunk) {
+          ngb = npool;
+        } else {
+          u64 k4[4];
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) k4[jx] = ((int)lane + 64 * jx) < npool ? pool[lane + 64 * jx] : 0;
+          wave_sync();
+          ngb = select4(k4, gb_key);
         }
       } else {
         lds_async_wait();   // invariant (2) above
-        (void)last;
         ngb = global_beam_from_hbm(beams, en + efirst, ncand, beam, G, gb_key);
       }
+    } else {
+      if (fastCand) {
+        // the candidates' beam slots go straight to LDS (one dwordx4 per slot); they stay there for the winners
+        for (u32 q0 = 0; q0 < ncand; q0 += 64) {
+          const u32 q = q0 + (u32)lane;
+          const u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
+          lds_async_load<16>(&cand[q0], &beams[(u64)enL[q < ncand ? l : 0] * beam + k], q < ncand);
+        }
+        lds_async_wait();   // invariant (1) above: also covers this boundary's prefetch() and ring refill
+        wave_sync();
+      }
+      {
+        u64 last = ~u64{0};
+        if (fastCand) {
+          // every lane keeps its <= 4 candidate keys in registers
+          u64 mykey[kCandCap / 64];
+  #pragma unroll
+          for (int jx = 0; jx < kCandCap / 64; ++jx) {
+            u32 q = (u32)lane + 64u * jx;
+            u64 key = 0;
+            if (q < ncand) {
+              u32 l = small_div(q, invBeam), k = q - l * (u32)beam;
+              BeamSlot sl = cand[q];
+              if (!slot_fake(sl)) key = ((u64)f32_sortable(sl.total) << 32) | ((u64)l << 16) | k;
+            }
+            mykey[jx] = key;
+          }
+          if (ncand <= 64u) {
+            // the keys are unique, so the global beam is "every key with fewer than G larger ones":
+            // each lane ranks its own key against the others (LDS broadcast reads)
+            ckey[lane] = mykey[0];
+            wave_sync();
+            const u64 me = mykey[0];
+            u32 rank = 0;
+            for (u32 z = 0; z < ncand; ++z) rank += ckey[z] > me ? 1u : 0u;
+            const int live = popc64(wave_ballot(me != 0));
+            ngb = live < G ? live : G;
+            if (me != 0 && rank < (u32)G) gb_key[rank] = me;
+          } else {
+            // More than 64 candidates (wide beams): the G-th largest key by a bitwise threshold search -- per
+            // bit one compare per register-resident key and a ballot count, no cross-lane reduction chain --
+            // then the selected keys are compacted and ranked among themselves (the keys are unique).
+            int live = 0;
+  #pragma unroll
+            for (int jx = 0; jx < kCandCap / 64; ++jx) live += popc64(wave_ballot(mykey[jx] != 0));
+            ngb = live < G ? live : G;
+            u64 thr = 1;   // every live key is >= 1
+            if (live > G) {
+              thr = 0;
+              // bits that can be set in a key: 63..32 total, 16 + log2(kEnnCap).. 16 left index, 4..0 (beam <= 32) slot
+              for (int bit = 63; bit >= 0; --bit) {
+                if (bit < 32 && !((bit >= 16 && bit <= 22) || bit <= 5)) continue;
+                const u64 c2 = thr | (u64{1} << bit);
+                int cntGe = 0;
+  #pragma unroll
+                for (int jx = 0; jx < kCandCap / 64; ++jx) cntGe += popc64(wave_ballot(mykey[jx] >= c2));
+                if (cntGe >= G) thr = c2;
+              }
+            }
+            // compaction: position = number of selected keys in earlier registers / lower lanes
+            int base = 0;
+  #pragma unroll
+            for (int jx = 0; jx < kCandCap / 64; ++jx) {
+              const bool sel = mykey[jx] != 0 && mykey[jx] >= thr;
+              const u64 m = wave_ballot(sel);
+              if (sel) ckey[base + popc64(m & ((u64{1} << lane) - 1))] = mykey[jx];
+              base += popc64(m);
+            }
+            wave_sync();
+            if (lane < ngb) {
+              const u64 me = ckey[lane];
+              u32 rank = 0;
+              for (int z = 0; z < ngb; ++z) rank += ckey[z] > me ? 1u : 0u;
+              gb_key[rank] = me;
+            }
+          }
+        } else {
+          lds_async_wait();   // invariant (2) above
+          (void)last;
+          ngb = global_beam_from_hbm(beams, en + efirst, ncand, beam, G, gb_key);
+        }
+      }
+
     }
     wave_sync();
     ngb = uni(ngb);
@@ -670,9 +779,12 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
       u32 l = (u32)(key >> 16) & 0xffff, k = (u32)key & 0xffff;
       u32 lnode;
       u32 pnode;
-      if (fastCand) {
+      if (fastCand && GM <= 8) {
         lnode = enL[l];
         pnode = as_lds(cand)[l * (u32)beam + k].prev_node;   // (a plain ds_read: see as_lds)
+      } else if (fastCand) {
+        lnode = as_lds(enL)[l];
+        pnode = beams[(u64)lnode * beam + k].prev_node;   // (wide variant: one gather for the <= 32 winners)
       } else {
         lnode = en[efirst + l];
         pnode = beams[(u64)lnode * beam + k].prev_node;
