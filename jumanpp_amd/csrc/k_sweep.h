@@ -366,10 +366,10 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   // default configuration: tail-association bigram sum of (right node t, T1 row 0), formed in the prescore pass
   constexpr bool kHeadShare = DEF && RM > 0;
   __shared__ float biS0[kHeadShare ? RM : 1];
-  __shared__ float tot[kChunk][GM];
+  __shared__ __attribute__((aligned(16))) float tot[kChunk][GM];
   // makeT0Beam replay (wide variant, ties only): (total bits << 32 | candidate index) per candidate, so that a
   // comparison of the step-by-step sort costs one LDS read per side instead of two dependent ones
-  __shared__ u64 skey[GM > 16 ? kChunk : 1][GM];
+  __shared__ __attribute__((aligned(16))) u64 skey[GM > 16 ? kChunk : 1][GM];
   __shared__ u8 shave[GM > 16 ? kChunk : 1];   // per node of the pass: length of the sorted range | 0x80 if already in final order
   __shared__ u8 sreplay[GM > 16 ? kChunk : 1];  // per node of the pass: its totals tie, the sort is replayed
   __shared__ float t0R[kChunk];
@@ -611,12 +611,22 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) mx = k4[jx] > mx ? k4[jx] : mx;
             if (popc64(wave_ballot(mx != 0)) > G) {
-              lo = 0;
-              for (int bit = 63; bit >= 0; --bit) {
-                if (!key_bit(bit)) continue;
-                const u64 c2 = lo | (u64{1} << bit);
-                if (popc64(wave_ballot(mx >= c2)) >= G) lo = c2;
+              // every lane ranks its maximum among the 64 (LDS broadcast reads, no serial chain: the search bit by bit
+              // that stood here until round 4 was 44 dependent ballots); the keys are unique, so one lane holds rank G-1
+              struct alignas(16) K2 { u64 k[2]; };
+              const K2* k2 = reinterpret_cast<const K2*>(ckey);
+              ckey[lane] = mx;
+              wave_sync();
+              u32 rk = 0;
+#pragma unroll
+              for (int z2 = 0; z2 < 32; ++z2) {
+                const K2 o2 = k2[z2];
+                rk += o2.k[0] > mx ? 1u : 0u;
+                rk += o2.k[1] > mx ? 1u : 0u;
               }
+              const u64 hit = wave_ballot(mx != 0 && rk == (u32)(G - 1));
+              lo = wave_shfl_u64(mx, hit ? __builtin_ctzll(hit) : 0);
+              wave_sync();   // (ckey is written again below)
             }
             int c0 = 0;
 #pragma unroll
@@ -643,12 +653,22 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
             if (sel) ckey[base + popc64(m & ((u64{1} << lane) - 1))] = k4[jx];
             base += popc64(m);
           }
+          if (lane >= base) ckey[lane] = 0;
           wave_sync();
-          if (lane < base) {
+          {
+            struct alignas(16) K2 { u64 k[2]; };
+            const K2* k2 = reinterpret_cast<const K2*>(ckey);
             const u64 me = ckey[lane];
             u32 rank = 0;
-            for (int z = 0; z < base; ++z) rank += ckey[z] > me ? 1u : 0u;
-            if (rank < (u32)want) dst[rank] = me;
+            for (int z0 = 0; z0 < base; z0 += 8) {   // (base <= 64 is uniform; eight keys in flight per round; the slots
+#pragma unroll                                     //  beyond `base` hold 0, which is greater than no key)
+              for (int u = 0; u < 4; ++u) {
+                const K2 o2 = k2[z0 / 2 + u];
+                rank += o2.k[0] > me ? 1u : 0u;
+                rank += o2.k[1] > me ? 1u : 0u;
+              }
+            }
+            if (lane < base && rank < (u32)want) dst[rank] = me;
           }
           wave_sync();
           return want;
@@ -666,6 +686,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
             raw[jx] = *reinterpret_cast<const u64*>(&beams[(u64)as_lds(enL)[l] * beam + k]);   // {u16 left, u16 beam, f32 total}
           }
           if (c0 == 0) lds_async_wait();   // invariant (1): this boundary's prefetch() and ring refill were issued before these loads
+          JPP_PROF(11);
 #pragma unroll
           for (int jx = 0; jx < 4; ++jx) {
             const u32 q = c0 + (u32)lane + 64u * jx;
@@ -674,6 +695,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
             k4[jx] = (q < ncand && !fake) ? (((u64)f32_sortable(__builtin_bit_cast(float, (u32)(raw[jx] >> 32))) << 32) | ((u64)l << 16) | k) : 0;
           }
           npool += select4(k4, oneChunk ? gb_key : pool + npool);
+          JPP_PROF(12);
         }
         if (oneChunk) {
           ngb = npool;
@@ -774,6 +796,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
     }
     wave_sync();
     ngb = uni(ngb);
+    JPP_PROF(13);
     if (lane < ngb) {
       u64 key = gb_key[lane];
       u32 l = (u32)(key >> 16) & 0xffff, k = (u32)key & 0xffff;
@@ -1020,13 +1043,19 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
       }
       auto s1Row = [&](int x) -> int { return small ? (int)order[op0 + x] : x; };
       auto t0Of = [&](int x) -> float { return small ? t0n[par][order[op0 + x]] : t0R[x]; };
-      // (narrow variant) the trigram weights of 5b are requested before the bigram pass 5a, so that both sets of
-      // gathers are in flight together instead of one HBM round trip after the other; nx * ngb <= 64: the lane
-      // that requests them is the lane that sums them in 5b
-      float wtri[spec::kNumTri] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (GM <= 8) {
-        static_assert(kChunk * GM <= 64 || GM > 8, "one lane per (node, entry) of a pass");
-        const int q = lane;
+      // The trigram weights of 5b are requested before the bigram pass 5a, so that both sets of gathers are in flight
+      // together instead of one HBM round trip after the other.  Narrow variant: nx * ngb <= 64, one (node, entry) per
+      // lane.  Wide variant (round 4): up to kChunk * GM / 64 = 4 per lane, 16 gathers in flight (until then 5b ran
+      // its items one after the other, four gathers and a full round trip each).  The lane that requests a weight is
+      // the lane that sums it in 5b.
+      constexpr int kItems = GM <= 8 ? 1 : kChunk * GM / 64;
+      static_assert(kChunk * GM <= 64 * kItems, "kItems (node, entry) pairs per lane cover a pass");
+      float wtri[kItems][spec::kNumTri];
+#pragma unroll
+      for (int jx = 0; jx < kItems; ++jx) {
+#pragma unroll
+        for (int f = 0; f < spec::kNumTri; ++f) wtri[jx][f] = 0.f;
+        const int q = lane + 64 * jx;
         if (q < nx * ngb) {
           const int x = (int)small_div((u32)q, invNgb), i = q - x * ngb;
           if (i >= c && (op0 + x) < K) {
@@ -1038,7 +1067,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
               if (DYN && f >= nTri) continue;
               const int i1 = DYN ? (int)s_trit[f][1] : kNg.tri_t1[f], i2 = DYN ? (int)s_trit[f][2] : kNg.tri_t2[f];
               u32 idx = hmix_index<W24>(hmix(st[f], t1r[i1]), t2r[i2], wmask);
-              wtri[f] = W[idx];
+              wtri[jx][f] = W[idx];
             }
           }
         }
@@ -1049,23 +1078,39 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         const int Ur = kHeadShare ? U - 1 : U;
         const u32 invUr = small_div_inv((u32)Ur);
         const int units = nx * Ur;
-        for (int base = 0; base < units; base += 8) {
-          int u = base + grp;
-          bool act = u < units;
-          int x = act ? (int)small_div((u32)u, invUr) : 0, tu = act ? u - x * Ur : 0;
-          if (kHeadShare) tu += 1;
-          act = act && (op0 + x) < K;
-          float w[kBiPerLane];
-          bi_gather_s1<W24>(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w, nBi);
-          const float s2 = DYN ? 0.f : bi_sum2(w, lane, gj, nBi);
-          const float s4 = bi_sum4(w, lane, gj, nBi);
-          if (act && gj == 0) biS[x][tu] = (DYN || tu == U - 1) ? s4 : s2;
+        // (wide variant: two rounds of units per iteration, their gathers in flight together)
+        constexpr int kRounds = GM <= 8 ? 1 : 2;
+        for (int base = 0; base < units; base += 8 * kRounds) {
+          float w[kRounds][kBiPerLane];
+          int xs[kRounds], tus[kRounds];
+          bool acts[kRounds];
+#pragma unroll
+          for (int r = 0; r < kRounds; ++r) {
+            int u = base + 8 * r + grp;
+            bool act = u < units;
+            int x = act ? (int)small_div((u32)u, invUr) : 0, tu = act ? u - x * Ur : 0;
+            if (kHeadShare) tu += 1;
+            act = act && (op0 + x) < K;
+            bi_gather_s1<W24>(lbi, gj, s1b[s1Row(x)], t1pat[tu], W, wmask, act, w[r], nBi);
+            xs[r] = x;
+            tus[r] = tu;
+            acts[r] = act;
+          }
+#pragma unroll
+          for (int r = 0; r < kRounds; ++r) {
+            const float s2 = DYN ? 0.f : bi_sum2(w[r], lane, gj, nBi);
+            const float s4 = bi_sum4(w[r], lane, gj, nBi);
+            if (acts[r] && gj == 0) biS[xs[r]][tus[r]] = (DYN || tus[r] == U - 1) ? s4 : s2;
+          }
         }
       }
       wave_sync();
       JPP_PROF(5);
       // 5b. cells and totals per (node, gbeam entry)
-      for (int q = lane; q < nx * ngb; q += 64) {
+#pragma unroll
+      for (int jx = 0; jx < kItems; ++jx) {
+        const int q = lane + 64 * jx;
+        if (q >= nx * ngb) continue;
         int x = (int)small_div((u32)q, invNgb), i = q - x * ngb;
         bool kept = (op0 + x) < K;
         u32 t = order[op0 + x];
@@ -1079,24 +1124,9 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           v += gb_score[i];
           total = v;
         } else if (kept) {
-          const u64* st = s1t[s1Row(x)];
-          const u64* t1r = t1pat[gb_t1[i]];
-          const u64* t2r = t2pat[i];
           float w[spec::kNumTri];
-          if constexpr (GM <= 8) {
-            (void)st; (void)t1r; (void)t2r;
 #pragma unroll
-            for (int f = 0; f < spec::kNumTri; ++f) w[f] = wtri[f];   // requested before 5a
-          } else {
-#pragma unroll
-            for (int f = 0; f < spec::kNumTri; ++f) {
-              w[f] = 0.f;
-              if (DYN && f >= nTri) continue;
-              const int i1 = DYN ? (int)s_trit[f][1] : kNg.tri_t1[f], i2 = DYN ? (int)s_trit[f][2] : kNg.tri_t2[f];
-              u32 idx = hmix_index<W24>(hmix(st[f], t1r[i1]), t2r[i2], wmask);
-              w[f] = W[idx];
-            }
-          }
+          for (int f = 0; f < spec::kNumTri; ++f) w[f] = wtri[jx][f];   // requested before 5a
           static_assert(spec::kNumTri == 4, "trigram association below is written for 4 features");
           float S;
           if (kHeadShare && gb_t1[i] == 0) S = biS0[t];
@@ -1149,8 +1179,8 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         static_assert(GM == 32, "one half-wave per right node");
         // Three passes over the nodes of the chunk (round 4; until then the replay ran inside the rank loop, two nodes
         // per iteration, i.e. up to four serial replays one after the other per chunk): A ranks and ties, nodes without
-        // a tie write their beams; B every node that needs the replay runs it at once, ONE LANE PER NODE; C the parallel
-        // stable rank of the partitioned keys.
+        // a tie write their beams; B the nodes that tie replay the partitioning steps, one half-wave per node (B1) or,
+        // when util::partition comes first, one lane per node (B2); C the parallel stable rank of the partitioned keys.
         for (int q0 = 0; q0 < nx * GM; q0 += 64) {
           const int q = q0 + lane;
           const bool in = q < nx * GM;
@@ -1163,17 +1193,33 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           float me = 0.f;
           int rank = 0;
           bool tie = false;
-          if (i < cnt) {
-            me = tot[x][i];
-            for (int jx = 0; jx < cnt; ++jx) {
-              const float o = tot[x][jx];
-              if (o > me || (o == me && jx < i)) ++rank;
-              tie = tie || (o == me && jx != i);
+          {
+            // every lane goes over all GM totals of its node, four per LDS read, whatever its own count, and keeps the
+            // two comparisons as bit masks by position -- no branch, no short-circuit (round 4: a loop up to `cnt` is
+            // divergent and is not unrolled: 32 dependent LDS round trips per lane and pass, a third of the kernel on
+            // the configs[4] shape, profiles/r04_v_phases5.txt).  Positions beyond the count hold stale totals: masked.
+            struct alignas(16) F4 { float v[4]; };
+            const F4* t4 = reinterpret_cast<const F4*>(tot[x]);
+            me = tot[x][i < GM ? i : 0];
+            u32 gtm = 0, eqm = 0;
+#pragma unroll
+            for (int j4 = 0; j4 < GM / 4; ++j4) {
+              const F4 o4 = t4[j4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const u32 bit = 1u << (j4 * 4 + u);
+                gtm |= o4.v[u] > me ? bit : 0u;
+                eqm |= o4.v[u] == me ? bit : 0u;
+              }
             }
+            const u32 cm = cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u);
+            const u32 below = i >= 32 ? 0xffffffffu : ((1u << i) - 1u), self = i >= 32 ? 0u : (1u << i);
+            rank = __builtin_popcount(gtm & cm) + __builtin_popcount(eqm & below & cm);
+            tie = i < cnt && (eqm & cm & ~self) != 0;
           }
           const u64 tb = wave_ballot(wide && tie);
           const bool replay = wide && ((tb >> (lane & 32)) & 0xffffffffull) != 0;
-          if (in && i == 0) sreplay[x] = replay ? 1 : 0;
+          if (in && i == 0) sreplay[x] = replay ? (cnt > partB ? 2 : 1) : 0;   // 2: util::partition first (serial lane)
           if (!replay) {
             if (i < cnt) {
               if (rank < beam) row[rank] = BeamSlot{gb_left[i], gb_slot[i], me, gb_lnode[i], (u32)i};
@@ -1184,11 +1230,95 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           if (i == 0) B.node_kept[nb + rfirst + t] = kept ? 1 : 0;
         }
         wave_sync();
+        JPP_PROF(8);
         // B. Ties: the partitioning steps of the reference's sort (util::partition beyond beam*4/3, then the Hoare
         // partitions of introsort while a range is longer than 16), replayed step by step.  What follows in std::sort is
         // libstdc++'s final insertion pass, a STABLE sort of the array as partitioned -- i.e. a rank again: greater
         // totals first, equal totals in their order after partitioning (std_sort_partition_only, jpp_select.h).
-        if (lane < nx && sreplay[lane] != 0) {
+        //
+        // B1 (nodes without util::partition, i.e. at most beam*4/3 candidates): one HALF-WAVE per node, lane = position
+        // in the array, the keys in registers.  A Hoare partition around the median-of-three pivot is then a handful of
+        // wave operations instead of a serial scan through LDS: the pivot's value comes from three shuffles; ONE pair
+        // of ballots gives, by position, the elements the upward scan stops at (not greater than the pivot) and the ones
+        // the downward scan stops at (not less); the scans are find-first-set / find-last-set on those masks, a swap
+        // exchanges two positions the scans never look at again except as each other's sentinel (their two bits are
+        // set), and all swaps of the partition -- every position takes part in at most one -- are applied as one
+        // permutation by a single shuffle at the end.  Element for element the sequence of util / libstdc++ steps
+        // (sel_move_median_to_first, sel_unguarded_partition, std_sort_partition_only_le32 in jpp_select.h).
+        for (int x0 = 0; x0 < nx; x0 += 2) {
+          const int x = x0 + (lane >> 5);
+          const int hl = lane & 31, hb = lane & 32;
+          const bool act0 = x < nx && sreplay[x < nx ? x : 0] == 1;
+          if (wave_ballot(act0) == 0) continue;
+          const int cnt = act0 ? (((op0 + x) < K) ? ngb : c) : 0;
+          float v = 0.f;
+          u32 idx = (u32)hl;
+          if (hl < cnt) v = tot[x][hl];
+          int f = 0, l = cnt;
+          int depth = 0;
+          while ((cnt >> (depth + 1)) != 0) ++depth;
+          depth *= 2;
+          bool act = act0, fail = false;
+          for (;;) {
+            bool run = act && (l - f > 16);
+            if (run && depth == 0) {   // introsort's heap-sort fallback: the serial lane replays all of it
+              fail = true;
+              run = false;
+              act = false;
+            }
+            if (wave_ballot(run) == 0) break;
+            --depth;
+            const int a = f + 1, mid = f + (l - f) / 2, cc = l - 1;
+            const float va = wave_shfl_f32(v, run ? hb + a : lane);
+            const float vb = wave_shfl_f32(v, run ? hb + mid : lane);
+            const float vc = wave_shfl_f32(v, run ? hb + cc : lane);
+            const float vf = wave_shfl_f32(v, run ? hb + f : lane);
+            int m;   // the median of the three goes to the front (comp(x, y) = x > y)
+            if (va > vb) m = vb > vc ? mid : va > vc ? cc : a;
+            else m = va > vc ? a : vb > vc ? cc : mid;
+            const float pv = m == a ? va : m == mid ? vb : vc;
+            const float myv = hl == f ? pv : hl == m ? vf : v;
+            const u32 range = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
+            u32 mNG = (u32)(wave_ballot(!(myv > pv)) >> hb) & range;   // the upward scan stops here
+            u32 mNL = (u32)(wave_ballot(!(pv > myv)) >> hb) & range;   // the downward scan stops here
+            int src = hl;
+            if (run) {
+              int first = f + 1, last = l;
+              for (;;) {
+                const u32 up = (mNG >> first) << first;
+                first = up ? __builtin_ctz(up) : l;
+                --last;
+                const u32 dn = mNL & ((2u << last) - 1u);
+                last = dn ? 31 - __builtin_clz(dn) : f;
+                if (!(first < last)) break;
+                if (hl == first) src = last;
+                else if (hl == last) src = first;
+                mNG |= 1u << last;
+                mNL |= 1u << first;
+                ++first;
+              }
+              src = src == f ? m : src == m ? f : src;   // the pivot's exchange came first
+              if (l - first > 16) f = first;   // the right part is the long one
+              else l = first;
+            }
+            v = wave_shfl_f32(v, hb + src);
+            idx = wave_shfl_u32(idx, hb + src);
+          }
+          if (act0 && fail) {
+            if (hl == 0) sreplay[x] = 2;
+          } else if (act0) {
+            if (hl < cnt) {
+              u32 bits;
+              __builtin_memcpy(&bits, &v, 4);
+              skey[x][hl] = ((u64)bits << 32) | idx;
+            }
+            if (hl == 0) shave[x] = (u8)cnt;
+          }
+        }
+        wave_sync();
+        JPP_PROF(9);
+        // B2 (util::partition first, or the depth limit): ONE LANE per node
+        if (lane < nx && sreplay[lane] == 2) {
           const int x = lane;
           const bool kept = (op0 + x) < K;
           const int cnt = kept ? ngb : c;
@@ -1225,6 +1355,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
           shave[x] = (u8)((itr - keys) | (sorted ? 0x80 : 0));
         }
         wave_sync();
+        JPP_PROF(10);
         // C. the replayed nodes' beams
         for (int q0 = 0; q0 < nx * GM; q0 += 64) {
           const int q = q0 + lane;
@@ -1243,12 +1374,22 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
             int pos = i;
             if (!sorted) {
               pos = 0;
-              for (int p2 = 0; p2 < have; ++p2) {
-                const u32 ob = (u32)(skey[x][p2] >> 32);
-                float ov;
-                __builtin_memcpy(&ov, &ob, 4);
-                if (ov > mv || (ov == mv && p2 < i)) ++pos;
+              struct alignas(16) K2 { u64 k[2]; };
+              const K2* k2 = reinterpret_cast<const K2*>(skey[x]);
+              u32 gtm = 0, eqm = 0;
+#pragma unroll
+              for (int j2 = 0; j2 < GM / 2; ++j2) {   // fixed trip count, two keys per LDS read, masks by position (see pass A)
+                const K2 o2 = k2[j2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                  const u32 bit = 1u << (j2 * 2 + u);
+                  const float ov = __builtin_bit_cast(float, (u32)(o2.k[u] >> 32));
+                  gtm |= ov > mv ? bit : 0u;
+                  eqm |= ov == mv ? bit : 0u;
+                }
               }
+              const u32 hm = have >= 32 ? 0xffffffffu : ((1u << have) - 1u);
+              pos = __builtin_popcount(gtm & hm) + __builtin_popcount(eqm & hm & ((1u << i) - 1u));
             }
             const u32 iz = (u32)mine & 0xffu;
             if (pos < beam) row[pos] = BeamSlot{gb_left[iz], gb_slot[iz], mv, gb_lnode[iz], iz};

@@ -48,5 +48,10 @@ if '--rnn' in sys.argv:
     for n_, v in zip(rn, rv):
         print('rnn %-30s %6.2f %%' % (n_, 100.0 * v / max(1, rt)))
     print('rnn cycles per sentence (lane 0): %.0f' % (buf[14] / max(1, buf[15])))
+if '--fine' in sys.argv:   # finer marks inside the phases (k_sweep<32,*>: 5c = A ranks | B1 half-wave replays | B2 serial replays | C)
+    fine = [buf[i] for i in range(8, 14)]
+    tot += sum(fine)
+    names += ['fine %d' % i for i in range(8, 14)]
+    vals += fine
 for n_, v in zip(names, vals):
     print('%-30s %6.2f %%' % (n_, 100.0 * v / max(1, tot)))
