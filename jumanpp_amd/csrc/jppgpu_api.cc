@@ -1688,18 +1688,18 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       // table-driven variants (a spec other than the built-in jumandic tables)
       if (nCls[0]) {
         if (narrow) JPP_LAUNCH((k_sweep<8, 64, false, false, kSweepWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
-        else JPP_LAUNCH((k_sweep<32, 64, false, false, kSweepWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
+        else JPP_LAUNCH((k_sweep<32, 64, false, false, kSweepWideWaves, 0, true>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
       }
       T.mark(11, st);
       T.mark(9, s12);
       if (nCls[1]) {
         if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
-        else JPP_LAUNCH((k_sweep<32, kMaxRight, false, false, kSweepWaves, 0, true>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
+        else JPP_LAUNCH((k_sweep<32, kMaxRight, false, false, kSweepWideWaves, 0, true>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
       }
       T.mark(10, s12);
       if (nCls[2]) {
         if (narrow) JPP_LAUNCH((k_sweep<8, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
-        else JPP_LAUNCH((k_sweep<32, 0, false, false, kSweepWaves, 0, true>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
+        else JPP_LAUNCH((k_sweep<32, 0, false, false, kSweepWideWaves, 0, true>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
       }
     } else {
     if (nCls[0]) {   // at most 64 right nodes per boundary, right-check <= 2
@@ -1717,18 +1717,18 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       else if (def && w24) JPP_LAUNCH_LDS((k_sweep<8, 64, true, true, 5, 2>), nCls[0], 64, devPad, st, B, dmS, ctx->cfg, lists[0]);
       else if (def) JPP_LAUNCH((k_sweep<8, 64, true, false, 5, 2>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
       else if (narrow) JPP_LAUNCH((k_sweep<8, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);
-      else JPP_LAUNCH((k_sweep<32, 64>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);   // 6 KB less LDS per wavefront than the 512-wide staging
+      else JPP_LAUNCH((k_sweep<32, 64, false, false, kSweepWideWaves>), nCls[0], 64, st, B, dmS, ctx->cfg, lists[0]);   // 6 KB less LDS per wavefront than the 512-wide staging
     }
     T.mark(11, st);
     T.mark(9, s12);
     if (nCls[1]) {   // at most kMaxRight right nodes per boundary (and right-check * R prescores within the staging)
       if (narrow) JPP_LAUNCH((k_sweep<8, kMaxRight>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
-      else JPP_LAUNCH((k_sweep<32, kMaxRight>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
+      else JPP_LAUNCH((k_sweep<32, kMaxRight, false, false, kSweepWideWaves>), nCls[1], 64, s12, B, dmS, ctx->cfg, lists[1]);
     }
     T.mark(10, s12);
     if (nCls[2]) {   // any width
       if (narrow) JPP_LAUNCH((k_sweep<8, 0>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
-      else JPP_LAUNCH((k_sweep<32, 0>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
+      else JPP_LAUNCH((k_sweep<32, 0, false, false, kSweepWideWaves>), nCls[2], 64, s12, B, dmS, ctx->cfg, lists[2]);
     }
     }
     T.mark(12, s12);

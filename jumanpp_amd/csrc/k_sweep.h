@@ -58,6 +58,7 @@ struct NgramTables {
 constexpr NgramTables kNg{};
 
 constexpr int kSweepWaves = 4;  // wavefronts per SIMD the LDS footprint of the narrow variant allows
+constexpr int kSweepWideWaves = 3;  // ... and of the wide variant (beam up to 32): 168 VGPRs, about 15 KB of LDS
 constexpr int kChunk = 8;       // right nodes processed per pass (= 8-lane groups per wave)
 constexpr int kPresCap = 1024;  // rcheck * R prescores staged in LDS
 
@@ -367,9 +368,6 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   constexpr bool kHeadShare = DEF && RM > 0;
   __shared__ float biS0[kHeadShare ? RM : 1];
   __shared__ __attribute__((aligned(16))) float tot[kChunk][GM];
-  // makeT0Beam replay (wide variant, ties only): (total bits << 32 | candidate index) per candidate, so that a
-  // comparison of the step-by-step sort costs one LDS read per side instead of two dependent ones
-  __shared__ __attribute__((aligned(16))) u64 skey[GM > 16 ? kChunk : 1][GM];
   __shared__ u8 shave[GM > 16 ? kChunk : 1];   // per node of the pass: length of the sorted range | 0x80 if already in final order
   __shared__ u8 sreplay[GM > 16 ? kChunk : 1];  // per node of the pass: its totals tie, the sort is replayed
   __shared__ float t0R[kChunk];
@@ -403,6 +401,10 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   BeamSlot* const cand = reinterpret_cast<BeamSlot*>(u_buf);                    // live beam slots of the left nodes
   u64* const ckey = reinterpret_cast<u64*>(u_buf + kCandSlots * sizeof(BeamSlot));  // their keys (rank selection)
   u64(*const s1b)[kS1] = reinterpret_cast<u64(*)[kS1]>(u_buf);
+  // makeT0Beam replay (wide variant, ties only): (total bits << 32 | candidate index) per candidate of the pass's nodes.
+  // Written and read in 5c only, when the candidates' keys (phase 1) and the bigram states (dead after 5a) are gone.
+  u64(*const skey)[GM] = reinterpret_cast<u64(*)[GM]>(u_buf);
+  static_assert(GM <= 16 || sizeof(u_buf) >= kChunk * GM * sizeof(u64), "replay keys share the candidate / state buffer");
   __shared__ u64 s1t[kChunk][kDynMaxTri];
   __shared__ u64 s_tripre[kDynMaxTri];
   __shared__ u8 s_trit[kDynMaxTri][4];
