@@ -242,17 +242,56 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_connect(Batch B) {
     }
     ok = ((reach >> n) & 1) != 0;
   } else {
-    if (lane != 0) return;
-    u8* reach = B.reach + g0;  // n + 1 entries
-    for (u32 i = 0; i <= n; ++i) reach[i] = 0;
-    reach[0] = 1;
-    for (u32 i = 0; i < n; ++i) {
-      if (!reach[i]) continue;
-      u32 first = B.bnd_first[bb0 + i + 2];
-      u32 cnt = B.bnd_cnt[bb0 + i + 2];
-      for (u32 k = 0; k < cnt; ++k) reach[ni[first + k].end] = 1;
+    // Longer sentences (round 4; until then one lane walked every node of the sentence, a dependent HBM read each:
+    // 3 ms per batch of 220-codepoint sentences).  64 start positions at a time: lane i builds the mask of the ends of
+    // its position's nodes RELATIVE to the position (bit d: a node of d codepoints), then the window `win` -- bit d:
+    // position p + d is reachable -- slides over the 64 positions with one broadcast per position.  A node longer than
+    // 63 codepoints (a long run of digits or letters) sends the sentence to the sequential pass below.
+    u64 win = 1;   // position 0 is reachable
+    bool far = false;
+    for (u32 p0 = 0; p0 < n && !far; p0 += 64) {
+      const u32 p = p0 + (u32)lane;
+      u64 rel = 0;
+      bool fr = false;
+      if (p < n) {
+        const u32 first = B.bnd_first[bb0 + p + 2];
+        const u32 cnt = B.bnd_cnt[bb0 + p + 2];
+        for (u32 k = 0; k < cnt; k += 4) {
+          u16 e[4];
+#pragma unroll
+          for (u32 q = 0; q < 4; ++q) e[q] = (k + q < cnt) ? ni[first + k + q].end : (u16)0;
+#pragma unroll
+          for (u32 q = 0; q < 4; ++q) {
+            if (k + q >= cnt) continue;
+            const u32 d = (u32)e[q] - p;
+            if (d <= 63) rel |= u64{1} << d;
+            else fr = true;
+          }
+        }
+      }
+      far = wave_ballot(fr) != 0;
+      if (far) break;
+      const u32 m = n - p0 < 64u ? n - p0 : 64u;
+      for (u32 i = 0; i < m; ++i) {
+        const u64 r = wave_shfl_u64(rel, (int)i);
+        if (win & 1) win |= r;
+        win >>= 1;
+      }
     }
-    ok = reach[n] != 0;
+    ok = (win & 1) != 0;   // bit 0 after n steps: the end of input
+    if (far) {
+      if (lane != 0) return;
+      u8* reach = B.reach + g0;  // n + 1 entries
+      for (u32 i = 0; i <= n; ++i) reach[i] = 0;
+      reach[0] = 1;
+      for (u32 i = 0; i < n; ++i) {
+        if (!reach[i]) continue;
+        u32 first = B.bnd_first[bb0 + i + 2];
+        u32 cnt = B.bnd_cnt[bb0 + i + 2];
+        for (u32 k = 0; k < cnt; ++k) reach[ni[first + k].end] = 1;
+      }
+      ok = reach[n] != 0;
+    }
   }
   if (!ok && lane == 0) {
     if (PASS == 1) B.sent_flags[s] |= 2;

@@ -368,6 +368,7 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
   constexpr bool kHeadShare = DEF && RM > 0;
   __shared__ float biS0[kHeadShare ? RM : 1];
   __shared__ __attribute__((aligned(16))) float tot[kChunk][GM];
+  __shared__ u8 hpart[GM > 16 ? 2 : 1][2][GM > 16 ? 36 : 1];   // per half-wave: positions of the k-th stop of the upward / downward scan (B1)
   __shared__ u8 shave[GM > 16 ? kChunk : 1];   // per node of the pass: length of the sorted range | 0x80 if already in final order
   __shared__ u8 sreplay[GM > 16 ? kChunk : 1];  // per node of the pass: its totals tie, the sort is replayed
   __shared__ float t0R[kChunk];
@@ -1242,10 +1243,9 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
         // in the array, the keys in registers.  A Hoare partition around the median-of-three pivot is then a handful of
         // wave operations instead of a serial scan through LDS: the pivot's value comes from three shuffles; ONE pair
         // of ballots gives, by position, the elements the upward scan stops at (not greater than the pivot) and the ones
-        // the downward scan stops at (not less); the scans are find-first-set / find-last-set on those masks, a swap
-        // exchanges two positions the scans never look at again except as each other's sentinel (their two bits are
-        // set), and all swaps of the partition -- every position takes part in at most one -- are applied as one
-        // permutation by a single shuffle at the end.  Element for element the sequence of util / libstdc++ steps
+        // the downward scan stops at (not less); which positions the loop exchanges follows from the two masks alone
+        // (below), and all exchanges of the partition -- every position takes part in at most one -- are applied as
+        // one permutation by a single shuffle at the end.  Element for element the sequence of util / libstdc++ steps
         // (sel_move_median_to_first, sel_unguarded_partition, std_sort_partition_only_le32 in jpp_select.h).
         for (int x0 = 0; x0 < nx; x0 += 2) {
           const int x = x0 + (lane >> 5);
@@ -1280,29 +1280,54 @@ k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restr
             else m = va > vc ? a : vb > vc ? cc : mid;
             const float pv = m == a ? va : m == mid ? vb : vc;
             const float myv = hl == f ? pv : hl == m ? vf : v;
+            // The scans of sel_unguarded_partition in closed form.  a_1 < a_2 < ... : the positions from f + 1 up whose
+            // element is not greater than the pivot (where the upward scan stops); b_1 > b_2 > ... : the positions from
+            // l - 1 down to f whose element is not less (where the downward scan stops; f holds the pivot itself).  The
+            // k-th round of the loop exchanges a_k and b_k as long as a_k < b_k: in between, the array is untouched, and
+            // an exchanged position stops the other scan (it now holds an element from the other side), so round k + 1
+            // ends at min(a_{k+1}, b_k) and max(b_{k+1}, a_k) -- which cross exactly when a_{k+1} >= b_{k+1}.  With K
+            // exchanges the function returns a_1 (K = 0) or min(a_{K+1}, b_K).  Every lane finds its own rank among the
+            // a's / b's with a population count and its partner through two small tables in LDS: no loop.
             const u32 range = l >= 32 ? 0xffffffffu : ((1u << l) - 1u);
-            u32 mNG = (u32)(wave_ballot(!(myv > pv)) >> hb) & range;   // the upward scan stops here
-            u32 mNL = (u32)(wave_ballot(!(pv > myv)) >> hb) & range;   // the downward scan stops here
+            const u32 ngm = (u32)(wave_ballot(!(myv > pv)) >> hb) & range & ~((2u << f) - 1u);
+            const u32 nlm = (u32)(wave_ballot(!(pv > myv)) >> hb) & range & ~((1u << f) - 1u);
+            const int nL = __builtin_popcount(ngm), nR = __builtin_popcount(nlm);
+            const bool isL = run && ((ngm >> hl) & 1u) != 0, isR = run && ((nlm >> hl) & 1u) != 0;
+            const int kL = __builtin_popcount(ngm & ((2u << hl) - 1u));   // 1-based, from the bottom
+            const int kR = __builtin_popcount(nlm >> hl);                 // 1-based, from the top
+            u8* const pl = hpart[lane >> 5][0];
+            u8* const pr = hpart[lane >> 5][1];
+            if (isL) pl[kL] = (u8)hl;
+            if (isR) pr[kR] = (u8)hl;
+            wave_sync();
             int src = hl;
+            bool partL = false;
+            if (isL && kL <= nR) {
+              const int bk = pr[kL];
+              if (hl < bk) {
+                src = bk;
+                partL = true;
+              }
+            }
+            if (!partL && isR && kR <= nL) {
+              const int ak = pl[kR];
+              if (ak < hl) src = ak;
+            }
+            const int Kx = __builtin_popcount((u32)(wave_ballot(partL) >> hb));
             if (run) {
-              int first = f + 1, last = l;
-              for (;;) {
-                const u32 up = (mNG >> first) << first;
-                first = up ? __builtin_ctz(up) : l;
-                --last;
-                const u32 dn = mNL & ((2u << last) - 1u);
-                last = dn ? 31 - __builtin_clz(dn) : f;
-                if (!(first < last)) break;
-                if (hl == first) src = last;
-                else if (hl == last) src = first;
-                mNG |= 1u << last;
-                mNL |= 1u << first;
-                ++first;
+              int cut;
+              if (Kx == 0) {
+                cut = ngm ? __builtin_ctz(ngm) : l;
+              } else {
+                const int aN = Kx + 1 <= nL ? (int)pl[Kx + 1] : 64;
+                const int bK = pr[Kx];
+                cut = aN < bK ? aN : bK;
               }
               src = src == f ? m : src == m ? f : src;   // the pivot's exchange came first
-              if (l - first > 16) f = first;   // the right part is the long one
-              else l = first;
+              if (l - cut > 16) f = cut;   // the right part is the long one
+              else l = cut;
             }
+            wave_sync();   // (the tables are written again by the next partition)
             v = wave_shfl_f32(v, hb + src);
             idx = wave_shfl_u32(idx, hb + src);
           }

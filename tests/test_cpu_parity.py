@@ -745,6 +745,44 @@ def test_emulated_maximum_size_sentences(emu_lib, ref_tools, tmp_path):
     assert not errs, errs[:10]
 
 
+def check_long_sentence_connectivity(lib, ref_tools, tmp):
+    """sentences of more than 63 codepoints through k_connect's sliding window: plain ones, ones with a node longer
+    than the window (a run of 70 / 150 digits: the sequential pass), ones whose stretches of unknown characters only
+    connect through the stage-2 makers, and one of each kind next to the 64-codepoint limit"""
+    import test_gpu_parity as tg
+    img, base, _ = tg._fresh_workload(ref_tools, tmp, 2500, 4, 14, 77, length=90)
+    fuzz = _fuzz_lines(40, 9)
+    lines = list(base)
+    lines.append(base[0][:30] + '1' * 70 + base[1][:20])
+    lines.append('9' * 150 + base[2][:10])
+    lines.append(base[3][:20] + 'ａｂｃ' * 25 + base[0][:20])
+    lines.append(''.join(fuzz[:4]))
+    lines.append(''.join(fuzz[4:9]))
+    lines.append(''.join(fuzz[9:12])[:64])
+    lines.append(''.join(fuzz[12:15])[:63])
+    lines.append(''.join(fuzz[15:18])[:65])
+    lines.append(base[1][:60] + '𠮷😀' * 3 + 'ゝゞ々' + base[2][:30])
+    txt = os.path.join(tmp, 'long.txt')
+    open(txt, 'w', encoding='utf-8').write('\n'.join(lines) + '\n')
+    with open(txt, 'rb') as f:
+        subprocess.check_call([os.path.join(ref_tools, 'ref_dump'), 'dump', os.path.join(tmp, 'w.model'),
+                               os.path.join(tmp, 'long.gold')], stdin=f, stderr=subprocess.DEVNULL)
+    meta, gold = G.read_gold(os.path.join(tmp, 'long.gold'))
+    ctx = J.Context(img, lib_path=lib)
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, (len(errs), errs[:10])
+    assert max(len(l) for l in lines) > 150
+
+
+def test_emulated_long_sentence_connectivity(emu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_long_sentence_connectivity(emu_lib, ref_tools, str(tmp_path))
+
+
 # ---- training hook: top-1 n-gram feature values, weight upload ----
 
 def check_top1_ngrams_against_reference(lib, ref_tools, golden_dir, tmp_path, workload=None, min_checked=300):

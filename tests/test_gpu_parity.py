@@ -507,3 +507,11 @@ def test_gpu_wide_global_beam_candidates(gpu_lib, ref_tools, tmp_path, beams):
         pytest.skip('oracle/_ref not built')
     import test_cpu_parity as tc
     tc.check_wide_global_beam_candidates(gpu_lib, ref_tools, str(tmp_path), beams, n_lines=200)
+
+
+@pytest.mark.gpu
+def test_gpu_long_sentence_connectivity(gpu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tc.check_long_sentence_connectivity(gpu_lib, ref_tools, str(tmp_path))

@@ -12,6 +12,7 @@
 #   valu           SQ instruction / activity counters of the hot kernels         -> <TAG>_pmc_summary.txt
 #   variants       A/B of prebuilt build/libjppgpu_*.so (JPPGPU_LIB)             -> <TAG>_variants.txt
 #   cfg5           the configs[4]-shape leg alone                                -> <TAG>_config5.json
+#   trace5         rocprofv3 --kernel-trace of tools/gpu_config5_trace.py          -> <TAG>_config5_rocprof_summary.txt
 #   cli            the CLI end-to-end leg alone                                  -> <TAG>_cli.json
 #   run=SCRIPT     any other helper under tools/ (python or bash), stdout        -> <TAG>_<script>.txt
 # environment: BENCH_ARGS (extra bench.py arguments for quick/trace/traffic/valu/variants), STEPS (default 8)
@@ -51,6 +52,12 @@ for step in "$@"; do
       cd /tmp; rm -rf "$OUT/prof_trace"
       timeout 500 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o trace -- python "$REPO/bench.py" --steps "$STEPS" --warmup 2 $LEAN --no-parity $BA > "$OUT/${TAG}_trace_bench.json" 2> "$OUT/prof_trace.log"
       summ "$OUT/${TAG}_trace_bench.json" ;;
+    trace5)
+      cd /tmp; rm -rf "$OUT/prof_trace"
+      timeout 500 rocprofv3 --kernel-trace --stats -d "$OUT/prof_trace" -o trace -- python "$REPO/tools/gpu_config5_trace.py" > "$OUT/${TAG}_trace5.log" 2> "$OUT/prof_trace.log"
+      python "$REPO/tools/summarize_prof.py" "$OUT" > "$OUT/${TAG}_config5_rocprof_summary.txt" 2>&1
+      head -24 "$OUT/${TAG}_config5_rocprof_summary.txt"; tail -1 "$OUT/${TAG}_trace5.log"
+      rm -rf "$OUT/prof_trace" ;;
     traffic)
       cd /tmp; rm -rf "$OUT/prof_fetch" "$OUT/prof_write"
       timeout 500 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_fetch" -o fetch -- python "$REPO/bench.py" --steps 2 --warmup 1 $LEAN --no-parity $BA > "$OUT/prof_fetch.log" 2>&1
