@@ -223,7 +223,38 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   // id is a chain of a dozen dependent loads through the double array, paid once per 64 list entries instead of
   // once per 64 (boundary, path) slots, most of which are empty or repeats.
   u32 nfirst = 0;
-  for (u32 q0 = 0; q0 < nq; q0 += 64) {
+  // Long sentences (the arrays are in HBM): "which earlier path runs through the same node / the same connection" is
+  // answered inside the wavefront -- 64 / G boundaries per round, lane = (boundary, path), the other paths'
+  // connections by shuffle -- instead of by up to G - 1 dependent reads per slot (round 4: 9.3 -> ... ms per batch
+  // of the configs[4] shape).
+  const u32 rowsPer = 64u / (u32)G > 0 ? 64u / (u32)G : 1u;
+  // first earlier path with the same lattice node (low byte, + 1) and with the same connection (second byte, + 1)
+  auto earlier_paths = [&](u32 c, u32 r, u32 p, bool valid) -> u32 {
+    const u32 nd = c & 0x03ffffffu;
+    u32 fn = 0, fc = 0;
+    for (u32 pp = 0; pp < (u32)G; ++pp) {
+      const u32 c2 = wave_shfl_u32(c, valid ? (int)(r * (u32)G + pp) : lane);
+      const bool before = valid && pp < p && c != kNoConn && c2 != kNoConn;
+      if (before && fn == 0 && (c2 & 0x03ffffffu) == nd) fn = pp + 1;
+      if (before && fc == 0 && c2 == c) fc = pp + 1;
+    }
+    return fn | (fc << 8);
+  };
+  if (!inLds) {
+    for (u32 b0 = 0; b0 <= bE; b0 += rowsPer) {
+      const u32 r = (u32)lane / (u32)G, p = (u32)lane - r * (u32)G;
+      const u32 b = b0 + r;
+      const bool valid = r < rowsPer && b <= bE;
+      const u32 q = b * (u32)G + p;
+      const u32 c = valid ? conn[q] : kNoConn;
+      const u32 e = earlier_paths(c, r, p, valid);
+      const bool first = c != kNoConn && (e & 0xffu) == 0;
+      const u64 m = wave_ballot(first);
+      if (first) assign[nfirst + (u32)popc64(m & ((u64{1} << lane) - 1))] = q;
+      nfirst += (u32)popc64(m);
+    }
+  }
+  for (u32 q0 = 0; inLds && q0 < nq; q0 += 64) {
     const u32 q = q0 + (u32)lane;
     bool first = false;
     if (q < nq) {
@@ -252,7 +283,21 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
     wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
   }
   wave_sync();
-  for (u32 q = lane; q < nq; q += 64) {
+  if (!inLds) {
+    // the other paths take the id of the first path through their node; and the ptrCache byte of B2 (see below)
+    for (u32 b0 = 0; b0 <= bE; b0 += rowsPer) {
+      const u32 r = (u32)lane / (u32)G, p = (u32)lane - r * (u32)G;
+      const u32 b = b0 + r;
+      const bool valid = r < rowsPer && b <= bE;
+      const u32 q = b * (u32)G + p;
+      const u32 c = valid ? conn[q] : kNoConn;
+      const u32 e = earlier_paths(c, r, p, valid);
+      if (!valid) continue;
+      if (c != kNoConn && (e & 0xffu) != 0) wid[q] = wid[(u64)b * G + (e & 0xffu) - 1];
+      assign[q] = (c == kNoConn ? 0xffu : (e >> 8)) << 24;
+    }
+  }
+  for (u32 q = lane; inLds && q < nq; q += 64) {
     u32 c = conn[q];
     if (c == kNoConn) continue;
     const u32 nd = c & 0x03ffffffu;
@@ -283,7 +328,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   // serial loop reads one byte instead of walking the earlier paths' connections.
   // (kept in the top byte of the slot's `assign` word, which the step itself overwrites with its result: 0xff no
   // connection, 0 first path through its connection, else 1 + the earlier path sharing it)
-  for (u32 q = lane; q < nq; q += 64) {
+  for (u32 q = lane; inLds && q < nq; q += 64) {
     const u32 c = conn[q];
     u32 v = 0xffu;
     if (c != kNoConn) {

@@ -745,6 +745,28 @@ def test_emulated_maximum_size_sentences(emu_lib, ref_tools, tmp_path):
     assert not errs, errs[:10]
 
 
+def check_wide_beam_rnn_long_sentences(lib, ref_tools, tmp, n_lines=3, length=110):
+    """the configs[4] shape with the RNN: beam = global beam = 32 on sentences far beyond the LDS staging of
+    k_rnn_prep / k_rnn_score (the rnn lattice is built in the HBM arrays, earlier paths found by shuffles)"""
+    import test_gpu_parity as tg
+    beams = [32, 32, 1, 32]
+    img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, n_lines, 14, 29, length=length, rnn=(32, 600), beams=beams)
+    ctx = J.Context(img, lib_path=lib, beam=32, global_beam=32, right_check=1, right_beam=32)
+    meta, gold = G.read_gold(gold_path)
+    assert meta['nscorers'] == 2
+    res = ctx.analyze(lines).fetch(full=True)
+    errs = []
+    for s in range(len(lines)):
+        errs += G.compare_sentence(res, s, gold[s], meta)
+    assert not errs, errs[:10]
+
+
+def test_emulated_wide_beam_rnn_long_sentences(emu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_wide_beam_rnn_long_sentences(emu_lib, ref_tools, str(tmp_path))
+
+
 def check_long_sentence_connectivity(lib, ref_tools, tmp):
     """sentences of more than 63 codepoints through k_connect's sliding window: plain ones, ones with a node longer
     than the window (a run of 70 / 150 digits: the sequential pass), ones whose stretches of unknown characters only
