@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""(GPU box, developer tool) run-to-run spread of `jumanpp_gpu corpus -o file` on the bench workload, and what disturbs it.
+
+  python tools/gpu_cli_probe.py            # the command on its own: back to back, --devices=0,0, pinned to the GPU's NUMA
+                                           # node, after idle pauses                  (profiles/r04_ag_cli_probe.txt)
+  python tools/gpu_cli_probe.py parent     # next to a parent process that first has no device state, then a torch
+                                           # context, then a live analysis context, then destroys it
+                                           #                                          (profiles/r04_ah_cli_probe2.txt)
+"""
+import gc
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def sh(c):
+    try:
+        return subprocess.run(c, shell=True, capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as e:
+        return 'ERR %s' % e
+
+
+def main():
+    args = bench.build_parser().parse_args([])
+    cache = args.cache
+    mdic, model, img = bench.make_workload(args, cache)
+    corpus = bench.make_corpus(args, mdic, cache, args.batch * 16, args.seed + 1)
+    import __graft_entry__ as ge
+    cli = ge.build_host()
+    out = os.path.join(cache, 'cli_probe_out.txt')
+
+    def run(tag, prefix=(), flags=()):
+        t0 = time.perf_counter()
+        p = subprocess.run(list(prefix) + [cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out, corpus] + list(flags),
+                           capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        last = (p.stderr.strip().splitlines() or [''])[-1]
+        m = re.search(r'sent_per_s=([0-9.e+]+)', last)
+        g = re.search(r'gpu_ms=([0-9.]+)', last)
+        print('%-44s %9.0f sentences/s  gpu_ms %s  process wall %.2f s' % (tag, float(m.group(1)) if m else 0, g.group(1) if g else '?', wall), flush=True)
+        if os.path.exists(out):
+            os.remove(out)
+
+    if 'parent' not in sys.argv[1:]:
+        print(sh('lscpu | grep -i "numa\\|socket\\|^CPU(s)"'))
+        print('gpu numa:', sh('cat /sys/class/drm/card*/device/numa_node'), '| nproc', sh('nproc'))
+        print('cgroup cpus:', sh('cat /sys/fs/cgroup/cpuset.cpus.effective 2>/dev/null; cat /sys/fs/cgroup/cpu.max 2>/dev/null'))
+        for i in range(5):
+            run('back to back %d' % i)
+        for i in range(3):
+            run('--devices=0,0 %d' % i, flags=['--devices=0,0'])
+        node = sh('cat /sys/class/drm/card*/device/numa_node | head -1')
+        cpus = sh('cat /sys/devices/system/node/node%s/cpulist' % (node if node not in ('', '-1') else '0'))
+        for i in range(3):
+            run('taskset -c %s %d' % (cpus[:20], i), prefix=['taskset', '-c', cpus])
+        time.sleep(12)
+        run('after 12 s idle')
+        run('right after')
+        time.sleep(12)
+        run('after 12 s idle, --devices=0,0', flags=['--devices=0,0'])
+        run('right after, --devices=0,0', flags=['--devices=0,0'])
+        return
+    import numpy as np
+    for i in range(3):
+        run('no GPU state in the parent %d' % i)
+    import torch
+    import jumanpp_amd as J
+    dev = torch.device('cuda', 0)
+    x = torch.zeros(1 << 20, device=dev)
+    torch.cuda.synchronize()
+    for i in range(3):
+        run('parent: torch context only %d' % i)
+    batches = bench.load_batches(corpus, args.batch, np)
+    ctx = J.Context(img, use_rnn=True)
+    text, offs = batches[0]
+    t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    o = torch.from_numpy(offs.astype(np.int32)).to(dev)
+    for it in range(6):
+        r = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(offs) - 1, len(text), None)
+        r.release()
+    torch.cuda.synchronize()
+    for i in range(4):
+        run('parent: + live analysis context %d' % i)
+    for it in range(40):
+        r = ctx.analyze_device(t.data_ptr(), o.data_ptr(), len(offs) - 1, len(text), None)
+        r.release()
+    torch.cuda.synchronize()
+    run('right after 40 parent batches')
+    run('again')
+    del ctx, r, x
+    gc.collect()
+    torch.cuda.empty_cache()
+    for i in range(3):
+        run('parent: context destroyed %d' % i)
+
+
+if __name__ == '__main__':
+    main()
