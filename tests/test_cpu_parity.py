@@ -531,6 +531,77 @@ int main() {
     assert int(out[0]) > 20000 and int(out[1]) == 0 and int(out[2]) < int(out[0]) // 20, out
 
 
+def test_hoare_partition_in_closed_form_is_the_loop():
+    """k_sweep<32,*> pass B1 replays libstdc++'s __unguarded_partition_pivot without its loop: the k-th stop of the upward
+    scan (element not greater than the pivot, from f + 1 up) is exchanged with the k-th stop of the downward scan (not
+    less, from l - 1 down to f) as long as they have not crossed, and the function returns a_1 (no exchange) or
+    min(a_{K+1}, b_K).  A plain restatement of that rule against a plain restatement of the loop (jpp_select.h:
+    sel_move_median_to_first + sel_unguarded_partition), on arrays with heavy ties and on sub-ranges; the kernel code itself
+    is checked by the reference on every test with a wide beam."""
+    import random
+
+    def loop(v, f, l):
+        v = v[:]
+
+        def swap(i, j):
+            v[i], v[j] = v[j], v[i]
+        a, mid, c = f + 1, f + (l - f) // 2, l - 1
+        if v[a][0] > v[mid][0]:
+            swap(f, mid) if v[mid][0] > v[c][0] else swap(f, c) if v[a][0] > v[c][0] else swap(f, a)
+        elif v[a][0] > v[c][0]:
+            swap(f, a)
+        elif v[mid][0] > v[c][0]:
+            swap(f, c)
+        else:
+            swap(f, mid)
+        first, last = f + 1, l
+        while True:
+            while v[first][0] > v[f][0]:
+                first += 1
+            last -= 1
+            while v[f][0] > v[last][0]:
+                last -= 1
+            if not first < last:
+                return v, first
+            swap(first, last)
+            first += 1
+
+    def closed(v, f, l):
+        n = len(v)
+        a, mid, c = f + 1, f + (l - f) // 2, l - 1
+        va, vb, vc, vf = v[a][0], v[mid][0], v[c][0], v[f][0]
+        if va > vb:
+            m = mid if vb > vc else c if va > vc else a
+        else:
+            m = a if va > vc else c if vb > vc else mid
+        pv = va if m == a else vb if m == mid else vc
+        my = [pv if h == f else vf if h == m else v[h][0] for h in range(n)]
+        ups = [h for h in range(f + 1, l) if not my[h] > pv]          # a_1 < a_2 < ...
+        downs = [h for h in range(l - 1, f - 1, -1) if not pv > my[h]]  # b_1 > b_2 > ...
+        src = list(range(n))
+        K = 0
+        for k in range(min(len(ups), len(downs))):
+            if ups[k] < downs[k]:
+                src[ups[k]], src[downs[k]] = downs[k], ups[k]
+                K += 1
+        # (a prefix: once a pair has crossed, every later one has)
+        assert all(not ups[k] < downs[k] for k in range(K, min(len(ups), len(downs))))
+        cut = (ups[0] if ups else l) if K == 0 else min(ups[K] if K < len(ups) else 64, downs[K - 1])
+        src = [m if q == f else f if q == m else q for q in src]   # the pivot's exchange came first
+        return [v[q] for q in src], cut
+
+    rnd = random.Random(4)
+    for _ in range(20000):
+        n = rnd.randint(17, 32)
+        f, l = 0, n
+        if rnd.random() < 0.4:
+            f = rnd.randint(0, n - 17)
+            l = rnd.randint(f + 17, n)
+        top = rnd.choice([1, 2, 3, 5, 50])
+        v = [(rnd.randint(0, top), i) for i in range(n)]
+        assert loop(v, f, l) == closed(v, f, l), (v, f, l)
+
+
 def test_make_t0_beam_is_a_rank_when_totals_are_distinct(tmp_path):
     """k_sweep<32,512> 5c / remakeEosBeam fast path: with pairwise distinct totals, util::partition
     (beyond beam*4/3) followed by std::sort (introsort beyond 16) yields the first `beam` entries of the
