@@ -221,7 +221,9 @@ void jppgpu_ctx_destroy(jppgpu_ctx* ctx);
  * table, RNN tables, per-entry T0 records, format table); workspaces, streams and configuration are its own.  What a
  * second Analyzer over the same CoreHolder is in the reference (src/core/env.cc:109-121: makeAnalyzer).  The shared
  * tables are freed with the last context using them; jppgpu_ctx_set_weights / jppgpu_ctx_set_format_table on either
- * context acts on the shared copy. */
+ * context acts on the shared copy: such a call waits for everything enqueued on the device (the sibling contexts'
+ * batches included) before it touches the tables, writers exclude each other, and the caller must not start a batch
+ * on a sibling context while the call runs. */
 int jppgpu_ctx_create_shared(jppgpu_ctx* base, const jppgpu_config* config, jppgpu_ctx** out);
 int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t global_beam, int32_t right_check,
                          int32_t right_beam);
@@ -513,6 +515,8 @@ int jppgpu_result_stats(jppgpu_result* res, uint64_t* total_nodes, uint64_t* tot
  * across GPUs with RCCL): d_offsets[n+1] (exclusive scan of morphemes per sentence) and
  * d_items[cap_items] of jppgpu_node in text order.  Enqueued on the batch's stream. */
 int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_items, uint64_t cap_items);
+/* May be called from any thread, also while another thread analyses or fetches on the result's context (the host
+ * blocks of a result go back to the context's pools under a lock), and after the context was destroyed. */
 void jppgpu_result_release(jppgpu_result* res);
 
 /* device timing of the last batch's kernels in milliseconds (HIP events on the launch stream):

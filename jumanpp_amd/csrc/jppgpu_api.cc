@@ -63,6 +63,7 @@ void rt_free(void* p) { free(p); }
 void rt_h2d(void* d, const void* h, size_t n, jpp_stream_t) { memcpy(d, h, n); }
 void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t) { memcpy(h, d, n); }
 void rt_sync(jpp_stream_t) {}
+void rt_device_sync() {}
 struct SyncPoint {
   void init() {}
   void destroy() {}
@@ -109,6 +110,7 @@ void rt_d2h(void* h, const void* d, size_t n, jpp_stream_t s) {
 // sync when the host is idle, and it DOUBLED the batch time inside jumanpp_gpu, whose 32 format workers own the cores
 // the polling thread yields to.  The driver's blocking wait it is.)
 void rt_sync(jpp_stream_t s) { (void)hipStreamSynchronize(s); }
+void rt_device_sync() { (void)hipDeviceSynchronize(); }
 // "Everything enqueued before mark() has completed": lets the host wait for a copy while kernels enqueued behind
 // the mark keep the GPU busy.
 struct SyncPoint {
@@ -293,25 +295,37 @@ struct HostPool {
     size_t cap;
   };
   bool pinned = false;   // blocks come from rt_host_alloc_pinned
+  // A result may be released on another thread than the one that analyses on its context (jumanpp_gpu hands the text of
+  // a batch to a writer thread while the analysis and format threads keep taking blocks): the free list is locked.
+  std::mutex mu;
   std::vector<Block> free_blocks;
   Block take(size_t bytes) {
-    int best = -1;
-    for (int i = 0; i < (int)free_blocks.size(); ++i)
-      if (free_blocks[i].cap >= bytes && (best < 0 || free_blocks[i].cap < free_blocks[best].cap)) best = i;
-    if (best >= 0 && free_blocks[best].cap <= 2 * bytes + 4096) {
-      Block b = free_blocks[best];
-      free_blocks.erase(free_blocks.begin() + best);
-      return b;
+    {
+      std::lock_guard<std::mutex> l(mu);
+      int best = -1;
+      for (int i = 0; i < (int)free_blocks.size(); ++i)
+        if (free_blocks[i].cap >= bytes && (best < 0 || free_blocks[i].cap < free_blocks[best].cap)) best = i;
+      if (best >= 0 && free_blocks[best].cap <= 2 * bytes + 4096) {
+        Block b = free_blocks[best];
+        free_blocks.erase(free_blocks.begin() + best);
+        return b;
+      }
     }
     size_t want = bytes + bytes / 8 + 256;
     return Block{pinned ? rt_host_alloc_pinned(want) : rt_host_alloc(want), want};
   }
   void give(Block b) {
-    if (b.p) free_blocks.push_back(b);
+    if (!b.p) return;
+    std::lock_guard<std::mutex> l(mu);
+    free_blocks.push_back(b);
   }
   void clear() {
-    for (auto& b : free_blocks) rt_host_free(b.p);
-    free_blocks.clear();
+    std::vector<Block> all;
+    {
+      std::lock_guard<std::mutex> l(mu);
+      all.swap(free_blocks);
+    }
+    for (auto& b : all) rt_host_free(b.p);
   }
   ~HostPool() { clear(); }
 };
@@ -424,6 +438,9 @@ struct ModelBufs {
   bool fmt_have = false;
   DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table;
   int device = 0;
+  // jppgpu_ctx_set_weights / jppgpu_ctx_set_format_table change tables that every context of the copy reads: one writer
+  // at a time, and a writer first waits for the whole device (the batches its sibling contexts have enqueued)
+  std::mutex mu;
   ~ModelBufs();
 };
 
@@ -477,7 +494,7 @@ struct jppgpu_ctx {
   u64* mail_dev = nullptr;
   std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
-  DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text;
+  DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text, fmt_st;
   bool timing_pending = false;
 };
 
@@ -1179,7 +1196,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
                     &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
-                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text};
+                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text, &ctx->fmt_st};
   for (auto* b : bufs) b->release();
   ctx->mb.reset();   // (the model tables go with their last context)
   rt_stream_destroy(ctx->own_stream);
@@ -1235,6 +1252,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
 
   ctx->generation++;
   jppgpu_result* Rp = new jppgpu_result();
+  // (every early return below -- allocation failures, a failing host callback -- drops the result and its pooled blocks)
+  std::unique_ptr<jppgpu_result, void (*)(jppgpu_result*)> result_guard(Rp, jppgpu_result_release);
   Rp->pool_ref = ctx->host_pool;
   Rp->text_pool_ref = ctx->text_pool;
   Rp->bind(ctx->host_pool.get());
@@ -1313,7 +1332,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   if (n == 0) {
     B.total_nodes = 0;
-    *out = Rp;
+    *out = result_guard.release();
     return JPPGPU_OK;
   }
 
@@ -1832,7 +1851,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(JPPGPU_INVALID_STATE, std::string("kernel launch failed: ") + hipGetErrorString(e));
 #endif
-  *out = Rp;
+  *out = result_guard.release();
   return JPPGPU_OK;
 }
 
@@ -2022,6 +2041,9 @@ extern "C" int jppgpu_ctx_set_format_table(jppgpu_ctx* ctx, const jppgpu_format_
     return fail(JPPGPU_INVALID_PARAMETER, "format table: literal beyond its field");
   static_assert(sizeof(FmtRow) == sizeof(jppgpu_format_row), "row layout");
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  std::lock_guard<std::mutex> shared_lock(ctx->mb->mu);
+  // the buffers below may be freed and re-allocated: no kernel of a context that shares the copy may still read them
+  if (ctx->mb.use_count() > 1) rt_device_sync();
   if (!(ctx->mb->fmt_slots.ensure(t->n_slots * 4) && ctx->mb->fmt_rows.ensure(t->n_rows * sizeof(FmtRow)) &&
         ctx->mb->fmt_blob.ensure(t->blob_bytes + 64) && ctx->mb->fmt_table.ensure(sizeof(FmtTable))))
     return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format table)");
@@ -2068,10 +2090,10 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
     if (res->generation != ctx->generation)
       return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
     jpp_stream_t st = ctx->last_stream;
-    if (!(ctx->fmt_len.ensure((B.total_nodes + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8)))
+    if (!(ctx->fmt_len.ensure((B.total_nodes + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) && ctx->fmt_st.ensure(((size_t)n + 1) * 4)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format)");
     const FmtTable* T = ctx->mb->fmt_table.as<FmtTable>();
-    if (n) JPP_LAUNCH(k_fmt_count, (n + 3) / 4, 256, st, B, T, ctx->fmt_len.as<u32>(), ctx->fmt_cnt.as<u32>());
+    if (n) JPP_LAUNCH(k_fmt_count, (n + 3) / 4, 256, st, B, T, ctx->fmt_len.as<u32>(), ctx->fmt_cnt.as<u32>(), ctx->fmt_st.as<i32>());
     JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
     rt_sync(st);   // the byte total sizes the text buffers
@@ -2079,9 +2101,9 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
     const u64 total = res->fm_off.data()[n];
     if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
     if (n) JPP_LAUNCH(k_fmt_write, (n + 3) / 4, 256, st, B, T, (const u32*)ctx->fmt_len.as<u32>(), (const u64*)ctx->fmt_off.as<u64>(),
-                      ctx->fmt_text.as<u8>());
+                      ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
     ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
-    ok &= pull(res->fm_status, B.sent_status, n, st);   // (k_fmt_count may have failed a sentence the table cannot render)
+    ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);   // (the text's own status: a sentence the table cannot render answers ST_CAPACITY)
     rt_sync(st);
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format text)");
     res->fm_have = true;
@@ -2361,7 +2383,11 @@ extern "C" int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uin
   if (!ctx || !weights) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   if (n != (uint64_t)ctx->hmodel.wmask + 1) return fail(JPPGPU_INVALID_PARAMETER, "weight count does not match the model's table");
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
-  // (ordered behind every batch already enqueued on the context's streams)
+  std::lock_guard<std::mutex> shared_lock(ctx->mb->mu);
+  // (ordered behind every batch already enqueued on the context's streams -- and, when the model copy is shared
+  // (jppgpu_ctx_create_shared), behind every batch of the sibling contexts: the table and the T0 records are theirs too.
+  // The caller must not START a batch on a sibling while this call runs.)
+  if (ctx->mb.use_count() > 1) rt_device_sync();
   if (ctx->last_stream) rt_sync(ctx->last_stream);
   rt_sync(ctx->own_stream);
   rt_h2d(ctx->mb->weights.p, weights, (size_t)n * 4, nullptr);

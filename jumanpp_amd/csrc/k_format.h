@@ -118,14 +118,19 @@ __device__ __forceinline__ u32 fmt_node_bytes(const FmtTable& T, const u8* text,
 }
 
 // sentence s -> its number of text bytes; per path node (text order k = 0 .. pl - 2) the bytes at fmt_len[node_base + k]
-__global__ void __launch_bounds__(256) k_fmt_count(Batch B, const FmtTable* __restrict__ Tp, u32* fmt_len, u32* sent_bytes) {
+// fmt_status: the status the TEXT of a sentence answers with -- the analysis' own, or ST_CAPACITY when the table cannot
+// render a node of the path (B.sent_status is not touched: earlier fetches of the result have reported it)
+__global__ void __launch_bounds__(256) k_fmt_count(Batch B, const FmtTable* __restrict__ Tp, u32* fmt_len, u32* sent_bytes, i32* fmt_status) {
   const FmtTable& T = *Tp;
   const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   if (s >= B.n_sent) return;
   const u32 pl = B.sent_status[s] == ST_OK ? B.path_len[s] : 0;
   if (B.sent_status[s] != ST_OK) {
-    if (lane == 0) sent_bytes[s] = T.error_len;
+    if (lane == 0) {
+      sent_bytes[s] = T.error_len;
+      fmt_status[s] = B.sent_status[s];
+    }
     return;
   }
   const u64 nb = B.node_base[s];
@@ -144,7 +149,7 @@ __global__ void __launch_bounds__(256) k_fmt_count(Batch B, const FmtTable* __re
   sum = wave_sum_u32(sum);
   const bool allOk = wave_ballot(!ok) == 0;
   if (lane == 0) {
-    if (!allOk) B.sent_status[s] = ST_CAPACITY;   // (a node the table cannot render: the sentence answers like a failed one)
+    fmt_status[s] = allOk ? ST_OK : ST_CAPACITY;   // (a node the table cannot render: the text answers like a failed sentence)
     sent_bytes[s] = allOk ? sum + T.eos_len : T.error_len;
   }
 }
@@ -159,13 +164,13 @@ __device__ __forceinline__ u64 fmt_put1(u8* out, u64 o, u8 c, u32 lane) {
   return o + 1;
 }
 
-__global__ void __launch_bounds__(256) k_fmt_write(Batch B, const FmtTable* __restrict__ Tp, const u32* fmt_len, const u64* sent_off, u8* out) {
+__global__ void __launch_bounds__(256) k_fmt_write(Batch B, const FmtTable* __restrict__ Tp, const u32* fmt_len, const u64* sent_off, u8* out, const i32* fmt_status) {
   const FmtTable& T = *Tp;
   const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   if (s >= B.n_sent) return;
   u64 o = sent_off[s];
-  if (B.sent_status[s] != ST_OK) {
+  if (fmt_status[s] != ST_OK) {
     fmt_put(out, o, T.error_text, T.error_len, lane);
     return;
   }

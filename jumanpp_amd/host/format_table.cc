@@ -139,14 +139,22 @@ Status JumanFormatTable::build(const ModelImage* model, unsigned threads) {
   rows_.reserve(nrows);
   blob_.clear();
   blob_.reserve(nblob + 64);
+  std::vector<int32_t> slotOwner(slots_.size(), 0);
   for (unsigned t = 0; t < threads; ++t) {
     Part& P = parts[t];
     const uint32_t rowBase = (uint32_t)rows_.size(), blobBase = (uint32_t)blob_.size();
     const size_t lo = t * per;
     for (size_t k = 0; k < P.firstRow.size(); ++k) {
       const size_t slot = (size_t)((uint32_t)eptrs[lo + k] >> 4);
-      // one slot, one entry: an entry row is at least 8 bytes long (an entry listed under two keys renders the same rows)
-      if (slots_[slot] == 0) slots_[slot] = 1 + rowBase + P.firstRow[k];
+      // one slot, one entry (an entry listed under two keys renders the same rows).  Two DIFFERENT entries whose rows
+      // start within the same 8 bytes of the entry data cannot share a slot: the table says so and the caller keeps
+      // the host formatter (the T0 memo does the same with its records, jppgpu_api.cc: collect_memo_seeds)
+      if (slots_[slot] == 0) {
+        slots_[slot] = 1 + rowBase + P.firstRow[k];
+        slotOwner[slot] = eptrs[lo + k];
+      } else if (slotOwner[slot] != eptrs[lo + k]) {
+        return Status::NotImplemented("format table: two dictionary entries within 8 bytes of entry data");
+      }
     }
     for (jppgpu_format_row r : P.rows) {
       r.blob_off += blobBase;

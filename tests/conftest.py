@@ -21,12 +21,18 @@ def golden_dir():
 def emu_lib():
     """TEST ONLY: kernel sources built against the CPU fiber emulator."""
     import __graft_entry__ as ge
+    # (tools/emu_asan.sh: the emulator library built with -fsanitize=address)
+    if os.environ.get('JPPEMU_TEST_LIB'):
+        return os.environ['JPPEMU_TEST_LIB']
     return ge.build_emu()
 
 
 @pytest.fixture(scope='session')
 def gpu_lib():
     import __graft_entry__ as ge
+    # developer builds of the same sources (tools/gpu_session.sh asan: the device-AddressSanitizer library)
+    if os.environ.get('JPPGPU_TEST_LIB'):
+        return os.environ['JPPGPU_TEST_LIB']
     return ge.build_native()
 
 

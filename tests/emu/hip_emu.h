@@ -107,8 +107,34 @@ __attribute__((noinline)) inline void resume(Fiber& f) {
   }
 }
 
+// LDS is NOT preserved between workgroups and holds whatever the previous wavefronts of the CU left there.  `__shared__`
+// is `static` here, which would make every never-written element a stable, small, valid-looking value (zero, or what the
+// previous block wrote): a kernel that reads such an element as an index passes here and faults on the MI355X (round 4:
+// the eight-keys-per-lane global beam read enn[0] of a boundary WITHOUT left nodes and loaded through it,
+// DESIGN.md section 8).  The emulator's link (tests/emu/lds.ld) gathers every function-local static of the kernel
+// sources into one section, and every block starts with that section poisoned: an index made of 0xA5 bytes points
+// gigabytes away and the process dies on the spot (or AddressSanitizer names the load).
+extern "C" char __start_jpp_lds[] __attribute__((weak));
+extern "C" char __stop_jpp_lds[] __attribute__((weak));
+#if defined(__SANITIZE_ADDRESS__)
+// (an AddressSanitizer build puts red zones between the statics: the section is filled by a loop the sanitizer does not
+// instrument -- the red zones' shadow is untouched, so out-of-bounds accesses to an LDS array are still reported)
+__attribute__((no_sanitize_address, noinline)) inline void poison_range(char* a, char* b) {
+  for (volatile char* p = a; p < b; ++p) *p = (char)0xA5;
+}
+#else
+inline void poison_range(char* a, char* b) { memset(a, 0xA5, (size_t)(b - a)); }
+#endif
+inline void poison_lds() {
+  static const bool off = std::getenv("JPP_EMU_NO_LDS_POISON") != nullptr;   // (A/B timing of the poisoning itself)
+  if (off) return;
+  if (__start_jpp_lds != nullptr && __stop_jpp_lds > __start_jpp_lds) poison_range(__start_jpp_lds, __stop_jpp_lds);
+}
+inline size_t lds_section_bytes() { return __start_jpp_lds ? (size_t)(__stop_jpp_lds - __start_jpp_lds) : 0; }
+
 inline void run_block(unsigned nthreads) {
   State& s = st();
+  poison_lds();
   constexpr size_t kStack = 256 * 1024;
   if (s.fibers.size() < nthreads) {
     // (the vector may not move fibers that are parked inside it: reserve once for the largest block there is)
