@@ -72,11 +72,15 @@ def make_workload(args, cache_dir):
 
 def make_corpus(args, mdic, cache_dir, n_lines, seed):
     oov = float(getattr(args, 'oov', 0.05))
-    path = os.path.join(cache_dir, 'corpus_%d_%d_%d%s.txt' % (n_lines, args.sent_len, seed, '' if oov == 0.05 else '_oov%g' % oov))
+    zipf = float(getattr(args, 'zipf', 0.0) or 0.0)
+    path = os.path.join(cache_dir, 'corpus_%d_%d_%d%s%s.txt' % (n_lines, args.sent_len, seed, '' if oov == 0.05 else '_oov%g' % oov,
+                                                                '_zipf%g' % zipf if zipf else ''))
     if not os.path.exists(path):
-        with open(path, 'w', encoding='utf-8') as f:
+        with open(path + '.tmp', 'w', encoding='utf-8') as f:
             subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines),
-                                   '--seed', str(seed), '--len', str(args.sent_len), '--oov', str(oov)], stdout=f)
+                                   '--seed', str(seed), '--len', str(args.sent_len), '--oov', str(oov)] +
+                                  (['--zipf', str(zipf)] if zipf else []), stdout=f)
+        os.rename(path + '.tmp', path)
     return path
 
 
@@ -489,7 +493,10 @@ def realism_legs(args, cache, local_rank, np, torch, J):
     legs = {}
     dev = torch.device('cuda', local_rank)
     stream = torch.cuda.current_stream().cuda_stream
-    for name, over in (('dict_300k_weights_2e22', {'dict_entries': 300000, 'weights_exp': 22}), ('weights_2e26', {'weights_exp': 26})):
+    # (iv, round 5) the headline model on a ZIPF corpus (word rank r drawn with weight 1/r): the word statistics of real
+    # text -- most weight gathers repeat and hit the caches, the regime where k_sweep is bound by instruction issue
+    for name, over in (('dict_300k_weights_2e22', {'dict_entries': 300000, 'weights_exp': 22}), ('weights_2e26', {'weights_exp': 26}),
+                       ('zipf_corpus', {'zipf': 1.0})):
         try:
             a = copy.copy(args)
             for k, v in over.items():
@@ -712,6 +719,22 @@ def homograph_leg(args, cache, local_rank, np, torch, J):
         return {'error': str(e)[:300]}
 
 
+def _timing_kv(stderr):
+    """key=value tokens of every `--timing` line of jumanpp_gpu (the pipeline line, `reserve:`, `batches:`); the reserve
+    line's own `ms` is kept as reserve_ms"""
+    kv = {}
+    for line in (stderr or '').strip().splitlines():
+        pre = 'reserve_' if line.startswith('reserve:') else ''
+        for tok in line.split():
+            if '=' in tok:
+                k, v = tok.split('=', 1)
+                try:
+                    kv[pre + k if pre and k == 'ms' else k] = float(v)
+                except ValueError:
+                    pass
+    return kv
+
+
 def cli_end_to_end(args, model, corpus, n_lines, ge):
     """The product binary end to end, timed by this process: jumanpp_gpu (C++14 host pipeline above the C ABI)
     reads the corpus file, analyses it in 65,536-sentence batches and writes the JUMAN-format text to a file.
@@ -729,14 +752,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
             wall = time.perf_counter() - t0
             if p.returncode != 0:
                 return {'error': (p.stderr or '')[-200:]}
-            kv = {}
-            for tok in (p.stderr.strip().splitlines() or [''])[-1].split():
-                if '=' in tok:
-                    k, v = tok.split('=', 1)
-                    try:
-                        kv[k] = float(v)
-                    except ValueError:
-                        pass
+            kv = _timing_kv(p.stderr)
             size = os.path.getsize(out_path)
             os.remove(out_path)
             r = {'what': 'jumanpp_gpu --model=M.jppmdl corpus -o file: %d lines, file in -> JUMAN text out (%.0f MB), '
@@ -747,7 +763,9 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                  'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1), 'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
                  'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
                  'process_wall_s_incl_model_load': round(wall, 2),
-                 'sentences_per_s_incl_model_load': round(n_lines / wall, 1)}
+                 'sentences_per_s_incl_model_load': round(n_lines / wall, 1),
+                 'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')},
+                 'reserve_ms': round(kv.get('reserve_ms', 0.0), 1)}
             main_rates.append(round(r['value']))
             if best is None or r['value'] > best['value']:
                 best = r
@@ -761,14 +779,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                                    capture_output=True, text=True)
                 if p.returncode != 0:
                     return None, None, rates
-                kv = {}
-                for tok in (p.stderr.strip().splitlines() or [''])[-1].split():
-                    if '=' in tok:
-                        k, v = tok.split('=', 1)
-                        try:
-                            kv[k] = float(v)
-                        except ValueError:
-                            pass
+                kv = _timing_kv(p.stderr)
                 os.remove(out_path)
                 rates.append(round(kv.get('sent_per_s', 0.0)))
                 if top is None or kv.get('sent_per_s', 0.0) > top:
@@ -805,14 +816,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                 p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, big], capture_output=True, text=True)
                 if p.returncode != 0:
                     break
-                kv = {}
-                for tok in (p.stderr.strip().splitlines() or [''])[-1].split():
-                    if '=' in tok:
-                        k, v = tok.split('=', 1)
-                        try:
-                            kv[k] = float(v)
-                        except ValueError:
-                            pass
+                kv = _timing_kv(p.stderr)
                 size = os.path.getsize(out_path)
                 os.remove(out_path)
                 r = {'what': 'the same command on %d lines (%.1f GB of JUMAN text written), best of 2 runs' % (4 * n_lines, size / 1e9),
@@ -1054,6 +1058,7 @@ def main():
             except Exception as e:  # the checker must never take the main line down -- but it must say so
                 parity = {'error': str(e)[:300]}
         avg = {k: v / args.steps for k, v in kernel_ms.items()}
+        pipe_stats = ctx.stats()   # (of the timed context: warm-up batch 0 sized the buffers, the rest are one enqueue each)
         dom = 'sweep' if avg['sweep'] >= avg['t0'] else 't0'  # k_rnn has its own line in kernel_ms_per_step
         achieved = ab[dom] / (avg[dom] * 1e-3) / 1e9 if avg[dom] > 0 else 0.0
         # HBM traffic of the dominant kernel: measured offline (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -1122,13 +1127,14 @@ def main():
                      'entry_pointer_bytes_per_sentence': round(fb['entry_pointer_bytes'], 1),
                      'what': 'SURVEY 8(d): 4 B per double-array unit touched + entry-pointer list bytes (host walk of the '
                              "model's trie over 384 sentences of the timed batch) + sentence bytes + the arrays the front end "
-                             'writes; includes the two host syncs of the phase'}
+                             'writes; since round 5 the phase has no host wait inside (one enqueue per batch, the '
+                             'capacity guards run on the device)'}
             try:
-                if traffic is not None or True:
-                    tpk = tp['kernels'] if tp.get('kernel_source_id') == src_id else {}
-                    fk = [k for k in tpk if k.startswith(('k_decode', 'k_seeds', 'k_norm', 'k_layout', 'k_connect', 'k_ends', 'k_relocate'))]
-                    if fk:
-                        front['traffic'] = int(sum(tpk[k]['hbm_bytes_per_launch'] for k in fk))
+                tpk = tp['kernels'] if tp.get('kernel_source_id') == src_id else {}
+                fk = [k for k in tpk if k.startswith(('k_decode', 'k_seeds', 'k_norm', 'k_layout', 'k_connect', 'k_ends', 'k_relocate',
+                                                      'k_scan', 'k_cap_guard', 'k_cls_guard', 'k_sweep_classify'))]
+                if fk:
+                    front['traffic'] = int(sum(tpk[k]['hbm_bytes_per_launch'] for k in fk))
             except Exception:
                 pass
         except Exception as e:
@@ -1172,34 +1178,34 @@ def main():
                 streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
                 offsB = [torch.zeros(args.batch + 1, dtype=torch.int32, device=dev) for _ in range(2)]
                 itemsB = [torch.zeros((cap_items, 2), dtype=torch.int32, device=dev) for _ in range(2)]
-                def launch(i):
-                    t, o, n, nbytes = d_batches[i % len(d_batches)]
-                    k = i % 2
-                    r = ctxs[k].analyze_device(t.data_ptr(), o.data_ptr(), n, nbytes, streams[k].cuda_stream)
-                    r.pack(offsB[k].data_ptr(), itemsB[k].data_ptr(), cap_items)
-                    return r
-                launch(0).release()
-                launch(1).release()
-                torch.cuda.synchronize()
+                # (a batch is one enqueue followed by one wait inside the library since round 5: two batches are in
+                # flight when two host threads drive the two contexts, which is how jumanpp_gpu runs a device)
+                import threading
                 k3 = min(args.steps, 8)
+                def worker(k, count):
+                    torch.cuda.set_device(local_rank)
+                    for j in range(count):
+                        t, o, n, nbytes = d_batches[(2 * j + k) % len(d_batches)]
+                        r = ctxs[k].analyze_device(t.data_ptr(), o.data_ptr(), n, nbytes, streams[k].cuda_stream)
+                        r.pack(offsB[k].data_ptr(), itemsB[k].data_ptr(), cap_items)
+                        streams[k].synchronize()      # (its packed result is ready)
+                        r.release()
+                for k in range(2):
+                    worker(k, 1)
+                torch.cuda.synchronize()
                 t2 = time.perf_counter()
-                pending = None
-                for i in range(k3):
-                    r = launch(i)
-                    if pending is not None:
-                        pr, pk = pending
-                        streams[pk].synchronize()      # completion of the previous batch (its packed result is ready)
-                        pr.release()
-                    pending = (r, i % 2)
-                pr, pk = pending
-                streams[pk].synchronize()
-                pr.release()
+                th = [threading.Thread(target=worker, args=(k, k3 // 2)) for k in range(2)]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
                 torch.cuda.synchronize()
                 e3 = time.perf_counter() - t2
-                overlapped = {'what': 'two batches in flight on two HIP streams (two contexts), same workload',
+                k3 = 2 * (k3 // 2)
+                overlapped = {'what': 'two batches in flight: two contexts on two HIP streams, each driven by its own host thread, same workload',
                               'value': round(args.batch * k3 / e3, 1), 'unit': 'sentences/s', 'steps': k3,
                               'ms_per_step': round(e3 / k3 * 1e3, 3)}
-                del ctxs, ctxB, pending, pr, r, offsB, itemsB   # (the list kept both contexts alive into the CLI leg)
+                del ctxs, ctxB, offsB, itemsB, th   # (the list kept both contexts alive into the CLI leg)
             except Exception as e:  # the extra measurement must never take the main line down
                 overlapped = {'error': str(e)[:200]}
         out = {
@@ -1229,6 +1235,9 @@ def main():
                 'parallelism': 'sentence-sharded x%d, no data-path collective' % world,
             },
             'kernel_ms_per_step': {k: round(v, 3) for k, v in avg.items()},
+            'batches': dict(pipe_stats, what='one_enqueue_batches: enqueued against the held capacity, ONE host wait (at the end); '
+                                             'sized_batches: the three-wait path (the first batch of the context); '
+                                             'device_allocations: hipMalloc calls of the process up to the read-out'),
             'roofline': {
                 'bound': 'hbm',
                 'kernel': 'k_' + dom,

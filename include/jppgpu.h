@@ -225,6 +225,35 @@ void jppgpu_ctx_destroy(jppgpu_ctx* ctx);
  * batches included) before it touches the tables, writers exclude each other, and the caller must not start a batch
  * on a sibling context while the call runs. */
 int jppgpu_ctx_create_shared(jppgpu_ctx* base, const jppgpu_config* config, jppgpu_ctx** out);
+
+/* Buffers at their final size when the analyzer is made (round 5).  The reference grows its per-sentence arena while it
+ * analyses (src/jumandic/main/jumanpp.cc:156-179 is the loop this replaces: one analyze() per line, memory taken as it
+ * goes); a batched context knows the size of its batches beforehand -- jumanpp_gpu mmaps its input and fixes --batch --
+ * and takes everything at once: after jppgpu_ctx_reserve a batch within the reserved size allocates nothing and is ONE
+ * enqueue (no host wait between the decode kernel and the sweep; the totals that used to size the node tables, the
+ * lattice arrays and the hidden-state rows are compared with the capacity on the device, jppgpu_ctx_stats counts the
+ * batches that did not fit and were run again the sized way). */
+typedef struct jppgpu_reserve {
+  uint32_t struct_size;        /* sizeof(jppgpu_reserve) */
+  uint32_t max_sentences;      /* sentences per batch */
+  uint64_t max_total_bytes;    /* input bytes per batch */
+  float nodes_per_byte;        /* lattice nodes per input byte to provide for; 0: the library's default (3.0) */
+  float text_bytes_per_byte;   /* jppgpu_result_format_top1 output bytes per input byte; 0: no text buffers */
+  uint32_t text_host_blocks;   /* page-locked host blocks of that size kept ready (results in flight at once) */
+  uint32_t reserved;
+} jppgpu_reserve;
+int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r);
+
+typedef struct jppgpu_ctx_statistics {
+  uint32_t struct_size;            /* sizeof(jppgpu_ctx_statistics), set by the caller */
+  uint32_t reserved;
+  uint64_t one_enqueue_batches;    /* batches enqueued against the held capacity, no host wait inside */
+  uint64_t one_enqueue_overflows;  /* ... of which did not fit and were run again */
+  uint64_t sized_batches;          /* batches run with the three sizing waits (first batch of an unreserved context,
+                                      host-callback entry points, full-beam scoring, overflows) */
+  uint64_t device_allocations;     /* device (re)allocations of the whole process so far */
+} jppgpu_ctx_statistics;
+int jppgpu_ctx_stats(jppgpu_ctx* ctx, jppgpu_ctx_statistics* out);
 int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t global_beam, int32_t right_check,
                          int32_t right_beam);
 const char* jppgpu_last_error(void);

@@ -256,7 +256,10 @@ __device__ __forceinline__ float row_shl_f32(float v) {
 // dance per iteration), comparisons take an SGPR operand, address arithmetic goes to the scalar unit and the VGPR is
 // free.  The caller guarantees the uniformity; the emulator returns the value as it is.
 __device__ __forceinline__ u32 uni(u32 v) {
-#if defined(JPP_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+#if defined(JPP_EMU) && defined(JPP_EMU_CHECK_UNI)
+  hip_emu::check_uniform(v, __FILE__, __LINE__);   // (test build: the claim is checked across the wavefront)
+  return v;
+#elif defined(JPP_EMU) || !defined(__HIP_DEVICE_COMPILE__)
   return v;
 #else
   return (u32)__builtin_amdgcn_readfirstlane((int)v);
@@ -318,6 +321,14 @@ __device__ __forceinline__ u32 wave_sum_u32(u32 v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     v += wave_shfl_u32(v, lane_id() ^ off);
+  }
+  return v;
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v += wave_shfl_u64(v, lane_id() ^ off);
   }
   return v;
 }

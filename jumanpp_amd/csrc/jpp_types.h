@@ -206,6 +206,9 @@ struct ClNodes {
 //   gn  = node_base[s] + k         node k of sentence s        (arrays sized total_nodes)
 // sentence-local node ids: 0 = BOS (boundary 0), 1 = BOS (boundary 1),
 // 2.. = lattice nodes ordered by (start, seed order), last = EOS.
+// gstats[kGstatOverflow]: the batch did not fit the capacity it was enqueued against (k_lattice.h: k_cap_guard)
+constexpr int kGstatOverflow = 8;
+
 struct Batch {
   // input
   const u8* text;

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -250,11 +251,14 @@ struct Timer {
 };
 #endif
 
+// device (re)allocations of the process: a steady pipeline makes none after its first batch (jppgpu_ctx_stats)
+std::atomic<unsigned long long> g_dev_allocs{0};
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   bool ensure(size_t bytes) {
     if (bytes <= cap) return true;
+    ++g_dev_allocs;
     rt_free(p);
     size_t want = bytes + bytes / 4 + 256;
     p = rt_malloc(want);
@@ -496,6 +500,12 @@ struct jppgpu_ctx {
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
   DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text, fmt_st;
   bool timing_pending = false;
+  // one enqueue per batch (k_lattice.h: k_cap_guard): grids of the rare sweep classes and the scratch geometry the next
+  // batch is launched with before its totals are known; statistics for the bench / tests
+  u32 spec_grid1 = 64, spec_grid2 = 16, spec_maxr_cap = 0;
+  DevBuf scan_ws;        // k_scan_mb: tile sums + epoch-stamped flags
+  u32 scan_epoch = 0;
+  u64 n_spec_batches = 0, n_spec_overflows = 0, n_exact_batches = 0, n_dev_allocs_at_last_batch = 0;
 };
 
 static_assert(sizeof(jppgpu_node) == sizeof(NodeInfo), "node layout");
@@ -901,6 +911,23 @@ void finish_context(jppgpu_ctx* ctx) {
   ctx->mail_host = static_cast<volatile u64*>(rt_mailbox_alloc(16 * 8, &dev));
   ctx->mail_dev = static_cast<u64*>(dev);
   ctx->text_pool->pinned = true;
+  if (ctx->scan_ws.ensure(sizeof(ScanWs))) {
+    const ScanWs zero{};
+    rt_h2d(ctx->scan_ws.p, &zero, sizeof(zero), nullptr);
+    rt_sync(nullptr);
+  }
+}
+
+// exclusive scan of n u32 counts into u64 offsets (+ *base), out[n] = total: one tile per workgroup when the tiles fit
+// the look-back window (k_lattice.h: k_scan_mb), the single-workgroup form otherwise
+void launch_scan(jppgpu_ctx* ctx, jpp_stream_t st, const u32* in, u64* out, u32 n, const u64* base) {
+  const u32 tiles = (n + 1024 * kScanPer - 1) / (1024 * kScanPer);
+  if (ctx->scan_ws.p != nullptr && tiles <= kScanMbBlocks) {
+    if (++ctx->scan_epoch == 0) ctx->scan_epoch = 1;
+    JPP_LAUNCH(k_scan_mb, tiles ? tiles : 1, 1024, st, in, out, n, base, ctx->scan_ws.as<ScanWs>(), ctx->scan_epoch);
+  } else {
+    JPP_LAUNCH(k_scan, 1, 1024, st, in, out, n, base);
+  }
 }
 }  // namespace
 
@@ -1196,7 +1223,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
                     &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
-                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text, &ctx->fmt_st};
+                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text, &ctx->fmt_st, &ctx->scan_ws};
   for (auto* b : bufs) b->release();
   ctx->mb.reset();   // (the model tables go with their last context)
   rt_stream_destroy(ctx->own_stream);
@@ -1223,15 +1250,12 @@ void sweep_class_thresholds(const Config& cfg, u32* t0, u32* t1) {
 }
 }  // namespace
 
-extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
-                                           uint32_t total_bytes, void* stream_, jppgpu_result** out) {
-  if (!ctx || !out || (!d_utf8 && total_bytes) || !d_offsets) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
-  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
-  jpp_stream_t st = static_cast<jpp_stream_t>(stream_);
-  *out = nullptr;
-  const size_t cpN = (size_t)total_bytes + n + 8;
-  const size_t bbN = (size_t)total_bytes + 4 * (size_t)n + 8;
-  const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
+namespace {
+// the workspaces whose size follows from the input alone (codepoint / boundary / sentence index spaces)
+bool ensure_front(jppgpu_ctx* ctx, size_t n, size_t total_bytes) {
+  const size_t cpN = total_bytes + n + 8;
+  const size_t bbN = total_bytes + 4 * n + 8;
+  const int G = ctx->cfg.gbeam;
   bool ok = ctx->cp_code.ensure(cpN * 4) && ctx->cp_class.ensure(cpN * 4) && ctx->cp_boff.ensure(cpN * 2) &&
             ctx->cl_nodes.ensure(cpN * sizeof(ClNodes)) && ctx->pos_cnt1.ensure(cpN * 2) &&
             ctx->pos_cntN.ensure(cpN * 2) && ctx->pos_norm.ensure(cpN * 8 * kNormCache) && ctx->pos_cnt2.ensure(cpN * 2) && ctx->pos_ends.ensure(cpN * 8) && ctx->pos_walk.ensure(cpN * sizeof(WalkCache)) && ctx->reach.ensure(cpN) &&
@@ -1248,6 +1272,95 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
               ctx->rnn_noff.ensure(bbN * 4) && ctx->rnn_rows.ensure(((size_t)n + 1) * 4) && ctx->rnn_rowbase.ensure(((size_t)n + 2) * 8)));
   ok = ok && ctx->gstats.ensure(64) && ctx->sent_maxr.ensure(((size_t)n + 1) * 4) && ctx->sweep_list.ensure((3 * (size_t)n + 1) * 4);
+  return ok;
+}
+}  // namespace
+
+namespace {
+// the HBM slices (and their locks) of the normalize maker's long starts: once per context
+bool ensure_norm_scratch(jppgpu_ctx* ctx, jpp_stream_t st) {
+  if (ctx->norm_locks.p) return true;
+  static_assert(sizeof(NormState) == 16 && sizeof(NormResult) == 8, "slice layout");
+  const std::vector<u32> zeros(kNormSlotGroups * 64, 0u);
+  if (!(ctx->norm_scratch.ensure((size_t)kNormSlotGroups * 64 * norm_slice_bytes()) && ctx->norm_locks.ensure(zeros.size() * 4))) return false;
+  rt_h2d(ctx->norm_locks.p, zeros.data(), zeros.size() * 4, st);
+  rt_sync(st);
+  return true;
+}
+}  // namespace
+
+// Takes every device buffer a batch of up to `max_sentences` sentences / `max_total_bytes` input bytes needs at its final
+// size NOW, so that the batches themselves allocate nothing and run as one enqueue from the first one on: the
+// workspaces that follow from the input size exactly, the node tables / lattice arrays / hidden-state rows from
+// nodes_per_byte (0: kDefaultNodesPerByte), the output-text buffers when text_bytes_per_byte != 0.  A batch that needs
+// more than was reserved still works: it is run again the sized way and the buffers grow (jppgpu_ctx_stats counts it).
+extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
+  if (!ctx || !r) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (r->struct_size != sizeof(jppgpu_reserve)) return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_reserve::struct_size is not the size this library was built with");
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  const size_t n = r->max_sentences, bytes = (size_t)r->max_total_bytes;
+  if (n == 0) return JPPGPU_OK;
+  constexpr double kDefaultNodesPerByte = 3.0;   // (the 10^6-row bench dictionary: 2.1; 220-codepoint sentences: 2.2)
+  const double npb = r->nodes_per_byte > 0.f ? (double)r->nodes_per_byte : kDefaultNodesPerByte;
+  const u64 nodes = (u64)((double)bytes * npb) + 16 * (u64)n + 8;
+  const int G = ctx->cfg.gbeam > 0 ? ctx->cfg.gbeam : 1, beam = ctx->cfg.beam;
+  bool ok = ensure_front(ctx, n, bytes) && ctx->text.ensure(bytes + 64) && ctx->offs.ensure((n + 1) * 4);
+  if (ok && ctx->hmodel.norm_maker >= 0) ok = ensure_norm_scratch(ctx, ctx->own_stream);
+  // (the node tables also hold the relocation area of the stage-2 sentences: k_layout's upper bound is twice the nodes)
+  const u64 seeds = 2 * nodes + nodes / 4;
+  ok = ok && ctx->node_info.ensure(seeds * sizeof(NodeInfo)) && ctx->node_aux.ensure(seeds * sizeof(NodeAux));
+  ok = ok && ctx->end_nodes.ensure(nodes * 4) && ctx->node_entry.ensure(nodes * spec::kNumDicFeatures * 4) &&
+       ctx->node_pat.ensure(nodes * kPat * 8) && ctx->node_t0.ensure(nodes * 4) && ctx->node_beam.ensure(nodes * beam * sizeof(BeamSlot)) &&
+       ctx->node_cells.ensure(nodes * G * 4 * ctx->cfg.nscorers) && ctx->node_kept.ensure(nodes) && ctx->path_nodes.ensure(nodes * 4);
+  if (ctx->use_rnn) ok = ok && ctx->rnn_ctx.ensure((nodes / 4 + 2 * (u64)n + 8) * (size_t)ctx->hmodel.rnn_EP * 4);
+  if (ok && ctx->cfg.gbeam != 0) {
+    // 64 slices of the wide-lattice variant, 2 048 right nodes each
+    const u64 rc = ctx->cfg.rcheck > 0 ? (u64)ctx->cfg.rcheck : 1;
+    const u64 mr = std::max<u64>(2048, ctx->spec_maxr_cap);
+    const u64 stride = (((rc + 1) * mr * 4 + mr * 2) + 63) & ~u64{63};
+    ok = ctx->sweep_scratch.ensure((size_t)(stride * 64));
+    if (ok) ctx->spec_maxr_cap = (u32)mr;
+  }
+  // packed / top-1 / text read-outs
+  ok = ok && ctx->pack_cnt.ensure((n + 1) * 4) && ctx->pack_off.ensure((n + 2) * 8);
+  if (ok && r->text_bytes_per_byte > 0.f) {
+    const u64 tb = (u64)((double)bytes * (double)r->text_bytes_per_byte) + 64 * (u64)n + 64;
+    ok = ctx->fmt_len.ensure((nodes + 1) * 4) && ctx->fmt_cnt.ensure((n + 1) * 4) && ctx->fmt_off.ensure((n + 2) * 8) &&
+         ctx->fmt_st.ensure((n + 1) * 4) && ctx->fmt_text.ensure(tb + 64);
+    // page-locked host blocks of the text, as many as the caller keeps in flight (jumanpp_gpu: analysed, being written, next)
+    std::vector<HostPool::Block> blocks;
+    for (uint32_t k = 0; ok && k < r->text_host_blocks; ++k) {
+      HostPool::Block b = ctx->text_pool->take((size_t)tb);
+      ok = b.p != nullptr;
+      blocks.push_back(b);
+    }
+    for (auto& b : blocks) ctx->text_pool->give(b);
+  }
+  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (jppgpu_ctx_reserve)");
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_ctx_stats(jppgpu_ctx* ctx, jppgpu_ctx_statistics* out) {
+  if (!ctx || !out) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (out->struct_size != sizeof(jppgpu_ctx_statistics)) return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_ctx_statistics::struct_size is not the size this library was built with");
+  out->one_enqueue_batches = ctx->n_spec_batches;
+  out->one_enqueue_overflows = ctx->n_spec_overflows;
+  out->sized_batches = ctx->n_exact_batches;
+  out->device_allocations = g_dev_allocs.load();
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, const void* d_offsets, uint32_t n,
+                                           uint32_t total_bytes, void* stream_, jppgpu_result** out) {
+  if (!ctx || !out || (!d_utf8 && total_bytes) || !d_offsets) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  jpp_stream_t st = static_cast<jpp_stream_t>(stream_);
+  *out = nullptr;
+  const size_t cpN = (size_t)total_bytes + n + 8;
+  const size_t bbN = (size_t)total_bytes + 4 * (size_t)n + 8;
+  (void)cpN;
+  const int G = ctx->cfg.gbeam, beam = ctx->cfg.beam;
+  bool ok = ensure_front(ctx, n, total_bytes);
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (batch workspace)");
 
   ctx->generation++;
@@ -1318,14 +1431,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.norm_locks = nullptr;
   B.norm_slots = 0;
   if (ctx->hmodel.norm_maker >= 0) {
-    if (!ctx->norm_locks.p) {
-      static_assert(sizeof(NormState) == 16 && sizeof(NormResult) == 8, "slice layout");
-      const std::vector<u32> zeros(kNormSlotGroups * 64, 0u);
-      if (!(ctx->norm_scratch.ensure((size_t)kNormSlotGroups * 64 * norm_slice_bytes()) && ctx->norm_locks.ensure(zeros.size() * 4)))
-        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (normalize scratch)");
-      rt_h2d(ctx->norm_locks.p, zeros.data(), zeros.size() * 4, st);
-      rt_sync(st);
-    }
+    if (!ensure_norm_scratch(ctx, st)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (normalize scratch)");
     B.norm_scratch = ctx->norm_scratch.as<unsigned char>();
     B.norm_locks = ctx->norm_locks.as<u32>();
     B.norm_slots = kNormSlotGroups;
@@ -1336,6 +1442,12 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     return JPPGPU_OK;
   }
 
+  // The pipeline, enqueued one of two ways (k_lattice.h: k_cap_guard).  spec: against the capacity the context holds,
+  // no host wait until the end, *overflowed says whether the batch fitted.  Otherwise (first batch of a context that
+  // was not reserved, a batch that did not fit, the host-callback entry points, full-beam scoring): three waits, each
+  // sizing the next group of buffers from the device's totals.
+  auto pipeline = [&](const bool spec, bool* overflowed) -> int {
+  *overflowed = false;
   const u32 sblocks = (n + 255) / 256;
   const u32 wblocks = (n + kLatWaves - 1) / kLatWaves;
   Timer& T = ctx->timer;
@@ -1348,23 +1460,28 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   else JPP_LAUNCH(k_seeds<0>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_norm<0>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_layout<1>, wblocks, 64 * kLatWaves, st, B);
-  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
-  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
-  u64 totals[2] = {0, 0};
-  if (ctx->mail_host) {
-    JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.node_base + n), (const u64*)(B.node_base2 + n), (const u32*)nullptr, ctx->mail_dev);
-    rt_sync(st);
-    totals[0] = ctx->mail_host[0];
-    totals[1] = ctx->mail_host[1];
+  launch_scan(ctx, st, (const u32*)B.sent_nodes, B.node_base, n, (const u64*)nullptr);
+  launch_scan(ctx, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)nullptr);
+  if (spec) {
+    // the node tables the context holds against the totals, on the device (no host wait)
+    const u64 seedCapHave = std::min(ctx->node_info.cap / sizeof(NodeInfo), ctx->node_aux.cap / sizeof(NodeAux));
+    JPP_LAUNCH(k_cap_guard, sblocks, 256, st, B, (const u64*)(B.node_base + n), (const u64*)(B.node_base2 + n), seedCapHave);
   } else {
-    rt_d2h(&totals[0], B.node_base + n, 8, st);
-    rt_d2h(&totals[1], B.node_base2 + n, 8, st);
-    rt_sync(st);
+    u64 totals[2] = {0, 0};
+    if (ctx->mail_host) {
+      JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.node_base + n), (const u64*)(B.node_base2 + n), (const u32*)nullptr, ctx->mail_dev);
+      rt_sync(st);
+      totals[0] = ctx->mail_host[0];
+      totals[1] = ctx->mail_host[1];
+    } else {
+      rt_d2h(&totals[0], B.node_base + n, 8, st);
+      rt_d2h(&totals[1], B.node_base2 + n, 8, st);
+      rt_sync(st);
+    }
+    const u64 seedCap = totals[0] + totals[1] + 8;
+    if (!(ctx->node_info.ensure(seedCap * sizeof(NodeInfo)) && ctx->node_aux.ensure(seedCap * sizeof(NodeAux))))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (node table)");
   }
-  const u64 total1 = totals[0];
-  const u64 seedCap = total1 + totals[1] + 8;
-  if (!(ctx->node_info.ensure(seedCap * sizeof(NodeInfo)) && ctx->node_aux.ensure(seedCap * sizeof(NodeAux))))
-    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (node table)");
   B.node_info = ctx->node_info.as<NodeInfo>();
   B.node_aux = ctx->node_aux.as<NodeAux>();
   if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<1, 6>), n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
@@ -1378,14 +1495,33 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     sweep_class_thresholds(ctx->cfg, &t0c, &t1c);
     JPP_LAUNCH(k_sweep_classify, sblocks, 256, st, B, t0c, t1c);
   }
-  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
+  launch_scan(ctx, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
   JPP_LAUNCH(k_relocate, sblocks, 256, st, B);
   JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
   JPP_LAUNCH(k_connect<2>, wblocks, 64 * kLatWaves, st, B);
   u64 totalNodes = 0;
   u32 gstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (ctx->mail_host) {
+  const u64 rcS = ctx->cfg.rcheck > 0 ? (u64)ctx->cfg.rcheck : 1;
+  auto scratch_stride = [&](u64 maxr) { return (((rcS + 1) * maxr * 4 + maxr * 2) + 63) & ~u64{63}; };
+  u32 specSlots = 0;   // scratch slices the class-2 variant may use (spec)
+  if (spec) {
+    // what the lattice arrays hold, in nodes, under this batch's beam configuration
+    u64 latCap = ctx->end_nodes.cap / 4;
+    latCap = std::min<u64>(latCap, ctx->node_entry.cap / (spec::kNumDicFeatures * 4));
+    latCap = std::min<u64>(latCap, ctx->node_pat.cap / (kPat * 8));
+    latCap = std::min<u64>(latCap, ctx->node_t0.cap / 4);
+    latCap = std::min<u64>(latCap, ctx->node_beam.cap / ((size_t)beam * sizeof(BeamSlot)));
+    latCap = std::min<u64>(latCap, ctx->node_cells.cap / ((size_t)(G > 0 ? G : 1) * 4 * ctx->cfg.nscorers));
+    latCap = std::min<u64>(latCap, ctx->node_kept.cap);
+    latCap = std::min<u64>(latCap, ctx->path_nodes.cap / 4);
+    if (ctx->spec_maxr_cap != 0) {
+      const u64 slots = ctx->sweep_scratch.cap / scratch_stride(ctx->spec_maxr_cap);
+      specSlots = (u32)std::min<u64>(slots, 0x7fffffffu);
+    }
+    JPP_LAUNCH(k_cls_guard, 1, 64, st, B, ctx->spec_grid1, ctx->spec_grid2, ctx->spec_maxr_cap, specSlots);
+    JPP_LAUNCH(k_cap_guard, sblocks, 256, st, B, (const u64*)(B.node_base2 + n), (const u64*)nullptr, latCap);
+  } else if (ctx->mail_host) {
     JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.node_base2 + n), (const u64*)nullptr, (const u32*)B.gstats, ctx->mail_dev);
     rt_sync(st);
     totalNodes = ctx->mail_host[0];
@@ -1481,13 +1617,15 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     }
   }
   const u32 maxR = gstats[0];
-  B.total_nodes = totalNodes;
-  const u64 cap = totalNodes + 8;
-  ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * spec::kNumDicFeatures * 4) &&
-       ctx->node_pat.ensure(cap * kPat * 8) && ctx->node_t0.ensure(cap * 4) &&
-       ctx->node_beam.ensure(cap * beam * sizeof(BeamSlot)) && ctx->node_cells.ensure(cap * G * 4 * ctx->cfg.nscorers) &&
-       ctx->node_kept.ensure(cap) && ctx->path_nodes.ensure(cap * 4);
-  if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice)");
+  B.total_nodes = totalNodes;   // (spec: known at the end of the batch)
+  if (!spec) {
+    const u64 cap = totalNodes + 8;
+    ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * spec::kNumDicFeatures * 4) &&
+         ctx->node_pat.ensure(cap * kPat * 8) && ctx->node_t0.ensure(cap * 4) &&
+         ctx->node_beam.ensure(cap * beam * sizeof(BeamSlot)) && ctx->node_cells.ensure(cap * G * 4 * ctx->cfg.nscorers) &&
+         ctx->node_kept.ensure(cap) && ctx->path_nodes.ensure(cap * 4);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice)");
+  }
   B.end_nodes = ctx->end_nodes.as<u32>();
   B.node_entry = ctx->node_entry.as<i32>();
   B.node_pat = ctx->node_pat.as<u64>();
@@ -1651,20 +1789,30 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   // sweep_class_thresholds()).  The <8, *> variants have no makeT0Beam replay (util::partition / introsort): they
   // take the configurations whose beams are plain stable ranks, i.e. at most 8 candidates and global beam <= beam*4/3.
   const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
-  const u32 nCls[3] = {gstats[1], gstats[2], gstats[3]};
+  // (spec: the GRIDS of the classes -- every sentence for class 0, what earlier batches suggest for the rare wide
+  // classes; k_sweep leaves a workgroup beyond its class's list at once, k_cls_guard has checked that the lists fit)
+  const u32 nCls[3] = {spec ? n : gstats[1], spec ? ctx->spec_grid1 : gstats[2], spec ? std::min(ctx->spec_grid2, specSlots) : gstats[3]};
   const u32* lists[3] = {B.sweep_list, B.sweep_list + n, B.sweep_list + 2 * (size_t)n};
   B.sweep_scratch = nullptr;
   B.sweep_scratch_stride = 0;
   B.sweep_scratch_maxr = 0;
-  if (ctx->cfg.gbeam != 0 && nCls[2] != 0) {
+  if (spec) {
+    if (nCls[2] != 0) {
+      B.sweep_scratch = ctx->sweep_scratch.as<unsigned char>();
+      B.sweep_scratch_stride = scratch_stride(ctx->spec_maxr_cap);
+      B.sweep_scratch_maxr = ctx->spec_maxr_cap;
+    }
+  } else if (ctx->cfg.gbeam != 0 && nCls[2] != 0) {
     // class 2: the per-right-node arrays (prescores, their sums, cutoff order) in an HBM slice per workgroup
-    const u64 rc = ctx->cfg.rcheck > 0 ? (u64)ctx->cfg.rcheck : 1;
-    const u64 stride = (((rc + 1) * maxR * 4 + (u64)maxR * 2) + 63) & ~u64{63};
-    if (!ctx->sweep_scratch.ensure((size_t)(stride * nCls[2])))
+    // (kept at least as wide / as many as a later one-enqueue batch is promised: spec_maxr_cap)
+    const u64 mr = std::max<u64>(maxR, ctx->spec_maxr_cap);
+    const u64 stride = scratch_stride(mr);
+    if (!ctx->sweep_scratch.ensure((size_t)(stride * std::max<u64>(nCls[2], 16))))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (wide-lattice scratch)");
+    ctx->spec_maxr_cap = (u32)mr;
     B.sweep_scratch = ctx->sweep_scratch.as<unsigned char>();
     B.sweep_scratch_stride = stride;
-    B.sweep_scratch_maxr = maxR;
+    B.sweep_scratch_maxr = (u32)mr;
   }
   const DevModel* dmS = (const DevModel*)ctx->mb->dmodel;
   B.full_scratch = nullptr;
@@ -1756,7 +1904,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       ctx->sweep_join.make_stream_wait(st);
     }
   }
-  ctx->last_class_n[0] = nCls[0]; ctx->last_class_n[1] = nCls[1]; ctx->last_class_n[2] = nCls[2];
+  if (!spec) { ctx->last_class_n[0] = nCls[0]; ctx->last_class_n[1] = nCls[1]; ctx->last_class_n[2] = nCls[2]; }
   T.mark(5, st);
   if (ctx->use_rnn) {
     JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
@@ -1769,11 +1917,16 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     // 40-codepoint sentence instead of the (codepoints + 3) * G = 258 of a boundary-indexed table (1.0 GB instead of
     // 8.6 GB per 65 536 sentences).  The row total is only known here: a third host sync; the sentence ordering of
     // the lock-step recurrence (which does not need the table) is enqueued before the host waits.
-    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)B.rnn_rows, B.rnn_rowbase, n, (const u64*)nullptr);
+    launch_scan(ctx, st, (const u32*)B.rnn_rows, B.rnn_rowbase, n, (const u64*)nullptr);
     u64 rnnRows = 0;
-    if (ctx->mail_host) JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr, (const u32*)nullptr, ctx->mail_dev + 12);
-    else rt_d2h(&rnnRows, B.rnn_rowbase + n, 8, st);
-    ctx->rnn_sync.mark(st);
+    if (spec) {
+      JPP_LAUNCH(k_cap_guard, sblocks, 256, st, B, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr,
+                 (u64)(ctx->rnn_ctx.cap / ((size_t)ctx->hmodel.rnn_EP * 4)));
+    } else {
+      if (ctx->mail_host) JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr, (const u32*)nullptr, ctx->mail_dev + 12);
+      else rt_d2h(&rnnRows, B.rnn_rowbase + n, 8, st);
+      ctx->rnn_sync.mark(st);
+    }
     if (ctx->hmodel.rnn_EP <= 128) {
       // lock-step workgroups take sentences of equal chain length
       B.rnn_order = B.rnn_key + n;
@@ -1784,11 +1937,13 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       JPP_LAUNCH(k_rnn_order_scan, 1, kRnnOrderBins, st, B);
       JPP_LAUNCH(k_rnn_order_fill, (n + 255) / 256, 256, st, B);
     }
-    ctx->rnn_sync.wait(st);
-    if (ctx->mail_host) rnnRows = ctx->mail_host[12];
-    ctx->last_rnn_rows = rnnRows;
-    if (!ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4))
-      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
+    if (!spec) {
+      ctx->rnn_sync.wait(st);
+      if (ctx->mail_host) rnnRows = ctx->mail_host[12];
+      ctx->last_rnn_rows = rnnRows;
+      if (!ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4))
+        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
+    }
     B.rnn_ctx = ctx->rnn_ctx.as<float>();
     const u32 slowGrid = (n + 15) / 16 < 512u ? (n + 15) / 16 : 512u;   // k_rnn_score<.., 3> (16 sentences per workgroup) loops over its list
     if (ctx->hmodel.rnn_EP == 64) {
@@ -1817,6 +1972,42 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(7, st);
   ctx->last_stream = st;
   ctx->timing_pending = true;
+  if (spec) {
+    // the batch's ONE host wait: totals, class sizes and the overflow verdict in one mapped-memory record
+    JPP_LAUNCH(k_mail_all, 1, 64, st, (const u64*)(B.node_base + n), (const u64*)(B.node_base2 + n), (const u32*)B.gstats,
+               ctx->use_rnn ? (const u64*)(B.rnn_rowbase + n) : (const u64*)nullptr, ctx->mail_dev);
+    rt_sync(st);
+    volatile u64* mh = ctx->mail_host;
+    B.total_nodes = mh[1];
+    ctx->last_class_n[0] = (u32)mh[3]; ctx->last_class_n[1] = (u32)mh[4]; ctx->last_class_n[2] = (u32)mh[5];
+    ctx->last_rnn_rows = mh[11];
+    *overflowed = mh[10] != 0;
+  }
+  if (!*overflowed) {
+    // what the next one-enqueue batch launches the rare classes with: twice what this one held
+    ctx->spec_grid1 = std::max<u32>(64u, 2 * ctx->last_class_n[1]);
+    ctx->spec_grid2 = std::max<u32>(16u, 2 * ctx->last_class_n[2]);
+  }
+  return JPPGPU_OK;
+  };
+  const bool hostInLoop = ctx->seed_hook || ctx->pair_fn || ctx->plugin_fn || ctx->partial_pending || ctx->scored_fns;
+  static const bool devExact = std::getenv("JPPGPU_DEV_EXACT") != nullptr;   // (developer knob: always the three-wait path)
+  const bool canSpec = !devExact && !hostInLoop && ctx->mail_host != nullptr && ctx->cfg.gbeam != 0 && ctx->node_info.cap != 0 &&
+                       ctx->node_beam.cap != 0 && (!ctx->use_rnn || ctx->rnn_ctx.cap != 0);
+  bool overflowed = false;
+  {
+    int prc = pipeline(canSpec, &overflowed);
+    if (prc != JPPGPU_OK) return prc;
+    if (canSpec) ctx->n_spec_batches++;
+    else ctx->n_exact_batches++;
+    if (overflowed) {
+      ctx->n_spec_overflows++;
+      ctx->n_exact_batches++;
+      prc = pipeline(false, &overflowed);
+      if (prc != JPPGPU_OK) return prc;
+    }
+  }
+  ctx->n_dev_allocs_at_last_batch = g_dev_allocs.load();
   if (ctx->scored_fns != nullptr) {
     // ScorerDef::others on the host (AnalyzerImpl::computeScoresGbeam, analyzer_impl.cc:286-294): every host scorer sees
     // the scored lattice and fills its slot of the cells; the device then re-makes the totals and the EOS beam from the
@@ -1842,7 +2033,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
     if (sortE) JPP_LAUNCH((k_adjust<true>), (n + 3) / 4, 256, st, B, ctx->cfg, ctx->score_weights, ctx->adj_stack.as<u32>());
     else JPP_LAUNCH((k_adjust<false>), (n + 3) / 4, 256, st, B, ctx->cfg, ctx->score_weights, ctx->adj_stack.as<u32>());
-    JPP_LAUNCH(k_path, sblocks, 256, st, B, ctx->cfg);
+    JPP_LAUNCH(k_path, (n + 255) / 256, 256, st, B, ctx->cfg);
     rt_sync(st);   // (the host copy of the cells may be recycled by the next fetch)
     // beam totals, the EOS beam and the paths have changed: later fetches copy them again
     Rp->fetched_basic = Rp->fetched_full = Rp->fetched_top1 = false;
@@ -2022,7 +2213,7 @@ extern "C" int jppgpu_result_pack(jppgpu_result* res, void* d_offsets, void* d_i
   jpp_stream_t st = ctx->last_stream;
   const u32 sblocks = (n + 1 + 255) / 256;
   if (n) JPP_LAUNCH(k_pack_count, sblocks, 256, st, B, ctx->pack_cnt.as<u32>());
-  JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
+  launch_scan(ctx, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
   JPP_LAUNCH(k_pack_write, sblocks, 256, st, B, (const u64*)ctx->pack_off.as<u64>(), static_cast<u32*>(d_offsets),
              static_cast<NodeInfo*>(d_items), (u64)cap_items);
   return JPPGPU_OK;
@@ -2094,7 +2285,7 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format)");
     const FmtTable* T = ctx->mb->fmt_table.as<FmtTable>();
     if (n) JPP_LAUNCH(k_fmt_count, (n + 3) / 4, 256, st, B, T, ctx->fmt_len.as<u32>(), ctx->fmt_cnt.as<u32>(), ctx->fmt_st.as<i32>());
-    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
+    launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
     rt_sync(st);   // the byte total sizes the text buffers
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format offsets)");
@@ -2135,7 +2326,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
             ctx->top1_nodes.ensure(cap * sizeof(NodeInfo)) && ctx->top1_aux.ensure(cap * sizeof(NodeAux))))
         return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (top-1 fetch)");
       if (n) JPP_LAUNCH(k_top1_count, (n + 255) / 256, 256, st, B, ctx->pack_cnt.as<u32>());
-      JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
+      launch_scan(ctx, st, (const u32*)ctx->pack_cnt.as<u32>(), ctx->pack_off.as<u64>(), n, (const u64*)nullptr);
       if (n) JPP_LAUNCH(k_top1_gather, (n + 3) / 4, 256, st, B, (const u64*)ctx->pack_off.as<u64>(),
                         ctx->top1_nodes.as<NodeInfo>(), ctx->top1_aux.as<NodeAux>());
       ok &= pull(res->t1_status, B.sent_status, n, st);
@@ -2273,7 +2464,7 @@ extern "C" int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jpp
       JPP_LAUNCH((k_nbest<false>), (n + 3) / 4, 256, st, B, res->cfg, (int)n_best, ctx->nbest_cnt.as<u32>(),
                  (const u64*)nullptr, (NbestItem*)nullptr, (BeamSlot*)nullptr);
     }
-    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->nbest_cnt.as<u32>(), ctx->nbest_off.as<u64>(), (u32)paths, (const u64*)nullptr);
+    launch_scan(ctx, st, (const u32*)ctx->nbest_cnt.as<u32>(), ctx->nbest_off.as<u64>(), (u32)paths, (const u64*)nullptr);
     ok &= pull(res->nb_first, ctx->nbest_off.p, (size_t)paths + 1, st);
     rt_sync(st);
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");
@@ -2324,7 +2515,7 @@ extern "C" int jppgpu_result_fetch_top1_ngrams(jppgpu_result* res, jppgpu_top1_n
     if (!(ctx->nbest_cnt.ensure(((size_t)n + 1) * 4) && ctx->nbest_off.ensure(((size_t)n + 2) * 8)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (n-gram fetch)");
     if (n) JPP_LAUNCH(k_path_count, (n + 255) / 256, 256, st, B, ctx->nbest_cnt.as<u32>());
-    JPP_LAUNCH(k_scan, 1, 1024, st, (const u32*)ctx->nbest_cnt.as<u32>(), ctx->nbest_off.as<u64>(), n, (const u64*)nullptr);
+    launch_scan(ctx, st, (const u32*)ctx->nbest_cnt.as<u32>(), ctx->nbest_off.as<u64>(), n, (const u64*)nullptr);
     bool ok = pull(res->ng_first, ctx->nbest_off.p, (size_t)n + 1, st);
     rt_sync(st);
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (result copies)");

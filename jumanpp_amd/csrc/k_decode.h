@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64 * kDecWaves) k_decode(Batch B, Config cfg) 
   __shared__ u32 l_cp_all[kDecWaves][kDecLds];
   __shared__ i32 l_cls_all[kDecWaves][kDecLds];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    for (int q = 0; q < 8; ++q) B.gstats[q] = 0;
+    for (int q = 0; q < 16; ++q) B.gstats[q] = 0;   // ([8]: overflow flag of the one-enqueue path, k_lattice.h)
   }
   if (s >= B.n_sent) return;
   const u32 off = B.byte_off[s];

@@ -162,6 +162,89 @@ __global__ void __launch_bounds__(1024) k_scan(const u32* in, u64* out, u32 n, c
   if (t == 0) out[n] = carry;
 }
 
+// The same scan over several workgroups (round 5): the single-workgroup form walks a 65 536-sentence batch in eight
+// tiles, three barriers each -- 44 us, five times per batch.  Here every workgroup takes ONE tile: it publishes the
+// tile's sum (value, then an epoch-stamped flag), reads the sums of the workgroups before it as they appear (at most
+// kScanMbBlocks - 1 of them: one lane each, no chain), and scans its tile from that base.  Workgroups are dispatched in
+// index order and all fit the chip at once, so the wait cannot deadlock; the epoch (a counter of the context) makes a
+// flag of an earlier launch meaningless, nothing is reset.  n up to kScanMbBlocks tiles; the host falls back to k_scan
+// beyond that.
+constexpr u32 kScanMbBlocks = 64;
+struct ScanWs {
+  u64 part[kScanMbBlocks];
+  u32 flag[kScanMbBlocks];
+};
+__global__ void __launch_bounds__(1024) k_scan_mb(const u32* in, u64* out, u32 n, const u64* base_ptr, ScanWs* ws, u32 epoch) {
+  __shared__ u32 tile[1024 * kScanPer];
+  __shared__ u64 otile[1024 * kScanPer];
+  __shared__ u64 part[16];
+  __shared__ u64 s_carry;
+  const u32 t = threadIdx.x;
+  const int lane = (int)(t & 63);
+  const u32 b = blockIdx.x;
+  const u32 t0 = b * 1024u * kScanPer;
+#pragma unroll
+  for (u32 q = 0; q < kScanPer; ++q) {
+    const u32 i = t0 + q * 1024u + t;
+    tile[q * 1024u + t] = i < n ? in[i] : 0u;
+  }
+  __syncthreads();
+  u32 v[kScanPer];
+  u64 sum = 0;
+#pragma unroll
+  for (u32 q = 0; q < kScanPer; ++q) {
+    v[q] = tile[t * kScanPer + q];
+    sum += v[q];
+  }
+  u64 incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u64 o = wave_shfl_u64(incl, lane >= d ? lane - d : lane);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) part[t >> 6] = incl;
+  __syncthreads();
+  u64 wbase = 0, all = 0;
+  for (u32 k = 0; k < 16; ++k) {
+    const u64 pv = part[k];
+    if (k < (t >> 6)) wbase += pv;
+    all += pv;
+  }
+  // publish this tile's sum, then collect the tiles before it
+  if (t == 0) {
+    ws->part[b] = all;
+    __threadfence();
+    atomicExch(&ws->flag[b], epoch);
+  }
+  if (t < 64) {
+    u64 mine = 0;
+    if (t < b) {
+      volatile u32* f = ws->flag + t;
+      while (*f != epoch) {
+      }
+      __threadfence();
+      mine = *(volatile u64*)(ws->part + t);
+    }
+    const u64 before = wave_sum_u64(mine);
+    if (t == 0) s_carry = before + (base_ptr ? *base_ptr : 0);
+  }
+  __syncthreads();
+  const u64 carry = s_carry;
+  u64 acc = carry + wbase + incl - sum;
+#pragma unroll
+  for (u32 q = 0; q < kScanPer; ++q) {
+    otile[t * kScanPer + q] = acc;
+    acc += v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 q = 0; q < kScanPer; ++q) {
+    const u32 i = t0 + q * 1024u + t;
+    if (i < n) out[i] = otile[q * 1024u + t];
+  }
+  if (t == 0 && b == gridDim.x - 1) out[n] = carry + all;
+}
+
 // Sentences are routed to the sweep variant that fits THEIR widest boundary, not the batch's (one sentence with a
 // 100-homograph boundary must not move the other 65 535 to the generic kernel): class 0 = at most t0 right nodes at
 // every boundary (the variants that stage 64 in LDS), class 1 = at most t1 (LDS staging of kMaxRight), class 2 =
@@ -483,6 +566,42 @@ __global__ void k_mail(const u64* a, const u64* b, const u32* g, u64* out) {
     out[1] = b ? *b : 0;
   }
   if (g && threadIdx.x < 8) out[2 + threadIdx.x] = g[threadIdx.x];
+}
+
+// ---- one enqueue per batch (round 5) --------------------------------------------------------------------------------
+// The reference sizes nothing ahead: its lattice grows in an arena while the sentence is analysed (analyzer_impl.cc:
+// 100-195).  Here the node tables, the lattice arrays and the RNN rows of a batch are sized from totals that only the
+// device knows, which used to cost three host waits per batch.  Now the pipeline is enqueued against the CAPACITY the
+// context already holds (jppgpu_ctx_reserve, or what earlier batches left) and these guards compare the totals with it
+// on the device: a batch that does not fit marks every sentence ST_CAPACITY -- every later kernel skips such sentences,
+// so nothing is written out of bounds -- and raises gstats[8]; the host reads the flag with the batch totals once, at
+// the end, and runs the batch again the exact way (with the waits, growing the buffers).  One thread per sentence.
+__global__ void __launch_bounds__(256) k_cap_guard(Batch B, const u64* a, const u64* b, u64 cap) {
+  const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 need = *a + (b ? *b : 0) + 8;
+  // (the flag is only ever raised by a thread that sees the same totals, or by an earlier kernel)
+  if (need <= cap && B.gstats[kGstatOverflow] == 0) return;
+  if (s < B.n_sent && B.sent_status[s] == ST_OK) B.sent_status[s] = ST_CAPACITY;
+  if (s == 0) B.gstats[kGstatOverflow] = 1;
+}
+// the sweep classes against the grids / the scratch slices they were given (one thread; k_cap_guard, launched behind
+// it, spreads the verdict)
+__global__ void k_cls_guard(Batch B, u32 grid1, u32 grid2, u32 maxr_cap, u32 slots) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const u32 c1 = B.gstats[2], c2 = B.gstats[3], maxR = B.gstats[0];
+  if (c1 > grid1 || c2 > grid2 || (c2 != 0 && (maxR > maxr_cap || c2 > slots))) B.gstats[kGstatOverflow] = 1;
+}
+// everything the host wants to know about a batch, once: [0] stage-1 nodes, [1] nodes, [2..9] gstats[0..7],
+// [10] overflow flag, [11] hidden-state rows
+__global__ void k_mail_all(const u64* total1, const u64* total, const u32* g, const u64* rows, u64* out) {
+  const u32 t = threadIdx.x;
+  if (t == 0) {
+    out[0] = *total1;
+    out[1] = *total;
+    out[10] = g[kGstatOverflow];
+    out[11] = rows ? *rows : 0;
+  }
+  if (t < 8) out[2 + t] = g[t];
 }
 
 }  // namespace jpp

@@ -698,7 +698,9 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
     const u32 bb0 = B.byte_off[s] + 4 * s;
     const u32 bE = n + 2;
     own = own && n != 0 && B.bnd_ngb[bb0 + bE] != 0;
-    rn_ctx[g] = B.rnn_ctx + B.rnn_rowbase[s] * (u64)EP;   // (not own: some sentence's row 0 serves as the parking row)
+    // (not own: some sentence's row 0 serves as the parking row; a batch that overflowed its capacity -- every sentence
+    // failed by k_cap_guard, the row bases beyond the table -- parks in the table's first row)
+    rn_ctx[g] = B.rnn_ctx + (B.gstats[kGstatOverflow] != 0 ? u64{0} : B.rnn_rowbase[s]) * (u64)EP;
     nchain[g] = 0;
     const u32 nq = (bE + 1) * (u32)G;
     const u32* rn_cnt = B.rnn_cnt + bb0;

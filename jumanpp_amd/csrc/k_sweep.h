@@ -299,6 +299,9 @@ __global__ void __launch_bounds__(64) JPP_WAVES_PER_EU_RANGE(WAVES, WAVES)
 k_sweep(Batch B, const DevModel* __restrict__ Mp, Config cfg, const u32* __restrict__ slist) {
   const DevModel& M = *Mp;
   // workgroup -> sentence through the list of the variant's class (k_sweep_classify)
+  // (the one-enqueue path launches a class with a grid chosen before its size is known: the list holds
+  // gstats[1 + class] sentences, k_sweep_classify; the lists are sweep_list + class * n_sent)
+  if (blockIdx.x >= B.gstats[1 + (u32)((u64)(slist - B.sweep_list) / B.n_sent)]) return;
   const u32 s = slist[blockIdx.x];
   if (B.sent_status[s] != ST_OK) return;
   const int lane = (int)threadIdx.x;

@@ -430,6 +430,32 @@ Status GpuAnalyzer::setFormatTable(const jppgpu_format_table& table) {
   return Status::Ok();
 }
 
+Status GpuAnalyzer::reserve(uint32_t maxSentences, uint64_t maxBytes, float textBytesPerByte, uint32_t textBlocks) {
+  if (!ctx_) return Status::InvalidState("GpuAnalyzer::reserve before initialize");
+  jppgpu_reserve r;
+  std::memset(&r, 0, sizeof(r));
+  r.struct_size = (uint32_t)sizeof(r);
+  r.max_sentences = maxSentences;
+  r.max_total_bytes = maxBytes;
+  r.text_bytes_per_byte = textMode_ ? textBytesPerByte : 0.f;
+  r.text_host_blocks = textMode_ ? textBlocks : 0;
+  int rc = jppgpu_ctx_reserve(ctx_, &r);
+  return rc == JPPGPU_OK ? Status::Ok() : fromCode(rc);
+}
+
+void GpuAnalyzer::pipelineStats(uint64_t out[4]) const {
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!ctx_) return;
+  jppgpu_ctx_statistics st;
+  std::memset(&st, 0, sizeof(st));
+  st.struct_size = (uint32_t)sizeof(st);
+  if (jppgpu_ctx_stats(ctx_, &st) != JPPGPU_OK) return;
+  out[0] = st.one_enqueue_batches;
+  out[1] = st.one_enqueue_overflows;
+  out[2] = st.sized_batches;
+  out[3] = st.device_allocations;
+}
+
 void GpuAnalyzer::lastTimings(float ms[8]) const {
   for (int i = 0; i < 8; ++i) ms[i] = 0.f;
   if (ctx_) jppgpu_last_timings(ctx_, ms, 8);

@@ -268,6 +268,12 @@ class GpuAnalyzer {
   const ScoringConfig& scoringConfig() const { return sconf_; }
   // [0]decode [1]seeds [2]layout [3]t0 [4]sweep [5]rnn [6]path [7]total, ms of the last batch
   void lastTimings(float ms[8]) const;
+  // Every buffer of a batch of up to maxSentences sentences / maxBytes input bytes now (jppgpu_ctx_reserve): the batches
+  // then allocate nothing and are one enqueue each.  textBytesPerByte != 0 (text mode): also the device text buffer and
+  // `textBlocks` page-locked host blocks of that size.  A batch beyond the reservation still works (it is run again).
+  Status reserve(uint32_t maxSentences, uint64_t maxBytes, float textBytesPerByte = 0.f, uint32_t textBlocks = 0);
+  // one-enqueue batches / of which re-run / sized batches / device allocations of the process (jppgpu_ctx_stats)
+  void pipelineStats(uint64_t out[4]) const;
 };
 
 }  // namespace jumanpp_amd

@@ -70,6 +70,7 @@ struct Conf {
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
+  bool noReserve = false;   // --no-reserve: the analyzers size their buffers batch by batch (round-4 behaviour)
   bool help = false;
   int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
   enum { Juman, Morph, FullMorph, Segment, DicSubset } kind = Juman;
@@ -404,6 +405,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (std::strcmp(argv[i], "--host-format") == 0) conf.hostFormat = true;
     else if (argValue(argc, argv, i, "--pipelines-per-device", &v)) conf.pipelinesPerDevice = std::max(1, std::min(4, std::atoi(v.c_str())));
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
+    else if (std::strcmp(argv[i], "--no-reserve") == 0) conf.noReserve = true;
     else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -469,7 +471,7 @@ int main(int argc, const char** argv) {
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
-                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing,\n"
+                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing, --no-reserve,\n"
                  "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format),\n"
                  "           --pipelines-per-device=2 (bulk runs: analysis threads, each with its analyzer pair, per GPU)\n";
     return 1;
@@ -731,6 +733,50 @@ int main(int argc, const char** argv) {
         std::cerr << "could not map the input file " << path << "\n";
         return 1;
       }
+    }
+    // Every analyzer takes the buffers of its batches at their final size NOW, all of them in parallel and before the
+    // clock of the pipeline starts (GpuAnalyzer::reserve): the input is mapped, so the bytes of a batch are known ahead --
+    // lines per batch x the mean line of a sample, with a margin -- and the text of a batch from the mean row of the
+    // format table.  Up to round 4 the buffers grew inside the first batches (hipMalloc / hipHostMalloc stalls of
+    // 0.2-0.9 s in batches 0-2, profiles/r04_t_cli_stages.txt) and every batch waited three times for the totals that
+    // size them; now a batch is one enqueue and allocates nothing.  (--no-reserve: the round-4 behaviour.)
+    if (!conf.noReserve) {
+      size_t sampleBytes = 0, sampleLines = 0;
+      for (auto& mf : maps) {
+        const size_t take = std::min<size_t>(mf->size, size_t{4} << 20);
+        sampleBytes += take;
+        for (const char* q = mf->data; q < mf->data + take;) {
+          const char* nl = static_cast<const char*>(memchr(q, '\n', (size_t)(mf->data + take - q)));
+          ++sampleLines;
+          if (!nl) break;
+          q = nl + 1;
+        }
+      }
+      size_t inputTotal = 0;
+      for (auto& mf : maps) inputTotal += mf->size;
+      const double meanLine = sampleLines ? (double)sampleBytes / (double)sampleLines : 64.0;
+      const uint64_t batchBytes = std::min<uint64_t>((uint64_t)inputTotal + 64, (uint64_t)((double)conf.batch * meanLine * 1.25) + 65536);
+      const uint32_t batchLines = (uint32_t)std::min<uint64_t>(conf.batch, (uint64_t)((double)inputTotal / std::max(1.0, meanLine - 1.0)) + 16);
+      // text per input byte: a morpheme covers ~5 input bytes and prints ~one mean row of the table
+      float textPerByte = 0.f;
+      if (deviceText && formatTable.numRows() > 0)
+        textPerByte = (float)(1.25 * ((double)formatTable.blobBytes() / (double)formatTable.numRows()) / 5.0);
+      const double r0 = clock.ms();
+      std::vector<std::future<Status>> reserved;
+      for (int d = 0; d < nDev; ++d)
+        for (int a = 0; a < nAnalyzers; ++a)
+          if (analyzers[(size_t)d][(size_t)a])
+            reserved.emplace_back(std::async(std::launch::async, [&, d, a]() {
+              return analyzers[(size_t)d][(size_t)a]->reserve(batchLines, batchBytes, textPerByte, 2);
+            }));
+      for (auto& f : reserved) {
+        Status rs = f.get();
+        if (!rs && conf.timing) std::cerr << "reserve failed (the batches size their buffers themselves): " << rs << "\n";
+      }
+      if (conf.timing)
+        std::cerr << "reserve: batch_lines=" << batchLines << " batch_bytes=" << batchBytes << " text_per_byte=" << textPerByte
+                  << " analyzers=" << reserved.size() << " ms=" << clock.ms() - r0 << "\n";
+      clock = Clock();   // (like the model load and the analyzers themselves: not the pipeline's time)
     }
     const int ofd = ::open(conf.output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
     if (ofd < 0) {
@@ -1067,6 +1113,16 @@ int main(int argc, const char** argv) {
                 << " read_ms=" << (scanUs + prepUs) / 1000.0 << " analyze_ms=" << analyzeMs << " format_ms=" << formatUs / 1000.0
                 << " write_ms=" << writeUs / 1000.0 << " threads=" << conf.threads << " pipeline=1 sharded=1 sent_per_s="
                 << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
+      uint64_t tot[4] = {0, 0, 0, 0};
+      for (auto& v : analyzers)
+        for (auto& a : v)
+          if (a) {
+            uint64_t st[4];
+            a->pipelineStats(st);
+            for (int q = 0; q < 3; ++q) tot[q] += st[q];
+            tot[3] = st[3];
+          }
+      std::cerr << "batches: one_enqueue=" << tot[0] << " rerun=" << tot[1] << " sized=" << tot[2] << " device_allocations=" << tot[3] << "\n";
     }
     return result;
   }

@@ -105,6 +105,19 @@ GBEAM_DT = np.dtype([('left', '<u2'), ('beam', '<u2'), ('score', '<f4')])
 NBEST_DT = np.dtype([('node', '<u4'), ('slot', '<u4'), ('beam', BEAM_DT), ('info', NODE_DT), ('unk', UNK_DT),
                      ('cells', '<f4', (2,))])
 
+class Reserve(C.Structure):
+    """jppgpu_reserve"""
+    _fields_ = [('struct_size', C.c_uint32), ('max_sentences', C.c_uint32), ('max_total_bytes', C.c_uint64),
+                ('nodes_per_byte', C.c_float), ('text_bytes_per_byte', C.c_float), ('text_host_blocks', C.c_uint32),
+                ('reserved', C.c_uint32)]
+
+
+class CtxStatistics(C.Structure):
+    """jppgpu_ctx_statistics"""
+    _fields_ = [('struct_size', C.c_uint32), ('reserved', C.c_uint32), ('one_enqueue_batches', C.c_uint64),
+                ('one_enqueue_overflows', C.c_uint64), ('sized_batches', C.c_uint64), ('device_allocations', C.c_uint64)]
+
+
 _libs = {}
 
 
@@ -138,6 +151,8 @@ def load_library(path=None):
     lib.jppgpu_result_release.argtypes = [C.c_void_p]
     lib.jppgpu_result_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     lib.jppgpu_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    lib.jppgpu_ctx_reserve.argtypes = [C.c_void_p, C.POINTER(Reserve)]
+    lib.jppgpu_ctx_stats.argtypes = [C.c_void_p, C.POINTER(CtxStatistics)]
     _libs[path] = lib
     return lib
 
@@ -363,6 +378,21 @@ class Context:
             raise JppGpuError('jppgpu_ctx_create failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
         self.handle = h
         self.cfg = cfg
+
+    def reserve(self, max_sentences, max_total_bytes, nodes_per_byte=0.0, text_bytes_per_byte=0.0, text_host_blocks=0):
+        """jppgpu_ctx_reserve: every buffer of a batch of that size now; batches within it allocate nothing and are one enqueue"""
+        r = Reserve(C.sizeof(Reserve), max_sentences, max_total_bytes, nodes_per_byte, text_bytes_per_byte, text_host_blocks, 0)
+        rc = self.lib.jppgpu_ctx_reserve(self.handle, C.byref(r))
+        if rc != 0:
+            raise JppGpuError('jppgpu_ctx_reserve failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+
+    def stats(self):
+        """jppgpu_ctx_stats as a dict"""
+        st = CtxStatistics(C.sizeof(CtxStatistics))
+        rc = self.lib.jppgpu_ctx_stats(self.handle, C.byref(st))
+        if rc != 0:
+            raise JppGpuError('jppgpu_ctx_stats failed (%d): %s' % (rc, self.lib.jppgpu_last_error().decode()))
+        return {k: int(getattr(st, k)) for k in ('one_enqueue_batches', 'one_enqueue_overflows', 'sized_batches', 'device_allocations')}
 
     def analyze(self, sentences):
         """sentences: list of bytes/str.  Host buffers in, Result (device resident) out."""

@@ -259,6 +259,23 @@ inline uint64_t ballot(bool p) {
   wave_barrier();
   return r;
 }
+// -DJPP_EMU_CHECK_UNI (tools/emu_asan.sh): uni(v) = v_readfirstlane on the device is only right when v IS the same in
+// every lane that executes it; the plain emulator returns v as it is and would never notice.  Every lane of the
+// wavefront publishes its value and compares (a uni() under divergent control flow shows up as the emulator's deadlock).
+inline void check_uniform(uint64_t v, const char* file, int line) {
+  State& s = st();
+  int base = s.cur - s.cur % kWave;
+  s.xchg[s.cur] = v;
+  wave_barrier();
+  for (int i = 0; i < kWave && base + i < (int)s.block.x; ++i) {
+    if (!s.fibers[base + i].done && s.xchg[base + i] != v) {
+      fprintf(stderr, "hip_emu: uni() of a value that differs between lanes (%s:%d, block %u, lanes %d / %d: %llu / %llu)\n", file, line,
+              s.bidx.x, s.cur % kWave, i, (unsigned long long)v, (unsigned long long)s.xchg[base + i]);
+      abort();
+    }
+  }
+  wave_barrier();
+}
 // element `i` of a lane's v_mfma_f32_16x16x4_f32 result: the lanes publish (a, b), then lane l forms
 // D[4 * (l >> 4) + i][l & 15] as the k-ascending fused chain the matrix core computes
 inline float mfma_f32_16x16x4(float a, float b, float c, int i) {

@@ -1006,6 +1006,80 @@ def test_shared_model_contexts(emu_lib, golden_dir):
     check_shared_model_contexts(emu_lib, golden_dir)
 
 
+def check_one_enqueue_path(lib, golden_dir):
+    """round 5: a batch is ONE enqueue against the capacity the context holds (k_cap_guard); the first batch of an
+    unreserved context and a batch that does not fit run the sized way.  Every way must give the reference's lattice."""
+    lines = [l.rstrip('\n') for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8')]
+    for image, gold_name in (('mini.img', 'mini.gold'), ('mini_rnn.img', 'mini_rnn.gold')):
+        meta, gold = G.read_gold(os.path.join(golden_dir, gold_name))
+
+        def check(res, idx):
+            errs = []
+            for k, s_ in enumerate(idx):
+                errs += G.compare_sentence(res, k, gold[s_], meta)
+            assert not errs, (image, errs[:5])
+        all_idx = list(range(len(lines)))
+        # (a) unreserved: sized, then one enqueue twice; the same lattice every time
+        ctx = J.Context(os.path.join(golden_dir, image), lib_path=lib)
+        for rep in range(3):
+            res = ctx.analyze(lines).fetch(full=True)
+            check(res, all_idx)
+            res.release()
+        st = ctx.stats()
+        assert st['sized_batches'] == 1 and st['one_enqueue_batches'] == 2 and st['one_enqueue_overflows'] == 0, st
+        allocs = st['device_allocations']
+        res = ctx.analyze(lines).fetch(full=True)
+        check(res, all_idx)
+        res.release()
+        assert ctx.stats()['device_allocations'] == allocs, 'a steady batch allocated device memory'
+        ctx.close()
+        # (b) a small batch first, then the whole file: the second batch does not fit what the first one left, is run
+        # again the sized way and comes out right; the third fits
+        ctx = J.Context(os.path.join(golden_dir, image), lib_path=lib)
+        res = ctx.analyze(lines[:2]).fetch(full=True)
+        check(res, [0, 1])
+        res.release()
+        many = lines * 3
+        idx3 = all_idx * 3
+        res = ctx.analyze(many).fetch(full=True)
+        check(res, idx3)
+        res.release()
+        st = ctx.stats()
+        assert st['one_enqueue_overflows'] == 1 and st['sized_batches'] == 2, st
+        res = ctx.analyze(many).fetch(full=True)
+        check(res, idx3)
+        res.release()
+        st = ctx.stats()
+        assert st['one_enqueue_overflows'] == 1 and st['one_enqueue_batches'] == 2, st
+        ctx.close()
+        # (c) reserved: one enqueue from the first batch on, nothing allocated by the batches
+        ctx = J.Context(os.path.join(golden_dir, image), lib_path=lib)
+        nbytes = sum(len(l.encode('utf-8')) for l in lines)
+        ctx.reserve(len(lines), nbytes, nodes_per_byte=8.0)
+        allocs = ctx.stats()['device_allocations']
+        for rep in range(2):
+            res = ctx.analyze(lines).fetch(full=True)
+            check(res, all_idx)
+            res.release()
+        st = ctx.stats()
+        assert st['sized_batches'] == 0 and st['one_enqueue_batches'] == 2 and st['one_enqueue_overflows'] == 0, st
+        assert st['device_allocations'] == allocs, (allocs, st)
+        # ... and a reservation that is too small only costs the second run
+        ctx.close()
+        ctx = J.Context(os.path.join(golden_dir, image), lib_path=lib)
+        ctx.reserve(len(lines), nbytes, nodes_per_byte=0.05)
+        res = ctx.analyze(lines).fetch(full=True)
+        check(res, all_idx)
+        res.release()
+        st = ctx.stats()
+        assert st['one_enqueue_overflows'] == 1 and st['sized_batches'] == 1, st
+        ctx.close()
+
+
+def test_emulated_one_enqueue_path(emu_lib, golden_dir):
+    check_one_enqueue_path(emu_lib, golden_dir)
+
+
 def check_wide_global_beam_candidates(lib, ref_tools, tmp, beams, nhom=(3, 9, 14, 20), n_lines=6):
     """the wide sweep variant's global beam by candidate count: surfaces with 3 / 9 / 14 / 20 homographs put 96, 288, 448
     and 640 (left node, slot) candidates on a boundary at beam 32 -- one key per lane, the per-lane-maxima prefilter

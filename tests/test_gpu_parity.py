@@ -501,6 +501,12 @@ def test_gpu_shared_model_contexts(gpu_lib, golden_dir):
     tc.check_shared_model_contexts(gpu_lib, golden_dir)
 
 
+def test_gpu_one_enqueue_path(gpu_lib, golden_dir):
+    """the one-enqueue pipeline (capacity guards on the device), its overflow re-run and jppgpu_ctx_reserve"""
+    import test_cpu_parity as tc
+    tc.check_one_enqueue_path(gpu_lib, golden_dir)
+
+
 @pytest.mark.parametrize('beams', [[32, 32, 1, 32], [24, 32, 2, 16]])
 def test_gpu_wide_global_beam_candidates(gpu_lib, ref_tools, tmp_path, beams):
     """96 .. 640 global-beam candidates per boundary at beam 32 (keys in registers, prefilter, HBM rounds), 200 sentences"""

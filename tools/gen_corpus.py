@@ -5,7 +5,10 @@ of out-of-dictionary katakana / kanji / digit / ASCII runs and occasional
 prolong marks, small kana and sokuon so every UNK maker (incl. the normalizer)
 fires.
 
-usage: gen_corpus.py <dict.mdic> <n_lines> [--len 40] [--seed 1] [--oov 0.05] > corpus.txt
+usage: gen_corpus.py <dict.mdic> <n_lines> [--len 40] [--seed 1] [--oov 0.05] [--zipf S] > corpus.txt
+
+--zipf S: dictionary words are drawn with probability proportional to 1 / rank^S (rank over a seeded shuffle of the
+surfaces) instead of uniformly -- the word statistics of real text, where a few thousand words make most of the tokens.
 """
 import argparse
 import random
@@ -35,7 +38,7 @@ SPECIAL = ['ー', '〜', 'っ', 'ッ', 'ぁ', 'ぃ', 'ぅ', 'ぇ', 'ぉ', '、',
            '（', '）', '「', '」', '％', 'キロ', 'メガ', 'ミリ', '数', '何', '分の', 'ぶんの', ' ', '　']
 
 
-def make_line(rng, surfaces, length, oov):
+def make_line(rng, surfaces, length, oov, cum=None):
     parts = []
     n = 0
     while n < length:
@@ -63,7 +66,7 @@ def make_line(rng, surfaces, length, oov):
                 if rng.random() < 0.5:
                     w += rng.choice(['ー', '〜', 'っ', 'ぁ', 'ぇ', 'ーー'])
         else:
-            w = rng.choice(surfaces)
+            w = rng.choice(surfaces) if cum is None else rng.choices(surfaces, cum_weights=cum)[0]
         parts.append(w)
         n += len(w)
     line = ''.join(parts)[:length]
@@ -80,12 +83,20 @@ def main():
     ap.add_argument('--len', type=int, default=40)
     ap.add_argument('--seed', type=int, default=1)
     ap.add_argument('--oov', type=float, default=0.05)
+    ap.add_argument('--zipf', type=float, default=0.0)
     a = ap.parse_args()
     rng = random.Random(a.seed)
     surfaces = load_surfaces(a.dict)
+    cum = None
+    if a.zipf > 0:
+        random.Random(a.seed ^ 0x5bd1e995).shuffle(surfaces)
+        cum, acc = [], 0.0
+        for r in range(len(surfaces)):
+            acc += 1.0 / float(r + 1) ** a.zipf
+            cum.append(acc)
     out = sys.stdout
     for _ in range(a.n):
-        out.write(make_line(rng, surfaces, a.len, a.oov) + '\n')
+        out.write(make_line(rng, surfaces, a.len, a.oov, cum) + '\n')
 
 
 if __name__ == '__main__':

@@ -46,7 +46,7 @@ def main():
                                capture_output=True, text=True, env=env)
             wall = time.perf_counter() - t0
             lines = p.stderr.strip().splitlines()
-            last = lines[-1] if lines else ''
+            last = ([l for l in lines if 'sent_per_s=' in l] or [''])[-1]   # (the pipeline line; `reserve:` / `batches:` lines follow it)
             m = re.search(r'sent_per_s=([0-9.e+]+)', last)
             rate = float(m.group(1)) if m else 0.0
             if best is None or rate > best[0]:
@@ -56,6 +56,16 @@ def main():
         rate, last, lines, wall = best
         print('== %s: %.0f sentences/s (process wall %.2f s)' % (name, rate, wall))
         print('   ' + last[:400])
+        for l in lines:
+            if l.startswith(('reserve:', 'batches:')):
+                print('   ' + l[:300])
+        # the first three batches against the steady ones (nothing above 1.5 x)
+        rb0 = [l for l in lines if l.startswith('runBatch')]
+        tot = [float(m.group(1)) for m in (re.search(r'total[= ]([0-9.]+)', l) for l in rb0) if m]
+        if len(tot) > 6:
+            steady = statistics.median(tot[3:])
+            print('   batch totals (ms): first three %s, steady median %.2f, worst first-three / steady %.2f' % (
+                [round(x, 1) for x in tot[:3]], steady, max(tot[:3]) / steady if steady > 0 else 0.0))
         rb = [l for l in lines if l.startswith('runBatch')]
         if rb:
             cols = {}
