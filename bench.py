@@ -834,6 +834,115 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
         return {'error': str(e)[:200]}
 
 
+def config5_cli_lattice(args, cache, ge, np):
+    """BASELINE configs[4] as it is stated -- "beam=32 long-sentence stress, RNNLM on, LATTICE-FORMAT output" -- through the
+    product binary: jumanpp_gpu --beam=32 --global-beam=32 --right-beam=32 -s 32, file in, lattice text out, on the leg's
+    own corpus (2 x 16,384 sentences of 220 codepoints); and the checker: the first 2,048 lattice blocks against the
+    reference CLI.  The reference prints, for a node with several connections, the one std::max_element finds in a
+    FlatSet hashed by HOST ADDRESS (lattice_format.cc:133-141): on exact score ties two runs of jumanpp_v2 itself print
+    different lines, so the reference runs twice and a block counts as a mismatch only if it differs from BOTH runs while
+    they agree with each other (tools/gpu_config5.py, rounds 2-4)."""
+    import copy
+    import re
+    try:
+        a = copy.copy(args)
+        a.sent_len = 220
+        batch = int(getattr(args, 'config5_batch', 16384))
+        mdic, model, img = make_workload(a, cache)
+        corpus = make_corpus(a, mdic, cache, batch * 2, 31)
+        cli = ge.build_host()
+        out_path = os.path.join(cache, 'c5_lattice_out.txt')
+        flags = ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '32']
+        best, rates = None, []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run([cli, '--model=' + model, '--batch=%d' % batch, '--timing', '-o', out_path] + flags + [corpus],
+                               capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {'error': (p.stderr or '')[-200:]}
+            kv = _timing_kv(p.stderr)
+            rates.append(round(kv.get('sent_per_s', 0.0)))
+            if best is None or kv.get('sent_per_s', 0.0) > best[0]:
+                best = (kv.get('sent_per_s', 0.0), kv, wall)
+        rate, kv, wall = best
+        size = os.path.getsize(out_path)
+        res = {'what': 'jumanpp_gpu %s --batch=%d corpus -o file: %d sentences x 220 codepoints, N-best lattice format written '
+                       '(%.0f MB); the 32 best paths are gathered on the device (k_nbest), the lattice text is printed by the host '
+                       'format workers; best of 2 runs' % (' '.join(flags), batch, 2 * batch, size / 1e6),
+               'value': round(rate, 1), 'unit': 'sentences/s', 'runs': rates, 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
+               'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
+               'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
+               'process_wall_s_incl_model_load': round(wall, 2)}
+        if not args.no_parity and not args.no_cpu_baseline:
+            t = time.time()
+            n_check = 2048
+            lines = []
+            with open(corpus, 'rb') as f:
+                for i, line in enumerate(f):
+                    if i >= n_check:
+                        break
+                    lines.append(line)
+            ref_dir = reference_build()[0]
+            procs = max(1, min(usable_cores(), 16))
+            per = (n_check + procs - 1) // procs
+            tmp = os.path.join(cache, 'parity_tmp')
+            os.makedirs(tmp, exist_ok=True)
+
+            def ref_run(tag):
+                running = []
+                for k in range(procs):
+                    part = os.path.join(tmp, 'c5lat_%s_%d.txt' % (tag, k))
+                    with open(part, 'wb') as f:
+                        f.writelines(lines[k * per:(k + 1) * per])
+                    running.append((subprocess.Popen([os.path.join(ref_dir, 'jumanpp_v2'), '--model=' + model] + flags + [part],
+                                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL), part))
+                blocks = []
+                for pr, part in running:
+                    out, _ = pr.communicate()
+                    os.remove(part)
+                    if pr.returncode != 0:
+                        raise RuntimeError('jumanpp_v2 failed (rc %d)' % pr.returncode)
+                    b = out.split(b'EOS\n')
+                    blocks += b[:-1]
+                return blocks
+            r1, r2 = ref_run('a'), ref_run('b')
+            with open(out_path, 'rb') as f:
+                ours = []
+                buf = b''
+                while len(ours) < n_check:
+                    chunk = f.read(1 << 24)
+                    if not chunk:
+                        break
+                    buf += chunk
+                    parts = buf.split(b'EOS\n')
+                    buf = parts.pop()
+                    ours += parts
+                ours = ours[:n_check]
+
+            def fold(block):   # scores to 3 significant digits (diagnostic only: the verdict below is byte for byte)
+                return re.sub('(スコア:|rank[0-9]+:)(-?[0-9.e+-]+)'.encode('utf-8'),
+                              lambda m: m.group(1) + ('%.3g' % float(m.group(2))).encode(), block)
+            n = min(len(ours), len(r1), len(r2))
+            unstable = [i for i in range(n) if r1[i] != r2[i]]
+            differing = [i for i in range(n) if ours[i] != r1[i]]
+            explained = [i for i in differing if ours[i] == r2[i] or r1[i] != r2[i]]
+            unexplained = [i for i in differing if i not in set(explained)]
+            res['parity_sample'] = {
+                'blocks': n, 'identical_to_reference_run_1': n - len(differing),
+                'reference_runs_disagreeing_with_each_other': len(unstable),
+                'differing_but_equal_to_run_2_or_on_an_unstable_block': len(explained),
+                'mismatches': len(unexplained) + (n_check - n), 'first_mismatches': unexplained[:8],
+                'identical_with_scores_folded_to_3_digits': sum(1 for i in range(n) if fold(ours[i]) == fold(r1[i])),
+                'what': 'lattice (-s 32) blocks of the first %d sentences vs jumanpp_v2 run twice (%d processes each); a block that '
+                        'differs from run 1 counts as a mismatch unless it equals run 2 or the two reference runs differ on it '
+                        '(address-hashed tie-break, lattice_format.cc:133-141); %.1f s' % (n_check, procs, time.time() - t)}
+        os.remove(out_path)
+        return res
+    except Exception as e:  # an extra measurement must never take the main line down
+        return {'error': str(e)[:300]}
+
+
 def config5_leg(args, cache, local_rank, np, torch, J):
     """BASELINE configs[4] on one GPU (never `value`): beam = global beam = right beam = 32, right-check 1,
     220-codepoint sentences, RNNLM on, 16,384 sentences per batch (4,096 until round 3: one wavefront per 1 100-node
@@ -874,7 +983,7 @@ def config5_leg(args, cache, local_rank, np, torch, J):
         r = run(0)
         par = None
         if not args.no_parity and not args.no_cpu_baseline:
-            par = leg_parity(model, r, batch, batches[0][0], batches[0][1], 2048, [32, 32, 1, 32], np, torch, dev,
+            par = leg_parity(model, r, batch, batches[0][0], batches[0][1], batch, [32, 32, 1, 32], np, torch, dev,
                              os.path.join(cache, 'parity_tmp'), 220)
         r = r.fetch()
         nodes = float(r.nnodes.sum())
@@ -945,19 +1054,31 @@ def main():
     import numpy as np
     import torch
     import __graft_entry__ as ge
-    ge.build_native()
+    if os.environ.get('JPPGPU_BENCH_EMU') != '1':
+        ge.build_native()
     import jumanpp_amd as J
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if not torch.cuda.is_available():
+    # TEST ONLY (tests/test_dist_cpu.py): JPPGPU_BENCH_EMU=1 walks this file's control flow -- the rank-0 model build
+    # behind barriers, the sharded corpus, the gather inside the timed loop, the max over ranks, rank 0 certifying and timing
+    # the CPU while the others wait -- on the kernel emulator with the gloo backend, at toy sizes.  The line it prints says
+    # so and measures nothing; without the variable there is no CPU path.
+    emu = os.environ.get('JPPGPU_BENCH_EMU') == '1'
+    if not emu and not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
-    torch.cuda.set_device(local_rank)
+    lib_path = ge.build_emu() if emu else None
+    if not emu:
+        torch.cuda.set_device(local_rank)
+
+    def _sync():
+        if not emu:
+            torch.cuda.synchronize()
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl')
+        dist.init_process_group('gloo' if emu else 'nccl')
     cache = args.cache
     # one model for all ranks: rank 0 builds it (bootstrap + embedding + export on the host cores), the others wait
     if dist is not None and rank != 0:
@@ -976,17 +1097,20 @@ def main():
     # not its speed: the first child after such a change spends 2-4 s more on the GPU side, and after the legs below have
     # freed their contexts eight runs in a row do (profiles/r04_ah_cli_probe2.txt, the `runs` lists of profiles/r04_t_*).
     cli_result = None
-    if not args.no_cli and world == 1:
+    if not args.no_cli and world == 1 and not emu:
         cli_result = cli_end_to_end(args, model, corpus, args.batch * len(batches), ge)
+    c5_cli = None
+    if not args.no_config5 and world == 1 and not emu:
+        c5_cli = config5_cli_lattice(args, cache, ge, np)
 
-    ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank)
-    dev = torch.device('cuda', local_rank)
+    ctx = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=0 if emu else local_rank, lib_path=lib_path)
+    dev = torch.device('cpu') if emu else torch.device('cuda', local_rank)
     d_batches = []
     for text, offs in batches:
         t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
         o = torch.from_numpy(offs.astype(np.int32).view(np.int32)).to(dev)
         d_batches.append((t, o, len(offs) - 1, len(text)))
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = None if emu else torch.cuda.current_stream().cuda_stream
     # packed top-1 output (8 B / morpheme) -- what a CLI would format, and what is gathered across GPUs
     cap_items = args.batch * (args.sent_len + 1)
     d_offs = torch.zeros(args.batch + 1, dtype=torch.int32, device=dev)
@@ -1000,10 +1124,10 @@ def main():
 
     for i in range(args.warmup):
         step(i).release()
-    torch.cuda.synchronize()
+    _sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     t0 = time.perf_counter()
     kernel_ms = {}
     total_path = 0
@@ -1019,10 +1143,10 @@ def main():
         for k, v in ctx.timings().items():
             kernel_ms[k] = kernel_ms.get(k, 0.0) + v
         r.release()
-    torch.cuda.synchronize()
+    _sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    _sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -1045,7 +1169,7 @@ def main():
                 def run_packed(i):
                     rr = step(i)
                     rr.pack(d_offs.data_ptr(), d_items.data_ptr(), cap_items)
-                    torch.cuda.synchronize()
+                    _sync()
                     ho = d_offs.cpu().numpy().view(np.uint32)
                     hi = d_items[:int(ho[-1])].cpu().numpy()
                     rr.release()
@@ -1143,13 +1267,13 @@ def main():
         # configs[1] (perceptron only) on the same model and batches, outside the timed region
         perceptron_only = None
         ctx2 = None
-        if args.rnn and world == 1:
+        if args.rnn and world == 1 and not emu:
             ctx2 = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank, use_rnn=False)
             def step2(i):
                 t, o, n, nbytes = d_batches[i % len(d_batches)]
                 return ctx2.analyze_device(t.data_ptr(), o.data_ptr(), n, nbytes, stream)
             step2(0).release()
-            torch.cuda.synchronize()
+            _sync()
             k2 = min(args.steps, 8)
             t1 = time.perf_counter()
             km2 = {}
@@ -1160,7 +1284,7 @@ def main():
                 for k, v in ctx2.timings().items():
                     km2[k] = km2.get(k, 0.0) + v
                 r2.release()
-            torch.cuda.synchronize()
+            _sync()
             e2 = time.perf_counter() - t1
             perceptron_only = {'workload': 'BASELINE configs[1]: same model and batches, RNN off', 'value': round(args.batch * k2 / e2, 1),
                                'unit': 'sentences/s', 'steps': k2, 'ms_per_step': round(e2 / k2 * 1e3, 3),
@@ -1170,7 +1294,7 @@ def main():
         # k_rnn_score: VALU-bound).  Reported beside `value`, not as it: per-kernel durations under overlap are
         # inflated, so the roofline figures stay those of the serial timed region above.
         overlapped = None
-        if world == 1 and not args.no_overlap:
+        if world == 1 and not args.no_overlap and not emu:
             try:
                 ctxB = J.Context(img, beam=5, global_beam=6, right_check=1, right_beam=5, device=local_rank,
                                  use_rnn=None if args.rnn else False, share_with=ctx)   # (one copy of the model in HBM)
@@ -1192,14 +1316,14 @@ def main():
                         r.release()
                 for k in range(2):
                     worker(k, 1)
-                torch.cuda.synchronize()
+                _sync()
                 t2 = time.perf_counter()
                 th = [threading.Thread(target=worker, args=(k, k3 // 2)) for k in range(2)]
                 for x in th:
                     x.start()
                 for x in th:
                     x.join()
-                torch.cuda.synchronize()
+                _sync()
                 e3 = time.perf_counter() - t2
                 k3 = 2 * (k3 // 2)
                 overlapped = {'what': 'two batches in flight: two contexts on two HIP streams, each driven by its own host thread, same workload',
@@ -1220,7 +1344,7 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'u64+f32',  # 64-bit integer hashing, f32 score sums
-            'data': 'synthetic',
+            'data': 'synthetic' if not emu else 'synthetic -- EMULATOR CONTROL-FLOW TEST (JPPGPU_BENCH_EMU=1): not a measurement',
             'config': {
                 'workload': (('BASELINE configs[2]: 1xMI355X per rank, perceptron + RNNLM (E=%d), ' % args.rnn_hidden)
                              if args.rnn else
@@ -1270,9 +1394,14 @@ def main():
         ctx2 = None
         import gc
         gc.collect()
-        torch.cuda.empty_cache()
+        if not emu:
+            torch.cuda.empty_cache()
+        if emu:
+            args.no_config5 = args.no_realism = args.no_trainer = True
         if not args.no_config5 and world == 1:
             out['config5'] = config5_leg(args, cache, local_rank, np, torch, J)
+            if c5_cli is not None and isinstance(out['config5'], dict):
+                out['config5']['cli_lattice'] = c5_cli   # (measured before the first device allocation of this process)
         if not args.no_realism and world == 1:
             out['realism'] = realism_legs(args, cache, local_rank, np, torch, J)
         if not args.no_trainer and world == 1:
