@@ -141,6 +141,16 @@ typedef struct {
    * host scorers in order; at most 4 in all.  Needs a global beam, like every extra scorer (analyzer_impl.cc:81-86). */
   int32_t num_host_scorers; /* 0 .. 2 */
   float weight_host[2];     /* ScorerDef::scoreWeights of the host scorers */
+  /* (round 5) What jppgpu_ctx_create DERIVES from the model -- the per-dictionary-entry T0 records of k_t0_memo: a walk
+   * over the whole trie and 30-odd weight gathers per entry, 0.3-0.6 s for a 10^6-entry dictionary -- may be handed in
+   * instead, as jppgpu_ctx_t0_memo_image returned it for this very model (same file, same weights) and this library
+   * (jppgpu_t0_memo_format).  The reference re-reads and re-derives its model on every start as well
+   * (src/core/impl/model_io.cc:115-176); jumanpp_gpu keeps the image beside the .jppmdl, keyed by size + mtime.
+   * A context made from an image drops its T0 records when jppgpu_ctx_set_weights replaces the table. */
+  const void* t0_memo_image;
+  uint64_t t0_memo_image_bytes;
+  uint32_t t0_memo_slots;
+  int32_t keep_t0_memo_image;   /* 1: keep a host copy of the records for jppgpu_ctx_t0_memo_image */
 } jppgpu_config;
 #define JPPGPU_CONFIG_MIN_SIZE 44u   /* struct_size .. dynamic_features: the first layout that carried a size */
 #define JPPGPU_CONFIG_INIT {(uint32_t)sizeof(jppgpu_config)}
@@ -242,7 +252,16 @@ typedef struct jppgpu_reserve {
   uint32_t text_host_blocks;   /* page-locked host blocks of that size kept ready (results in flight at once) */
   uint32_t reserved;
 } jppgpu_reserve;
+/* the derived T0 records of a context made with keep_t0_memo_image (host memory owned by the context's model copy, valid
+ * until its last context is destroyed); *bytes = 0 when the context has none.  jppgpu_t0_memo_format: changes whenever
+ * the record layout or its arithmetic does -- part of a cache key. */
+int jppgpu_ctx_t0_memo_image(jppgpu_ctx* ctx, const void** data, uint64_t* bytes, uint32_t* slots);
+uint64_t jppgpu_t0_memo_format(void);
 int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r);
+/* `count` page-locked host blocks of `bytes` each, pinned on the calling thread and left where the text pools of the
+ * contexts (jppgpu_result_format_top1) take them from.  Meant for a thread of its own at process start: page-locking a
+ * few hundred MB takes longer than a batch. */
+int jppgpu_host_prepin(int32_t device, uint64_t bytes, uint32_t count);
 
 typedef struct jppgpu_ctx_statistics {
   uint32_t struct_size;            /* sizeof(jppgpu_ctx_statistics), set by the caller */

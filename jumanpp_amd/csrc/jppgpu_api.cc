@@ -293,11 +293,17 @@ u64 host_varint(const u8* p, size_t& pos) {
 // Host copies of a result live in blocks that a context recycles across batches (the per-batch sizes
 // repeat; a fresh std::vector would be allocated and zero-filled every time).  A block goes back to its
 // pool when the result is released; the pool is freed with the context.
+struct HostBlock {
+  void* p;
+  size_t cap;
+};
+// page-locked blocks pinned ahead of time by jppgpu_host_prepin (any thread, before or while contexts are made): the
+// text pools of the contexts take from here before they pin anything themselves
+static std::mutex g_prepin_mu;
+static std::vector<HostBlock> g_prepinned;
+
 struct HostPool {
-  struct Block {
-    void* p;
-    size_t cap;
-  };
+  typedef HostBlock Block;
   bool pinned = false;   // blocks come from rt_host_alloc_pinned
   // A result may be released on another thread than the one that analyses on its context (jumanpp_gpu hands the text of
   // a batch to a writer thread while the analysis and format threads keep taking blocks): the free list is locked.
@@ -312,6 +318,17 @@ struct HostPool {
       if (best >= 0 && free_blocks[best].cap <= 2 * bytes + 4096) {
         Block b = free_blocks[best];
         free_blocks.erase(free_blocks.begin() + best);
+        return b;
+      }
+    }
+    if (pinned) {
+      std::lock_guard<std::mutex> l(g_prepin_mu);
+      int best = -1;
+      for (int i = 0; i < (int)g_prepinned.size(); ++i)
+        if (g_prepinned[i].cap >= bytes && (best < 0 || g_prepinned[i].cap < g_prepinned[best].cap)) best = i;
+      if (best >= 0) {
+        Block b = g_prepinned[best];
+        g_prepinned.erase(g_prepinned.begin() + best);
         return b;
       }
     }
@@ -438,6 +455,8 @@ struct ModelBufs {
     i32 row[spec::kNumDicFeatures];
   };
   std::vector<MemoSeed> t0_memo_seeds;
+  bool t0_memo_from_image = false;       // uploaded from jppgpu_config::t0_memo_image: no seeds to rebuild it from
+  std::vector<T0Memo> t0_memo_host;      // keep_t0_memo_image: what jppgpu_ctx_t0_memo_image hands out
   // output text on the device (jppgpu_ctx_set_format_table)
   bool fmt_have = false;
   DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table;
@@ -823,13 +842,15 @@ void fill_memo(const std::vector<ModelBufs::MemoSeed>& seeds, const float* weigh
   for (auto& th : pool) th.join();
 }
 
-bool upload_memo(jppgpu_ctx* ctx, const float* weights) {
+bool upload_memo(jppgpu_ctx* ctx, const float* weights, bool keep_host = false) {
   std::vector<T0Memo> table((size_t)ctx->mb->t0_memo_slots);
   memset(static_cast<void*>(table.data()), 0, table.size() * sizeof(T0Memo));
   fill_memo(ctx->mb->t0_memo_seeds, weights, ctx->hmodel.wmask, &table);
   if (!ctx->mb->t0_memo.ensure(table.size() * sizeof(T0Memo))) return false;
   rt_h2d(ctx->mb->t0_memo.p, table.data(), table.size() * sizeof(T0Memo), nullptr);
   rt_sync(nullptr);
+  if (keep_host) ctx->mb->t0_memo_host.swap(table);
+  else std::vector<T0Memo>().swap(ctx->mb->t0_memo_host);
   return true;
 }
 }  // namespace
@@ -1139,11 +1160,23 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   rt_sync(nullptr);
   // (developer knob JPPGPU_DEV_T0_MEMO=0: k_t0 without the per-entry memo)
   static const bool devT0Memo = !(std::getenv("JPPGPU_DEV_T0_MEMO") && std::atoi(std::getenv("JPPGPU_DEV_T0_MEMO")) == 0);
-  if (!ctx->dynamic_spec && devT0Memo) {
+  const u32 memoSlotsOfModel = (u32)(m->entry_data_bytes / 8 + 1);
+  if (!ctx->dynamic_spec && devT0Memo && c->t0_memo_image != nullptr && c->t0_memo_slots == memoSlotsOfModel &&
+      c->t0_memo_image_bytes == (uint64_t)memoSlotsOfModel * sizeof(T0Memo)) {
+    // the records as an earlier process derived them from this model: uploaded as they are
+    if (!ctx->mb->t0_memo.ensure((size_t)c->t0_memo_image_bytes)) {
+      jppgpu_ctx_destroy(ctx);
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
+    }
+    rt_h2d(ctx->mb->t0_memo.p, c->t0_memo_image, (size_t)c->t0_memo_image_bytes, nullptr);
+    rt_sync(nullptr);
+    ctx->mb->t0_memo_slots = memoSlotsOfModel;
+    ctx->mb->t0_memo_from_image = true;
+  } else if (!ctx->dynamic_spec && devT0Memo) {
     const auto t_a = std::chrono::steady_clock::now();
     collect_memo_seeds(m, &ctx->mb->t0_memo_seeds, &ctx->mb->t0_memo_slots);
     const auto t_b = std::chrono::steady_clock::now();
-    if (!upload_memo(ctx, m->weights)) {
+    if (!upload_memo(ctx, m->weights, c->keep_t0_memo_image != 0)) {
       jppgpu_ctx_destroy(ctx);
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
     }
@@ -1300,6 +1333,7 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const size_t n = r->max_sentences, bytes = (size_t)r->max_total_bytes;
   if (n == 0) return JPPGPU_OK;
+  const auto t_reserve0 = std::chrono::steady_clock::now();
   constexpr double kDefaultNodesPerByte = 3.0;   // (the 10^6-row bench dictionary: 2.1; 220-codepoint sentences: 2.2)
   const double npb = r->nodes_per_byte > 0.f ? (double)r->nodes_per_byte : kDefaultNodesPerByte;
   const u64 nodes = (u64)((double)bytes * npb) + 16 * (u64)n + 8;
@@ -1337,6 +1371,39 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
     for (auto& b : blocks) ctx->text_pool->give(b);
   }
   if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (jppgpu_ctx_reserve)");
+  if (std::getenv("JPPGPU_HOST_TIMING") != nullptr)
+    std::fprintf(stderr, "[jppgpu] reserve: %u sentences, %llu bytes, %llu nodes: %.1f ms\n", (unsigned)n, (unsigned long long)bytes,
+                 (unsigned long long)nodes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_reserve0).count());
+  return JPPGPU_OK;
+}
+
+// `count` page-locked host blocks of `bytes` each, pinned NOW on the calling thread and left where the contexts' text
+// pools find them (jppgpu_result_format_top1 copies the text of a batch into such a block).  Page-locking runs at
+// ~1-2 GB/s: jumanpp_gpu calls this on a thread of its own while the model is loaded and the analyzers are made, so that
+// neither the first batches (round 4: 0.2-0.9 s stalls) nor the start-up (jppgpu_ctx_reserve with text_host_blocks:
+// 2.3 s for 8 x 215 MB, profiles/r05b) wait for it.  Blocks nobody took are freed at process exit.
+extern "C" int jppgpu_host_prepin(int32_t device, uint64_t bytes, uint32_t count) {
+  if (bytes == 0 || count == 0) return JPPGPU_OK;
+  if (!bind_device(device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed");
+  for (uint32_t k = 0; k < count; ++k) {
+    void* p = rt_host_alloc_pinned((size_t)bytes);
+    if (!p) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (jppgpu_host_prepin)");
+    std::lock_guard<std::mutex> l(g_prepin_mu);
+    g_prepinned.push_back(HostBlock{p, (size_t)bytes});
+  }
+  return JPPGPU_OK;
+}
+
+extern "C" uint64_t jppgpu_t0_memo_format(void) {
+  // record size, the split of the unigram list it folds, the spec it was generated from
+  return (u64{0x54304d52} << 32) ^ ((u64)sizeof(T0Memo) << 16) ^ ((u64)kT0CtxFirst << 8) ^ (u64)kT0CtxLast ^ ((u64)spec::kSpecBlobSize << 40) ^ 1u;
+}
+
+extern "C" int jppgpu_ctx_t0_memo_image(jppgpu_ctx* ctx, const void** data, uint64_t* bytes, uint32_t* slots) {
+  if (!ctx || !data || !bytes || !slots) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  *data = ctx->mb->t0_memo_host.empty() ? nullptr : ctx->mb->t0_memo_host.data();
+  *bytes = (uint64_t)ctx->mb->t0_memo_host.size() * sizeof(T0Memo);
+  *slots = ctx->mb->t0_memo_host.empty() ? 0u : ctx->mb->t0_memo_slots;
   return JPPGPU_OK;
 }
 
@@ -2583,6 +2650,12 @@ extern "C" int jppgpu_ctx_set_weights(jppgpu_ctx* ctx, const float* weights, uin
   rt_sync(ctx->own_stream);
   rt_h2d(ctx->mb->weights.p, weights, (size_t)n * 4, nullptr);
   rt_sync(nullptr);
+  if (ctx->mb->t0_memo_from_image) {
+    // (the records came from a cache of the model file's own weights and there are no seeds to re-derive them from:
+    // the context goes on without them -- k_t0 instead of k_t0_memo, same results)
+    ctx->mb->t0_memo_slots = 0;
+    ctx->mb->t0_memo_from_image = false;
+  }
   if (ctx->mb->t0_memo_slots && !upload_memo(ctx, weights)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (T0 memo)");
   return JPPGPU_OK;
 }

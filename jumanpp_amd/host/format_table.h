@@ -26,10 +26,16 @@ class JumanFormatTable {
   // the table has no slot for, no JUMAN id map, entry pointers that are not the builder's consecutive lists):
   // the caller keeps formatting on the host
   Status build(const ModelImage* model, unsigned threads);
+  // the table as an earlier process built it for this model (host/derived_cache.h): the arrays stay where they are
+  void adopt(const jppgpu_format_table& cached, size_t entries) {
+    view_ = cached;
+    entries_ = entries;
+    buildMs_ = 0;
+  }
   const jppgpu_format_table& view() const { return view_; }
   size_t numEntries() const { return entries_; }
-  size_t numRows() const { return rows_.size(); }
-  size_t blobBytes() const { return blob_.size(); }
+  size_t numRows() const { return (size_t)view_.n_rows; }
+  size_t blobBytes() const { return (size_t)view_.blob_bytes; }
   double buildMs() const { return buildMs_; }
 };
 

@@ -96,6 +96,10 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
     haveFormatTable_ = false;
     textMode_ = false;
   }
+  c.t0_memo_image = memoImage_;
+  c.t0_memo_image_bytes = memoImageBytes_;
+  c.t0_memo_slots = memoImageSlots_;
+  c.keep_t0_memo_image = keepMemoImage_ ? 1 : 0;
   int rc;
   if (shareModelWith != nullptr && shareModelWith->ctx_ != nullptr && shareModelWith->model_ == model) {
     rc = jppgpu_ctx_create_shared(shareModelWith->ctx_, &c, &ctx_);
@@ -441,6 +445,11 @@ Status GpuAnalyzer::reserve(uint32_t maxSentences, uint64_t maxBytes, float text
   r.text_host_blocks = textMode_ ? textBlocks : 0;
   int rc = jppgpu_ctx_reserve(ctx_, &r);
   return rc == JPPGPU_OK ? Status::Ok() : fromCode(rc);
+}
+
+bool GpuAnalyzer::exportT0MemoImage(const void** data, uint64_t* bytes, uint32_t* slots) const {
+  if (!ctx_) return false;
+  return jppgpu_ctx_t0_memo_image(ctx_, data, bytes, slots) == JPPGPU_OK && *bytes != 0;
 }
 
 void GpuAnalyzer::pipelineStats(uint64_t out[4]) const {

@@ -178,6 +178,10 @@ class GpuAnalyzer {
   bool textMode_ = false;          // results are fetched as formatted text (jppgpu_result_format_top1)
   bool haveFormatTable_ = false;
   bool deferText_ = false, textFetched_ = false;
+  const void* memoImage_ = nullptr;
+  uint64_t memoImageBytes_ = 0;
+  uint32_t memoImageSlots_ = 0;
+  bool keepMemoImage_ = false;
   jppgpu_text_view text_{};
   std::vector<Group> groups_;
   std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
@@ -268,6 +272,15 @@ class GpuAnalyzer {
   const ScoringConfig& scoringConfig() const { return sconf_; }
   // [0]decode [1]seeds [2]layout [3]t0 [4]sweep [5]rnn [6]path [7]total, ms of the last batch
   void lastTimings(float ms[8]) const;
+  // the derived per-entry T0 records of the model (jppgpu_config::t0_memo_image): handed in from a cache before
+  // initialize(), or kept by initialize() for exportT0MemoImage() so that the caller can write the cache
+  void setT0MemoImage(const void* data, uint64_t bytes, uint32_t slots) {
+    memoImage_ = data;
+    memoImageBytes_ = bytes;
+    memoImageSlots_ = slots;
+  }
+  void setKeepT0MemoImage(bool keep) { keepMemoImage_ = keep; }
+  bool exportT0MemoImage(const void** data, uint64_t* bytes, uint32_t* slots) const;
   // Every buffer of a batch of up to maxSentences sentences / maxBytes input bytes now (jppgpu_ctx_reserve): the batches
   // then allocate nothing and are one enqueue each.  textBytesPerByte != 0 (text mode): also the device text buffer and
   // `textBlocks` page-locked host blocks of that size.  A batch beyond the reservation still works (it is run again).

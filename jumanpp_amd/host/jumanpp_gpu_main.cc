@@ -49,6 +49,7 @@
 #include <sched.h>
 #include <vector>
 
+#include "derived_cache.h"
 #include "format_table.h"
 #include "gpu_analyzer.h"
 #include "juman_format.h"
@@ -70,6 +71,7 @@ struct Conf {
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
+  bool noImageCache = false;   // --no-image-cache: derive the T0 records and the format table afresh, write no cache
   bool noReserve = false;   // --no-reserve: the analyzers size their buffers batch by batch (round-4 behaviour)
   bool help = false;
   int lattice = 0;  // -s N / --lattice N / --specifics N: LatticeFormat with the N best paths; -1 = beam width
@@ -406,6 +408,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--pipelines-per-device", &v)) conf.pipelinesPerDevice = std::max(1, std::min(4, std::atoi(v.c_str())));
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (std::strcmp(argv[i], "--no-reserve") == 0) conf.noReserve = true;
+    else if (std::strcmp(argv[i], "--no-image-cache") == 0) conf.noImageCache = true;
     else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -471,7 +474,7 @@ int main(int argc, const char** argv) {
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
-                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing, --no-reserve,\n"
+                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache,\n"
                  "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format),\n"
                  "           --pipelines-per-device=2 (bulk runs: analysis threads, each with its analyzer pair, per GPU)\n";
     return 1;
@@ -656,12 +659,66 @@ int main(int argc, const char** argv) {
   JumanFormatTable formatTable;
   bool deviceText = !conf.hostFormat && !latticeFormat && !useLattice && conf.kind == Conf::Juman && acfg.autoBeamStep <= 0 &&
                     std::getenv("JUMANPP_GPU_HOST_FORMAT") == nullptr;
-  if (deviceText) {
+  // What a process derives from the model before its first batch (per-entry T0 records, rendered entry rows) is kept
+  // beside the model file by the first run and mapped by the later ones (derived_cache.h)
+  DerivedCache derived;
+  const bool useImageCache = !conf.noImageCache && std::getenv("JPPGPU_NO_IMAGE_CACHE") == nullptr && !conf.partialInput;
+  const bool cacheHit = useImageCache && derived.load(conf.model);
+  bool tableFromCache = false;
+  if (deviceText && cacheHit && derived.hasFormatTable()) {
+    formatTable.adopt(derived.formatTable(), (size_t)derived.formatTableEntries());
+    tableFromCache = true;
+    if (conf.timing)
+      std::cerr << "device_format=1 table_entries=" << formatTable.numEntries() << " rows=" << formatTable.numRows()
+                << " blob_bytes=" << formatTable.blobBytes() << " build_ms=0 (image cache)\n";
+  }
+  if (deviceText && !tableFromCache) {
     Status built = formatTable.build(&model, (unsigned)std::max(1, conf.threads));
     if (!built) deviceText = false;   // (e.g. an UNK maker that rewrites a field the table renders: host formatters)
     if (conf.timing)
       std::cerr << "device_format=" << (deviceText ? 1 : 0) << " table_entries=" << formatTable.numEntries() << " rows=" << formatTable.numRows()
                 << " blob_bytes=" << formatTable.blobBytes() << " build_ms=" << formatTable.buildMs() << (built ? "" : " (" + statusText(built) + ")") << "\n";
+  }
+  // The batches of a file-to-file run, sized before anything is allocated (the inputs are regular files): lines per batch
+  // x the mean line of a sample, with a margin; the JUMAN text of a batch from the mean row of the format table (a
+  // morpheme covers ~5.5 input bytes and prints about one row).  Used twice: the page-locked text blocks are pinned on
+  // a thread of their own from HERE on -- beside the analyzers being made, which is the slower half of the start-up --
+  // and every analyzer reserves its device buffers before the pipeline's clock starts (below).
+  uint64_t planBatchBytes = 0;
+  uint32_t planBatchLines = 0;
+  float planTextPerByte = 0.f;
+  struct Joiner {
+    std::thread t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } prepin;
+  if (sharded && !conf.noReserve) {
+    size_t inputTotal = 0, sampleBytes = 0, sampleLines = 0;
+    for (auto& path : conf.inputs) {
+      struct stat si;
+      if (::stat(path.c_str(), &si) == 0) inputTotal += (size_t)si.st_size;
+    }
+    {
+      std::ifstream f(conf.inputs[0], std::ios::binary);
+      std::vector<char> buf(size_t{4} << 20);
+      f.read(buf.data(), (std::streamsize)buf.size());
+      sampleBytes = (size_t)f.gcount();
+      for (size_t i = 0; i < sampleBytes; ++i) sampleLines += buf[i] == '\n';
+      if (sampleBytes && (sampleLines == 0 || buf[sampleBytes - 1] != '\n')) ++sampleLines;
+    }
+    const double meanLine = sampleLines ? (double)sampleBytes / (double)sampleLines : 64.0;
+    planBatchBytes = std::min<uint64_t>((uint64_t)inputTotal + 64, (uint64_t)((double)conf.batch * meanLine * 1.25) + 65536);
+    planBatchLines = (uint32_t)std::min<uint64_t>(conf.batch, (uint64_t)((double)inputTotal / std::max(1.0, meanLine - 1.0)) + 16);
+    if (deviceText && formatTable.numRows() > 0) {
+      planTextPerByte = (float)(1.1 * ((double)formatTable.blobBytes() / (double)formatTable.numRows()) / 5.5);
+      const uint64_t textBytes = (uint64_t)((double)planBatchBytes * planTextPerByte) + 64 * (uint64_t)planBatchLines + 4096;
+      const size_t nBatches = (size_t)((double)inputTotal / std::max(1.0, (double)planBatchBytes / 1.25)) + 1;
+      // per pipeline: the block being filled, one queued, one being written
+      const uint32_t blocks = (uint32_t)std::min<size_t>(nBatches, 3 * conf.devices.size());
+      const int dev0 = conf.devices.empty() ? conf.device : conf.devices[0];
+      prepin.t = std::thread([=]() { (void)jppgpu_host_prepin(dev0, textBytes, blocks); });
+    }
   }
   auto makeAnalyzer = [&](int d, int a) -> Status {
     analyzers[d][a].reset(new GpuAnalyzer());
@@ -673,6 +730,10 @@ int main(int argc, const char** argv) {
       if (conf.devices[d2] == conf.devices[d] && analyzers[d2][0] && analyzers[d2][0].get() != analyzers[d][a].get() &&
           analyzers[d2][0]->ready())
         donor = analyzers[d2][0].get();
+    if (donor == nullptr && cacheHit && derived.memo() != nullptr)
+      analyzers[d][a]->setT0MemoImage(derived.memo(), derived.memoBytes(), derived.memoSlots());
+    else if (donor == nullptr && useImageCache && !cacheHit && d == 0 && a == 0)
+      analyzers[d][a]->setKeepT0MemoImage(true);   // (this run writes the cache, below)
     Status made = analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d], donor);
     if (made && deviceText) {
       if (donor == nullptr) made = analyzers[d][a]->setFormatTable(formatTable.view());
@@ -688,6 +749,24 @@ int main(int argc, const char** argv) {
     if (!s) {
       std::cerr << "failed to initialize the analyzer on device " << conf.devices[d] << ": " << s << "\n";
       return 1;
+    }
+  }
+  if (conf.timing && useImageCache) std::cerr << std::string(cacheHit ? "image_cache=hit\n" : "image_cache=miss\n");
+  Joiner cacheWriter;
+  if (useImageCache && !cacheHit && analyzers[0][0]) {
+    const void* memo = nullptr;
+    uint64_t memoBytes = 0;
+    uint32_t memoSlots = 0;
+    const bool haveMemo = analyzers[0][0]->exportT0MemoImage(&memo, &memoBytes, &memoSlots);
+    const jppgpu_format_table* tbl = deviceText ? &formatTable.view() : nullptr;
+    if (haveMemo || tbl != nullptr) {
+      const std::string modelPath = conf.model;
+      const uint64_t entries = formatTable.numEntries();
+      const bool timing = conf.timing;
+      cacheWriter.t = std::thread([=]() {
+        const bool ok = DerivedCache::store(modelPath, haveMemo ? memo : nullptr, memoBytes, memoSlots, tbl, entries);
+        if (timing) std::cerr << (std::string("image cache ") + (ok ? "written" : "not written") + " for " + modelPath + "\n");   // (one write: other threads print too)
+      });
     }
   }
   std::vector<std::unique_ptr<OutputFormat>> formats;
@@ -741,33 +820,16 @@ int main(int argc, const char** argv) {
     // 0.2-0.9 s in batches 0-2, profiles/r04_t_cli_stages.txt) and every batch waited three times for the totals that
     // size them; now a batch is one enqueue and allocates nothing.  (--no-reserve: the round-4 behaviour.)
     if (!conf.noReserve) {
-      size_t sampleBytes = 0, sampleLines = 0;
-      for (auto& mf : maps) {
-        const size_t take = std::min<size_t>(mf->size, size_t{4} << 20);
-        sampleBytes += take;
-        for (const char* q = mf->data; q < mf->data + take;) {
-          const char* nl = static_cast<const char*>(memchr(q, '\n', (size_t)(mf->data + take - q)));
-          ++sampleLines;
-          if (!nl) break;
-          q = nl + 1;
-        }
-      }
-      size_t inputTotal = 0;
-      for (auto& mf : maps) inputTotal += mf->size;
-      const double meanLine = sampleLines ? (double)sampleBytes / (double)sampleLines : 64.0;
-      const uint64_t batchBytes = std::min<uint64_t>((uint64_t)inputTotal + 64, (uint64_t)((double)conf.batch * meanLine * 1.25) + 65536);
-      const uint32_t batchLines = (uint32_t)std::min<uint64_t>(conf.batch, (uint64_t)((double)inputTotal / std::max(1.0, meanLine - 1.0)) + 16);
-      // text per input byte: a morpheme covers ~5 input bytes and prints ~one mean row of the table
-      float textPerByte = 0.f;
-      if (deviceText && formatTable.numRows() > 0)
-        textPerByte = (float)(1.25 * ((double)formatTable.blobBytes() / (double)formatTable.numRows()) / 5.0);
+      const uint64_t batchBytes = planBatchBytes;
+      const uint32_t batchLines = planBatchLines;
+      const float textPerByte = planTextPerByte;
       const double r0 = clock.ms();
       std::vector<std::future<Status>> reserved;
       for (int d = 0; d < nDev; ++d)
         for (int a = 0; a < nAnalyzers; ++a)
           if (analyzers[(size_t)d][(size_t)a])
             reserved.emplace_back(std::async(std::launch::async, [&, d, a]() {
-              return analyzers[(size_t)d][(size_t)a]->reserve(batchLines, batchBytes, textPerByte, 2);
+              return analyzers[(size_t)d][(size_t)a]->reserve(batchLines, batchBytes, textPerByte, 0);
             }));
       for (auto& f : reserved) {
         Status rs = f.get();

@@ -1,5 +1,10 @@
 #include "model_image.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstring>
 #include <fstream>
 
@@ -46,15 +51,45 @@ inline uint64_t key2(int32_t a, int32_t b) { return ((uint64_t)(uint32_t)a << 32
 
 }  // namespace
 
+void FileBytes::reset() {
+  if (p_) ::munmap(p_, map_);
+  p_ = nullptr;
+  map_ = size_ = 0;
+}
+
+bool FileBytes::open(const std::string& path) {
+  reset();
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat st;
+  if (::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+    ::close(fd);
+    return false;
+  }
+  const size_t sz = (size_t)st.st_size, page = 4096;
+  const size_t total = (sz + page - 1) / page * page + page;
+  void* r = ::mmap(nullptr, total, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (r == MAP_FAILED) {
+    ::close(fd);
+    return false;
+  }
+  if (sz != 0 && ::mmap(r, sz, PROT_READ, MAP_PRIVATE | MAP_FIXED | MAP_POPULATE, fd, 0) == MAP_FAILED) {
+    ::munmap(r, total);
+    ::close(fd);
+    return false;
+  }
+  ::close(fd);
+  p_ = static_cast<char*>(r);
+  map_ = total;
+  size_ = sz;
+  return true;
+}
+
 Status ModelImage::loadModel(StringPiece filename) {
   std::string fn = filename.str();
-  std::ifstream f(fn, std::ios::binary | std::ios::ate);
-  if (!f) return Status::InvalidParameter() << "could not open model image " << fn;
-  std::streamsize sz = f.tellg();
-  f.seekg(0);
-  // 8-byte aligned storage: every section payload starts on an 8-byte boundary of the file
-  data_.assign((size_t)sz + 8, 0);
-  if (!f.read(data_.data(), sz)) return Status::InvalidParameter() << "could not read model image " << fn;
+  // (every section payload starts on an 8-byte boundary of the file, and the mapping is page aligned)
+  if (!data_.open(fn)) return Status::InvalidParameter() << "could not open model image " << fn;
+  const std::streamsize sz = (std::streamsize)data_.size();
   fileSize_ = (size_t)sz;
   const char* base = data_.data();
   if (sz >= 24 && std::memcmp(base, "jp2Mdl!", 8) == 0) return loadJppmdl(fn);

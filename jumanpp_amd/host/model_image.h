@@ -78,8 +78,26 @@ struct RnnConfigOverride {
   }
 };
 
+// the bytes of a model file: mapped, not read (a 0.7 GB model was zero-filled and copied into a vector, ~0.3 s of
+// every process start).  8 readable zero bytes follow the file (varint readers may look ahead): the mapping is made over
+// an anonymous reservation one page longer than the file.
+class FileBytes {
+  char* p_ = nullptr;
+  size_t map_ = 0, size_ = 0;
+
+ public:
+  FileBytes() = default;
+  FileBytes(const FileBytes&) = delete;
+  FileBytes& operator=(const FileBytes&) = delete;
+  ~FileBytes() { reset(); }
+  void reset();
+  bool open(const std::string& path);
+  const char* data() const { return p_; }
+  size_t size() const { return size_; }
+};
+
 class ModelImage {
-  std::vector<char> data_;
+  FileBytes data_;
   jppgpu_model model_{};
   std::vector<jppgpu_unk_maker> makers_;
   std::vector<DictionaryField> fields_;

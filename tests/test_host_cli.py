@@ -26,8 +26,12 @@ def cli_gpu(gpu_lib):
     return ge.build_host()
 
 
-def _run(cli, args, stdin=None):
-    p = subprocess.run([cli] + args, input=stdin, capture_output=True)
+def _run(cli, args, stdin=None, image_cache=False):
+    # (the derived-image cache is written beside the model file: off for the models under tests/golden)
+    env = dict(os.environ)
+    if not image_cache:
+        env['JPPGPU_NO_IMAGE_CACHE'] = '1'
+    p = subprocess.run([cli] + args, input=stdin, capture_output=True, env=env)
     return p.returncode, p.stdout, p.stderr
 
 
@@ -875,3 +879,42 @@ def test_cli_without_the_t0_memo_equals_the_reference(cli_emu, ref_tools, golden
         assert p.returncode == 0, p.stderr[-300:]
         assert p.stdout == ref, memo
         assert (b'T0 memo:' in p.stderr) == (memo == '1')
+
+
+def _image_cache_case(cli, golden_dir, tmp_path):
+    """the derived-image cache (host/derived_cache.h): the first process writes <model>.jppgpu-cache, the second maps it
+    (T0 records handed to jppgpu_ctx_create, format table adopted) and prints the same bytes; a model file that changed
+    (mtime) is not served from the old cache"""
+    import shutil
+    import time
+    model = str(tmp_path / 'm.jppmdl')
+    shutil.copy(os.path.join(golden_dir, 'mini_rnn.jppmdl'), model)
+    txt = os.path.join(golden_dir, 'mini.txt')
+    ref = open(os.path.join(golden_dir, 'mini_rnn.juman.txt'), 'rb').read()
+    out1 = str(tmp_path / 'o1.txt')
+    rc, _, err = _run(cli, ['--model=' + model, '--timing', '-o', out1, txt], image_cache=True)
+    assert rc == 0 and b'image_cache=miss' in err and b'image cache written' in err, err[-400:]
+    assert os.path.exists(model + '.jppgpu-cache')
+    assert open(out1, 'rb').read() == ref
+    for mode in (['-o', str(tmp_path / 'o2.txt')], []):    # the sharded and the stream pipeline
+        rc, out, err = _run(cli, ['--model=' + model, '--timing'] + mode + [txt], image_cache=True)
+        assert rc == 0 and b'image_cache=hit' in err and b'(image cache)' in err, err[-400:]
+        got = open(mode[1], 'rb').read() if mode else out
+        assert got == ref
+    os.utime(model, (time.time() + 5, time.time() + 5))
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=miss' in err and out == ref, err[-400:]
+    # a truncated cache file is ignored
+    with open(model + '.jppgpu-cache', 'r+b') as f:
+        f.truncate(1000)
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=miss' in err and out == ref, err[-400:]
+
+
+def test_emulated_derived_image_cache(cli_emu, golden_dir, tmp_path):
+    _image_cache_case(cli_emu, golden_dir, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_derived_image_cache(cli_gpu, golden_dir, tmp_path):
+    _image_cache_case(cli_gpu, golden_dir, tmp_path)
