@@ -765,7 +765,9 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                  'process_wall_s_incl_model_load': round(wall, 2),
                  'sentences_per_s_incl_model_load': round(n_lines / wall, 1),
                  'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')},
-                 'reserve_ms': round(kv.get('reserve_ms', 0.0), 1)}
+                 'reserve_ms': round(kv.get('reserve_ms', 0.0), 1),
+                 'process_ms': {'first_analyzers_ready': round(kv.get('first_analyzers_ready_ms', 0.0), 1),
+                                'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)}}
             main_rates.append(round(r['value']))
             if best is None or r['value'] > best['value']:
                 best = r
@@ -873,7 +875,11 @@ def config5_cli_lattice(args, cache, ge, np):
                'value': round(rate, 1), 'unit': 'sentences/s', 'runs': rates, 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
                'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
                'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
-               'process_wall_s_incl_model_load': round(wall, 2)}
+               'process_wall_s_incl_model_load': round(wall, 2),
+               'process_ms': {'first_analyzers_ready': round(kv.get('first_analyzers_ready_ms', 0.0), 1),
+                              'reserve': round(kv.get('reserve_ms', 0.0), 1),
+                              'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)},
+               'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')}}
         if not args.no_parity and not args.no_cpu_baseline:
             t = time.time()
             n_check = 2048
@@ -997,6 +1003,21 @@ def config5_leg(args, cache, local_rank, np, torch, J):
         rs.release()
         sweep_bytes = ab['sweep'] * nodes / max(1.0, ab['nodes'])
         ach = sweep_bytes / (km['sweep'] * 1e-3) / 1e9
+        # the RNN block of this shape: bytes by SURVEY 8(d), flops of the recurrence (2 E^2 per rnn node); the sentences are
+        # beyond the LDS staging of k_rnn_chain, so the recurrence runs in k_rnn_score<.., 3> (W streamed from L2)
+        rnn_roof = None
+        if args.rnn and km.get('rnn', 0) > 0:
+            ctx.analyze_device(d[0][0].data_ptr(), d[0][1].data_ptr(), d[0][2], d[0][3], stream).release()
+            st = ctx.rnn_stats()
+            n_rnn = max(0, st['rows'] - 2 * batch)
+            E = args.rnn_hidden
+            rbytes = n_rnn * (2 * E * 4 + 12) + n_rnn * E * 4 * 2
+            fl = n_rnn * 2.0 * E * E
+            rnn_roof = {'bound': 'hbm', 'kernels': 'k_rnn_paths + k_rnn_prep + k_rnn_order_* + k_rnn_chain + k_rnn_score<.., 2 / 3>',
+                        'achieved': round(rbytes / (km['rnn'] * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': round(rbytes / (km['rnn'] * 1e-3) / 1e9 / 8000.0, 5), 'algorithmic_bytes_per_step': int(rbytes),
+                        'ms_per_step': round(km['rnn'], 3), 'rnn_nodes_per_sentence': round(n_rnn / batch, 1),
+                        'recurrence_tflops_if_all_of_it': round(fl / (km['rnn'] * 1e-3) / 1e12, 2)}
         return {'workload': 'BASELINE configs[4] shape, one GPU: beam=gbeam=rbeam=32 rcheck=1, %d sentences x 220 codepoints '
                             'per step, perceptron + RNNLM' % batch,
                 'value': round(batch * k / el, 1), 'unit': 'sentences/s', 'steps': k, 'ms_per_step': round(el / k * 1e3, 3),
@@ -1005,6 +1026,8 @@ def config5_leg(args, cache, local_rank, np, torch, J):
                 'roofline': {'bound': 'hbm', 'kernel': 'k_sweep<32,*>', 'achieved': round(ach, 2), 'peak': 8000.0, 'unit': 'GB/s',
                              'frac': round(ach / 8000.0, 5), 'algorithmic_bytes_per_launch': int(sweep_bytes),
                              'avg_launch_ms': round(km['sweep'], 3)},
+                'roofline_rnn': rnn_roof,
+                'batches': ctx.stats(),
                 'parity_sample': par}
     except Exception as e:  # an extra leg must never take the main line down
         return {'error': str(e)[:200]}

@@ -114,6 +114,20 @@ typedef struct {
   uint32_t rnn_fields[8];
 } jppgpu_model;
 
+/* The value storage of one dictionary column (dic::FieldsHolder / DictionaryField, src/core/dic/dictionary.h:19-58):
+ * what the LENGTH primitives of a feature spec read (ByteLength / CodepointSize, src/core/impl/feature_impl_prim.h:114-156,
+ * PrimitiveFeatureContext::lengthOf, feature_impl_types.h:156-174).  kind 1: a string storage (length-prefixed strings,
+ * the column's value << align_power = byte offset); kind 2: an int-list storage (the column's value = byte offset of a
+ * varint count: string-list columns, "positions").  Borrowed for the duration of jppgpu_ctx_create. */
+typedef struct {
+  int32_t column;        /* entry-row column (DictionaryField::idxInEntry >= 0) */
+  int32_t kind;          /* 1 strings, 2 int lists */
+  uint32_t align_power;
+  uint32_t reserved;
+  const void* data;
+  uint64_t bytes;
+} jppgpu_field_storage;
+
 /* AnalyzerConfig + ScoringConfig subset (src/core/analysis/analyzer.h:15-27,
  * defaults of the CLI: src/jumandic/shared/jumanpp_args.h:50-54) */
 typedef struct {
@@ -151,6 +165,11 @@ typedef struct {
   uint64_t t0_memo_image_bytes;
   uint32_t t0_memo_slots;
   int32_t keep_t0_memo_image;   /* 1: keep a host copy of the records for jppgpu_ctx_t0_memo_image */
+  /* (round 5) the column storages a spec with length primitives needs (any others are ignored); without them such a
+   * spec is JPPGPU_NOT_IMPLEMENTED */
+  const jppgpu_field_storage* field_storages;
+  uint32_t num_field_storages;
+  uint32_t reserved1;
 } jppgpu_config;
 #define JPPGPU_CONFIG_MIN_SIZE 44u   /* struct_size .. dynamic_features: the first layout that carried a size */
 #define JPPGPU_CONFIG_INIT {(uint32_t)sizeof(jppgpu_config)}

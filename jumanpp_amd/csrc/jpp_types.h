@@ -72,7 +72,7 @@ struct UnkMaker {
 // (features_api.cc:20-60).  Table-driven k_t0_dyn / k_sweep<.., DYN> read them; the limits are those of the
 // device layout (entry rows of at most 8 columns, at most kPat patterns referenced by bigrams / trigrams, ...).
 constexpr int kDynMaxPrims = 32, kDynMaxComputes = 32, kDynMaxPatterns = 64, kDynMaxArgs = 8, kDynMaxBranch = 8;
-constexpr int kDynMaxUni = 64, kDynMaxBi = 40, kDynMaxTri = 4;
+constexpr int kDynMaxUni = 64, kDynMaxBi = 40, kDynMaxTri = 4, kDynMaxStorages = 8;
 struct DevSpec {
   i32 nprims, ncomputes, npatterns, nstored, nuni, nbi, ntri, pad0;
   struct Prim { i32 kind, a, b; } prims[kDynMaxPrims];
@@ -83,6 +83,9 @@ struct DevSpec {
   u8 bi_t01[kDynMaxBi];        // (t0 slot << 4) | t1 slot
   u64 tri_prefix[kDynMaxTri];
   u8 tri_t[kDynMaxTri][4];     // t0, t1, t2 slots
+  // column storages of the length primitives (ByteLength / CodepointSize: prims[i].b = index here), in HBM
+  struct Storage { const u8* data; u64 bytes; u32 kind; u32 align; } storages[kDynMaxStorages];
+  i32 nstorages, pad1;
 };
 
 struct DevModel {

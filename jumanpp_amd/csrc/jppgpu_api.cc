@@ -455,6 +455,7 @@ struct ModelBufs {
     i32 row[spec::kNumDicFeatures];
   };
   std::vector<MemoSeed> t0_memo_seeds;
+  std::vector<DevBuf> field_blobs;       // column storages of the length primitives (DevSpec::storages)
   bool t0_memo_from_image = false;       // uploaded from jppgpu_config::t0_memo_image: no seeds to rebuild it from
   std::vector<T0Memo> t0_memo_host;      // keep_t0_memo_image: what jppgpu_ctx_t0_memo_image hands out
   // output text on the device (jppgpu_ctx_set_format_table)
@@ -549,7 +550,9 @@ namespace {
 // The flattened FeaturesSpec descriptors of a model (jppgpu_model::feature_spec; i32 counts and lists, see
 // include/jppgpu.h) into the device tables of the table-driven kernels.  Returns an empty string or why the spec is
 // outside what those kernels hold.
-std::string parse_feature_spec(const void* blob, size_t bytes, int numFeatures, DevSpec* out) {
+std::string parse_feature_spec(const void* blob, size_t bytes, int numFeatures, DevSpec* out,
+                               const jppgpu_field_storage* storages = nullptr, uint32_t numStorages = 0,
+                               std::vector<int>* usedStorages = nullptr) {
   const i32* p = static_cast<const i32*>(blob);
   const size_t n = bytes / 4;
   size_t pos = 0;
@@ -577,11 +580,28 @@ std::string parse_feature_spec(const void* blob, size_t bytes, int numFeatures, 
     if (!ok) return "truncated spec";
     // spec::PrimitiveFeatureKind: Copy 1, SingleBit 2, Provided 3, ByteLength 4, CodepointSize 5,
     // SurfaceCodepointSize 6, CodepointType 7, Codepoint 8
-    if (kind < 1 || kind > 8 || kind == 4 || kind == 5)
-      return "primitive feature kind " + std::to_string(kind) + " (length / match features need the dictionary's string storages)";
+    if (kind < 1 || kind > 8) return "primitive feature kind " + std::to_string(kind);
     out->prims[i].kind = kind;
     out->prims[i].a = a.size() > 0 ? a[0] : 0;
     out->prims[i].b = a.size() > 1 ? a[1] : 0;
+    if (kind == 4 || kind == 5) {
+      // ByteLength / CodepointSize over column a (feature_impl_prim.cc:51-90): the column's value storage must be here
+      if (a.size() != 1 || a[0] < 0 || a[0] >= numFeatures) return "length feature over a column outside the entry row";
+      int found = -1;
+      for (uint32_t q = 0; q < numStorages; ++q)
+        if (storages[q].column == a[0] && (storages[q].kind == 1 || storages[q].kind == 2) && storages[q].data != nullptr) found = (int)q;
+      if (found < 0)
+        return "length feature over column " + std::to_string(a[0]) + " whose value storage was not given (jppgpu_config::field_storages)";
+      int slot = -1;
+      for (size_t q = 0; usedStorages && q < usedStorages->size(); ++q)
+        if ((*usedStorages)[q] == found) slot = (int)q;
+      if (slot < 0) {
+        if (!usedStorages || usedStorages->size() >= (size_t)kDynMaxStorages) return "more column storages than the device tables hold";
+        slot = (int)usedStorages->size();
+        usedStorages->push_back(found);
+      }
+      out->prims[i].b = slot;
+    }
     if ((kind == 1 || kind == 2) && (out->prims[i].a < 0 || out->prims[i].a >= numFeatures)) return "primitive feature reads a column outside the entry row";
     if (kind == 3 && (out->prims[i].a < 0 || out->prims[i].a > 1)) return "more than two placeholders";
   }
@@ -860,6 +880,7 @@ ModelBufs::~ModelBufs() {
   DevBuf* bufs[] = {&trie, &eptrs, &edata, &weights, &dyn_spec, &rnn_known, &rnn_unk, &rnn_wt, &rnn_emb, &rnn_nce, &rnn_maxent,
                     &t0_memo, &fmt_slots, &fmt_rows, &fmt_blob, &fmt_table};
   for (auto* b : bufs) b->release();
+  for (auto& b : field_blobs) b.release();
   rt_free(dmodel);
 }
 
@@ -966,13 +987,15 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
                            m->feature_spec_bytes == spec::kSpecBlobSize &&
                            memcmp(m->feature_spec, spec::kSpecBlob, spec::kSpecBlobSize) == 0;
   std::unique_ptr<DevSpec> dynSpec;
+  std::vector<int> usedStorages;   // indices into c->field_storages of the storages the spec's length primitives read
   if (!builtinSpec || c->dynamic_features) {
     if (m->num_features < 1 || m->num_features > spec::kNumDicFeatures || m->num_placeholders < 0 ||
         m->num_placeholders > spec::kNumPlaceholders)
       return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: entry rows of more than 8 columns / more than 2 placeholders are not supported");
     if (!m->feature_spec || m->feature_spec_bytes < 16) return fail(JPPGPU_INVALID_PARAMETER, "model has no feature spec");
     dynSpec.reset(new DevSpec());
-    const std::string why = parse_feature_spec(m->feature_spec, m->feature_spec_bytes, m->num_features, dynSpec.get());
+    const std::string why = parse_feature_spec(m->feature_spec, m->feature_spec_bytes, m->num_features, dynSpec.get(),
+                                               c->field_storages, c->field_storages ? c->num_field_storages : 0, &usedStorages);
     if (!why.empty()) return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: feature spec outside the table-driven kernels: " + why);
   }
   if (m->weight_exponent >= 32 || !m->weights) return fail(JPPGPU_INVALID_PARAMETER, "bad perceptron weights");
@@ -996,6 +1019,20 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   rt_h2d(ctx->mb->weights.p, m->weights, wbytes, nullptr);
   H.spec = nullptr;
   if (dynSpec) {
+    dynSpec->nstorages = (i32)usedStorages.size();
+    ctx->mb->field_blobs.resize(usedStorages.size());
+    for (size_t q = 0; q < usedStorages.size(); ++q) {
+      const jppgpu_field_storage& fs = c->field_storages[usedStorages[q]];
+      if (!ctx->mb->field_blobs[q].ensure((size_t)fs.bytes + 16)) {
+        jppgpu_ctx_destroy(ctx);
+        return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (column storages)");
+      }
+      rt_h2d(ctx->mb->field_blobs[q].p, fs.data, (size_t)fs.bytes, nullptr);
+      dynSpec->storages[q].data = ctx->mb->field_blobs[q].as<u8>();
+      dynSpec->storages[q].bytes = fs.bytes;
+      dynSpec->storages[q].kind = (u32)fs.kind;
+      dynSpec->storages[q].align = fs.align_power;
+    }
     if (!ctx->mb->dyn_spec.ensure(sizeof(DevSpec))) {
       jppgpu_ctx_destroy(ctx);
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (feature tables)");

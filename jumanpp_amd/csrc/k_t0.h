@@ -372,6 +372,7 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
   u64 nb = B.node_base[s];
   const u32* cps = B.cp_code + g0;
   const i32* cls = B.cp_class + g0;
+  const u16* boffs = B.cp_boff + g0;
   const int nf = M.num_features;
   const float JPP_GLOBAL* W = as_global(M.weights);
 
@@ -421,6 +422,34 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
       if (kind == spec::SingleBit) return (col >> bsh) & 1u;
       if (kind == spec::Provided) return isUnk ? (u64)(u32)(a == 0 ? na.ph0 : na.ph1) : 0;
       if (kind == spec::SurfaceCodepointSize) return (u64)((i32)ni.end - (i32)ni.start);
+      if (kind == spec::ByteLength || kind == spec::CodepointSize) {
+        // PrimitiveFeatureContext::lengthOf (feature_impl_types.h:156-174): a negative column value is an UNK node's
+        // surface hash -> the BYTES of its surface, whichever of the two primitives asks (extra_nodes.h:89-93);
+        // otherwise the column's storage: int lists ("positions") their count, strings their byte length or codepoints
+        const i32 fp = (i32)col;
+        if (fp < 0) return (u64)((u32)boffs[ni.end] - (u32)boffs[ni.start]);
+        const DevSpec::Storage st = S.storages[bsh];
+        const u64 at = st.kind == 2 ? (u64)(u32)fp : (u64)(u32)fp << st.align;
+        if (at >= st.bytes) return ~u64{0};   // (cannot happen with a model the reference built)
+        const u8* p = st.data + at;
+        u32 len = 0;
+        int used = 0;
+        for (int sh = 0; sh < 35; sh += 7) {
+          const u32 b = p[used++];
+          len |= (b & 0x7fu) << sh;
+          if (b < 0x80u) break;
+        }
+        if (st.kind == 2 || kind == spec::ByteLength) return (u64)len;
+        // chars::numCodepoints (src/util/characters.cc:278-301): steps by the class of the lead byte; -1 when the last
+        // step overshoots the string
+        u32 q = 0, ncp = 0;
+        while (q < len && at + used + q < st.bytes) {
+          const u32 b = p[used + q];
+          q += b > 0xefu ? 4u : b > 0xdfu ? 3u : b > 0x7fu ? 2u : 1u;
+          ++ncp;
+        }
+        return q != len ? ~u64{0} : (u64)ncp;
+      }
       if (kind == spec::Codepoint) {
         if (a > 0) {
           const u32 pos = (u32)ni.end + (u32)(a - 1);

@@ -96,6 +96,9 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
     haveFormatTable_ = false;
     textMode_ = false;
   }
+  const std::vector<jppgpu_field_storage> storages = model->fieldStorages();
+  c.field_storages = storages.empty() ? nullptr : storages.data();
+  c.num_field_storages = (uint32_t)storages.size();
   c.t0_memo_image = memoImage_;
   c.t0_memo_image_bytes = memoImageBytes_;
   c.t0_memo_slots = memoImageSlots_;

@@ -483,8 +483,10 @@ int main(int argc, const char** argv) {
     std::cerr << "Model file was not specified\n";
     return 1;
   }
+  const Clock processClock;   // (--timing: where a process' life goes before and after the pipeline, `startup:` / `exit:` lines)
   ModelImage model;
   Status s = model.loadModel(conf.model);
+  const double tModelLoaded = processClock.ms();
   if (!s) {
     std::cerr << "failed to load model from disk: " << s << "\n";
     return 1;
@@ -752,6 +754,11 @@ int main(int argc, const char** argv) {
     }
   }
   if (conf.timing && useImageCache) std::cerr << std::string(cacheHit ? "image_cache=hit\n" : "image_cache=miss\n");
+  if (conf.timing) {
+    std::ostringstream ln;
+    ln << "startup: model_map_ms=" << tModelLoaded << " first_analyzers_ready_ms=" << processClock.ms() << "\n";
+    std::cerr << ln.str();
+  }
   Joiner cacheWriter;
   if (useImageCache && !cacheHit && analyzers[0][0]) {
     const void* memo = nullptr;
@@ -1185,6 +1192,9 @@ int main(int argc, const char** argv) {
             tot[3] = st[3];
           }
       std::cerr << "batches: one_enqueue=" << tot[0] << " rerun=" << tot[1] << " sized=" << tot[2] << " device_allocations=" << tot[3] << "\n";
+      std::ostringstream ln;
+      ln << "exit: process_ms_before_teardown=" << processClock.ms() << "\n";
+      std::cerr << ln.str();
     }
     return result;
   }

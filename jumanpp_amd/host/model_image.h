@@ -171,6 +171,31 @@ class ModelImage {
   const std::vector<TrainField>& trainFields() const { return trainFields_; }
   StringPiece intStorage(int32_t idx) const { return intStorages_[idx]; }
   StringPiece entryData() const { return StringPiece((const char*)model_.entry_data, model_.entry_data_bytes); }
+  // the value storages of the feature columns (jppgpu_config::field_storages: what a spec's length primitives read):
+  // string columns their string storage, string-list columns their int-list storage
+  std::vector<jppgpu_field_storage> fieldStorages() const {
+    std::vector<jppgpu_field_storage> out;
+    for (const DictionaryField& f : fields_) {
+      if (f.idxInEntry < 0) continue;
+      jppgpu_field_storage st;
+      st.column = f.idxInEntry;
+      st.align_power = f.alignPower;
+      st.reserved = 0;
+      if (f.columnType == FieldType::String && f.stringStorage >= 0 && (size_t)f.stringStorage < stringStorages_.size()) {
+        st.kind = 1;
+        st.data = stringStorages_[f.stringStorage].data();
+        st.bytes = stringStorages_[f.stringStorage].size();
+      } else if (f.columnType == FieldType::StringList && f.intStorage >= 0 && (size_t)f.intStorage < intStorages_.size()) {
+        st.kind = 2;
+        st.data = intStorages_[f.intStorage].data();
+        st.bytes = intStorages_[f.intStorage].size();
+      } else {
+        continue;
+      }
+      out.push_back(st);
+    }
+    return out;
+  }
 
   // JumandicIdResolver::dicToJuman (src/jumandic/shared/jumandic_id_resolver.cc:80-86), resolved at export time
   bool hasIdMap() const { return hasIdMap_; }

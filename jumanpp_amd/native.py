@@ -40,11 +40,20 @@ class Model(C.Structure):
                 ('rnn_num_fields', C.c_uint32), ('rnn_fields', C.c_uint32 * 8)]
 
 
+class FieldStorage(C.Structure):
+    """jppgpu_field_storage"""
+    _fields_ = [('column', C.c_int32), ('kind', C.c_int32), ('align_power', C.c_uint32), ('reserved', C.c_uint32),
+                ('data', C.c_void_p), ('bytes', C.c_uint64)]
+
+
 class Config(C.Structure):
     _fields_ = [('struct_size', C.c_uint32), ('beam', C.c_int32), ('global_beam', C.c_int32), ('right_check', C.c_int32),
                 ('right_beam', C.c_int32), ('max_input_bytes', C.c_int32), ('device', C.c_int32),
                 ('use_rnn', C.c_int32), ('weight_perceptron', C.c_float), ('weight_rnn', C.c_float),
-                ('dynamic_features', C.c_int32), ('num_host_scorers', C.c_int32), ('weight_host', C.c_float * 2)]
+                ('dynamic_features', C.c_int32), ('num_host_scorers', C.c_int32), ('weight_host', C.c_float * 2),
+                ('t0_memo_image', C.c_void_p), ('t0_memo_image_bytes', C.c_uint64), ('t0_memo_slots', C.c_uint32),
+                ('keep_t0_memo_image', C.c_int32),
+                ('field_storages', C.POINTER(FieldStorage)), ('num_field_storages', C.c_uint32), ('reserved1', C.c_uint32)]
 
 
 class ResultView(C.Structure):
@@ -293,7 +302,7 @@ class Context:
     def __init__(self, image_path, beam=5, global_beam=6, right_check=1, right_beam=5,
                  max_input_bytes=4096, device=0, lib_path=None, use_rnn=None,
                  weight_perceptron=None, weight_rnn=None, rnn_nce_bias=None, dynamic_features=False, max_unk_makers=None,
-                 host_scorer_weights=(), share_with=None):
+                 host_scorer_weights=(), share_with=None, _no_field_storages=False):
         """use_rnn=None: run the RNN scorer iff the model image has an RNN part (what
         JumanppEnv::loadModel does); the score weights default to the model's saved
         RnnInferenceConfig (env.cc:86-100)."""
@@ -369,6 +378,35 @@ class Context:
         cfg = Config(C.sizeof(Config), beam, global_beam, right_check, right_beam, max_input_bytes, device,
                      1 if use_rnn else 0, wp, wr, 1 if dynamic_features else 0, len(host_scorer_weights),
                      (C.c_float * 2)(*(list(host_scorer_weights) + [0.0, 0.0])[:2]))
+        # the value storages of the feature columns (what a spec's length primitives read): SEC_FIELDS (8) names, per
+        # column, its string storage (SEC_STRINGS, 9) or int-list storage (SEC_INTS, 10)
+        stor = []
+        if 8 in by:
+            fb = by[8][0][1]
+            (nfld,) = struct.unpack_from('<i', fb, 0)
+            pos = 4
+            strings = {a: p for a, p in by.get(9, [])}
+            ints = {a: p for a, p in by.get(10, [])}
+            for _ in range(nfld):
+                idx, _spec, ctype, sst, ist, align, _key = struct.unpack_from('<7i', fb, pos)
+                pos += 28
+                for _k in range(2):
+                    (ln,) = struct.unpack_from('<i', fb, pos)
+                    pos += 4 + ln
+                pos = (pos + 7) & ~7
+                if idx < 0:
+                    continue
+                if ctype == 0 and sst in strings:      # FieldType::String
+                    d, n = buf(strings[sst])
+                    stor.append(FieldStorage(idx, 1, align, 0, d, n))
+                elif ctype == 2 and ist in ints:       # FieldType::StringList
+                    d, n = buf(ints[ist])
+                    stor.append(FieldStorage(idx, 2, align, 0, d, n))
+        if stor and not _no_field_storages:
+            arr = (FieldStorage * len(stor))(*stor)
+            self._keep.append(arr)
+            cfg.field_storages = arr
+            cfg.num_field_storages = len(stor)
         h = C.c_void_p()
         if share_with is not None:   # the other context's copy of the model in HBM (jppgpu_ctx_create_shared)
             rc = self.lib.jppgpu_ctx_create_shared(share_with.handle, C.byref(cfg), C.byref(h))

@@ -27,11 +27,12 @@
 //   ref_dump ngrams  <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the trainer's read-out: NgramFeaturesComputer::calculateNgramFeatures for every connection of the top-1
 //       path on an analyzer that stores all patterns (what jppgpu_result_fetch_top1_ngrams must reproduce)
-//   ref_dump bootstrapv <dict.mdic> <out.jppmdl> <drop|add>
+//   ref_dump bootstrapv <dict.mdic> <out.jppmdl> <drop|add|len>
 //       jpp_jumandic_bootstrap with a VARIANT of the jumandic spec, so that the spec hash no longer matches the
 //       reference's generated static feature code and the reference runs its dynamic feature objects
 //       (features_api.cc:20-60): `drop` removes the last n-gram feature of the spec, `add` appends a unigram, a
-//       bigram and swaps two bigrams.  The checker of the table-driven kernels.
+//       bigram and swaps two bigrams, `len` adds a unigram over three LENGTH primitives (byte length / codepoints of dictionary
+//       strings, and of a column UNK makers overwrite).  The checker of the table-driven kernels.
 //   ref_dump top1    <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the packed top-1 result of Analyzer::analyze per sentence: u32 status (0 ok / 1 failed), u32 count, then count
 //       records {i32 EntryPtr raw, u16 start, u16 end} in text order (EOS dropped) -- the layout of jppgpu_result_pack.
@@ -726,6 +727,51 @@ int doBootstrapVariant(const char* mdic, const char* out, const char* variant) {
         else if (b < 0) b = i;
       }
     std::swap(ng[a], ng[b]);
+  } else if (v == "len") {
+    // LENGTH primitives: byte length of the baseform string, codepoints of the reading string, byte length
+    // of the surface (the column UNK makers overwrite with a hash: PrimitiveFeatureContext::lengthOf's UNK branch) --
+    // each a plain computed feature, all three in one new pattern that only a new unigram reads (it goes last: the
+    // trailing numUniOnlyPats patterns are the unigram-only ones, feature_impl_pattern.cc:39)
+    auto& F = spec.features;
+    auto dicIndexOf = [&](const char* name) -> i32 {
+      for (auto& f : spec.dictionary.fields)
+        if (f.name == name) return f.dicIndex;
+      std::cerr << "no dictionary field " << name << "\n";
+      std::exit(2);
+    };
+    const struct {
+      const char* name;
+      core::spec::PrimitiveFeatureKind kind;
+      const char* field;
+    } add[3] = {{"len_baseform_bytes", core::spec::PrimitiveFeatureKind::ByteLength, "baseform"},
+                {"len_reading_cps", core::spec::PrimitiveFeatureKind::CodepointSize, "reading"},
+                {"len_surface_bytes", core::spec::PrimitiveFeatureKind::ByteLength, "surface"}};
+    core::spec::PatternFeatureDescriptor pat;
+    pat.index = (i32)F.pattern.size();
+    pat.usage = 1;
+    for (auto& a : add) {
+      core::spec::PrimitiveFeatureDescriptor pd;
+      pd.index = (i32)F.primitive.size();
+      pd.name = a.name;
+      pd.kind = a.kind;
+      pd.references = {dicIndexOf(a.field)};
+      F.primitive.push_back(pd);
+      core::spec::ComputationFeatureDescriptor cd;
+      cd.name = a.name;
+      cd.index = (i32)F.computation.size();
+      cd.primitiveFeature = pd.index;
+      F.computation.push_back(cd);
+      pat.references.push_back(cd.index);
+    }
+    F.pattern.push_back(pat);
+    F.numUniOnlyPats += 1;
+    F.totalPrimitives = (i32)F.primitive.size();
+    i32 maxIdx = 0;
+    for (auto& f : ng) maxIdx = std::max(maxIdx, f.index);
+    core::spec::NgramFeatureDescriptor uni;
+    uni.index = maxIdx + 1;
+    uni.references = {pat.index};
+    ng.push_back(uni);
   } else {
     std::cerr << "unknown variant " << v << "\n";
     return 2;

@@ -250,10 +250,11 @@ def test_emulated_sentences_are_routed_to_sweep_variants_one_by_one(emu_lib, ref
     assert not errs, errs[:10]
 
 
-def _variant_spec_workload(ref_tools, tmp, variant, n_lines, beams=None, rnn=None, n_entries=2500, exp=14, length=30, seed=21):
+def _variant_spec_workload(ref_tools, tmp, variant, n_lines, beams=None, rnn=None, n_entries=2500, exp=14, length=30, seed=21, gold=True):
     """a model whose spec is NOT the built-in jumandic one (oracle/ref_dump.cc `bootstrapv`: the jumandic spec with its
     last n-gram feature dropped / with a unigram and a bigram added and two bigrams swapped): the reference's spec hash
     no longer matches its generated code and it runs its dynamic feature objects (features_api.cc:20-60)"""
+    os.makedirs(tmp, exist_ok=True)
     mdic = os.path.join(tmp, 'v.mdic')
     with open(mdic, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)], stdout=f)
@@ -277,9 +278,10 @@ def _variant_spec_workload(ref_tools, tmp, variant, n_lines, beams=None, rnn=Non
     with open(txt, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_corpus.py'), mdic, str(n_lines), '--seed', str(seed + 1),
                                '--oov', '0.08', '--len', str(length)], stdout=f)
-    with open(txt, 'rb') as f:
-        subprocess.check_call([rd, 'dump', os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.gold')] + [str(x) for x in (beams or [])],
-                              stdin=f, stderr=subprocess.DEVNULL)
+    if gold:
+        with open(txt, 'rb') as f:
+            subprocess.check_call([rd, 'dump', os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.gold')] + [str(x) for x in (beams or [])],
+                                  stdin=f, stderr=subprocess.DEVNULL)
     lines = [l.rstrip('\n') for l in open(txt, encoding='utf-8')]
     return os.path.join(tmp, 'v.img'), lines, os.path.join(tmp, 'v.gold')
 
@@ -1004,6 +1006,39 @@ def check_shared_model_contexts(emu_lib, golden_dir):
 
 def test_shared_model_contexts(emu_lib, golden_dir):
     check_shared_model_contexts(emu_lib, golden_dir)
+
+
+def check_length_primitives_spec(lib, ref_tools, tmp):
+    """SURVEY 8 f3, LENGTH primitives (ByteLength / CodepointSize, feature_impl_prim.h:114-156): `ref_dump bootstrapv len`
+    builds a jumandic variant with a unigram over three of them.  THE REFERENCE CANNOT ANALYSE WITH SUCH A SPEC: its
+    pattern pass over the EOS node sends the EOS entry pointer to ExtraNodesContext::lengthOf and segfaults on the first
+    sentence (profiles/r05_d_length_primitives.txt), so there are no goldens to compare scores with.  What is checked:
+    the model loads only when the column storages are handed in (jppgpu_config::field_storages), the analysis runs, the
+    lattice (which no feature influences) is the one of the same dictionary under the `drop` variant, and the T0 scores
+    differ from it exactly on nodes -- i.e. the new unigram is evaluated."""
+    img_len, lines, _ = _variant_spec_workload(ref_tools, os.path.join(tmp, 'len'), 'len', 30, gold=False)
+    img_drop, lines2, _ = _variant_spec_workload(ref_tools, os.path.join(tmp, 'drop'), 'drop', 30, gold=False)
+    assert lines == lines2
+    a = J.Context(img_len, lib_path=lib).analyze(lines).fetch(full=True)
+    b = J.Context(img_drop, lib_path=lib).analyze(lines).fetch(full=True)
+    assert list(a.status) == list(b.status) and int((a.status == 0).sum()) >= 25
+    assert np.array_equal(a.nnodes, b.nnodes) and np.array_equal(a.nodes['eptr'] >= 0, b.nodes['eptr'] >= 0)
+    assert np.array_equal(a.nodes['start'], b.nodes['start']) and np.array_equal(a.nodes['end'], b.nodes['end'])
+    assert not np.array_equal(a.t0, b.t0)
+    # without the storages the spec is refused, with the reason
+    import ctypes as C
+    ctx = J.Context.__new__(J.Context)
+    try:
+        J.Context.__init__(ctx, img_len, lib_path=lib, _no_field_storages=True)
+        assert False, 'a spec with length primitives was accepted without the column storages'
+    except J.JppGpuError as e:
+        assert 'value storage was not given' in str(e), str(e)
+
+
+def test_emulated_length_primitives_spec(emu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    check_length_primitives_spec(emu_lib, ref_tools, str(tmp_path))
 
 
 def check_one_enqueue_path(lib, golden_dir):

@@ -530,3 +530,11 @@ def test_gpu_wide_beam_rnn_long_sentences(gpu_lib, ref_tools, tmp_path):
         pytest.skip('oracle/_ref not built')
     import test_cpu_parity as tc
     tc.check_wide_beam_rnn_long_sentences(gpu_lib, ref_tools, str(tmp_path), n_lines=24, length=220)
+
+
+@pytest.mark.gpu
+def test_gpu_length_primitives_spec(gpu_lib, ref_tools, tmp_path):
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import test_cpu_parity as tc
+    tc.check_length_primitives_spec(gpu_lib, ref_tools, str(tmp_path))

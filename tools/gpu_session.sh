@@ -117,7 +117,7 @@ PY
     run)
       base="$(basename "$arg" | cut -d. -f1)"
       case "$arg" in
-        *.py) timeout 1200 python $arg > "$OUT/${TAG}_$base.txt" 2>&1 ;;
+        *.py|*.py\ *) timeout 1200 python $arg > "$OUT/${TAG}_$base.txt" 2>&1 ;;   # ("run=tools/x.py ARGS" quoted as one step)
         *) timeout 1200 bash $arg > "$OUT/${TAG}_$base.txt" 2>&1 ;;
       esac
       tail -30 "$OUT/${TAG}_$base.txt" ;;
