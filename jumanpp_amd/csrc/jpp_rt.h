@@ -268,6 +268,13 @@ __device__ __forceinline__ u32 uni(u32 v) {
 __device__ __forceinline__ int uni(int v) { return (int)uni((u32)v); }
 
 // broadcast lane `src` (wave-uniform) of v to every lane: v_readlane_b32
+__device__ __forceinline__ u32 wave_bcast_u32(u32 v, int src) {
+#if defined(JPP_EMU)
+  return wave_shfl_u32(v, src);
+#else
+  return (u32)__builtin_amdgcn_readlane((int)v, src);
+#endif
+}
 __device__ __forceinline__ float wave_bcast_f32(float v, int src) {
 #if defined(JPP_EMU)
   return wave_shfl_f32(v, src);

@@ -209,6 +209,14 @@ struct ClNodes {
 //   gn  = node_base[s] + k         node k of sentence s        (arrays sized total_nodes)
 // sentence-local node ids: 0 = BOS (boundary 0), 1 = BOS (boundary 1),
 // 2.. = lattice nodes ordered by (start, seed order), last = EOS.
+// one rnn node in hidden-state row order (rows of a sentence: 0 parking, 1 BOS state, then the rnn nodes in boundary order)
+struct RnnRec {
+  u32 q;         // handle: boundary * G + index within the boundary
+  i32 id;        // word id (RnnIdContainer::resolveId)
+  u32 prevrow;   // row of the predecessor (0 for BOS / the parking row)
+  u32 len;       // codepoints of the node (unkLengthPenalty)
+};
+
 // gstats[kGstatOverflow]: the batch did not fit the capacity it was enqueued against (k_lattice.h: k_cap_guard)
 constexpr int kGstatOverflow = 8;
 
@@ -265,6 +273,9 @@ struct Batch {
   u32* rnn_offs;           // [kRnnOrderBins] next free slot of every length class
   u32* rnn_hist;           // [kRnnOrderBins] sentences per length class (all zero between batches)
   u32* rnn_slow;           // [2] first slot and number of the sentences of the last class (not staged in LDS)
+  RnnRec* rnn_rec;         // [row] the rnn node of every hidden-state row (k_rnn_dense): what the recurrence and the
+                           // scoring of a sentence of ANY length read, 64 records per load
+  float* rnn_rscore;       // [row] RNN score of the row's rnn node (k_rnn_score_long)
   float* rnn_ctx;          // [row][EP] hidden states: row rnn_rowbase[s] + rnn_noff[b] + idx holds rnn node idx of boundary b
                            //   (per sentence: row 0 parking, row 1 the BOS state, then its rnn nodes in boundary order)
   u32* rnn_noff;           // [bb] first row of the boundary's rnn nodes within the sentence's rows (k_rnn_prep)

@@ -476,7 +476,7 @@ struct jppgpu_ctx {
   UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
   bool dynamic_spec = false;   // a spec other than the built-in jumandic tables: table-driven kernels
   bool builtin_spec = false;   // the spec equals the compiled-in tables (k_path_ngrams reads them), also when dynamic_spec is forced
-  DevBuf rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
+  DevBuf rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_rec, rnn_rscore, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
@@ -1289,7 +1289,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
                     &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
-                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
+                    &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_rec, &ctx->rnn_rscore, &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
                     &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
@@ -1383,7 +1383,10 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
   ok = ok && ctx->end_nodes.ensure(nodes * 4) && ctx->node_entry.ensure(nodes * spec::kNumDicFeatures * 4) &&
        ctx->node_pat.ensure(nodes * kPat * 8) && ctx->node_t0.ensure(nodes * 4) && ctx->node_beam.ensure(nodes * beam * sizeof(BeamSlot)) &&
        ctx->node_cells.ensure(nodes * G * 4 * ctx->cfg.nscorers) && ctx->node_kept.ensure(nodes) && ctx->path_nodes.ensure(nodes * 4);
-  if (ctx->use_rnn) ok = ok && ctx->rnn_ctx.ensure((nodes / 4 + 2 * (u64)n + 8) * (size_t)ctx->hmodel.rnn_EP * 4);
+  if (ctx->use_rnn) {
+    const u64 rows = nodes / 4 + 2 * (u64)n + 8;
+    ok = ok && ctx->rnn_ctx.ensure(rows * (size_t)ctx->hmodel.rnn_EP * 4) && ctx->rnn_rec.ensure(rows * sizeof(RnnRec)) && ctx->rnn_rscore.ensure(rows * 4);
+  }
   if (ok && ctx->cfg.gbeam != 0) {
     // 64 slices of the wide-lattice variant, 2 048 right nodes each
     const u64 rc = ctx->cfg.rcheck > 0 ? (u64)ctx->cfg.rcheck : 1;
@@ -1528,6 +1531,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_slow = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins : nullptr;
   B.rnn_key = B.rnn_hist ? B.rnn_hist + 2 * kRnnOrderBins + 2 : nullptr;
   B.rnn_ctx = ctx->rnn_ctx.as<float>();   // (sized after k_rnn_prep, once the number of rnn nodes is known)
+  B.rnn_rec = ctx->rnn_rec.as<RnnRec>();
+  B.rnn_rscore = ctx->rnn_rscore.as<float>();
   B.rnn_noff = ctx->rnn_noff.as<u32>();
   B.rnn_rows = ctx->rnn_rows.as<u32>();
   B.rnn_rowbase = ctx->rnn_rowbase.as<u64>();
@@ -2012,7 +2017,11 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(5, st);
   if (ctx->use_rnn) {
     JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
-    JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
+    JPP_LAUNCH(k_rnn_prep<false>, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
+               (const DevModel*)ctx->mb->dmodel, ctx->cfg);
+    // (the sentences beyond the LDS bookkeeping of the first launch -- (codepoints + 3) x global beam > 288: any batch
+    // may hold one, and a workgroup that finds none of its own leaves at once)
+    JPP_LAUNCH(k_rnn_prep<true>, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
                (const DevModel*)ctx->mb->dmodel, ctx->cfg);
     // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
@@ -2024,8 +2033,9 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     launch_scan(ctx, st, (const u32*)B.rnn_rows, B.rnn_rowbase, n, (const u64*)nullptr);
     u64 rnnRows = 0;
     if (spec) {
-      JPP_LAUNCH(k_cap_guard, sblocks, 256, st, B, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr,
-                 (u64)(ctx->rnn_ctx.cap / ((size_t)ctx->hmodel.rnn_EP * 4)));
+      const u64 rowsCap = std::min<u64>(ctx->rnn_ctx.cap / ((size_t)ctx->hmodel.rnn_EP * 4),
+                                        std::min<u64>(ctx->rnn_rec.cap / sizeof(RnnRec), ctx->rnn_rscore.cap / 4));
+      JPP_LAUNCH(k_cap_guard, sblocks, 256, st, B, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr, rowsCap);
     } else {
       if (ctx->mail_host) JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.rnn_rowbase + n), (const u64*)nullptr, (const u32*)nullptr, ctx->mail_dev + 12);
       else rt_d2h(&rnnRows, B.rnn_rowbase + n, 8, st);
@@ -2045,27 +2055,33 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       ctx->rnn_sync.wait(st);
       if (ctx->mail_host) rnnRows = ctx->mail_host[12];
       ctx->last_rnn_rows = rnnRows;
-      if (!ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4))
+      if (!(ctx->rnn_ctx.ensure((rnnRows + 8) * (size_t)ctx->hmodel.rnn_EP * 4) && ctx->rnn_rec.ensure((rnnRows + 8) * sizeof(RnnRec)) &&
+            ctx->rnn_rscore.ensure((rnnRows + 8) * 4)))
         return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (RNN hidden states)");
     }
     B.rnn_ctx = ctx->rnn_ctx.as<float>();
-    const u32 slowGrid = (n + 15) / 16 < 512u ? (n + 15) / 16 : 512u;   // k_rnn_score<.., 3> (16 sentences per workgroup) loops over its list
+    B.rnn_rec = ctx->rnn_rec.as<RnnRec>();
+    B.rnn_rscore = ctx->rnn_rscore.as<float>();
+    // the rnn nodes in row order: what the recurrence and the scoring of long sentences read (E <= 128)
+    if (ctx->hmodel.rnn_EP <= 128)
+      JPP_LAUNCH(k_rnn_dense, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B, ctx->cfg);
+    const u32 slowGrid = (n + 3) / 4 < 4096u ? (n + 3) / 4 : 4096u;   // k_rnn_score_long (4 sentences per workgroup) loops over its list
     if (ctx->hmodel.rnn_EP == 64) {
       T.mark(13, st);
       JPP_LAUNCH((k_rnn_chain<1>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
       T.mark(14, st);
       if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<1, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      if (sortE) JPP_LAUNCH((k_rnn_score<1, true, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<1, false, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score_long<1, true>), slowGrid, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score_long<1, false>), slowGrid, 256, st, B, dm, ctx->cfg);
     } else if (ctx->hmodel.rnn_EP == 128) {
       T.mark(13, st);
       JPP_LAUNCH((k_rnn_chain<2>), (n + 31) / 32, 1024, st, B, dm, ctx->cfg);
       T.mark(14, st);
       if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<2, false, 2>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
-      if (sortE) JPP_LAUNCH((k_rnn_score<2, true, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
-      else JPP_LAUNCH((k_rnn_score<2, false, 3>), slowGrid, 1024, st, B, dm, ctx->cfg);
+      if (sortE) JPP_LAUNCH((k_rnn_score_long<2, true>), slowGrid, 256, st, B, dm, ctx->cfg);
+      else JPP_LAUNCH((k_rnn_score_long<2, false>), slowGrid, 256, st, B, dm, ctx->cfg);
     } else {
       if (sortE) JPP_LAUNCH((k_rnn_score<4, true, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);
       else JPP_LAUNCH((k_rnn_score<4, false, 0>), (n + 3) / 4, 256, st, B, dm, ctx->cfg);

@@ -157,6 +157,10 @@ __global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
   }
 }
 
+// LONG = false: the sentences whose bookkeeping fits the LDS arrays; LONG = true: the others, built in place in the HBM
+// arrays -- a launch of its own without the LDS arrays (40 KB per workgroup held the kernel at 4 wavefronts per SIMD;
+// the long variant is a chain of dependent L2 round trips that only more wavefronts hide: 64 VGPRs, 8 per SIMD).
+template <bool LONG>
 __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
@@ -165,24 +169,32 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   if (s >= B.n_sent) return;
   // hidden-state rows of the sentence (rnn_rows, scanned into rnn_rowbase): every sentence owns at least its
   // parking row, sentences with an RNN lattice get parking + BOS + one row per rnn node (end of this kernel)
-  if (lane == 0) B.rnn_rows[s] = 1;
-  if (B.sent_status[s] != ST_OK) return;
+  constexpr u32 kCap = LONG ? 1 : 288, kCapB = LONG ? 1 : 48;
+  constexpr u32 kFitCap = 288, kFitCapB = 48;
+  bool live = B.sent_status[s] == ST_OK;
   const u32 off = B.byte_off[s];
   const u32 bb0 = off + 4 * s;
-  const u32 n = B.sent_ncp[s];
-  if (n == 0) return;
+  const u32 n = live ? B.sent_ncp[s] : 0u;
+  const u32 bE = n + 2;
+  const int G = cfg.gbeam;
+  const int ngb = n != 0 ? (int)B.bnd_ngb[bb0 + bE] : 0;
+  live = live && n != 0 && ngb != 0;
+  if (!live) {
+    if (!LONG && lane == 0) B.rnn_rows[s] = 1;   // (the LONG launch leaves the sentences it does not own alone)
+    return;
+  }
+  const u32 nq = (bE + 1) * (u32)G;
+  const bool fits = nq <= kFitCap && (bE + 1) <= kFitCapB;
+  if (fits == LONG) return;   // the other variant's sentence
   const u32 N = B.sent_nodes[s];
   const u64 nb = B.node_base[s];
   const int beam = cfg.beam;
-  const int G = cfg.gbeam;
-  const u32 bE = n + 2;
-  const int ngb = (int)B.bnd_ngb[bb0 + bE];
-  if (ngb == 0) return;
   const BeamSlot* beams = B.node_beam + nb * beam;
   const u32* en = B.end_nodes + nb;
+  (void)beams;
+  (void)en;
   // per (boundary, path) and per (boundary, rnn node) bookkeeping: built in LDS for ordinary
   // sentences and copied out at the end, built in place in the HBM arrays for very long ones
-  constexpr u32 kCap = 288, kCapB = 48;
   __shared__ u32 l_conn_all[kRnnPrepWaves][kCap];
   __shared__ i32 l_wid_all[kRnnPrepWaves][kCap];
   __shared__ u32 l_assign_all[kRnnPrepWaves][kCap];
@@ -192,8 +204,7 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   __shared__ u32 l_len_all[kRnnPrepWaves][kCap];
   __shared__ u32 l_cnt_all[kRnnPrepWaves][kCapB];
   __shared__ u16 l_clen_all[kRnnPrepWaves][kCap];   // codepoints of every connection's lattice node
-  const u32 nq = (bE + 1) * (u32)G;
-  const bool inLds = nq <= kCap && (bE + 1) <= kCapB;
+  constexpr bool inLds = !LONG;
   u32* g_conn = B.rnn_conn + (u64)bb0 * G;
   u32* g_assign = B.rnn_assign + (u64)bb0 * G;
   u32* g_prev = B.rnn_prev + (u64)bb0 * G;
@@ -415,6 +426,51 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
       carry += wave_shfl_u32(incl, 63);
     }
     if (lane == 0) B.rnn_rows[s] = carry;
+  }
+}
+
+// The rnn nodes of a sentence in hidden-state row order (round 5): one 16-byte record per row -- handle, word id, row of
+// the predecessor, length.  The recurrence (k_rnn_chain) and the scoring of long sentences (k_rnn_score_long) read the
+// rnn lattice from here, 64 records per load, instead of staging per-(boundary, index) arrays in LDS: a sentence of any
+// length and any beam takes the lock-step matrix-core recurrence (until round 4: at most 288 (boundary, path) slots;
+// everything longer ran boundary by boundary in k_rnn_score<.., 3>, a dependent L2 round trip per step).  Launched
+// behind the scan of the row counts (the records live at rnn_rowbase[s] + row).
+__global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_dense(Batch B, Config cfg) {
+  const int wv = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  const u32 s = blockIdx.x * kRnnPrepWaves + wv;
+  if (s >= B.n_sent) return;
+  if (B.gstats[kGstatOverflow] != 0) return;   // (a batch beyond its capacity: the row bases lie outside the table)
+  RnnRec* recs = B.rnn_rec + B.rnn_rowbase[s];
+  if (lane == 0) recs[0] = RnnRec{0, 0, 0, 0};
+  if (B.sent_status[s] != ST_OK) return;
+  const u32 n = B.sent_ncp[s];
+  if (n == 0) return;
+  const u32 bb0 = B.byte_off[s] + 4 * s;
+  const u32 bE = n + 2;
+  if (B.bnd_ngb[bb0 + bE] == 0) return;
+  const u32 G = (u32)cfg.gbeam;
+  const u32 nq = (bE + 1) * G;
+  const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
+  const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
+  const u32* rn_len = B.rnn_nlen + (u64)bb0 * G;
+  const u32* rn_cnt = B.rnn_cnt + bb0;
+  const u32* noff = B.rnn_noff + bb0;
+  if (lane == 0) recs[1] = RnnRec{G, 0, 0, 0};   // BOS (boundary 1, index 0)
+  for (u32 b0 = 2; b0 <= bE; b0 += 64) {
+    const u32 b = b0 + (u32)lane;
+    if (b > bE) continue;
+    const u32 cnt = rn_cnt[b], base = noff[b];
+    for (u32 idx = 0; idx < cnt; ++idx) {
+      const u32 q = b * G + idx;
+      const u32 hp = rn_prev[q];
+      u32 prow = 0;
+      if (hp < nq) {
+        const u32 pb = hp / G;
+        prow = noff[pb] + (hp - pb * G);
+      }
+      recs[base + idx] = RnnRec{q, rn_id[q], prow, rn_len[q]};
+    }
   }
 }
 
@@ -667,9 +723,6 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
   const int wv = (int)(threadIdx.x >> 6);
   const int lane = (int)(threadIdx.x & 63);
   __shared__ u64 s_exptab[kExp2fN];
-  __shared__ u16 l_prev_all[NG][kWaves][kRnnStageCap];
-  __shared__ i32 l_id_all[NG][kWaves][kRnnStageCap];
-  __shared__ u16 l_node_all[NG][kWaves][kRnnNodeCap];   // rnn nodes (boundary * G + index) in boundary order
   __shared__ __attribute__((aligned(16))) float s_B[NG][EP * 16];
   __shared__ __attribute__((aligned(16))) float s_out[NG][16 * kOutStride];
   __shared__ u32 s_rounds;
@@ -686,9 +739,17 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
   const u32 E = M.rnn_E;
   const float JPP_GLOBAL* __restrict__ embT = as_global(M.rnn_emb);
 
-  // ---- per sentence: stage predecessor handles and word ids, BOS state, node list ----
+  // ---- per sentence: BOS state, length of the chain, the rnn-node records (k_rnn_dense) ----
+  // Round r of a sentence makes the context of row 2 + r (rows are in boundary order: a predecessor's row is always
+  // lower).  The records of 64 rounds sit in one register per field, lane i holding row 2 + recBase + i, reloaded every
+  // 64 rounds.  Every wavefront issues the same loads at the same rounds (the rounds are the workgroup's), sentences
+  // without a chain read their parking row.
   u32 nchain[NG];
   float* rn_ctx[NG];
+  const RnnRec* recs[NG];
+  u32 recBase[NG];
+  u32 curPrev[NG];
+  i32 curId[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const u32 slot = (blockIdx.x * NG + (u32)g) * kWaves + (u32)wv;
@@ -700,22 +761,11 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
     own = own && n != 0 && B.bnd_ngb[bb0 + bE] != 0;
     // (not own: some sentence's row 0 serves as the parking row; a batch that overflowed its capacity -- every sentence
     // failed by k_cap_guard, the row bases beyond the table -- parks in the table's first row)
-    rn_ctx[g] = B.rnn_ctx + (B.gstats[kGstatOverflow] != 0 ? u64{0} : B.rnn_rowbase[s]) * (u64)EP;
+    const u64 rowBase = B.gstats[kGstatOverflow] != 0 ? u64{0} : B.rnn_rowbase[s];
+    rn_ctx[g] = B.rnn_ctx + rowBase * (u64)EP;
+    recs[g] = B.rnn_rec + rowBase;
     nchain[g] = 0;
-    const u32 nq = (bE + 1) * (u32)G;
-    const u32* rn_cnt = B.rnn_cnt + bb0;
-    if (own && rnn_stageable(bE, G, cfg.beam, B.sent_nodes[s])) {
-      const u32* rn_prev = B.rnn_prev + (u64)bb0 * G;
-      const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
-      // predecessors as hidden-state ROWS (rnn_noff): handle pb * G + pidx -> rnn_noff[pb] + pidx
-      const u32* rn_noff = B.rnn_noff + bb0;
-      const u32 invG = small_div_inv((u32)G);
-      for (u32 q = lane; q < nq; q += 64) {
-        const u32 hp = rn_prev[q];   // (a handle < nq for every rnn node; anything for the unused slots, the BOS node's "none")
-        const u32 pb = hp < nq ? small_div(hp, invG) : 0u;
-        l_prev_all[g][wv][q] = hp < nq ? (u16)(rn_noff[pb] + (hp - pb * (u32)G)) : (u16)0;
-        l_id_all[g][wv][q] = rn_id[q];
-      }
+    if (own) {
       // BOS state: sigmoid(W^T 0 + emb[0])  (GbeamRnnFactoryState::computeBosState)
 #pragma unroll
       for (int j = 0; j < J; ++j) {
@@ -727,13 +777,14 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
         }
         rn_ctx[g][(u64)1 * EP + i] = v;   // row 1
       }
-      // lane b lists the rnn nodes of boundary b at the offset an exclusive scan gives it
-      const u32 bq = (u32)lane;
-      const u32 cnt = (bq >= 2 && bq <= bE) ? rn_cnt[bq] : 0u;
-      const u32 incl = wave_scan_incl_u32(cnt, lane);
-      u32 nn = incl - cnt;
-      for (u32 i = 0; i < cnt; ++i) l_node_all[g][wv][nn++] = (u16)(bq * (u32)G + i);
-      nchain[g] = wave_shfl_u32(incl - cnt, (int)bE);   // nodes before the EOS boundary
+      nchain[g] = B.rnn_noff[bb0 + bE] - 2;   // rnn nodes before the EOS boundary (the EOS nodes are only scored)
+    }
+    recBase[g] = 0;
+    {
+      const u32 r0 = (u32)lane;
+      const RnnRec a = recs[g][r0 < nchain[g] ? 2 + r0 : 0];
+      curPrev[g] = a.prevrow;
+      curId[g] = a.id;
     }
   }
   wave_sync();
@@ -771,12 +822,22 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
   auto fetch = [&](int g, u32 r) {
     u32 eid = 0;
     q1[g] = hnd1[g] = 0;   // (rows: the node of round r is row 2 + r, hnd1 the row of its predecessor; row 0 parks)
-    if (r < nchain[g]) {
-      const u32 qh = l_node_all[g][wv][r];
-      q1[g] = 2 + r;
-      hnd1[g] = l_prev_all[g][wv][qh];
-      const i32 id = l_id_all[g][wv][qh];
-      eid = id == -1 ? 0u : (u32)id;
+    if (r >= recBase[g] + 64u) {   // (wave- and workgroup-uniform: r is the workgroup's round; one wait per 64 rounds)
+      recBase[g] += 64u;
+      const u32 rn = recBase[g] + (u32)lane;
+      const RnnRec c = recs[g][rn < nchain[g] ? 2 + rn : 0];
+      curPrev[g] = c.prevrow;
+      curId[g] = c.id;
+    }
+    {
+      const int src = (int)(r - recBase[g]);
+      const u32 pr = wave_bcast_u32(curPrev[g], src);
+      const i32 id = (i32)wave_bcast_u32((u32)curId[g], src);
+      if (r < nchain[g]) {
+        q1[g] = 2 + r;
+        hnd1[g] = pr;
+        eid = id == -1 ? 0u : (u32)id;
+      }
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) c1[g][j] = rn_ctx[g][(u64)hnd1[g] * EP + (u32)lane + 64u * j];   // (stale while that row is being made: then lastY is used)
@@ -857,6 +918,64 @@ __global__ void __launch_bounds__(1024) k_rnn_chain(Batch B, const DevModel* __r
     lds_barrier();
   }
   finish(1);
+}
+
+// ScoreProcessor::remakeEosBeam (score_processor.cc:548-576): the EOS beam from the adjusted totals of the EOS paths
+// (full[p] = weighted local score + total of the path's previous element, prev_total[p] = the latter), one wavefront.
+// makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16 -- both only permute, so with
+// pairwise distinct totals the stable rank is their result; the step-by-step replay runs when two candidates tie exactly.
+template <bool SORT>
+__device__ __forceinline__ void rnn_remake_eos(const Batch& B, BeamSlot* beams, const u32* en, u32 efirstE, u32 bb0, u32 bE, u32 N,
+                                               int G, int beam, int ngb, const float* full, const float* prev_total, int lane) {
+    BeamSlot* row = beams + (u64)(N - 1) * beam;
+    const int partB = beam * 4 / 3;
+    // makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16.  Both only
+    // permute, so with pairwise distinct totals the stable rank below is their result (see k_sweep 5c); the
+    // step-by-step replay runs only when two candidates tie exactly.
+    bool replay = false;
+    if (SORT && (ngb > 16 || ngb > partB)) {
+      bool tie = false;
+      if (lane < ngb) {
+        const float me = full[lane];
+        for (int j = 0; j < ngb; ++j) tie = tie || (j != lane && full[j] == me);
+      }
+      replay = wave_ballot(tie) != 0;
+    }
+    if (replay) {
+      if (lane == 0) {
+        u8 idx[kMaxGbeam];
+        for (int z = 0; z < ngb; ++z) idx[z] = (u8)z;
+        auto comp = [full](u8 a, u8 bb) { return full[a] > full[bb]; };
+        u8* itr = idx + ngb;
+        if (ngb > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
+        std_sort(idx, itr, comp);
+        const int have = (int)(itr - idx);
+        for (int z = 0; z < beam; ++z) {
+          if (z < have) {
+            GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + idx[z]];
+            row[z] = BeamSlot{ge.left, ge.beam, full[idx[z]], en[efirstE + ge.left], (u32)idx[z]};
+          } else {
+            row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+          }
+        }
+      }
+      wave_sync();
+      if (lane < ngb) B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
+    } else if (lane < kMaxGbeam) {
+      if (lane < ngb) {
+        float me = full[lane];
+        int rank = 0;
+        for (int j = 0; j < ngb; ++j) {
+          float o = full[j];
+          if (o > me || (o == me && j < lane)) ++rank;
+        }
+        GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
+        if (rank < beam) row[rank] = BeamSlot{ge.left, ge.beam, me, en[efirstE + ge.left], (u32)lane};
+        B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
+      } else if (lane < beam) {
+        row[lane] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+      }
+    }
 }
 
 // SORT: compile the makeT0Beam replay for remakeEosBeam (needed beyond 16 candidates / beam*4/3 only)
@@ -1342,62 +1461,135 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
     prev_total[lane] = prevT;
   }
   wave_sync();
-  {
-    BeamSlot* row = beams + (u64)(N - 1) * beam;
-    const int partB = beam * 4 / 3;
-    // makeT0Beam on the EOS candidates: util::partition beyond beam*4/3, introsort beyond 16.  Both only
-    // permute, so with pairwise distinct totals the stable rank below is their result (see k_sweep 5c); the
-    // step-by-step replay runs only when two candidates tie exactly.
-    bool replay = false;
-    if (SORT && (ngb > 16 || ngb > partB)) {
-      bool tie = false;
-      if (lane < ngb) {
-        const float me = full[lane];
-        for (int j = 0; j < ngb; ++j) tie = tie || (j != lane && full[j] == me);
-      }
-      replay = wave_ballot(tie) != 0;
-    }
-    if (replay) {
-      if (lane == 0) {
-        u8 idx[kMaxGbeam];
-        for (int z = 0; z < ngb; ++z) idx[z] = (u8)z;
-        auto comp = [full](u8 a, u8 bb) { return full[a] > full[bb]; };
-        u8* itr = idx + ngb;
-        if (ngb > partB) itr = jpp_partition(idx, itr, comp, (long)beam, (long)partB);
-        std_sort(idx, itr, comp);
-        const int have = (int)(itr - idx);
-        for (int z = 0; z < beam; ++z) {
-          if (z < have) {
-            GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + idx[z]];
-            row[z] = BeamSlot{ge.left, ge.beam, full[idx[z]], en[efirstE + ge.left], (u32)idx[z]};
-          } else {
-            row[z] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
-          }
-        }
-      }
-      wave_sync();
-      if (lane < ngb) B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
-    } else if (lane < kMaxGbeam) {
-      if (lane < ngb) {
-        float me = full[lane];
-        int rank = 0;
-        for (int j = 0; j < ngb; ++j) {
-          float o = full[j];
-          if (o > me || (o == me && j < lane)) ++rank;
-        }
-        GbeamEntry ge = B.bnd_gbeam[(u64)(bb0 + bE) * G + lane];
-        if (rank < beam) row[rank] = BeamSlot{ge.left, ge.beam, me, en[efirstE + ge.left], (u32)lane};
-        B.bnd_gbeam[(u64)(bb0 + bE) * G + lane].score = prev_total[lane];
-      } else if (lane < beam) {
-        row[lane] = BeamSlot{kFake16, kFake16, 0.f, 0xffffffffu, 0};
-      }
-    }
-  }
+  rnn_remake_eos<SORT>(B, beams, en, efirstE, bb0, bE, N, G, beam, ngb, full, prev_total, lane);
   JPP_RPROF(5);
   JPP_RPROF_FLUSH;
   wave_sync();
   slot += gridDim.x * kWaves;
   } while (MODE == 3 && slot < nslow);
+}
+
+// Scores, score cells, adjustBeamScores and remakeEosBeam of the sentences beyond k_rnn_score<.., 2>'s LDS staging
+// (long sentences, wide global beams), after k_rnn_chain has left every hidden state in HBM (round 5; until then such a
+// sentence ran k_rnn_score<.., 3>: recurrence and scores boundary by boundary, ~17 us of dependent round trips per
+// boundary -- 7.7 ms per batch of the configs[4] shape).  Same arithmetic as MODE 2, the rnn lattice read from the row
+// records (k_rnn_dense):
+//   per ROW (lane = row): maxent sum (w0 + w1 + ...), NCE dot product (rnn_dot_seq), - nceConstant; UNK: one fused
+//     multiply-add                                                        -> rnn_rscore[row]
+//   per (boundary, path) slot: the connection's score cell               <- rnn_rscore[noff[b] + assign]
+//   per path (lane = path): adjustBeamScores front to back, remakeEosBeam inputs
+// One wavefront per sentence, a fixed grid walking the last class of the chain-length order (the sentences that are
+// not staged).
+template <int J, bool SORT>
+__global__ void __launch_bounds__(256) k_rnn_score_long(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
+  constexpr int kWaves = 4;
+  constexpr int EP = 64 * J;
+  const DevModel& M = *Mp;
+  const int wv = (int)(threadIdx.x >> 6);
+  const int lane = (int)(threadIdx.x & 63);
+  __shared__ float full_all[kWaves][kMaxGbeam];
+  __shared__ float prev_total_all[kWaves][kMaxGbeam];
+  float* full = full_all[wv];
+  float* prev_total = prev_total_all[wv];
+  if (B.gstats[kGstatOverflow] != 0) return;
+  u32 slot = blockIdx.x * kWaves + wv;
+  const u32 nslow = B.rnn_slow[1];
+  for (; slot < nslow; slot += gridDim.x * kWaves) {
+    const u32 s = B.rnn_order[B.rnn_slow[0] + slot];
+    if (s >= B.n_sent || B.sent_status[s] != ST_OK) continue;
+    const u32 n = B.sent_ncp[s];
+    if (n == 0) continue;
+    const u32 bb0 = B.byte_off[s] + 4 * s;
+    const u32 bE = n + 2;
+    const int ngb = (int)B.bnd_ngb[bb0 + bE];
+    if (ngb == 0) continue;
+    const u32 N = B.sent_nodes[s];
+    const u64 nb = B.node_base[s];
+    const int beam = cfg.beam, G = cfg.gbeam, S = cfg.nscorers;
+    const u32 E = M.rnn_E;
+    const float JPP_GLOBAL* __restrict__ nceT = as_global(M.rnn_nce);
+    const float JPP_GLOBAL* __restrict__ maxentT = as_global(M.rnn_maxent);
+    const u32 mxOrder = M.rnn_order;
+    const u64 hashMax = M.rnn_hash_max, hashMagic = M.rnn_hash_magic, mxBase = M.rnn_mx_base;
+    const u64 mxCoef[4] = {M.rnn_mx_coef[0], M.rnn_mx_coef[1], M.rnn_mx_coef[2], M.rnn_mx_coef[3]};
+    const float nceConst = M.rnn_nce_const, unkConst = M.rnn_unk_const, unkLen = M.rnn_unk_len;
+    const i32 unkId = M.rnn_unk_id;
+    BeamSlot* beams = B.node_beam + nb * beam;
+    const u32* en = B.end_nodes + nb;
+    const u32* conn = B.rnn_conn + (u64)bb0 * G;
+    const u32* assign = B.rnn_assign + (u64)bb0 * G;
+    const u32* g_gi = B.rnn_gi + (u64)bb0 * G;
+    const u32* noff = B.rnn_noff + bb0;
+    const u64 rowBase = B.rnn_rowbase[s];
+    const RnnRec* recs = B.rnn_rec + rowBase;
+    float* rsc = B.rnn_rscore + rowBase;
+    const float* rn_ctx = B.rnn_ctx + rowBase * (u64)EP;
+    const u32 rows = B.rnn_rows[s];
+    const u32 nq = (bE + 1) * (u32)G;
+    // ---- scores: one lane per row (rows 2 .. rows - 1 are the rnn nodes, the EOS boundary's included) ----
+    for (u32 j0 = 2; j0 < rows; j0 += 64) {
+      const u32 j = j0 + (u32)lane;
+      if (j < rows) {
+        const RnnRec rc = recs[j];
+        float score;
+        if (rc.id == unkId) {
+          score = __builtin_fmaf(unkLen, (float)rc.len, unkConst);
+        } else if (mxOrder == 0) {
+          score = 0.f - nceConst;  // MikolovScoreCalculator::addScores case 0 zero-fills the result
+        } else {
+          float mw[4] = {0.f, 0.f, 0.f, 0.f};
+          rnn_maxent_gather(maxentT, rc.id, recs[rc.prevrow].id, mxOrder, mxBase, mxCoef, hashMax, hashMagic, mw);
+          float me = mw[0];   // calcScoresN: w0 + w1 + ... left to right
+#pragma unroll
+          for (u32 i = 1; i < 4; ++i)
+            if (i < mxOrder) me += mw[i];
+          const u32 eid = rc.id == -1 ? 0u : (u32)rc.id;
+          score = rnn_dot_seq(nceT + (u64)eid * E, rn_ctx + (u64)rc.prevrow * EP, E);
+          score += me;
+          score -= nceConst;
+        }
+        rsc[j] = score;
+      }
+    }
+    wave_sync();   // (the scores are read by other lanes below: written and read by this wavefront only)
+#if !defined(JPP_EMU)
+    __threadfence_block();
+#endif
+    // ---- score cells of the connections (one lane per (boundary, path) slot) ----
+    for (u32 q = 2u * (u32)G + (u32)lane; q < nq; q += 64) {
+      const u32 c = conn[q];
+      if (c == kNoConn) continue;
+      const u32 b = q / (u32)G;
+      const u32 nd = c & 0x03ffffffu;
+      const u32 gi = g_gi[q] & 0xffffu;
+      B.node_cells[((nb + nd) * G + gi) * S + 1] = rsc[noff[b] + (assign[q] & 0xffffu)];
+    }
+    // ---- ScoreProcessor::adjustBeamScores along the EOS paths (lane = path), remakeEosBeam inputs ----
+    if (lane < ngb) {
+      float prevT = 0.f;   // BOS element total = 0
+      for (u32 b = 2; b <= bE; ++b) {
+        const u32 q = b * (u32)G + (u32)lane;
+        const u32 c = conn[q];
+        if (c == kNoConn) continue;
+        const u32 nd = c & 0x03ffffffu, k = c >> 26;
+        const u32 gi = g_gi[q] & 0xffffu;
+        const float rs = rsc[noff[b] + (assign[q] & 0xffffu)];
+        const float cell0 = B.node_cells[((nb + nd) * G + gi) * S];
+        const float local = weighted_score2(cell0, rs, cfg);
+        if (b < bE) {
+          const float tot = local + prevT;
+          beams[(u64)nd * beam + k].total = tot;
+          prevT = tot;
+        } else {
+          full[lane] = local + prevT;  // remakeEosBeam: fullScores[i] = localScore + beamScore
+          prev_total[lane] = prevT;
+        }
+      }
+    }
+    wave_sync();
+    rnn_remake_eos<SORT>(B, beams, en, B.end_first[bb0 + bE], bb0, bE, N, G, beam, ngb, full, prev_total, lane);
+    wave_sync();
+  }
 }
 
 }  // namespace jpp
