@@ -71,6 +71,7 @@ struct Conf {
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
+  bool cleanExit = false;      // --clean-exit: run every destructor at the end of a file-to-file run instead of leaving at once
   bool noImageCache = false;   // --no-image-cache: derive the T0 records and the format table afresh, write no cache
   bool noReserve = false;   // --no-reserve: the analyzers size their buffers batch by batch (round-4 behaviour)
   bool help = false;
@@ -409,6 +410,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (std::strcmp(argv[i], "--timing") == 0) conf.timing = true;
     else if (std::strcmp(argv[i], "--no-reserve") == 0) conf.noReserve = true;
     else if (std::strcmp(argv[i], "--no-image-cache") == 0) conf.noImageCache = true;
+    else if (std::strcmp(argv[i], "--clean-exit") == 0) conf.cleanExit = true;
     else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -474,7 +476,7 @@ int main(int argc, const char** argv) {
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
-                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache,\n"
+                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache, --clean-exit,\n"
                  "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format),\n"
                  "           --pipelines-per-device=2 (bulk runs: analysis threads, each with its analyzer pair, per GPU)\n";
     return 1;
@@ -1195,6 +1197,18 @@ int main(int argc, const char** argv) {
       std::ostringstream ln;
       ln << "exit: process_ms_before_teardown=" << processClock.ms() << "\n";
       std::cerr << ln.str();
+    }
+    // The output is written and closed.  Taking the process down object by object -- four contexts with ~10 GB of
+    // device buffers each, 1 GB of page-locked blocks, the mapped model -- costs 0.25 s of a 1.2 s run
+    // (profiles/r05d: 811 ms at this point, 1 190 ms for the parent); the operating system and the driver release all of
+    // it at process exit anyway.  --clean-exit runs the destructors (leak checkers).
+    if (!conf.cleanExit) {
+      if (prepin.t.joinable()) prepin.t.join();
+      if (cacheWriter.t.joinable()) cacheWriter.t.join();
+      std::cout.flush();
+      std::cerr.flush();
+      std::fflush(nullptr);
+      std::_Exit(result);
     }
     return result;
   }

@@ -1022,9 +1022,16 @@ def check_length_primitives_spec(lib, ref_tools, tmp):
     a = J.Context(img_len, lib_path=lib).analyze(lines).fetch(full=True)
     b = J.Context(img_drop, lib_path=lib).analyze(lines).fetch(full=True)
     assert list(a.status) == list(b.status) and int((a.status == 0).sum()) >= 25
-    assert np.array_equal(a.nnodes, b.nnodes) and np.array_equal(a.nodes['eptr'] >= 0, b.nodes['eptr'] >= 0)
-    assert np.array_equal(a.nodes['start'], b.nodes['start']) and np.array_equal(a.nodes['end'], b.nodes['end'])
-    assert not np.array_equal(a.t0, b.t0)
+    assert np.array_equal(a.nnodes, b.nnodes)
+    differ = 0
+    for s_ in range(len(lines)):   # (per sentence: the node tables have unwritten gaps between the sentences)
+        if a.status[s_] != 0:
+            continue
+        na, nb_, k = int(a.node_base[s_]), int(b.node_base[s_]), int(a.nnodes[s_])
+        xa, xb = a.nodes[na:na + k], b.nodes[nb_:nb_ + k]
+        assert np.array_equal(xa['eptr'], xb['eptr']) and np.array_equal(xa['start'], xb['start']) and np.array_equal(xa['end'], xb['end'])
+        differ += int((a.t0[na + 2:na + k] != b.t0[nb_ + 2:nb_ + k]).sum())
+    assert differ > 0
     # without the storages the spec is refused, with the reason
     import ctypes as C
     ctx = J.Context.__new__(J.Context)
