@@ -355,6 +355,11 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
     assign[q] = v << 24;
   }
   wave_sync();
+  // (Round 5 tried to shorten the LONG variant's dependent chain -- the slot's bytes requested a step ahead, the current
+  // node's prefix hash carried in a register, a boundary's first nodes read with its count: 6.8 -> 10.3-10.7 ms on the
+  // configs[4] shape, profiles/r05f / r05g.  The replay is not latency-bound but bound by the number of distinct cache
+  // lines a step touches: lane p works at boundary t - p, so every lane's accesses fall into a line of their own, and
+  // unconditional prefetches only add lines.  A skewed layout of the per-slot arrays ([b + p][p]) would coalesce them.)
   {
     const int p = lane;
     u32 cur = 1u * G;  // handle of the BOS node
@@ -1555,34 +1560,72 @@ __global__ void __launch_bounds__(256) k_rnn_score_long(Batch B, const DevModel*
 #if !defined(JPP_EMU)
     __threadfence_block();
 #endif
+    // Both loops below are chains of three dependent loads per step (connection -> its rnn node / cell index -> the
+    // score); four steps are loaded level by level -- unconditionally, from addresses that are always inside the
+    // sentence's arrays -- before any of them is used, so a round trip is paid once per four.
+    constexpr int kU = 4;
+    const u32 invG = small_div_inv((u32)G);   // (q < 2048 * ... does not hold here: plain division below for the boundary of a slot)
+    (void)invG;
     // ---- score cells of the connections (one lane per (boundary, path) slot) ----
-    for (u32 q = 2u * (u32)G + (u32)lane; q < nq; q += 64) {
-      const u32 c = conn[q];
-      if (c == kNoConn) continue;
-      const u32 b = q / (u32)G;
-      const u32 nd = c & 0x03ffffffu;
-      const u32 gi = g_gi[q] & 0xffffu;
-      B.node_cells[((nb + nd) * G + gi) * S + 1] = rsc[noff[b] + (assign[q] & 0xffffu)];
+    for (u32 q0 = 2u * (u32)G + (u32)lane; q0 < nq; q0 += 64u * kU) {
+      u32 c[kU], qq[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const u32 q = q0 + 64u * (u32)u;
+        qq[u] = q < nq ? q : (u32)lane;   // (slot `lane` of boundary 0 / 1: allocated, never a connection's)
+        c[u] = q < nq ? conn[q] : kNoConn;
+      }
+      u32 gi[kU], row[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        gi[u] = g_gi[qq[u]] & 0xffffu;
+        row[u] = noff[qq[u] / (u32)G] + (assign[qq[u]] & 0xffffu);
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (c[u] == kNoConn) continue;
+        const u32 nd = c[u] & 0x03ffffffu;
+        B.node_cells[((nb + nd) * G + gi[u]) * S + 1] = rsc[row[u]];
+      }
     }
     // ---- ScoreProcessor::adjustBeamScores along the EOS paths (lane = path), remakeEosBeam inputs ----
     if (lane < ngb) {
       float prevT = 0.f;   // BOS element total = 0
-      for (u32 b = 2; b <= bE; ++b) {
-        const u32 q = b * (u32)G + (u32)lane;
-        const u32 c = conn[q];
-        if (c == kNoConn) continue;
-        const u32 nd = c & 0x03ffffffu, k = c >> 26;
-        const u32 gi = g_gi[q] & 0xffffu;
-        const float rs = rsc[noff[b] + (assign[q] & 0xffffu)];
-        const float cell0 = B.node_cells[((nb + nd) * G + gi) * S];
-        const float local = weighted_score2(cell0, rs, cfg);
-        if (b < bE) {
-          const float tot = local + prevT;
-          beams[(u64)nd * beam + k].total = tot;
-          prevT = tot;
-        } else {
-          full[lane] = local + prevT;  // remakeEosBeam: fullScores[i] = localScore + beamScore
-          prev_total[lane] = prevT;
+      for (u32 b0 = 2; b0 <= bE; b0 += kU) {
+        u32 c[kU], qq[kU], bb[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          bb[u] = b0 + (u32)u;
+          qq[u] = (bb[u] <= bE ? bb[u] : bE) * (u32)G + (u32)lane;
+          c[u] = bb[u] <= bE ? conn[qq[u]] : kNoConn;
+        }
+        u32 gi[kU], row[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          gi[u] = g_gi[qq[u]] & 0xffffu;
+          row[u] = noff[bb[u] <= bE ? bb[u] : bE] + (assign[qq[u]] & 0xffffu);
+        }
+        float rs[kU], cell0[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const bool live = c[u] != kNoConn;
+          const u32 nd = live ? (c[u] & 0x03ffffffu) : 0u;
+          rs[u] = live ? rsc[row[u]] : 0.f;
+          cell0[u] = live ? B.node_cells[((nb + nd) * G + gi[u]) * S] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          if (c[u] == kNoConn) continue;
+          const u32 nd = c[u] & 0x03ffffffu, k = c[u] >> 26;
+          const float local = weighted_score2(cell0[u], rs[u], cfg);
+          if (bb[u] < bE) {
+            const float tot = local + prevT;
+            beams[(u64)nd * beam + k].total = tot;
+            prevT = tot;
+          } else {
+            full[lane] = local + prevT;  // remakeEosBeam: fullScores[i] = localScore + beamScore
+            prev_total[lane] = prevT;
+          }
         }
       }
     }
