@@ -1378,13 +1378,13 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
   bool ok = ensure_front(ctx, n, bytes) && ctx->text.ensure(bytes + 64) && ctx->offs.ensure((n + 1) * 4);
   if (ok && ctx->hmodel.norm_maker >= 0) ok = ensure_norm_scratch(ctx, ctx->own_stream);
   // (the node tables also hold the relocation area of the stage-2 sentences: k_layout's upper bound is twice the nodes)
-  const u64 seeds = 2 * nodes + nodes / 4;
+  const u64 seeds = 2 * nodes + nodes / 8;
   ok = ok && ctx->node_info.ensure(seeds * sizeof(NodeInfo)) && ctx->node_aux.ensure(seeds * sizeof(NodeAux));
   ok = ok && ctx->end_nodes.ensure(nodes * 4) && ctx->node_entry.ensure(nodes * spec::kNumDicFeatures * 4) &&
        ctx->node_pat.ensure(nodes * kPat * 8) && ctx->node_t0.ensure(nodes * 4) && ctx->node_beam.ensure(nodes * beam * sizeof(BeamSlot)) &&
        ctx->node_cells.ensure(nodes * G * 4 * ctx->cfg.nscorers) && ctx->node_kept.ensure(nodes) && ctx->path_nodes.ensure(nodes * 4);
   if (ctx->use_rnn) {
-    const u64 rows = nodes / 4 + 2 * (u64)n + 8;
+    const u64 rows = nodes / 6 + 2 * (u64)n + 8;   // (an rnn node per ~8 lattice nodes on 40-codepoint sentences, ~9 on long ones)
     ok = ok && ctx->rnn_ctx.ensure(rows * (size_t)ctx->hmodel.rnn_EP * 4) && ctx->rnn_rec.ensure(rows * sizeof(RnnRec)) && ctx->rnn_rscore.ensure(rows * 4);
   }
   if (ok && ctx->cfg.gbeam != 0) {
@@ -1628,7 +1628,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
       const u64 slots = ctx->sweep_scratch.cap / scratch_stride(ctx->spec_maxr_cap);
       specSlots = (u32)std::min<u64>(slots, 0x7fffffffu);
     }
-    JPP_LAUNCH(k_cls_guard, 1, 64, st, B, ctx->spec_grid1, ctx->spec_grid2, ctx->spec_maxr_cap, specSlots);
+    JPP_LAUNCH(k_cls_guard, 1, 64, st, B, std::min(ctx->spec_grid1, n), std::min(std::min(ctx->spec_grid2, specSlots), n), ctx->spec_maxr_cap, specSlots);
     JPP_LAUNCH(k_cap_guard, sblocks, 256, st, B, (const u64*)(B.node_base2 + n), (const u64*)nullptr, latCap);
   } else if (ctx->mail_host) {
     JPP_LAUNCH(k_mail, 1, 64, st, (const u64*)(B.node_base2 + n), (const u64*)nullptr, (const u32*)B.gstats, ctx->mail_dev);
@@ -1900,7 +1900,8 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   const bool narrow = ctx->cfg.gbeam <= 8 && ctx->cfg.beam <= 8 && ctx->cfg.gbeam <= ctx->cfg.beam * 4 / 3;
   // (spec: the GRIDS of the classes -- every sentence for class 0, what earlier batches suggest for the rare wide
   // classes; k_sweep leaves a workgroup beyond its class's list at once, k_cls_guard has checked that the lists fit)
-  const u32 nCls[3] = {spec ? n : gstats[1], spec ? ctx->spec_grid1 : gstats[2], spec ? std::min(ctx->spec_grid2, specSlots) : gstats[3]};
+  const u32 nCls[3] = {spec ? n : gstats[1], spec ? std::min(ctx->spec_grid1, n) : gstats[2],
+                       spec ? std::min(std::min(ctx->spec_grid2, specSlots), n) : gstats[3]};
   const u32* lists[3] = {B.sweep_list, B.sweep_list + n, B.sweep_list + 2 * (size_t)n};
   B.sweep_scratch = nullptr;
   B.sweep_scratch_stride = 0;
@@ -2105,8 +2106,10 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   if (!*overflowed) {
     // what the next one-enqueue batch launches the rare classes with: twice what this one held
-    ctx->spec_grid1 = std::max<u32>(64u, 2 * ctx->last_class_n[1]);
-    ctx->spec_grid2 = std::max<u32>(16u, 2 * ctx->last_class_n[2]);
+    // (and no less than three quarters of the last grid: a batch without wide sentences between two with many does not
+    // send the second one through the sized path)
+    ctx->spec_grid1 = std::max<u32>(std::max<u32>(64u, 2 * ctx->last_class_n[1]), ctx->spec_grid1 - ctx->spec_grid1 / 4);
+    ctx->spec_grid2 = std::max<u32>(std::max<u32>(16u, 2 * ctx->last_class_n[2]), ctx->spec_grid2 - ctx->spec_grid2 / 4);
   }
   return JPPGPU_OK;
   };

@@ -444,6 +444,11 @@ Status GpuAnalyzer::reserve(uint32_t maxSentences, uint64_t maxBytes, float text
   r.struct_size = (uint32_t)sizeof(r);
   r.max_sentences = maxSentences;
   r.max_total_bytes = maxBytes;
+  // lattice nodes per input byte to provide for: 2.1 on the 10^6-row bench dictionary, 2.2 on 220-codepoint sentences.
+  // Every GB reserved is a GB the driver has to hand out (and scrub after the previous process) before the first batch:
+  // 40 GB across four analyzers cost 2.4 s in a session where the same run with warm memory took 8 ms
+  // (profiles/r05h); a denser lattice only costs the second run of its first batch.
+  r.nodes_per_byte = 2.5f;
   r.text_bytes_per_byte = textMode_ ? textBytesPerByte : 0.f;
   r.text_host_blocks = textMode_ ? textBlocks : 0;
   int rc = jppgpu_ctx_reserve(ctx_, &r);

@@ -712,12 +712,12 @@ int main(int argc, const char** argv) {
       if (sampleBytes && (sampleLines == 0 || buf[sampleBytes - 1] != '\n')) ++sampleLines;
     }
     const double meanLine = sampleLines ? (double)sampleBytes / (double)sampleLines : 64.0;
-    planBatchBytes = std::min<uint64_t>((uint64_t)inputTotal + 64, (uint64_t)((double)conf.batch * meanLine * 1.25) + 65536);
+    planBatchBytes = std::min<uint64_t>((uint64_t)inputTotal + 64, (uint64_t)((double)conf.batch * meanLine * 1.15) + 65536);
     planBatchLines = (uint32_t)std::min<uint64_t>(conf.batch, (uint64_t)((double)inputTotal / std::max(1.0, meanLine - 1.0)) + 16);
     if (deviceText && formatTable.numRows() > 0) {
       planTextPerByte = (float)(1.1 * ((double)formatTable.blobBytes() / (double)formatTable.numRows()) / 5.5);
       const uint64_t textBytes = (uint64_t)((double)planBatchBytes * planTextPerByte) + 64 * (uint64_t)planBatchLines + 4096;
-      const size_t nBatches = (size_t)((double)inputTotal / std::max(1.0, (double)planBatchBytes / 1.25)) + 1;
+      const size_t nBatches = (size_t)((double)inputTotal / std::max(1.0, (double)planBatchBytes / 1.15)) + 1;
       // per pipeline: the block being filled, one queued, one being written
       const uint32_t blocks = (uint32_t)std::min<size_t>(nBatches, 3 * conf.devices.size());
       const int dev0 = conf.devices.empty() ? conf.device : conf.devices[0];
