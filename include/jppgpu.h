@@ -87,7 +87,8 @@ typedef struct {
   const void* feature_spec;    /* flattened FeaturesSpec descriptors (i32 lists: primitive, computed, pattern and n-gram
                                 * features in spec order).  Equal to the built-in jumandic tables: the compiled-in
                                 * kernels run (the reference's generated static code, features_api.cc:38-47); any
-                                * other spec within the device layout: the table-driven kernels with the summation
+                                * other spec within the device layout (entry rows of up to 16 columns, 2 placeholders):
+                                * the table-driven kernels with the summation
                                 * orders of the reference's dynamic feature objects; outside it: JPPGPU_NOT_IMPLEMENTED
                                 * with the reason in jppgpu_last_error() */
   size_t feature_spec_bytes;
@@ -215,7 +216,8 @@ typedef struct {
   uint64_t total_boundaries;
   int32_t beam, global_beam;
   int32_t num_scorers;
-  int32_t reserved0;
+  int32_t entry_row_stride;          /* columns per row of entry_rows: 8, or 16 for models with more than 8 feature columns
+                                      * (0 from the compact JPPGPU_FETCH_TOP1 view, which has no rows) */
   /* top-1 path: node ids from EOS back to the first morpheme, path_len[i] entries at node_base[i] */
   const uint32_t* path_len;
   const uint32_t* path_nodes;
@@ -227,7 +229,7 @@ typedef struct {
   const uint32_t* end_first;         /* offset into end_nodes (relative to node_base) */
   const uint32_t* end_count;         /* L_b */
   const uint32_t* end_nodes;         /* [total_nodes] */
-  const int32_t* entry_rows;         /* [total_nodes][num_features] */
+  const int32_t* entry_rows;         /* [total_nodes][entry_row_stride] */
   const uint64_t* patterns;          /* [total_nodes][14] */
   const float* t0_scores;            /* [total_nodes] */
   const jppgpu_beam_slot* beams;     /* [total_nodes][beam] */

@@ -254,7 +254,8 @@ struct Batch {
   u32* end_nodes;          // [gn] local node ids
   NodeInfo* node_info;     // [gn]
   NodeAux* node_aux;       // [gn]
-  i32* node_entry;         // [gn][8]
+  i32* node_entry;         // [gn][row_stride]: the entry row of the node (8 columns, 16 for models with more than 8 feature columns)
+  u32 row_stride;
   u64* node_pat;           // [gn][14]
   float* node_t0;          // [gn]
   BeamSlot* node_beam;     // [gn][beam]

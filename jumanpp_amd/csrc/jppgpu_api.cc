@@ -475,6 +475,7 @@ struct jppgpu_ctx {
   std::shared_ptr<ModelBufs> mb = std::make_shared<ModelBufs>();
   UnkRank unk_rank{};   // creation order of the UNK makers (k_ends numbers the UNK entry pointers with it)
   bool dynamic_spec = false;   // a spec other than the built-in jumandic tables: table-driven kernels
+  u32 row_stride = 8;          // columns of a node's entry row in node_entry: 8, or 16 for models with more than 8 feature columns
   bool builtin_spec = false;   // the spec equals the compiled-in tables (k_path_ngrams reads them), also when dynamic_spec is forced
   DevBuf rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_rec, rnn_rscore, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
@@ -989,9 +990,9 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   std::unique_ptr<DevSpec> dynSpec;
   std::vector<int> usedStorages;   // indices into c->field_storages of the storages the spec's length primitives read
   if (!builtinSpec || c->dynamic_features) {
-    if (m->num_features < 1 || m->num_features > spec::kNumDicFeatures || m->num_placeholders < 0 ||
+    if (m->num_features < 1 || m->num_features > kMaxDicFeatures || m->num_placeholders < 0 ||
         m->num_placeholders > spec::kNumPlaceholders)
-      return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: entry rows of more than 8 columns / more than 2 placeholders are not supported");
+      return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: entry rows of more than 16 columns (JPP_MAX_DIC_FIELDS) / more than 2 placeholders are not supported");
     if (!m->feature_spec || m->feature_spec_bytes < 16) return fail(JPPGPU_INVALID_PARAMETER, "model has no feature spec");
     dynSpec.reset(new DevSpec());
     const std::string why = parse_feature_spec(m->feature_spec, m->feature_spec_bytes, m->num_features, dynSpec.get(),
@@ -1060,6 +1061,7 @@ extern "C" int jppgpu_ctx_create(const jppgpu_model* m, const jppgpu_config* c_i
   H.entry_data_bytes = (u32)m->entry_data_bytes;
   H.wmask = (u32)((size_t{1} << m->weight_exponent) - 1);
   H.num_features = m->num_features;
+  ctx->row_stride = m->num_features <= 8 ? 8u : (u32)kMaxDicFeatures;
   // makers: [stage-1 except normalize][stage-2][normalize]
   std::vector<UnkMaker> st1, st2, norm;
   bool seenNorm = false;
@@ -1253,6 +1255,7 @@ extern "C" int jppgpu_ctx_create_shared(jppgpu_ctx* base, const jppgpu_config* c
   ctx->unk_rank = base->unk_rank;
   ctx->dynamic_spec = base->dynamic_spec;
   ctx->builtin_spec = base->builtin_spec;
+  ctx->row_stride = base->row_stride;
   finish_context(ctx);
   *out = ctx;
   return JPPGPU_OK;
@@ -1380,7 +1383,7 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
   // (the node tables also hold the relocation area of the stage-2 sentences: k_layout's upper bound is twice the nodes)
   const u64 seeds = 2 * nodes + nodes / 8;
   ok = ok && ctx->node_info.ensure(seeds * sizeof(NodeInfo)) && ctx->node_aux.ensure(seeds * sizeof(NodeAux));
-  ok = ok && ctx->end_nodes.ensure(nodes * 4) && ctx->node_entry.ensure(nodes * spec::kNumDicFeatures * 4) &&
+  ok = ok && ctx->end_nodes.ensure(nodes * 4) && ctx->node_entry.ensure(nodes * ctx->row_stride * 4) &&
        ctx->node_pat.ensure(nodes * kPat * 8) && ctx->node_t0.ensure(nodes * 4) && ctx->node_beam.ensure(nodes * beam * sizeof(BeamSlot)) &&
        ctx->node_cells.ensure(nodes * G * 4 * ctx->cfg.nscorers) && ctx->node_kept.ensure(nodes) && ctx->path_nodes.ensure(nodes * 4);
   if (ctx->use_rnn) {
@@ -1617,7 +1620,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   if (spec) {
     // what the lattice arrays hold, in nodes, under this batch's beam configuration
     u64 latCap = ctx->end_nodes.cap / 4;
-    latCap = std::min<u64>(latCap, ctx->node_entry.cap / (spec::kNumDicFeatures * 4));
+    latCap = std::min<u64>(latCap, ctx->node_entry.cap / ((size_t)ctx->row_stride * 4));
     latCap = std::min<u64>(latCap, ctx->node_pat.cap / (kPat * 8));
     latCap = std::min<u64>(latCap, ctx->node_t0.cap / 4);
     latCap = std::min<u64>(latCap, ctx->node_beam.cap / ((size_t)beam * sizeof(BeamSlot)));
@@ -1729,7 +1732,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.total_nodes = totalNodes;   // (spec: known at the end of the batch)
   if (!spec) {
     const u64 cap = totalNodes + 8;
-    ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * spec::kNumDicFeatures * 4) &&
+    ok = ctx->end_nodes.ensure(cap * 4) && ctx->node_entry.ensure(cap * ctx->row_stride * 4) &&
          ctx->node_pat.ensure(cap * kPat * 8) && ctx->node_t0.ensure(cap * 4) &&
          ctx->node_beam.ensure(cap * beam * sizeof(BeamSlot)) && ctx->node_cells.ensure(cap * G * 4 * ctx->cfg.nscorers) &&
          ctx->node_kept.ensure(cap) && ctx->path_nodes.ensure(cap * 4);
@@ -1737,6 +1740,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   B.end_nodes = ctx->end_nodes.as<u32>();
   B.node_entry = ctx->node_entry.as<i32>();
+  B.row_stride = ctx->row_stride;
   B.node_pat = ctx->node_pat.as<u64>();
   B.node_t0 = ctx->node_t0.as<float>();
   B.node_beam = ctx->node_beam.as<BeamSlot>();
@@ -1772,7 +1776,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     std::vector<u64> h_base(n + 1), h_bbase(n);
     std::vector<NodeInfo> h_nodes(N);
     std::vector<NodeAux> h_aux(N);
-    std::vector<i32> h_rows(N * spec::kNumDicFeatures);
+    std::vector<i32> h_rows(N * ctx->row_stride);
     std::vector<u32> h_bf(NB), h_bc(NB), h_ef(NB), h_ec(NB), h_en(N);
     rt_d2h(h_status.data(), B.sent_status, n * 4, st);
     rt_d2h(h_ncp.data(), B.sent_ncp, n * 4, st);
@@ -1786,7 +1790,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     if (N) {
       rt_d2h(h_nodes.data(), B.node_info, N * sizeof(NodeInfo), st);
       rt_d2h(h_aux.data(), B.node_aux, N * sizeof(NodeAux), st);
-      rt_d2h(h_rows.data(), B.node_entry, N * spec::kNumDicFeatures * 4, st);
+      rt_d2h(h_rows.data(), B.node_entry, N * ctx->row_stride * 4, st);
       rt_d2h(h_en.data(), B.end_nodes, N * 4, st);
     }
     rt_sync(st);
@@ -1810,7 +1814,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     }
     jppgpu_lattice_pairs view{};
     view.n_sentences = n;
-    view.num_features = spec::kNumDicFeatures;
+    view.num_features = (int32_t)ctx->row_stride;
     view.status = h_status.data();
     view.n_codepoints = h_ncp.data();
     view.n_nodes = h_nn.data();
@@ -1861,7 +1865,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     std::vector<u64> h_base(n + 1);
     std::vector<NodeInfo> h_nodes(N);
     std::vector<NodeAux> h_aux(N);
-    std::vector<i32> h_rows(N * spec::kNumDicFeatures);
+    std::vector<i32> h_rows(N * ctx->row_stride);
     rt_d2h(h_status.data(), B.sent_status, n * 4, st);
     rt_d2h(h_ncp.data(), B.sent_ncp, n * 4, st);
     rt_d2h(h_nn.data(), B.sent_nodes, n * 4, st);
@@ -1869,7 +1873,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     if (N) {
       rt_d2h(h_nodes.data(), B.node_info, N * sizeof(NodeInfo), st);
       rt_d2h(h_aux.data(), B.node_aux, N * sizeof(NodeAux), st);
-      rt_d2h(h_rows.data(), B.node_entry, N * spec::kNumDicFeatures * 4, st);
+      rt_d2h(h_rows.data(), B.node_entry, N * ctx->row_stride * 4, st);
     }
     rt_sync(st);
     for (u32 q = 0; q < n; ++q)
@@ -1877,7 +1881,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
     static_assert(sizeof(jppgpu_node) == sizeof(NodeInfo) && sizeof(jppgpu_unk) == sizeof(NodeAux), "ABI node records");
     jppgpu_lattice_nodes view{};
     view.n_sentences = n;
-    view.num_features = spec::kNumDicFeatures;
+    view.num_features = (int32_t)ctx->row_stride;
     view.status = h_status.data();
     view.n_codepoints = h_ncp.data();
     view.n_nodes = h_nn.data();
@@ -2521,7 +2525,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
     ok &= pull(res->ngb, B.bnd_ngb, NB, st);
     ok &= pull(res->gbeam, B.bnd_gbeam, NB * G * 2, st);
     ok &= pull(res->end_nodes, B.end_nodes, N, st);
-    ok &= pull(res->entry_rows, B.node_entry, N * spec::kNumDicFeatures, st);
+    ok &= pull(res->entry_rows, B.node_entry, N * ctx->row_stride, st);
     ok &= pull(res->patterns, B.node_pat, N * kPat, st);
     ok &= pull(res->t0, B.node_t0, N, st);
     ok &= pull(res->beams, B.node_beam, N * beam, st);
@@ -2543,6 +2547,7 @@ extern "C" int jppgpu_result_fetch(jppgpu_result* res, int full, jppgpu_result_v
   v->beam = beam;
   v->global_beam = G;
   v->num_scorers = res->cfg.nscorers;
+  v->entry_row_stride = (int32_t)ctx->row_stride;
   v->path_len = res->path_len.data();
   v->path_nodes = res->path_nodes.data();
   v->nodes = res->nodes.data();

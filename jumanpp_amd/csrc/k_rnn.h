@@ -62,7 +62,7 @@ __device__ __forceinline__ bool rnn_trie_byte(UP units, u32& id, u32& unit, u32 
 // RnnIdContainer::resolveId: word id of lattice node `k` (not EOS)
 __device__ inline i32 rnn_resolve_id(const DevModel& M, const Batch& B, u32 s, u64 nb, u32 k) {
   NodeInfo ni = B.node_info[nb + k];
-  const i32* entry = B.node_entry + (nb + k) * spec::kNumDicFeatures;
+  const i32* entry = B.node_entry + (nb + k) * B.row_stride;
   const u32 JPP_GLOBAL* units = as_global(ni.eptr >= 0 ? M.rnn_known : M.rnn_unk);
   u32 id = 0;
   u32 unit = units[0];

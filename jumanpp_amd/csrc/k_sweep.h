@@ -260,7 +260,7 @@ __global__ void k_penalty(Batch B) {
         if (len != c.length) {
           hard = true;
         } else {
-          const i32* row = B.node_entry + (nb + k) * spec::kNumDicFeatures;
+          const i32* row = B.node_entry + (nb + k) * B.row_stride;
           for (u32 t = 0; t < c.tag_count; ++t) {
             PcTag tg = B.pc_tags[c.tag_first + t];
             if (row[tg.field] != tg.value) {

@@ -379,14 +379,15 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
   for (u32 k = 2 + threadIdx.x; k < N; k += blockDim.x) {
     NodeInfo ni = B.node_info[nb + k];
     NodeAux na = B.node_aux[nb + k];
-    // ---- entry row ----
-    i32 entry[spec::kNumDicFeatures];
+    // ---- entry row (up to kMaxDicFeatures = JPP_MAX_DIC_FIELDS columns, round 5) ----
+    constexpr int kRowMax = kMaxDicFeatures;
+    i32 entry[kRowMax];
 #pragma unroll
-    for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = 0;
+    for (int f = 0; f < kRowMax; ++f) entry[f] = 0;
     bool isUnk = false;
     if (ni.eptr == kEptrEOS) {
 #pragma unroll
-      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? kEptrEOS : 0;
+      for (int f = 0; f < kRowMax; ++f) entry[f] = f < nf ? kEptrEOS : 0;
     } else if (ni.eptr >= 0) {
       read_entry_row(M, ni.eptr, entry, nf);
     } else if (na.maker == kGoldMaker) {
@@ -394,7 +395,7 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
       isUnk = true;
       const ExtraSeed* g = B.gold + B.gold_off[s] + na.pad;
 #pragma unroll
-      for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? g->row[f] : 0;
+      for (int f = 0; f < kRowMax; ++f) entry[f] = (f < nf && f < 8) ? g->row[f < 8 ? f : 0] : 0;   // (the trainer's gold rows: 8 columns)
     } else {
       isUnk = true;
       const UnkMaker& mk = M.makers[M.maker_of_spec[na.maker]];
@@ -402,22 +403,22 @@ __global__ void __launch_bounds__(64) k_t0_dyn(Batch B, const DevModel* __restri
         read_entry_row(M, na.tmpl, entry, nf);
       } else {
 #pragma unroll
-        for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = f < nf ? mk.tmpl[f] : 0;
+        for (int f = 0; f < kRowMax; ++f) entry[f] = f < nf ? mk.tmpl[f] : 0;
       }
 #pragma unroll
-      for (int f = 0; f < spec::kNumDicFeatures; ++f) {
+      for (int f = 0; f < kRowMax; ++f) {
         if (f < nf && ((mk.replace_mask >> f) & 1)) entry[f] = na.hash;
       }
     }
 #pragma unroll
-    for (int f = 0; f < spec::kNumDicFeatures; ++f) B.node_entry[(nb + k) * spec::kNumDicFeatures + f] = entry[f];
+    for (int f = 0; f < kRowMax; ++f) if (f < (int)B.row_stride) B.node_entry[(nb + k) * B.row_stride + f] = entry[f];
 
     // ---- primitive features (feature_impl_prim.h:62-236) ----
     auto primitive = [&](int p) -> u64 {
       const int kind = S.prims[p].kind, a = S.prims[p].a, bsh = S.prims[p].b;
       u32 col = 0;
 #pragma unroll
-      for (int f = 0; f < spec::kNumDicFeatures; ++f) col = f == a ? (u32)entry[f] : col;   // (no dynamic register index)
+      for (int f = 0; f < kRowMax; ++f) col = f == a ? (u32)entry[f] : col;   // (no dynamic register index)
       if (kind == spec::Copy) return col;
       if (kind == spec::SingleBit) return (col >> bsh) & 1u;
       if (kind == spec::Provided) return isUnk ? (u64)(u32)(a == 0 ? na.ph0 : na.ph1) : 0;

@@ -32,7 +32,7 @@ __device__ __forceinline__ void ngrams_of(const Batch& B, u32 s, u32 node, u32 t
   const NodeAux na = B.node_aux[nb + node];
   i32 entry[spec::kNumDicFeatures];
 #pragma unroll
-  for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = B.node_entry[(nb + node) * spec::kNumDicFeatures + f];
+  for (int f = 0; f < spec::kNumDicFeatures; ++f) entry[f] = B.node_entry[(nb + node) * B.row_stride + f];
   const bool isUnk = ni.eptr < 0 && ni.eptr != kEptrEOS;
   u64 pat[spec::kNumPatterns];
   t0_patterns(entry, ni, na, isUnk, cps, cls, n, pat);

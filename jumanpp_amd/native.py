@@ -61,7 +61,7 @@ class ResultView(C.Structure):
                 ('status', C.c_void_p), ('n_codepoints', C.c_void_p), ('n_nodes', C.c_void_p),
                 ('node_base', C.c_void_p), ('bnd_base', C.c_void_p),
                 ('total_nodes', C.c_uint64), ('total_boundaries', C.c_uint64),
-                ('beam', C.c_int32), ('global_beam', C.c_int32), ('num_scorers', C.c_int32), ('reserved0', C.c_int32),
+                ('beam', C.c_int32), ('global_beam', C.c_int32), ('num_scorers', C.c_int32), ('entry_row_stride', C.c_int32),
                 ('path_len', C.c_void_p), ('path_nodes', C.c_void_p),
                 ('nodes', C.c_void_p), ('unk', C.c_void_p),
                 ('bnd_first', C.c_void_p), ('bnd_count', C.c_void_p),
@@ -227,7 +227,8 @@ class Result:
             self.end_first = self._arr(v.end_first, '<u4', NB)
             self.end_count = self._arr(v.end_count, '<u4', NB)
             self.end_nodes = self._arr(v.end_nodes, '<u4', N)
-            self.entry_rows = self._arr(v.entry_rows, '<i4', N * 8).reshape(-1, 8)
+            stride = int(v.entry_row_stride) or 8
+            self.entry_rows = self._arr(v.entry_rows, '<i4', N * stride).reshape(-1, stride)
             self.patterns = self._arr(v.patterns, '<u8', N * 14).reshape(-1, 14)
             self.t0 = self._arr(v.t0_scores, '<f4', N)
             self.beams = self._arr(v.beams, BEAM_DT, N * v.beam).reshape(-1, v.beam)

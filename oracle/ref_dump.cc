@@ -27,12 +27,13 @@
 //   ref_dump ngrams  <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the trainer's read-out: NgramFeaturesComputer::calculateNgramFeatures for every connection of the top-1
 //       path on an analyzer that stores all patterns (what jppgpu_result_fetch_top1_ngrams must reproduce)
-//   ref_dump bootstrapv <dict.mdic> <out.jppmdl> <drop|add|len>
+//   ref_dump bootstrapv <dict.mdic> <out.jppmdl> <drop|add|len|cols>
 //       jpp_jumandic_bootstrap with a VARIANT of the jumandic spec, so that the spec hash no longer matches the
 //       reference's generated static feature code and the reference runs its dynamic feature objects
 //       (features_api.cc:20-60): `drop` removes the last n-gram feature of the spec, `add` appends a unigram, a
 //       bigram and swaps two bigrams, `len` adds a unigram over three LENGTH primitives (byte length / codepoints of dictionary
-//       strings, and of a column UNK makers overwrite).  The checker of the table-driven kernels.
+//       strings, and of a column UNK makers overwrite), `cols` adds four dictionary columns (12 feature columns per entry row) with
+//       unigram features over them.  The checker of the table-driven kernels.
 //   ref_dump top1    <model.jppmdl> <out.bin> [beam gbeam rcheck rbeam] < corpus
 //       the packed top-1 result of Analyzer::analyze per sentence: u32 status (0 ok / 1 failed), u32 count, then count
 //       records {i32 EntryPtr raw, u16 start, u16 end} in text order (EOS dropped) -- the layout of jppgpu_result_pack.
@@ -703,7 +704,25 @@ int doDump(const char* modelFile, const char* out, char** extra, int nextra) {
 // ------------------------------------------------------------------ time ---
 int doBootstrapVariant(const char* mdic, const char* out, const char* variant) {
   core::spec::AnalysisSpec spec;
-  CHECK_OK(jumandic::SpecFactory::makeSpec(&spec));
+  if (std::string(variant) == "cols") {
+    // MORE THAN 8 FEATURE COLUMNS (JPP_MAX_DIC_FIELDS = 16): the jumandic spec as SpecFactory fills it, plus
+    // four string columns read from CSV columns 13-16 (the test appends them to the generated dictionary) that four new
+    // unigram features read -- 12 feature columns per entry row.
+    core::spec::dsl::ModelSpecBuilder bldr;
+    jumandic::SpecFactory::fillSpec(bldr);
+    auto& x1 = bldr.field(13, "extra1").strings().emptyValue("*").align(3);
+    auto& x2 = bldr.field(14, "extra2").strings().emptyValue("*").align(3);
+    auto& x3 = bldr.field(15, "extra3").strings().emptyValue("*").align(3);
+    auto& x4 = bldr.field(16, "extra4").strings().emptyValue("*").align(3);
+    // (unigram features only: the jumandic spec already fills the 14 stored-pattern slots of the device's sweep)
+    bldr.unigram({x1});
+    bldr.unigram({x2, x3});
+    bldr.unigram({x4, x1});
+    bldr.unigram({x3, x4, x2, x1});
+    CHECK_OK(bldr.build(&spec));
+  } else {
+    CHECK_OK(jumandic::SpecFactory::makeSpec(&spec));
+  }
   auto& ng = spec.features.ngram;
   const std::string v{variant};
   if (v == "drop") {
@@ -772,6 +791,8 @@ int doBootstrapVariant(const char* mdic, const char* out, const char* variant) {
     uni.index = maxIdx + 1;
     uni.references = {pat.index};
     ng.push_back(uni);
+  } else if (v == "cols") {
+    // (built above)
   } else {
     std::cerr << "unknown variant " << v << "\n";
     return 2;

@@ -180,7 +180,7 @@ def compare_sentence(res, s, g, meta, check_scores=True, tol=0.0, verbose=True, 
                     bad('b%d n%d: unk (%d,%d,%d,%d) vs %s' % (b, r, u['tmpl'], u['hash'], u['ph0'], u['ph1'], gn['unk']))
             if not scored:
                 continue
-            if not np.array_equal(res.entry_rows[k], gn['entry']):
+            if not np.array_equal(res.entry_rows[k][:len(gn['entry'])], gn['entry']):   # (rows are padded to 8 / 16 columns)
                 bad('b%d n%d: entry row %s vs %s' % (b, r, res.entry_rows[k], gn['entry']))
             if pat_slots is None:
                 if not np.array_equal(res.patterns[k], gn['pat']):

@@ -258,6 +258,15 @@ def _variant_spec_workload(ref_tools, tmp, variant, n_lines, beams=None, rnn=Non
     mdic = os.path.join(tmp, 'v.mdic')
     with open(mdic, 'w', encoding='utf-8') as f:
         subprocess.check_call(['python3', os.path.join(ROOT, 'tools', 'gen_dict.py'), str(n_entries), '--seed', str(seed)], stdout=f)
+    if variant == 'cols':
+        # four more dictionary columns (CSV columns 13-16) for the spec variant with 12 feature columns per entry row
+        import random
+        rng = random.Random(seed + 5)
+        rows = [l.rstrip('\n') for l in open(mdic, encoding='utf-8')]
+        with open(mdic, 'w', encoding='utf-8') as f:
+            for l in rows:
+                f.write('%s,%s,%s,%s,%s\n' % (l, rng.choice('ABCDE'), rng.choice(['p', 'q', 'r']), rng.choice(['x', 'y']),
+                                             rng.choice(['m', 'n', 'o', '*'])))
     rd = os.path.join(ref_tools, 'ref_dump')
     subprocess.check_call([rd, 'bootstrapv', mdic, os.path.join(tmp, 'v.seed'), variant], stderr=subprocess.DEVNULL)
     subprocess.check_call([rd, 'mkmodel', os.path.join(tmp, 'v.seed'), os.path.join(tmp, 'v.model'), str(exp), '3', '0.1'],
@@ -302,11 +311,13 @@ def check_variant_spec(lib, ref_tools, tmp, variant, n_lines, beams, rnn, **kw):
 
 
 @pytest.mark.parametrize('variant,beams,rnn', [('drop', None, None), ('add', None, (32, 600)), ('add', [20, 24, 1, 20], None),
-                                               ('drop', [5, 0, 0, 0], None)])
+                                               ('drop', [5, 0, 0, 0], None), ('cols', None, None), ('cols', [4, 12, 2, 6], (32, 600)),
+                                               ('cols', [5, 0, 0, 0], None)])
 def test_emulated_table_driven_kernels_on_a_non_jumandic_spec(emu_lib, ref_tools, tmp_path, variant, beams, rnn):
     """a spec other than the compiled-in tables is analysed by the table-driven kernels (k_t0_dyn,
     k_sweep<.., DYN>, k_sweep_full<DYN> without a global beam) with the summation orders of the reference's DYNAMIC
-    feature code: whole lattice bit-identical"""
+    feature code: whole lattice bit-identical.  `cols`: 12 feature columns per entry row (rows of 16 in node_entry;
+    JPP_MAX_DIC_FIELDS = 16 in the reference)"""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     check_variant_spec(emu_lib, ref_tools, str(tmp_path), variant, 40, beams, rnn)

@@ -483,7 +483,8 @@ def test_gpu_full_beam_beyond_the_lds_staging(gpu_lib, ref_tools, tmp_path):
 
 
 @pytest.mark.parametrize('variant,rnn,beams', [('drop', None, None), ('add', (128, 3000), None), ('drop', None, [5, 0, 0, 0]),
-                                               ('add', None, [20, 24, 1, 20]), ('drop', (64, 3000), [32, 32, 1, 32])])
+                                               ('add', None, [20, 24, 1, 20]), ('drop', (64, 3000), [32, 32, 1, 32]),
+                                               ('cols', None, None), ('cols', (64, 3000), [4, 12, 2, 6])])
 def test_gpu_table_driven_kernels_on_a_non_jumandic_spec(gpu_lib, ref_tools, tmp_path, variant, rnn, beams):
     """SURVEY 8 f3 on the MI355X: 1 500 sentences of a 30 k-entry dictionary under a spec whose hash does not match the
     reference's generated code -- table-driven kernels (global-beam and full-beam sweeps) against the reference's dynamic

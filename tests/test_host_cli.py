@@ -255,13 +255,19 @@ def test_cli_on_a_non_jumandic_spec(cli_emu, ref_tools, tmp_path):
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     import test_cpu_parity as tc
-    tmp = str(tmp_path)
-    tc._variant_spec_workload(ref_tools, tmp, 'add', 25)
-    model, txt = os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.txt')
-    for flags in ([], ['-s', '3']):
-        ref = _ref_cli(ref_tools, model, flags, txt)
-        rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
-        assert rc == 0 and out == ref, (flags, err[-300:])
+    # `add`: more n-gram features; `cols`: 12 feature columns per dictionary entry (round 5; > 8 was NotImplemented)
+    for variant in ('add', 'cols'):
+        tmp = str(tmp_path / variant)
+        tc._variant_spec_workload(ref_tools, tmp, variant, 25, gold=False)
+        model, txt = os.path.join(tmp, 'v.model'), os.path.join(tmp, 'v.txt')
+        for flags in ([], ['-s', '3']):
+            ref = _ref_cli(ref_tools, model, flags, txt)
+            rc, out, err = _run(cli_emu, ['--model=' + model] + flags + [txt])
+            assert rc == 0 and out == ref, (variant, flags, err[-300:])
+        # the file-to-file pipeline (device-printed text)
+        out_path = os.path.join(tmp, 'o.txt')
+        rc, _, err = _run(cli_emu, ['--model=' + model, '-o', out_path, txt])
+        assert rc == 0 and open(out_path, 'rb').read() == _ref_cli(ref_tools, model, [], txt), (variant, err[-300:])
 
 
 def _sharded_input(golden_dir, tmp, copies):
