@@ -45,4 +45,22 @@ __device__ unsigned long long g_rnn_cnt[2];
       atomicAdd(&g_rnn_cnt[1], rprof_nodes);                                               \
     }                                                                                      \
   } while (0)
+// k_rnn_prep<true> (long sentences): cycles per phase, lane 0 of every wavefront (jppgpu_debug_prep_prof, tools/gpu_prep_phases.py)
+__device__ unsigned long long g_prep_prof[8];
+#define JPP_PPROF_DECL unsigned long long pprof_t = __builtin_readcyclecounter(), pprof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define JPP_PPROF(i)                                         \
+  do {                                                       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    unsigned long long now_ = __builtin_readcyclecounter();  \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    asm volatile("" ::: "memory");                           \
+    pprof_acc[i] += now_ - pprof_t;                          \
+    pprof_t = now_;                                          \
+  } while (0)
+#define JPP_PPROF_FLUSH                                                                \
+  do {                                                                                 \
+    if (lane == 0)                                                                     \
+      for (int q_ = 0; q_ < 8; ++q_) atomicAdd(&g_prep_prof[q_], pprof_acc[q_]);       \
+  } while (0)
 #endif  // JPP_DEV_PROF_H

@@ -34,6 +34,9 @@ typedef hipStream_t jpp_stream_t;
 #define JPP_RPROF(i)
 #define JPP_RPROF_COUNT(cn)
 #define JPP_RPROF_FLUSH
+#define JPP_PPROF_DECL
+#define JPP_PPROF(i)
+#define JPP_PPROF_FLUSH
 #endif
 
 typedef uint8_t u8;

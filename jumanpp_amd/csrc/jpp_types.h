@@ -261,11 +261,10 @@ struct Batch {
   BeamSlot* node_beam;     // [gn][beam]
   float* node_cells;       // [gn][gbeam][nscorers]
   u32* rnn_conn;           // [bb][gbeam] connection of EOS path p at boundary b: node (26 bits) | slot<<26, or ~0
-  i32* rnn_id;             // [bb][gbeam] RNN vocabulary id of that node
+  i32* rnn_id;             // [bb][gbeam] RNN vocabulary id of the connection's lattice node, at the first path through it (k_rnn_prep)
   u32* rnn_gi;             // [bb][gbeam] global-beam index of the connection (= which score cell of its node it owns) | codepoints of its lattice node << 16
   u32* rnn_assign;         // [bb][gbeam] rnn node (index within boundary) a connection is scored with
   u32* rnn_prev;           // [bb][gbeam] rnn node -> prev rnn node handle (b * G + idx)
-  u64* rnn_hash;           // [bb][gbeam] prefix hash of the rnn node
   i32* rnn_nid;            // [bb][gbeam] word id of the rnn node
   u32* rnn_nlen;           // [bb][gbeam] codepoint length of the rnn node
   u32* rnn_cnt;            // [bb] rnn nodes per boundary

@@ -477,7 +477,7 @@ struct jppgpu_ctx {
   bool dynamic_spec = false;   // a spec other than the built-in jumandic tables: table-driven kernels
   u32 row_stride = 8;          // columns of a node's entry row in node_entry: 8, or 16 for models with more than 8 feature columns
   bool builtin_spec = false;   // the spec equals the compiled-in tables (k_path_ngrams reads them), also when dynamic_spec is forced
-  DevBuf rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_hash, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_rec, rnn_rscore, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
+  DevBuf rnn_conn, rnn_id, rnn_gi, rnn_assign, rnn_prev, rnn_nid, rnn_nlen, rnn_cnt, rnn_ctx, rnn_rec, rnn_rscore, rnn_noff, rnn_rows, rnn_rowbase, rnn_ord, pack_cnt, pack_off, top1_nodes, top1_aux, nbest_cnt, nbest_off, nbest_items, nbest_eos, ng_nodes, ng_feat, gstats;
   // workspace
   DevBuf text, offs;
   DevBuf cp_code, cp_class, cp_boff, cl_nodes, pos_cnt1, pos_cntN, pos_norm, pos_cnt2, pos_ends, pos_walk, reach;
@@ -1291,7 +1291,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->end_cnt,    &ctx->bnd_ngb,   &ctx->bnd_gbeam,  &ctx->node_info, &ctx->node_aux,
                     &ctx->end_nodes,  &ctx->node_entry, &ctx->node_pat,  &ctx->node_t0,   &ctx->node_beam,
                     &ctx->node_cells, &ctx->node_kept, &ctx->path_nodes, &ctx->rnn_conn,  &ctx->rnn_id,  &ctx->rnn_gi,
-                    &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_hash,  &ctx->rnn_nid,   &ctx->rnn_nlen,
+                    &ctx->rnn_assign, &ctx->rnn_prev, &ctx->rnn_nid,   &ctx->rnn_nlen,
                     &ctx->rnn_cnt,    &ctx->rnn_ctx,    &ctx->rnn_rec, &ctx->rnn_rscore, &ctx->rnn_noff, &ctx->rnn_rows, &ctx->rnn_rowbase,    &ctx->rnn_ord,    &ctx->pack_cnt,  &ctx->pack_off,  &ctx->top1_nodes, &ctx->top1_aux, &ctx->nbest_cnt, &ctx->nbest_off, &ctx->nbest_items, &ctx->nbest_eos,
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
@@ -1341,7 +1341,7 @@ bool ensure_front(jppgpu_ctx* ctx, size_t n, size_t total_bytes) {
             ctx->bnd_gbeam.ensure(bbN * G * sizeof(GbeamEntry)) &&
             (!ctx->use_rnn || (ctx->rnn_conn.ensure(bbN * G * 4) && ctx->rnn_id.ensure(bbN * G * 4) && ctx->rnn_gi.ensure(bbN * G * 4) &&
               ctx->rnn_assign.ensure(bbN * G * 4) && ctx->rnn_prev.ensure(bbN * G * 4) &&
-              ctx->rnn_hash.ensure(bbN * G * 8) && ctx->rnn_nid.ensure(bbN * G * 4) &&
+              ctx->rnn_nid.ensure(bbN * G * 4) &&
               ctx->rnn_nlen.ensure(bbN * G * 4) && ctx->rnn_cnt.ensure(bbN * 4) && ctx->rnn_ord.ensure((2 * n + 2 * kRnnOrderBins + 2) * 4) &&
               ctx->rnn_noff.ensure(bbN * 4) && ctx->rnn_rows.ensure(((size_t)n + 1) * 4) && ctx->rnn_rowbase.ensure(((size_t)n + 2) * 8)));
   ok = ok && ctx->gstats.ensure(64) && ctx->sent_maxr.ensure(((size_t)n + 1) * 4) && ctx->sweep_list.ensure((3 * (size_t)n + 1) * 4);
@@ -1524,7 +1524,6 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   B.rnn_gi = ctx->rnn_gi.as<u32>();
   B.rnn_assign = ctx->rnn_assign.as<u32>();
   B.rnn_prev = ctx->rnn_prev.as<u32>();
-  B.rnn_hash = ctx->rnn_hash.as<u64>();
   B.rnn_nid = ctx->rnn_nid.as<i32>();
   B.rnn_nlen = ctx->rnn_nlen.as<u32>();
   B.rnn_cnt = ctx->rnn_cnt.as<u32>();
@@ -2022,11 +2021,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   T.mark(5, st);
   if (ctx->use_rnn) {
     JPP_LAUNCH(k_rnn_paths, (u32)(((u64)n * ctx->cfg.gbeam + 255) / 256), 256, st, B, ctx->cfg);
-    JPP_LAUNCH(k_rnn_prep<false>, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
-               (const DevModel*)ctx->mb->dmodel, ctx->cfg);
-    // (the sentences beyond the LDS bookkeeping of the first launch -- (codepoints + 3) x global beam > 288: any batch
-    // may hold one, and a workgroup that finds none of its own leaves at once)
-    JPP_LAUNCH(k_rnn_prep<true>, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
+    JPP_LAUNCH(k_rnn_prep, (n + kRnnPrepWaves - 1) / kRnnPrepWaves, 64 * kRnnPrepWaves, st, B,
                (const DevModel*)ctx->mb->dmodel, ctx->cfg);
     // SORT: remakeEosBeam needs the makeT0Beam replay (more than 16 EOS candidates or global beam > beam*4/3)
     const bool sortE = ctx->cfg.gbeam > 16 || ctx->cfg.gbeam > ctx->cfg.beam * 4 / 3;
@@ -2280,6 +2275,13 @@ extern "C" int jppgpu_debug_sweep_prof(unsigned long long* out16) {
   hipMemcpyToSymbol(HIP_SYMBOL(g_rnn_cnt), z2, sizeof(z2));
   unsigned long long z[16] = {};
   hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_prof), z, sizeof(z));
+  return 0;
+}
+extern "C" int jppgpu_debug_prep_prof(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prep_prof), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_prep_prof), z, sizeof(z));
   return 0;
 }
 #endif

@@ -157,10 +157,22 @@ __global__ void __launch_bounds__(256) k_rnn_paths(Batch B, Config cfg) {
   }
 }
 
-// LONG = false: the sentences whose bookkeeping fits the LDS arrays; LONG = true: the others, built in place in the HBM
-// arrays -- a launch of its own without the LDS arrays (40 KB per workgroup held the kernel at 4 wavefronts per SIMD;
-// the long variant is a chain of dependent L2 round trips that only more wavefronts hide: 64 VGPRs, 8 per SIMD).
-template <bool LONG>
+// The RNN lattice of a sentence (RnnIdContainer::addPath / addPrevChain over its surviving EOS paths, rnn_id_resolver.cc),
+// one wavefront per sentence, lane = path, everything in registers.
+//
+// The reference adds the paths one after the other, each from BOS to EOS.  What path p does at boundary b depends on the
+// earlier paths at b (the rnn nodes they published there, the ptrCache entry of a shared connection) and on p's own
+// previous node, so the boundaries can be taken in order with all paths of a boundary side by side -- as long as the
+// DISTINCT connections of the boundary are handled in path order.  Per boundary: one coalesced row of connections /
+// lengths / ids comes in (requested a boundary ahead), the lanes are grouped by connection with ballots, and for every
+// distinct connection (there are one or two, not G) the boundary's published nodes -- node x in lane x's registers --
+// are searched with two ballots.  The rnn nodes and the paths' assignments leave as coalesced rows.
+//
+// Until round 5 lane p replayed path p on a diagonal (boundary t - p in step t) with the bookkeeping in LDS (short
+// sentences, 40 KB per workgroup) or in the HBM arrays (long ones): every lane in a cache line of its own, a dependent
+// round trip per published node -- 6.8 ms per batch of the configs[4] shape, 4.8 ms with the chain moved into an LDS
+// ring (profiles/r05i-r05l: ~9 000 cycles of a wavefront's life per step, the texture path's line rate and HBM latency,
+// not arithmetic).  The shortcut tried before (prefetching on the diagonal) made it slower: 10.3-10.7 ms, r05f / r05g.
 __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const DevModel* __restrict__ Mp, Config cfg) {
   const DevModel& M = *Mp;
   const int wv = (int)(threadIdx.x >> 6);
@@ -169,269 +181,303 @@ __global__ void __launch_bounds__(64 * kRnnPrepWaves) k_rnn_prep(Batch B, const 
   if (s >= B.n_sent) return;
   // hidden-state rows of the sentence (rnn_rows, scanned into rnn_rowbase): every sentence owns at least its
   // parking row, sentences with an RNN lattice get parking + BOS + one row per rnn node (end of this kernel)
-  constexpr u32 kCap = LONG ? 1 : 288, kCapB = LONG ? 1 : 48;
-  constexpr u32 kFitCap = 288, kFitCapB = 48;
   bool live = B.sent_status[s] == ST_OK;
   const u32 off = B.byte_off[s];
   const u32 bb0 = off + 4 * s;
   const u32 n = live ? B.sent_ncp[s] : 0u;
   const u32 bE = n + 2;
-  const int G = cfg.gbeam;
-  const int ngb = n != 0 ? (int)B.bnd_ngb[bb0 + bE] : 0;
+  const u32 G = (u32)cfg.gbeam;
+  const u32 ngb = n != 0 ? B.bnd_ngb[bb0 + bE] : 0u;
   live = live && n != 0 && ngb != 0;
   if (!live) {
-    if (!LONG && lane == 0) B.rnn_rows[s] = 1;   // (the LONG launch leaves the sentences it does not own alone)
+    if (lane == 0) B.rnn_rows[s] = 1;
     return;
   }
-  const u32 nq = (bE + 1) * (u32)G;
-  const bool fits = nq <= kFitCap && (bE + 1) <= kFitCapB;
-  if (fits == LONG) return;   // the other variant's sentence
   const u32 N = B.sent_nodes[s];
   const u64 nb = B.node_base[s];
-  const int beam = cfg.beam;
-  const BeamSlot* beams = B.node_beam + nb * beam;
-  const u32* en = B.end_nodes + nb;
-  (void)beams;
-  (void)en;
-  // per (boundary, path) and per (boundary, rnn node) bookkeeping: built in LDS for ordinary
-  // sentences and copied out at the end, built in place in the HBM arrays for very long ones
-  __shared__ u32 l_conn_all[kRnnPrepWaves][kCap];
-  __shared__ i32 l_wid_all[kRnnPrepWaves][kCap];
-  __shared__ u32 l_assign_all[kRnnPrepWaves][kCap];
-  __shared__ u32 l_prev_all[kRnnPrepWaves][kCap];
-  __shared__ u64 l_hash_all[kRnnPrepWaves][kCap];
-  __shared__ i32 l_id_all[kRnnPrepWaves][kCap];
-  __shared__ u32 l_len_all[kRnnPrepWaves][kCap];
-  __shared__ u32 l_cnt_all[kRnnPrepWaves][kCapB];
-  __shared__ u16 l_clen_all[kRnnPrepWaves][kCap];   // codepoints of every connection's lattice node
-  constexpr bool inLds = !LONG;
-  u32* g_conn = B.rnn_conn + (u64)bb0 * G;
-  u32* g_assign = B.rnn_assign + (u64)bb0 * G;
-  u32* g_prev = B.rnn_prev + (u64)bb0 * G;
+  const u32* g_conn = B.rnn_conn + (u64)bb0 * G;   // lattice connection of path p at boundary b (k_rnn_paths)
+  const u32* g_gi = B.rnn_gi + (u64)bb0 * G;       // (k_rnn_paths: global-beam index | node length << 16)
+  u32* g_assign = B.rnn_assign + (u64)bb0 * G;     // rnn node (index within boundary) scoring the connection
+  u32* g_prev = B.rnn_prev + (u64)bb0 * G;         // rnn node -> handle (pb * G + pidx) of its predecessor
   i32* g_id = B.rnn_nid + (u64)bb0 * G;
   u32* g_len = B.rnn_nlen + (u64)bb0 * G;
-  u32* g_cnt = B.rnn_cnt + bb0;
-  const u32* g_clen = B.rnn_gi + (u64)bb0 * G;   // (k_rnn_paths: global-beam index | node length << 16)
-  u32* conn = inLds ? l_conn_all[wv] : g_conn;                  // lattice connection of path p at boundary b
-  i32* wid = inLds ? l_wid_all[wv] : B.rnn_id + (u64)bb0 * G;   // word id of that connection's lattice node
-  u32* assign = inLds ? l_assign_all[wv] : g_assign;            // rnn node (index within boundary) scoring it
-  u32* rn_prev = inLds ? l_prev_all[wv] : g_prev;               // rnn node -> handle (pb * G + pidx) of its prev
-  u64* rn_hash = inLds ? l_hash_all[wv] : B.rnn_hash + (u64)bb0 * G;
-  i32* rn_id = inLds ? l_id_all[wv] : g_id;
-  u32* rn_len = inLds ? l_len_all[wv] : g_len;
-  u32* rn_cnt = inLds ? l_cnt_all[wv] : g_cnt;                  // rnn nodes per boundary
-  u16* clen = inLds ? l_clen_all[wv] : nullptr;
+  u32* g_cnt = B.rnn_cnt + bb0;                    // rnn nodes per boundary
+  i32* wid = B.rnn_id + (u64)bb0 * G;              // vocabulary id of the connection's lattice node, at the FIRST path through it
+  constexpr u32 kNodeMask = 0x03ffffffu;
+  const u64 laneBit = u64{1} << lane;
+  JPP_PPROF_DECL;
 
-  // ---- A. connection of every EOS path at every boundary: made by k_rnn_paths ----
-  if (inLds)
-    for (u32 q = lane; q < nq; q += 64) conn[q] = g_conn[q];
-  for (u32 q = lane; q <= bE; q += 64) rn_cnt[q] = 0;
-  wave_sync();
-  // ---- B. word ids of the connections ----
-  // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the
-  // first path that passes through it, and copied to the others.
-  // The first occurrences are gathered into a dense list first (in `assign`, not needed before B2): resolving an
-  // id is a chain of a dozen dependent loads through the double array, paid once per 64 list entries instead of
-  // once per 64 (boundary, path) slots, most of which are empty or repeats.
+  // ---- A. vocabulary ids ----
+  // The surviving paths mostly run through the same lattice nodes: the id of a node is resolved once, by the first path
+  // through it.  The first occurrences are gathered into a dense list (in `assign`, not written before B): resolving an
+  // id is a chain of a dozen dependent loads through the double array, paid once per 64 list entries instead of once
+  // per 64 (boundary, path) slots, most of which are empty or repeats.  64 / G boundaries per round, lane = (boundary,
+  // path); equal nodes lie in the same boundary, so the lanes are simply grouped by value, one ballot per distinct node.
+  const u32 rowsPer = 64u / G;   // (G <= kMaxGbeam = 32)
+  const u32 r = (u32)lane / G, p = (u32)lane - r * G;
   u32 nfirst = 0;
-  // Long sentences (the arrays are in HBM): "which earlier path runs through the same node / the same connection" is
-  // answered inside the wavefront -- 64 / G boundaries per round, lane = (boundary, path), the other paths'
-  // connections by shuffle -- instead of by up to G - 1 dependent reads per slot (round 4: 9.3 -> ... ms per batch
-  // of the configs[4] shape).
-  const u32 rowsPer = 64u / (u32)G > 0 ? 64u / (u32)G : 1u;
-  // first earlier path with the same lattice node (low byte, + 1) and with the same connection (second byte, + 1)
-  auto earlier_paths = [&](u32 c, u32 r, u32 p, bool valid) -> u32 {
-    const u32 nd = c & 0x03ffffffu;
-    u32 fn = 0, fc = 0;
-    for (u32 pp = 0; pp < (u32)G; ++pp) {
-      const u32 c2 = wave_shfl_u32(c, valid ? (int)(r * (u32)G + pp) : lane);
-      const bool before = valid && pp < p && c != kNoConn && c2 != kNoConn;
-      if (before && fn == 0 && (c2 & 0x03ffffffu) == nd) fn = pp + 1;
-      if (before && fc == 0 && c2 == c) fc = pp + 1;
+  constexpr u32 kTrip = 4;   // rounds requested together (a round alone waits a whole HBM latency for one line)
+  for (u32 b0 = 0; b0 <= bE; b0 += kTrip * rowsPer) {
+    u32 cs[kTrip];
+#pragma unroll
+    for (u32 k = 0; k < kTrip; ++k) {
+      const u32 b = b0 + k * rowsPer + r;
+      cs[k] = (r < rowsPer && b <= bE) ? g_conn[b * G + p] : kNoConn;
     }
-    return fn | (fc << 8);
-  };
-  if (!inLds) {
-    for (u32 b0 = 0; b0 <= bE; b0 += rowsPer) {
-      const u32 r = (u32)lane / (u32)G, p = (u32)lane - r * (u32)G;
-      const u32 b = b0 + r;
-      const bool valid = r < rowsPer && b <= bE;
-      const u32 q = b * (u32)G + p;
-      const u32 c = valid ? conn[q] : kNoConn;
-      const u32 e = earlier_paths(c, r, p, valid);
-      const bool first = c != kNoConn && (e & 0xffu) == 0;
-      const u64 m = wave_ballot(first);
-      if (first) assign[nfirst + (u32)popc64(m & ((u64{1} << lane) - 1))] = q;
-      nfirst += (u32)popc64(m);
-    }
-  }
-  for (u32 q0 = 0; inLds && q0 < nq; q0 += 64) {
-    const u32 q = q0 + (u32)lane;
-    bool first = false;
-    if (q < nq) {
-      const u32 c = conn[q];
-      if (c != kNoConn) {
-        const u32 nd = c & 0x03ffffffu;
-        const u32 b = q / (u32)G, p = q - b * (u32)G;
-        first = true;
-        for (u32 pp = 0; pp < p; ++pp) {
-          const u32 c2 = conn[(u64)b * G + pp];
-          if (c2 != kNoConn && (c2 & 0x03ffffffu) == nd) {
-            first = false;
-            break;
-          }
-        }
+#pragma unroll
+    for (u32 k = 0; k < kTrip; ++k) {
+      const u32 c = cs[k];
+      const u32 nd = c & kNodeMask;
+      u64 todo = wave_ballot(c != kNoConn), firsts = 0;
+      while (todo != 0) {
+        const int L = __builtin_ctzll(todo);
+        const u32 ndL = wave_bcast_u32(nd, L);
+        firsts |= u64{1} << L;
+        todo &= ~wave_ballot(c != kNoConn && nd == ndL);
       }
+      if ((firsts & laneBit) != 0) g_assign[nfirst + (u32)popc64(firsts & (laneBit - 1))] = (b0 + k * rowsPer + r) * G + p;
+      nfirst += (u32)popc64(firsts);
     }
-    const u64 m = wave_ballot(first);
-    if (first) assign[nfirst + (u32)popc64(m & ((u64{1} << lane) - 1))] = q;
-    nfirst += (u32)popc64(m);
   }
   wave_sync();
-  for (u32 i = lane; i < nfirst; i += 64) {
-    const u32 q = assign[i];
-    const u32 nd = conn[q] & 0x03ffffffu;
+  JPP_PPROF(0);
+  for (u32 i = (u32)lane; i < nfirst; i += 64) {
+    const u32 q = g_assign[i];
+    const u32 nd = g_conn[q] & kNodeMask;
     wid[q] = (nd == N - 1) ? 0 : rnn_resolve_id(M, B, s, nb, nd);
   }
   wave_sync();
-  if (!inLds) {
-    // the other paths take the id of the first path through their node; and the ptrCache byte of B2 (see below)
-    for (u32 b0 = 0; b0 <= bE; b0 += rowsPer) {
-      const u32 r = (u32)lane / (u32)G, p = (u32)lane - r * (u32)G;
-      const u32 b = b0 + r;
-      const bool valid = r < rowsPer && b <= bE;
-      const u32 q = b * (u32)G + p;
-      const u32 c = valid ? conn[q] : kNoConn;
-      const u32 e = earlier_paths(c, r, p, valid);
-      if (!valid) continue;
-      if (c != kNoConn && (e & 0xffu) != 0) wid[q] = wid[(u64)b * G + (e & 0xffu) - 1];
-      assign[q] = (c == kNoConn ? 0xffu : (e >> 8)) << 24;
-    }
-  }
-  for (u32 q = lane; inLds && q < nq; q += 64) {
-    u32 c = conn[q];
-    if (c == kNoConn) continue;
-    const u32 nd = c & 0x03ffffffu;
-    if (clen) clen[q] = (u16)(g_clen[q] >> 16);   // the node length the replay below hashes
-    const u32 b = q / (u32)G, p = q - b * (u32)G;
-    for (u32 pp = 0; pp < p; ++pp) {
-      const u32 c2 = conn[(u64)b * G + pp];
-      if (c2 != kNoConn && (c2 & 0x03ffffffu) == nd) {
-        wid[q] = wid[(u64)b * G + pp];  // pp is a first occurrence: the smallest path index with this node
-        break;
-      }
-    }
-  }
+  JPP_PPROF(1);
+
+  // ---- B. the rnn lattice, boundary by boundary ----
   // BOS node (boundary 1): RnnIdContainer::addBos
   if (lane == 0) {
-    rn_cnt[1] = 1;
-    rn_hash[(u64)1 * G] = 0xdeadbeef0000ULL;
-    rn_id[(u64)1 * G] = 0;
-    rn_len[(u64)1 * G] = 0;
-    rn_prev[(u64)1 * G] = kNoConn;
+    g_cnt[0] = 0;
+    g_cnt[1] = 1;
+    g_id[G] = 0;
+    g_len[G] = 0;
+    g_prev[G] = kNoConn;
   }
-  wave_sync();
-  // ---- B2. RNN lattice: RnnIdContainer::addPath / addPrevChain ----
-  // Path p (= lane p) is at boundary t - p in step t: all earlier paths have already published
-  // their rnn nodes of that boundary, later ones have not touched it yet.
-  // What a step needs that does not depend on the earlier steps -- is there a connection, does an earlier path
-  // share it (the ptrCache hit) -- is worked out for every (boundary, path) slot at once beforehand, so that the
-  // serial loop reads one byte instead of walking the earlier paths' connections.
-  // (kept in the top byte of the slot's `assign` word, which the step itself overwrites with its result: 0xff no
-  // connection, 0 first path through its connection, else 1 + the earlier path sharing it)
-  for (u32 q = lane; inLds && q < nq; q += 64) {
-    const u32 c = conn[q];
-    u32 v = 0xffu;
-    if (c != kNoConn) {
-      const u32 b = q / (u32)G, p = q - b * (u32)G;
-      v = 0;
-      for (u32 pp = 0; pp < p; ++pp) {
-        if (conn[(u64)b * G + pp] == c) {
-          v = pp + 1;
-          break;
-        }
-      }
+  if ((u32)lane < 2 * G) g_assign[lane] = 0xffu << 24;   // (boundaries 0 and 1: no connections)
+  u32 curB = 1, curX = 0;             // lane = path: its current rnn node (the BOS node) ...
+  u64 curHash = 0xdeadbeef0000ULL;    // ... and that node's prefix hash
+  const bool isPath = (u32)lane < G;
+  // The rows of connections / lengths / ids come in 64 / G boundaries per load, lane = (boundary, path) as in A and two
+  // rounds ahead; a boundary's row is brought to the path lanes by shuffle, its results go back the same way, and the
+  // rows of assignments / rnn nodes leave coalesced, once per round.
+  auto load_round = [&](u32 b0, u32& cc, u32& gg, i32& ww) {
+    const u32 b = b0 + r;
+    cc = kNoConn;
+    if (r < rowsPer && b <= bE) {
+      const u32 q = b * G + p;
+      cc = g_conn[q];
+      gg = g_gi[q];
+      ww = wid[q];
     }
-    assign[q] = v << 24;
-  }
-  wave_sync();
-  // (Round 5 tried to shorten the LONG variant's dependent chain -- the slot's bytes requested a step ahead, the current
-  // node's prefix hash carried in a register, a boundary's first nodes read with its count: 6.8 -> 10.3-10.7 ms on the
-  // configs[4] shape, profiles/r05f / r05g.  The replay is not latency-bound but bound by the number of distinct cache
-  // lines a step touches: lane p works at boundary t - p, so every lane's accesses fall into a line of their own, and
-  // unconditional prefetches only add lines.  A skewed layout of the per-slot arrays ([b + p][p]) would coalesce them.)
-  {
-    const int p = lane;
-    u32 cur = 1u * G;  // handle of the BOS node
-    for (u32 t = 2; t < bE + 1 + (u32)ngb; ++t) {
-      const u32 b = t - (u32)p;
-      if (p < ngb && t >= (u32)p + 2 && b <= bE) {
-        const u32 v = assign[(u64)b * G + p] >> 24;
-        const int shared = (int)v - 1;   // ptrCache hit: an earlier path went through the same connection (-1: none)
-        if (v != 0xffu) {
-          if (shared >= 0) {
-            u32 a = assign[(u64)b * G + shared];
-            assign[(u64)b * G + p] = a;
-            cur = b * G + a;
-          } else {
-            i32 id = wid[(u64)b * G + p];
-            u32 len = clen ? (u32)clen[(u64)b * G + p] : (g_clen[(u64)b * G + p] >> 16);
-            u64 h = fh1_mix(rn_hash[cur], (u64)(u32)id | ((u64)len << 32));
-            u32 cnt = rn_cnt[b];
-            // crdCache_.find(coord): newest published node with the same (boundary, length, id).  Then nextInBnd is
-            // walked (all older nodes of the boundary) comparing the prefix hash; on a match the connection is
-            // attached to it->second, not to the matching node.  Both searches without early exits: the reads of all
-            // published nodes are then independent of each other (one LDS round trip, not one per node).
-            int it = -1;
-            u64 hmatch = 0;   // bit x: node x has the prefix hash h
-            for (int x = 0; x < (int)cnt; ++x) {
-              const bool same = rn_id[(u64)b * G + x] == id && rn_len[(u64)b * G + x] == len;
-              it = same ? x : it;
-              hmatch |= (rn_hash[(u64)b * G + x] == h) ? (u64{1} << x) : u64{0};
-            }
-            const bool merged = it >= 0 && (hmatch & ((u64{2} << it) - 1)) != 0;
+  };
+  u32 c1 = kNoConn, g1 = 0, c2 = kNoConn, g2 = 0;
+  i32 w1 = 0, w2 = 0;
+  load_round(2, c1, g1, w1);
+  load_round(2 + rowsPer, c2, g2, w2);
+  const u64 rowBits = G >= 64 ? ~u64{0} : (u64{1} << G) - 1;
+  for (u32 b0 = 2; b0 <= bE; b0 += rowsPer) {
+    const u32 cR = c1, gR = g1;
+    const i32 wR = w1;
+    c1 = c2;
+    g1 = g2;
+    w1 = w2;
+    load_round(b0 + 2 * rowsPer, c2, g2, w2);
+    const u64 anyConn = wave_ballot(cR != kNoConn);
+    JPP_PPROF(2);
+    u32 outA = 0xffu << 24, outLen = 0, outPrev = 0, outCnt = 0;
+    i32 outId = 0;
+    for (u32 k = 0; anyConn != 0 && k < rowsPer && b0 + k <= bE; ++k) {
+      const u64 act = (anyConn >> (k * G)) & rowBits;
+      if (act == 0) continue;
+      const u32 b = b0 + k;
+      const int src = isPath ? (int)(k * G) + lane : lane;
+      const u32 c = wave_shfl_u32(cR, src), len = wave_shfl_u32(gR, src) >> 16;
+      const i32 w = (i32)wave_shfl_u32((u32)wR, src);
+      const bool has = isPath && c != kNoConn;
+      // the boundary's rnn nodes: node x in lane x
+      u32 cnt = 0, myres = 0;
+      i32 nid = 0;
+      u32 nlen = 0, nprev = 0;
+      u64 nhash = 0;
+      if (act != 0) {
+        // every path takes the id of the first path through its node
+        const u32 nd = c & kNodeMask;
+        i32 myid = w;
+        u64 todo = act;
+        while (todo != 0) {
+          const int L = __builtin_ctzll(todo);
+          const u32 ndL = wave_bcast_u32(nd, L);
+          const i32 idv = (i32)wave_bcast_u32((u32)w, L);
+          const bool inNode = has && nd == ndL;
+          if (inNode) myid = idv;
+          todo &= ~wave_ballot(inNode);
+        }
+        // What the reference does for a path at this boundary, paths in order (addPrevChain): a path whose connection an
+        // earlier path went through takes that path's rnn node (ptrCache_).  Otherwise h = hash(previous rnn node, id,
+        // length); `it` = the NEWEST published node of the boundary with the same (id, length), crdCache_; if there is one
+        // and a node not newer than it carries the hash h, the connection is attached to `it` (not to the node with the
+        // hash), else a new node (id, length, h) is published.
+        // All paths at once: every lane hashes its own step.  Lanes with equal h form a group (equal connections have
+        // equal histories, so they sit in one group), and as long as equal hashes mean equal (id, length):
+        //   - the first lane of a group finds no node with its hash: it publishes the group's node;
+        //   - every other first-through-its-connection lane of the group finds it, and is attached to the newest node
+        //     with its (id, length) published so far -- the group's own node unless a LATER group with the same (id,
+        //     length), another history reaching the same word, has published in between;
+        //   - the others copy.
+        // So: rnn node of lane p = the last node with p's (id, length) published not later than the first lane through
+        // p's connection.  One round of ballots per group (one or two per boundary; the paths differ in part-of-speech
+        // far more often than in words); the first lanes of the connections are worked out only where a second group
+        // with the same (id, length) exists.  Equal hashes with different (id, length) -- a 64-bit collision inside one
+        // boundary of one sentence -- take the path-by-path replay below.
+        const u64 h = fh1_mix(curHash, (u64)(u32)myid | ((u64)len << 32));
+        const u32 prevMine = curB * G + curX;
+        u32 ncreate = 0;       // (node lanes) the lane that published the node
+        bool needFirst = false;
+        u64 collide = 0;
+        todo = act;
+        while (todo != 0) {
+          const int L = __builtin_ctzll(todo);
+          const u64 hv = (u64)wave_bcast_u32((u32)h, L) | ((u64)wave_bcast_u32((u32)(h >> 32), L) << 32);
+          const i32 idv = (i32)wave_bcast_u32((u32)myid, L);
+          const u32 lenv = wave_bcast_u32(len, L);
+          const u32 prevv = wave_bcast_u32(prevMine, L);
+          const bool inGroup = has && h == hv;
+          const bool sameWord = myid == idv && len == lenv;
+          collide |= wave_ballot(inGroup && !sameWord);
+          if (wave_ballot((u32)lane < cnt && nid == idv && nlen == lenv) != 0)   // a second history reaching this word
+            needFirst = needFirst || (has && sameWord && lane > L);
+          if ((u32)lane == cnt) {
+            nid = idv;
+            nlen = lenv;
+            nhash = hv;
+            nprev = prevv;
+            ncreate = (u32)L;
+          }
+          if (inGroup) myres = cnt;
+          cnt += 1;
+          todo &= ~wave_ballot(inGroup);
+        }
+        u64 newHash = h;
+#if defined(JPP_RNN_PREP_SERIAL)
+        collide = ~u64{0};   // (test builds: every boundary through the path-by-path replay)
+#endif
+        const u64 fix = wave_ballot(needFirst);
+        if (collide == 0 && fix != 0) {
+          // first lane through the connection, for the lanes that need it
+          u32 firstLane = (u32)lane;
+          todo = fix;
+          while (todo != 0) {
+            const int L = __builtin_ctzll(todo);
+            const u32 cL = wave_bcast_u32(c, L);
+            const u64 mConn = wave_ballot(has && c == cL);
+            if (has && c == cL) firstLane = (u32)__builtin_ctzll(mConn);
+            todo &= ~mConn;
+          }
+          for (u32 x = 0; x < cnt; ++x) {
+            const i32 idx = (i32)wave_bcast_u32((u32)nid, (int)x);
+            const u32 lenx = wave_bcast_u32(nlen, (int)x);
+            const u32 crx = wave_bcast_u32(ncreate, (int)x);
+            if (needFirst && myid == idx && len == lenx && crx <= firstLane) myres = x;
+          }
+          const u64 hres = (u64)wave_shfl_u32((u32)nhash, (int)myres) | ((u64)wave_shfl_u32((u32)(nhash >> 32), (int)myres) << 32);
+          if (needFirst) newHash = hres;
+        }
+        if (collide != 0) {
+          // path by path: the distinct connections in path order, the boundary's nodes searched with two ballots each
+          cnt = 0;
+          todo = act;
+          while (todo != 0) {
+            const int L = __builtin_ctzll(todo);
+            const u32 cL = wave_bcast_u32(c, L);
+            const bool inConn = has && c == cL;
+            const i32 idL = (i32)wave_bcast_u32((u32)myid, L);
+            const u32 lenL = wave_bcast_u32(len, L);
+            const u64 hL = (u64)wave_bcast_u32((u32)h, L) | ((u64)wave_bcast_u32((u32)(h >> 32), L) << 32);
+            const u32 prevL = wave_bcast_u32(prevMine, L);
+            const bool published = (u32)lane < cnt;
+            const u64 mSame = wave_ballot(published && nid == idL && nlen == lenL);
+            const u64 mHash = wave_ballot(published && nhash == hL);
+            const int it = mSame != 0 ? 63 - __builtin_clzll(mSame) : -1;
+            const bool merged = it >= 0 && (mHash & ((u64{2} << it) - 1)) != 0;
+            u32 res;
+            u64 nh;
             if (merged) {
-              assign[(u64)b * G + p] = (u32)it;
-              cur = b * G + (u32)it;
+              res = (u32)it;
+              nh = (u64)wave_bcast_u32((u32)nhash, it) | ((u64)wave_bcast_u32((u32)(nhash >> 32), it) << 32);
             } else {
-              rn_cnt[b] = cnt + 1;
-              rn_hash[(u64)b * G + cnt] = h;
-              rn_id[(u64)b * G + cnt] = id;
-              rn_len[(u64)b * G + cnt] = len;
-              rn_prev[(u64)b * G + cnt] = cur;
-              assign[(u64)b * G + p] = cnt;
-              cur = b * G + cnt;
+              res = cnt;
+              nh = hL;
+              if ((u32)lane == cnt) {
+                nid = idL;
+                nlen = lenL;
+                nhash = hL;
+                nprev = prevL;
+              }
+              cnt += 1;
             }
+            if (inConn) {
+              myres = res;
+              newHash = nh;
+            }
+            todo &= ~wave_ballot(inConn);
           }
         }
+        if (has) {
+          curHash = newHash;
+          curB = b;
+          curX = myres;
+        }
       }
-      wave_sync();
+      // back to the row's lanes
+      const int back = r == k ? (int)p : lane;
+      const u32 vA = wave_shfl_u32(has ? myres : 0xffu << 24, back);
+      if (r == k) outA = vA;
+      if (cnt != 0) {
+        const i32 vI = (i32)wave_shfl_u32((u32)nid, back);
+        const u32 vL = wave_shfl_u32(nlen, back), vP = wave_shfl_u32(nprev, back);
+        if (r == k) {
+          outId = vI;
+          outLen = vL;
+          outPrev = vP;
+          outCnt = cnt;
+        }
+      }
     }
+    JPP_PPROF(3);
+    const u32 bq = b0 + r;
+    if (r < rowsPer && bq <= bE) {
+      const u32 q = bq * G + p;
+      g_assign[q] = outA;
+      if (p < outCnt) {
+        g_id[q] = outId;
+        g_len[q] = outLen;
+        g_prev[q] = outPrev;
+      }
+      if (p == 0) g_cnt[bq] = outCnt;
+    }
+    JPP_PPROF(4);
   }
   wave_sync();
-  if (inLds) {
-    for (u32 q = lane; q < nq; q += 64) {
-      g_conn[q] = conn[q];
-      g_assign[q] = assign[q];
-      g_prev[q] = rn_prev[q];
-      g_id[q] = rn_id[q];
-      g_len[q] = rn_len[q];
-    }
-    for (u32 q = lane; q <= bE; q += 64) g_cnt[q] = rn_cnt[q];
-  }
   // dense hidden-state rows: node idx of boundary b lives in row rnn_noff[b] + idx of the sentence's slice of
   // rnn_ctx; row 0 = parking row (boundary 0), row 1 = BOS state (boundary 1), then the rnn nodes in boundary order
   {
     u32 carry = 0;
     for (u32 b0 = 0; b0 <= bE; b0 += 64) {
       const u32 b = b0 + (u32)lane;
-      const u32 c = b > bE ? 0u : b < 2 ? 1u : rn_cnt[b];
+      const u32 c = b > bE ? 0u : b < 2 ? 1u : g_cnt[b];
       const u32 incl = wave_scan_incl_u32(c, lane);
       if (b <= bE) B.rnn_noff[bb0 + b] = carry + incl - c;
       carry += wave_shfl_u32(incl, 63);
     }
     if (lane == 0) B.rnn_rows[s] = carry;
   }
+  JPP_PPROF(5);
+  JPP_PPROF_FLUSH;
 }
 
 // The rnn nodes of a sentence in hidden-state row order (round 5): one 16-byte record per row -- handle, word id, row of
