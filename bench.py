@@ -1029,8 +1029,8 @@ def config5_leg(args, cache, local_rank, np, torch, J):
         rs.release()
         sweep_bytes = ab['sweep'] * nodes / max(1.0, ab['nodes'])
         ach = sweep_bytes / (km['sweep'] * 1e-3) / 1e9
-        # the RNN block of this shape: bytes by SURVEY 8(d), flops of the recurrence (2 E^2 per rnn node); the sentences are
-        # beyond the LDS staging of k_rnn_chain, so the recurrence runs in k_rnn_score<.., 3> (W streamed from L2)
+        # the RNN block of this shape: bytes by SURVEY 8(d), flops of the recurrence (2 E^2 per rnn node); the recurrence
+        # of these long sentences runs in k_rnn_chain like everyone's (row records), their scores in k_rnn_score_long
         rnn_roof = None
         if args.rnn and km.get('rnn', 0) > 0:
             ctx.analyze_device(d[0][0].data_ptr(), d[0][1].data_ptr(), d[0][2], d[0][3], stream).release()
@@ -1039,7 +1039,7 @@ def config5_leg(args, cache, local_rank, np, torch, J):
             E = args.rnn_hidden
             rbytes = n_rnn * (2 * E * 4 + 12) + n_rnn * E * 4 * 2
             fl = n_rnn * 2.0 * E * E
-            rnn_roof = {'bound': 'hbm', 'kernels': 'k_rnn_paths + k_rnn_prep + k_rnn_order_* + k_rnn_chain + k_rnn_score<.., 2 / 3>',
+            rnn_roof = {'bound': 'hbm', 'kernels': 'k_rnn_paths + k_rnn_prep + k_rnn_dense + k_rnn_order_* + k_rnn_chain + k_rnn_score_long',
                         'achieved': round(rbytes / (km['rnn'] * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
                         'frac': round(rbytes / (km['rnn'] * 1e-3) / 1e9 / 8000.0, 5), 'algorithmic_bytes_per_step': int(rbytes),
                         'ms_per_step': round(km['rnn'], 3), 'rnn_nodes_per_sentence': round(n_rnn / batch, 1),
@@ -1270,7 +1270,7 @@ def main():
             n_rnn = max(0, st['rows'] - 2 * args.batch)
             E = args.rnn_hidden
             rbytes = n_rnn * (2 * E * 4 + 12) + n_rnn * E * 4 * 2
-            rnn_roof = {'bound': 'hbm', 'kernels': 'k_rnn_paths + k_rnn_prep + k_rnn_order_* + k_rnn_chain + k_rnn_score',
+            rnn_roof = {'bound': 'hbm', 'kernels': 'k_rnn_paths + k_rnn_prep + k_rnn_dense + k_rnn_order_* + k_rnn_chain + k_rnn_score',
                         'achieved': round(rbytes / (avg['rnn'] * 1e-3) / 1e9, 2), 'peak': 8000.0, 'unit': 'GB/s',
                         'frac': round(rbytes / (avg['rnn'] * 1e-3) / 1e9 / 8000.0, 5), 'algorithmic_bytes_per_step': int(rbytes),
                         'ms_per_step': round(avg['rnn'], 3), 'rnn_nodes_per_sentence': round(n_rnn / args.batch, 2)}

@@ -3,17 +3,17 @@
 //
 //   k_rnn_paths    one thread per (sentence, EOS path): walks the beam pointers back from EOS -- the lattice
 //                  connection of every surviving path at every boundary, its global-beam index, its node's length.
-//   k_rnn_prep     one wavefront per sentence: resolves the RNN vocabulary id of every node on the paths and replays
-//                  RnnIdContainer::addPath / addPrevChain exactly (including its attach-to-it->second quirk) to
-//                  obtain the RNN lattice: which rnn node scores which connection, and each rnn node's predecessor.
-//                  The replay is a skewed pipeline: lane p handles path p and reaches boundary b at step b + p, i.e.
-//                  after every earlier path has finished that boundary, which is the only ordering the sequential
-//                  algorithm depends on.
+//   k_rnn_prep     one wavefront per sentence: resolves the RNN vocabulary id of every node on the paths and builds the
+//                  RNN lattice of RnnIdContainer::addPath / addPrevChain exactly (including its attach-to-it->second
+//                  quirk): which rnn node scores which connection, and each rnn node's predecessor.  Boundary by
+//                  boundary, lane = path, all paths of a boundary at once (the rule that makes that exact is at the
+//                  kernel); everything in registers, the rows in and out coalesced.
+//   k_rnn_dense    the rnn nodes as one record per hidden-state row.
 //   k_rnn_order_*  counting sort of the sentences by the length of their recurrence.
 //   k_rnn_chain    the recurrence (hidden states of all rnn nodes before EOS) on the matrix cores, 32 sentences per
 //                  workgroup in lock step.
 //   k_rnn_score<J, SORT, 2>   maxent sums, NCE scores, score cells, adjustBeamScores, remakeEosBeam.
-//   k_rnn_score<J, SORT, 3>   everything, boundary by boundary, for sentences beyond the LDS staging limits.
+//   k_rnn_score_long<J, SORT> the same for sentences beyond the LDS staging limits of k_rnn_score (per-row scores).
 // E > 128 (up to 256): k_rnn_paths, k_rnn_prep, k_rnn_score<4, SORT, 0> (everything in one launch, W from L2).
 // The hidden vector of a node is spread over the lanes of its wavefront (EP = E rounded up to 64 / 128 / 256).
 //
@@ -669,7 +669,7 @@ constexpr u32 kRnnNodeCap = kRnnStageCap;               // rnn nodes of a staged
 // batch, because that launch then lasts as long as its slowest sentence)
 
 // whether a sentence's rnn lattice is staged in LDS by k_rnn_chain / k_rnn_score<.., 2>.  k_rnn_order_key files the
-// others in the last class, which k_rnn_score<.., 3> serves.
+// others in the last class, which k_rnn_score_long serves.
 __device__ __forceinline__ bool rnn_stageable(u32 bE, int G, int beam, u32 N) {
   const u32 nq = (bE + 1) * (u32)G;
   return nq <= kRnnStageCap && (bE + 1) <= kRnnStageCapB && (bE + 1) * (((u32)G + kRnnCN - 1) / kRnnCN) <= 2 * kRnnStageCapB &&
@@ -1121,7 +1121,7 @@ __global__ void __launch_bounds__(MODE == 3 ? 1024 : 256) k_rnn_score(Batch B, c
   const i32* rn_id = B.rnn_nid + (u64)bb0 * G;
   const u32* rn_cnt = B.rnn_cnt + bb0;
   const bool staged = MODE != 3 && rnn_stageable(bE, G, beam, N);
-  if (MODE == 2 && !staged) return;   // (k_rnn_score<.., 3> takes it)
+  if (MODE == 2 && !staged) return;   // (k_rnn_score_long takes it)
   const bool inLds = MODE == 2 || (MODE == 0 && staged);   // a compile-time constant in MODE 2 and 3
   if (inLds) {
     for (u32 q = lane; q < nq; q += 64) {

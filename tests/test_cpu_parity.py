@@ -88,8 +88,9 @@ def test_emulated_partition_branch_of_make_t0_beam(emu_lib, golden_dir, ref_tool
 
 @pytest.mark.parametrize('hidden', [48, 128])
 def test_emulated_rnn_staged_and_unstaged_sentences_in_one_batch(emu_lib, ref_tools, tmp_path, hidden):
-    """k_rnn_prep / k_rnn_score stage a sentence's beam records in LDS when it has at most 45 codepoints (global
-    beam 6) and read them from HBM otherwise: a batch with both kinds, bit-exact RNN scores (E = 48 and 128)."""
+    """k_rnn_score stages a sentence's beam records in LDS when it has at most 45 codepoints (global beam 6);
+    k_rnn_score_long serves the others from the row records: a batch with both kinds, bit-exact RNN scores
+    (E = 48 and 128)."""
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     import test_gpu_parity as tg
@@ -831,7 +832,8 @@ def test_emulated_maximum_size_sentences(emu_lib, ref_tools, tmp_path):
 
 def check_wide_beam_rnn_long_sentences(lib, ref_tools, tmp, n_lines=3, length=110):
     """the configs[4] shape with the RNN: beam = global beam = 32 on sentences far beyond the LDS staging of
-    k_rnn_prep / k_rnn_score (the rnn lattice is built in the HBM arrays, earlier paths found by shuffles)"""
+    k_rnn_score (k_rnn_prep: 32 paths side by side, several histories reaching the same word at one boundary;
+    k_rnn_score_long)"""
     import test_gpu_parity as tg
     beams = [32, 32, 1, 32]
     img, lines, gold_path = tg._fresh_workload(ref_tools, tmp, 2500, n_lines, 14, 29, length=length, rnn=(32, 600), beams=beams)
@@ -849,6 +851,20 @@ def test_emulated_wide_beam_rnn_long_sentences(emu_lib, ref_tools, tmp_path):
     if ref_tools is None:
         pytest.skip('oracle/_ref not built')
     check_wide_beam_rnn_long_sentences(emu_lib, ref_tools, str(tmp_path))
+
+
+def test_emulated_rnn_lattice_path_by_path_replay(golden_dir, ref_tools, tmp_path):
+    """k_rnn_prep builds a boundary's rnn nodes for all paths at once and keeps the reference's order of events -- one
+    distinct connection after the other, the boundary's nodes searched for each -- for boundaries where equal prefix
+    hashes carry different (id, length), which no corpus produces.  -DJPP_RNN_PREP_SERIAL sends every boundary that
+    way: the same goldens, default and wide beams."""
+    import __graft_entry__ as ge
+    lib = ge.build_emu_variant('serial', ['-DJPP_RNN_PREP_SERIAL'])
+    _run_golden(lib, golden_dir, 'mini_rnn.gold', image='mini_rnn.img')
+    _run_golden(lib, golden_dir, 'mini_rnn_b4g12.gold', image='mini_rnn.img', n_lines=8, beam=4, global_beam=12,
+                right_check=1, right_beam=4)
+    if ref_tools is not None:
+        check_wide_beam_rnn_long_sentences(lib, ref_tools, str(tmp_path), n_lines=2, length=80)
 
 
 def check_long_sentence_connectivity(lib, ref_tools, tmp):
