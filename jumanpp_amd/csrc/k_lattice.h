@@ -9,6 +9,8 @@
 #ifndef JPP_K_LATTICE_H
 #define JPP_K_LATTICE_H
 
+#include <type_traits>
+
 #include "jpp_device.h"
 
 namespace jpp {
@@ -384,7 +386,9 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_connect(Batch B) {
 
 // BOS/EOS nodes, UNK entry pointers, ends lists.  One wavefront per sentence: the node ends are staged
 // in LDS, then one lane per boundary collects the nodes ending there in node order (= seed order,
-// LatticeBuilder::fillEnds).  Sentences with more than kEndsNodeCap nodes run sequentially on lane 0.
+// LatticeBuilder::fillEnds).  Sentences with more than kEndsNodeCap nodes read the ends from the node table instead
+// (until round 5 they ran sequentially on lane 0: one such sentence in a batch of 220-codepoint sentences, 1 454 nodes on
+// average, held the launch for 1.1 ms instead of 0.36, profiles/r05_y_bench.json config5.kernel_ms_per_step.layout).
 constexpr u32 kEndsNodeCap = 2048;
 
 // UNK entry pointers are numbered in CREATION order, like the reference's: ExtraNodesContext::allocateExtra
@@ -423,7 +427,8 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
     ni[N - 1] = NodeInfo{kEptrEOS, (u16)n, (u16)n};
     na[0] = na[1] = na[N - 1] = NodeAux{0, 0, 0, 0, 0, 0};
   }
-  if (N <= kEndsNodeCap) {
+  const bool staged = N <= kEndsNodeCap;
+  {
     // UNK entry pointers ~0, ~1, ... in creation order; stage the ends.  k_seeds left -(1 + rank of the maker) in the
     // entry pointer of every UNK node.  First the number of UNK nodes per maker (wave-uniform counters), ...
     u32 ubase[kMaxUnkMakers];
@@ -472,7 +477,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
           ni[k] = x;
         }
       }
-      if (act) l_end[k] = x.end;
+      if (act && staged) l_end[k] = x.end;
       const u32 len = act ? (u32)x.end - (u32)x.start : 0u;
       const u32 ml = wave_max_u32(len);
       if (ml > maxLen) maxLen = ml;
@@ -482,6 +487,11 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
     // the nodes that end at position `want` are among those that start at want - maxLen .. want - 1, a few dozen
     // (round 4; until then every lane went over all nodes of the sentence, twice: 2 ms per batch of 220-codepoint
     // sentences).
+    // (two copies of the loop, chosen once per sentence: a per-node choice between the LDS copy and the node table costs
+    // the common case 0.15 ms per batch -- measured, r05x)
+    auto fill = [&](auto stagedTag) {
+    constexpr bool kStaged = decltype(stagedTag)::value;
+    auto end_of = [&](u32 k) -> u32 { return kStaged ? (u32)l_end[k] : (u32)ni[k].end; };
     u32 carry = 0;
     for (u32 b0 = 0; b0 <= n + 2; b0 += 64) {
       const u32 b = b0 + (u32)lane;
@@ -492,7 +502,7 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
         const u32 want = b - 2;
         klo = B.bnd_first[bb0 + (b - 2 > maxLen ? b - maxLen : 2u)];
         khi = B.bnd_first[bb0 + b];   // (nodes that start at `want` end later)
-        for (u32 k = klo; k < khi; ++k) cnt += (l_end[k] == want) ? 1u : 0u;
+        for (u32 k = klo; k < khi; ++k) cnt += (end_of(k) == want) ? 1u : 0u;
       }
       const u32 incl = wave_scan_incl_u32(cnt, lane);
       const u32 first = carry + incl - cnt;
@@ -507,44 +517,13 @@ __global__ void __launch_bounds__(64 * kLatWaves) k_ends(Batch B, Config cfg, Un
         if (b >= 2) {
           const u32 want = b - 2;
           for (u32 k = klo; k < khi; ++k)
-            if (l_end[k] == want) en[w++] = k;
+            if (end_of(k) == want) en[w++] = k;
         }
       }
     }
-  } else if (lane == 0) {
-    for (u32 b = 0; b <= n + 2; ++b) ecnt[b] = 0;
-    ecnt[1] = 1;
-    ecnt[2] = 1;
-    u32 ubase[kMaxUnkMakers];
-    for (int c = 0; c < kMaxUnkMakers; ++c) ubase[c] = 0;
-    for (u32 k = 2; k + 1 < N; ++k)
-      if (ni[k].eptr < 0) ubase[(u32)(-1 - ni[k].eptr) & (kMaxUnkMakers - 1)] += 1;
-    for (u32 c = 0, acc = 0; c < (u32)kMaxUnkMakers; ++c) {
-      const u32 v = ubase[c];
-      ubase[c] = acc;
-      acc += v;
-    }
-    for (u32 k = 2; k + 1 < N; ++k) {
-      NodeInfo x = ni[k];
-      if (x.eptr < 0) {
-        x.eptr = ~(i32)(ubase[(u32)(-1 - x.eptr) & (kMaxUnkMakers - 1)]++);
-        ni[k] = x;
-      }
-      ecnt[x.end + 2] += 1;
-    }
-    u32 acc = 0;
-    for (u32 b = 0; b <= n + 2; ++b) {
-      efirst[b] = acc;
-      acc += ecnt[b];
-      ecnt[b] = 0;
-    }
-    en[efirst[1] + ecnt[1]++] = 0;
-    en[efirst[2] + ecnt[2]++] = 1;
-    for (u32 k = 2; k + 1 < N; ++k) {
-      u32 b = (u32)ni[k].end + 2;
-      en[efirst[b] + ecnt[b]++] = k;
-    }
-    for (u32 b = 0; b <= n + 2; ++b) B.bnd_meta[bb0 + b] = BndMeta{B.bnd_first[bb0 + b], B.bnd_cnt[bb0 + b], efirst[b], ecnt[b]};
+    };
+    if (staged) fill(std::true_type{});
+    else fill(std::false_type{});
   }
   // BOS beams (reference AnalyzerImpl::bootstrapAnalysis, analyzer_impl.cc:179-195)
   BeamSlot* bm = B.node_beam + nb * cfg.beam;
