@@ -63,10 +63,16 @@ class ScoreComputer {
   virtual Status scoreLattice(const jppgpu_result_view& lattice, uint32_t scorerIdx, float* cells) = 0;
 };
 
-// core::analysis::ScorerFactory (score_api.h:61-64)
+// core::analysis::ScorerFactory (score_api.h:61-64).  `load` is the owner's call, as in the reference (RnnHolder::load ->
+// RnnScorerGbeamFactory::load(ModelInfo), src/core/env.cc:52-63): a factory reads what it needs from the loaded model
+// -- the ModelImage stands where the reference passes model::ModelInfo -- before analyzers are made from it.
 class ScorerFactory {
  public:
   virtual ~ScorerFactory() = default;
+  virtual Status load(const ModelImage& model) {
+    (void)model;
+    return Status::Ok();
+  }
   virtual Status makeInstance(std::unique_ptr<ScoreComputer>* result) = 0;
   // the model's own RNN (RnnScorerGbeamFactory): scored by the device kernels, no ScoreComputer instance is made
   virtual bool isModelRnn() const { return false; }
@@ -75,6 +81,11 @@ class ScorerFactory {
 // the RnnHolder's scorer factory (src/core/analysis/rnn_scorer_gbeam.h): stands for the RNN part of the loaded model
 class ModelRnnScorerFactory : public ScorerFactory {
  public:
+  // RnnScorerGbeamFactory::load fails on a model without an RNN part (rnn_scorer_gbeam.cc:377-393)
+  Status load(const ModelImage& model) override {
+    if (!model.hasRnn()) return Status::InvalidState("the model has no RNN part");
+    return Status::Ok();
+  }
   Status makeInstance(std::unique_ptr<ScoreComputer>*) override { return Status::Ok(); }
   bool isModelRnn() const override { return true; }
 };

@@ -46,7 +46,13 @@ struct TestScorer : public ScoreComputer {
   }
 };
 struct TestScorerFactory : public ScorerFactory {
+  bool loaded = false;
+  Status load(const ModelImage& model) override {   // ScorerFactory::load(ModelInfo): what the scorer reads from the model
+    loaded = model.numFeatures() > 0;
+    return Status::Ok();
+  }
   Status makeInstance(std::unique_ptr<ScoreComputer>* result) override {
+    if (!loaded) return Status::InvalidState("TestScorerFactory: load() was not called");
     result->reset(new TestScorer());
     return Status::Ok();
   }
@@ -89,10 +95,17 @@ int main(int argc, char** argv) {
   RnnScoreWeights w = model.savedScoreWeights();
   def.scoreWeights.push_back(useRnn ? w.perceptron : 1.0f);
   if (useRnn) {
+    s = rnn.load(model);
+    if (!s) { std::cerr << s << "\n"; return 1; }
     def.others.push_back(&rnn);   // the reference's RnnHolder factory, first in `others`
     def.scoreWeights.push_back(w.rnn);
+  } else if (model.hasRnn() == false && rnn.load(model)) {
+    std::cerr << "ModelRnnScorerFactory::load accepted a model without an RNN part\n";
+    return 1;
   }
   if (std::strcmp(argv[3], "none") != 0) {
+    s = factory.load(model);
+    if (!s) { std::cerr << s << "\n"; return 1; }
     def.others.push_back(&factory);
     def.scoreWeights.push_back((float)std::atof(argv[3]));
   }
