@@ -9,7 +9,18 @@ namespace jumanpp_amd {
 namespace {
 
 inline void put(std::string& p, StringPiece s) { p.append(s.data(), s.size()); }
-inline void putInt(std::string& p, long long v) { p += std::to_string(v); }
+inline void putInt(std::string& p, long long v) {
+  char buf[24];
+  char* e = buf + sizeof(buf);
+  char* q = e;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do {
+    *--q = (char)('0' + u % 10);
+    u /= 10;
+  } while (u != 0);
+  if (v < 0) *--q = '-';
+  p.append(q, (size_t)(e - q));
+}
 // the reference prints floats through fmt's BasicWriter << double, i.e. printf("%g")
 inline void putFloat(std::string& p, float v) {
   char buf[48];
@@ -62,72 +73,82 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
   const float* cells = nullptr;
   uint32_t eos = 0;
   const jppgpu_beam_slot fakeSlot{0xffff, 0xffff, 0.f, 0xffffffffu, 0};
-  nbItems_.clear();
+  const jppgpu_nbest_item* nbFirst = nullptr;   // (n-best view) the records of this sentence's paths, path after path
+  const uint64_t* nbPath = nullptr;
   if (nbv != nullptr) {
     if (nbv->n_best < std::min<int32_t>(beam, outputN)) return Status::InvalidState("n-best view holds fewer paths than the format prints");
-    const uint64_t p0 = (uint64_t)local * (uint32_t)nbv->n_best;
-    for (uint64_t q = nbv->path_first[p0]; q < nbv->path_first[p0 + (uint32_t)nbv->n_best]; ++q) {
-      const jppgpu_nbest_item& it = nbv->items[q];
-      nbItems_.emplace(((uint64_t)it.node << 8) | it.slot, &it);
-    }
+    nbFirst = nbv->items;
+    nbPath = nbv->path_first + (uint64_t)local * (uint32_t)nbv->n_best;
   } else {
     const uint64_t nb = v.node_base[local];
     beams = v.beams + nb * (uint64_t)beam;
     cells = v.cells + nb * (uint64_t)G * S;
     eos = s.numNodes - 1;
   }
-  auto itemOf = [&](uint32_t node, uint32_t slot) -> const jppgpu_nbest_item* {
-    auto f = nbItems_.find(((uint64_t)node << 8) | slot);
-    return f == nbItems_.end() ? nullptr : f->second;
-  };
   auto eosSlot = [&](int32_t i) -> const jppgpu_beam_slot& {
     if (nbv != nullptr) return i < nbv->n_best ? nbv->eos[(uint64_t)local * (uint32_t)nbv->n_best + (uint32_t)i] : fakeSlot;
     return beams[(uint64_t)eos * beam + i];
   };
-  auto slotOf = [&](uint32_t node, uint32_t slot) -> const jppgpu_beam_slot& {
-    if (nbv != nullptr) {
-      const jppgpu_nbest_item* it = itemOf(node, slot);
-      return it ? it->beam : fakeSlot;
-    }
-    return beams[(uint64_t)node * beam + slot];
-  };
-  auto cellsOf = [&](uint32_t node, uint32_t slot) -> const float* {
-    if (nbv != nullptr) {
-      const jppgpu_nbest_item* it = itemOf(node, slot);
-      return it ? it->cells : fakeCells_;
-    }
-    return cells + ((uint64_t)node * G + beams[(uint64_t)node * beam + slot].pad) * S;
-  };
 
   // LatticeFormatInfo::fillInfo (lattice_format.cc:13-43)
+  for (uint32_t nd : order_) infoOf_[nd] = -1;
+  order_.clear();
   info_.clear();
-  const int32_t maxN = std::min<int32_t>(beam, outputN);
+  if (infoOf_.size() < s.numNodes) infoOf_.resize(s.numNodes, -1);
+  const int32_t maxN = std::min<int32_t>(std::min<int32_t>(beam, outputN), kMaxPaths);
   for (int32_t i = 0; i < maxN; ++i) {
     const jppgpu_beam_slot& el = eosSlot(i);
     if (isFake(el)) break;
     uint32_t node = el.prev_node;
     uint32_t slot = el.beam;
+    // (n-best view) the connections of path i lie in path order, from the one the EOS slot points at back to BOS (k_nbest)
+    uint64_t q = nbv != nullptr ? nbPath[i] : 0;
+    const uint64_t qEnd = nbv != nullptr ? nbPath[i + 1] : 0;
     while (node >= 2 && node != 0xffffffffu) {
-      const jppgpu_beam_slot& c = slotOf(node, slot);
+      const jppgpu_nbest_item* item = nullptr;
+      if (nbv != nullptr) {
+        if (q >= qEnd || nbFirst[q].node != node || nbFirst[q].slot != slot) {
+          return Status::InvalidState("n-best view does not cover a path of the lattice format");
+        }
+        item = &nbFirst[q++];
+      }
+      if (node >= s.numNodes) return Status::InvalidState("lattice format: node outside the sentence");
+      const jppgpu_beam_slot& c = item ? item->beam : beams[(uint64_t)node * beam + slot];
       if (isFake(c)) return Status::InvalidState("n-best view does not cover a path of the lattice format");
-      NodeInfo& ni = info_[node];
-      ni.ranks.push_back((uint16_t)i);
-      if (std::find(ni.slots.begin(), ni.slots.end(), slot) == ni.slots.end()) ni.slots.push_back(slot);
+      int32_t at = infoOf_[node];
+      if (at < 0) {
+        at = infoOf_[node] = (int32_t)info_.size();
+        info_.emplace_back();
+        info_.back().node = node;
+        order_.push_back(node);
+      }
+      NodeInfo& ni = info_[at];
+      ni.ranks[ni.nRanks++] = (uint16_t)i;
+      uint16_t k = 0;
+      while (k < ni.nSlots && ni.slots[k] != slot) ++k;
+      if (k == ni.nSlots) {
+        ni.slots[k] = (uint16_t)slot;
+        ni.items[k] = item;
+        ni.nSlots++;
+      }
       const uint32_t pnode = c.prev_node;
-      if (std::find(ni.prev.begin(), ni.prev.end(), pnode) == ni.prev.end()) ni.prev.push_back(pnode);
+      k = 0;
+      while (k < ni.nPrev && ni.prev[k] != pnode) ++k;
+      if (k == ni.nPrev) ni.prev[ni.nPrev++] = pnode;
       node = pnode;
       slot = c.beam;
     }
   }
   // publishResult: prev lists sorted by (boundary, position) = node id; ids from 1 in node order
+  std::sort(order_.begin(), order_.end());
   int32_t nextId = 1;
-  for (auto& kv : info_) {
-    std::sort(kv.second.prev.begin(), kv.second.prev.end());
-    kv.second.id = nextId++;
+  for (uint32_t nd : order_) {
+    NodeInfo& ni = info_[infoOf_[nd]];
+    std::sort(ni.prev, ni.prev + ni.nPrev);
+    ni.id = nextId++;
   }
   auto idOf = [&](uint32_t node) -> int32_t {
-    auto it = info_.find(node);
-    return it == info_.end() ? 0 : it->second.id;
+    return node < infoOf_.size() && infoOf_[node] >= 0 ? info_[infoOf_[node]].id : 0;
   };
 
   std::string& printer = printer_;
@@ -150,18 +171,21 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
   }
 
   OutputManager om(model_);
-  for (auto& kv : info_) {
-    const uint32_t node = kv.first;
-    const NodeInfo& ni = kv.second;
-    const jppgpu_nbest_item* rec = nbv != nullptr ? itemOf(node, ni.slots[0]) : nullptr;
+  for (uint32_t node : order_) {
+    const NodeInfo& ni = info_[infoOf_[node]];
+    const jppgpu_nbest_item* rec = ni.items[0];
     const jppgpu_node& nd = rec ? rec->info : s.nodes[node];
     if (!(rec ? om.locate(s, rec->info, rec->unk, &walker_) : om.locate(s, node, &walker_))) {
       return Status::InvalidState() << "failed to locate node: " << (nd.start + 2) << ":" << node;
     }
+    auto cellsOf = [&](uint16_t k) -> const float* {
+      if (nbv != nullptr) return ni.items[k]->cells;
+      return cells + ((uint64_t)node * G + beams[(uint64_t)node * beam + ni.slots[k]].pad) * S;
+    };
     // std::max_element with `total1 > total2` as the ordering (lattice_format.cc:129-141) selects the
     // connection with the SMALLEST weighted score among those the N best paths use (first one on ties)
-    auto total = [&](uint32_t slot) {
-      const float* sc = cellsOf(node, slot);
+    auto total = [&](uint16_t k) {
+      const float* sc = cellsOf(k);
       // `total += s[i] * weights[i]`: one fused multiply-add per scorer in the reference's FMA build
       // (-march=native / haswell; the same contraction as in adjustBeamScores), so near-equal connections
       // compare as they do there
@@ -169,23 +193,23 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
       for (size_t i = 0; i < weights_.size(); ++i) t = std::fma(sc[i], weights_[i], t);
       return t;
     };
-    uint32_t best = ni.slots[0];
-    float bestTotal = total(best);
-    for (size_t q = 1; q < ni.slots.size(); ++q) {
-      float t = total(ni.slots[q]);
+    uint16_t best = 0;
+    float bestTotal = total(0);
+    for (uint16_t q = 1; q < ni.nSlots; ++q) {
+      float t = total(q);
       if (bestTotal > t) {
-        best = ni.slots[q];
+        best = q;
         bestTotal = t;
       }
     }
-    const float* scores = cellsOf(node, best);
+    const float* scores = cellsOf(best);
     while (walker_.next()) {
       put(printer, "-\t");
       putInt(printer, ni.id);
       printer += '\t';
-      for (size_t i = 0; i < ni.prev.size(); ++i) {
+      for (uint16_t i = 0; i < ni.nPrev; ++i) {
         putInt(printer, idOf(ni.prev[i]));
-        if (i != ni.prev.size() - 1) printer += ';';
+        if (i + 1 != ni.nPrev) printer += ';';
       }
       printer += '\t';
       const int32_t position = nd.start;  // cptr.boundary - 2
@@ -258,9 +282,9 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
       putFloat(printer, totalScore);
       printer += '|';
       put(printer, "ランク:");
-      for (size_t i = 0; i < ni.ranks.size(); ++i) {
+      for (uint16_t i = 0; i < ni.nRanks; ++i) {
         putInt(printer, ni.ranks[i] + 1);
-        if (i != ni.ranks.size() - 1) printer += ';';
+        if (i + 1 != ni.nRanks) printer += ';';
       }
       printer += '\n';
     }

@@ -6,8 +6,6 @@
 #ifndef JUMANPP_AMD_HOST_LATTICE_FORMAT_H
 #define JUMANPP_AMD_HOST_LATTICE_FORMAT_H
 
-#include <map>
-#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -16,21 +14,27 @@
 namespace jumanpp_amd {
 
 class LatticeFormat : public OutputFormat {
-  // LatticeNodeInfo (lattice_format.h:17-25) keyed by sentence-local node id, which is already
-  // ordered by (boundary, position) like publishResult's sort
+  // LatticeNodeInfo (lattice_format.h:17-25) of the nodes on the printed paths.  Flat records reused from sentence to
+  // sentence (the reference keeps a map of vectors per node: at beam 32 on 220-codepoint sentences that bookkeeping,
+  // not the printing, was most of the 0.8 ms a sentence cost -- round 5): at most kMaxPaths ranks, distinct beam slots
+  // (= the ConnectionPtr set) and distinct previous nodes per node.
+  static constexpr int kMaxPaths = 64;
   struct NodeInfo {
-    std::vector<uint16_t> ranks;
-    std::vector<uint32_t> prev;    // distinct previous lattice nodes
-    std::vector<uint32_t> slots;   // distinct beam slots of this node = the ConnectionPtr set
+    uint32_t node = 0;
     int32_t id = 0;
+    uint16_t nRanks = 0, nSlots = 0, nPrev = 0;
+    uint16_t ranks[kMaxPaths];
+    uint16_t slots[kMaxPaths];
+    const jppgpu_nbest_item* items[kMaxPaths];   // (n-best view) the record of (node, slots[k])
+    uint32_t prev[kMaxPaths];
   };
   const ModelImage* model_ = nullptr;
   JumandicFields flds_;
   std::string printer_;
   NodeWalker walker_;
-  std::map<uint32_t, NodeInfo> info_;
-  std::unordered_map<uint64_t, const jppgpu_nbest_item*> nbItems_;  // (node << 8 | slot) of the n-best view
-  float fakeCells_[2] = {0.f, 0.f};
+  std::vector<NodeInfo> info_;          // in order of first visit
+  std::vector<int32_t> infoOf_;         // sentence-local node -> index in info_, -1 (reset through order_)
+  std::vector<uint32_t> order_;         // the visited nodes sorted by id = (boundary, position), publishResult's order
   int32_t topN_ = 1;
   std::vector<float> weights_;
 
