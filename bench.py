@@ -858,7 +858,9 @@ def config5_cli_lattice(args, cache, ge, np):
         best, rates = None, []
         for _ in range(2):
             t0 = time.perf_counter()
-            p = subprocess.run([cli, '--model=' + model, '--batch=%d' % batch, '--timing', '-o', out_path] + flags + [corpus],
+            # (no --batch: for lattice output the CLI sizes its batches so that the gathered N best paths stay below 1 GB,
+            # 3 072 sentences here; with --batch=16384 the same command runs at 17-21 k sentences/s, profiles/r05_t_*)
+            p = subprocess.run([cli, '--model=' + model, '--timing', '-o', out_path] + flags + [corpus],
                                capture_output=True, text=True)
             wall = time.perf_counter() - t0
             if p.returncode != 0:
@@ -869,9 +871,10 @@ def config5_cli_lattice(args, cache, ge, np):
                 best = (kv.get('sent_per_s', 0.0), kv, wall)
         rate, kv, wall = best
         size = os.path.getsize(out_path)
-        res = {'what': 'jumanpp_gpu %s --batch=%d corpus -o file: %d sentences x 220 codepoints, N-best lattice format written '
+        res = {'what': 'jumanpp_gpu %s corpus -o file: %d sentences x 220 codepoints, N-best lattice format written '
                        '(%.0f MB); the 32 best paths are gathered on the device (k_nbest), the lattice text is printed by the host '
-                       'format workers; best of 2 runs' % (' '.join(flags), batch, 2 * batch, size / 1e6),
+                       'format workers; batches of %d sentences (the CLI\'s choice for lattice output); best of 2 runs'
+                       % (' '.join(flags), 2 * batch, size / 1e6, int(kv.get('batch_lines', 0))),
                'value': round(rate, 1), 'unit': 'sentences/s', 'runs': rates, 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
                'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
                'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},

@@ -66,6 +66,7 @@ struct Conf {
   int beam = 5, globalBeam = 6, rightCheck = 1, rightBeam = 5;  // jumanpp_args.h:50-54
   bool noRnn = false;
   size_t batch = 65536;
+  bool batchGiven = false;    // --batch on the command line or in the config file: taken as it is
   int device = 0;
   std::vector<int> devices;   // --devices=LIST: one analysis thread (and analyzer pair) per listed GPU
   std::string output;
@@ -330,7 +331,10 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (argValue(argc, argv, i, "--global-beam", &v)) conf.globalBeam = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--right-check", &v)) conf.rightCheck = std::atoi(v.c_str());
     else if (argValue(argc, argv, i, "--right-beam", &v)) conf.rightBeam = std::atoi(v.c_str());
-    else if (argValue(argc, argv, i, "--batch", &v)) conf.batch = (size_t)std::atoll(v.c_str());
+    else if (argValue(argc, argv, i, "--batch", &v)) {
+      conf.batch = (size_t)std::atoll(v.c_str());
+      conf.batchGiven = true;
+    }
     else if (argValue(argc, argv, i, "--devices", &v)) {
       // comma-separated ordinals and ranges: 0-7, 0,2,5, 0-3,6
       conf.devices.clear();
@@ -476,7 +480,7 @@ int main(int argc, const char** argv) {
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
-                 "Batching:  --batch=65536 sentences per GPU launch, --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache, --clean-exit,\n"
+                 "Batching:  --batch=65536 sentences per GPU launch (lattice output: fewer by default, so that the gathered N best paths of a batch stay below 1 GB), --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache, --clean-exit,\n"
                  "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format),\n"
                  "           --pipelines-per-device=2 (bulk runs: analysis threads, each with its analyzer pair, per GPU)\n";
     return 1;
@@ -542,6 +546,28 @@ int main(int argc, const char** argv) {
   StringPiece emptyResult = "# ERROR\nEOS\n";
   const bool latticeFormat = conf.lattice != 0;
   const bool useLattice = latticeFormat || conf.kind == Conf::DicSubset;  // formats that read the whole lattice
+  if (latticeFormat && !conf.batchGiven && !conf.inputs.empty()) {
+    // The lattice format reads the N best paths of every sentence as the device gathers them (jppgpu_result_fetch_nbest:
+    // 64 B per path and node).  At beam 32 on 220-codepoint sentences that is 0.2 MB per sentence; a 16 384-sentence
+    // batch moves 3.3 GB through fresh host pages and the analysis stage spends five times the GPU's time on it
+    // (tools/gpu_cli_lattice_probe.py: 20.8 k sentences/s at --batch=16384, 36.2 k at 8192, 48.8 k at 4096).  Unless the
+    // user names a batch size, a batch's gathered paths stay below ~1 GB: nodes per path estimated from the mean line.
+    std::ifstream f(conf.inputs[0], std::ios::binary);
+    std::vector<char> buf(size_t{1} << 20);
+    f.read(buf.data(), (std::streamsize)buf.size());
+    const size_t got = (size_t)f.gcount();
+    size_t lines = 0;
+    for (size_t i = 0; i < got; ++i) lines += buf[i] == '\n';
+    if (got != 0 && lines != 0) {
+      const double meanLine = (double)got / (double)lines;
+      const double nodesPerPath = std::max(4.0, meanLine / 5.0);   // ~3 bytes per codepoint, ~1.7 codepoints per node
+      const double paths = (double)(conf.lattice == -1 ? conf.beam : conf.lattice);
+      const double perSentence = std::max(1.0, std::min(paths, 64.0)) * nodesPerPath * 64.0;
+      size_t cap = (size_t)(1.0e9 / perSentence);
+      cap = std::max<size_t>(1024, cap / 1024 * 1024);
+      if (cap < conf.batch) conf.batch = cap;
+    }
+  }
   if (!latticeFormat && (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph)) emptyResult = "# ERROR\n";
   if (!latticeFormat && (conf.kind == Conf::Segment || conf.kind == Conf::DicSubset)) emptyResult = "";
   auto makeFormat = [&](Status* st) -> OutputFormat* {

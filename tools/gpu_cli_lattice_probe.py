@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""(GPU box, developer tool) the configs[4] command through the CLI -- beam 32, -s 32 lattice output -- on a corpus
+four times the bench leg's (65 536 sentences x 220 codepoints, 3.2 GB of text) at several --batch sizes: what the
+binary sustains once both analyzers of a pipeline have warm result buffers (the bench leg's two batches are both
+cold)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+import __graft_entry__ as ge
+
+args = bench.build_parser().parse_args([])
+args.sent_len = 220
+cache = os.path.join(tempfile.gettempdir(), 'jppgpu_bench_cache')
+mdic, model, img = bench.make_workload(args, cache)
+corpus = bench.make_corpus(args, mdic, cache, 65536, 31)
+cli = ge.build_host()
+out = os.path.join(cache, 'probe_out.txt')
+flags = ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '32']
+for batch in [int(x) for x in (sys.argv[1:] or ['16384', '8192', '4096'])]:
+    p = subprocess.run([cli, '--model=' + model, '--batch=%d' % batch, '--timing', '-o', out] + flags + [corpus],
+                       capture_output=True, text=True)
+    kv = bench._timing_kv(p.stderr)
+    print('batch %6d: %8.0f sentences/s  wall %7.1f ms  gpu %7.1f  analyze %7.1f  format %7.1f  write %7.1f  reserve %7.1f  rc %d' % (
+        batch, kv.get('sent_per_s', 0), kv.get('wall_ms', 0), kv.get('gpu_ms', 0), kv.get('analyze_ms', 0), kv.get('format_ms', 0),
+        kv.get('write_ms', 0), kv.get('reserve_ms', 0), p.returncode))
+    if os.path.exists(out):
+        os.remove(out)
