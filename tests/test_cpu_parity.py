@@ -867,6 +867,28 @@ def test_emulated_rnn_lattice_path_by_path_replay(golden_dir, ref_tools, tmp_pat
         check_wide_beam_rnn_long_sentences(lib, ref_tools, str(tmp_path), n_lines=2, length=80)
 
 
+@pytest.mark.parametrize('beams', [[3, 7, 1, 3], [8, 16, 2, 8], [16, 31, 1, 16]])
+def test_emulated_rnn_lattice_beam_shapes(emu_lib, ref_tools, tmp_path, beams):
+    """k_rnn_prep packs 64 / G boundaries into a round (G = global beam): global beams that do not divide 64, leave idle
+    lanes in a round or fill half a wavefront, on sentences long enough for several histories to reach the same word;
+    the all-paths-at-once construction and the path-by-path replay against the reference's lattice, cells and EOS beam."""
+    if ref_tools is None:
+        pytest.skip('oracle/_ref not built')
+    import __graft_entry__ as ge
+    import test_gpu_parity as tg
+    img, lines, gold_path = tg._fresh_workload(ref_tools, str(tmp_path), 2500, 6, 14, 37 + beams[1], length=70, rnn=(32, 600),
+                                               beams=beams)
+    meta, gold = G.read_gold(gold_path)
+    assert meta['nscorers'] == 2
+    for lib in (emu_lib, ge.build_emu_variant('serial', ['-DJPP_RNN_PREP_SERIAL'])):
+        ctx = J.Context(img, lib_path=lib, beam=beams[0], global_beam=beams[1], right_check=beams[2], right_beam=beams[3])
+        res = ctx.analyze(lines).fetch(full=True)
+        errs = []
+        for s in range(len(lines)):
+            errs += G.compare_sentence(res, s, gold[s], meta)
+        assert not errs, (lib, errs[:10])
+
+
 def check_long_sentence_connectivity(lib, ref_tools, tmp):
     """sentences of more than 63 codepoints through k_connect's sliding window: plain ones, ones with a node longer
     than the window (a run of 70 / 150 digits: the sequential pass), ones whose stretches of unknown characters only
