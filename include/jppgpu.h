@@ -274,7 +274,8 @@ typedef struct jppgpu_reserve {
   uint32_t reserved;
 } jppgpu_reserve;
 /* the derived T0 records of a context made with keep_t0_memo_image (host memory owned by the context's model copy, valid
- * until its last context is destroyed); *bytes = 0 when the context has none.  jppgpu_t0_memo_format: changes whenever
+ * until its last context is destroyed; jppgpu_ctx_set_weights refills the same storage in place -- the pointer stays
+ * valid, the records must not be read while that call runs); *bytes = 0 when the context has none.  jppgpu_t0_memo_format: changes whenever
  * the record layout or its arithmetic does -- part of a cache key. */
 int jppgpu_ctx_t0_memo_image(jppgpu_ctx* ctx, const void** data, uint64_t* bytes, uint32_t* slots);
 uint64_t jppgpu_t0_memo_format(void);

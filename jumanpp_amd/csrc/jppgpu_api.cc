@@ -458,6 +458,7 @@ struct ModelBufs {
   std::vector<DevBuf> field_blobs;       // column storages of the length primitives (DevSpec::storages)
   bool t0_memo_from_image = false;       // uploaded from jppgpu_config::t0_memo_image: no seeds to rebuild it from
   std::vector<T0Memo> t0_memo_host;      // keep_t0_memo_image: what jppgpu_ctx_t0_memo_image hands out
+  bool keep_memo_host = false;           // ... refilled in place by jppgpu_ctx_set_weights
   // output text on the device (jppgpu_ctx_set_format_table)
   bool fmt_have = false;
   DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table;
@@ -864,14 +865,17 @@ void fill_memo(const std::vector<ModelBufs::MemoSeed>& seeds, const float* weigh
 }
 
 bool upload_memo(jppgpu_ctx* ctx, const float* weights, bool keep_host = false) {
-  std::vector<T0Memo> table((size_t)ctx->mb->t0_memo_slots);
+  // A copy made with keep_t0_memo_image keeps its host records for good: jppgpu_ctx_set_weights refills them IN PLACE
+  // (same storage: a pointer jppgpu_ctx_t0_memo_image handed out stays valid until the last context is destroyed)
+  ctx->mb->keep_memo_host = ctx->mb->keep_memo_host || keep_host;
+  std::vector<T0Memo> local;
+  std::vector<T0Memo>& table = ctx->mb->keep_memo_host ? ctx->mb->t0_memo_host : local;
+  if (table.size() != (size_t)ctx->mb->t0_memo_slots) table.resize((size_t)ctx->mb->t0_memo_slots);
   memset(static_cast<void*>(table.data()), 0, table.size() * sizeof(T0Memo));
   fill_memo(ctx->mb->t0_memo_seeds, weights, ctx->hmodel.wmask, &table);
   if (!ctx->mb->t0_memo.ensure(table.size() * sizeof(T0Memo))) return false;
   rt_h2d(ctx->mb->t0_memo.p, table.data(), table.size() * sizeof(T0Memo), nullptr);
   rt_sync(nullptr);
-  if (keep_host) ctx->mb->t0_memo_host.swap(table);
-  else std::vector<T0Memo>().swap(ctx->mb->t0_memo_host);
   return true;
 }
 }  // namespace
@@ -1439,7 +1443,10 @@ extern "C" int jppgpu_host_prepin(int32_t device, uint64_t bytes, uint32_t count
 
 extern "C" uint64_t jppgpu_t0_memo_format(void) {
   // record size, the split of the unigram list it folds, the spec it was generated from
-  return (u64{0x54304d52} << 32) ^ ((u64)sizeof(T0Memo) << 16) ^ ((u64)kT0CtxFirst << 8) ^ (u64)kT0CtxLast ^ ((u64)spec::kSpecBlobSize << 40) ^ 1u;
+  // (the CONTENTS of the compiled-in spec, not only its size: a regenerated jumandic_spec.inc changes the key)
+  u64 h = 0xcbf29ce484222325ull;
+  for (unsigned i = 0; i < spec::kSpecBlobSize; ++i) h = (h ^ spec::kSpecBlob[i]) * 0x100000001b3ull;
+  return (u64{0x54304d52} << 32) ^ ((u64)sizeof(T0Memo) << 16) ^ ((u64)kT0CtxFirst << 8) ^ (u64)kT0CtxLast ^ ((u64)spec::kSpecBlobSize << 40) ^ 2u ^ (h << 1);
 }
 
 extern "C" int jppgpu_ctx_t0_memo_image(jppgpu_ctx* ctx, const void** data, uint64_t* bytes, uint32_t* slots) {
@@ -2222,6 +2229,8 @@ extern "C" int jppgpu_analyze_batch_seeds(jppgpu_ctx* ctx, const char* utf8, con
   if (!ctx->dynamic_spec)
     return fail(JPPGPU_INVALID_STATE, "jppgpu: gold seeds need a context created with dynamic_features = 1 (the trainer's feature code)");
   if (ctx->cfg.nscorers > 1) return fail(JPPGPU_INVALID_STATE, "jppgpu: gold seeds are not scored by the RNN (the trainer runs the perceptron only)");
+  if (ctx->row_stride != 8)   // (jppgpu_extra_seed::row holds eight columns)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: gold seeds for models with more than 8 feature columns");
   ctx->seed_hook = hook;
   ctx->seed_user = user;
   int rc = jppgpu_analyze_batch(ctx, utf8, offsets, n, out);
@@ -2360,6 +2369,17 @@ extern "C" int jppgpu_ctx_set_format_table(jppgpu_ctx* ctx, const jppgpu_format_
   if (t->n_escapes > 4 || t->n_flags > 16 || t->flag_label_len > 32 || t->eos_len > 16 || t->error_len > 32 || t->flag_placeholder > 1)
     return fail(JPPGPU_INVALID_PARAMETER, "format table: literal beyond its field");
   static_assert(sizeof(FmtRow) == sizeof(jppgpu_format_row), "row layout");
+  // The kernels index with what the table says (k_format.h: rows[slot_first_row[..] - 1], blob + blob_off, rows walked
+  // to the one flagged "last of its entry"): a table from a file is checked once, here, not trusted.
+  for (uint64_t i = 0; i < t->n_slots; ++i)
+    if (t->slot_first_row[i] > t->n_rows) return fail(JPPGPU_INVALID_PARAMETER, "format table: a slot names a row beyond the table");
+  for (uint64_t i = 0; i < t->n_rows; ++i) {
+    const jppgpu_format_row& r = t->rows[i];
+    const uint64_t pieces = (uint64_t)r.len_pre + r.len_s + 1 + r.len_r + 1 + r.len_b + r.len_mid + r.len_feat;
+    if ((uint64_t)r.blob_off + r.len_total > t->blob_bytes || pieces > r.len_total)
+      return fail(JPPGPU_INVALID_PARAMETER, "format table: a row's text lies outside the blob");
+  }
+  if ((t->rows[t->n_rows - 1].flags & 2) == 0) return fail(JPPGPU_INVALID_PARAMETER, "format table: the last row does not end its entry");
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   std::lock_guard<std::mutex> shared_lock(ctx->mb->mu);
   // the buffers below may be freed and re-allocated: no kernel of a context that shares the copy may still read them

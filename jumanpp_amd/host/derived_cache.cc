@@ -7,8 +7,12 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
+
+#include "format_table.h"
 
 namespace jumanpp_amd {
 
@@ -30,9 +34,70 @@ struct Header {
   uint64_t rowsOffset, nRows;       // jppgpu_format_row[nRows]
   uint64_t blobOffset, blobBytes;
   uint64_t totalBytes;
+  uint32_t tableBuilder;            // kFormatTableBuilderVersion of the writer
+  uint32_t reserved;
+  uint64_t contentHash;             // of everything behind the header (hashPayload); the header's own fields are checked one by one
   jppgpu_format_table literals;     // the table with its three pointers null
 };
-constexpr uint32_t kVersion = 1;
+constexpr uint32_t kVersion = 2;
+
+// offset + len within total, without wrapping
+bool within(uint64_t off, uint64_t len, uint64_t total) { return off <= total && len <= total - off; }
+bool withinN(uint64_t off, uint64_t n, uint64_t each, uint64_t total) { return off <= total && n <= (total - off) / each; }
+
+// Content hash of the payload: 4 MB pieces, each mixed 32 bytes at a time in four lanes (multiply-rotate; ~10 GB/s per
+// core), the piece hashes folded in order.  Pieces are hashed by a few threads: a 300 MB image is checked in ~10 ms.
+uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+uint64_t hashPiece(const unsigned char* p, size_t n, uint64_t seed) {
+  const uint64_t P1 = 0x9E3779B185EBCA87ull, P2 = 0xC2B2AE3D27D4EB4Full;
+  uint64_t a = seed + P1, b = seed ^ P2, c = seed * P1 + 1, d = seed - P2;
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, p + i, 32);
+    a = rotl(a + w[0] * P2, 31) * P1;
+    b = rotl(b + w[1] * P2, 31) * P1;
+    c = rotl(c + w[2] * P2, 31) * P1;
+    d = rotl(d + w[3] * P2, 31) * P1;
+  }
+  uint64_t h = rotl(a, 1) + rotl(b, 7) + rotl(c, 12) + rotl(d, 18) + (uint64_t)n;
+  for (; i < n; ++i) h = rotl(h ^ (p[i] * P1), 11) * P2;
+  h ^= h >> 33;
+  h *= P2;
+  h ^= h >> 29;
+  return h;
+}
+uint64_t hashPayload(const unsigned char* p, uint64_t n) {
+  const uint64_t piece = uint64_t{4} << 20;
+  const size_t np = (size_t)((n + piece - 1) / piece);
+  std::vector<uint64_t> hs(np, 0);
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 1 : nt > 8 ? 8 : nt;
+  if (np < 4) nt = 1;
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t k; (k = next.fetch_add(1)) < np;) {
+      const uint64_t lo = k * piece, len = n - lo < piece ? n - lo : piece;
+      hs[k] = hashPiece(p + lo, (size_t)len, (uint64_t)k);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  uint64_t h = 0x4a50504750554443ull ^ n;
+  for (uint64_t x : hs) h = rotl(h ^ x, 27) * 0x9E3779B185EBCA87ull + 0x165667B19E3779F9ull;
+  return h;
+}
+
+// The per-user fallback directory must be OURS: a directory (not a link), owned by this user, closed to everyone else.
+// Anything else -- somebody else made it first -- is not used, neither for reading nor for writing.
+bool ownPrivateDir(const std::string& dir, bool create) {
+  if (create) (void)::mkdir(dir.c_str(), 0700);
+  struct stat ds;
+  if (::lstat(dir.c_str(), &ds) != 0) return false;
+  return S_ISDIR(ds.st_mode) && ds.st_uid == ::getuid() && (ds.st_mode & 077) == 0;
+}
 
 bool statModel(const std::string& path, struct stat* st) { return ::stat(path.c_str(), st) == 0 && S_ISREG(st->st_mode); }
 
@@ -42,13 +107,18 @@ std::string baseName(const std::string& p) {
 }
 
 // the two places a cache may live: beside the model, or in a per-user directory under $TMPDIR
-std::vector<std::string> candidates(const std::string& modelPath, const struct stat& st) {
-  std::vector<std::string> out;
-  out.push_back(modelPath + ".jppgpu-cache");
+struct Candidate {
+  std::string path;
+  std::string privateDir;   // non-empty: the per-user directory the file lives in (ownPrivateDir)
+};
+std::vector<Candidate> candidates(const std::string& modelPath, const struct stat& st) {
+  std::vector<Candidate> out;
+  out.push_back({modelPath + ".jppgpu-cache", ""});
   const char* tmp = std::getenv("TMPDIR");
   char buf[96];
   std::snprintf(buf, sizeof(buf), ".%llu.%lld", (unsigned long long)st.st_size, (long long)st.st_mtim.tv_sec);
-  out.push_back(std::string(tmp && *tmp ? tmp : "/tmp") + "/jppgpu-cache-" + std::to_string((unsigned)::getuid()) + "/" + baseName(modelPath) + buf);
+  const std::string dir = std::string(tmp && *tmp ? tmp : "/tmp") + "/jppgpu-cache-" + std::to_string((unsigned)::getuid());
+  out.push_back({dir + "/" + baseName(modelPath) + buf, dir});
   return out;
 }
 
@@ -80,11 +150,15 @@ DerivedCache::~DerivedCache() {
 bool DerivedCache::load(const std::string& modelPath) {
   struct stat st;
   if (!statModel(modelPath, &st)) return false;
-  for (const std::string& path : candidates(modelPath, st)) {
-    const int fd = ::open(path.c_str(), O_RDONLY);
+  for (const Candidate& cand : candidates(modelPath, st)) {
+    if (!cand.privateDir.empty() && !ownPrivateDir(cand.privateDir, false)) continue;
+    const int fd = ::open(cand.path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
     if (fd < 0) continue;
     struct stat cs;
-    if (::fstat(fd, &cs) != 0 || (size_t)cs.st_size < sizeof(Header)) {
+    // a regular file written by this user or by the owner of the model (whoever can replace the model is trusted with
+    // its cache), not writable by group or others
+    if (::fstat(fd, &cs) != 0 || !S_ISREG(cs.st_mode) || (size_t)cs.st_size < sizeof(Header) ||
+        (cs.st_uid != ::getuid() && cs.st_uid != st.st_uid) || (cs.st_mode & 022) != 0) {
       ::close(fd);
       continue;
     }
@@ -93,12 +167,16 @@ bool DerivedCache::load(const std::string& modelPath) {
     ::close(fd);
     if (m == MAP_FAILED) continue;
     const Header* h = static_cast<const Header*>(m);
-    const bool ok = std::memcmp(h->magic, "JPPGPUDC", 8) == 0 && h->version == kVersion && h->memoFormat == jppgpu_t0_memo_format() &&
-                    h->tableStructSize == sizeof(jppgpu_format_table) && h->modelSize == (uint64_t)st.st_size &&
-                    h->modelMtimeSec == (int64_t)st.st_mtim.tv_sec && h->modelMtimeNsec == (int64_t)st.st_mtim.tv_nsec &&
-                    h->totalBytes == (uint64_t)cs.st_size && h->memoOffset + h->memoBytes <= h->totalBytes &&
-                    (!h->hasTable || (h->slotsOffset + h->nSlots * 4 <= h->totalBytes && h->rowsOffset + h->nRows * sizeof(jppgpu_format_row) <= h->totalBytes &&
-                                      h->blobOffset + h->blobBytes <= h->totalBytes));
+    const uint64_t total = (uint64_t)cs.st_size;
+    const uint64_t body = (sizeof(Header) + 63) / 64 * 64;
+    bool ok = std::memcmp(h->magic, "JPPGPUDC", 8) == 0 && h->version == kVersion && h->memoFormat == jppgpu_t0_memo_format() &&
+              h->tableStructSize == sizeof(jppgpu_format_table) && h->modelSize == (uint64_t)st.st_size &&
+              h->modelMtimeSec == (int64_t)st.st_mtim.tv_sec && h->modelMtimeNsec == (int64_t)st.st_mtim.tv_nsec &&
+              h->totalBytes == total && total >= body && within(h->memoOffset, h->memoBytes, total) && (h->memoBytes == 0 || h->memoOffset >= body) &&
+              (!h->hasTable || (h->tableBuilder == kFormatTableBuilderVersion && h->slotsOffset >= body && h->rowsOffset >= body && h->blobOffset >= body &&
+                                withinN(h->slotsOffset, h->nSlots, 4, total) && withinN(h->rowsOffset, h->nRows, sizeof(jppgpu_format_row), total) &&
+                                within(h->blobOffset, h->blobBytes, total)));
+    ok = ok && hashPayload(static_cast<const unsigned char*>(m) + body, total - body) == h->contentHash;
     if (!ok) {
       ::munmap(m, (size_t)cs.st_size);
       continue;
@@ -132,11 +210,12 @@ bool DerivedCache::store(const std::string& modelPath, const void* memo, uint64_
   struct stat st;
   if (!statModel(modelPath, &st)) return false;
   if (memo == nullptr && table == nullptr) return false;
-  for (const std::string& path : candidates(modelPath, st)) {
-    const size_t slash = path.find_last_of('/');
-    if (slash != std::string::npos) (void)::mkdir(path.substr(0, slash).c_str(), 0700);   // (the per-user directory; EEXIST otherwise)
+  for (const Candidate& cand : candidates(modelPath, st)) {
+    const std::string& path = cand.path;
+    if (!cand.privateDir.empty() && !ownPrivateDir(cand.privateDir, true)) continue;
     const std::string tmp = path + ".tmp" + std::to_string((long)::getpid());
-    const int fd = ::open(tmp.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+    (void)::unlink(tmp.c_str());
+    const int fd = ::open(tmp.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_NOFOLLOW | O_CLOEXEC, 0644);
     if (fd < 0) continue;
     Header h;
     std::memset(&h, 0, sizeof(h));
@@ -170,6 +249,9 @@ bool DerivedCache::store(const std::string& modelPath, const void* memo, uint64_
       pos += h.blobBytes;
     }
     h.totalBytes = pos;
+    h.tableBuilder = kFormatTableBuilderVersion;
+    // the payload exactly as it will lie in the file (pads are zeros), hashed piece by piece without assembling it:
+    // hashPayload works on one buffer, so the file is written first and hashed from its own mapping below
     uint64_t at = 0;
     bool ok = writeAll(fd, &h, sizeof(h));
     at = sizeof(h);
@@ -191,6 +273,21 @@ bool DerivedCache::store(const std::string& modelPath, const void* memo, uint64_
     }
     ok = ok && at == h.totalBytes;
     ::close(fd);
+    if (ok) {   // the content hash: over the bytes the file holds, then the header once more
+      const int rfd = ::open(tmp.c_str(), O_RDWR | O_NOFOLLOW | O_CLOEXEC);
+      ok = rfd >= 0;
+      if (ok) {
+        void* m = ::mmap(nullptr, (size_t)h.totalBytes, PROT_READ, MAP_SHARED, rfd, 0);
+        ok = m != MAP_FAILED;
+        if (ok) {
+          const uint64_t body = (sizeof(Header) + 63) / 64 * 64;
+          h.contentHash = hashPayload(static_cast<const unsigned char*>(m) + body, h.totalBytes - body);
+          ::munmap(m, (size_t)h.totalBytes);
+          ok = ::pwrite(rfd, &h, sizeof(h), 0) == (ssize_t)sizeof(h);
+        }
+        ::close(rfd);
+      }
+    }
     if (ok && ::rename(tmp.c_str(), path.c_str()) == 0) return true;
     ::unlink(tmp.c_str());
   }

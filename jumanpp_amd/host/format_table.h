@@ -13,6 +13,10 @@
 
 namespace jumanpp_amd {
 
+// Changes whenever build() or formatJumanRow render an entry differently: part of the derived-image cache key
+// (host/derived_cache.cc), so that a table written by an older builder is not adopted after an update.
+constexpr uint32_t kFormatTableBuilderVersion = 1;
+
 class JumanFormatTable {
   std::vector<uint32_t> slots_;
   std::vector<jppgpu_format_row> rows_;

@@ -546,7 +546,11 @@ int main(int argc, const char** argv) {
   StringPiece emptyResult = "# ERROR\nEOS\n";
   const bool latticeFormat = conf.lattice != 0;
   const bool useLattice = latticeFormat || conf.kind == Conf::DicSubset;  // formats that read the whole lattice
-  if (latticeFormat && !conf.batchGiven && !conf.inputs.empty()) {
+  // (only a regular file is sampled: a FIFO, /dev/stdin or a process substitution would lose the sampled megabyte, or
+  // block on the second open once its writer is gone -- those keep the default batch, as the reference reads any stream)
+  struct stat sampleStat;
+  const bool sampleable = !conf.inputs.empty() && ::stat(conf.inputs[0].c_str(), &sampleStat) == 0 && S_ISREG(sampleStat.st_mode);
+  if (latticeFormat && !conf.batchGiven && sampleable) {
     // The lattice format reads the N best paths of every sentence as the device gathers them (jppgpu_result_fetch_nbest:
     // 64 B per path and node).  At beam 32 on 220-codepoint sentences that is 0.2 MB per sentence; a 16 384-sentence
     // batch moves 3.3 GB through fresh host pages and the analysis stage spends five times the GPU's time on it
@@ -762,8 +766,8 @@ int main(int argc, const char** argv) {
         donor = analyzers[d2][0].get();
     if (donor == nullptr && cacheHit && derived.memo() != nullptr)
       analyzers[d][a]->setT0MemoImage(derived.memo(), derived.memoBytes(), derived.memoSlots());
-    else if (donor == nullptr && useImageCache && !cacheHit && d == 0 && a == 0)
-      analyzers[d][a]->setKeepT0MemoImage(true);   // (this run writes the cache, below)
+    else if (donor == nullptr && useImageCache && d == 0 && a == 0)
+      analyzers[d][a]->setKeepT0MemoImage(true);   // (no records in a cache: this run writes them, below)
     Status made = analyzers[d][a]->initialize(&model, acfg, sconf, &def, conf.devices[d], donor);
     if (made && deviceText) {
       if (donor == nullptr) made = analyzers[d][a]->setFormatTable(formatTable.view());
@@ -787,19 +791,37 @@ int main(int argc, const char** argv) {
     ln << "startup: model_map_ms=" << tModelLoaded << " first_analyzers_ready_ms=" << processClock.ms() << "\n";
     std::cerr << ln.str();
   }
+  // The cache is written by the run that misses it -- and REwritten by a run that hit a cache lacking a part it needs
+  // (the first run of a model may have had no device text: -s N, --host-format, another output format; or no memo): the
+  // missing part is added to what the mapping holds, so that the next start finds both.  The records come from the
+  // library's own host copy (valid until the last context goes; this process never calls jppgpu_ctx_set_weights, which
+  // would refill them in place), the mapped parts from `derived`, which outlives the writer.
   Joiner cacheWriter;
-  if (useImageCache && !cacheHit && analyzers[0][0]) {
-    const void* memo = nullptr;
-    uint64_t memoBytes = 0;
-    uint32_t memoSlots = 0;
-    const bool haveMemo = analyzers[0][0]->exportT0MemoImage(&memo, &memoBytes, &memoSlots);
-    const jppgpu_format_table* tbl = deviceText ? &formatTable.view() : nullptr;
-    if (haveMemo || tbl != nullptr) {
+  if (useImageCache && analyzers[0][0]) {
+    const void* memo = cacheHit ? derived.memo() : nullptr;
+    uint64_t memoBytes = cacheHit ? derived.memoBytes() : 0;
+    uint32_t memoSlots = cacheHit ? derived.memoSlots() : 0;
+    bool newPart = !cacheHit;
+    if (memo == nullptr) {
+      const bool haveMemo = analyzers[0][0]->exportT0MemoImage(&memo, &memoBytes, &memoSlots);
+      if (!haveMemo) memo = nullptr;
+      newPart = newPart || haveMemo;
+    }
+    const jppgpu_format_table* tbl = nullptr;
+    uint64_t entries = 0;
+    if (deviceText) {
+      tbl = &formatTable.view();
+      entries = formatTable.numEntries();
+      newPart = newPart || !tableFromCache;
+    } else if (cacheHit && derived.hasFormatTable()) {
+      tbl = &derived.formatTable();
+      entries = derived.formatTableEntries();
+    }
+    if (newPart && (memo != nullptr || tbl != nullptr)) {
       const std::string modelPath = conf.model;
-      const uint64_t entries = formatTable.numEntries();
       const bool timing = conf.timing;
       cacheWriter.t = std::thread([=]() {
-        const bool ok = DerivedCache::store(modelPath, haveMemo ? memo : nullptr, memoBytes, memoSlots, tbl, entries);
+        const bool ok = DerivedCache::store(modelPath, memo, memoBytes, memoSlots, tbl, entries);
         if (timing) std::cerr << (std::string("image cache ") + (ok ? "written" : "not written") + " for " + modelPath + "\n");   // (one write: other threads print too)
       });
     }

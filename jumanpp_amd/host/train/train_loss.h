@@ -42,7 +42,9 @@ struct SentenceLattice {
   uint32_t s = 0;
   int32_t numFeatures = 0;
   const jppgpu_node* nodes() const { return view->nodes + view->node_base[s]; }
-  const int32_t* row(uint32_t node) const { return view->entry_rows + (view->node_base[s] + node) * (uint64_t)numFeatures; }
+  // the device writes rows of 8 or 16 columns whatever the model's numFeatures (jppgpu_result_view::entry_row_stride)
+  uint64_t rowStride() const { return view->entry_row_stride > 0 ? (uint64_t)view->entry_row_stride : 8u; }
+  const int32_t* row(uint32_t node) const { return view->entry_rows + (view->node_base[s] + node) * rowStride(); }
   const jppgpu_beam_slot* beam(uint32_t node) const { return view->beams + (view->node_base[s] + node) * (uint64_t)view->beam; }
   uint32_t bndFirst(uint32_t b) const { return view->bnd_first[view->bnd_base[s] + b]; }
   uint32_t numNodes() const { return view->n_nodes[s]; }

@@ -915,6 +915,62 @@ def _image_cache_case(cli, golden_dir, tmp_path):
         f.truncate(1000)
     rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
     assert rc == 0 and b'image_cache=miss' in err and out == ref, err[-400:]
+    # (that run rewrote it) one flipped payload byte: the content hash of the header no longer matches -> ignored
+    cache = model + '.jppgpu-cache'
+    size = os.path.getsize(cache)
+    with open(cache, 'r+b') as f:
+        f.seek(size - 200)
+        b = f.read(1)
+        f.seek(size - 200)
+        f.write(bytes([b[0] ^ 0x40]))
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=miss' in err and out == ref, err[-400:]
+    # a cache that is writable by others is not trusted
+    os.chmod(cache, 0o666)
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=miss' in err and out == ref, err[-400:]
+    # a first run WITHOUT device text (lattice output) stores the records only; the next device-text run hits, builds
+    # the table, and rewrites the cache with both parts; the run after that adopts the table
+    os.unlink(cache)
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', '-s', '2', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=miss' in err and b'image cache written' in err, err[-400:]
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=hit' in err and b'(image cache)' not in err and b'image cache written' in err and out == ref, err[-400:]
+    rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
+    assert rc == 0 and b'image_cache=hit' in err and b'(image cache)' in err and b'image cache written' not in err and out == ref, err[-400:]
+
+
+def _lattice_from_fifo_case(cli, golden_dir, tmp_path):
+    """-s N without --batch samples its input for the default batch size: only a regular file may be sampled (ADVICE r05:
+    a FIFO lost its first megabyte, or the second open blocked for good)"""
+    import threading
+    model = os.path.join(golden_dir, 'mini_rnn.jppmdl')
+    txt = os.path.join(golden_dir, 'mini.txt')
+    rc, ref, err = _run(cli, ['--model=' + model, '-s', '3', txt])
+    assert rc == 0 and ref, err[-300:]
+    fifo = str(tmp_path / 'in.fifo')
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, 'wb') as f:
+            f.write(open(txt, 'rb').read())
+    t = threading.Thread(target=feed)
+    t.start()
+    try:
+        p = subprocess.run([cli, '--model=' + model, '-s', '3', fifo], capture_output=True, timeout=120,
+                           env=dict(os.environ, JPPGPU_NO_IMAGE_CACHE='1'))
+    finally:
+        t.join(timeout=10)
+    assert p.returncode == 0 and p.stdout == ref, p.stderr[-300:]
+
+
+def test_emulated_lattice_output_from_a_fifo(cli_emu, golden_dir, tmp_path):
+    _lattice_from_fifo_case(cli_emu, golden_dir, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_lattice_output_from_a_fifo(cli_gpu, golden_dir, tmp_path):
+    _lattice_from_fifo_case(cli_gpu, golden_dir, tmp_path)
 
 
 def test_emulated_derived_image_cache(cli_emu, golden_dir, tmp_path):
