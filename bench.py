@@ -871,10 +871,15 @@ def config5_cli_lattice(args, cache, ge, np):
                 best = (kv.get('sent_per_s', 0.0), kv, wall)
         rate, kv, wall = best
         size = os.path.getsize(out_path)
+        device_text = 'device_lattice_format=1' in (p.stderr or '')
         res = {'what': 'jumanpp_gpu %s corpus -o file: %d sentences x 220 codepoints, N-best lattice format written '
-                       '(%.0f MB); the 32 best paths are gathered on the device (k_nbest), the lattice text is printed by the host '
-                       'format workers; batches of %d sentences (the CLI\'s choice for lattice output); best of 2 runs'
-                       % (' '.join(flags), 2 * batch, size / 1e6, int(kv.get('batch_lines', 0))),
+                       '(%.0f MB); %s; batches of %d sentences (the CLI\'s choice for lattice output); best of 2 runs'
+                       % (' '.join(flags), 2 * batch, size / 1e6,
+                          'the lattice text is printed by the device (k_lat_count / k_lat_write: per-node path sets, ids, "%g" scores; '
+                          'entry-row columns from the per-model table) and only text crosses PCIe' if device_text else
+                          'the 32 best paths are gathered on the device (k_nbest), the lattice text is printed by the host format workers',
+                          int(kv.get('batch_lines', 0))),
+               'device_text': device_text,
                'value': round(rate, 1), 'unit': 'sentences/s', 'runs': rates, 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
                'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
                'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
@@ -883,6 +888,19 @@ def config5_cli_lattice(args, cache, ge, np):
                               'reserve': round(kv.get('reserve_ms', 0.0), 1),
                               'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)},
                'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')}}
+        if device_text:   # the round-5 form of the same command: N best paths gathered on the device, text printed by the host workers
+            ph = subprocess.run([cli, '--model=' + model, '--timing', '--host-format', '-o', out_path + '.host'] + flags + [corpus],
+                                capture_output=True, text=True)
+            if ph.returncode == 0:
+                kh = _timing_kv(ph.stderr)
+                res['host_format'] = {'what': 'the same run with --host-format (k_nbest + %d host format threads)' % int(kh.get('threads', 0)),
+                                      'value': round(kh.get('sent_per_s', 0.0), 1), 'unit': 'sentences/s',
+                                      'pipeline_wall_ms': round(kh.get('wall_ms', 0.0), 1),
+                                      'stage_busy_ms': {k: round(kh.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
+                                      'same_bytes_as_device_text': os.path.getsize(out_path + '.host') == size and
+                                      subprocess.run(['cmp', '-s', out_path, out_path + '.host']).returncode == 0}
+            if os.path.exists(out_path + '.host'):
+                os.remove(out_path + '.host')
         if not args.no_parity and not args.no_cpu_baseline:
             t = time.time()
             n_check = 2048

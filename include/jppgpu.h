@@ -18,6 +18,8 @@
  *       src/core/analysis/analysis_result.cc:25-76, output.cc:69-111     -> jppgpu_result_fetch(JPPGPU_FETCH_TOP1)
  *   LatticeFormatInfo::fillInfo (what the N-best lattice format reads)
  *       src/jumandic/shared/lattice_format.cc:13-43,129-141             -> jppgpu_result_fetch_nbest
+ *   LatticeFormat::format (the N-best lattice text itself)
+ *       src/jumandic/shared/lattice_format.cc:83-242                    -> jppgpu_result_format_lattice
  *   ScorePlugin (partial annotation)  src/core/analysis/score_plugin.h:14-19,
  *       src/core/input/partial_example.cc                                -> jppgpu_analyze_batch_partial
  *   ScorePlugin::updateScore as an extension point (any right-node-dependent plugin)
@@ -524,6 +526,9 @@ typedef struct {
   const uint64_t* offsets;   /* [n + 1] byte offsets into text: sentence i is text[offsets[i] .. offsets[i + 1]) */
   const char* text;          /* host copy, owned by the result (valid until jppgpu_result_release) */
   const int32_t* status;     /* [n] JPPGPU_SENT_* */
+  const uint32_t* head_len;  /* jppgpu_result_format_lattice: [n] bytes of the "# MA-SCORE ..." line a sentence's text starts
+                              * with (0: none) -- a caller that has a comment for the sentence prints "# comment\n" in its
+                              * place (lattice_format.cc:105-120); NULL for jppgpu_result_format_top1 */
 } jppgpu_text_view;
 /* the formatted top-1 analyses of the batch; needs jppgpu_ctx_set_format_table.  The device side of the result must
  * still be valid (no later batch on the context). */
@@ -555,6 +560,60 @@ typedef struct {
 } jppgpu_nbest_view;
 
 int jppgpu_result_fetch_nbest(jppgpu_result* res, int32_t n_best, jppgpu_nbest_view* view);
+
+/* ---- the lattice (-s N) format on the device (replaces jumandic::output::LatticeFormat::format,
+ * src/jumandic/shared/lattice_format.cc:83-242, and the LatticeFormatInfo bookkeeping :13-66,250-270) -------------------------
+ * One line per lattice node on any of the N best paths and per row of its dictionary entry:
+ *     "-" TAB id TAB prev-ids(;) TAB start TAB end TAB  S TAB X TAB R TAB B TAB REST  [flag '|']  scores  ranks(;) LF
+ * S / R / B = surface / reading / baseform with a lone tab escaped, X = the canonic form or B '/' R when it is empty, REST
+ * = pos, ids, conjugation columns and the feature list as the reference prints them -- for a DICTIONARY node the whole
+ * run S .. REST is a function of the entry row and is rendered once per model by the host (host/lattice_table.cc); an UNK
+ * node prints the input surface in the columns its maker replaces.  ids, previous ids, ranks and the three scores ("%g")
+ * are computed per sentence by the kernels (csrc/k_latfmt.h).  The library knows nothing of JUMAN: every literal is here. */
+typedef struct {
+  uint32_t blob_off;       /* S TAB X TAB R TAB B TAB REST, contiguous in `blob` */
+  uint32_t len_rest;
+  uint16_t len_s, len_c, len_r, len_b;   /* len_c = 0: X is B '/' R */
+  uint32_t flags;          /* bit 1: last row of its entry */
+} jppgpu_lattice_row;      /* 20 bytes */
+
+typedef struct {
+  uint32_t struct_size;    /* sizeof(jppgpu_lattice_table) */
+  const uint32_t* slot_first_row;   /* as in jppgpu_format_table */
+  uint64_t n_slots;
+  const jppgpu_lattice_row* rows;
+  uint64_t n_rows;
+  const char* blob;
+  uint64_t blob_bytes;
+  uint8_t maker_replaces[16];   /* per UNK maker: bit 0 / 1 / 2 / 3 = S / R / B / canonic form print the input surface */
+  uint8_t n_escapes;            /* escapeTab (lattice_format.cc:74-79) */
+  char escape_from[4];
+  uint8_t escape_len[4];
+  char escape_to[4][8];
+  int32_t flag_placeholder;     /* formatNormalizedFeature, as in jppgpu_format_table (followed by '|' here) */
+  uint8_t flag_label_len;
+  char flag_label[32];
+  uint8_t n_flags;
+  uint32_t flag_mask[16];
+  char flag_char[16];
+  uint8_t head_len, rank_len, feat_len, lm_len, total_len, ranks_len, eos_len, error_len;
+  char head_text[16];      /* "# MA-SCORE\t" */
+  char rank_text[8];       /* "rank" */
+  char feat_text[32];      /* label of scores[0] * weights[0] */
+  char lm_text[32];        /* label of scores[1] * weights[1] (printed when there are two weights) */
+  char total_text[32];     /* label of their sum */
+  char ranks_text[16];     /* label of the rank list */
+  char eos_text[16];
+  char error_text[32];     /* whole text of a sentence that failed */
+  uint32_t n_weights;      /* ScorerDef::scoreWeights as the format reads them */
+  float weights[2];
+} jppgpu_lattice_table;
+
+int jppgpu_ctx_set_lattice_table(jppgpu_ctx* ctx, const jppgpu_lattice_table* table);
+/* the lattice-format text of the batch's n_best (<= 64) best analyses; view->head_len is filled.  Needs
+ * jppgpu_ctx_set_lattice_table and a context with a global beam (the format reads the score cells); the device side of
+ * the result must still be valid.  A result holds ONE text: the first of format_top1 / format_lattice called on it. */
+int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, jppgpu_text_view* view);
 /* Training hook.  What the reference's trainer reads off an analysed lattice besides the scores
  * (LossCalculator::addTopNgrams, src/core/training/loss.cc:289-300 -> NgramFeaturesComputer::calculateNgramFeatures,
  * src/core/impl/feature_computer.cc:13-31): for every connection on the top-1 path of every sentence, from the EOS

@@ -23,6 +23,7 @@
 #include "k_adjust.h"
 #include "k_decode.h"
 #include "k_format.h"
+#include "k_latfmt.h"
 #include "k_gold.h"
 #include "k_lattice.h"
 #include "k_rnn.h"
@@ -420,6 +421,9 @@ struct jppgpu_result {
   HostVec<jppgpu_unk> t1_unk;
   // jppgpu_result_format_top1
   bool fm_have = false;
+  int fm_kind = 0;         // 1: top-1 text (format_top1), 2: lattice text (format_lattice)
+  int fm_nbest = 0;
+  HostVec<u32> fm_head;    // format_lattice: header bytes per sentence
   HostVec<i32> fm_status;
   HostVec<u64> fm_off;
   HostVec<char> fm_text;   // (page-locked: text_pool_ref)
@@ -462,6 +466,9 @@ struct ModelBufs {
   // output text on the device (jppgpu_ctx_set_format_table)
   bool fmt_have = false;
   DevBuf fmt_slots, fmt_rows, fmt_blob, fmt_table;
+  // the lattice format on the device (jppgpu_ctx_set_lattice_table)
+  bool lat_have = false;
+  DevBuf lat_slots, lat_rows, lat_blob, lat_table;
   int device = 0;
   // jppgpu_ctx_set_weights / jppgpu_ctx_set_format_table change tables that every context of the copy reads: one writer
   // at a time, and a writer first waits for the whole device (the batches its sibling contexts have enqueued)
@@ -521,6 +528,7 @@ struct jppgpu_ctx {
   std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
   DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text, fmt_st;
+  DevBuf lat_mask, lat_used, lat_best, lat_id, lat_head;   // k_latfmt.h: per-node sets of the N best paths, header bytes per sentence
   bool timing_pending = false;
   // one enqueue per batch (k_lattice.h: k_cap_guard): grids of the rare sweep classes and the scratch geometry the next
   // batch is launched with before its totals are known; statistics for the bench / tests
@@ -544,7 +552,7 @@ void jppgpu_result::bind(HostPool* pool) {
   t1_zero.pool = pool; t1_nodes.pool = pool; t1_unk.pool = pool;
   ng_first.pool = pool; ng_nodes.pool = pool; ng_feat.pool = pool;
   gp_first.pool = pool; gp_nodes.pool = pool; gp_feat.pool = pool;
-  fm_status.pool = pool; fm_off.pool = pool;
+  fm_status.pool = pool; fm_off.pool = pool; fm_head.pool = pool;
   nb_status.pool = pool; nb_ncp.pool = pool; nb_nnodes.pool = pool; nb_first.pool = pool; nb_eos.pool = pool; nb_items.pool = pool;
 }
 
@@ -883,7 +891,7 @@ bool upload_memo(jppgpu_ctx* ctx, const float* weights, bool keep_host = false) 
 ModelBufs::~ModelBufs() {
   (void)bind_device(device);
   DevBuf* bufs[] = {&trie, &eptrs, &edata, &weights, &dyn_spec, &rnn_known, &rnn_unk, &rnn_wt, &rnn_emb, &rnn_nce, &rnn_maxent,
-                    &t0_memo, &fmt_slots, &fmt_rows, &fmt_blob, &fmt_table};
+                    &t0_memo, &fmt_slots, &fmt_rows, &fmt_blob, &fmt_table, &lat_slots, &lat_rows, &lat_blob, &lat_table};
   for (auto* b : bufs) b->release();
   for (auto& b : field_blobs) b.release();
   rt_free(dmodel);
@@ -2426,6 +2434,7 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
   if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
   const Batch& B = res->B;
   const u32 n = B.n_sent;
+  if (res->fm_have && res->fm_kind != 1) return fail(JPPGPU_INVALID_STATE, "the result holds the lattice text already");
   if (!res->fm_have) {
     if (res->generation != ctx->generation)
       return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
@@ -2447,11 +2456,133 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
     rt_sync(st);
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format text)");
     res->fm_have = true;
+    res->fm_kind = 1;
   }
   v->n_sentences = n;
   v->offsets = res->fm_off.data();
   v->text = res->fm_text.data();
   v->status = res->fm_status.data();
+  v->head_len = nullptr;
+  return JPPGPU_OK;
+}
+
+// ---- the lattice format on the device (k_latfmt.h) ------------------------------------------------------------------------
+extern "C" int jppgpu_ctx_set_lattice_table(jppgpu_ctx* ctx, const jppgpu_lattice_table* t) {
+  if (!ctx || !t) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  if (t->struct_size != sizeof(jppgpu_lattice_table))
+    return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_lattice_table::struct_size is not the size this library was built with");
+  if (!t->slot_first_row || !t->rows || !t->blob || t->n_rows == 0)
+    return fail(JPPGPU_INVALID_PARAMETER, "lattice table: empty");
+  if (t->n_rows >= 0xffffffffull || t->blob_bytes >= 0xffffffffull || t->n_slots >= 0xffffffffull)
+    return fail(JPPGPU_NOT_IMPLEMENTED, "lattice table: more than 2^32 rows / blob bytes / slots");
+  if (t->n_escapes > 4 || t->n_flags > 16 || t->flag_label_len > 32 || t->flag_placeholder > 1 || t->head_len > 16 || t->rank_len > 8 ||
+      t->feat_len > 32 || t->lm_len > 32 || t->total_len > 32 || t->ranks_len > 16 || t->eos_len > 16 || t->error_len > 32 ||
+      t->n_weights < 1 || t->n_weights > 2)
+    return fail(JPPGPU_INVALID_PARAMETER, "lattice table: literal beyond its field");
+  for (int e = 0; e < (int)t->n_escapes; ++e)
+    if (t->escape_len[e] > 8) return fail(JPPGPU_INVALID_PARAMETER, "lattice table: literal beyond its field");
+  static_assert(sizeof(LatRow) == sizeof(jppgpu_lattice_row), "row layout");
+  // checked once, not trusted (the table may come from a file): k_latfmt.h indexes with these
+  for (uint64_t i = 0; i < t->n_slots; ++i)
+    if (t->slot_first_row[i] > t->n_rows) return fail(JPPGPU_INVALID_PARAMETER, "lattice table: a slot names a row beyond the table");
+  for (uint64_t i = 0; i < t->n_rows; ++i) {
+    const jppgpu_lattice_row& r = t->rows[i];
+    const uint64_t lenX = r.len_c ? (uint64_t)r.len_c : (uint64_t)r.len_b + 1 + r.len_r;
+    const uint64_t total = (uint64_t)r.len_s + 1 + lenX + 1 + r.len_r + 1 + r.len_b + 1 + r.len_rest;
+    if ((uint64_t)r.blob_off + total > t->blob_bytes) return fail(JPPGPU_INVALID_PARAMETER, "lattice table: a row's text lies outside the blob");
+  }
+  if ((t->rows[t->n_rows - 1].flags & 2) == 0) return fail(JPPGPU_INVALID_PARAMETER, "lattice table: the last row does not end its entry");
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  std::lock_guard<std::mutex> shared_lock(ctx->mb->mu);
+  if (ctx->mb.use_count() > 1) rt_device_sync();
+  if (!(ctx->mb->lat_slots.ensure(t->n_slots * 4) && ctx->mb->lat_rows.ensure(t->n_rows * sizeof(LatRow)) &&
+        ctx->mb->lat_blob.ensure(t->blob_bytes + 64) && ctx->mb->lat_table.ensure(sizeof(LatTable))))
+    return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice table)");
+  jpp_stream_t st = ctx->own_stream;
+  rt_h2d(ctx->mb->lat_slots.p, t->slot_first_row, t->n_slots * 4, st);
+  rt_h2d(ctx->mb->lat_rows.p, t->rows, t->n_rows * sizeof(LatRow), st);
+  rt_h2d(ctx->mb->lat_blob.p, t->blob, t->blob_bytes, st);
+  LatTable T;
+  memset(&T, 0, sizeof(T));
+  T.slot_first_row = ctx->mb->lat_slots.as<u32>();
+  T.n_slots = t->n_slots;
+  T.rows = ctx->mb->lat_rows.as<LatRow>();
+  T.n_rows = t->n_rows;
+  T.blob = ctx->mb->lat_blob.as<u8>();
+  memcpy(T.maker_replaces, t->maker_replaces, 16);
+  T.n_escapes = t->n_escapes;
+  memcpy(T.escape_from, t->escape_from, 4);
+  memcpy(T.escape_len, t->escape_len, 4);
+  memcpy(T.escape_to, t->escape_to, 32);
+  T.flag_placeholder = t->flag_placeholder;
+  T.flag_label_len = t->flag_label_len;
+  memcpy(T.flag_label, t->flag_label, 32);
+  T.n_flags = t->n_flags;
+  memcpy(T.flag_mask, t->flag_mask, sizeof(T.flag_mask));
+  memcpy(T.flag_char, t->flag_char, 16);
+  T.head_len = t->head_len; T.rank_len = t->rank_len; T.feat_len = t->feat_len; T.lm_len = t->lm_len;
+  T.total_len = t->total_len; T.ranks_len = t->ranks_len; T.eos_len = t->eos_len; T.error_len = t->error_len;
+  memcpy(T.head_text, t->head_text, 16);
+  memcpy(T.rank_text, t->rank_text, 8);
+  memcpy(T.feat_text, t->feat_text, 32);
+  memcpy(T.lm_text, t->lm_text, 32);
+  memcpy(T.total_text, t->total_text, 32);
+  memcpy(T.ranks_text, t->ranks_text, 16);
+  memcpy(T.eos_text, t->eos_text, 16);
+  memcpy(T.error_text, t->error_text, 32);
+  T.n_weights = t->n_weights;
+  T.weights[0] = t->weights[0];
+  T.weights[1] = t->weights[1];
+  rt_h2d(ctx->mb->lat_table.p, &T, sizeof(T), st);
+  rt_sync(st);
+  ctx->mb->lat_have = true;
+  return JPPGPU_OK;
+}
+
+extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, jppgpu_text_view* v) {
+  if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
+  jppgpu_ctx* ctx = res->ctx;
+  if (!ctx->mb->lat_have) return fail(JPPGPU_INVALID_STATE, "jppgpu_result_format_lattice needs jppgpu_ctx_set_lattice_table");
+  if (n_best < 1 || n_best > 64) return fail(JPPGPU_INVALID_PARAMETER, "jppgpu_result_format_lattice: n_best outside 1..64");
+  if (res->cfg.gbeam <= 0) return fail(JPPGPU_NOT_IMPLEMENTED, "lattice format needs the global beam (score cells)");
+  if (!bind_device(ctx->device)) return fail(JPPGPU_INVALID_STATE, "hipSetDevice failed for the context's device");
+  const Batch& B = res->B;
+  const u32 n = B.n_sent;
+  if (res->fm_have && (res->fm_kind != 2 || res->fm_nbest != n_best)) return fail(JPPGPU_INVALID_STATE, "the result holds another text already");
+  if (!res->fm_have) {
+    if (res->generation != ctx->generation)
+      return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
+    jpp_stream_t st = ctx->last_stream;
+    const size_t N = (size_t)B.total_nodes + 1;
+    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_used.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) &&
+          ctx->lat_head.ensure(((size_t)n + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) &&
+          ctx->fmt_st.ensure(((size_t)n + 1) * 4)))
+      return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice format)");
+    const LatTable* T = ctx->mb->lat_table.as<LatTable>();
+    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_used.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>()};
+    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_st.as<i32>());
+    launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
+    bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
+    rt_sync(st);   // the byte total sizes the text buffers
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format offsets)");
+    const u64 total = res->fm_off.data()[n];
+    if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
+    if (n) JPP_LAUNCH(k_lat_write, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, (const u64*)ctx->fmt_off.as<u64>(), ctx->fmt_text.as<u8>(),
+                      (const i32*)ctx->fmt_st.as<i32>());
+    ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
+    ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);
+    ok &= pull(res->fm_head, ctx->lat_head.p, n, st);
+    rt_sync(st);
+    if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format text)");
+    res->fm_have = true;
+    res->fm_kind = 2;
+    res->fm_nbest = n_best;
+  }
+  v->n_sentences = n;
+  v->offsets = res->fm_off.data();
+  v->text = res->fm_text.data();
+  v->status = res->fm_status.data();
+  v->head_len = res->fm_head.data();
   return JPPGPU_OK;
 }
 

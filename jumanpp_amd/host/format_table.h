@@ -43,6 +43,27 @@ class JumanFormatTable {
   double buildMs() const { return buildMs_; }
 };
 
+// The same for the lattice (-s N) format (jppgpu_lattice_table, csrc/k_latfmt.h): the entry-row columns of a line --
+// surface, canonic form or baseform/reading, reading, baseform, grammar columns with ids, feature list -- rendered once per
+// entry row by formatLatticeRow, the printer LatticeFormat itself uses (src/jumandic/shared/lattice_format.cc:168-205).
+class LatticeFormatTable {
+  std::vector<uint32_t> slots_;
+  std::vector<jppgpu_lattice_row> rows_;
+  std::string blob_;
+  jppgpu_lattice_table view_{};
+  size_t entries_ = 0;
+  double buildMs_ = 0;
+
+ public:
+  // scoreWeights: ScorerDef::scoreWeights (the format multiplies the score cells by them, lattice_format.cc:127,218-227)
+  Status build(const ModelImage* model, const std::vector<float>& scoreWeights, unsigned threads);
+  const jppgpu_lattice_table& view() const { return view_; }
+  size_t numEntries() const { return entries_; }
+  size_t numRows() const { return (size_t)view_.n_rows; }
+  size_t blobBytes() const { return (size_t)view_.blob_bytes; }
+  double buildMs() const { return buildMs_; }
+};
+
 }  // namespace jumanpp_amd
 
 #endif  // JUMANPP_AMD_HOST_FORMAT_TABLE_H

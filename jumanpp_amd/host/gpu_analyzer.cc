@@ -93,8 +93,9 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
     releaseResult();
     jppgpu_ctx_destroy(ctx_);
     ctx_ = nullptr;
-    haveFormatTable_ = false;
+    haveFormatTable_ = haveLatticeTable_ = false;
     textMode_ = false;
+    latticeTextN_ = 0;
   }
   const std::vector<jppgpu_field_storage> storages = model->fieldStorages();
   c.field_storages = storages.empty() ? nullptr : storages.data();
@@ -106,7 +107,10 @@ Status GpuAnalyzer::initialize(const ModelImage* model, const AnalyzerConfig& cf
   int rc;
   if (shareModelWith != nullptr && shareModelWith->ctx_ != nullptr && shareModelWith->model_ == model) {
     rc = jppgpu_ctx_create_shared(shareModelWith->ctx_, &c, &ctx_);
-    if (rc == JPPGPU_OK) haveFormatTable_ = shareModelWith->haveFormatTable_;   // (the table is part of the shared copy)
+    if (rc == JPPGPU_OK) {   // (the tables are part of the shared copy)
+      haveFormatTable_ = shareModelWith->haveFormatTable_;
+      haveLatticeTable_ = shareModelWith->haveLatticeTable_;
+    }
   } else {
     rc = jppgpu_ctx_create(&model->cmodel(), &c, &ctx_);
   }
@@ -311,7 +315,13 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
     double t1 = now();
     tAnalyze += t1 - t0;
     // host copies are taken right away: the next group's batch invalidates the device side of this result
-    if (fullLattice && latticeNBest_ > 0) {
+    const bool asText = textMode_ && (latticeTextN_ > 0 || !fullLattice);
+    if (asText) {
+      textFetched_ = false;
+      text_ = jppgpu_text_view{};
+      G.view = jppgpu_result_view{};
+      if (!deferText_) JPPA_RETURN_IF_ERROR(fetchText());
+    } else if (fullLattice && latticeNBest_ > 0) {
       const int32_t nBest = std::min<int32_t>(64, cfg_.autoBeamStep > 0 ? G.beam : latticeNBest_);
       rc = jppgpu_result_fetch_nbest(G.result, nBest, &G.nbest);
       if (rc != JPPGPU_OK) return fromCode(rc);
@@ -324,11 +334,6 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
       G.view.beam = G.nbest.beam;
       G.view.global_beam = G.nbest.global_beam;
       G.view.num_scorers = G.nbest.num_scorers;
-    } else if (textMode_ && !fullLattice) {
-      textFetched_ = false;
-      text_ = jppgpu_text_view{};
-      G.view = jppgpu_result_view{};
-      if (!deferText_) JPPA_RETURN_IF_ERROR(fetchText());
     } else {
       rc = jppgpu_result_fetch(G.result, fullLattice ? JPPGPU_FETCH_FULL : JPPGPU_FETCH_TOP1, &G.view);
       if (rc != JPPGPU_OK) return fromCode(rc);
@@ -340,7 +345,7 @@ Status GpuAnalyzer::runBatch(const std::vector<StringPiece>& inputs, bool fullLa
   // which may come from any format worker (distinct sentences write distinct ranges)
   cpOffsetsBase_.assign(n + 1, 0);
   uint64_t cpTotal = 0;
-  for (size_t i = 0; i < n && !(textMode_ && !fullLattice); ++i) {
+  for (size_t i = 0; i < n && !(textMode_ && (latticeTextN_ > 0 || !fullLattice)); ++i) {
     cpOffsetsBase_[i] = cpTotal;
     const jppgpu_result_view& v = groups_[groupOf_[i]].view;
     if (v.status[localIdx_[i]] == JPPGPU_SENT_OK) cpTotal += (uint64_t)v.n_codepoints[localIdx_[i]] + 1;
@@ -405,7 +410,7 @@ Status GpuAnalyzer::fetchText() {
   Group& G = groups_[0];
   static const bool hostTiming = std::getenv("JPPGPU_HOST_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  int rc = jppgpu_result_format_top1(G.result, &text_);
+  int rc = latticeTextN_ > 0 ? jppgpu_result_format_lattice(G.result, latticeTextN_, &text_) : jppgpu_result_format_top1(G.result, &text_);
   if (rc != JPPGPU_OK) return fromCode(rc);
   if (hostTiming)
     std::fprintf(stderr, "fetchText n=%u bytes=%llu total=%.2f ms\n", text_.n_sentences, (unsigned long long)text_.offsets[text_.n_sentences],
@@ -434,6 +439,14 @@ Status GpuAnalyzer::setFormatTable(const jppgpu_format_table& table) {
   int rc = jppgpu_ctx_set_format_table(ctx_, &table);
   if (rc != JPPGPU_OK) return fromCode(rc);
   haveFormatTable_ = true;
+  return Status::Ok();
+}
+
+Status GpuAnalyzer::setLatticeTable(const jppgpu_lattice_table& table) {
+  if (!ctx_) return Status::InvalidState("GpuAnalyzer::setLatticeTable before initialize");
+  int rc = jppgpu_ctx_set_lattice_table(ctx_, &table);
+  if (rc != JPPGPU_OK) return fromCode(rc);
+  haveLatticeTable_ = true;
   return Status::Ok();
 }
 

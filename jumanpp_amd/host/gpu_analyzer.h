@@ -187,7 +187,8 @@ class GpuAnalyzer {
   };
   int32_t latticeNBest_ = 0;
   bool textMode_ = false;          // results are fetched as formatted text (jppgpu_result_format_top1)
-  bool haveFormatTable_ = false;
+  bool haveFormatTable_ = false, haveLatticeTable_ = false;
+  int32_t latticeTextN_ = 0;       // > 0: the text is the lattice format of the N best paths (jppgpu_result_format_lattice)
   bool deferText_ = false, textFetched_ = false;
   const void* memoImage_ = nullptr;
   uint64_t memoImageBytes_ = 0;
@@ -245,7 +246,19 @@ class GpuAnalyzer {
   Status setFormatTable(const jppgpu_format_table& table);
   bool setTextMode(bool on) {
     textMode_ = on && haveFormatTable_ && cfg_.autoBeamStep <= 0;
+    latticeTextN_ = 0;
     return textMode_ == on;
+  }
+  // LatticeFormat::format on the device (jppgpu_lattice_table, csrc/k_latfmt.h): after setLatticeTable, lattice text
+  // mode makes analyzeBatch fetch the lattice-format text of the n best paths of every sentence (also when called with
+  // fullLattice = true: nothing of the lattice itself crosses PCIe).  batchText().head_len says how many bytes of a
+  // sentence's text are the "# MA-SCORE" line a comment replaces.  Not with auto-beam; n <= 64.
+  Status setLatticeTable(const jppgpu_lattice_table& table);
+  bool setLatticeTextMode(int32_t n) {
+    const bool ok = n > 0 && n <= 64 && haveLatticeTable_ && cfg_.autoBeamStep <= 0 && cfg_.globalBeamSize > 0;
+    textMode_ = ok;
+    latticeTextN_ = ok ? n : 0;
+    return ok;
   }
   bool textMode() const { return textMode_; }
   // deferred: analyzeBatch only analyses; fetchText() -- from any thread, before the analyzer's next batch -- runs the

@@ -546,32 +546,6 @@ int main(int argc, const char** argv) {
   StringPiece emptyResult = "# ERROR\nEOS\n";
   const bool latticeFormat = conf.lattice != 0;
   const bool useLattice = latticeFormat || conf.kind == Conf::DicSubset;  // formats that read the whole lattice
-  // (only a regular file is sampled: a FIFO, /dev/stdin or a process substitution would lose the sampled megabyte, or
-  // block on the second open once its writer is gone -- those keep the default batch, as the reference reads any stream)
-  struct stat sampleStat;
-  const bool sampleable = !conf.inputs.empty() && ::stat(conf.inputs[0].c_str(), &sampleStat) == 0 && S_ISREG(sampleStat.st_mode);
-  if (latticeFormat && !conf.batchGiven && sampleable) {
-    // The lattice format reads the N best paths of every sentence as the device gathers them (jppgpu_result_fetch_nbest:
-    // 64 B per path and node).  At beam 32 on 220-codepoint sentences that is 0.2 MB per sentence; a 16 384-sentence
-    // batch moves 3.3 GB through fresh host pages and the analysis stage spends five times the GPU's time on it
-    // (tools/gpu_cli_lattice_probe.py: 20.8 k sentences/s at --batch=16384, 36.2 k at 8192, 48.8 k at 4096).  Unless the
-    // user names a batch size, a batch's gathered paths stay below ~1 GB: nodes per path estimated from the mean line.
-    std::ifstream f(conf.inputs[0], std::ios::binary);
-    std::vector<char> buf(size_t{1} << 20);
-    f.read(buf.data(), (std::streamsize)buf.size());
-    const size_t got = (size_t)f.gcount();
-    size_t lines = 0;
-    for (size_t i = 0; i < got; ++i) lines += buf[i] == '\n';
-    if (got != 0 && lines != 0) {
-      const double meanLine = (double)got / (double)lines;
-      const double nodesPerPath = std::max(4.0, meanLine / 5.0);   // ~3 bytes per codepoint, ~1.7 codepoints per node
-      const double paths = (double)(conf.lattice == -1 ? conf.beam : conf.lattice);
-      const double perSentence = std::max(1.0, std::min(paths, 64.0)) * nodesPerPath * 64.0;
-      size_t cap = (size_t)(1.0e9 / perSentence);
-      cap = std::max<size_t>(1024, cap / 1024 * 1024);
-      if (cap < conf.batch) conf.batch = cap;
-    }
-  }
   if (!latticeFormat && (conf.kind == Conf::Morph || conf.kind == Conf::FullMorph)) emptyResult = "# ERROR\n";
   if (!latticeFormat && (conf.kind == Conf::Segment || conf.kind == Conf::DicSubset)) emptyResult = "";
   auto makeFormat = [&](Status* st) -> OutputFormat* {
@@ -713,6 +687,55 @@ int main(int argc, const char** argv) {
       std::cerr << "device_format=" << (deviceText ? 1 : 0) << " table_entries=" << formatTable.numEntries() << " rows=" << formatTable.numRows()
                 << " blob_bytes=" << formatTable.blobBytes() << " build_ms=" << formatTable.buildMs() << (built ? "" : " (" + statusText(built) + ")") << "\n";
   }
+  // The lattice (-s N) format is printed by the device as well (jppgpu_lattice_table, csrc/k_latfmt.h): the entry-row
+  // columns of every dictionary entry rendered once, here; ids, previous ids, ranks and scores come from the kernels.
+  // --auto-nbest (N differs per sentence), N > 64, --global-beam=0 (no score cells) and --host-format keep the host
+  // formatter, which reads the N best paths gathered on the device (jppgpu_result_fetch_nbest).
+  const int32_t latticeN = conf.lattice == -1 ? conf.beam : conf.lattice;
+  LatticeFormatTable latticeTable;
+  bool deviceLattice = !conf.hostFormat && latticeFormat && acfg.autoBeamStep <= 0 && latticeN >= 1 && latticeN <= 64 &&
+                       acfg.globalBeamSize > 0 && !conf.partialInput && std::getenv("JUMANPP_GPU_HOST_FORMAT") == nullptr;
+  if (deviceLattice) {
+    Status built = latticeTable.build(&model, def.scoreWeights, (unsigned)std::max(1, conf.threads));
+    if (!built) deviceLattice = false;
+    if (conf.timing)
+      std::cerr << "device_lattice_format=" << (deviceLattice ? 1 : 0) << " table_entries=" << latticeTable.numEntries() << " rows=" << latticeTable.numRows()
+                << " blob_bytes=" << latticeTable.blobBytes() << " build_ms=" << latticeTable.buildMs() << (built ? "" : " (" + statusText(built) + ")") << "\n";
+  }
+  // text bytes per input byte, for the plans below: a morpheme covers ~5.5 input bytes; the lattice prints a line of
+  // row text + ~70 bytes of ids and scores for every node on one of the N paths (3-4 times the top-1 path at N = 32)
+  const double latticeTextPerByte =
+      !deviceLattice || latticeTable.numRows() == 0
+          ? 0.0
+          : 1.2 * ((double)latticeTable.blobBytes() / (double)latticeTable.numRows() + 70.0) / 5.5 * (1.0 + 0.075 * std::min<int32_t>(latticeN, 32));
+  // (only a regular file is sampled: a FIFO, /dev/stdin or a process substitution would lose the sampled megabyte, or
+  // block on the second open once its writer is gone -- those keep the default batch, as the reference reads any stream)
+  struct stat sampleStat;
+  const bool sampleable = !conf.inputs.empty() && ::stat(conf.inputs[0].c_str(), &sampleStat) == 0 && S_ISREG(sampleStat.st_mode);
+  if (latticeFormat && !conf.batchGiven && sampleable) {
+    // The lattice format reads the N best paths of every sentence as the device gathers them (jppgpu_result_fetch_nbest:
+    // 64 B per path and node).  At beam 32 on 220-codepoint sentences that is 0.2 MB per sentence; a 16 384-sentence
+    // batch moves 3.3 GB through fresh host pages and the analysis stage spends five times the GPU's time on it
+    // (tools/gpu_cli_lattice_probe.py: 20.8 k sentences/s at --batch=16384, 36.2 k at 8192, 48.8 k at 4096).  Unless the
+    // user names a batch size, a batch's gathered paths stay below ~1 GB: nodes per path estimated from the mean line.
+    std::ifstream f(conf.inputs[0], std::ios::binary);
+    std::vector<char> buf(size_t{1} << 20);
+    f.read(buf.data(), (std::streamsize)buf.size());
+    const size_t got = (size_t)f.gcount();
+    size_t lines = 0;
+    for (size_t i = 0; i < got; ++i) lines += buf[i] == '\n';
+    if (got != 0 && lines != 0) {
+      const double meanLine = (double)got / (double)lines;
+      const double nodesPerPath = std::max(4.0, meanLine / 5.0);   // ~3 bytes per codepoint, ~1.7 codepoints per node
+      const double paths = (double)latticeN;
+      // (device text: what crosses PCIe is the text itself; a batch's text stays below ~256 MB, the size of one of the
+      // page-locked blocks it is copied into)
+      const double perSentence = deviceLattice ? meanLine * latticeTextPerByte * 4.0 : std::max(1.0, std::min(paths, 64.0)) * nodesPerPath * 64.0;
+      size_t cap = (size_t)(1.0e9 / perSentence);
+      cap = std::max<size_t>(1024, cap / 1024 * 1024);
+      if (cap < conf.batch) conf.batch = cap;
+    }
+  }
   // The batches of a file-to-file run, sized before anything is allocated (the inputs are regular files): lines per batch
   // x the mean line of a sample, with a margin; the JUMAN text of a batch from the mean row of the format table (a
   // morpheme covers ~5.5 input bytes and prints about one row).  Used twice: the page-locked text blocks are pinned on
@@ -744,8 +767,8 @@ int main(int argc, const char** argv) {
     const double meanLine = sampleLines ? (double)sampleBytes / (double)sampleLines : 64.0;
     planBatchBytes = std::min<uint64_t>((uint64_t)inputTotal + 64, (uint64_t)((double)conf.batch * meanLine * 1.15) + 65536);
     planBatchLines = (uint32_t)std::min<uint64_t>(conf.batch, (uint64_t)((double)inputTotal / std::max(1.0, meanLine - 1.0)) + 16);
-    if (deviceText && formatTable.numRows() > 0) {
-      planTextPerByte = (float)(1.1 * ((double)formatTable.blobBytes() / (double)formatTable.numRows()) / 5.5);
+    if ((deviceText && formatTable.numRows() > 0) || deviceLattice) {
+      planTextPerByte = deviceLattice ? (float)latticeTextPerByte : (float)(1.1 * ((double)formatTable.blobBytes() / (double)formatTable.numRows()) / 5.5);
       const uint64_t textBytes = (uint64_t)((double)planBatchBytes * planTextPerByte) + 64 * (uint64_t)planBatchLines + 4096;
       const size_t nBatches = (size_t)((double)inputTotal / std::max(1.0, (double)planBatchBytes / 1.15)) + 1;
       // per pipeline: the block being filled, one queued, one being written
@@ -757,7 +780,7 @@ int main(int argc, const char** argv) {
   auto makeAnalyzer = [&](int d, int a) -> Status {
     analyzers[d][a].reset(new GpuAnalyzer());
     // the lattice format reads the N best paths only: they are gathered on the device (N = what it prints)
-    if (latticeFormat) analyzers[d][a]->setLatticeNBest(conf.lattice == -1 ? conf.beam : conf.lattice);
+    if (latticeFormat && !deviceLattice) analyzers[d][a]->setLatticeNBest(latticeN);
     // one copy of the model per GPU: a later analyzer of the same physical device uses the first one's
     const GpuAnalyzer* donor = nullptr;
     for (int d2 = 0; d2 < nDev && donor == nullptr; ++d2)
@@ -775,6 +798,11 @@ int main(int argc, const char** argv) {
         analyzers[d][a]->setTextMode(true);
         analyzers[d][a]->setDeferredText(sharded);
       }
+    }
+    if (made && deviceLattice) {
+      if (donor == nullptr) made = analyzers[d][a]->setLatticeTable(latticeTable.view());
+      if (made && !analyzers[d][a]->setLatticeTextMode(latticeN)) made = Status::InvalidState("lattice text mode was refused");
+      if (made) analyzers[d][a]->setDeferredText(sharded);
     }
     return made;
   };
@@ -1031,7 +1059,7 @@ int main(int argc, const char** argv) {
         while (fmtQ[d]->pop(&job)) {
           const long long t0 = us();
           const size_t n = job->inputs.size();
-          if (deviceText && job->batchStatus.isOk()) {
+          if ((deviceText || deviceLattice) && job->batchStatus.isOk()) {
             // the device formats: this thread runs the format kernels and copies the text (while the analysis thread is
             // on the device's other analyzer), then cuts the batch's bytes into the segments the writer puts out --
             // one run per stretch of sentences without a comment line, a failed read or an error message
@@ -1069,16 +1097,21 @@ int main(int argc, const char** argv) {
                 }
                 if (tv.status[i] != JPPGPU_SENT_OK) errors += statusText(an.sentenceStatus(i));   // (its text is the error result)
                 const StringPiece& cm = job->comments[i];
-                if (cm.size() >= 2 && tv.status[i] == JPPGPU_SENT_OK) {
+                // lattice text: a comment takes the place of the "# MA-SCORE" line the text starts with, and a sentence
+                // without that line (empty input: "EOS" alone) prints none (lattice_format.cc:87-120)
+                const size_t head = tv.head_len != nullptr ? tv.head_len[i] : 0;
+                size_t skip = 0;
+                if (cm.size() >= 2 && tv.status[i] == JPPGPU_SENT_OK && (tv.head_len == nullptr || head != 0)) {
                   seg(cm.data(), cm.size());   // "# comment", as it stands in the mapped input
                   seg("\n", 1);
+                  skip = head;
                 }
-                seg(tv.text + tv.offsets[i], (size_t)(tv.offsets[i + 1] - tv.offsets[i]));
+                seg(tv.text + tv.offsets[i] + skip, (size_t)(tv.offsets[i + 1] - tv.offsets[i]) - skip);
               }
               job->deviceText = an.takeText();
             }
           }
-          if (deviceText && job->batchStatus.isOk()) {
+          if ((deviceText || deviceLattice) && job->batchStatus.isOk()) {
             freeAnalyzers[d]->release();
             formatUs += us() - t0;
             std::unique_lock<std::mutex> l(seqMu);
@@ -1335,13 +1368,17 @@ int main(int argc, const char** argv) {
       StringPiece comment = e.comment.size() < 2 ? StringPiece("") : StringPiece(e.comment.data() + 2, e.comment.size() - 2);
       if (conf.partialInput) comment = StringPiece(e.partial->comment);
       if (analyzer.textMode()) {   // the device printed the sentence; the comment line goes in front of it
-        if (!comment.empty()) {
+        const uint32_t* heads = analyzer.batchText().head_len;   // (lattice text: the comment replaces the "# MA-SCORE" line)
+        const size_t head = heads != nullptr ? heads[i] : 0;
+        size_t skip = 0;
+        if (!comment.empty() && (heads == nullptr || head != 0)) {
           text->append("# ");
           text->append(comment.data(), comment.size());
           *text += '\n';
+          skip = head;
         }
         const StringPiece r = analyzer.sentenceText(i);
-        text->append(r.data(), r.size());
+        text->append(r.data() + skip, r.size() - skip);
         continue;
       }
       st = format->format(analyzer, i, comment);

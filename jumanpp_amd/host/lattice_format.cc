@@ -38,6 +38,72 @@ inline bool isFake(const jppgpu_beam_slot& s) { return s.left == 0xffff && s.bea
 
 void formatNormalizedFeature(std::string& p, int32_t v);  // juman_format.cc
 
+// the columns of a line that come from the entry row the walker stands on (lattice_format.cc:168-205): surface, canonic
+// form (or baseform '/' reading), reading, baseform, the four grammar columns with their JUMAN ids, the feature list
+void formatLatticeRow(const ModelImage& model, const JumandicFields& flds, const NodeWalker& walker, std::string& printer,
+                      LatticeRowPieces* pieces) {
+  const size_t at0 = printer.size();
+  const StringPiece surface = flds.surface[walker], reading = flds.reading[walker], baseform = flds.baseform[walker];
+  put(printer, escapeTab(surface));
+  const size_t endS = printer.size();
+  printer += '\t';
+  const StringPiece canFrm = flds.canonicForm[walker];
+  if (!canFrm.empty()) {
+    put(printer, canFrm);
+  } else {
+    put(printer, baseform);
+    printer += '/';
+    put(printer, reading);
+  }
+  printer += '\t';
+  const size_t atR = printer.size();
+  put(printer, escapeTab(reading));
+  const size_t endR = printer.size();
+  printer += '\t';
+  put(printer, escapeTab(baseform));
+  const size_t endB = printer.size();
+  printer += '\t';
+  const int32_t* fb = walker.features();
+  int32_t ids[4];
+  model.dicToJuman(fb[1], fb[2], fb[4], fb[3], ids);   // conjForm and conjType are reversed in the entry row
+  put(printer, flds.pos[walker]);
+  printer += '\t';
+  putInt(printer, ids[0]);
+  printer += '\t';
+  put(printer, ifEmpty(flds.subpos[walker], "*"));
+  printer += '\t';
+  putInt(printer, ids[1]);
+  printer += '\t';
+  put(printer, ifEmpty(flds.conjType[walker], "*"));
+  printer += '\t';
+  putInt(printer, ids[2]);
+  printer += '\t';
+  put(printer, ifEmpty(flds.conjForm[walker], "*"));
+  printer += '\t';
+  putInt(printer, ids[3]);
+  printer += '\t';
+  KVListIterator features = flds.features[walker];
+  while (features.next()) {
+    put(printer, features.key());
+    if (features.hasValue()) {
+      printer += ':';
+      put(printer, features.value());
+    }
+    printer += '|';
+  }
+  if (pieces != nullptr) {
+    pieces->s = (uint32_t)(endS - at0);
+    pieces->c = (uint32_t)canFrm.size();
+    pieces->r = (uint32_t)(endR - atR);
+    pieces->b = (uint32_t)(endB - endR - 1);
+    pieces->rest = (uint32_t)(printer.size() - endB - 1);
+    pieces->total = (uint32_t)(printer.size() - at0);
+    // a lone tab in one of the three escaped columns prints differently in the second column: not a table row
+    auto lone = [](StringPiece x) { return x.size() == 1 && x[0] == '\t'; };
+    pieces->tabField = lone(surface) || lone(reading) || lone(baseform);
+  }
+}
+
 Status LatticeFormat::initialize(const ModelImage* model, const std::vector<float>& scoreWeights) {
   model_ = model;
   weights_ = scoreWeights;
@@ -217,49 +283,7 @@ Status LatticeFormat::format(const GpuAnalyzer& analysis, size_t sentence, Strin
       printer += '\t';
       putInt(printer, position + (nd.end - nd.start) - 1);
       printer += '\t';
-      put(printer, escapeTab(flds_.surface[walker_]));
-      printer += '\t';
-      StringPiece canFrm = flds_.canonicForm[walker_];
-      if (!canFrm.empty()) {
-        put(printer, canFrm);
-      } else {
-        put(printer, flds_.baseform[walker_]);
-        printer += '/';
-        put(printer, flds_.reading[walker_]);
-      }
-      printer += '\t';
-      put(printer, escapeTab(flds_.reading[walker_]));
-      printer += '\t';
-      put(printer, escapeTab(flds_.baseform[walker_]));
-      printer += '\t';
-      const int32_t* fb = walker_.features();
-      int32_t ids[4];
-      model_->dicToJuman(fb[1], fb[2], fb[4], fb[3], ids);
-      put(printer, flds_.pos[walker_]);
-      printer += '\t';
-      putInt(printer, ids[0]);
-      printer += '\t';
-      put(printer, ifEmpty(flds_.subpos[walker_], "*"));
-      printer += '\t';
-      putInt(printer, ids[1]);
-      printer += '\t';
-      put(printer, ifEmpty(flds_.conjType[walker_], "*"));
-      printer += '\t';
-      putInt(printer, ids[2]);
-      printer += '\t';
-      put(printer, ifEmpty(flds_.conjForm[walker_], "*"));
-      printer += '\t';
-      putInt(printer, ids[3]);
-      printer += '\t';
-      KVListIterator features = flds_.features[walker_];
-      while (features.next()) {
-        put(printer, features.key());
-        if (features.hasValue()) {
-          printer += ':';
-          put(printer, features.value());
-        }
-        printer += '|';
-      }
+      formatLatticeRow(*model_, flds_, walker_, printer, nullptr);
       if (walker_.isSpecial()) {
         int32_t u = walker_.placeholder(NormalizedPlaceholderIdx);
         if (u != 0) {

@@ -13,6 +13,14 @@
 
 namespace jumanpp_amd {
 
+// byte lengths of the parts of the entry-row columns of one lattice line (include/jppgpu.h: jppgpu_lattice_row)
+struct LatticeRowPieces {
+  uint32_t s = 0, c = 0, r = 0, b = 0, rest = 0, total = 0;
+  bool tabField = false;
+};
+void formatLatticeRow(const ModelImage& model, const JumandicFields& flds, const NodeWalker& walker, std::string& printer,
+                      LatticeRowPieces* pieces);
+
 class LatticeFormat : public OutputFormat {
   // LatticeNodeInfo (lattice_format.h:17-25) of the nodes on the printed paths.  Flat records reused from sentence to
   // sentence (the reference keeps a map of vectors per node: at beam 32 on 220-codepoint sentences that bookkeeping,

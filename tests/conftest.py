@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    # The CLI writes its derived-image cache beside the model file: not for the models under tests/golden (a cache left
+    # by one run would change what the next run exercises).  The cache tests switch it on for a copy of a model.
+    os.environ.setdefault('JPPGPU_NO_IMAGE_CACHE', '1')
 
 
 @pytest.fixture(scope='session')
@@ -30,7 +33,7 @@ def emu_lib():
 @pytest.fixture(scope='session')
 def gpu_lib():
     import __graft_entry__ as ge
-    # developer builds of the same sources (tools/gpu_session.sh asan: the device-AddressSanitizer library)
+    # developer builds of the same sources
     if os.environ.get('JPPGPU_TEST_LIB'):
         return os.environ['JPPGPU_TEST_LIB']
     return ge.build_native()

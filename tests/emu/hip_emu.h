@@ -336,5 +336,10 @@ inline unsigned atomicOr(unsigned* p, unsigned v) {
   *p = o | v;
   return o;
 }
+inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) {
+  unsigned long long o = *p;
+  *p = o | v;
+  return o;
+}
 
 #endif  // JPP_TESTS_HIP_EMU_H

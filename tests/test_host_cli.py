@@ -31,6 +31,8 @@ def _run(cli, args, stdin=None, image_cache=False):
     env = dict(os.environ)
     if not image_cache:
         env['JPPGPU_NO_IMAGE_CACHE'] = '1'
+    else:
+        env.pop('JPPGPU_NO_IMAGE_CACHE', None)   # (conftest.py switches the cache off for every other CLI run of the suite)
     p = subprocess.run([cli] + args, input=stdin, capture_output=True, env=env)
     return p.returncode, p.stdout, p.stderr
 
@@ -108,6 +110,73 @@ def _device_format_case(cli, golden_dir, tmp_path):
         out = str(tmp_path / 'o2.txt')
         rc3, _, e3 = _run(cli, ['--model=' + model, '--batch=' + batch, '-o', out, str(src)])
         assert open(out, 'rb').read() == host and rc3 == rc and e3 == eh, batch
+
+
+def _device_lattice_case(cli, golden_dir, tmp_path):
+    """the lattice (-s N) format is printed by the DEVICE by default (k_lat_count / k_lat_write, csrc/k_latfmt.h, over
+    the table host/format_table.cc renders with LatticeFormat's own row printer): it must say so, and its bytes must be
+    those of the host formatter (--host-format; that one is compared with the reference in
+    test_lattice_format_byte_identical_to_reference_cli and the fixtures of tests/golden/ref).  Reference's own
+    dictionaries (alias entries, every UNK maker), with and without the RNN (one / two score weights), N from 1 to
+    beyond the beam, stream and file pipelines, tiny batches, comments (which replace the "# MA-SCORE" line), empty and
+    failing lines, a tab as a one-byte surface."""
+    fix = os.path.join(golden_dir, 'ref')
+    cases = [(os.path.join(golden_dir, 'mini.jppmdl'), os.path.join(golden_dir, 'mini.txt')),
+             (os.path.join(golden_dir, 'mini_rnn.jppmdl'), os.path.join(golden_dir, 'mini.txt'))]
+    for m in ('minimal', 'minimal_trained', 'codegen', 'bug28', 'bug950111'):
+        cases.append((os.path.join(fix, m + '.jppmdl'), os.path.join(fix, m + '.txt')))
+    for model, txt in cases:
+        for flags in (['-s', '1'], ['-s', '5'], ['--beam=12', '--global-beam=12', '--right-beam=12', '-s', '12'], ['-s', '30']):
+            rc, host, eh = _run(cli, ['--model=' + model, '--host-format'] + flags + [txt])
+            assert rc == 0 and host, eh[-300:]
+            rc, dev, err = _run(cli, ['--model=' + model, '--timing'] + flags + [txt])
+            assert rc == 0 and b'device_lattice_format=1' in err, err[-300:]
+            assert dev == host, (model, flags)
+        out = str(tmp_path / 'o.txt')
+        rc, host, eh = _run(cli, ['--model=' + model, '--host-format', '-s', '5', txt])
+        rc, _, err = _run(cli, ['--model=' + model, '--timing', '--batch=5', '-s', '5', '-o', out, txt])
+        assert rc == 0 and b'device_lattice_format=1' in err and b'sharded=1' in err and open(out, 'rb').read() == host, model
+    # the reference's lattice goldens of its own dictionaries, through the device formatter
+    for m in ('minimal', 'codegen', 'bug28', 'bug950111'):
+        ref = open(os.path.join(fix, m + '.s5.out'), 'rb').read()
+        rc, dev, err = _run(cli, ['--model=' + os.path.join(fix, m + '.jppmdl'), '-s', '5', os.path.join(fix, m + '.txt')])
+        assert rc == 0 and dev == ref, m
+    for model in (cases[0][0], cases[1][0]):
+        data = ('# S-ID:1 first\n' + open(cases[0][1], encoding='utf-8').read() + '# c2\n\n# c3\nすごーーい〜かぁっこいいねぇっッ！\n').encode('utf-8') \
+            + b'\xe3\x81\n' + ('あ' * 1400).encode('utf-8') + b'\n\t\nx\ty\n \n# last comment'
+        src = tmp_path / 'in.txt'
+        src.write_bytes(data)
+        rc, host, eh = _run(cli, ['--model=' + model, '--host-format', '-s', '4', str(src)])
+        rc2, dev, ed = _run(cli, ['--model=' + model, '-s', '4', str(src)])
+        assert dev == host and rc == rc2 and ed == eh
+        for batch in ('3', '1000'):
+            out = str(tmp_path / 'o2.txt')
+            rc3, _, e3 = _run(cli, ['--model=' + model, '--batch=' + batch, '-s', '4', '-o', out, str(src)])
+            assert open(out, 'rb').read() == host and rc3 == rc and e3 == eh, batch
+    # what keeps the host formatter: --auto-nbest (N per sentence), no global beam
+    rc, a, err = _run(cli, ['--model=' + cases[1][0], '--timing', '--auto-nbest=2:3:8', '-s', '1', cases[1][1]])
+    assert rc == 0 and b'device_lattice_format' not in err
+    rc, b, err = _run(cli, ['--model=' + cases[0][0], '--timing', '--global-beam=0', '-s', '2', cases[0][1]])
+    assert b'device_lattice_format' not in err
+
+
+def test_device_side_lattice_format(cli_emu, golden_dir, tmp_path):
+    _device_lattice_case(cli_emu, golden_dir, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_device_side_lattice_format(cli_gpu, golden_dir, tmp_path):
+    _device_lattice_case(cli_gpu, golden_dir, tmp_path)
+
+
+def test_exact_percent_g_of_the_device(tmp_path):
+    """csrc/jpp_fmtg.h -- the "%g" the device prints scores with -- against the C library: every exponent with structured
+    mantissas, the neighbourhoods of the powers of ten and of d.ddddd5 ties, denormals, 2 M random bit patterns"""
+    exe = str(tmp_path / 'fmtg_test')
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-DJPP_EMU', '-I' + os.path.join(ROOT, 'tests', 'emu'),
+                           '-I' + os.path.join(ROOT, 'jumanpp_amd', 'csrc'), os.path.join(ROOT, 'tests', 'host', 'fmtg_test.cc'), '-o', exe])
+    p = subprocess.run([exe, '2000000'], capture_output=True, text=True)
+    assert p.returncode == 0 and ' 0 mismatches' in p.stdout, p.stdout[-300:] + p.stderr[-2000:]
 
 
 def test_device_side_juman_format(cli_emu, golden_dir, tmp_path):

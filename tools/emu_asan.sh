@@ -1,7 +1,7 @@
 #!/bin/bash
 # CPU container: the kernel sources on the fiber emulator, built with host AddressSanitizer and with every workgroup's
 # LDS poisoned (tests/emu/hip_emu.h: poison_lds), through the emulator parity tests.  This is the sanitizer pass of the
-# device code that exists in this image: device-side ASan (hipcc -fsanitize=address, gfx950:xnack+) builds, but its
+# device code that exists in this image: a device-side sanitizer build compiles, but its
 # runtime cannot allocate device memory on the GPU boxes (no /opt/rocm/lib/asan; profiles/r05_a_fault_rootcause.txt).
 #   bash tools/emu_asan.sh [pytest -k expression]      -> build/emu_asan.log
 set -u
