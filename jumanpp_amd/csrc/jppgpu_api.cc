@@ -528,7 +528,7 @@ struct jppgpu_ctx {
   std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
   DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text, fmt_st;
-  DevBuf lat_mask, lat_used, lat_best, lat_id, lat_head;   // k_latfmt.h: per-node sets of the N best paths, header bytes per sentence
+  DevBuf lat_mask, lat_used, lat_best, lat_id, lat_list, lat_marked, lat_head;   // k_latfmt.h: per-node sets of the N best paths, header bytes per sentence
   bool timing_pending = false;
   // one enqueue per batch (k_lattice.h: k_cap_guard): grids of the rare sweep classes and the scratch geometry the next
   // batch is launched with before its totals are known; statistics for the bench / tests
@@ -2554,21 +2554,21 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
       return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
     jpp_stream_t st = ctx->last_stream;
     const size_t N = (size_t)B.total_nodes + 1;
-    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_used.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) &&
-          ctx->lat_head.ensure(((size_t)n + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) &&
+    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_used.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) && ctx->lat_list.ensure(N * 4) && ctx->lat_marked.ensure(((size_t)n + 1) * 4) &&
+          ctx->lat_head.ensure(((size_t)n + 1) * 4) && ctx->fmt_len.ensure(N * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) &&
           ctx->fmt_st.ensure(((size_t)n + 1) * 4)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice format)");
     const LatTable* T = ctx->mb->lat_table.as<LatTable>();
-    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_used.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>()};
-    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_st.as<i32>());
+    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_used.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<u32>(), ctx->lat_marked.as<u32>()};
+    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_len.as<u32>(), ctx->fmt_st.as<i32>());
     launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
     rt_sync(st);   // the byte total sizes the text buffers
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format offsets)");
     const u64 total = res->fm_off.data()[n];
     if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
-    if (n) JPP_LAUNCH(k_lat_write, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, (const u64*)ctx->fmt_off.as<u64>(), ctx->fmt_text.as<u8>(),
-                      (const i32*)ctx->fmt_st.as<i32>());
+    if (n) JPP_LAUNCH(k_lat_write, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, (const u64*)ctx->fmt_off.as<u64>(), (const u32*)ctx->lat_head.as<u32>(),
+                      (const u32*)ctx->fmt_len.as<u32>(), ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
     ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
     ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);
     ok &= pull(res->fm_head, ctx->lat_head.p, n, st);

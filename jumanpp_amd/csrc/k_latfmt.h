@@ -21,17 +21,20 @@
 //   k_lat_count  lane = path: walks its path back from EOS and leaves, per lattice node, the set of paths through it
 //                (64-bit mask = the ranks), the set of beam slots used (= the distinct connections) and the connection
 //                with the smallest total (atomicMin of an ordered key) in four per-node words of HBM; then numbers the
-//                marked nodes (ballot + popcount = publishResult's ids), and counts the bytes of every line;
-//   k_lat_write  the same walk over the marked nodes in id order, one line at a time: numbers and scores are printed
-//                by lane 0 into an LDS line buffer and flushed by all lanes, entry-row text is copied blob -> output by
-//                all 64 lanes (a dictionary node's row is ONE contiguous run), so stores are coalesced.
-// What is wave-uniform is kept uniform (node, masks, lengths): a line is a straight sequence of cooperative copies.
+//                marked nodes (ballot + popcount = publishResult's ids); then lane = node: the bytes of its lines;
+//   k_lat_write  lane = node again: every lane prints the lines of its own node -- ids, previous ids, "%g" digits, ranks,
+//                the entry-row text read from the blob eight bytes at a time -- into the wavefront's LDS window, at the
+//                offset a wave scan of the byte counts gives it; the window leaves as whole dwords.
+// (The first form printed ONE line at a time with all 64 lanes copying its pieces: 25 us per line -- every line waited
+// for its own chain of dependent loads and for the table's literals, read byte by byte from HBM -- 19 ms of format
+// kernels per 4 096-sentence batch at beam 32, more than the analysis.  profiles/r06_c_*.)
 #ifndef JPP_K_LATFMT_H
 #define JPP_K_LATFMT_H
 
 #include "jpp_device.h"
 #include "jpp_fmtg.h"
 #include "k_format.h"
+#include "k_lattice.h"
 
 namespace jpp {
 
@@ -73,17 +76,15 @@ struct LatScratch {
   u64* slots;   // beam slots of the node those paths use
   u64* best;    // min over those connections of (ordered total << 32 | path << 8 | slot)
   u32* id;      // publishResult's id, 0 = not on a path
+  u32* list;    // [node_base + id - 1] = the node with that id (the marked nodes in output order)
+  u32* marked;  // [sentence] how many
 };
-
-constexpr u32 kLatTmp = 1024;       // LDS line buffer per wavefront (room() flushes before it would overflow)
 
 __device__ __forceinline__ u32 lat_order_f32(float t) {
   u32 b;
   __builtin_memcpy(&b, &t, 4);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-
-__device__ __forceinline__ u32 wave_min_u32(u32 v) { return ~wave_max_u32(~v); }
 
 __device__ __forceinline__ u32 lat_first_row(const LatTable& T, i32 eptr) {
   const u32 slot = ((u32)eptr >> 1) >> 3;
@@ -92,73 +93,63 @@ __device__ __forceinline__ u32 lat_first_row(const LatTable& T, i32 eptr) {
   return v == 0 ? ~0u : v - 1;
 }
 
-// The cursor of one sentence's text: `o` is the next output byte, `n` the fill of the LDS line buffer.  WRITE = false
-// only counts.  All arguments of its members are wave-uniform.
-template <bool WRITE>
+// One lane's cursor into the output: `p` is where its text goes (WRITE = false only counts, p is unused).  Everything
+// here is per lane -- different lanes print different lattice nodes.
+template <bool WRITE, typename P = u8*>
 struct LatOut {
-  u8* out;
-  u8* tmp;
-  u64 o;
-  u32 n;
-  u32 lane;
-  __device__ __forceinline__ void flush() {
-    if (WRITE) {
-      wave_sync();
-      for (u32 i = lane; i < n; i += 64) out[o + i] = tmp[i];
-      wave_sync();
-    }
-    o += n;
-    n = 0;
-  }
-  // lane 0's cursor into the line buffer (null for the other lanes and when counting)
-  __device__ __forceinline__ u8* cur() const { return (WRITE && lane == 0) ? tmp + n : nullptr; }
+  P p;      // (u8* into the output, or a typed pointer into the wavefront's LDS window)
+  u64 n;
   __device__ __forceinline__ void ch(u8 c) {
-    if (WRITE && lane == 0) tmp[n] = c;
+    if (WRITE) p[n] = c;
     ++n;
   }
-  __device__ __forceinline__ void num(u32 v) { n += u32_format(v, cur()); }
-  __device__ __forceinline__ void flt(float v) { n += g_format(v, cur()); }
-  __device__ __forceinline__ void lit(const u8* p, u32 len) {   // a short literal of the table (by value in the kernel argument's copy)
-    if (WRITE && lane == 0)
-      for (u32 i = 0; i < len; ++i) tmp[n + i] = p[i];
+  __device__ __forceinline__ void num(u32 v) { n += u32_format(v, WRITE ? p + n : P(nullptr)); }
+  __device__ __forceinline__ void flt(const GDigits& g) { n += g_emit(g, WRITE ? p + n : P(nullptr)); }
+  // a literal of the table (the table's copy in LDS)
+  __device__ __forceinline__ void lit(const u8* src, u32 len) {
+    if (WRITE)
+      for (u32 i = 0; i < len; ++i) p[n + i] = src[i];
     n += len;
   }
-  // a run of bytes from HBM (the blob, the input text) straight to the output, after what the line buffer holds
+  // a run of bytes from HBM (the blob, the input text): read eight at a time (unaligned reads are the hardware's business)
   __device__ __forceinline__ void run(const u8* src, u32 len) {
-    if (n) flush();
-    if (WRITE)
-      for (u32 i = lane; i < len; i += 64) out[o + i] = src[i];
-    o += len;
-  }
-  __device__ __forceinline__ void room(u32 need) {
-    if (n + need > kLatTmp) flush();
+    if (WRITE) {
+      P d = p + n;
+      u32 i = 0;
+      for (; i + 8 <= len; i += 8) {
+        u64 v;
+        __builtin_memcpy(&v, src + i, 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[i + k] = (u8)(v >> (8 * k));
+      }
+      for (; i < len; ++i) d[i] = src[i];
+    }
+    n += len;
   }
 };
 
-// one lattice node of the output: its lines.  Returns false when the table has no row for it.
-template <bool WRITE>
-__device__ __forceinline__ bool lat_node_lines(LatOut<WRITE>& w, const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S,
+// One lattice node of the output: its lines (one per row of its entry), printed by ONE lane.  Returns false when the
+// table has no row for it.  T: the table's copy in LDS (its pointers point into HBM).
+template <bool WRITE, typename P>
+__device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S,
                                               u64 nb, u32 node, const u8* text, const u16* boff) {
-  const u32 lane = w.lane;
   const int beam = cfg.beam, G = cfg.gbeam, NS = cfg.nscorers;
   const u64 gn = nb + node;
   const NodeInfo ni = B.node_info[gn];
   const bool unk = ni.eptr < 0;
   NodeAux na{0, 0, 0, 0, 0, 0};
   if (unk) na = B.node_aux[gn];
-  u32 row = uni(lat_first_row(T, unk ? na.tmpl : ni.eptr));
+  u32 row = lat_first_row(T, unk ? na.tmpl : ni.eptr);
   if (row == ~0u) return false;
   const u64 mask = S.mask[gn], slots = S.slots[gn];
   const u32 bslot = (u32)(S.best[gn] & 0xffu);
   const BeamSlot* beams = B.node_beam + gn * (u64)beam;
-  // distinct previous nodes, ascending: lane j holds the previous node of slot j
-  const u32 pj = (lane < (u32)beam && ((slots >> lane) & 1)) ? beams[lane].prev_node : ~0u;
-  // the scores of the chosen connection
+  // the scores of the chosen connection, as "%g" digits (once per node, printed on every row)
   const float* cell = B.node_cells + (gn * (u64)G + beams[bslot].pad) * (u64)NS;
   const float f0 = cell[0] * T.weights[0];
   const bool two = T.n_weights == 2 && NS > 1;
   const float f1 = two ? cell[1] * T.weights[1] : 0.f;
-  const float ftot = two ? f0 + f1 : f0;
+  const GDigits g0 = g_digits(f0), g1 = g_digits(f1), gt = g_digits(two ? f0 + f1 : f0);
   const u32 id = S.id[gn];
   const u32 rep = unk && na.maker < 16 ? T.maker_replaces[na.maker] : 0;
   FmtSurface raw{text, 0}, esc{text, 0};
@@ -174,26 +165,28 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE>& w, const Batch& B,
   for (;; ++row) {
     const LatRow r = T.rows[row];
     // "-\t" id "\t" prevs "\t" start "\t" end "\t"
-    w.room(64);
     w.ch('-');
     w.ch('\t');
     w.num(id);
     w.ch('\t');
     {
+      // the distinct previous nodes in ascending order: the smallest one above the last printed, again and again (a
+      // node has one or two as a rule; the slots of the set are few)
       i64 last = -1;
       bool first = true;
       for (;;) {
-        const u32 cand = (pj != ~0u && (i64)pj > last) ? pj : ~0u;
-        const u32 m = uni(wave_min_u32(cand));
+        u32 m = ~0u;
+        for (u64 sm = slots; sm != 0; sm &= sm - 1) {
+          const u32 pj = beams[__builtin_ctzll(sm)].prev_node;
+          if ((i64)pj > last && pj < m) m = pj;
+        }
         if (m == ~0u) break;
-        w.room(16);
         if (!first) w.ch(';');
         w.num(S.id[nb + m]);
         last = (i64)m;
         first = false;
       }
     }
-    w.room(32);
     w.ch('\t');
     w.num(ni.start);
     w.ch('\t');
@@ -201,7 +194,7 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE>& w, const Batch& B,
     w.ch('\t');
     // the entry row: S \t X \t R \t B \t REST
     const u8* pS = T.blob + r.blob_off;
-    const u32 lenS = uni((u32)r.len_s), lenC = uni((u32)r.len_c), lenR = uni((u32)r.len_r), lenB = uni((u32)r.len_b), lenRest = uni(r.len_rest);
+    const u32 lenS = r.len_s, lenC = r.len_c, lenR = r.len_r, lenB = r.len_b, lenRest = r.len_rest;
     const u32 lenX = lenC ? lenC : lenB + 1 + lenR;
     if (!unk) {
       w.run(pS, lenS + 1 + lenX + 1 + lenR + 1 + lenB + 1 + lenRest);
@@ -234,7 +227,6 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE>& w, const Batch& B,
       w.ch('\t');
       w.run(pRest, lenRest);
       if (fv != 0) {
-        w.room(64);
         w.lit(T.flag_label, T.flag_label_len);
         for (int f = 0; f < (int)T.n_flags; ++f)
           if (fv & T.flag_mask[f]) w.ch(T.flag_char[f]);
@@ -242,83 +234,67 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE>& w, const Batch& B,
       }
     }
     // scores and ranks
-    w.room(160);
     w.lit(T.feat_text, T.feat_len);
-    w.flt(f0);
+    w.flt(g0);
     w.ch('|');
     if (two) {
       w.lit(T.lm_text, T.lm_len);
-      w.flt(f1);
+      w.flt(g1);
       w.ch('|');
     }
     w.lit(T.total_text, T.total_len);
-    w.flt(ftot);
+    w.flt(gt);
     w.ch('|');
     w.lit(T.ranks_text, T.ranks_len);
     for (u64 mm = mask; mm != 0;) {
       const u32 j = (u32)__builtin_ctzll(mm);
       mm &= mm - 1;
-      w.room(8);
       w.num(j + 1);
       if (mm != 0) w.ch(';');
     }
     w.ch('\n');
-    w.flush();
     if (r.flags & 2) break;
   }
   return true;
 }
 
-// "# MA-SCORE\t" "rank" i ":" total " " ... "\n"
-template <bool WRITE>
-__device__ __forceinline__ void lat_header(LatOut<WRITE>& w, const LatTable& T, const BeamSlot* eos, int beam, int n_best) {
+// "# MA-SCORE\t" "rank" i ":" total " " ... "\n" (one lane)
+template <bool WRITE, typename P>
+__device__ __forceinline__ void lat_header(LatOut<WRITE, P>& w, const LatTable& T, const BeamSlot* eos, int beam, int n_best) {
   w.lit(T.head_text, T.head_len);
   for (int i = 0; i < n_best && i < beam; ++i) {
     const BeamSlot el = eos[i];
     if (el.left == kFake16 && el.beam == kFake16) break;
-    w.room(48);
     w.lit(T.rank_text, T.rank_len);
     w.num((u32)i + 1);
     w.ch(':');
-    w.flt(el.total);
+    w.flt(g_digits(el.total));
     w.ch(' ');
   }
-  w.room(4);
   w.ch('\n');
-  w.flush();
 }
 
-// the body of both kernels from the numbered nodes on: header, lines, EOS.  Returns the bytes; *head = bytes of the header.
-template <bool WRITE>
-__device__ __forceinline__ u64 lat_sentence_text(const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S, u32 s, int n_best,
-                                                 u8* out, u64 o0, u8* tmp, u32 lane, u32* head, bool* ok) {
-  const u64 nb = B.node_base[s];
-  const u32 N = B.sent_nodes[s];
-  const u32 off = B.byte_off[s];
-  const u8* text = B.text + off;
-  const u16* boff = B.cp_boff + off + s;
-  LatOut<WRITE> w{out, tmp, o0, 0, lane};
-  lat_header(w, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best);
-  *head = (u32)(w.o - o0);
-  *ok = true;
-  for (u32 base = 2; base + 1 < N; base += 64) {   // (0, 1 = BOS, N - 1 = EOS are never on the list)
-    const u32 nd = base + lane;
-    u64 bal = wave_ballot(nd + 1 < N && S.id[nb + nd] != 0);
-    while (bal) {
-      const u32 j = (u32)__builtin_ctzll(bal);
-      bal &= bal - 1;
-      if (!lat_node_lines<WRITE>(w, B, cfg, T, S, nb, uni(base + j), text, boff)) *ok = false;
-    }
-  }
-  w.lit(T.eos_text, T.eos_len);
-  w.flush();
-  return w.o - o0;
+// the table's literals, copied to LDS once per workgroup (its pointers keep pointing into HBM)
+__device__ __forceinline__ void lat_stage_table(LatTable* dst, const LatTable* __restrict__ src) {
+  static_assert(sizeof(LatTable) % 4 == 0, "copied by words");
+  for (u32 i = threadIdx.x; i < sizeof(LatTable) / 4; i += blockDim.x) reinterpret_cast<u32*>(dst)[i] = reinterpret_cast<const u32*>(src)[i];
+  __syncthreads();
 }
 
-// sentence s -> its number of text bytes and of header bytes; leaves the per-node sets in the scratch for k_lat_write
+__device__ __forceinline__ u64 wave_or_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v |= wave_shfl_u64(v, lane_id() ^ off);
+  return v;
+}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) { return ~wave_max_u64(~v); }
+
+// sentence s -> the bytes of its text, of its header and of the lines of its i-th marked node (node_bytes[node_base + i]);
+// leaves the per-node sets, the ids and the list of marked nodes in the scratch for k_lat_write
 __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
-                                                   u32* sent_bytes, u32* head_bytes, i32* fmt_status) {
-  const LatTable& T = *Tp;
+                                                   u32* sent_bytes, u32* head_bytes, u32* node_bytes, i32* fmt_status) {
+  __shared__ LatTable s_T;
+  lat_stage_table(&s_T, Tp);
+  const LatTable& T = s_T;
   const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
   const u32 lane = threadIdx.x & 63;
   if (s >= B.n_sent) return;
@@ -326,6 +302,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
     if (lane == 0) {
       sent_bytes[s] = T.error_len;
       head_bytes[s] = 0;
+      S.marked[s] = 0;
       fmt_status[s] = B.sent_status[s];
     }
     return;
@@ -335,6 +312,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
     if (lane == 0) {
       sent_bytes[s] = T.eos_len;
       head_bytes[s] = 0;
+      S.marked[s] = 0;
       fmt_status[s] = ST_OK;
     }
     return;
@@ -349,73 +327,202 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
   }
   __threadfence();
   wave_sync();
-  // fillInfo: lane i walks path i back from the EOS beam (paths behind the first fake slot do not exist)
+  // fillInfo: lane i walks path i back from the EOS beam (paths behind the first fake slot do not exist).  The paths
+  // run in lock step, and the N best paths of a sentence mostly run through the SAME nodes: the lanes standing on one
+  // node are found with a ballot (which IS that node's share of the rank mask), their slot sets and smallest keys are
+  // reduced across the wavefront, and one lane sends the three atomics -- a dozen instead of a hundred per step.
   const BeamSlot* beams = B.node_beam + nb * (u64)beam;
   const int maxN = n_best < beam ? n_best : beam;
   BeamSlot el{kFake16, kFake16, 0.f, 0xffffffffu, 0};
   if ((int)lane < maxN) el = beams[(u64)(N - 1) * beam + lane];
   const u64 fakes = wave_ballot(el.left == kFake16 && el.beam == kFake16);
   const u32 npaths = fakes ? (u32)__builtin_ctzll(fakes) : 64u;
-  if (lane < npaths) {
+  {
     const bool two = T.n_weights == 2 && NS > 1;
+    const float w0 = T.weights[0], w1 = T.weights[1];
+    bool act = lane < npaths;
     u32 node = el.prev_node, slot = el.beam, steps = 0;
-    while (node >= 2 && node < N && slot < (u32)beam && steps++ <= N) {
-      const BeamSlot c = beams[(u64)node * beam + slot];
-      if (c.left == kFake16 && c.beam == kFake16) break;
-      const float* cell = B.node_cells + ((nb + node) * (u64)G + c.pad) * (u64)NS;
-      // `total += s[i] * weights[i]` is one fused multiply-add per scorer in the reference's build (host/lattice_format.cc)
-      float t = __builtin_fmaf(cell[0], T.weights[0], 0.f);
-      if (two) t = __builtin_fmaf(cell[1], T.weights[1], t);
-      atomicOr((unsigned long long*)&S.mask[nb + node], 1ull << lane);
-      atomicOr((unsigned long long*)&S.slots[nb + node], 1ull << slot);
-      atomicMin((unsigned long long*)&S.best[nb + node], ((unsigned long long)lat_order_f32(t) << 32) | (lane << 8) | slot);
-      node = c.prev_node;
-      slot = c.beam;
+    for (;;) {
+      act = act && node >= 2 && node < N && slot < (u32)beam && steps++ <= N;
+      BeamSlot c{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+      if (act) c = beams[(u64)node * beam + slot];
+      act = act && !(c.left == kFake16 && c.beam == kFake16);
+      u64 todo = wave_ballot(act);
+      if (todo == 0) break;
+      u64 key = ~0ull;
+      if (act) {
+        const float* cell = B.node_cells + ((nb + node) * (u64)G + c.pad) * (u64)NS;
+        // `total += s[i] * weights[i]` is one fused multiply-add per scorer in the reference's build (host/lattice_format.cc)
+        float t = __builtin_fmaf(cell[0], w0, 0.f);
+        if (two) t = __builtin_fmaf(cell[1], w1, t);
+        key = ((u64)lat_order_f32(t) << 32) | (lane << 8) | slot;
+      }
+      while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const u32 ln = wave_bcast_u32(node, leader);
+        const bool mine = act && node == ln;
+        const u64 grp = wave_ballot(mine);
+        const u64 used = wave_or_u64(mine ? (1ull << slot) : 0ull);
+        const u64 kmin = wave_min_u64(mine ? key : ~0ull);
+        if ((int)lane == leader) {
+          atomicOr((unsigned long long*)&S.mask[nb + ln], (unsigned long long)grp);
+          atomicOr((unsigned long long*)&S.slots[nb + ln], (unsigned long long)used);
+          atomicMin((unsigned long long*)&S.best[nb + ln], (unsigned long long)kmin);
+        }
+        todo &= ~grp;
+      }
+      if (act) {
+        node = c.prev_node;
+        slot = c.beam;
+      }
     }
   }
   __threadfence();
   wave_sync();
-  // publishResult: ids from 1 in node order
+  // publishResult: ids from 1 in node order, and the marked nodes listed in that order
   u32 next = 1;
   for (u32 base = 0; base < N; base += 64) {
     const u32 nd = base + lane;
-    const bool on = nd < N && S.mask[nb + nd] != 0;
+    const bool on = nd >= 2 && nd + 1 < N && S.mask[nb + nd] != 0;   // (0, 1 = BOS and N - 1 = EOS are never on a list)
     const u64 bal = wave_ballot(on);
-    if (on) S.id[nb + nd] = next + (u32)popc64(bal & ((1ull << lane) - 1ull));
+    if (on) {
+      const u32 id = next + (u32)popc64(bal & ((1ull << lane) - 1ull));
+      S.id[nb + nd] = id;
+      S.list[nb + id - 1] = nd;
+    }
     next += (u32)popc64(bal);
   }
+  const u32 M = next - 1;
   __threadfence();
   wave_sync();
-  u32 head = 0;
+  // the bytes of every marked node's lines, a lane per node
+  const u32 off = B.byte_off[s];
+  const u8* text = B.text + off;
+  const u16* boff = B.cp_boff + off + s;
+  u64 sum = 0;
   bool ok = true;
-  const u64 bytes = lat_sentence_text<false>(B, cfg, T, S, s, n_best, nullptr, 0, nullptr, lane, &head, &ok);
+  for (u32 base = 0; base < M; base += 64) {
+    const u32 i = base + lane;
+    if (i < M) {
+      LatOut<false> w{nullptr, 0};
+      ok = lat_node_lines(w, B, cfg, T, S, nb, S.list[nb + i], text, boff) && ok;
+      node_bytes[nb + i] = (u32)w.n;
+      sum += w.n;
+    }
+  }
+  sum = wave_sum_u64(sum);
+  const bool allOk = wave_ballot(!ok) == 0;
   if (lane == 0) {
-    fmt_status[s] = ok ? ST_OK : ST_CAPACITY;   // (a node the table cannot render: the text answers like a failed sentence)
-    sent_bytes[s] = ok ? (u32)bytes : T.error_len;
-    head_bytes[s] = ok ? head : 0;
+    LatOut<false> h{nullptr, 0};
+    lat_header(h, T, beams + (u64)(N - 1) * beam, beam, n_best);
+    fmt_status[s] = allOk ? ST_OK : ST_CAPACITY;   // (a node the table cannot render: the text answers like a failed sentence)
+    sent_bytes[s] = allOk ? (u32)(h.n + sum + T.eos_len) : T.error_len;
+    head_bytes[s] = allOk ? (u32)h.n : 0;
+    S.marked[s] = M;
   }
 }
 
+// The text leaves through an LDS window per wavefront: the lanes print their nodes' lines into it side by side (byte
+// stores into LDS cost nothing; byte stores into HBM are one 64-byte transaction EACH -- 1.5 G of them per batch made
+// the first lane-per-node form no faster than the serial one), and the window goes out as whole dwords, 256 contiguous
+// bytes per instruction.  The window starts at the output offset's own alignment so that the dwords of both sides match.
+#if !defined(JPP_LAT_WIN)
+#define JPP_LAT_WIN 12288   // (a test build of the emulator makes it tiny: every window path with ordinary sentences)
+#endif
+constexpr u32 kLatWin = JPP_LAT_WIN;
+
+__device__ __forceinline__ void lat_flush(u8* out, u64 o, const u8 JPP_LDS* buf, u32 b0, u32 bytes, u32 lane) {
+  wave_sync();
+  u32 a = (4u - b0) & 3u;
+  if (a > bytes) a = bytes;
+  if (lane < a) out[o + lane] = buf[b0 + lane];
+  const u32 mid = (bytes - a) >> 2;
+  const u32 JPP_LDS* src = (const u32 JPP_LDS*)(buf + b0 + a);
+  u32* dst = reinterpret_cast<u32*>(out + o + a);
+  for (u32 i = lane; i < mid; i += 64) dst[i] = src[i];
+  const u32 tail = bytes - a - 4u * mid;
+  if (lane < tail) out[o + a + 4u * mid + lane] = buf[b0 + a + 4u * mid + lane];
+  wave_sync();
+}
+
 __global__ void __launch_bounds__(256) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
-                                                   const u64* sent_off, u8* out, const i32* fmt_status) {
-  __shared__ u8 s_tmp[4][kLatTmp];
-  const LatTable& T = *Tp;
+                                                   const u64* sent_off, const u32* head_bytes, const u32* node_bytes, u8* out,
+                                                   const i32* fmt_status) {
+  __shared__ LatTable s_T;
+  __shared__ __attribute__((aligned(16))) u8 s_win[4][kLatWin + 16];
+  lat_stage_table(&s_T, Tp);
+  const LatTable& T = s_T;
   const u32 wv = threadIdx.x >> 6;
   const u32 s = blockIdx.x * 4 + wv;
   const u32 lane = threadIdx.x & 63;
   if (s >= B.n_sent) return;
-  const u64 o = sent_off[s];
+  u64 o = sent_off[s];
   if (fmt_status[s] != ST_OK) {
     fmt_put(out, o, T.error_text, T.error_len, lane);
     return;
   }
-  if (B.sent_nodes[s] <= 3) {
+  const u32 N = B.sent_nodes[s];
+  if (N <= 3) {
     fmt_put(out, o, T.eos_text, T.eos_len, lane);
     return;
   }
-  u32 head = 0;
-  bool ok = true;
-  (void)lat_sentence_text<true>(B, cfg, T, S, s, n_best, out, o, s_tmp[wv], lane, &head, &ok);
+  typedef u8 JPP_LDS* LP;
+  const LP win = (LP)s_win[wv];
+  const u64 nb = B.node_base[s];
+  const u32 off = B.byte_off[s];
+  const u8* text = B.text + off;
+  const u16* boff = B.cp_boff + off + s;
+  // the "# MA-SCORE" line (at most 64 ranks of some 22 bytes)
+  {
+    const u32 hb = head_bytes[s];
+    const u32 b0 = (u32)o & 3u;
+    if (hb <= kLatWin) {
+      if (lane == 0) {
+        LatOut<true, LP> h{win + b0, 0};
+        lat_header(h, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best);
+      }
+      lat_flush(out, o, win, b0, hb, lane);
+    } else if (lane == 0) {
+      LatOut<true> h{out + o, 0};
+      lat_header(h, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best);
+    }
+    o += hb;
+  }
+  // a lane per marked node; the nodes of a round whose lines fit the window together are printed into it and flushed
+  const u32 M = S.marked[s];
+  for (u32 base = 0; base < M; base += 64) {
+    const u32 i = base + lane;
+    const u32 bytes = i < M ? node_bytes[nb + i] : 0;
+    const u32 node = i < M ? S.list[nb + i] : 0;
+    const u32 incl = wave_scan_incl_u32(bytes, (int)lane);
+    const u32 start = incl - bytes;
+    const u32 total = wave_bcast_u32(incl, 63);
+    u32 f = 0;   // lanes before f are done
+    while (f < 64 && base + f < M) {
+      const u32 fstart = wave_bcast_u32(start, (int)f);
+      const u32 b0 = (u32)(o + fstart) & 3u;
+      const u64 fits = wave_ballot(lane >= f && i < M && incl - fstart <= kLatWin - 4u);
+      if (((fits >> f) & 1) == 0) {
+        // a single node beyond the window: straight to the output, byte by byte (never seen; a kilobyte feature list)
+        if (lane == f) {
+          LatOut<true> w{out + o + start, 0};
+          (void)lat_node_lines(w, B, cfg, T, S, nb, node, text, boff);
+        }
+        f += 1;
+        continue;
+      }
+      const u32 cnt = (u32)popc64(fits);   // (the fitting lanes are f .. f + cnt - 1: incl is monotonic)
+      const u32 wend = wave_bcast_u32(incl, (int)(f + cnt - 1));
+      if ((fits >> lane) & 1) {
+        LatOut<true, LP> w{win + b0 + (start - fstart), 0};
+        (void)lat_node_lines(w, B, cfg, T, S, nb, node, text, boff);
+      }
+      lat_flush(out, o + fstart, win, b0, wend - fstart, lane);
+      f += cnt;
+    }
+    o += total;
+  }
+  fmt_put(out, o, T.eos_text, T.eos_len, lane);
 }
 
 }  // namespace jpp

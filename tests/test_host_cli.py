@@ -164,6 +164,29 @@ def test_device_side_lattice_format(cli_emu, golden_dir, tmp_path):
     _device_lattice_case(cli_emu, golden_dir, tmp_path)
 
 
+@pytest.mark.parametrize('win', ['96', '400'])
+def test_device_side_lattice_format_window_paths(cli_emu, golden_dir, tmp_path, win):
+    """k_lat_write prints a round of 64 nodes into an LDS window of 12 KB and flushes it; nodes that do not fit together
+    take several windows, a node beyond the window goes straight to the output.  An emulator build with a window of 96 /
+    400 bytes walks those paths (and every alignment of the flush) on ordinary sentences: same bytes as the host class"""
+    import shutil
+    import __graft_entry__ as ge
+    lib = ge.build_emu_variant('latwin' + win, ['-DJPP_LAT_WIN=' + win])
+    d = tmp_path / 'lib'
+    d.mkdir()
+    shutil.copy(lib, str(d / 'libjppgpu_emu.so'))   # (found before the binary's RUNPATH)
+    env = dict(os.environ, LD_LIBRARY_PATH=str(d), JPPGPU_NO_IMAGE_CACHE='1')
+    fix = os.path.join(golden_dir, 'ref')
+    for model, txt in ((os.path.join(golden_dir, 'mini_rnn.jppmdl'), os.path.join(golden_dir, 'mini.txt')),
+                       (os.path.join(fix, 'minimal.jppmdl'), os.path.join(fix, 'minimal.txt')),
+                       (os.path.join(fix, 'bug950111.jppmdl'), os.path.join(fix, 'bug950111.txt'))):
+        for flags in (['-s', '5'], ['--beam=12', '--global-beam=12', '--right-beam=12', '-s', '12']):
+            rc, host, eh = _run(cli_emu, ['--model=' + model, '--host-format'] + flags + [txt])
+            p = subprocess.run([cli_emu, '--model=' + model, '--timing'] + flags + [txt], capture_output=True, env=env)
+            assert p.returncode == 0 and b'device_lattice_format=1' in p.stderr, p.stderr[-300:]
+            assert p.stdout == host, (model, flags)
+
+
 @pytest.mark.gpu
 def test_gpu_device_side_lattice_format(cli_gpu, golden_dir, tmp_path):
     _device_lattice_case(cli_gpu, golden_dir, tmp_path)

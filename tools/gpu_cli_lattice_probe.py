@@ -41,9 +41,12 @@ if trace:
     d = os.path.join(ROOT, 'gpurun_out', 'prof_lat')
     subprocess.run(['rm', '-rf', d])
     batch = int((argv or ['4096'])[-1])
-    subprocess.run(['rocprofv3', '--kernel-trace', '--stats', '-d', d, '-o', 'lat', '--', cli, '--model=' + model, '--batch=%d' % batch,
-                    '-o', out] + flags + [corpus], capture_output=True, text=True, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
-    for db in glob.glob(os.path.join(d, '**', '*.db'), recursive=True):
+    pr = subprocess.run(['rocprofv3', '--kernel-trace', '--stats', '-d', d, '-o', 'lat', '--', cli, '--model=' + model, '--batch=%d' % batch,
+                    '--clean-exit', '-o', out] + flags + [corpus], capture_output=True, text=True, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
+    found = glob.glob(os.path.join(d, '**', '*.db'), recursive=True)
+    if not found:
+        print('no trace database; rocprofv3 said:', (pr.stdout or '')[-600:], (pr.stderr or '')[-1200:])
+    for db in found:
         con = sqlite3.connect(db)
         try:   # (the view summarize_prof.py reads)
             rows = [(n, c, t, a) for n, c, t, a, _ in
