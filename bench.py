@@ -1193,7 +1193,13 @@ def main():
         return r
 
     for i in range(args.warmup):
-        step(i).release()
+        r = step(i)
+        if dist is not None:
+            # the gather's first call sets up the point-to-point connections between the ranks (RCCL does that lazily,
+            # hundreds of milliseconds): part of the warm-up, like the kernels' first launches
+            r.pack(d_offs.data_ptr(), d_items.data_ptr(), cap_items)
+            gather_packed_fixed(d_offs, d_items, dst=0)
+        r.release()
     _sync()
     if dist is not None:
         dist.barrier()
