@@ -900,6 +900,18 @@ ModelBufs::~ModelBufs() {
 extern "C" const char* jppgpu_last_error(void) { return g_err.c_str(); }
 
 namespace {
+// Beams beyond kMaxBeam.  With the global beam on, a node's beam is filled from the boundary's global beam -- at most
+// global_beam candidates, the other slots are fake (makeT0Beam, score_processor.cc:426-468; the EOS beam likewise,
+// remakeEosBeam :553-577) -- and nothing else reads the beam size but the partition threshold beam * 4 / 3 of that
+// function, which global_beam <= 32 stays below for every beam >= 32.  A beam of 40 or 500 (`-s N` widens the beam to N,
+// jumanpp_args.cc:261-264) therefore gives the lattice of beam 32 with more fake slots behind it: the device keeps 32.
+// Without the global beam the beam size is the real width of makeBeams (score_processor.cc:210-245): not beyond 32.
+bool beams_fit(int beam, int global_beam) {
+  if (global_beam > kMaxGbeam) return false;
+  return beam <= kMaxBeam || global_beam >= 1;
+}
+int device_beam(int beam, int global_beam) { return beam > kMaxBeam && global_beam >= 1 ? kMaxBeam : beam; }
+
 // the caller's struct may be older (shorter) or newer (longer) than ours: read what both sides know; then the
 // configuration checks of AnalyzerImpl::initScorers (analyzer_impl.cc:43-89)
 int read_config(const jppgpu_config* c_in, jppgpu_config* outc) {
@@ -932,16 +944,16 @@ int read_config(const jppgpu_config* c_in, jppgpu_config* outc) {
   if (c->global_beam > 0 && c->right_check > 0 && c->right_beam <= 0)
     return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
   if (c->right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
-  if (c->beam > kMaxBeam || c->global_beam > kMaxGbeam)
+  if (!beams_fit(c->beam, c->global_beam))
     return fail(JPPGPU_NOT_IMPLEMENTED,
-                "jppgpu: beam / global beam > 32 is not supported");
+                "jppgpu: a global beam > 32, or a beam > 32 without a global beam, is not supported");
   return JPPGPU_OK;
 }
 
 // Config, scorer weights of a new context
 void apply_config(jppgpu_ctx* ctx, const jppgpu_config* c) {
   ctx->device = c->device;
-  ctx->cfg = Config{c->beam, c->global_beam > 0 ? c->global_beam : 0, c->right_check, c->right_beam,
+  ctx->cfg = Config{device_beam(c->beam, c->global_beam), c->global_beam > 0 ? c->global_beam : 0, c->right_check, c->right_beam,
                     c->max_input_bytes > 0 ? c->max_input_bytes : 4096, 1 + (c->use_rnn ? 1 : 0) + c->num_host_scorers,
                     (c->use_rnn || c->num_host_scorers > 0) ? c->weight_perceptron : 1.0f, c->use_rnn ? c->weight_rnn : 0.0f};
   ctx->use_rnn = c->use_rnn != 0;
@@ -1283,9 +1295,9 @@ extern "C" int jppgpu_ctx_set_beams(jppgpu_ctx* ctx, int32_t beam, int32_t globa
   if (global_beam > 0 && right_check > 0 && right_beam <= 0)
     return fail(JPPGPU_INVALID_PARAMETER, "right global beam size should not be zero if you enable it");
   if (right_check < 0) return fail(JPPGPU_INVALID_PARAMETER, "right_check < 0");
-  if (beam > kMaxBeam || global_beam > kMaxGbeam)
-    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: beam / global beam > 32 is not supported");
-  ctx->cfg.beam = beam;
+  if (!beams_fit(beam, global_beam))
+    return fail(JPPGPU_NOT_IMPLEMENTED, "jppgpu: a global beam > 32, or a beam > 32 without a global beam, is not supported");
+  ctx->cfg.beam = device_beam(beam, global_beam);
   ctx->cfg.gbeam = global_beam > 0 ? global_beam : 0;
   ctx->cfg.rcheck = right_check;
   ctx->cfg.rbeam = right_beam;

@@ -344,6 +344,17 @@ def test_config_validation_mirrors_reference(emu_lib, golden_dir):
         J.Context(img, lib_path=emu_lib, beam=40, global_beam=40)
     with pytest.raises(J.JppGpuError, match='only with global beam'):
         J.Context(os.path.join(golden_dir, 'mini_rnn.img'), lib_path=emu_lib, global_beam=0)
+    with pytest.raises(J.JppGpuError, match='not supported'):
+        J.Context(img, lib_path=emu_lib, beam=40, global_beam=0)
+    # a beam beyond 32 WITH a global beam is the lattice of beam 32 (a node's beam holds at most global-beam entries)
+    lines = [l for l in open(os.path.join(golden_dir, 'mini.txt'), encoding='utf-8').read().split('\n') if l][:12]
+    got = []
+    for beam in (32, 40, 500):
+        ctx = J.Context(img, lib_path=emu_lib, beam=beam, global_beam=6, right_check=1, right_beam=5)
+        r = ctx.analyze(lines).fetch(full=True)
+        assert r.beam == 32
+        got.append((r.path_nodes.tolist(), r.beams.tobytes(), r.cells.tobytes()))
+    assert got[0] == got[1] == got[2]
 
 
 def check_top1_fetch_equals_basic_fetch(ctx, lines):

@@ -126,7 +126,7 @@ def _device_lattice_case(cli, golden_dir, tmp_path):
     for m in ('minimal', 'minimal_trained', 'codegen', 'bug28', 'bug950111'):
         cases.append((os.path.join(fix, m + '.jppmdl'), os.path.join(fix, m + '.txt')))
     for model, txt in cases:
-        for flags in (['-s', '1'], ['-s', '5'], ['--beam=12', '--global-beam=12', '--right-beam=12', '-s', '12'], ['-s', '30']):
+        for flags in (['-s', '1'], ['-s', '5'], ['--beam=12', '--global-beam=12', '--right-beam=12', '-s', '12'], ['-s', '40']):
             rc, host, eh = _run(cli, ['--model=' + model, '--host-format'] + flags + [txt])
             assert rc == 0 and host, eh[-300:]
             rc, dev, err = _run(cli, ['--model=' + model, '--timing'] + flags + [txt])
@@ -285,9 +285,14 @@ def test_gpu_analyzer_initialize_validates_like_the_reference(cli_emu, golden_di
     assert rc == 1 and b'Model file was not specified' in err
     rc, out, err = _run(cli_emu, ['--model=/nonexistent.img'])
     assert rc == 1 and b'failed to load model from disk' in err
-    # global beam larger than the beam allows (AnalyzerImpl::initScorers) is rejected at initialize
-    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.img'), '--beam=40'], stdin=b'')
+    # what the device layout does not hold is rejected at initialize: a global beam beyond 32, a beam beyond 32 without
+    # a global beam (with one, a wider beam is the lattice of beam 32 plus fake slots and is accepted)
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.img'), '--beam=40', '--global-beam=40'], stdin=b'')
     assert rc == 1 and b'failed to initialize the analyzer' in err
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.img'), '--beam=40', '--global-beam=0'], stdin=b'')
+    assert rc == 1 and b'failed to initialize the analyzer' in err
+    rc, out, err = _run(cli_emu, ['--model=' + os.path.join(golden_dir, 'mini.img'), '--beam=40'], stdin=b'')
+    assert rc == 0
 
 
 @pytest.mark.gpu
@@ -525,11 +530,18 @@ def test_lattice_format_byte_identical_to_reference_cli(cli_emu, ref_tools, tmp_
     img, lines, _ = tg._fresh_workload(ref_tools, tmp, 2500, 16, 14, 23, length=36)
     with open(os.path.join(tmp, 'w.txt'), 'ab') as f:
         f.write('\n# a comment replaces the MA-SCORE line\nすごーーい〜かぁっこいいねぇっッ！\nx\ty\n'.encode('utf-8'))
-    for n in ('1', '5'):
+    # (-s 40 widens the beam to 40, jumanpp_args.cc:261-264: with a global beam the device keeps 32 slots per node, the
+    # rest would be fake anyway -- csrc/jppgpu_api.cc: device_beam)
+    for n in ('1', '5', '40'):
         ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), ['-s', n], os.path.join(tmp, 'w.txt'))
-        rc, out, err = _run(cli_emu, ['--model=' + img, '-s', n, os.path.join(tmp, 'w.txt')])
-        assert rc == 0, err[-300:]
-        assert out == ref, n
+        for fmt in ([], ['--host-format']):
+            rc, out, err = _run(cli_emu, ['--model=' + img, '-s', n] + fmt + [os.path.join(tmp, 'w.txt')])
+            assert rc == 0, err[-300:]
+            assert out == ref, (n, fmt)
+    flags = ['--beam=50', '--global-beam=20', '--right-beam=9', '-s', '50']
+    ref = _ref_cli(ref_tools, os.path.join(tmp, 'w.model'), flags, os.path.join(tmp, 'w.txt'))
+    rc, out, err = _run(cli_emu, ['--model=' + img] + flags + [os.path.join(tmp, 'w.txt')])
+    assert rc == 0 and out == ref, err[-300:]
 
 
 def test_morph_and_segmented_formats_byte_identical(cli_emu, ref_tools, tmp_path):
