@@ -140,8 +140,9 @@ typedef struct {
                              * shipped (smaller than JPPGPU_CONFIG_MIN_SIZE, larger than its own with non-zero unknown
                              * tail, not a multiple of 4) is JPPGPU_INVALID_PARAMETER.  ABI break of round 4: up to
                              * round 3 the struct started with `beam` and had no size field. */
-  int32_t beam;             /* 5 */
-  int32_t global_beam;      /* 6 */
+  int32_t beam;             /* 5.  Beyond 32 only with a global beam: the result's beams then have 32 slots per node (what
+                             * lies behind the global_beam-th slot of a node is fake in the reference as well) */
+  int32_t global_beam;      /* 6; <= 32.  0: full-beam scoring (beam <= 32) */
   int32_t right_check;      /* 1 */
   int32_t right_beam;       /* 5 */
   int32_t max_input_bytes;  /* 4096 */
@@ -216,7 +217,7 @@ typedef struct {
   const uint64_t* bnd_base;      /* [n] */
   uint64_t total_nodes;
   uint64_t total_boundaries;
-  int32_t beam, global_beam;
+  int32_t beam, global_beam;         /* beam = slots per node in `beams` (min(configured beam, 32) with a global beam) */
   int32_t num_scorers;
   int32_t entry_row_stride;          /* columns per row of entry_rows: 8, or 16 for models with more than 8 feature columns
                                       * (0 from the compact JPPGPU_FETCH_TOP1 view, which has no rows) */
