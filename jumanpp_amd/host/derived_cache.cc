@@ -38,8 +38,16 @@ struct Header {
   uint32_t reserved;
   uint64_t contentHash;             // of everything behind the header (hashPayload); the header's own fields are checked one by one
   jppgpu_format_table literals;     // the table with its three pointers null
+  // the lattice format's table (round 6), same shape
+  uint32_t hasLattice;
+  uint32_t latticeStructSize;
+  uint64_t latticeEntries;
+  uint64_t latSlotsOffset, nLatSlots;
+  uint64_t latRowsOffset, nLatRows;
+  uint64_t latBlobOffset, latBlobBytes;
+  jppgpu_lattice_table latLiterals;
 };
-constexpr uint32_t kVersion = 2;
+constexpr uint32_t kVersion = 3;
 
 // offset + len within total, without wrapping
 bool within(uint64_t off, uint64_t len, uint64_t total) { return off <= total && len <= total - off; }
@@ -175,7 +183,12 @@ bool DerivedCache::load(const std::string& modelPath) {
               h->totalBytes == total && total >= body && within(h->memoOffset, h->memoBytes, total) && (h->memoBytes == 0 || h->memoOffset >= body) &&
               (!h->hasTable || (h->tableBuilder == kFormatTableBuilderVersion && h->slotsOffset >= body && h->rowsOffset >= body && h->blobOffset >= body &&
                                 withinN(h->slotsOffset, h->nSlots, 4, total) && withinN(h->rowsOffset, h->nRows, sizeof(jppgpu_format_row), total) &&
-                                within(h->blobOffset, h->blobBytes, total)));
+                                within(h->blobOffset, h->blobBytes, total))) &&
+              (!h->hasLattice || (h->tableBuilder == kFormatTableBuilderVersion && h->latticeStructSize == sizeof(jppgpu_lattice_table) &&
+                                  h->latSlotsOffset >= body && h->latRowsOffset >= body && h->latBlobOffset >= body &&
+                                  withinN(h->latSlotsOffset, h->nLatSlots, 4, total) &&
+                                  withinN(h->latRowsOffset, h->nLatRows, sizeof(jppgpu_lattice_row), total) &&
+                                  within(h->latBlobOffset, h->latBlobBytes, total)));
     ok = ok && hashPayload(static_cast<const unsigned char*>(m) + body, total - body) == h->contentHash;
     if (!ok) {
       ::munmap(m, (size_t)cs.st_size);
@@ -200,16 +213,28 @@ bool DerivedCache::load(const std::string& modelPath) {
       tableEntries_ = h->tableEntries;
       hasTable_ = true;
     }
+    if (h->hasLattice) {
+      lattice_ = h->latLiterals;
+      lattice_.slot_first_row = reinterpret_cast<const uint32_t*>(base + h->latSlotsOffset);
+      lattice_.n_slots = h->nLatSlots;
+      lattice_.rows = reinterpret_cast<const jppgpu_lattice_row*>(base + h->latRowsOffset);
+      lattice_.n_rows = h->nLatRows;
+      lattice_.blob = base + h->latBlobOffset;
+      lattice_.blob_bytes = h->latBlobBytes;
+      latticeEntries_ = h->latticeEntries;
+      hasLattice_ = true;
+    }
     return true;
   }
   return false;
 }
 
 bool DerivedCache::store(const std::string& modelPath, const void* memo, uint64_t memoBytes, uint32_t memoSlots,
-                         const jppgpu_format_table* table, uint64_t tableEntries) {
+                         const jppgpu_format_table* table, uint64_t tableEntries, const jppgpu_lattice_table* lattice,
+                         uint64_t latticeEntries) {
   struct stat st;
   if (!statModel(modelPath, &st)) return false;
-  if (memo == nullptr && table == nullptr) return false;
+  if (memo == nullptr && table == nullptr && lattice == nullptr) return false;
   for (const Candidate& cand : candidates(modelPath, st)) {
     const std::string& path = cand.path;
     if (!cand.privateDir.empty() && !ownPrivateDir(cand.privateDir, true)) continue;
@@ -246,7 +271,25 @@ bool DerivedCache::store(const std::string& modelPath, const void* memo, uint64_
       pos = (pos + h.nRows * sizeof(jppgpu_format_row) + 63) / 64 * 64;
       h.blobOffset = pos;
       h.blobBytes = table->blob_bytes;
-      pos += h.blobBytes;
+      pos = (pos + h.blobBytes + 63) / 64 * 64;
+    }
+    if (lattice) {
+      h.hasLattice = 1;
+      h.latticeStructSize = (uint32_t)sizeof(jppgpu_lattice_table);
+      h.latticeEntries = latticeEntries;
+      h.latLiterals = *lattice;
+      h.latLiterals.slot_first_row = nullptr;
+      h.latLiterals.rows = nullptr;
+      h.latLiterals.blob = nullptr;
+      h.latSlotsOffset = pos;
+      h.nLatSlots = lattice->n_slots;
+      pos = (pos + h.nLatSlots * 4 + 63) / 64 * 64;
+      h.latRowsOffset = pos;
+      h.nLatRows = lattice->n_rows;
+      pos = (pos + h.nLatRows * sizeof(jppgpu_lattice_row) + 63) / 64 * 64;
+      h.latBlobOffset = pos;
+      h.latBlobBytes = lattice->blob_bytes;
+      pos = (pos + h.latBlobBytes + 63) / 64 * 64;
     }
     h.totalBytes = pos;
     h.tableBuilder = kFormatTableBuilderVersion;
@@ -270,6 +313,18 @@ bool DerivedCache::store(const std::string& modelPath, const void* memo, uint64_
       ok = ok && padTo(fd, &at, 64);
       ok = ok && writeAll(fd, table->blob, (size_t)h.blobBytes);
       at += h.blobBytes;
+      ok = ok && padTo(fd, &at, 64);
+    }
+    if (ok && lattice) {
+      ok = writeAll(fd, lattice->slot_first_row, (size_t)h.nLatSlots * 4);
+      at += h.nLatSlots * 4;
+      ok = ok && padTo(fd, &at, 64);
+      ok = ok && writeAll(fd, lattice->rows, (size_t)h.nLatRows * sizeof(jppgpu_lattice_row));
+      at += h.nLatRows * sizeof(jppgpu_lattice_row);
+      ok = ok && padTo(fd, &at, 64);
+      ok = ok && writeAll(fd, lattice->blob, (size_t)h.latBlobBytes);
+      at += h.latBlobBytes;
+      ok = ok && padTo(fd, &at, 64);
     }
     ok = ok && at == h.totalBytes;
     ::close(fd);

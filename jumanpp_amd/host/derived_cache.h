@@ -1,5 +1,5 @@
 // What a process derives from a model file before its first batch -- the per-entry T0 records (k_t0_memo) and the
-// rendered-row table of the device formatter -- kept in a file beside the model, so that the next process maps it
+// rendered-row tables of the device formatters (JUMAN top-1, lattice) -- kept in a file beside the model, so that the next process maps it
 // instead of walking the trie and printing every dictionary entry again ("device-image cache").
 // The reference has no such thing: it re-reads and re-derives on every start (src/core/impl/model_io.cc:115-176).
 //
@@ -26,6 +26,9 @@ class DerivedCache {
   bool hasTable_ = false;
   jppgpu_format_table table_{};
   uint64_t tableEntries_ = 0;
+  bool hasLattice_ = false;
+  jppgpu_lattice_table lattice_{};
+  uint64_t latticeEntries_ = 0;
 
  public:
   DerivedCache() = default;
@@ -41,10 +44,15 @@ class DerivedCache {
   bool hasFormatTable() const { return hasTable_; }
   const jppgpu_format_table& formatTable() const { return table_; }   // (pointers into the mapping)
   uint64_t formatTableEntries() const { return tableEntries_; }
+  // the rendered rows of the lattice format (its score weights are the writer's: the adopter sets its own)
+  bool hasLatticeTable() const { return hasLattice_; }
+  const jppgpu_lattice_table& latticeTable() const { return lattice_; }
+  uint64_t latticeTableEntries() const { return latticeEntries_; }
 
-  // writes the cache of `modelPath`; either part may be absent (memo == nullptr / table == nullptr)
+  // writes the cache of `modelPath`; every part may be absent (null)
   static bool store(const std::string& modelPath, const void* memo, uint64_t memoBytes, uint32_t memoSlots,
-                    const jppgpu_format_table* table, uint64_t tableEntries);
+                    const jppgpu_format_table* table, uint64_t tableEntries,
+                    const jppgpu_lattice_table* lattice = nullptr, uint64_t latticeEntries = 0);
 };
 
 }  // namespace jumanpp_amd

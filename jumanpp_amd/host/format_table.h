@@ -57,6 +57,17 @@ class LatticeFormatTable {
  public:
   // scoreWeights: ScorerDef::scoreWeights (the format multiplies the score cells by them, lattice_format.cc:127,218-227)
   Status build(const ModelImage* model, const std::vector<float>& scoreWeights, unsigned threads);
+  // the table as an earlier process built it for this model (host/derived_cache.h), with THIS run's score weights
+  Status adopt(const jppgpu_lattice_table& cached, size_t entries, const std::vector<float>& scoreWeights) {
+    if (scoreWeights.empty() || scoreWeights.size() > 2) return Status::NotImplemented("lattice table: one or two score weights");
+    view_ = cached;
+    view_.n_weights = (uint32_t)scoreWeights.size();
+    view_.weights[0] = scoreWeights[0];
+    view_.weights[1] = scoreWeights.size() > 1 ? scoreWeights[1] : 0.f;
+    entries_ = entries;
+    buildMs_ = 0;
+    return Status::Ok();
+  }
   const jppgpu_lattice_table& view() const { return view_; }
   size_t numEntries() const { return entries_; }
   size_t numRows() const { return (size_t)view_.n_rows; }

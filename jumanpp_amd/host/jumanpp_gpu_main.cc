@@ -695,7 +695,15 @@ int main(int argc, const char** argv) {
   LatticeFormatTable latticeTable;
   bool deviceLattice = !conf.hostFormat && latticeFormat && acfg.autoBeamStep <= 0 && latticeN >= 1 && latticeN <= 64 &&
                        acfg.globalBeamSize > 0 && !conf.partialInput && std::getenv("JUMANPP_GPU_HOST_FORMAT") == nullptr;
-  if (deviceLattice) {
+  bool latticeFromCache = false;
+  if (deviceLattice && cacheHit && derived.hasLatticeTable() &&
+      latticeTable.adopt(derived.latticeTable(), (size_t)derived.latticeTableEntries(), def.scoreWeights)) {
+    latticeFromCache = true;
+    if (conf.timing)
+      std::cerr << "device_lattice_format=1 table_entries=" << latticeTable.numEntries() << " rows=" << latticeTable.numRows()
+                << " blob_bytes=" << latticeTable.blobBytes() << " build_ms=0 (image cache)\n";
+  }
+  if (deviceLattice && !latticeFromCache) {
     Status built = latticeTable.build(&model, def.scoreWeights, (unsigned)std::max(1, conf.threads));
     if (!built) deviceLattice = false;
     if (conf.timing)
@@ -845,11 +853,21 @@ int main(int argc, const char** argv) {
       tbl = &derived.formatTable();
       entries = derived.formatTableEntries();
     }
-    if (newPart && (memo != nullptr || tbl != nullptr)) {
+    const jppgpu_lattice_table* lat = nullptr;
+    uint64_t latEntries = 0;
+    if (deviceLattice) {
+      lat = &latticeTable.view();
+      latEntries = latticeTable.numEntries();
+      newPart = newPart || !latticeFromCache;
+    } else if (cacheHit && derived.hasLatticeTable()) {
+      lat = &derived.latticeTable();
+      latEntries = derived.latticeTableEntries();
+    }
+    if (newPart && (memo != nullptr || tbl != nullptr || lat != nullptr)) {
       const std::string modelPath = conf.model;
       const bool timing = conf.timing;
       cacheWriter.t = std::thread([=]() {
-        const bool ok = DerivedCache::store(modelPath, memo, memoBytes, memoSlots, tbl, entries);
+        const bool ok = DerivedCache::store(modelPath, memo, memoBytes, memoSlots, tbl, entries, lat, latEntries);
         if (timing) std::cerr << (std::string("image cache ") + (ok ? "written" : "not written") + " for " + modelPath + "\n");   // (one write: other threads print too)
       });
     }

@@ -1042,6 +1042,14 @@ def _image_cache_case(cli, golden_dir, tmp_path):
     assert rc == 0 and b'image_cache=hit' in err and b'(image cache)' not in err and b'image cache written' in err and out == ref, err[-400:]
     rc, out, err = _run(cli, ['--model=' + model, '--timing', txt], image_cache=True)
     assert rc == 0 and b'image_cache=hit' in err and b'(image cache)' in err and b'image cache written' not in err and out == ref, err[-400:]
+    # ... and the lattice format's table is the third part: that first -s 2 run stored it, this one adopts it and prints
+    # the host formatter's bytes (with its own score weights: they are not part of the cached table)
+    rc, lat_host, err = _run(cli, ['--model=' + model, '--host-format', '-s', '2', txt])
+    rc, lat_dev, err = _run(cli, ['--model=' + model, '--timing', '-s', '2', txt], image_cache=True)
+    assert rc == 0 and b'device_lattice_format=1' in err and b'build_ms=0 (image cache)' in err and lat_dev == lat_host, err[-400:]
+    rc, lat_host, err = _run(cli, ['--model=' + model, '--host-format', '--feature-weight-perceptron=0.5', '--feature-weight-rnn=2', '-s', '2', txt])
+    rc, lat_dev, err = _run(cli, ['--model=' + model, '--timing', '--feature-weight-perceptron=0.5', '--feature-weight-rnn=2', '-s', '2', txt], image_cache=True)
+    assert rc == 0 and b'build_ms=0 (image cache)' in err and lat_dev == lat_host, err[-400:]
 
 
 def _lattice_from_fifo_case(cli, golden_dir, tmp_path):
