@@ -591,7 +591,7 @@ typedef struct {
   char escape_from[4];
   uint8_t escape_len[4];
   char escape_to[4][8];
-  int32_t flag_placeholder;     /* formatNormalizedFeature, as in jppgpu_format_table (followed by '|' here) */
+  int32_t flag_placeholder;     /* formatNormalizedFeature as in the JUMAN table above; followed by a bar here */
   uint8_t flag_label_len;
   char flag_label[32];
   uint8_t n_flags;

@@ -72,6 +72,7 @@ struct Conf {
   std::string output;
   std::vector<std::string> inputs;
   bool timing = false;
+  int outputShards = 1;        // --output-shards=K: the input in K contiguous parts, part k's output in OUT.partNNNN (file to file only)
   bool cleanExit = false;      // --clean-exit: run every destructor at the end of a file-to-file run instead of leaving at once
   bool noImageCache = false;   // --no-image-cache: derive the T0 records and the format table afresh, write no cache
   bool noReserve = false;   // --no-reserve: the analyzers size their buffers batch by batch (round-4 behaviour)
@@ -133,7 +134,8 @@ struct Formatted {
 
 // SHARDED pipeline: one batch = a run of whole examples of a mapped input file
 struct ShardJob {
-  size_t seq = 0;              // position in input order
+  size_t seq = 0;              // position in input order (within its output shard)
+  int shard = 0;               // --output-shards: which part of the input, = which output file
   const char* data = nullptr;  // the batch's lines, each with its newline (the last one of a file maybe without)
   size_t bytes = 0;
   std::vector<StringPiece> inputs, comments;   // per example, pointing into the mapping
@@ -415,6 +417,7 @@ bool parseArgList(const std::vector<std::string>& args, Conf& conf) {
     else if (std::strcmp(argv[i], "--no-reserve") == 0) conf.noReserve = true;
     else if (std::strcmp(argv[i], "--no-image-cache") == 0) conf.noImageCache = true;
     else if (std::strcmp(argv[i], "--clean-exit") == 0) conf.cleanExit = true;
+    else if (argValue(argc, argv, i, "--output-shards", &v)) conf.outputShards = std::max(1, std::min(4096, std::atoi(v.c_str())));
     else if (argValue(argc, argv, i, "--log-level", &v)) { /* the reference's logging switch: accepted, nothing to log here */ }
     else if (std::strcmp(argv[i], "--help") == 0 || std::strcmp(argv[i], "-h") == 0) conf.help = true;
     else if (argv[i][0] == '-' && argv[i][1] != 0) {
@@ -480,8 +483,10 @@ int main(int argc, const char** argv) {
                  "Analysis:  --beam=5 --global-beam=6 --right-check=1 --right-beam=5 --auto-nbest=BASE:STEP:MAX --no-rnn\n"
                  "RNN:       --rnn-nce-bias=X --rnn-unk-constant=X --rnn-unk-length=X\n"
                  "           --feature-weight-perceptron=X --feature-weight-rnn=X   (0 switches the RNN off)\n"
-                 "Batching:  --batch=65536 sentences per GPU launch (lattice output: fewer by default, so that the gathered N best paths of a batch stay below 1 GB), --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache, --clean-exit,\n"
-                 "           --host-format (JUMAN text from the host formatters; by default the device prints the top-1 JUMAN format),\n"
+                 "Batching:  --batch=65536 sentences per GPU launch (lattice output: fewer by default, so that a batch's text stays below ~256 MB), --threads=N format workers, --no-pipeline, --timing, --no-reserve, --no-image-cache, --clean-exit,\n"
+                 "           --host-format (text from the host formatters; by default the device prints the top-1 JUMAN format and the -s N lattice format),\n"
+                 "           --output-shards=K (files in, file out: the input in K contiguous parts, part k's output in OUT.part000k;\n"
+                 "                              one file takes what one writer gives it, however many GPUs feed it),\n"
                  "           --pipelines-per-device=2 (bulk runs: analysis threads, each with its analyzer pair, per GPU)\n";
     return 1;
   }
@@ -589,6 +594,10 @@ int main(int argc, const char** argv) {
       if (::stat(path.c_str(), &si) != 0 || !S_ISREG(si.st_mode)) sharded = false;
       else if (haveOut && si.st_dev == so.st_dev && si.st_ino == so.st_ino) sharded = false;
     }
+  }
+  if (conf.outputShards > 1 && !sharded) {
+    std::cerr << "--output-shards needs regular input files and -o FILE (the file-to-file pipeline)\n";
+    return 1;
   }
   std::unique_ptr<std::ofstream> ofile;
   std::ostream* out = &std::cout;
@@ -943,10 +952,69 @@ int main(int argc, const char** argv) {
                   << " analyzers=" << reserved.size() << " ms=" << clock.ms() - r0 << "\n";
       clock = Clock();   // (like the model load and the analyzers themselves: not the pipeline's time)
     }
-    const int ofd = ::open(conf.output.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
-    if (ofd < 0) {
-      std::cerr << "could not open the output file " << conf.output << "\n";
-      return 1;
+    // One output file -- or, with --output-shards=K, K of them: the input is cut into K contiguous parts of about equal
+    // size at example boundaries, part k is analysed into OUT.part000k, and `cat OUT.part*` is the one-file output.
+    // Buffered writes to ONE file are serialised by the kernel on the file's inode whatever the number of writer threads
+    // (tools/host_write_ceiling.py on the MI355X box: 14 GB/s with 1 .. 16 threads, i.e. 5.9 M sentences/s of JUMAN text,
+    // the rate of 1.4 GPUs; 28 / 55 / 98 / 160 GB/s into 2 / 4 / 8 / 16 files): a node of eight GPUs needs the shards.
+    const int nShards = conf.outputShards;
+    std::vector<int> ofds;
+    for (int k = 0; k < nShards; ++k) {
+      char suffix[32];
+      std::snprintf(suffix, sizeof(suffix), ".part%04d", k);
+      const std::string path = nShards == 1 ? conf.output : conf.output + suffix;
+      const int fd = ::open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0644);
+      if (fd < 0) {
+        std::cerr << "could not open the output file " << path << "\n";
+        return 1;
+      }
+      ofds.push_back(fd);
+    }
+    // the parts: (file, begin, end) runs of whole examples.  A cut falls on the line start at or behind its byte offset,
+    // moved back over the "# " comment lines in front of it (they belong to the example that follows them).
+    struct PartRun {
+      size_t file;
+      const char* begin;
+      const char* end;
+    };
+    std::vector<std::vector<PartRun>> parts((size_t)nShards);
+    if (!maps.empty()) {
+      size_t total = 0;
+      for (auto& mf : maps) total += mf->size;
+      // bounds[k] .. bounds[k + 1]: part k, as (file, position) pairs in input order
+      std::vector<std::pair<size_t, const char*>> bounds;
+      bounds.emplace_back(0, maps[0]->data);
+      for (int k = 1; k < nShards; ++k) {
+        size_t want = (size_t)((double)total * k / nShards), f = 0;
+        while (f + 1 < maps.size() && want >= maps[f]->size) want -= maps[f++]->size;
+        const char* const b = maps[f]->data;
+        const char* const e = b + maps[f]->size;
+        const char* p = b + std::min(want, maps[f]->size);
+        if (p > b && p < e) {   // to the next line start
+          const char* nl = static_cast<const char*>(memchr(p - 1, '\n', (size_t)(e - (p - 1))));
+          p = nl ? nl + 1 : e;
+        }
+        while (p > b) {   // back over the comment lines in front of it
+          const char* prevEnd = p - 1;   // the newline that ends the previous line (or the last byte of a file without one)
+          if (*prevEnd != '\n') break;
+          const char* ls = prevEnd;
+          while (ls > b && ls[-1] != '\n') --ls;
+          if (prevEnd - ls > 2 && ls[0] == '#' && ls[1] == ' ') p = ls;
+          else break;
+        }
+        if (f < bounds.back().first || (f == bounds.back().first && p < bounds.back().second)) bounds.push_back(bounds.back());
+        else bounds.emplace_back(f, p);
+      }
+      bounds.emplace_back(maps.size() - 1, maps.back()->data + maps.back()->size);
+      for (int k = 0; k < nShards; ++k) {
+        const auto& lo = bounds[(size_t)k];
+        const auto& hi = bounds[(size_t)k + 1];
+        for (size_t f = lo.first; f <= hi.first; ++f) {
+          const char* begin = f == lo.first ? lo.second : maps[f]->data;
+          const char* end = f == hi.first ? hi.second : maps[f]->data + maps[f]->size;
+          if (begin < end) parts[(size_t)k].push_back(PartRun{f, begin, end});
+        }
+      }
     }
     std::vector<std::unique_ptr<BoundedQueue<std::unique_ptr<ShardJob>>>> readQ, fmtQ, writeQ;
     std::vector<std::unique_ptr<Semaphore>> freeAnalyzers;
@@ -970,11 +1038,31 @@ int main(int argc, const char** argv) {
     // scanner: batches of conf.batch examples (an example = its "# " comment lines + one other line,
     // PlainStreamReader::readExample, stream_reader.cc:12-38), dealt to the devices in turn
     std::thread scanner([&]() {
-      size_t seq = 0;
-      for (auto& mf : maps) {
-        const char* p = mf->data;
-        const char* const end = mf->data + mf->size;
-        while (p < end) {
+      // one cursor per part; the parts take turns, so that every output file has batches under way all the time
+      struct Cursor {
+        size_t run = 0;
+        const char* p = nullptr;
+        size_t seq = 0;
+      };
+      std::vector<Cursor> cur((size_t)nShards);
+      for (int k = 0; k < nShards; ++k)
+        if (!parts[(size_t)k].empty()) cur[(size_t)k].p = parts[(size_t)k][0].begin;
+      size_t dealt = 0;
+      for (bool any = true; any;) {
+        any = false;
+        for (int k = 0; k < nShards; ++k) {
+          Cursor& c = cur[(size_t)k];
+          const std::vector<PartRun>& runs = parts[(size_t)k];
+          while (c.run < runs.size() && c.p >= runs[c.run].end) {
+            ++c.run;
+            if (c.run < runs.size()) c.p = runs[c.run].begin;
+          }
+          if (c.run >= runs.size()) continue;
+          any = true;
+          const char* p = c.p;
+          const char* const end = runs[c.run].end;
+          // (the end of a run that is the end of its FILE: comment lines there make an example with an empty input)
+          const bool fileEnd = end == maps[runs[c.run].file]->data + maps[runs[c.run].file]->size;
           const long long t0 = us();
           const char* q = p;
           size_t examples = 0;
@@ -991,7 +1079,7 @@ int main(int argc, const char** argv) {
             q = nl ? nl + 1 : end;
             if (line.size() > 2 && line[0] == '#' && line[1] == ' ') {
               comment = line;
-              if (q < end) continue;
+              if (q < end || !fileEnd) continue;
               job->inputs.push_back(StringPiece("", 0));   // comment lines at the end of a file: an example with an empty input
             } else {
               job->inputs.push_back(line);
@@ -1005,13 +1093,15 @@ int main(int argc, const char** argv) {
             comment = StringPiece("", 0);
             ++examples;
           }
+          c.p = q;
+          if (job->inputs.empty()) continue;   // (a run of nothing but comment lines in front of a cut cannot happen: cuts move back over them)
           job->lastReadOk = job->readErrors.empty() || job->readErrors.back().first + 1 != job->inputs.size();
-          job->seq = seq;
+          job->seq = c.seq++;
+          job->shard = k;
           job->data = p;
           job->bytes = (size_t)(q - p);
-          job->device = (int)(seq % (size_t)nDev);
-          ++seq;
-          p = q;
+          job->device = (int)(dealt % (size_t)nDev);
+          ++dealt;
           scanUs += us() - t0;
           readQ[job->device]->push(std::move(job));
         }
@@ -1061,8 +1151,9 @@ int main(int argc, const char** argv) {
     // sequencer state: batches take their output offset in input order
     std::mutex seqMu;
     std::condition_variable seqCv;
-    size_t seqNext = 0;
-    uint64_t outTotal = 0;
+    std::vector<size_t> seqNext((size_t)nShards, 0);   // per output shard
+    std::vector<uint64_t> outTotal((size_t)nShards, 0);
+    std::vector<int> shardResult((size_t)nShards, -1);
     size_t sentences = 0;
     int result = 0;
 
@@ -1133,15 +1224,15 @@ int main(int argc, const char** argv) {
             freeAnalyzers[d]->release();
             formatUs += us() - t0;
             std::unique_lock<std::mutex> l(seqMu);
-            seqCv.wait(l, [&] { return seqNext == job->seq; });
-            job->outOffset = outTotal;
-            outTotal += job->outBytes;
+            seqCv.wait(l, [&] { return seqNext[(size_t)job->shard] == job->seq; });
+            job->outOffset = outTotal[(size_t)job->shard];
+            outTotal[(size_t)job->shard] += job->outBytes;
             sentences += n;
             gpuUs += (long long)(job->gpuMs * 1000.0);
-            result = job->lastReadOk ? 0 : 1;
+            shardResult[(size_t)job->shard] = job->lastReadOk ? 0 : 1;
             for (auto& e : job->errors)
               if (!e.empty()) std::cerr << e;
-            ++seqNext;
+            ++seqNext[(size_t)job->shard];
             seqCv.notify_all();
             l.unlock();
             writeQ[d]->push(std::move(job));
@@ -1189,15 +1280,15 @@ int main(int argc, const char** argv) {
           formatUs += us() - t0;
           {
             std::unique_lock<std::mutex> l(seqMu);
-            seqCv.wait(l, [&] { return seqNext == job->seq; });
-            job->outOffset = outTotal;
-            outTotal += job->outBytes;
+            seqCv.wait(l, [&] { return seqNext[(size_t)job->shard] == job->seq; });
+            job->outOffset = outTotal[(size_t)job->shard];
+            outTotal[(size_t)job->shard] += job->outBytes;
             sentences += n;
             gpuUs += (long long)(job->gpuMs * 1000.0);
-            result = job->lastReadOk ? 0 : 1;   // the reference's exit code is that of the last example read
+            shardResult[(size_t)job->shard] = job->lastReadOk ? 0 : 1;   // the reference's exit code is that of the last example read
             for (auto& e : job->errors)
-              if (!e.empty()) std::cerr << e;   // (in input order)
-            ++seqNext;
+              if (!e.empty()) std::cerr << e;   // (in input order; with several output shards: in each shard's order)
+            ++seqNext[(size_t)job->shard];
             seqCv.notify_all();
           }
           writeQ[d]->push(std::move(job));
@@ -1252,7 +1343,7 @@ int main(int argc, const char** argv) {
                 p2 += len;
                 ++k2;
               }
-              const ssize_t w = pwritev(ofd, part, cnt, (off_t)(base + pos));
+              const ssize_t w = pwritev(ofds[(size_t)job->shard], part, cnt, (off_t)(base + pos));
               if (w <= 0) {
                 writeFailed = true;
                 return;
@@ -1270,7 +1361,9 @@ int main(int argc, const char** argv) {
     for (auto& t : gpus) t.join();
     for (auto& t : formatters) t.join();
     for (auto& t : writers) t.join();
-    ::close(ofd);
+    for (int fd : ofds) ::close(fd);
+    for (int k = 0; k < nShards; ++k)
+      if (shardResult[(size_t)k] >= 0) result = shardResult[(size_t)k];   // (of the last part that held examples)
     if (writeFailed) {
       std::cerr << "write to " << conf.output << " failed\n";
       return 1;

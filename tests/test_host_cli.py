@@ -400,6 +400,55 @@ def test_sharded_pipeline_files_in_file_out(cli_emu, ref_tools, golden_dir, tmp_
     assert rc == 0 and open(out, 'rb').read() == two
 
 
+def _output_shards_case(cli, golden_dir, tmp_path):
+    """--output-shards=K: the input in K contiguous parts at example boundaries, part k analysed into OUT.part000k (one
+    file takes 14 GB/s however many threads write it, tools/host_write_ceiling.py: what eight GPUs print needs several).
+    `cat OUT.part*` must be the one-file output: comment lines in front of every cut, more parts than examples, two
+    input files, several devices, tiny batches, both device formatters and the host one"""
+    import glob
+    tmp = str(tmp_path)
+    m = os.path.join(golden_dir, 'mini_rnn.jppmdl')
+    lines = [l for l in open(os.path.join(golden_dir, 'mini.txt'), 'rb').read().split(b'\n') if l]
+    body = b''
+    for i, l in enumerate(lines * 3):
+        # a comment (or two) in front of most examples: wherever a cut lands, comments are near it
+        if i % 3 != 2:
+            body += b'# S-ID:%d\n' % i
+        if i % 7 == 0:
+            body += b'# second comment line %d\n' % i
+        body += l + b'\n'
+    body += b'\n\xe3\x81\n# trailing comment'
+    a, b = os.path.join(tmp, 'a.txt'), os.path.join(tmp, 'b.txt')
+    open(a, 'wb').write(body)
+    open(b, 'wb').write(b'# first of b\n' + lines[0] + b'\n' + lines[1])   # (no newline at the end)
+    one = os.path.join(tmp, 'one.txt')
+    for inputs in ([a], [a, b]):
+        for fmt in (([], ['-s', '3'], ['--host-format'], ['-M']) if len(inputs) == 1 else ([],)):
+            rc, _, e1 = _run(cli, ['--model=' + m, '--batch=7', '-o', one] + fmt + inputs)
+            ref = open(one, 'rb').read()
+            assert ref
+            for shards, dev, batch in ((2, '0', 1000), (5, '0,1,2', 4), (64, '0,1', 3)):
+                for f in glob.glob(os.path.join(tmp, 'sh.txt.part*')):
+                    os.remove(f)
+                rc2, so, err = _run(cli, ['--model=' + m, '--devices=' + dev, '--batch=%d' % batch, '--output-shards=%d' % shards,
+                                          '--timing', '-o', os.path.join(tmp, 'sh.txt')] + fmt + inputs)
+                files = sorted(glob.glob(os.path.join(tmp, 'sh.txt.part*')))
+                assert rc2 == rc and len(files) == shards and b'sharded=1' in err, err[-300:]
+                got = b''.join(open(f, 'rb').read() for f in files)
+                assert got == ref, (inputs, fmt, shards)
+                if shards == 2:
+                    assert all(os.path.getsize(f) > len(ref) // 4 for f in files)   # (the parts are about equal)
+
+
+def test_output_shards(cli_emu, golden_dir, tmp_path):
+    _output_shards_case(cli_emu, golden_dir, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_output_shards(cli_gpu, golden_dir, tmp_path):
+    _output_shards_case(cli_gpu, golden_dir, tmp_path)
+
+
 def test_sharded_pipeline_only_for_regular_files(cli_emu, golden_dir, tmp_path):
     """-o /dev/stdout (a pipe), a FIFO as input and an output that names the input must not take the mmap / pwrite
     pipeline: same bytes as the plain run, no ESPIPE failure, no SIGBUS"""
