@@ -192,6 +192,44 @@ def test_gpu_device_side_lattice_format(cli_gpu, golden_dir, tmp_path):
     _device_lattice_case(cli_gpu, golden_dir, tmp_path)
 
 
+def _adversarial_lattice_case(cli, golden_dir, ref_tools, tmp_path, n_fuzz, models, flag_sets):
+    """the device lattice formatter on lines made to be nasty (every character class of util/characters.cc, 4-byte code
+    points, ZWJ sequences, half-width kana, full-width digits, onomatopoeia and prolongation runs, tabs, '#' lines, empty
+    lines, a 150-codepoint run): UNK nodes of every maker, normalized nodes with their flags, alias entries.  Same bytes
+    as the host class, and equal to jumanpp_v2 up to the reference's own unstable choice among tied connections"""
+    import random
+    import test_cpu_parity as tc
+    lines = tc._fuzz_lines(n_fuzz, 123)
+    extra = ['すごーーーい', 'かぁっこいいねぇっッ！', 'ﾊﾝｶｸｶﾅ', '１２３４５６７８９０', '#not a comment', '# a comment', '', '\t', 'a\tb',
+             '👨\u200d👩\u200d👧\u200d👦家族', '𠮷野家', 'きらきらきらきら', 'ワンワン', 'あ' * 150]
+    lines = lines + extra * 2
+    random.Random(5).shuffle(lines)
+    path = str(tmp_path / 'fz.txt')
+    open(path, 'w', encoding='utf-8').write('\n'.join(lines) + '\n')
+    for model in models:
+        for flags in flag_sets:
+            rc, host, eh = _run(cli, ['--model=' + model, '--host-format'] + flags + [path])
+            rc2, dev, ed = _run(cli, ['--model=' + model, '--timing'] + flags + [path])
+            assert rc == rc2 and b'device_lattice_format=1' in ed and dev == host, (model, flags)
+            if ref_tools is not None:
+                refs = [_ref_cli(ref_tools, model, flags, path) for _ in range(2)]
+                _lattice_blocks_equal_except_reference_unstable(dev, refs)
+
+
+def test_device_lattice_format_on_adversarial_lines(cli_emu, golden_dir, ref_tools, tmp_path):
+    _adversarial_lattice_case(cli_emu, golden_dir, ref_tools, tmp_path, 100,
+                              [os.path.join(golden_dir, 'ref', 'minimal_trained.jppmdl'), os.path.join(golden_dir, 'mini_rnn.jppmdl')],
+                              [['-s', '5'], ['-s', '60']])
+
+
+@pytest.mark.gpu
+def test_gpu_device_lattice_format_on_adversarial_lines(cli_gpu, golden_dir, ref_tools, tmp_path):
+    _adversarial_lattice_case(cli_gpu, golden_dir, ref_tools, tmp_path, 400,
+                              [os.path.join(golden_dir, 'ref', m) for m in ('minimal_trained.jppmdl', 'bug950111.jppmdl')] + [os.path.join(golden_dir, 'mini_rnn.jppmdl')],
+                              [['-s', '5'], ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '32'],
+                               ['--beam=3', '--global-beam=10', '--right-check=2', '--right-beam=4', '-s', '3'], ['-s', '60']])
+
+
 def test_exact_percent_g_of_the_device(tmp_path):
     """csrc/jpp_fmtg.h -- the "%g" the device prints scores with -- against the C library: every exponent with structured
     mantissas, the neighbourhoods of the powers of ten and of d.ddddd5 ties, denormals, 2 M random bit patterns"""
