@@ -438,7 +438,7 @@ def test_sharded_pipeline_files_in_file_out(cli_emu, ref_tools, golden_dir, tmp_
     assert rc == 0 and open(out, 'rb').read() == two
 
 
-def _output_shards_case(cli, golden_dir, tmp_path):
+def _output_shards_case(cli, golden_dir, tmp_path, devs=('0', '0,1,2', '0,1')):
     """--output-shards=K: the input in K contiguous parts at example boundaries, part k analysed into OUT.part000k (one
     file takes 14 GB/s however many threads write it, tools/host_write_ceiling.py: what eight GPUs print needs several).
     `cat OUT.part*` must be the one-file output: comment lines in front of every cut, more parts than examples, two
@@ -465,7 +465,8 @@ def _output_shards_case(cli, golden_dir, tmp_path):
             rc, _, e1 = _run(cli, ['--model=' + m, '--batch=7', '-o', one] + fmt + inputs)
             ref = open(one, 'rb').read()
             assert ref
-            for shards, dev, batch in ((2, '0', 1000), (5, '0,1,2', 4), (64, '0,1', 3)):
+            # (every part count with the default format; the other formats with one of them)
+            for shards, dev, batch in ((2, devs[0], 1000), (5, devs[1], 6), (64, devs[2], 16)) if not fmt else ((5, devs[1], 6),):
                 for f in glob.glob(os.path.join(tmp, 'sh.txt.part*')):
                     os.remove(f)
                 rc2, so, err = _run(cli, ['--model=' + m, '--devices=' + dev, '--batch=%d' % batch, '--output-shards=%d' % shards,
@@ -484,7 +485,7 @@ def test_output_shards(cli_emu, golden_dir, tmp_path):
 
 @pytest.mark.gpu
 def test_gpu_output_shards(cli_gpu, golden_dir, tmp_path):
-    _output_shards_case(cli_gpu, golden_dir, tmp_path)
+    _output_shards_case(cli_gpu, golden_dir, tmp_path, devs=('0', '0,0,0', '0,0'))   # (a one-GPU box: its GPU named again)
 
 
 def test_sharded_pipeline_only_for_regular_files(cli_emu, golden_dir, tmp_path):
