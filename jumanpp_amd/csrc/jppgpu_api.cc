@@ -848,7 +848,6 @@ void fill_memo_range(const std::vector<ModelBufs::MemoSeed>& seeds, size_t from,
     }
     if (!ok) continue;
     for (int f = 0; f < spec::kNumDicFeatures; ++f) r.row[f] = sd.row[f];
-    for (int p = 0; p < spec::kNumStoredPatterns; ++p) r.pat[p] = pat[p];
     for (int j = 0; j < 4; ++j) {
       float acc = w[j];
       for (int u = j + 4; u < kT0CtxFirst; u += 4) acc += w[u];

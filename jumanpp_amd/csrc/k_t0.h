@@ -140,28 +140,31 @@ __device__ __forceinline__ void t0_patterns(const i32 (&entry)[spec::kNumDicFeat
 
 // ---- per-entry memo ------------------------------------------------------------------------------------------------
 // A dictionary node's entry row, its 14 stored patterns and 26 of its 32 unigram weights depend on the dictionary entry
-// only (placeholders are 0 for dictionary nodes, the surface length is the key's): one 176-byte record per entry, built
-// on the host when the model (or a new weight table) is loaded, replaces the varint decode, 32 pattern hashes and 26
-// scattered weight gathers -- the gathers are what bound k_t0 (3.2x line amplification at the fabric ceiling).
+// only (placeholders are 0 for dictionary nodes, the surface length is the key's): one 64-byte record per entry, built
+// on the host when the model (or a new weight table) is loaded, replaces the varint decode and 26 scattered weight
+// gathers -- the gathers are what bound k_t0 (3.2x line amplification at the fabric ceiling).
 // Record of the entry at EntryPtr e: slot (e >> 1) >> 3 (an entry row is at least 8 bytes long, so slots are unique).
+//   row:    the decoded entry row;
 //   pre[j]: the weights of the features u = j, j + 4, ... < 23 summed in that order -- the four accumulators of
 //           computeUnrolled4RawPerceptron up to the first feature that looks at the context;
 //   raw[]:  the weights of the three features behind the context block (u = 29, 30, 31);
 //   len:    codepoints of the key (0: no record -- the node takes the full path).
 // The context features (u = 23..28) are hashed and gathered per node and added between the two, in the reference's order.
+// Round 6: the record no longer carries the 14 stored patterns (176 -> 64 bytes: one 128-byte line per node instead of
+// 2.4 on average, and a table a third the size); they are hashed from the row again -- 38 multiply-mixes per node on
+// arithmetic units that a kernel at the fabric ceiling leaves idle.
 struct alignas(16) U4 {
   u32 x, y, z, w;
 };
 __host__ __device__ inline float bits_f32(u32 v) { return __builtin_bit_cast(float, v); }
 
-struct T0Memo {
+struct alignas(64) T0Memo {
   i32 row[spec::kNumDicFeatures];
-  u64 pat[spec::kNumStoredPatterns];
   float pre[4];
   float raw[3];
   u32 len;
 };
-static_assert(sizeof(T0Memo) == 176 && spec::kNumDicFeatures == 8 && spec::kNumStoredPatterns == 14, "memo record layout");
+static_assert(sizeof(T0Memo) == 64 && spec::kNumDicFeatures == 8 && spec::kNumStoredPatterns == 14, "memo record layout");
 constexpr int kT0CtxFirst = 23, kT0CtxLast = 28;   // unigram positions (summation order) that read the context
 constexpr bool t0_memo_layout_ok() {
   if (spec::kNumUni != 32) return false;
@@ -172,6 +175,15 @@ constexpr bool t0_memo_layout_ok() {
   return true;
 }
 static_assert(t0_memo_layout_ok(), "the memo assumes which unigram features read the context");
+
+// the first kNumStoredPatterns patterns only (what bigrams / trigrams read of a node)
+template <int P = 0>
+__host__ __device__ inline void t0_stored_patterns(const u64 (&prim)[spec::kNumPrims], u64 (&pat)[spec::kNumStoredPatterns]) {
+  if constexpr (P < spec::kNumStoredPatterns) {
+    pat[P] = t0_pattern_one<P>(prim);
+    t0_stored_patterns<P + 1>(prim, pat);
+  }
+}
 
 // entry-only primitives (host: building the memo; placeholders 0, context primitives unused)
 __host__ __device__ inline void t0_entry_prims(const i32 (&entry)[spec::kNumDicFeatures], u32 len, u64 (&prim)[spec::kNumPrims]) {
@@ -312,25 +324,27 @@ __global__ void __launch_bounds__(64) k_t0_memo(Batch B, const DevModel* __restr
       const u32 slot = ni.eptr >= 0 ? (u32)ni.eptr >> 4 : nslots;
       if (slot < nslots) {
         const U4 JPP_GLOBAL* rec = reinterpret_cast<const U4 JPP_GLOBAL*>(as_global(memo + slot));
-        const U4 tail = rec[10];   // raw[0..2], len
+        const U4 tail = rec[3];   // raw[0..2], len
         if (tail.w == len) {
           hit = true;
-          U4 q[10];
-#pragma unroll
-          for (int z = 0; z < 10; ++z) q[z] = rec[z];
-          // entry row and stored patterns, as read
+          const U4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+          // entry row, as read
           U4* orow = reinterpret_cast<U4*>(B.node_entry + (S.nb + k) * spec::kNumDicFeatures);
-          orow[0] = q[0];
-          orow[1] = q[1];
-          U4* opat = reinterpret_cast<U4*>(B.node_pat + (S.nb + k) * kPat);
-#pragma unroll
-          for (int z = 0; z < 7; ++z) opat[z] = q[2 + z];
-          i32 entry[spec::kNumDicFeatures] = {(i32)q[0].x, (i32)q[0].y, (i32)q[0].z, (i32)q[0].w, (i32)q[1].x, (i32)q[1].y, (i32)q[1].z, (i32)q[1].w};
+          orow[0] = q0;
+          orow[1] = q1;
+          i32 entry[spec::kNumDicFeatures] = {(i32)q0.x, (i32)q0.y, (i32)q0.z, (i32)q0.w, (i32)q1.x, (i32)q1.y, (i32)q1.z, (i32)q1.w};
           u64 prim[spec::kNumPrims];
           t0_prims(entry, ni, NodeAux{0, 0, 0, 0, 0, 0}, false, S.cps, S.cls, S.n, prim);
+          // (the six gathers first: the hashing below runs while they are in flight)
           float wc[kT0CtxLast - kT0CtxFirst + 1];
           t0_context_weights<W24>(prim, as_global(M.weights), M.wmask, wc);
-          float part[4] = {bits_f32(q[9].x), bits_f32(q[9].y), bits_f32(q[9].z), bits_f32(q[9].w)};
+          // the stored patterns, hashed from the row (they are functions of the entry and its length alone)
+          u64 sp[spec::kNumStoredPatterns];
+          t0_stored_patterns(prim, sp);
+          U4* opat = reinterpret_cast<U4*>(B.node_pat + (S.nb + k) * kPat);
+#pragma unroll
+          for (int z = 0; z < 7; ++z) opat[z] = U4{(u32)sp[2 * z], (u32)(sp[2 * z] >> 32), (u32)sp[2 * z + 1], (u32)(sp[2 * z + 1] >> 32)};
+          float part[4] = {bits_f32(q2.x), bits_f32(q2.y), bits_f32(q2.z), bits_f32(q2.w)};
           const float raw[3] = {bits_f32(tail.x), bits_f32(tail.y), bits_f32(tail.z)};
 #pragma unroll
           for (int u = kT0CtxFirst; u < spec::kNumUni; ++u) part[u & 3] += u <= kT0CtxLast ? wc[u - kT0CtxFirst] : raw[u - kT0CtxLast - 1];
