@@ -324,10 +324,11 @@ __global__ void __launch_bounds__(64) k_t0_memo(Batch B, const DevModel* __restr
       const u32 slot = ni.eptr >= 0 ? (u32)ni.eptr >> 4 : nslots;
       if (slot < nslots) {
         const U4 JPP_GLOBAL* rec = reinterpret_cast<const U4 JPP_GLOBAL*>(as_global(memo + slot));
+        // (the whole record at once -- it is one line -- instead of its length word first and the rest behind the test)
+        const U4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const U4 tail = rec[3];   // raw[0..2], len
         if (tail.w == len) {
           hit = true;
-          const U4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
           // entry row, as read
           U4* orow = reinterpret_cast<U4*>(B.node_entry + (S.nb + k) * spec::kNumDicFeatures);
           orow[0] = q0;
