@@ -500,6 +500,7 @@ struct jppgpu_ctx {
   void* plugin_user = nullptr;
   jpp_stream_t aux_stream = nullptr;   // the sweep variants of the rare wide sentences run here, beside the main variant
   SyncPoint sweep_fork, sweep_join;
+  SyncPoint front_fork, front_join;   // the normalize maker's emit passes run on aux_stream beside k_seeds<1> / <2>
   // scorers: slot 0 perceptron, slot 1 the RNN when use_rnn, then the host scorers (jppgpu_analyze_batch_scored)
   bool use_rnn = false;
   int n_host_scorers = 0;
@@ -971,6 +972,8 @@ void finish_context(jppgpu_ctx* ctx) {
   ctx->aux_stream = rt_stream_create();
   ctx->sweep_fork.init();
   ctx->sweep_join.init();
+  ctx->front_fork.init();
+  ctx->front_join.init();
   ctx->timer.init();
   ctx->rnn_sync.init();
   void* dev = nullptr;
@@ -1326,6 +1329,8 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   rt_stream_destroy(ctx->aux_stream);
   ctx->sweep_fork.destroy();
   ctx->sweep_join.destroy();
+  ctx->front_fork.destroy();
+  ctx->front_join.destroy();
   rt_mailbox_free((void*)ctx->mail_host);
   ctx->host_pool->clear();
   ctx->text_pool->clear();
@@ -1621,9 +1626,33 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   B.node_info = ctx->node_info.as<NodeInfo>();
   B.node_aux = ctx->node_aux.as<NodeAux>();
-  if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<1, 6>), n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
-  else JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
-  JPP_LAUNCH(k_norm<1>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  // The two emit passes of a stage write disjoint slots of the node tables (the normalize maker's nodes follow the
+  // others of their start) and read only what the count passes left: they run side by side, k_norm on the context's
+  // second stream -- both are chains of dependent loads, and each fills the other's tail (JPPGPU_DEV_FRONT_SERIAL=1: one
+  // after the other, as until round 6).
+  static const bool frontSerial = std::getenv("JPPGPU_DEV_FRONT_SERIAL") != nullptr;
+  const bool frontSplit = !frontSerial && ctx->aux_stream != nullptr && ctx->hmodel.norm_maker >= 0;
+  auto emit_pair = [&](int mode) {
+    jpp_stream_t s2 = st;
+    if (frontSplit) {
+      ctx->front_fork.mark(st);
+      ctx->front_fork.make_stream_wait(ctx->aux_stream);
+      s2 = ctx->aux_stream;
+    }
+    if (mode == 1) {
+      JPP_LAUNCH(k_norm<1>, n, 64, s2, B, (const DevModel*)ctx->mb->dmodel);
+      if (devSeedsWaves == 6) JPP_LAUNCH((k_seeds<1, 6>), n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+      else JPP_LAUNCH(k_seeds<1>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+    } else {
+      JPP_LAUNCH(k_norm<2>, n, 64, s2, B, (const DevModel*)ctx->mb->dmodel);
+      JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+    }
+    if (frontSplit) {
+      ctx->front_join.mark(s2);
+      ctx->front_join.make_stream_wait(st);
+    }
+  };
+  emit_pair(1);
   JPP_LAUNCH(k_connect<1>, wblocks, 64 * kLatWaves, st, B);
   // stage 2 for disconnected sentences: relocate them behind the stage-1 region
   JPP_LAUNCH(k_layout<2>, wblocks, 64 * kLatWaves, st, B);
@@ -1634,8 +1663,7 @@ extern "C" int jppgpu_analyze_batch_device(jppgpu_ctx* ctx, const void* d_utf8, 
   }
   launch_scan(ctx, st, (const u32*)B.sent_nodes2, B.node_base2, n, (const u64*)(B.node_base + n));
   JPP_LAUNCH(k_relocate, sblocks, 256, st, B);
-  JPP_LAUNCH(k_seeds<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
-  JPP_LAUNCH(k_norm<2>, n, 64, st, B, (const DevModel*)ctx->mb->dmodel);
+  emit_pair(2);
   JPP_LAUNCH(k_connect<2>, wblocks, 64 * kLatWaves, st, B);
   u64 totalNodes = 0;
   u32 gstats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
