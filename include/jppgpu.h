@@ -527,9 +527,6 @@ typedef struct {
   const uint64_t* offsets;   /* [n + 1] byte offsets into text: sentence i is text[offsets[i] .. offsets[i + 1]) */
   const char* text;          /* host copy, owned by the result (valid until jppgpu_result_release) */
   const int32_t* status;     /* [n] JPPGPU_SENT_* */
-  const uint32_t* head_len;  /* jppgpu_result_format_lattice: [n] bytes of the "# MA-SCORE ..." line a sentence's text starts
-                              * with (0: none) -- a caller that has a comment for the sentence prints "# comment\n" in its
-                              * place (lattice_format.cc:105-120); NULL for jppgpu_result_format_top1 */
 } jppgpu_text_view;
 /* the formatted top-1 analyses of the batch; needs jppgpu_ctx_set_format_table.  The device side of the result must
  * still be valid (no later batch on the context). */
@@ -611,10 +608,19 @@ typedef struct {
 } jppgpu_lattice_table;
 
 int jppgpu_ctx_set_lattice_table(jppgpu_ctx* ctx, const jppgpu_lattice_table* table);
-/* the lattice-format text of the batch's n_best (<= 64) best analyses; view->head_len is filled.  Needs
+/* jppgpu_text_view (which older callers of jppgpu_result_format_top1 hold at its old size) plus one array */
+typedef struct {
+  uint32_t n_sentences;
+  const uint64_t* offsets;   /* [n + 1] */
+  const char* text;
+  const int32_t* status;     /* [n] */
+  const uint32_t* head_len;  /* [n] bytes of the "# MA-SCORE ..." line a sentence's text starts with (0: none) -- a caller that
+                              * has a comment for the sentence prints "# comment\n" in its place (lattice_format.cc:105-120) */
+} jppgpu_lattice_text_view;
+/* the lattice-format text of the batch's n_best (<= 64) best analyses.  Needs
  * jppgpu_ctx_set_lattice_table and a context with a global beam (the format reads the score cells); the device side of
  * the result must still be valid.  A result holds ONE text: the first of format_top1 / format_lattice called on it. */
-int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, jppgpu_text_view* view);
+int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, jppgpu_lattice_text_view* view);
 /* Training hook.  What the reference's trainer reads off an analysed lattice besides the scores
  * (LossCalculator::addTopNgrams, src/core/training/loss.cc:289-300 -> NgramFeaturesComputer::calculateNgramFeatures,
  * src/core/impl/feature_computer.cc:13-31): for every connection on the top-1 path of every sentence, from the EOS

@@ -2501,7 +2501,6 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
   v->offsets = res->fm_off.data();
   v->text = res->fm_text.data();
   v->status = res->fm_status.data();
-  v->head_len = nullptr;
   return JPPGPU_OK;
 }
 
@@ -2578,7 +2577,7 @@ extern "C" int jppgpu_ctx_set_lattice_table(jppgpu_ctx* ctx, const jppgpu_lattic
   return JPPGPU_OK;
 }
 
-extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, jppgpu_text_view* v) {
+extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, jppgpu_lattice_text_view* v) {
   if (!res || !res->ctx || !v) return fail(JPPGPU_INVALID_PARAMETER, "null argument");
   jppgpu_ctx* ctx = res->ctx;
   if (!ctx->mb->lat_have) return fail(JPPGPU_INVALID_STATE, "jppgpu_result_format_lattice needs jppgpu_ctx_set_lattice_table");

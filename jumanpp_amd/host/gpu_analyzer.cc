@@ -410,7 +410,16 @@ Status GpuAnalyzer::fetchText() {
   Group& G = groups_[0];
   static const bool hostTiming = std::getenv("JPPGPU_HOST_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  int rc = latticeTextN_ > 0 ? jppgpu_result_format_lattice(G.result, latticeTextN_, &text_) : jppgpu_result_format_top1(G.result, &text_);
+  int rc;
+  textHeads_ = nullptr;
+  if (latticeTextN_ > 0) {
+    jppgpu_lattice_text_view lv{};
+    rc = jppgpu_result_format_lattice(G.result, latticeTextN_, &lv);
+    text_ = jppgpu_text_view{lv.n_sentences, lv.offsets, lv.text, lv.status};
+    textHeads_ = lv.head_len;
+  } else {
+    rc = jppgpu_result_format_top1(G.result, &text_);
+  }
   if (rc != JPPGPU_OK) return fromCode(rc);
   if (hostTiming)
     std::fprintf(stderr, "fetchText n=%u bytes=%llu total=%.2f ms\n", text_.n_sentences, (unsigned long long)text_.offsets[text_.n_sentences],
@@ -426,6 +435,8 @@ TextBatch GpuAnalyzer::takeText() {
   if (textFetched_ && groups_.size() == 1) {
     tb.result = groups_[0].result;
     tb.view = text_;
+    tb.headLen = textHeads_;
+    textHeads_ = nullptr;
     groups_[0].result = nullptr;
     groups_.clear();
     textFetched_ = false;

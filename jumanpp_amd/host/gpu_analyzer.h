@@ -137,15 +137,17 @@ class ScorePlugin {
 struct TextBatch {
   jppgpu_result* result = nullptr;
   jppgpu_text_view view{};
+  const uint32_t* headLen = nullptr;   // lattice text: bytes of the "# MA-SCORE" line per sentence (jppgpu_lattice_text_view)
   TextBatch() = default;
   TextBatch(const TextBatch&) = delete;
   TextBatch& operator=(const TextBatch&) = delete;
-  TextBatch(TextBatch&& o) noexcept : result(o.result), view(o.view) { o.result = nullptr; }
+  TextBatch(TextBatch&& o) noexcept : result(o.result), view(o.view), headLen(o.headLen) { o.result = nullptr; }
   TextBatch& operator=(TextBatch&& o) noexcept {
     if (this != &o) {
       reset();
       result = o.result;
       view = o.view;
+      headLen = o.headLen;
       o.result = nullptr;
     }
     return *this;
@@ -195,6 +197,7 @@ class GpuAnalyzer {
   uint32_t memoImageSlots_ = 0;
   bool keepMemoImage_ = false;
   jppgpu_text_view text_{};
+  const uint32_t* textHeads_ = nullptr;   // lattice text mode: header bytes per sentence
   std::vector<Group> groups_;
   std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
   AnalyzerConfig cfg_;
@@ -251,7 +254,7 @@ class GpuAnalyzer {
   }
   // LatticeFormat::format on the device (jppgpu_lattice_table, csrc/k_latfmt.h): after setLatticeTable, lattice text
   // mode makes analyzeBatch fetch the lattice-format text of the n best paths of every sentence (also when called with
-  // fullLattice = true: nothing of the lattice itself crosses PCIe).  batchText().head_len says how many bytes of a
+  // fullLattice = true: nothing of the lattice itself crosses PCIe).  batchTextHeads() says how many bytes of a
   // sentence's text are the "# MA-SCORE" line a comment replaces.  Not with auto-beam; n <= 64.
   Status setLatticeTable(const jppgpu_lattice_table& table);
   bool setLatticeTextMode(int32_t n) {
@@ -273,6 +276,8 @@ class GpuAnalyzer {
   }
   // the whole batch: sentence i is text[offsets[i] .. offsets[i + 1])
   const jppgpu_text_view& batchText() const { return text_; }
+  // lattice text mode: [n] bytes of the "# MA-SCORE" line each sentence's text starts with (a comment replaces it); else null
+  const uint32_t* batchTextHeads() const { return textHeads_; }
   // the n-best view holding sentence i (nullptr unless the batch was fetched in n-best mode)
   const jppgpu_nbest_view* nbestOf(size_t i, uint32_t* local) const {
     *local = localIdx_[i];

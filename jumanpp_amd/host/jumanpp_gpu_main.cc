@@ -1181,6 +1181,7 @@ int main(int argc, const char** argv) {
               job->batchStatus = fs;
             } else {
               const jppgpu_text_view& tv = an.batchText();
+              const uint32_t* heads = an.batchTextHeads();
               auto seg = [&](const char* p, size_t len) {
                 if (len == 0) return;
                 if (!job->segments.empty()) {
@@ -1208,9 +1209,9 @@ int main(int argc, const char** argv) {
                 const StringPiece& cm = job->comments[i];
                 // lattice text: a comment takes the place of the "# MA-SCORE" line the text starts with, and a sentence
                 // without that line (empty input: "EOS" alone) prints none (lattice_format.cc:87-120)
-                const size_t head = tv.head_len != nullptr ? tv.head_len[i] : 0;
+                const size_t head = heads != nullptr ? heads[i] : 0;
                 size_t skip = 0;
-                if (cm.size() >= 2 && tv.status[i] == JPPGPU_SENT_OK && (tv.head_len == nullptr || head != 0)) {
+                if (cm.size() >= 2 && tv.status[i] == JPPGPU_SENT_OK && (heads == nullptr || head != 0)) {
                   seg(cm.data(), cm.size());   // "# comment", as it stands in the mapped input
                   seg("\n", 1);
                   skip = head;
@@ -1479,7 +1480,7 @@ int main(int argc, const char** argv) {
       StringPiece comment = e.comment.size() < 2 ? StringPiece("") : StringPiece(e.comment.data() + 2, e.comment.size() - 2);
       if (conf.partialInput) comment = StringPiece(e.partial->comment);
       if (analyzer.textMode()) {   // the device printed the sentence; the comment line goes in front of it
-        const uint32_t* heads = analyzer.batchText().head_len;   // (lattice text: the comment replaces the "# MA-SCORE" line)
+        const uint32_t* heads = analyzer.batchTextHeads();   // (lattice text: the comment replaces the "# MA-SCORE" line)
         const size_t head = heads != nullptr ? heads[i] : 0;
         size_t skip = 0;
         if (!comment.empty() && (heads == nullptr || head != 0)) {
