@@ -768,6 +768,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                  'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')},
                  'reserve_ms': round(kv.get('reserve_ms', 0.0), 1),
                  'process_ms': {'first_analyzers_ready': round(kv.get('first_analyzers_ready_ms', 0.0), 1),
+                                'waited_for_page_locking': round(kv.get('waited_ms', 0.0), 1),
                                 'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)}}
             main_rates.append(round(r['value']))
             if best is None or r['value'] > best['value']:
@@ -898,6 +899,7 @@ def config5_cli_lattice(args, cache, ge, np):
                'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},
                'process_wall_s_incl_model_load': round(wall, 2),
                'process_ms': {'first_analyzers_ready': round(kv.get('first_analyzers_ready_ms', 0.0), 1),
+                                'waited_for_page_locking': round(kv.get('waited_ms', 0.0), 1),
                               'reserve': round(kv.get('reserve_ms', 0.0), 1),
                               'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)},
                'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')}}

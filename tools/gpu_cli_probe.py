@@ -47,6 +47,45 @@ def main():
         if os.path.exists(out):
             os.remove(out)
 
+    if 'spread' in sys.argv[1:]:
+        # (round 6) a session in which 8 of 11 device-text runs of the bench leg ran at 0.5 M sentences/s with five times
+        # the GPU time per batch (profiles/r06_n_bench.json): the command back to back with the whole --timing output,
+        # the memory state of the box before each run, and the three suspects switched off one at a time
+        def meminfo():
+            want = ('MemFree', 'Cached', 'Dirty', 'Writeback', 'Unevictable', 'Mlocked')
+            kv = {}
+            for line in open('/proc/meminfo'):
+                k, v = line.split(':', 1)
+                if k in want:
+                    kv[k] = int(v.split()[0]) // 1024
+            return ' '.join('%s=%dM' % (k, kv.get(k, -1)) for k in want)
+
+        def run2(tag, flags=(), env=None):
+            print('-- %s | %s' % (tag, meminfo()), flush=True)
+            e = dict(os.environ)
+            e.update(env or {})
+            t0 = time.perf_counter()
+            p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out, corpus] + list(flags),
+                               capture_output=True, text=True, env=e)
+            wall = time.perf_counter() - t0
+            keep = [ln for ln in p.stderr.strip().splitlines() if ln.startswith(('startup:', 'reserve:', 'devices=', 'batches:', 'exit:', 'prepin:'))]
+            for ln in keep:
+                print('   ' + ln[:260])
+            print('   process wall %.2f s' % wall, flush=True)
+            for f in [out] + [out + '.part%04d' % k for k in range(8)]:
+                if os.path.exists(f):
+                    os.remove(f)
+        for i in range(6):
+            run2('default %d' % i)
+        for i in range(3):
+            run2('emit passes one after the other %d' % i, env={'JPPGPU_DEV_FRONT_SERIAL': '1'})
+        for i in range(3):
+            run2('--pipelines-per-device=1 %d' % i, flags=['--pipelines-per-device=1'])
+        for i in range(3):
+            run2('--host-format %d' % i, flags=['--host-format'])
+        for i in range(3):
+            run2('default again %d' % i)
+        return
     if 'parent' not in sys.argv[1:]:
         print(sh('lscpu | grep -i "numa\\|socket\\|^CPU(s)"'))
         print('gpu numa:', sh('cat /sys/class/drm/card*/device/numa_node'), '| nproc', sh('nproc'))
