@@ -736,6 +736,16 @@ def _timing_kv(stderr):
     return kv
 
 
+def _settle():
+    """Between two child processes of the CLI legs.  A GPU process that starts within a second of another one's exit can
+    lose 4-5 s anywhere -- inside its pipeline (a run at 0.3 M sentences/s with ten times the GPU time per batch) or in
+    its start-up (a normal run with 5-6 s of process wall): 6 of 30 back-to-back runs in tools/gpu_cli_probe.py spread,
+    with and without --clean-exit, no CPU throttling, no memory events (profiles/r06_r_*, r06_s_*); 0 of 6 after a 3 s
+    pause.  The driver is still taking the previous process' queues and 40 GB of buffers apart.  A service is one
+    process; the legs below are twenty, so they wait."""
+    time.sleep(3.0)
+
+
 def cli_end_to_end(args, model, corpus, n_lines, ge):
     """The product binary end to end, timed by this process: jumanpp_gpu (C++14 host pipeline above the C ABI)
     reads the corpus file, analyses it in 65,536-sentence batches and writes the JUMAN-format text to a file.
@@ -747,6 +757,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
         main_rates = []
         for _ in range(3):   # a fresh process sometimes stalls for seconds in its first device allocations (seen as 2.5 s in one of
                              # four runs, tools/gpu_cli_loop.sh), and the 2 GB output goes to the box's scratch disk: best of three runs
+            _settle()
             t0 = time.perf_counter()
             p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, corpus],
                                capture_output=True, text=True)
@@ -779,6 +790,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
             seconds in its first device allocations / on the scratch disk, see above)"""
             top, kvt, rates = None, None, []
             for _ in range(reps):
+                _settle()
                 p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, corpus] + flags,
                                    capture_output=True, text=True)
                 if p.returncode != 0:
@@ -829,6 +841,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                 os.rename(big + '.tmp', big)
             ss = None
             for _ in range(2):
+                _settle()
                 p = subprocess.run([cli, '--model=' + model, '--batch=%d' % args.batch, '--timing', '-o', out_path, big], capture_output=True, text=True)
                 if p.returncode != 0:
                     break
@@ -871,9 +884,10 @@ def config5_cli_lattice(args, cache, ge, np):
         flags = ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '32']
         best, rates = None, []
         for _ in range(2):
+            # (no --batch: for lattice output the CLI sizes its batches itself -- a batch's text near 100 MB, 2 048
+            # sentences here; with the host printer: the gathered N best paths below 1 GB, 3 072 sentences)
+            _settle()
             t0 = time.perf_counter()
-            # (no --batch: for lattice output the CLI sizes its batches so that the gathered N best paths stay below 1 GB,
-            # 3 072 sentences here; with --batch=16384 the same command runs at 17-21 k sentences/s, profiles/r05_t_*)
             p = subprocess.run([cli, '--model=' + model, '--timing', '-o', out_path] + flags + [corpus],
                                capture_output=True, text=True)
             wall = time.perf_counter() - t0
@@ -904,6 +918,7 @@ def config5_cli_lattice(args, cache, ge, np):
                               'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)},
                'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')}}
         if device_text:   # the round-5 form of the same command: N best paths gathered on the device, text printed by the host workers
+            _settle()
             ph = subprocess.run([cli, '--model=' + model, '--timing', '--host-format', '-o', out_path + '.host'] + flags + [corpus],
                                 capture_output=True, text=True)
             if ph.returncode == 0:
@@ -918,6 +933,7 @@ def config5_cli_lattice(args, cache, ge, np):
                 os.remove(out_path + '.host')
             # the device-text run again with the output in four files: this leg writes 48 KB per sentence and sits on the
             # one-file write ceiling of the host (see cli_end_to_end.output_shards_4)
+            _settle()
             ps = subprocess.run([cli, '--model=' + model, '--timing', '--output-shards=4', '-o', out_path + '.sh'] + flags + [corpus],
                                 capture_output=True, text=True)
             if ps.returncode == 0:

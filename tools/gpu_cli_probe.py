@@ -60,7 +60,24 @@ def main():
                     kv[k] = int(v.split()[0]) // 1024
             return ' '.join('%s=%dM' % (k, kv.get(k, -1)) for k in want)
 
+        def cg(name):
+            try:
+                return open('/sys/fs/cgroup/' + name).read().strip().replace('\n', ' ')
+            except OSError:
+                return '?'
+
+        def cgstat():
+            cs = dict(x.split() for x in cg('cpu.stat').split('  ')) if False else {}
+            raw = cg('cpu.stat').split()
+            cs = dict(zip(raw[0::2], raw[1::2])) if len(raw) % 2 == 0 else {}
+            ev = cg('memory.events').split()
+            me = dict(zip(ev[0::2], ev[1::2])) if len(ev) % 2 == 0 else {}
+            return {'throttled_usec': int(cs.get('throttled_usec', 0)), 'nr_throttled': int(cs.get('nr_throttled', 0)),
+                    'mem_high': int(me.get('high', 0)), 'mem_max': int(me.get('max', 0)), 'mem_current_M': int(cg('memory.current') or 0) >> 20 if cg('memory.current').isdigit() else -1}
+        print('cgroup: cpu.max=%s memory.max=%s memory.high=%s cpuset=%s' % (cg('cpu.max'), cg('memory.max'), cg('memory.high'), cg('cpuset.cpus.effective')[:60]), flush=True)
+
         def run2(tag, flags=(), env=None):
+            before = cgstat()
             print('-- %s | %s' % (tag, meminfo()), flush=True)
             e = dict(os.environ)
             e.update(env or {})
@@ -71,20 +88,24 @@ def main():
             keep = [ln for ln in p.stderr.strip().splitlines() if ln.startswith(('startup:', 'reserve:', 'devices=', 'batches:', 'exit:', 'prepin:'))]
             for ln in keep:
                 print('   ' + ln[:260])
-            print('   process wall %.2f s' % wall, flush=True)
+            after = cgstat()
+            print('   process wall %.2f s | cgroup: cpu throttled %+d ms in %+d periods, memory.events high %+d max %+d, memory.current %d M' % (
+                wall, (after['throttled_usec'] - before['throttled_usec']) // 1000, after['nr_throttled'] - before['nr_throttled'],
+                after['mem_high'] - before['mem_high'], after['mem_max'] - before['mem_max'], after['mem_current_M']), flush=True)
             for f in [out] + [out + '.part%04d' % k for k in range(8)]:
                 if os.path.exists(f):
                     os.remove(f)
-        for i in range(6):
+        # r06_r: no CPU throttling, no memory events, and the ~4 s land anywhere -- inside the pipeline (a slow run) or in
+        # the start-up / exit of a run whose pipeline was normal (process wall 5 s).  Suspect: the process BEFORE, which
+        # leaves without tearing its device state down (--clean-exit restores the destructors)
+        mode = [a for a in sys.argv[1:] if a != 'spread']
+        for i in range(10):
             run2('default %d' % i)
-        for i in range(3):
-            run2('emit passes one after the other %d' % i, env={'JPPGPU_DEV_FRONT_SERIAL': '1'})
-        for i in range(3):
-            run2('--pipelines-per-device=1 %d' % i, flags=['--pipelines-per-device=1'])
-        for i in range(3):
-            run2('--host-format %d' % i, flags=['--host-format'])
-        for i in range(3):
-            run2('default again %d' % i)
+        for i in range(10):
+            run2('--clean-exit %d' % i, flags=['--clean-exit'])
+        for i in range(6):
+            time.sleep(3.0)
+            run2('default after a 3 s pause %d' % i)
         return
     if 'parent' not in sys.argv[1:]:
         print(sh('lscpu | grep -i "numa\\|socket\\|^CPU(s)"'))
