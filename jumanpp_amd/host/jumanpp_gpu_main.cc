@@ -931,12 +931,9 @@ int main(int argc, const char** argv) {
     // format table.  Up to round 4 the buffers grew inside the first batches (hipMalloc / hipHostMalloc stalls of
     // 0.2-0.9 s in batches 0-2, profiles/r04_t_cli_stages.txt) and every batch waited three times for the totals that
     // size them; now a batch is one enqueue and allocates nothing.  (--no-reserve: the round-4 behaviour.)
-    // The page-locked text blocks must be pinned BEFORE the first batch: page-locking holds a lock of the runtime that
-    // kernel launches need, and a process whose start-up was quick (image cache hit: analyzers ready in 0.5 s) reached
-    // its pipeline while the blocks were still being pinned -- every batch of the run then spent seconds waiting to be
-    // enqueued (a session of round 6: 8 of 11 device-text runs at 0.5 M sentences/s, 2 s of "analyze" and five times
-    // the GPU time per batch, the one run with a cache MISS in front of them at 3.5 M; profiles/r06_n_bench.json).  The
-    // wait, if any, belongs to the start-up like the reservation below.
+    // The page-locked text blocks are pinned on a thread of their own since process start; normally they are ready long
+    // before this point (`prepin: waited_ms=0.00x`).  If a box pins slowly, the wait belongs to the start-up like the
+    // reservation below, not to the first batches (page-locking and kernel launches share locks of the runtime).
     if (prepin.t.joinable()) {
       const double p0 = clock.ms();
       prepin.t.join();
