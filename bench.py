@@ -886,6 +886,11 @@ def config5_cli_lattice(args, cache, ge, np):
         for _ in range(2):
             # (no --batch: for lattice output the CLI sizes its batches itself -- a batch's text near 100 MB, 2 048
             # sentences here; with the host printer: the gathered N best paths below 1 GB, 3 072 sentences)
+            if os.path.exists(out_path):
+                # a NEW file every run, like the other leg: the second of two runs into the same path ran at half the
+                # rate in every session of round 6 (135 k / 61 k) -- truncating 1.6 GB of dirty pages and rewriting the
+                # file makes ext4 write it out synchronously when it is closed (replace-via-truncate), inside the CLI's clock
+                os.remove(out_path)
             _settle()
             t0 = time.perf_counter()
             p = subprocess.run([cli, '--model=' + model, '--timing', '-o', out_path] + flags + [corpus],
