@@ -877,7 +877,13 @@ int main(int argc, const char** argv) {
       const bool timing = conf.timing;
       cacheWriter.t = std::thread([=]() {
         const bool ok = DerivedCache::store(modelPath, memo, memoBytes, memoSlots, tbl, entries, lat, latEntries);
-        if (timing) std::cerr << (std::string("image cache ") + (ok ? "written" : "not written") + " for " + modelPath + "\n");   // (one write: other threads print too)
+        if (timing) {
+          // (write(2), not std::cerr: the main thread prints through the unsynchronised stream object at the same time,
+          // and once in a few hundred runs this line was lost)
+          const std::string line = std::string("image cache ") + (ok ? "written" : "not written") + " for " + modelPath + "\n";
+          const ssize_t w = ::write(2, line.data(), line.size());
+          (void)w;
+        }
       });
     }
   }
