@@ -20,7 +20,7 @@ mdic, model, img = bench.make_workload(args, cache)
 corpus = bench.make_corpus(args, mdic, cache, 65536, 31)
 cli = ge.build_host()
 out = os.path.join(cache, 'probe_out.txt')
-flags = ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '32']
+flags = ['--beam=32', '--global-beam=32', '--right-beam=32', '-s', '32'] + os.environ.get('PROBE_FLAGS', '').split()   # (e.g. PROBE_FLAGS='--no-pipeline --pipelines-per-device=1': the kernels one after the other)
 argv = [x for x in sys.argv[1:] if not x.startswith('--')]
 trace = '--trace' in sys.argv[1:]
 for batch in [int(x) for x in (argv or ['16384', '8192', '4096'])]:
