@@ -608,7 +608,7 @@ typedef struct {
 } jppgpu_lattice_table;
 
 int jppgpu_ctx_set_lattice_table(jppgpu_ctx* ctx, const jppgpu_lattice_table* table);
-/* jppgpu_text_view (which older callers of jppgpu_result_format_top1 hold at its old size) plus one array */
+/* the fields of jppgpu_text_view -- which callers of jppgpu_result_format_top1 hold at its old size -- plus one array */
 typedef struct {
   uint32_t n_sentences;
   const uint64_t* offsets;   /* [n + 1] */
