@@ -13,6 +13,7 @@
 #   variants       A/B of prebuilt build/libjppgpu_*.so (JPPGPU_LIB)             -> <TAG>_variants.txt
 #   cfg5           the configs[4]-shape leg alone                                -> <TAG>_config5.json
 #   trace5         rocprofv3 --kernel-trace of tools/gpu_config5_trace.py          -> <TAG>_config5_rocprof_summary.txt
+#   traffic5       FETCH_SIZE / WRITE_SIZE passes of the same (configs[4] shape)   -> <TAG>_config5_traffic.txt
 #   cli            the CLI end-to-end leg alone                                  -> <TAG>_cli.json
 #   run=SCRIPT     any other helper under tools/ (python or bash), stdout        -> <TAG>_<script>.txt
 # environment: BENCH_ARGS (extra bench.py arguments for quick/trace/traffic/valu/variants), STEPS (default 8)
@@ -58,6 +59,32 @@ for step in "$@"; do
       python "$REPO/tools/summarize_prof.py" "$OUT" > "$OUT/${TAG}_config5_rocprof_summary.txt" 2>&1
       head -24 "$OUT/${TAG}_config5_rocprof_summary.txt"; tail -1 "$OUT/${TAG}_trace5.log"
       rm -rf "$OUT/prof_trace" ;;
+    traffic5)
+      # FETCH_SIZE / WRITE_SIZE of the configs[4] shape (tools/gpu_config5_trace.py), separate passes -> <TAG>_config5_traffic.txt
+      cd /tmp; rm -rf "$OUT/prof_fetch" "$OUT/prof_write" "$OUT/prof_trace"
+      timeout 500 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_fetch" -o fetch -- python "$REPO/tools/gpu_config5_trace.py" > "$OUT/prof_fetch.log" 2>&1
+      timeout 500 rocprofv3 --pmc WRITE_SIZE -d "$OUT/prof_write" -o write -- python "$REPO/tools/gpu_config5_trace.py" > "$OUT/prof_write.log" 2>&1
+      python - "$OUT" > "$OUT/${TAG}_config5_traffic.txt" 2>&1 <<'PY'
+import glob, os, sqlite3, sys
+out = sys.argv[1]
+per = {}
+for sub, key in (('prof_fetch', 'FETCH_SIZE'), ('prof_write', 'WRITE_SIZE')):
+    for db in glob.glob(os.path.join(out, sub, '**', '*.db'), recursive=True):
+        con = sqlite3.connect(db)
+        for kn, n, v, d in con.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection where counter_name = ? group by kernel_name", (key,)):
+            per.setdefault(kn, {})[key] = (n, v, d / 1e3)
+print('== configs[4] shape (16 384 x 220 codepoints, beam 32, RNN): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; per launch')
+print('   bytes = 2 x FETCH_SIZE KB (gfx950 tallies a 128-byte request at 64 B) + WRITE_SIZE KB')
+rows = []
+for kn, v in per.items():
+    f = v.get('FETCH_SIZE', (0, 0.0, 0.0)); w = v.get('WRITE_SIZE', (0, 0.0, 0.0))
+    rows.append((2 * f[1] * 1024 + w[1] * 1024, kn, f, w))
+for b, kn, f, w in sorted(rows, reverse=True)[:14]:
+    dur = f[2] or w[2]
+    print('  %-72s %8.2f GB  (fetch %8.2f GB x2, write %7.2f GB)  %9.1f us  %5.2f TB/s' % (kn[:72], b / 1e9, f[1] * 1024 / 1e9, w[1] * 1024 / 1e9, dur, b / 1e12 / (dur * 1e-6) if dur else 0))
+PY
+      cat "$OUT/${TAG}_config5_traffic.txt"
+      rm -rf "$OUT/prof_fetch" "$OUT/prof_write" ;;
     traffic)
       cd /tmp; rm -rf "$OUT/prof_fetch" "$OUT/prof_write"
       timeout 500 rocprofv3 --pmc FETCH_SIZE -d "$OUT/prof_fetch" -o fetch -- python "$REPO/bench.py" --steps 2 --warmup 1 $LEAN --no-parity $BA > "$OUT/prof_fetch.log" 2>&1
