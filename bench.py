@@ -778,6 +778,7 @@ def cli_end_to_end(args, model, corpus, n_lines, ge):
                  'sentences_per_s_incl_model_load': round(n_lines / wall, 1),
                  'batches': {k: int(kv.get(k, -1)) for k in ('one_enqueue', 'rerun', 'sized', 'device_allocations')},
                  'reserve_ms': round(kv.get('reserve_ms', 0.0), 1),
+                 'format_kernels_ms': {'count': round(kv.get('format_count_gpu_ms', 0.0), 1), 'write': round(kv.get('format_write_gpu_ms', 0.0), 1)},
                  'process_ms': {'first_analyzers_ready': round(kv.get('first_analyzers_ready_ms', 0.0), 1),
                                 'waited_for_page_locking': round(kv.get('waited_ms', 0.0), 1),
                                 'before_teardown': round(kv.get('process_ms_before_teardown', 0.0), 1)}}
@@ -913,6 +914,10 @@ def config5_cli_lattice(args, cache, ge, np):
                           'the 32 best paths are gathered on the device (k_nbest), the lattice text is printed by the host format workers',
                           int(kv.get('batch_lines', 0))),
                'device_text': device_text,
+               'format_kernels': {'count_ms': round(kv.get('format_count_gpu_ms', 0.0), 1), 'write_ms': round(kv.get('format_write_gpu_ms', 0.0), 1),
+                                  'text_GB_per_s_of_the_write_pass': round(size / 1e9 / (kv.get('format_write_gpu_ms', 0.0) / 1e3), 1) if kv.get('format_write_gpu_ms', 0.0) > 0 else None,
+                                  'what': 'HIP events around k_lat_count (+ offset scan) and k_lat_write, summed over the batches of the '
+                                          'run (the two pipelines of the GPU overlap: a kernel of one waits for the other\'s sweep)'},
                'value': round(rate, 1), 'unit': 'sentences/s', 'runs': rates, 'pipeline_wall_ms': round(kv.get('wall_ms', 0.0), 1),
                'gpu_busy_ms': round(kv.get('gpu_ms', 0.0), 1),
                'stage_busy_ms': {k: round(kv.get(k + '_ms', 0.0), 1) for k in ('read', 'analyze', 'format', 'write')},

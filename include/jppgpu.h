@@ -660,7 +660,8 @@ void jppgpu_result_release(jppgpu_result* res);
  * sentence class (every sentence runs the kernel variant of its own widest boundary): [8] [9] [10] ms of the variants
  * for at most 64 / at most 512 / any number of nodes starting at one boundary, [11] [12] [13] sentences in each class,
  * [14] rows of the RNN hidden-state table of the batch (rnn nodes + 2 per sentence; 0 without the RNN), [15] ms of
- * k_rnn_chain alone (0 when it did not run) */
+ * k_rnn_chain alone (0 when it did not run); of the context's last jppgpu_result_format_top1 / _lattice call: [16] ms of
+ * the count pass + offset scan, [17] ms of the write pass, [18] MB of text */
 int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n);
 
 #ifdef __cplusplus

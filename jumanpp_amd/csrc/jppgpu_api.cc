@@ -93,6 +93,12 @@ struct Timer {
     for (int i = 0; i < 12; ++i) ms[i] = 0;
   }
 };
+struct FmtTimer {
+  void init() {}
+  void destroy() {}
+  void mark(int, jpp_stream_t) {}
+  void collect(float* ms) { ms[0] = ms[1] = 0.f; }
+};
 #else
 void* rt_malloc(size_t n) {
   void* p = nullptr;
@@ -248,6 +254,30 @@ struct Timer {
     }
     ms[11] = 0;
     if (chain) (void)hipEventElapsedTime(&ms[11], ev[13], ev[14]);
+  }
+};
+// the format kernels of a result (jppgpu_result_format_top1 / _lattice): ev[0] .. ev[1] count pass + offset scan (the
+// host then reads the byte total), ev[2] .. ev[3] write pass
+struct FmtTimer {
+  hipEvent_t ev[4];
+  bool have = false;
+  void init() {
+    for (auto& e : ev) (void)hipEventCreate(&e);
+    have = true;
+  }
+  void destroy() {
+    if (have)
+      for (auto& e : ev) (void)hipEventDestroy(e);
+    have = false;
+  }
+  void mark(int i, jpp_stream_t s) {
+    if (have) (void)hipEventRecord(ev[i], s);
+  }
+  void collect(float* ms) {   // (after the stream was synchronised)
+    ms[0] = ms[1] = 0.f;
+    if (!have) return;
+    (void)hipEventElapsedTime(&ms[0], ev[0], ev[1]);
+    (void)hipEventElapsedTime(&ms[1], ev[2], ev[3]);
   }
 };
 #endif
@@ -520,6 +550,9 @@ struct jppgpu_ctx {
   Timer timer;
   SyncPoint rnn_sync;
   float last_ms[12] = {0};   // [11] = k_rnn_chain
+  FmtTimer fmt_timer;
+  float last_fmt_ms[2] = {0.f, 0.f};   // count + scan / write pass of the last jppgpu_result_format_* call
+  u64 last_fmt_bytes = 0;
   u64 last_rnn_rows = 0;     // hidden-state rows of the last batch (rnn nodes + 2 per sentence)
   jpp_stream_t last_stream = nullptr;
   jpp_stream_t own_stream = nullptr;  // used by the host-buffer entry points
@@ -974,6 +1007,7 @@ void finish_context(jppgpu_ctx* ctx) {
   ctx->sweep_join.init();
   ctx->front_fork.init();
   ctx->front_join.init();
+  ctx->fmt_timer.init();
   ctx->timer.init();
   ctx->rnn_sync.init();
   void* dev = nullptr;
@@ -1331,6 +1365,7 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
   ctx->sweep_join.destroy();
   ctx->front_fork.destroy();
   ctx->front_join.destroy();
+  ctx->fmt_timer.destroy();
   rt_mailbox_free((void*)ctx->mail_host);
   ctx->host_pool->clear();
   ctx->text_pool->clear();
@@ -2354,6 +2389,9 @@ extern "C" int jppgpu_last_timings(jppgpu_ctx* ctx, float* ms, int n) {
   for (int i = 11; i < n && i < 14; ++i) ms[i] = (float)ctx->last_class_n[i - 11];
   if (n > 14) ms[14] = (float)ctx->last_rnn_rows;
   if (n > 15) ms[15] = ctx->last_ms[11];
+  if (n > 16) ms[16] = ctx->last_fmt_ms[0];
+  if (n > 17) ms[17] = ctx->last_fmt_ms[1];
+  if (n > 18) ms[18] = (float)((double)ctx->last_fmt_bytes / 1.0e6);
   return JPPGPU_OK;
 }
 
@@ -2481,18 +2519,24 @@ extern "C" int jppgpu_result_format_top1(jppgpu_result* res, jppgpu_text_view* v
     if (!(ctx->fmt_len.ensure((B.total_nodes + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) && ctx->fmt_st.ensure(((size_t)n + 1) * 4)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format)");
     const FmtTable* T = ctx->mb->fmt_table.as<FmtTable>();
+    ctx->fmt_timer.mark(0, st);
     if (n) JPP_LAUNCH(k_fmt_count, (n + 3) / 4, 256, st, B, T, ctx->fmt_len.as<u32>(), ctx->fmt_cnt.as<u32>(), ctx->fmt_st.as<i32>());
     launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
+    ctx->fmt_timer.mark(1, st);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
     rt_sync(st);   // the byte total sizes the text buffers
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format offsets)");
     const u64 total = res->fm_off.data()[n];
     if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
+    ctx->fmt_timer.mark(2, st);
     if (n) JPP_LAUNCH(k_fmt_write, (n + 3) / 4, 256, st, B, T, (const u32*)ctx->fmt_len.as<u32>(), (const u64*)ctx->fmt_off.as<u64>(),
                       ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
+    ctx->fmt_timer.mark(3, st);
     ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
     ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);   // (the text's own status: a sentence the table cannot render answers ST_CAPACITY)
     rt_sync(st);
+    ctx->fmt_timer.collect(ctx->last_fmt_ms);
+    ctx->last_fmt_bytes = total;
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format text)");
     res->fm_have = true;
     res->fm_kind = 1;
@@ -2598,19 +2642,25 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice format)");
     const LatTable* T = ctx->mb->lat_table.as<LatTable>();
     const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_used.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<u32>(), ctx->lat_marked.as<u32>()};
+    ctx->fmt_timer.mark(0, st);
     if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_len.as<u32>(), ctx->fmt_st.as<i32>());
     launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
+    ctx->fmt_timer.mark(1, st);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
     rt_sync(st);   // the byte total sizes the text buffers
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format offsets)");
     const u64 total = res->fm_off.data()[n];
     if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
+    ctx->fmt_timer.mark(2, st);
     if (n) JPP_LAUNCH(k_lat_write, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, (const u64*)ctx->fmt_off.as<u64>(), (const u32*)ctx->lat_head.as<u32>(),
                       (const u32*)ctx->fmt_len.as<u32>(), ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
+    ctx->fmt_timer.mark(3, st);
     ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
     ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);
     ok &= pull(res->fm_head, ctx->lat_head.p, n, st);
     rt_sync(st);
+    ctx->fmt_timer.collect(ctx->last_fmt_ms);
+    ctx->last_fmt_bytes = total;
     if (!ok) return fail(JPPGPU_OUT_OF_MEMORY, "host allocation failed (format text)");
     res->fm_have = true;
     res->fm_kind = 2;

@@ -424,6 +424,13 @@ Status GpuAnalyzer::fetchText() {
   if (hostTiming)
     std::fprintf(stderr, "fetchText n=%u bytes=%llu total=%.2f ms\n", text_.n_sentences, (unsigned long long)text_.offsets[text_.n_sentences],
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  {
+    float ms[19] = {0};
+    if (jppgpu_last_timings(ctx_, ms, 19) == JPPGPU_OK) {
+      lastFormatMs_[0] = ms[16];
+      lastFormatMs_[1] = ms[17];
+    }
+  }
   G.view.n_sentences = text_.n_sentences;
   G.view.status = text_.status;
   textFetched_ = true;

@@ -198,6 +198,7 @@ class GpuAnalyzer {
   bool keepMemoImage_ = false;
   jppgpu_text_view text_{};
   const uint32_t* textHeads_ = nullptr;   // lattice text mode: header bytes per sentence
+  float lastFormatMs_[2] = {0.f, 0.f};    // device time of the last fetchText(): count pass + scan, write pass
   std::vector<Group> groups_;
   std::vector<uint32_t> groupOf_, localIdx_;  // sentence -> (group, index inside the group's batch)
   AnalyzerConfig cfg_;
@@ -269,6 +270,11 @@ class GpuAnalyzer {
   // device's other analyzer)
   void setDeferredText(bool on) { deferText_ = on; }
   Status fetchText();
+  // device time of the format kernels of the last fetchText(): [0] count pass + offset scan, [1] write pass (ms)
+  void lastFormatTimings(float ms[2]) const {
+    ms[0] = lastFormatMs_[0];
+    ms[1] = lastFormatMs_[1];
+  }
   // hands the batch's text (and the result that owns it) to the caller; sentenceStatus / sentenceText are gone with it
   TextBatch takeText();
   StringPiece sentenceText(size_t i) const {

@@ -1043,7 +1043,7 @@ int main(int argc, const char** argv) {
       writeQ.emplace_back(new BoundedQueue<std::unique_ptr<ShardJob>>(2));
       freeAnalyzers.emplace_back(new Semaphore(nAnalyzers));
     }
-    std::atomic<long long> scanUs(0), prepUs(0), formatUs(0), writeUs(0), gpuUs(0);
+    std::atomic<long long> scanUs(0), prepUs(0), formatUs(0), writeUs(0), gpuUs(0), fmtCountUs(0), fmtWriteUs(0);
     std::vector<double> analyzeMsDev((size_t)nDev, 0.0);
     auto us = [&]() { return (long long)(clock.ms() * 1000.0); };
     // The second analyzer of a device (a second copy of the model and its per-entry tables in HBM: ~0.15 s) is made on
@@ -1193,6 +1193,12 @@ int main(int argc, const char** argv) {
             // one run per stretch of sentences without a comment line, a failed read or an error message
             GpuAnalyzer& an = *analyzers[d][job->analyzer];
             Status fs = an.fetchText();
+            {
+              float fm[2];
+              an.lastFormatTimings(fm);
+              fmtCountUs += (long long)(fm[0] * 1000.0);
+              fmtWriteUs += (long long)(fm[1] * 1000.0);
+            }
             job->errors.assign(1, std::string());
             std::string& errors = job->errors[0];
             job->outBytes = 0;
@@ -1394,7 +1400,8 @@ int main(int argc, const char** argv) {
       for (double v : analyzeMsDev) analyzeMs = std::max(analyzeMs, v);
       std::cerr << "devices=" << nDev << " sentences=" << sentences << " gpu_ms=" << gpuUs / 1000.0 << " wall_ms=" << wall
                 << " read_ms=" << (scanUs + prepUs) / 1000.0 << " analyze_ms=" << analyzeMs << " format_ms=" << formatUs / 1000.0
-                << " write_ms=" << writeUs / 1000.0 << " threads=" << conf.threads << " pipeline=1 sharded=1 sent_per_s="
+                << " write_ms=" << writeUs / 1000.0 << " format_count_gpu_ms=" << fmtCountUs / 1000.0 << " format_write_gpu_ms=" << fmtWriteUs / 1000.0
+                << " threads=" << conf.threads << " pipeline=1 sharded=1 sent_per_s="
                 << (wall > 0 ? sentences / (wall / 1000.0) : 0.0) << "\n";
       uint64_t tot[4] = {0, 0, 0, 0};
       for (auto& v : analyzers)
