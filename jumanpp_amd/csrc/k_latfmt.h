@@ -258,20 +258,45 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
   return true;
 }
 
-// "# MA-SCORE\t" "rank" i ":" total " " ... "\n" (one lane)
+// "# MA-SCORE\t" "rank" i ":" total " " ... "\n": lane i prints rank i + 1 at the offset a wave scan gives it (one
+// lane printing all of them -- 32 "%g" conversions in a row on one lane of 64 -- was a third of both kernels).  All lanes
+// call; returns the bytes of the line.
 template <bool WRITE, typename P>
-__device__ __forceinline__ void lat_header(LatOut<WRITE, P>& w, const LatTable& T, const BeamSlot* eos, int beam, int n_best) {
-  w.lit(T.head_text, T.head_len);
-  for (int i = 0; i < n_best && i < beam; ++i) {
-    const BeamSlot el = eos[i];
-    if (el.left == kFake16 && el.beam == kFake16) break;
-    w.lit(T.rank_text, T.rank_len);
-    w.num((u32)i + 1);
-    w.ch(':');
-    w.flt(g_digits(el.total));
-    w.ch(' ');
+__device__ __forceinline__ u32 lat_header(P base, const LatTable& T, const BeamSlot* eos, int beam, int n_best, u32 lane) {
+  const int maxN = n_best < beam ? n_best : beam;
+  BeamSlot el{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+  if ((int)lane < maxN) el = eos[lane];
+  const u64 fakes = wave_ballot(el.left == kFake16 && el.beam == kFake16);
+  const u32 npaths = fakes ? (u32)__builtin_ctzll(fakes) : 64u;
+  const bool mine = lane < npaths;
+  const GDigits g = g_digits(mine ? el.total : 0.f);
+  LatOut<false> c{nullptr, 0};
+  if (mine) {
+    c.n = T.rank_len;
+    c.num(lane + 1);
+    c.ch(':');
+    c.flt(g);
+    c.ch(' ');
   }
-  w.ch('\n');
+  const u32 bytes = (u32)c.n;
+  const u32 incl = wave_scan_incl_u32(bytes, (int)lane);
+  const u32 total = (u32)T.head_len + wave_bcast_u32(incl, 63) + 1u;
+  if (WRITE) {
+    if (lane == 0) {
+      LatOut<true, P> h{base, 0};
+      h.lit(T.head_text, T.head_len);
+      base[total - 1] = (u8)'\n';
+    }
+    if (mine) {
+      LatOut<true, P> w{base + T.head_len + (incl - bytes), 0};
+      w.lit(T.rank_text, T.rank_len);
+      w.num(lane + 1);
+      w.ch(':');
+      w.flt(g);
+      w.ch(' ');
+    }
+  }
+  return total;
 }
 
 // the table's literals, copied to LDS once per workgroup (its pointers keep pointing into HBM)
@@ -412,12 +437,11 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
   }
   sum = wave_sum_u64(sum);
   const bool allOk = wave_ballot(!ok) == 0;
+  const u32 hn = lat_header<false>((u8*)nullptr, T, beams + (u64)(N - 1) * beam, beam, n_best, lane);
   if (lane == 0) {
-    LatOut<false> h{nullptr, 0};
-    lat_header(h, T, beams + (u64)(N - 1) * beam, beam, n_best);
     fmt_status[s] = allOk ? ST_OK : ST_CAPACITY;   // (a node the table cannot render: the text answers like a failed sentence)
-    sent_bytes[s] = allOk ? (u32)(h.n + sum + T.eos_len) : T.error_len;
-    head_bytes[s] = allOk ? (u32)h.n : 0;
+    sent_bytes[s] = allOk ? (u32)(hn + sum + T.eos_len) : T.error_len;
+    head_bytes[s] = allOk ? hn : 0;
     S.marked[s] = M;
   }
 }
@@ -477,14 +501,10 @@ __global__ void __launch_bounds__(256) k_lat_write(Batch B, Config cfg, const La
     const u32 hb = head_bytes[s];
     const u32 b0 = (u32)o & 3u;
     if (hb <= kLatWin) {
-      if (lane == 0) {
-        LatOut<true, LP> h{win + b0, 0};
-        lat_header(h, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best);
-      }
+      (void)lat_header<true>(win + b0, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best, lane);
       lat_flush(out, o, win, b0, hb, lane);
-    } else if (lane == 0) {
-      LatOut<true> h{out + o, 0};
-      lat_header(h, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best);
+    } else {
+      (void)lat_header<true>(out + o, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best, lane);
     }
     o += hb;
   }

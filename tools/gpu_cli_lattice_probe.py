@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,10 +26,13 @@ argv = [x for x in sys.argv[1:] if not x.startswith('--')]
 trace = '--trace' in sys.argv[1:]
 for batch in [int(x) for x in (argv or ['16384', '8192', '4096'])]:
   for rep in range(2):
+    time.sleep(3.0)   # (a process started right behind another one's exit runs with gaps between its launches: DESIGN section 8)
     p = subprocess.run([cli, '--model=' + model, '--batch=%d' % batch, '--timing', '-o', out] + flags + [corpus],
                        capture_output=True, text=True)
     kv = bench._timing_kv(p.stderr)
     print('device_text=%d ' % int('device_lattice_format=1' in p.stderr), end='')
+    if os.environ.get('PROBE_VERBOSE'):
+        print('\n'.join(ln[:240] for ln in p.stderr.strip().splitlines() if ln.startswith(('batches:', 'reserve:', 'startup:', 'devices='))))
     print('batch %6d: %8.0f sentences/s  wall %7.1f ms  gpu %7.1f  analyze %7.1f  format %7.1f  write %7.1f  reserve %7.1f  rc %d' % (
         batch, kv.get('sent_per_s', 0), kv.get('wall_ms', 0), kv.get('gpu_ms', 0), kv.get('analyze_ms', 0), kv.get('format_ms', 0),
         kv.get('write_ms', 0), kv.get('reserve_ms', 0), p.returncode))
