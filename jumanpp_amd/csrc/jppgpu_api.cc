@@ -562,7 +562,7 @@ struct jppgpu_ctx {
   std::shared_ptr<HostPool> text_pool = std::make_shared<HostPool>();   // page-locked blocks (constructor sets the flag)
   // output text on the device (jppgpu_ctx_set_format_table): the table in HBM and the per-batch buffers
   DevBuf fmt_len, fmt_cnt, fmt_off, fmt_text, fmt_st;
-  DevBuf lat_mask, lat_used, lat_best, lat_id, lat_list, lat_marked, lat_head;   // k_latfmt.h: per-node sets of the N best paths, header bytes per sentence
+  DevBuf lat_mask, lat_best, lat_id, lat_list, lat_marked, lat_head;   // k_latfmt.h: per-node sets of the N best paths, header bytes per sentence
   bool timing_pending = false;
   // one enqueue per batch (k_lattice.h: k_cap_guard): grids of the rare sweep classes and the scratch geometry the next
   // batch is launched with before its totals are known; statistics for the bench / tests
@@ -1356,7 +1356,8 @@ extern "C" void jppgpu_ctx_destroy(jppgpu_ctx* ctx) {
                     &ctx->gstats,     &ctx->bnd_meta,  &ctx->sweep_scratch, &ctx->sent_maxr, &ctx->sweep_list,  &ctx->pc_nb_off,  &ctx->pc_nb,     &ctx->pc_b_off,
                     &ctx->pc_b,       &ctx->pc_node_off, &ctx->pc_nodes, &ctx->pc_tags,   &ctx->node_penalty,
                     &ctx->node_info2, &ctx->node_aux2, &ctx->gold_off, &ctx->gold, &ctx->gold_base, &ctx->full_scratch, &ctx->full_locks, &ctx->norm_scratch, &ctx->norm_locks,
-                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text, &ctx->fmt_st, &ctx->scan_ws};
+                    &ctx->adj_stack, &ctx->pair_penalty, &ctx->pair_base, &ctx->fmt_len, &ctx->fmt_cnt, &ctx->fmt_off, &ctx->fmt_text, &ctx->fmt_st, &ctx->scan_ws,
+                    &ctx->lat_mask, &ctx->lat_best, &ctx->lat_id, &ctx->lat_list, &ctx->lat_marked, &ctx->lat_head};
   for (auto* b : bufs) b->release();
   ctx->mb.reset();   // (the model tables go with their last context)
   rt_stream_destroy(ctx->own_stream);
@@ -1467,6 +1468,10 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
     const u64 tb = (u64)((double)bytes * (double)r->text_bytes_per_byte) + 64 * (u64)n + 64;
     ok = ctx->fmt_len.ensure((nodes + 1) * 4) && ctx->fmt_cnt.ensure((n + 1) * 4) && ctx->fmt_off.ensure((n + 2) * 8) &&
          ctx->fmt_st.ensure((n + 1) * 4) && ctx->fmt_text.ensure(tb + 64);
+    // the lattice formatter's per-node words, when that is the text this context prints
+    if (ok && ctx->mb->lat_have)
+      ok = ctx->lat_mask.ensure((nodes + 1) * 8) && ctx->lat_best.ensure((nodes + 1) * 8) && ctx->lat_id.ensure((nodes + 1) * 4) &&
+           ctx->lat_list.ensure((nodes + 1) * 4) && ctx->lat_marked.ensure((n + 1) * 4) && ctx->lat_head.ensure((n + 1) * 4);
     // page-locked host blocks of the text, as many as the caller keeps in flight (jumanpp_gpu: analysed, being written, next)
     std::vector<HostPool::Block> blocks;
     for (uint32_t k = 0; ok && k < r->text_host_blocks; ++k) {
@@ -2636,12 +2641,12 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
       return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
     jpp_stream_t st = ctx->last_stream;
     const size_t N = (size_t)B.total_nodes + 1;
-    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_used.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) && ctx->lat_list.ensure(N * 4) && ctx->lat_marked.ensure(((size_t)n + 1) * 4) &&
+    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) && ctx->lat_list.ensure(N * 4) && ctx->lat_marked.ensure(((size_t)n + 1) * 4) &&
           ctx->lat_head.ensure(((size_t)n + 1) * 4) && ctx->fmt_len.ensure(N * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) &&
           ctx->fmt_st.ensure(((size_t)n + 1) * 4)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice format)");
     const LatTable* T = ctx->mb->lat_table.as<LatTable>();
-    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_used.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<u32>(), ctx->lat_marked.as<u32>()};
+    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<u32>(), ctx->lat_marked.as<u32>()};
     ctx->fmt_timer.mark(0, st);
     if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_len.as<u32>(), ctx->fmt_st.as<i32>());
     launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);

@@ -72,8 +72,8 @@ struct LatTable {
 
 // per-node scratch of the formatter (HBM, [total_nodes] each)
 struct LatScratch {
-  u64* mask;    // paths (ranks) through the node
-  u64* slots;   // beam slots of the node those paths use
+  u64* mask;    // low half: paths (ranks) through the node; high half: beam slots of the node those paths use (both at
+                // most 32: a path is an EOS beam slot, and the device keeps at most 32 slots per node) -- ONE atomic for both
   u64* best;    // min over those connections of (ordered total << 32 | path << 8 | slot)
   u32* id;      // publishResult's id, 0 = not on a path
   u32* list;    // [node_base + id - 1] = the node with that id (the marked nodes in output order)
@@ -141,7 +141,8 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
   if (unk) na = B.node_aux[gn];
   u32 row = lat_first_row(T, unk ? na.tmpl : ni.eptr);
   if (row == ~0u) return false;
-  const u64 mask = S.mask[gn], slots = S.slots[gn];
+  const u64 both = S.mask[gn];
+  const u64 mask = both & 0xffffffffull, slots = both >> 32;
   const u32 bslot = (u32)(S.best[gn] & 0xffu);
   const BeamSlot* beams = B.node_beam + gn * (u64)beam;
   // the scores of the chosen connection, as "%g" digits (once per node, printed on every row)
@@ -162,6 +163,52 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
         if (text[b0] == T.escape_from[e]) esc = FmtSurface{T.escape_to[e], T.escape_len[e]};
   }
   const u32 fv = !unk ? 0u : T.flag_placeholder == 0 ? na.ph0 : T.flag_placeholder == 1 ? na.ph1 : 0u;
+  // The distinct previous nodes, ascending.  At beam 32 the paths through a node use a dozen or two of its beam slots
+  // (they differ EARLIER in the sentence), but those slots have one to three distinct left nodes: ONE pass over the
+  // slots, four loads in flight, into a sorted set of four (a pass per distinct previous node -- the first form -- made a
+  // few hundred dependent loads per node and the sentences with such nodes the tail of both kernels:
+  // profiles/r06_ah_lattice_counters.txt, 840 of 20 480 wavefront slots busy on average)
+  u32 pv[4] = {~0u, ~0u, ~0u, ~0u};
+  u32 nPrev = 0;
+  bool manyPrev = false;
+  for (u64 sm = slots; sm != 0;) {
+    u32 a[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = ~0u;
+      if (sm != 0) {
+        a[q] = beams[__builtin_ctzll(sm)].prev_node;
+        sm &= sm - 1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const u32 x = a[q];
+      if (x == ~0u || x == pv[0] || x == pv[1] || x == pv[2] || x == pv[3]) continue;
+      if (nPrev == 4) {
+        manyPrev = true;
+        continue;
+      }
+      // insertion into the ascending set (the unused places hold ~0u, the largest value)
+      if (x < pv[0]) {
+        pv[3] = pv[2]; pv[2] = pv[1]; pv[1] = pv[0]; pv[0] = x;
+      } else if (x < pv[1]) {
+        pv[3] = pv[2]; pv[2] = pv[1]; pv[1] = x;
+      } else if (x < pv[2]) {
+        pv[3] = pv[2]; pv[2] = x;
+      } else {
+        pv[3] = x;
+      }
+      ++nPrev;
+    }
+  }
+#if defined(JPP_LAT_FORCE_MANY_PREV)
+  manyPrev = true;   // (test build: every node through the pass-per-previous-node form below)
+#endif
+  u32 pid[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if ((u32)q < nPrev && !manyPrev) pid[q] = S.id[nb + pv[q]];
   for (;; ++row) {
     const LatRow r = T.rows[row];
     // "-\t" id "\t" prevs "\t" start "\t" end "\t"
@@ -169,9 +216,13 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
     w.ch('\t');
     w.num(id);
     w.ch('\t');
-    {
-      // the distinct previous nodes in ascending order: the smallest one above the last printed, again and again (a
-      // node has one or two as a rule; the slots of the set are few)
+    if (!manyPrev) {
+      for (u32 q = 0; q < nPrev; ++q) {
+        if (q) w.ch(';');
+        w.num(pid[q]);
+      }
+    } else {
+      // more than four distinct previous nodes: the smallest one above the last printed, again and again
       i64 last = -1;
       bool first = true;
       for (;;) {
@@ -346,7 +397,6 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
   const int beam = cfg.beam, G = cfg.gbeam, NS = cfg.nscorers;
   for (u32 k = lane; k < N; k += 64) {
     S.mask[nb + k] = 0;
-    S.slots[nb + k] = 0;
     S.best[nb + k] = ~0ull;
     S.id[nb + k] = 0;
   }
@@ -357,7 +407,8 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
   // node are found with a ballot (which IS that node's share of the rank mask), their slot sets and smallest keys are
   // reduced across the wavefront, and one lane sends the three atomics -- a dozen instead of a hundred per step.
   const BeamSlot* beams = B.node_beam + nb * (u64)beam;
-  const int maxN = n_best < beam ? n_best : beam;
+  int maxN = n_best < beam ? n_best : beam;
+  if (maxN > 32) maxN = 32;   // (the device keeps at most 32 slots per node: jppgpu_api.cc device_beam; the packed masks rely on it)
   BeamSlot el{kFake16, kFake16, 0.f, 0xffffffffu, 0};
   if ((int)lane < maxN) el = beams[(u64)(N - 1) * beam + lane];
   const u64 fakes = wave_ballot(el.left == kFake16 && el.beam == kFake16);
@@ -367,13 +418,19 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
     const float w0 = T.weights[0], w1 = T.weights[1];
     bool act = lane < npaths;
     u32 node = el.prev_node, slot = el.beam, steps = 0;
+    const BeamSlot fake{kFake16, kFake16, 0.f, 0xffffffffu, 0};
+    auto live = [&](u32 nd, u32 sl) { return nd >= 2 && nd < N && sl < (u32)beam; };
+    // the slot of the first step; from then on the NEXT step's slot is requested before this step's score cell is waited
+    // for (both hang off the slot just read: one round trip per step instead of two)
+    act = act && live(node, slot);
+    BeamSlot c = act ? beams[(u64)node * beam + slot] : fake;
     for (;;) {
-      act = act && node >= 2 && node < N && slot < (u32)beam && steps++ <= N;
-      BeamSlot c{kFake16, kFake16, 0.f, 0xffffffffu, 0};
-      if (act) c = beams[(u64)node * beam + slot];
-      act = act && !(c.left == kFake16 && c.beam == kFake16);
+      act = act && steps++ <= N && !(c.left == kFake16 && c.beam == kFake16);
       u64 todo = wave_ballot(act);
       if (todo == 0) break;
+      const u32 nnode = c.prev_node, nslot = c.beam;
+      const bool nact = act && live(nnode, nslot);
+      const BeamSlot cn = nact ? beams[(u64)nnode * beam + nslot] : fake;
       u64 key = ~0ull;
       if (act) {
         const float* cell = B.node_cells + ((nb + node) * (u64)G + c.pad) * (u64)NS;
@@ -390,16 +447,15 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
         const u64 used = wave_or_u64(mine ? (1ull << slot) : 0ull);
         const u64 kmin = wave_min_u64(mine ? key : ~0ull);
         if ((int)lane == leader) {
-          atomicOr((unsigned long long*)&S.mask[nb + ln], (unsigned long long)grp);
-          atomicOr((unsigned long long*)&S.slots[nb + ln], (unsigned long long)used);
+          atomicOr((unsigned long long*)&S.mask[nb + ln], (unsigned long long)(grp | (used << 32)));
           atomicMin((unsigned long long*)&S.best[nb + ln], (unsigned long long)kmin);
         }
         todo &= ~grp;
       }
-      if (act) {
-        node = c.prev_node;
-        slot = c.beam;
-      }
+      act = nact;
+      node = nnode;
+      slot = nslot;
+      c = cn;
     }
   }
   __threadfence();
@@ -469,7 +525,9 @@ __device__ __forceinline__ void lat_flush(u8* out, u64 o, const u8 JPP_LDS* buf,
   wave_sync();
 }
 
-__global__ void __launch_bounds__(256) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
+// (three wavefronts per SIMD: left to itself the compiler took 274 vector registers for the inlined line printer -- ONE
+// workgroup per CU, 1.9 ms per 8 192 sentences where one round of wavefronts takes 0.2; the LDS window allows three)
+__global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
                                                    const u64* sent_off, const u32* head_bytes, const u32* node_bytes, u8* out,
                                                    const i32* fmt_status) {
   __shared__ LatTable s_T;

@@ -171,7 +171,8 @@ def test_device_side_lattice_format_window_paths(cli_emu, golden_dir, tmp_path, 
     bytes (one or two lines fit, an alias entry's lines do not) walks those paths (and every alignment of the flush) on ordinary sentences: same bytes as the host class"""
     import shutil
     import __graft_entry__ as ge
-    lib = ge.build_emu_variant('latwin' + win, ['-DJPP_LAT_WIN=' + win])
+    # (the same build sends every node's previous-node list through the form for more than four distinct previous nodes)
+    lib = ge.build_emu_variant('latwin' + win, ['-DJPP_LAT_WIN=' + win, '-DJPP_LAT_FORCE_MANY_PREV'])
     d = tmp_path / 'lib'
     d.mkdir()
     shutil.copy(lib, str(d / 'libjppgpu_emu.so'))   # (found before the binary's RUNPATH)
