@@ -116,6 +116,27 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 }
 
+// Order this wavefront's global stores and atomics before its own later loads (other LANES read what a lane wrote):
+// workgroup scope, which is the waits alone.  __threadfence() is device scope -- `buffer_wbl2 sc1` + `buffer_inv sc1`, a
+// write-back and an invalidate of the XCD's whole L2 per call, paid by every wavefront of the chip that shares it
+// (k_lat_count with three of them per sentence: 8 192 sentences took 7 x the time of 256; k_decode's note).
+__device__ __forceinline__ void wave_fence_global() {
+#if !defined(JPP_EMU)
+  __threadfence_block();
+#endif
+}
+
+// A load served by L2, not by the CU's vector cache: for words this wavefront has just changed with atomics (they
+// execute in L2; a neighbour wavefront of the CU may have left the line in the vector cache)
+template <typename T>
+__device__ __forceinline__ T load_l2(const T* p) {
+#if defined(JPP_EMU) || !defined(__HIP_DEVICE_COMPILE__)
+  return *p;
+#else
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // Asynchronous global -> LDS copy (gfx950 `global_load_lds_dword` / `_dwordx4`): every lane for which
 // `act` holds copies BYTES (4 or 16) from its own global address to lds_base + lane * BYTES without
 // passing through VGPRs.  lds_base must be wave-uniform.  The data is visible after lds_async_wait()

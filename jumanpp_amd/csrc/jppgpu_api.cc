@@ -1471,7 +1471,7 @@ extern "C" int jppgpu_ctx_reserve(jppgpu_ctx* ctx, const jppgpu_reserve* r) {
     // the lattice formatter's per-node words, when that is the text this context prints
     if (ok && ctx->mb->lat_have)
       ok = ctx->lat_mask.ensure((nodes + 1) * 8) && ctx->lat_best.ensure((nodes + 1) * 8) && ctx->lat_id.ensure((nodes + 1) * 4) &&
-           ctx->lat_list.ensure((nodes + 1) * 4) && ctx->lat_marked.ensure((n + 1) * 4) && ctx->lat_head.ensure((n + 1) * 4);
+           ctx->lat_list.ensure((nodes + 1) * sizeof(LatRec)) && ctx->lat_marked.ensure((n + 1) * 4) && ctx->lat_head.ensure((n + 1) * 4);
     // page-locked host blocks of the text, as many as the caller keeps in flight (jumanpp_gpu: analysed, being written, next)
     std::vector<HostPool::Block> blocks;
     for (uint32_t k = 0; ok && k < r->text_host_blocks; ++k) {
@@ -2641,14 +2641,14 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
       return fail(JPPGPU_INVALID_STATE, "result was invalidated by a later jppgpu_analyze_batch on the same context");
     jpp_stream_t st = ctx->last_stream;
     const size_t N = (size_t)B.total_nodes + 1;
-    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) && ctx->lat_list.ensure(N * 4) && ctx->lat_marked.ensure(((size_t)n + 1) * 4) &&
-          ctx->lat_head.ensure(((size_t)n + 1) * 4) && ctx->fmt_len.ensure(N * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) &&
+    if (!(ctx->lat_mask.ensure(N * 8) && ctx->lat_best.ensure(N * 8) && ctx->lat_id.ensure(N * 4) && ctx->lat_list.ensure(N * sizeof(LatRec)) && ctx->lat_marked.ensure(((size_t)n + 1) * 4) &&
+          ctx->lat_head.ensure(((size_t)n + 1) * 4) && ctx->fmt_cnt.ensure(((size_t)n + 1) * 4) && ctx->fmt_off.ensure(((size_t)n + 2) * 8) &&
           ctx->fmt_st.ensure(((size_t)n + 1) * 4)))
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice format)");
     const LatTable* T = ctx->mb->lat_table.as<LatTable>();
-    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<u32>(), ctx->lat_marked.as<u32>()};
+    const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<LatRec>(), ctx->lat_marked.as<u32>()};
     ctx->fmt_timer.mark(0, st);
-    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_len.as<u32>(), ctx->fmt_st.as<i32>());
+    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_st.as<i32>());
     launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
     ctx->fmt_timer.mark(1, st);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
@@ -2658,7 +2658,7 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
     if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
     ctx->fmt_timer.mark(2, st);
     if (n) JPP_LAUNCH(k_lat_write, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, (const u64*)ctx->fmt_off.as<u64>(), (const u32*)ctx->lat_head.as<u32>(),
-                      (const u32*)ctx->fmt_len.as<u32>(), ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
+                      ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
     ctx->fmt_timer.mark(3, st);
     ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
     ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);

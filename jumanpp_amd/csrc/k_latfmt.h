@@ -70,13 +70,30 @@ struct LatTable {
   float weights[2];
 };
 
+// What k_lat_count found out about a marked node, for k_lat_write: both kernels printed from the lattice at first, and
+// each paid some ten random 128-byte lines per node for it (four of its beam slots, two of its score cells, its sets, the
+// ids of its previous nodes) -- 8 GB per 8 192 sentences of 220 codepoints at N = 32 between them.  The record is read
+// in order, 48 bytes a lane.
+struct alignas(16) LatRec {
+  u32 node;
+  u32 row;        // the first row of its entry
+  float f0, f1;   // the weighted scores of the chosen connection
+  u32 pid[4];     // the ids of its previous nodes, ascending
+  u32 ranks;      // the paths through it
+  u32 flags;      // bits 0-2: how many of pid; kLatRecMany: more than four -- k_lat_write derives them again
+  u32 bytes;      // of its lines
+  u32 pad;
+};
+static_assert(sizeof(LatRec) == 48, "three 16-byte loads");
+constexpr u32 kLatRecMany = 8u;
+
 // per-node scratch of the formatter (HBM, [total_nodes] each)
 struct LatScratch {
   u64* mask;    // low half: paths (ranks) through the node; high half: beam slots of the node those paths use (both at
                 // most 32: a path is an EOS beam slot, and the device keeps at most 32 slots per node) -- ONE atomic for both
   u64* best;    // min over those connections of (ordered total << 32 | path << 8 | slot)
   u32* id;      // publishResult's id, 0 = not on a path
-  u32* list;    // [node_base + id - 1] = the node with that id (the marked nodes in output order)
+  LatRec* rec;  // [node_base + id - 1] = the node with that id and what its lines print (the marked nodes in output order)
   u32* marked;  // [sentence] how many
 };
 
@@ -128,41 +145,27 @@ struct LatOut {
   }
 };
 
-// One lattice node of the output: its lines (one per row of its entry), printed by ONE lane.  Returns false when the
-// table has no row for it.  T: the table's copy in LDS (its pointers point into HBM).
-template <bool WRITE, typename P>
-__device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S,
-                                              u64 nb, u32 node, const u8* text, const u16* boff) {
+// What the lines of one lattice node print besides its entry rows (ONE lane; k_lat_count).  Returns false when the table
+// has no row for it.  T: the table's copy in LDS (its pointers point into HBM).
+__device__ __forceinline__ bool lat_node_facts(LatRec& r, const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S, u64 nb,
+                                              u32 node) {
   const int beam = cfg.beam, G = cfg.gbeam, NS = cfg.nscorers;
   const u64 gn = nb + node;
   const NodeInfo ni = B.node_info[gn];
-  const bool unk = ni.eptr < 0;
-  NodeAux na{0, 0, 0, 0, 0, 0};
-  if (unk) na = B.node_aux[gn];
-  u32 row = lat_first_row(T, unk ? na.tmpl : ni.eptr);
+  const u32 row = lat_first_row(T, ni.eptr < 0 ? B.node_aux[gn].tmpl : ni.eptr);
   if (row == ~0u) return false;
-  const u64 both = S.mask[gn];
-  const u64 mask = both & 0xffffffffull, slots = both >> 32;
-  const u32 bslot = (u32)(S.best[gn] & 0xffu);
+  const u64 both = load_l2(&S.mask[gn]);
+  const u64 slots = both >> 32;
+  const u32 bslot = (u32)(load_l2(&S.best[gn]) & 0xffu);
   const BeamSlot* beams = B.node_beam + gn * (u64)beam;
-  // the scores of the chosen connection, as "%g" digits (once per node, printed on every row)
+  // the scores of the chosen connection (once per node, printed on every row)
   const float* cell = B.node_cells + (gn * (u64)G + beams[bslot].pad) * (u64)NS;
-  const float f0 = cell[0] * T.weights[0];
   const bool two = T.n_weights == 2 && NS > 1;
-  const float f1 = two ? cell[1] * T.weights[1] : 0.f;
-  const GDigits g0 = g_digits(f0), g1 = g_digits(f1), gt = g_digits(two ? f0 + f1 : f0);
-  const u32 id = S.id[gn];
-  const u32 rep = unk && na.maker < 16 ? T.maker_replaces[na.maker] : 0;
-  FmtSurface raw{text, 0}, esc{text, 0};
-  if (unk) {
-    const u32 b0 = boff[ni.start], b1 = boff[ni.end];
-    raw = FmtSurface{text + b0, b1 - b0};
-    esc = raw;
-    if (raw.len == 1)
-      for (int e = 0; e < (int)T.n_escapes; ++e)
-        if (text[b0] == T.escape_from[e]) esc = FmtSurface{T.escape_to[e], T.escape_len[e]};
-  }
-  const u32 fv = !unk ? 0u : T.flag_placeholder == 0 ? na.ph0 : T.flag_placeholder == 1 ? na.ph1 : 0u;
+  r.node = node;
+  r.row = row;
+  r.f0 = cell[0] * T.weights[0];
+  r.f1 = two ? cell[1] * T.weights[1] : 0.f;
+  r.ranks = (u32)both;
   // The distinct previous nodes, ascending.  At beam 32 the paths through a node use a dozen or two of its beam slots
   // (they differ EARLIER in the sentence), but those slots have one to three distinct left nodes: ONE pass over the
   // slots, four loads in flight, into a sorted set of four (a pass per distinct previous node -- the first form -- made a
@@ -203,13 +206,41 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
     }
   }
 #if defined(JPP_LAT_FORCE_MANY_PREV)
-  manyPrev = true;   // (test build: every node through the pass-per-previous-node form below)
+  manyPrev = true;   // (test build: every node through the pass-per-previous-node form of lat_node_lines)
 #endif
-  u32 pid[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if ((u32)q < nPrev && !manyPrev) pid[q] = S.id[nb + pv[q]];
-  for (;; ++row) {
+  for (int q = 0; q < 4; ++q) r.pid[q] = (u32)q < nPrev && !manyPrev ? S.id[nb + pv[q]] : 0u;
+  r.flags = manyPrev ? kLatRecMany : nPrev;
+  r.bytes = 0;
+  r.pad = 0;
+  return true;
+}
+
+// One lattice node of the output: its lines (one per row of its entry), printed by ONE lane from its record.
+template <bool WRITE, typename P>
+__device__ __forceinline__ void lat_node_lines(LatOut<WRITE, P>& w, const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S,
+                                              u64 nb, const LatRec& rec, u32 id, const u8* text, const u16* boff) {
+  const u64 gn = nb + rec.node;
+  const NodeInfo ni = B.node_info[gn];
+  const bool unk = ni.eptr < 0;
+  NodeAux na{0, 0, 0, 0, 0, 0};
+  if (unk) na = B.node_aux[gn];
+  const bool two = T.n_weights == 2 && cfg.nscorers > 1;
+  const GDigits g0 = g_digits(rec.f0), g1 = g_digits(rec.f1), gt = g_digits(two ? rec.f0 + rec.f1 : rec.f0);
+  const u32 rep = unk && na.maker < 16 ? T.maker_replaces[na.maker] : 0;
+  FmtSurface raw{text, 0}, esc{text, 0};
+  if (unk) {
+    const u32 b0 = boff[ni.start], b1 = boff[ni.end];
+    raw = FmtSurface{text + b0, b1 - b0};
+    esc = raw;
+    if (raw.len == 1)
+      for (int e = 0; e < (int)T.n_escapes; ++e)
+        if (text[b0] == T.escape_from[e]) esc = FmtSurface{T.escape_to[e], T.escape_len[e]};
+  }
+  const u32 fv = !unk ? 0u : T.flag_placeholder == 0 ? na.ph0 : T.flag_placeholder == 1 ? na.ph1 : 0u;
+  const bool manyPrev = (rec.flags & kLatRecMany) != 0;
+  const u32 nPrev = rec.flags & 7u;
+  for (u32 row = rec.row;; ++row) {
     const LatRow r = T.rows[row];
     // "-\t" id "\t" prevs "\t" start "\t" end "\t"
     w.ch('-');
@@ -219,10 +250,12 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
     if (!manyPrev) {
       for (u32 q = 0; q < nPrev; ++q) {
         if (q) w.ch(';');
-        w.num(pid[q]);
+        w.num(rec.pid[q]);
       }
     } else {
       // more than four distinct previous nodes: the smallest one above the last printed, again and again
+      const u64 slots = load_l2(&S.mask[gn]) >> 32;
+      const BeamSlot* beams = B.node_beam + gn * (u64)cfg.beam;
       i64 last = -1;
       bool first = true;
       for (;;) {
@@ -297,8 +330,8 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
     w.flt(gt);
     w.ch('|');
     w.lit(T.ranks_text, T.ranks_len);
-    for (u64 mm = mask; mm != 0;) {
-      const u32 j = (u32)__builtin_ctzll(mm);
+    for (u32 mm = rec.ranks; mm != 0;) {
+      const u32 j = (u32)__builtin_ctz(mm);
       mm &= mm - 1;
       w.num(j + 1);
       if (mm != 0) w.ch(';');
@@ -306,7 +339,6 @@ __device__ __forceinline__ bool lat_node_lines(LatOut<WRITE, P>& w, const Batch&
     w.ch('\n');
     if (r.flags & 2) break;
   }
-  return true;
 }
 
 // "# MA-SCORE\t" "rank" i ":" total " " ... "\n": lane i prints rank i + 1 at the offset a wave scan gives it (one
@@ -364,10 +396,10 @@ __device__ __forceinline__ u64 wave_or_u64(u64 v) {
 }
 __device__ __forceinline__ u64 wave_min_u64(u64 v) { return ~wave_max_u64(~v); }
 
-// sentence s -> the bytes of its text, of its header and of the lines of its i-th marked node (node_bytes[node_base + i]);
-// leaves the per-node sets, the ids and the list of marked nodes in the scratch for k_lat_write
+// sentence s -> the bytes of its text and of its header; leaves the per-node sets, the ids and the records of the marked
+// nodes (with the bytes of their lines) in the scratch for k_lat_write
 __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
-                                                   u32* sent_bytes, u32* head_bytes, u32* node_bytes, i32* fmt_status) {
+                                                   u32* sent_bytes, u32* head_bytes, i32* fmt_status) {
   __shared__ LatTable s_T;
   lat_stage_table(&s_T, Tp);
   const LatTable& T = s_T;
@@ -400,7 +432,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
     S.best[nb + k] = ~0ull;
     S.id[nb + k] = 0;
   }
-  __threadfence();
+  wave_fence_global();
   wave_sync();
   // fillInfo: lane i walks path i back from the EOS beam (paths behind the first fake slot do not exist).  The paths
   // run in lock step, and the N best paths of a sentence mostly run through the SAME nodes: the lanes standing on one
@@ -458,23 +490,23 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
       c = cn;
     }
   }
-  __threadfence();
+  wave_fence_global();
   wave_sync();
   // publishResult: ids from 1 in node order, and the marked nodes listed in that order
   u32 next = 1;
   for (u32 base = 0; base < N; base += 64) {
     const u32 nd = base + lane;
-    const bool on = nd >= 2 && nd + 1 < N && S.mask[nb + nd] != 0;   // (0, 1 = BOS and N - 1 = EOS are never on a list)
+    const bool on = nd >= 2 && nd + 1 < N && load_l2(&S.mask[nb + nd]) != 0;   // (0, 1 = BOS and N - 1 = EOS are never on a list)
     const u64 bal = wave_ballot(on);
     if (on) {
       const u32 id = next + (u32)popc64(bal & ((1ull << lane) - 1ull));
       S.id[nb + nd] = id;
-      S.list[nb + id - 1] = nd;
+      S.rec[nb + id - 1].node = nd;
     }
     next += (u32)popc64(bal);
   }
   const u32 M = next - 1;
-  __threadfence();
+  wave_fence_global();
   wave_sync();
   // the bytes of every marked node's lines, a lane per node
   const u32 off = B.byte_off[s];
@@ -485,10 +517,16 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
   for (u32 base = 0; base < M; base += 64) {
     const u32 i = base + lane;
     if (i < M) {
+      LatRec r;
       LatOut<false> w{nullptr, 0};
-      ok = lat_node_lines(w, B, cfg, T, S, nb, S.list[nb + i], text, boff) && ok;
-      node_bytes[nb + i] = (u32)w.n;
-      sum += w.n;
+      if (lat_node_facts(r, B, cfg, T, S, nb, S.rec[nb + i].node)) {
+        lat_node_lines(w, B, cfg, T, S, nb, r, i + 1, text, boff);
+        r.bytes = (u32)w.n;
+        S.rec[nb + i] = r;
+        sum += w.n;
+      } else {
+        ok = false;
+      }
     }
   }
   sum = wave_sum_u64(sum);
@@ -528,7 +566,7 @@ __device__ __forceinline__ void lat_flush(u8* out, u64 o, const u8 JPP_LDS* buf,
 // (three wavefronts per SIMD: left to itself the compiler took 274 vector registers for the inlined line printer -- ONE
 // workgroup per CU, 1.9 ms per 8 192 sentences where one round of wavefronts takes 0.2; the LDS window allows three)
 __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
-                                                   const u64* sent_off, const u32* head_bytes, const u32* node_bytes, u8* out,
+                                                   const u64* sent_off, const u32* head_bytes, u8* out,
                                                    const i32* fmt_status) {
   __shared__ LatTable s_T;
   __shared__ __attribute__((aligned(16))) u8 s_win[4][kLatWin + 16];
@@ -570,8 +608,9 @@ __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, 
   const u32 M = S.marked[s];
   for (u32 base = 0; base < M; base += 64) {
     const u32 i = base + lane;
-    const u32 bytes = i < M ? node_bytes[nb + i] : 0;
-    const u32 node = i < M ? S.list[nb + i] : 0;
+    LatRec rec{};
+    if (i < M) rec = S.rec[nb + i];
+    const u32 bytes = rec.bytes;
     const u32 incl = wave_scan_incl_u32(bytes, (int)lane);
     const u32 start = incl - bytes;
     const u32 total = wave_bcast_u32(incl, 63);
@@ -584,7 +623,7 @@ __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, 
         // a single node beyond the window: straight to the output, byte by byte (never seen; a kilobyte feature list)
         if (lane == f) {
           LatOut<true> w{out + o + start, 0};
-          (void)lat_node_lines(w, B, cfg, T, S, nb, node, text, boff);
+          lat_node_lines(w, B, cfg, T, S, nb, rec, i + 1, text, boff);
         }
         f += 1;
         continue;
@@ -593,7 +632,7 @@ __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, 
       const u32 wend = wave_bcast_u32(incl, (int)(f + cnt - 1));
       if ((fits >> lane) & 1) {
         LatOut<true, LP> w{win + b0 + (start - fstart), 0};
-        (void)lat_node_lines(w, B, cfg, T, S, nb, node, text, boff);
+        lat_node_lines(w, B, cfg, T, S, nb, rec, i + 1, text, boff);
       }
       lat_flush(out, o + fstart, win, b0, wend - fstart, lane);
       f += cnt;
