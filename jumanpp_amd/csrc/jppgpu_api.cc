@@ -2647,8 +2647,15 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
       return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (lattice format)");
     const LatTable* T = ctx->mb->lat_table.as<LatTable>();
     const LatScratch S{ctx->lat_mask.as<u64>(), ctx->lat_best.as<u64>(), ctx->lat_id.as<u32>(), ctx->lat_list.as<LatRec>(), ctx->lat_marked.as<u32>()};
+    // (developer switches for the tests: k_latfmt.h kLatDevWinMask / kLatDevManyPrev)
+    static const u32 latDev = [] {
+      u32 v = 0;
+      if (const char* w = std::getenv("JPPGPU_DEV_LAT_WIN")) v |= (u32)std::strtoul(w, nullptr, 10) & kLatDevWinMask;
+      if (std::getenv("JPPGPU_DEV_LAT_MANY_PREV") != nullptr) v |= kLatDevManyPrev;
+      return v;
+    }();
     ctx->fmt_timer.mark(0, st);
-    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_st.as<i32>());
+    if (n) JPP_LAUNCH(k_lat_count, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, ctx->fmt_cnt.as<u32>(), ctx->lat_head.as<u32>(), ctx->fmt_st.as<i32>(), latDev);
     launch_scan(ctx, st, (const u32*)ctx->fmt_cnt.as<u32>(), ctx->fmt_off.as<u64>(), n, (const u64*)nullptr);
     ctx->fmt_timer.mark(1, st);
     bool ok = pull(res->fm_off, ctx->fmt_off.p, (size_t)n + 1, st);
@@ -2658,7 +2665,7 @@ extern "C" int jppgpu_result_format_lattice(jppgpu_result* res, int32_t n_best, 
     if (!ctx->fmt_text.ensure(total + 64)) return fail(JPPGPU_OUT_OF_MEMORY, "device allocation failed (format text)");
     ctx->fmt_timer.mark(2, st);
     if (n) JPP_LAUNCH(k_lat_write, (n + 3) / 4, 256, st, B, res->cfg, T, S, (int)n_best, (const u64*)ctx->fmt_off.as<u64>(), (const u32*)ctx->lat_head.as<u32>(),
-                      ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>());
+                      ctx->fmt_text.as<u8>(), (const i32*)ctx->fmt_st.as<i32>(), latDev);
     ctx->fmt_timer.mark(3, st);
     ok = pull(res->fm_text, ctx->fmt_text.p, (size_t)total, st);
     ok &= pull(res->fm_status, ctx->fmt_st.p, n, st);

@@ -87,6 +87,12 @@ struct alignas(16) LatRec {
 static_assert(sizeof(LatRec) == 48, "three 16-byte loads");
 constexpr u32 kLatRecMany = 8u;
 
+// Developer switches of the two kernels (their last argument; jppgpu_api.cc reads JPPGPU_DEV_LAT_WIN / JPPGPU_DEV_LAT_MANY_PREV):
+// a smaller LDS window and the many-previous-nodes form for every node, so that the tests walk those paths -- windows
+// split between nodes, a node beyond the window, every alignment of the flush -- with ordinary sentences ON THE DEVICE.
+constexpr u32 kLatDevWinMask = 0xffffu;    // window bytes (0: the whole window)
+constexpr u32 kLatDevManyPrev = 0x10000u;
+
 // per-node scratch of the formatter (HBM, [total_nodes] each)
 struct LatScratch {
   u64* mask;    // low half: paths (ranks) through the node; high half: beam slots of the node those paths use (both at
@@ -148,7 +154,7 @@ struct LatOut {
 // What the lines of one lattice node print besides its entry rows (ONE lane; k_lat_count).  Returns false when the table
 // has no row for it.  T: the table's copy in LDS (its pointers point into HBM).
 __device__ __forceinline__ bool lat_node_facts(LatRec& r, const Batch& B, const Config& cfg, const LatTable& T, const LatScratch& S, u64 nb,
-                                              u32 node) {
+                                              u32 node, bool forceMany) {
   const int beam = cfg.beam, G = cfg.gbeam, NS = cfg.nscorers;
   const u64 gn = nb + node;
   const NodeInfo ni = B.node_info[gn];
@@ -205,9 +211,7 @@ __device__ __forceinline__ bool lat_node_facts(LatRec& r, const Batch& B, const 
       ++nPrev;
     }
   }
-#if defined(JPP_LAT_FORCE_MANY_PREV)
-  manyPrev = true;   // (test build: every node through the pass-per-previous-node form of lat_node_lines)
-#endif
+  if (forceMany) manyPrev = true;   // (kLatDevManyPrev: every node through the pass-per-previous-node form of lat_node_lines)
 #pragma unroll
   for (int q = 0; q < 4; ++q) r.pid[q] = (u32)q < nPrev && !manyPrev ? S.id[nb + pv[q]] : 0u;
   r.flags = manyPrev ? kLatRecMany : nPrev;
@@ -399,7 +403,7 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) { return ~wave_max_u64(~v); }
 // sentence s -> the bytes of its text and of its header; leaves the per-node sets, the ids and the records of the marked
 // nodes (with the bytes of their lines) in the scratch for k_lat_write
 __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
-                                                   u32* sent_bytes, u32* head_bytes, i32* fmt_status) {
+                                                   u32* sent_bytes, u32* head_bytes, i32* fmt_status, u32 dev) {
   __shared__ LatTable s_T;
   lat_stage_table(&s_T, Tp);
   const LatTable& T = s_T;
@@ -519,7 +523,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
     if (i < M) {
       LatRec r;
       LatOut<false> w{nullptr, 0};
-      if (lat_node_facts(r, B, cfg, T, S, nb, S.rec[nb + i].node)) {
+      if (lat_node_facts(r, B, cfg, T, S, nb, S.rec[nb + i].node, (dev & kLatDevManyPrev) != 0)) {
         lat_node_lines(w, B, cfg, T, S, nb, r, i + 1, text, boff);
         r.bytes = (u32)w.n;
         S.rec[nb + i] = r;
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
 // the first lane-per-node form no faster than the serial one), and the window goes out as whole dwords, 256 contiguous
 // bytes per instruction.  The window starts at the output offset's own alignment so that the dwords of both sides match.
 #if !defined(JPP_LAT_WIN)
-#define JPP_LAT_WIN 12288   // (a test build of the emulator makes it tiny: every window path with ordinary sentences)
+#define JPP_LAT_WIN 12288   // (the tests shrink it at run time: kLatDevWinMask)
 #endif
 constexpr u32 kLatWin = JPP_LAT_WIN;
 
@@ -567,7 +571,7 @@ __device__ __forceinline__ void lat_flush(u8* out, u64 o, const u8 JPP_LDS* buf,
 // workgroup per CU, 1.9 ms per 8 192 sentences where one round of wavefronts takes 0.2; the LDS window allows three)
 __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
                                                    const u64* sent_off, const u32* head_bytes, u8* out,
-                                                   const i32* fmt_status) {
+                                                   const i32* fmt_status, u32 dev) {
   __shared__ LatTable s_T;
   __shared__ __attribute__((aligned(16))) u8 s_win[4][kLatWin + 16];
   lat_stage_table(&s_T, Tp);
@@ -588,6 +592,8 @@ __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, 
   }
   typedef u8 JPP_LDS* LP;
   const LP win = (LP)s_win[wv];
+  u32 winB = kLatWin;
+  if ((dev & kLatDevWinMask) != 0 && (dev & kLatDevWinMask) < kLatWin) winB = (dev & kLatDevWinMask) < 16u ? 16u : (dev & kLatDevWinMask);
   const u64 nb = B.node_base[s];
   const u32 off = B.byte_off[s];
   const u8* text = B.text + off;
@@ -596,7 +602,7 @@ __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, 
   {
     const u32 hb = head_bytes[s];
     const u32 b0 = (u32)o & 3u;
-    if (hb <= kLatWin) {
+    if (hb <= winB) {
       (void)lat_header<true>(win + b0, T, B.node_beam + (nb + (N - 1)) * (u64)cfg.beam, cfg.beam, n_best, lane);
       lat_flush(out, o, win, b0, hb, lane);
     } else {
@@ -618,7 +624,7 @@ __global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, 
     while (f < 64 && base + f < M) {
       const u32 fstart = wave_bcast_u32(start, (int)f);
       const u32 b0 = (u32)(o + fstart) & 3u;
-      const u64 fits = wave_ballot(lane >= f && i < M && incl - fstart <= kLatWin - 4u);
+      const u64 fits = wave_ballot(lane >= f && i < M && incl - fstart <= winB - 4u);
       if (((fits >> f) & 1) == 0) {
         // a single node beyond the window: straight to the output, byte by byte (never seen; a kilobyte feature list)
         if (lane == f) {

@@ -164,28 +164,32 @@ def test_device_side_lattice_format(cli_emu, golden_dir, tmp_path):
     _device_lattice_case(cli_emu, golden_dir, tmp_path)
 
 
-@pytest.mark.parametrize('win', ['256'])
-def test_device_side_lattice_format_window_paths(cli_emu, golden_dir, tmp_path, win):
+def _lattice_window_case(cli, golden_dir):
     """k_lat_write prints a round of 64 nodes into an LDS window of 12 KB and flushes it; nodes that do not fit together
-    take several windows, a node beyond the window goes straight to the output.  An emulator build with a window of 256
-    bytes (one or two lines fit, an alias entry's lines do not) walks those paths (and every alignment of the flush) on ordinary sentences: same bytes as the host class"""
-    import shutil
-    import __graft_entry__ as ge
-    # (the same build sends every node's previous-node list through the form for more than four distinct previous nodes)
-    lib = ge.build_emu_variant('latwin' + win, ['-DJPP_LAT_WIN=' + win, '-DJPP_LAT_FORCE_MANY_PREV'])
-    d = tmp_path / 'lib'
-    d.mkdir()
-    shutil.copy(lib, str(d / 'libjppgpu_emu.so'))   # (found before the binary's RUNPATH)
-    env = dict(os.environ, LD_LIBRARY_PATH=str(d), JPPGPU_NO_IMAGE_CACHE='1')
+    take several windows, a node beyond the window goes straight to the output.  With the library's developer switches
+    (JPPGPU_DEV_LAT_WIN: a window of 256 / 64 bytes -- one or two lines fit, an alias entry's lines do not / hardly any
+    line fits; JPPGPU_DEV_LAT_MANY_PREV: every node's previous-node list through the form for more than four distinct
+    previous nodes) ordinary sentences walk those paths and every alignment of the flush: same bytes as the host class"""
     fix = os.path.join(golden_dir, 'ref')
-    for model, txt in ((os.path.join(golden_dir, 'mini_rnn.jppmdl'), os.path.join(golden_dir, 'mini.txt')),
-                       (os.path.join(fix, 'minimal.jppmdl'), os.path.join(fix, 'minimal.txt')),
-                       (os.path.join(fix, 'bug950111.jppmdl'), os.path.join(fix, 'bug950111.txt'))):
-        for flags in (['-s', '5'], ['--beam=12', '--global-beam=12', '--right-beam=12', '-s', '12']):
-            rc, host, eh = _run(cli_emu, ['--model=' + model, '--host-format'] + flags + [txt])
-            p = subprocess.run([cli_emu, '--model=' + model, '--timing'] + flags + [txt], capture_output=True, env=env)
-            assert p.returncode == 0 and b'device_lattice_format=1' in p.stderr, p.stderr[-300:]
-            assert p.stdout == host, (model, flags)
+    for win in ('256', '64'):
+        env = dict(os.environ, JPPGPU_DEV_LAT_WIN=win, JPPGPU_DEV_LAT_MANY_PREV='1', JPPGPU_NO_IMAGE_CACHE='1')
+        for model, txt in ((os.path.join(golden_dir, 'mini_rnn.jppmdl'), os.path.join(golden_dir, 'mini.txt')),
+                           (os.path.join(fix, 'minimal.jppmdl'), os.path.join(fix, 'minimal.txt')),
+                           (os.path.join(fix, 'bug950111.jppmdl'), os.path.join(fix, 'bug950111.txt'))):
+            for flags in (['-s', '5'], ['--beam=12', '--global-beam=12', '--right-beam=12', '-s', '12']):
+                rc, host, eh = _run(cli, ['--model=' + model, '--host-format'] + flags + [txt])
+                p = subprocess.run([cli, '--model=' + model, '--timing'] + flags + [txt], capture_output=True, env=env)
+                assert p.returncode == 0 and b'device_lattice_format=1' in p.stderr, p.stderr[-300:]
+                assert p.stdout == host, (win, model, flags)
+
+
+def test_device_side_lattice_format_window_paths(cli_emu, golden_dir):
+    _lattice_window_case(cli_emu, golden_dir)
+
+
+@pytest.mark.gpu
+def test_gpu_device_side_lattice_format_window_paths(cli_gpu, golden_dir):
+    _lattice_window_case(cli_gpu, golden_dir)
 
 
 @pytest.mark.gpu
