@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
 // the first lane-per-node form no faster than the serial one), and the window goes out as whole dwords, 256 contiguous
 // bytes per instruction.  The window starts at the output offset's own alignment so that the dwords of both sides match.
 #if !defined(JPP_LAT_WIN)
-#define JPP_LAT_WIN 12288   // (the tests shrink it at run time: kLatDevWinMask)
+#define JPP_LAT_WIN 12288   // (a test build of the emulator makes it tiny: every window path with ordinary sentences)
 #endif
 constexpr u32 kLatWin = JPP_LAT_WIN;
 
