@@ -19,12 +19,14 @@
 // 220-codepoint sentence at N = 32) and rebuilt the per-node sets with a few thousand steps per sentence.  Here one
 // wavefront per sentence does it where the lattice lies:
 //   k_lat_count  lane = path: walks its path back from EOS and leaves, per lattice node, the set of paths through it
-//                (64-bit mask = the ranks), the set of beam slots used (= the distinct connections) and the connection
-//                with the smallest total (atomicMin of an ordered key) in four per-node words of HBM; then numbers the
-//                marked nodes (ballot + popcount = publishResult's ids); then lane = node: the bytes of its lines;
-//   k_lat_write  lane = node again: every lane prints the lines of its own node -- ids, previous ids, "%g" digits, ranks,
-//                the entry-row text read from the blob eight bytes at a time -- into the wavefront's LDS window, at the
-//                offset a wave scan of the byte counts gives it; the window leaves as whole dwords.
+//                (= the ranks) and the set of its beam slots they use (= the distinct connections) in ONE word of HBM
+//                (atomicOr), the connection with the smallest total in a second (atomicMin of an ordered key); then
+//                numbers the marked nodes (ballot + popcount = publishResult's ids); then lane = node: a 48-byte record
+//                of what the node's lines print -- first row, the connection's weighted scores, the ids of the previous
+//                nodes, the ranks -- and the bytes of those lines;
+//   k_lat_write  lane = node again: every lane prints the lines of its own node from its record -- ids, "%g" digits,
+//                ranks, the entry-row text read from the blob eight bytes at a time -- into the wavefront's LDS window,
+//                at the offset a wave scan of the byte counts gives it; the window leaves as whole dwords.
 // (The first form printed ONE line at a time with all 64 lanes copying its pieces: 25 us per line -- every line waited
 // for its own chain of dependent loads and for the table's literals, read byte by byte from HBM -- 19 ms of format
 // kernels per 4 096-sentence batch at beam 32, more than the analysis.  profiles/r06_c_*.)
@@ -213,7 +215,7 @@ __device__ __forceinline__ bool lat_node_facts(LatRec& r, const Batch& B, const 
   }
   if (forceMany) manyPrev = true;   // (kLatDevManyPrev: every node through the pass-per-previous-node form of lat_node_lines)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) r.pid[q] = (u32)q < nPrev && !manyPrev ? S.id[nb + pv[q]] : 0u;
+  for (int q = 0; q < 4; ++q) r.pid[q] = (u32)q < nPrev && !manyPrev ? load_l2(&S.id[nb + pv[q]]) : 0u;
   r.flags = manyPrev ? kLatRecMany : nPrev;
   r.bytes = 0;
   r.pad = 0;
@@ -270,7 +272,7 @@ __device__ __forceinline__ void lat_node_lines(LatOut<WRITE, P>& w, const Batch&
         }
         if (m == ~0u) break;
         if (!first) w.ch(';');
-        w.num(S.id[nb + m]);
+        w.num(load_l2(&S.id[nb + m]));
         last = (i64)m;
         first = false;
       }
@@ -393,12 +395,11 @@ __device__ __forceinline__ void lat_stage_table(LatTable* dst, const LatTable* _
   __syncthreads();
 }
 
-__device__ __forceinline__ u64 wave_or_u64(u64 v) {
+__device__ __forceinline__ u32 wave_or_u32(u32 v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v |= wave_shfl_u64(v, lane_id() ^ off);
+  for (int off = 32; off > 0; off >>= 1) v |= wave_shfl_u32(v, lane_id() ^ off);
   return v;
 }
-__device__ __forceinline__ u64 wave_min_u64(u64 v) { return ~wave_max_u64(~v); }
 
 // sentence s -> the bytes of its text and of its header; leaves the per-node sets, the ids and the records of the marked
 // nodes (with the bytes of their lines) in the scratch for k_lat_write
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
   // fillInfo: lane i walks path i back from the EOS beam (paths behind the first fake slot do not exist).  The paths
   // run in lock step, and the N best paths of a sentence mostly run through the SAME nodes: the lanes standing on one
   // node are found with a ballot (which IS that node's share of the rank mask), their slot sets and smallest keys are
-  // reduced across the wavefront, and one lane sends the three atomics -- a dozen instead of a hundred per step.
+  // reduced across the wavefront, and one lane sends the two atomics -- half a dozen instead of a hundred per step.
   const BeamSlot* beams = B.node_beam + nb * (u64)beam;
   int maxN = n_best < beam ? n_best : beam;
   if (maxN > 32) maxN = 32;   // (the device keeps at most 32 slots per node: jppgpu_api.cc device_beam; the packed masks rely on it)
@@ -467,21 +468,24 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
       const u32 nnode = c.prev_node, nslot = c.beam;
       const bool nact = act && live(nnode, nslot);
       const BeamSlot cn = nact ? beams[(u64)nnode * beam + nslot] : fake;
-      u64 key = ~0ull;
+      u32 ord = ~0u;   // the connection's total as an ordered word; its key is (ord << 32 | path << 8 | slot)
       if (act) {
         const float* cell = B.node_cells + ((nb + node) * (u64)G + c.pad) * (u64)NS;
         // `total += s[i] * weights[i]` is one fused multiply-add per scorer in the reference's build (host/lattice_format.cc)
         float t = __builtin_fmaf(cell[0], w0, 0.f);
         if (two) t = __builtin_fmaf(cell[1], w1, t);
-        key = ((u64)lat_order_f32(t) << 32) | (lane << 8) | slot;
+        ord = lat_order_f32(t);
       }
       while (todo) {
         const int leader = __builtin_ctzll(todo);
         const u32 ln = wave_bcast_u32(node, leader);
         const bool mine = act && node == ln;
         const u64 grp = wave_ballot(mine);
-        const u64 used = wave_or_u64(mine ? (1ull << slot) : 0ull);
-        const u64 kmin = wave_min_u64(mine ? key : ~0ull);
+        // (32-bit reductions: a slot is below 32, and among equal totals the smallest key is the lowest lane's)
+        const u64 used = wave_or_u32(mine ? (1u << slot) : 0u);
+        const u32 omin = ~wave_max_u32(mine ? ~ord : 0u);
+        const int first = __builtin_ctzll(wave_ballot(mine && ord == omin));
+        const u64 kmin = ((u64)omin << 32) | ((u32)first << 8) | wave_bcast_u32(slot, first);
         if ((int)lane == leader) {
           atomicOr((unsigned long long*)&S.mask[nb + ln], (unsigned long long)(grp | (used << 32)));
           atomicMin((unsigned long long*)&S.best[nb + ln], (unsigned long long)kmin);
@@ -523,7 +527,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
     if (i < M) {
       LatRec r;
       LatOut<false> w{nullptr, 0};
-      if (lat_node_facts(r, B, cfg, T, S, nb, S.rec[nb + i].node, (dev & kLatDevManyPrev) != 0)) {
+      if (lat_node_facts(r, B, cfg, T, S, nb, load_l2(&S.rec[nb + i].node), (dev & kLatDevManyPrev) != 0)) {
         lat_node_lines(w, B, cfg, T, S, nb, r, i + 1, text, boff);
         r.bytes = (u32)w.n;
         S.rec[nb + i] = r;
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(256) k_lat_count(Batch B, Config cfg, const La
 // the first lane-per-node form no faster than the serial one), and the window goes out as whole dwords, 256 contiguous
 // bytes per instruction.  The window starts at the output offset's own alignment so that the dwords of both sides match.
 #if !defined(JPP_LAT_WIN)
-#define JPP_LAT_WIN 12288   // (a test build of the emulator makes it tiny: every window path with ordinary sentences)
+#define JPP_LAT_WIN 12288   // (the tests shrink it at run time: kLatDevWinMask)
 #endif
 constexpr u32 kLatWin = JPP_LAT_WIN;
 
