@@ -1463,6 +1463,44 @@ def main():
                 del ctxs, ctxB, offsB, itemsB, th   # (the list kept both contexts alive into the CLI leg)
             except Exception as e:  # the extra measurement must never take the main line down
                 overlapped = {'error': str(e)[:200]}
+        # The same batches through the host entry point of the C ABI: text and offsets in host memory in
+        # (jppgpu_analyze_batch uploads them), the packed top-1 result in page-locked host memory out.  The PCIe-inclusive
+        # rate of the boundary; reported beside `value`, never as it (the contract: inputs resident in HBM).
+        host_buffers = None
+        if world == 1 and not emu:
+            try:
+                import ctypes as C
+                h_offs = torch.empty(args.batch + 1, dtype=torch.int32).pin_memory()
+                h_items = torch.empty((cap_items, 2), dtype=torch.int32).pin_memory()
+                k4 = min(args.steps, 8)
+
+                def host_step(i):
+                    text, offs = batches[i % len(batches)]
+                    h = C.c_void_p()
+                    if ctx.lib.jppgpu_analyze_batch(ctx.handle, text, offs.ctypes.data, len(offs) - 1, C.byref(h)) != 0:
+                        raise RuntimeError(ctx.lib.jppgpu_last_error().decode())
+                    res = J.Result(ctx, h)
+                    res.pack(d_offs.data_ptr(), d_items.data_ptr(), cap_items)
+                    _sync()                                  # (the pack kernels run on the library's stream)
+                    h_offs.copy_(d_offs)
+                    m = int(h_offs[-1])
+                    h_items[:m].copy_(d_items[:m])
+                    res.release()
+                    return m
+                host_step(0)
+                _sync()
+                t4 = time.perf_counter()
+                got = sum(host_step(1 + j) for j in range(k4))
+                _sync()
+                e4 = time.perf_counter() - t4
+                host_buffers = {'what': 'host buffers in (jppgpu_analyze_batch: text + offsets uploaded by the library), packed top-1 result '
+                                        'copied to page-locked host memory; PCIe inclusive, one batch at a time',
+                                'value': round(args.batch * k4 / e4, 1), 'unit': 'sentences/s', 'steps': k4,
+                                'ms_per_step': round(e4 / k4 * 1e3, 3), 'morphemes_per_step': got // k4,
+                                'bytes_over_pcie_per_step': int(sum(len(b[0]) + 4 * len(b[1]) for b in batches) // len(batches) + 8 * (got // k4))}
+                del h_offs, h_items
+            except Exception as e:  # the extra measurement must never take the main line down
+                host_buffers = {'error': str(e)[:200]}
         out = {
             'metric': 'sentences/sec whole-node, beam=5 jumandic %s; achieved HBM GB/s' % ('+RNNLM' if args.rnn else 'perceptron (RNN off)'),
             'value': round(value, 1),
@@ -1520,6 +1558,8 @@ def main():
             out['perceptron_only'] = perceptron_only
         if overlapped is not None:
             out['overlapped_two_streams'] = overlapped
+        if host_buffers is not None:
+            out['host_buffers'] = host_buffers
         # (this process' contexts go before the legs that run child processes or make contexts of their own)
         del ctx
         ctx2 = None
