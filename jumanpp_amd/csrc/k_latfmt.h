@@ -177,8 +177,7 @@ __device__ __forceinline__ bool lat_node_facts(LatRec& r, const Batch& B, const 
   // The distinct previous nodes, ascending.  At beam 32 the paths through a node use a dozen or two of its beam slots
   // (they differ EARLIER in the sentence), but those slots have one to three distinct left nodes: ONE pass over the
   // slots, four loads in flight, into a sorted set of four (a pass per distinct previous node -- the first form -- made a
-  // few hundred dependent loads per node and the sentences with such nodes the tail of both kernels:
-  // profiles/r06_ah_lattice_counters.txt, 840 of 20 480 wavefront slots busy on average)
+  // few hundred dependent loads per node and the sentences with such nodes the tail of both kernels)
   u32 pv[4] = {~0u, ~0u, ~0u, ~0u};
   u32 nPrev = 0;
   bool manyPrev = false;
@@ -571,9 +570,11 @@ __device__ __forceinline__ void lat_flush(u8* out, u64 o, const u8 JPP_LDS* buf,
   wave_sync();
 }
 
-// (three wavefronts per SIMD: left to itself the compiler took 274 vector registers for the inlined line printer -- ONE
-// workgroup per CU, 1.9 ms per 8 192 sentences where one round of wavefronts takes 0.2; the LDS window allows three)
-__global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(3) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
+// (two wavefronts per SIMD: left to itself the compiler took 274 vector registers for the inlined line printer -- ONE
+// workgroup per CU, 1.9 ms per 8 192 sentences where one round of wavefronts takes 0.2.  Held to 256 registers it
+// spills 96 bytes and two workgroups share a CU; at three per SIMD (168 registers, 432 bytes of scratch) the same launch
+// takes 6 % longer: profiles/r06_ar_*, r06_bc_*)
+__global__ void __launch_bounds__(256) JPP_WAVES_PER_EU(2) k_lat_write(Batch B, Config cfg, const LatTable* __restrict__ Tp, LatScratch S, int n_best,
                                                    const u64* sent_off, const u32* head_bytes, u8* out,
                                                    const i32* fmt_status, u32 dev) {
   __shared__ LatTable s_T;

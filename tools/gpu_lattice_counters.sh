@@ -44,6 +44,10 @@ for kn, c in per.items():
         print('   -> VALU issue %.2f of the slots; %.0f VALU wave-instructions per wavefront' % (v * 4 / (us * 1e-6 * 2.4e9 * 1024), v / max(1.0, w or 1)))
     if c.get('SQ_WAVE_CYCLES') and c.get('SQ_WAIT_ANY'):
         print('   -> wavefronts waiting %.0f %% of their cycles' % (100.0 * c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']))
+        # (SQ_WAVE_CYCLES counts quad-cycles: MI355X_MICROARCH.md, PMC units)
+        if us:
+            print('   -> %.1f wavefronts per SIMD resident on average, each alive %.0f us' % (
+                4.0 * c['SQ_WAVE_CYCLES'] / (us * 1e-6 * 2.4e9 * 1024), 4.0 * c['SQ_WAVE_CYCLES'] / max(1.0, w or 1) / 2.4e3))
 PY
 cat "$OUT/${TAG}_lattice_counters.txt"
 for j in 1 2; do rm -rf "$OUT/pmcl_$j"; done
