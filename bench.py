@@ -1201,8 +1201,11 @@ def main():
         if not emu:
             torch.cuda.synchronize()
     dist = None
-    if world > 1:
+    # (JPPGPU_BENCH_DIST1=1, tests/test_dist_gpu.py: the N > 1 control flow -- barriers, the gather inside the timed loop,
+    # the max over ranks -- through the RCCL backend with ONE rank, which is all a one-GPU box can run of it)
+    if world > 1 or os.environ.get('JPPGPU_BENCH_DIST1') == '1':
         import torch.distributed as dist
+        os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')   # (RCCL's version banner: not on stdout, see the end of main)
         dist.init_process_group('gloo' if emu else 'nccl')
     cache = args.cache
     # one model for all ranks: rank 0 builds it (bootstrap + embedding + export on the host cores), the others wait
@@ -1526,6 +1529,8 @@ def main():
                 'failed_sentences_in_batch': bad,
                 'morphemes_per_sentence': round(total_path / max(1, sentences), 2),
                 'parallelism': 'sentence-sharded x%d, no data-path collective' % world,
+                'result_gather': ('packed top-1 results gathered to rank 0 inside the timed region (%s backend)' % dist.get_backend())
+                                 if dist is not None else 'none (one rank)',
             },
             'kernel_ms_per_step': {k: round(v, 3) for k, v in avg.items()},
             'batches': dict(pipe_stats, what='one_enqueue_batches: enqueued against the held capacity, ONE host wait (at the end); '
@@ -1581,10 +1586,19 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, model, mdic, cache)
         if cli_result is not None:
             out['cli_end_to_end'] = cli_result   # (measured before the first device allocation of this process, see above)
-        print(json.dumps(out, ensure_ascii=False), flush=True)
+    # The JSON line is the LAST thing on stdout.  RCCL prints a version banner to the C library's stdout (found on the
+    # MI355X with one rank, tests/test_dist_gpu.py): behind a pipe that buffer is flushed when the process ends, i.e.
+    # after a line printed here -- so the process group goes first, the C streams are flushed, then the line.
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    if rank == 0:
+        print(json.dumps(out, ensure_ascii=False), flush=True)
 
 
 if __name__ == '__main__':

@@ -108,3 +108,4 @@ def test_bench_world_2_control_flow_on_the_emulator(emu_lib, ref_tools, tmp_path
     assert d['cpu_baseline']['kind'] == 'reference' and d['cpu_baseline']['value'] > 0
     assert d['parity_sample']['mismatches'] == 0 and d['parity_sample']['sentences'] == 48, d['parity_sample']
     assert d['batches']['one_enqueue_batches'] >= 2 and d['batches']['one_enqueue_overflows'] == 0, d['batches']
+
