@@ -52,7 +52,8 @@ def gather_packed_fixed(offsets, items, dst=0):
     """The same gather without a host sync: every rank contributes its WHOLE packed buffer -- offsets int32 [n+1] and
     the items array at its fixed capacity int32 [cap, 2], both the same shape on every rank (the bench's case: equal
     batch sizes) -- so no size has to cross to the host first.  What is sent beyond the used prefix is padding
-    (~1.6x the payload at 24 morphemes per 40-codepoint sentence: 21 MB per rank and step, nothing for xGMI).
+    (the caller chooses the prefix of the items array that every rank sends: bench.py takes the largest morpheme count
+    any of its batches packs, found before the timed region -- 13 MB per rank and step for 65 536 sentences).
     Returns on `dst` a list of (offsets, items) per rank; items[:offsets[-1]] is the valid part."""
     world = dist.get_world_size()
     rank = dist.get_rank()
